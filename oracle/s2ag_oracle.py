@@ -1,0 +1,778 @@
+"""CPU oracle for the S2AG generator/discriminator GAN step.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain PyTorch-CPU (fp32) *restatement* of the algorithm of
+the reference hot path.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import it; the product package (``speech2affective_gestures_amd``) never
+does and has no CPU fallback.
+
+Parity status: PINNED.  Every function below is checked against golden vectors produced by
+importing the reference itself in the build container (``tests/golden/gen_golden.py`` is the
+generating script; ``tests/test_oracle_golden.py`` is the check).
+
+Style: purely functional.  A model is a flat ``dict[str, Tensor]`` that uses the *reference's*
+``state_dict`` key names, so a reference checkpoint can be fed directly.
+All randomness (dropout masks, re-parametrisation noise, the speaker permutation) is explicit:
+callers pass a ``Noise`` object; ``Noise(None)`` draws from torch's CPU generator.
+
+Reference citations are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+# ----------------------------------------------------------------------------------------------
+# skeleton constants  (utils/ted_db_utils.py:14-19)
+# ----------------------------------------------------------------------------------------------
+DIR_EDGE_PAIRS = [(0, 1), (1, 2), (0, 3), (3, 4), (4, 5), (0, 6), (6, 7), (7, 8)]
+BODY_PARTS_EDGE_IDX = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+BODY_PARTS_EDGE_PAIRS = [(0, 1), (0, 2)]
+N_DIR_VECS = 9
+N_BODY_PARTS = 3
+
+
+# ----------------------------------------------------------------------------------------------
+# graph adjacency  (net/utils/graph.py:4-142; strategy 'spatial', centre node 0)
+# ----------------------------------------------------------------------------------------------
+def hop_distance(num_nodes: int, links: Sequence[Tuple[int, int]], max_hop: int) -> np.ndarray:
+    """graph.py:108-120 -- smallest d<=max_hop with (A^d)[i,j] > 0, else inf (self links included)."""
+    adj = np.zeros((num_nodes, num_nodes))
+    for i in range(num_nodes):
+        adj[i, i] = 1
+    for a, b in links:
+        adj[a, b] = 1
+        adj[b, a] = 1
+    dis = np.full((num_nodes, num_nodes), np.inf)
+    power = np.eye(num_nodes)
+    reach = []
+    for d in range(max_hop + 1):
+        reach.append(power > 0)
+        power = power @ adj
+    for d in range(max_hop, -1, -1):
+        dis[reach[d]] = d
+    return dis
+
+
+def spatial_adjacency(num_nodes: int, links: Sequence[Tuple[int, int]], max_hop: int = 2) -> np.ndarray:
+    """graph.py:62-105 -- K x V x V stack, K = 1 + 2*max_hop, column-normalised (A . D^-1)."""
+    dis = hop_distance(num_nodes, links, max_hop)
+    reach = np.zeros((num_nodes, num_nodes))
+    reach[dis <= max_hop] = 1
+    col = reach.sum(0)
+    norm = reach / np.where(col > 0, col, 1)[None, :]          # graph.py:123-131
+    centre = dis[:, 0]
+    out = []
+    for hop in range(max_hop + 1):
+        root = np.zeros_like(reach)
+        close = np.zeros_like(reach)
+        further = np.zeros_like(reach)
+        for i in range(num_nodes):
+            for j in range(num_nodes):
+                if dis[j, i] != hop:
+                    continue
+                if centre[j] == centre[i]:
+                    root[j, i] = norm[j, i]
+                elif centre[j] > centre[i]:
+                    close[j, i] = norm[j, i]
+                else:
+                    further[j, i] = norm[j, i]
+        if hop == 0:
+            out.append(root)
+        else:
+            out.append(root + close)
+            out.append(further)
+    return np.stack(out)
+
+
+_A_CACHE: Dict[str, Tensor] = {}
+
+
+def aff_adjacencies() -> Tuple[Tensor, Tensor]:
+    """A1 (5,9,9) and A2 (5,3,3) of AffEncoder (net/multimodal_context_net_v2.py:99-115)."""
+    if 'A1' not in _A_CACHE:
+        _A_CACHE['A1'] = torch.tensor(spatial_adjacency(N_DIR_VECS, DIR_EDGE_PAIRS, 2), dtype=torch.float32)
+        _A_CACHE['A2'] = torch.tensor(spatial_adjacency(N_BODY_PARTS, BODY_PARTS_EDGE_PAIRS, 2),
+                                      dtype=torch.float32)
+    return _A_CACHE['A1'], _A_CACHE['A2']
+
+
+# ----------------------------------------------------------------------------------------------
+# explicit randomness
+# ----------------------------------------------------------------------------------------------
+class Noise:
+    """Source of every random tensor of one forward pass.
+
+    ``Noise(None)``            -> draw from torch's global CPU generator (baseline timing).
+    ``Noise({'name': t, ...})``-> return pinned tensors by call-site name (parity tests); a missing
+                                  name raises, so a test can never silently use fresh randomness.
+    ``Noise('off')``           -> dropout is the identity (keep mask of ones, scale 1) and eps = 0.
+    Call-site names: '<prefix>emb_drop', '<prefix>tcn.<i>.drop1|drop2', '<prefix>gru.drop<l>', 'eps'.
+    Dropout tensors are *keep masks already multiplied by 1/(1-p)*.
+    """
+
+    def __init__(self, pinned=None):
+        self.pinned = pinned
+        self.drawn: Dict[str, Tensor] = {}
+
+    def dropout(self, name: str, x: Tensor, p: float) -> Tensor:
+        if p <= 0.0:
+            return x
+        if self.pinned == 'off':
+            return x
+        if self.pinned is None:
+            m = torch.bernoulli(torch.full_like(x, 1.0 - p)) / (1.0 - p)
+        else:
+            m = self.pinned[name]
+        self.drawn[name] = m
+        return x * m
+
+    def normal(self, name: str, like: Tensor) -> Tensor:
+        if self.pinned == 'off':
+            return torch.zeros_like(like)
+        if self.pinned is None:
+            e = torch.randn_like(like)
+        else:
+            e = self.pinned[name]
+        self.drawn[name] = e
+        return e
+
+
+# ----------------------------------------------------------------------------------------------
+# building blocks
+# ----------------------------------------------------------------------------------------------
+def _bn(sd: SD, p: str, x: Tensor, training: bool) -> Tensor:
+    """nn.BatchNorm{1,2}d semantics (eps 1e-5, momentum 0.1, biased var for normalising,
+    unbiased for the running estimate); updates running stats in ``sd`` in place when training."""
+    if training and (p + 'num_batches_tracked') in sd:
+        sd[p + 'num_batches_tracked'] += 1
+    return F.batch_norm(x, sd[p + 'running_mean'], sd[p + 'running_var'], sd[p + 'weight'], sd[p + 'bias'],
+                        training, 0.1, 1e-5)
+
+
+def wav_encoder(sd: SD, p: str, wav: Tensor, training: bool) -> Tensor:
+    """WavEncoder (net/multimodal_context_net_v2.py:14-33): (B, n_samples) -> (B, frames, 32)."""
+    fe = p + 'feat_extractor.'
+    x = wav.unsqueeze(1)
+    x = F.conv1d(x, sd[fe + '0.weight'], sd[fe + '0.bias'], stride=5, padding=1600)
+    x = F.leaky_relu(_bn(sd, fe + '1.', x, training), 0.3)
+    x = F.conv1d(x, sd[fe + '3.weight'], sd[fe + '3.bias'], stride=6)
+    x = F.leaky_relu(_bn(sd, fe + '4.', x, training), 0.3)
+    x = F.conv1d(x, sd[fe + '6.weight'], sd[fe + '6.bias'], stride=6)
+    x = F.leaky_relu(_bn(sd, fe + '7.', x, training), 0.3)
+    x = F.conv1d(x, sd[fe + '9.weight'], sd[fe + '9.bias'], stride=6)
+    return x.transpose(1, 2)
+
+
+def mfcc_encoder(sd: SD, p: str, mfcc: Tensor, training: bool) -> Tensor:
+    """MFCCEncoder (:36-58): (B, num_mfcc, mfcc_length) -> (B, time_steps, 32).
+    MFCC *frames* are the conv channels; the coefficient index is the conv axis."""
+    x = mfcc.permute(0, 2, 1)
+    for i, pad in ((1, 2), (2, 2), (3, 1), (4, 1)):
+        x = F.conv1d(x, sd[f'{p}conv{i}.weight'], sd[f'{p}conv{i}.bias'], padding=pad)
+        x = F.leaky_relu(_bn(sd, f'{p}batch_norm{i}.', x, training), 0.3)
+    return F.leaky_relu(F.linear(x, sd[p + 'linear1.weight'], sd[p + 'linear1.bias']), 0.3)
+
+
+def weight_norm_weight(g: Tensor, v: Tensor) -> Tensor:
+    """torch.nn.utils.weight_norm (dim=0): w = g * v / ||v|| with the norm over all dims but 0."""
+    return g * v / v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
+
+
+def temporal_block(sd: SD, p: str, x: Tensor, dilation: int, training: bool, drop_p: float,
+                   noise: Noise, name: str) -> Tensor:
+    """TemporalBlock (net/tcn.py:16-46), kernel 2: causal dilated conv -> chomp -> ReLU -> dropout, twice,
+    then ReLU(out + x).  (No downsample: n_inputs == n_outputs on this path, tcn.py:33.)"""
+    out = x
+    for j, tag in ((1, 'conv1'), (2, 'conv2')):
+        w = weight_norm_weight(sd[f'{p}{tag}.weight_g'], sd[f'{p}{tag}.weight_v'])
+        k = w.shape[2]
+        pad = (k - 1) * dilation
+        out = F.conv1d(out, w, sd[f'{p}{tag}.bias'], padding=pad, dilation=dilation)
+        out = F.relu(out[:, :, :-pad])
+        if training:
+            out = noise.dropout(f'{name}.drop{j}', out, drop_p)
+    if (p + 'downsample.weight') in sd:
+        x = F.conv1d(x, sd[p + 'downsample.weight'], sd[p + 'downsample.bias'])
+    return F.relu(out + x)
+
+
+def text_encoder_tcn(sd: SD, p: str, ids: Tensor, training: bool, drop_p: float, noise: Noise,
+                     emb_drop_p: float = 0.1) -> Tensor:
+    """TextEncoderTCN (net/multimodal_context_net_v2.py:61-91): (B,T) int64 -> (B,T,32)."""
+    emb = F.embedding(ids, sd[p + 'embedding.weight'])
+    if training:
+        emb = noise.dropout(p + 'emb_drop', emb, emb_drop_p)
+    y = emb.transpose(1, 2)
+    i = 0
+    while f'{p}tcn.network.{i}.conv1.weight_g' in sd:
+        y = temporal_block(sd, f'{p}tcn.network.{i}.', y, 2 ** i, training, drop_p, noise, f'{p}tcn.{i}')
+        i += 1
+    y = F.linear(y.transpose(1, 2), sd[p + 'decoder.weight'], sd[p + 'decoder.bias'])
+    return y.contiguous()
+
+
+def st_graph_conv(sd: SD, p: str, x: Tensor, A: Tensor, training: bool) -> Tensor:
+    """STGraphConv (net/utils/tgcn.py:133-218) with ConvTemporalGraphical (:15-71).
+    x (N,C,T,V).  The residual branch is always conv1x1 + BN (tgcn.py:195 compares a tuple to 1)."""
+    res = F.conv2d(x, sd[p + 'residual.0.weight'], sd[p + 'residual.0.bias'])
+    res = _bn(sd, p + 'residual.1.', res, training)
+    wg = sd[p + 'gcn.conv.weight']
+    kt = wg.shape[2]
+    g = F.conv2d(x, wg, sd[p + 'gcn.conv.bias'], padding=(kt // 2, 0))
+    n, kc, t, v = g.shape
+    K = A.shape[0]
+    g = torch.einsum('nkctv,kvw->nctw', g.view(n, K, kc // K, t, v), A)
+    h = F.relu(_bn(sd, p + 'tcn.0.', g, training))
+    wt = sd[p + 'tcn.2.weight']
+    h = F.conv2d(h, wt, sd[p + 'tcn.2.bias'], padding=(wt.shape[2] // 2, wt.shape[3] // 2))
+    h = _bn(sd, p + 'tcn.3.', h, training)
+    return F.leaky_relu(h + res, 0.01)
+
+
+def aff_encoder(sd: SD, p: str, poses: Tensor, training: bool) -> Tensor:
+    """AffEncoder (net/multimodal_context_net_v2.py:94-175): (B,T,27) -> (B,T,8)."""
+    A1, A2 = aff_adjacencies()
+    n, t, _ = poses.shape
+    x = poses.reshape(n, t, N_DIR_VECS, 3).permute(0, 3, 1, 2)                      # (n,3,t,9)
+    f1 = st_graph_conv(sd, p + 'st_gcn1.', x, A1, training)                         # (n,16,t,9)
+    c1 = f1.shape[1]
+    f1 = _bn(sd, p + 'batch_norm1.', f1.permute(0, 1, 3, 2).reshape(n, c1 * N_DIR_VECS, t), training)
+    f1 = f1.view(n, c1, N_DIR_VECS, t)                                              # (n,c,v,t)
+    # regroup the 9 edges into 3 body parts; channel index c*3 + j (:161-167)
+    parts = [f1[:, :, idx, :].reshape(n, c1 * len(idx), t) for idx in BODY_PARTS_EDGE_IDX]
+    x2 = torch.stack(parts, dim=3)                                                  # (n,48,t,3)
+    f2 = st_graph_conv(sd, p + 'st_gcn2.', x2, A2, training)                        # (n,16,t,3)
+    c2 = f2.shape[1]
+    f2 = _bn(sd, p + 'batch_norm2.', f2.permute(0, 1, 3, 2).reshape(n, c2 * N_BODY_PARTS, t), training)
+    x3 = F.conv1d(f2, sd[p + 'conv3.weight'], sd[p + 'conv3.bias'], padding=sd[p + 'conv3.weight'].shape[2] // 2)
+    x3 = F.leaky_relu(_bn(sd, p + 'batch_norm3.', x3, training), 0.01)
+    x4 = F.conv1d(x3, sd[p + 'conv4.weight'], sd[p + 'conv4.bias'], padding=sd[p + 'conv4.weight'].shape[2] // 2)
+    x4 = F.leaky_relu(_bn(sd, p + 'batch_norm4.', x4, training), 0.01)
+    return x4.permute(0, 2, 1)
+
+
+def gru_cell_step(x_proj: Tensor, h: Tensor, w_hh: Tensor, b_hh: Tensor) -> Tensor:
+    """One GRU cell step, PyTorch gate order (r, z, n):
+    n = tanh(W_in x + b_in + r * (W_hn h + b_hn)); h' = (1 - z) * n + z * h."""
+    H = h.shape[1]
+    gh = F.linear(h, w_hh, b_hh)
+    r = torch.sigmoid(x_proj[:, :H] + gh[:, :H])
+    z = torch.sigmoid(x_proj[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(x_proj[:, 2 * H:] + r * gh[:, 2 * H:])
+    return (1 - z) * n + z * h
+
+
+def gru(sd: SD, p: str, x: Tensor, training: bool, drop_p: float, noise: Noise, name: str) -> Tensor:
+    """nn.GRU(batch_first, bidirectional) restated cell by cell: (B,T,I) -> (B,T,2H).
+    Inter-layer dropout on the concatenated output of every layer but the last (train mode)."""
+    B, T, _ = x.shape
+    layer = 0
+    while f'{p}weight_ih_l{layer}' in sd:
+        outs = []
+        for suffix, order in (('', range(T)), ('_reverse', range(T - 1, -1, -1))):
+            w_ih, w_hh = sd[f'{p}weight_ih_l{layer}{suffix}'], sd[f'{p}weight_hh_l{layer}{suffix}']
+            b_ih, b_hh = sd[f'{p}bias_ih_l{layer}{suffix}'], sd[f'{p}bias_hh_l{layer}{suffix}']
+            H = w_hh.shape[1]
+            proj = F.linear(x, w_ih, b_ih)
+            h = x.new_zeros(B, H)
+            ys: List[Optional[Tensor]] = [None] * T
+            for t in order:
+                h = gru_cell_step(proj[:, t], h, w_hh, b_hh)
+                ys[t] = h
+            outs.append(torch.stack(ys, dim=1))
+        x = torch.cat(outs, dim=2)
+        layer += 1
+        if training and f'{p}weight_ih_l{layer}' in sd:
+            x = noise.dropout(f'{name}.drop{layer - 1}', x, drop_p)
+    return x
+
+
+def gru_fast(sd: SD, p: str, x: Tensor, training: bool, drop_p: float) -> Tensor:
+    """Same op through ATen's fused ``gru`` (what the reference dispatches, nn.GRU); used for the
+    CPU-baseline timing only (dropout drawn by ATen).  Equality with ``gru`` is tested."""
+    flat, layer = [], 0
+    while f'{p}weight_ih_l{layer}' in sd:
+        for suffix in ('', '_reverse'):
+            flat += [sd[f'{p}weight_ih_l{layer}{suffix}'], sd[f'{p}weight_hh_l{layer}{suffix}'],
+                     sd[f'{p}bias_ih_l{layer}{suffix}'], sd[f'{p}bias_hh_l{layer}{suffix}']]
+        layer += 1
+    H = flat[1].shape[1]
+    h0 = x.new_zeros(2 * layer, x.shape[0], H)
+    y, _ = torch._VF.gru(x, h0, flat, True, layer, drop_p if training else 0.0, training, True, True)
+    return y
+
+
+def re_parametrize(mu: Tensor, log_var: Tensor, noise: Noise) -> Tensor:
+    """net/embedding_net.py:10-13 -- noise is drawn in eval mode too."""
+    std = torch.exp(0.5 * log_var)
+    return mu + noise.normal('eps', std) * std
+
+
+@dataclass
+class ModelCfg:
+    """The fields of the reference's args namespace the nets read (parse_args.py:39-63)."""
+    n_poses: int = 34
+    n_pre_poses: int = 4
+    hidden_size: int = 300
+    hidden_size_s2eg: int = 300
+    n_layers: int = 4
+    dropout_prob: float = 0.3
+    input_context: str = 'both'
+    freeze_wordembed: bool = False
+
+
+def _speaker_z(sd: SD, vid: Tensor, noise: Noise):
+    z = F.embedding(vid, sd['speaker_embedding.0.weight'])
+    z = F.linear(z, sd['speaker_embedding.1.weight'], sd['speaker_embedding.1.bias'])
+    mu = F.linear(z, sd['speaker_mu.weight'], sd['speaker_mu.bias'])
+    log_var = F.linear(z, sd['speaker_log_var.weight'], sd['speaker_log_var.bias'])
+    return re_parametrize(mu, log_var, noise), mu, log_var
+
+
+def _decode(sd: SD, cfg_drop: float, in_data: Tensor, training: bool, noise: Noise, out_slope: float,
+            fast: bool):
+    if fast and noise.pinned is None:
+        y = gru_fast(sd, 'gru.', in_data, training, cfg_drop)
+    else:
+        y = gru(sd, 'gru.', in_data, training, cfg_drop, noise, 'gru')
+    H = y.shape[2] // 2
+    y = y[:, :, :H] + y[:, :, H:]
+    y = F.linear(y, sd['out.0.weight'], sd['out.0.bias'])
+    y = F.leaky_relu(y, out_slope)
+    return F.linear(y, sd['out.2.weight'], sd['out.2.bias'])
+
+
+def pose_generator(sd: SD, cfg: ModelCfg, pre_seq: Tensor, in_text: Tensor, in_mfcc: Tensor, vid: Tensor,
+                   training: bool, noise: Noise, fast: bool = False):
+    """PoseGenerator.forward (net/multimodal_context_net_v2.py:492-546), input_context 'both', speaker z."""
+    audio = mfcc_encoder(sd, 'audio_encoder.', in_mfcc, training)
+    text = text_encoder_tcn(sd, 'text_encoder.', in_text, training, cfg.dropout_prob, noise)
+    assert audio.shape[1] == text.shape[1], 'Audio and text features must have the same number of time steps.'
+    z, mu, log_var = _speaker_z(sd, vid, noise)
+    pre = aff_encoder(sd, 'aff_encoder.', pre_seq[..., :-1], training)
+    in_data = torch.cat((pre, audio, text, z.unsqueeze(1).expand(-1, pre.shape[1], -1)), dim=2)
+    out = _decode(sd, cfg.dropout_prob, in_data, training, noise, 0.01, fast)
+    return out, z, mu, log_var
+
+
+def pose_generator_abl_audio(sd: SD, cfg: ModelCfg, pre_seq, in_text, in_audio, vid, training: bool, noise: Noise,
+                             fast: bool = False):
+    """_abl_audio.PoseGenerator (net/multimodal_context_net_v2_abl_audio.py:413-521): WavEncoder audio branch."""
+    audio = wav_encoder(sd, 'audio_encoder.', in_audio, training)
+    text = text_encoder_tcn(sd, 'text_encoder.', in_text, training, cfg.dropout_prob, noise)
+    assert audio.shape[1] == text.shape[1]
+    z, mu, log_var = _speaker_z(sd, vid, noise)
+    pre = aff_encoder(sd, 'aff_encoder.', pre_seq[..., :-1], training)
+    in_data = torch.cat((pre, audio, text, z.unsqueeze(1).expand(-1, pre.shape[1], -1)), dim=2)
+    out = _decode(sd, cfg.dropout_prob, in_data, training, noise, 0.01, fast)
+    return out, z, mu, log_var
+
+
+def pose_generator_trimodal(sd: SD, cfg: ModelCfg, pre_seq, in_text, in_audio, vid, training: bool, noise: Noise,
+                            fast: bool = False):
+    """PoseGeneratorTriModal.forward (:287-343): raw pre_seq into the GRU; ``nn.LeakyReLU(True)`` in
+    ``out`` has negative_slope == 1.0, i.e. the identity (:285)."""
+    audio = wav_encoder(sd, 'audio_encoder.', in_audio, training)
+    text = text_encoder_tcn(sd, 'text_encoder.', in_text, training, cfg.dropout_prob, noise)
+    assert audio.shape[1] == text.shape[1]
+    z, mu, log_var = _speaker_z(sd, vid, noise)
+    in_data = torch.cat((pre_seq, audio, text, z.unsqueeze(1).expand(-1, pre_seq.shape[1], -1)), dim=2)
+    out = _decode(sd, cfg.dropout_prob, in_data, training, noise, 1.0, fast)
+    return out, z, mu, log_var
+
+
+def aff_discriminator(sd: SD, poses: Tensor, training: bool, noise: Noise, fast: bool = False) -> Tensor:
+    """AffDiscriminator.forward (:568-585): GRU dropout is hard-wired to 0.3 (:558)."""
+    feat = aff_encoder(sd, 'aff_encoder.', poses, training)
+    if fast and noise.pinned is None:
+        y = gru_fast(sd, 'gru.', feat, training, 0.3)
+    else:
+        y = gru(sd, 'gru.', feat, training, 0.3, noise, 'gru')
+    H = y.shape[2] // 2
+    y = y[:, :, :H] + y[:, :, H:]
+    y = F.linear(y, sd['out.weight'], sd['out.bias']).squeeze(2)
+    return torch.sigmoid(F.linear(y, sd['out2.weight'], sd['out2.bias']))
+
+
+def conv_discriminator(sd: SD, poses: Tensor, training: bool, noise: Noise, fast: bool = False) -> Tensor:
+    """ConvDiscriminatorTriModal / ConvDiscriminator (:390-435): three valid k=3 convs; the two
+    ``nn.LeakyReLU(True)`` are identities (slope 1.0, :399,:402)."""
+    x = poses.transpose(1, 2)
+    x = F.conv1d(x, sd['pre_conv.0.weight'], sd['pre_conv.0.bias'])
+    x = _bn(sd, 'pre_conv.1.', x, training)
+    x = F.conv1d(x, sd['pre_conv.3.weight'], sd['pre_conv.3.bias'])
+    x = _bn(sd, 'pre_conv.4.', x, training)
+    x = F.conv1d(x, sd['pre_conv.6.weight'], sd['pre_conv.6.bias']).transpose(1, 2)
+    if fast and noise.pinned is None:
+        y = gru_fast(sd, 'gru.', x, training, 0.3)
+    else:
+        y = gru(sd, 'gru.', x, training, 0.3, noise, 'gru')
+    H = y.shape[2] // 2
+    y = y[:, :, :H] + y[:, :, H:]
+    y = F.linear(y, sd['out.weight'], sd['out.bias']).squeeze(2)
+    return torch.sigmoid(F.linear(y, sd['out2.weight'], sd['out2.bias']))
+
+
+# ----------------------------------------------------------------------------------------------
+# the GAN step  (processor_v2.py:776-957) and Adam (processor_v2.py:215-220)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class StepCfg:
+    """config/multimodal_context_v2.yml:29-36 + parse_args.py defaults."""
+    n_pre_poses: int = 4
+    loss_warmup: int = 0
+    loss_gan_weight: float = 5.0
+    loss_regression_weight: float = 500.0
+    loss_kld_weight: float = 0.1
+    loss_reg_weight: float = 0.05
+    z_type: str = 'speaker'
+    lr_gen: float = 5e-4
+    lr_dis: float = 1e-4          # learning_rate * discriminator_lr_weight (0.2)
+    betas: Tuple[float, float] = (0.5, 0.999)
+    adam_eps: float = 1e-8
+
+
+def is_param(key: str) -> bool:
+    return not (key.endswith('running_mean') or key.endswith('running_var') or key.endswith('num_batches_tracked'))
+
+
+def param_keys(sd: SD) -> List[str]:
+    """Trainable entries, with the TCN's duplicated aliases (net.0 == conv1, net.4 == conv2) removed."""
+    return [k for k in sd if is_param(k) and '.net.' not in k]
+
+
+@dataclass
+class AdamState:
+    step: int = 0
+    m: Dict[str, Tensor] = field(default_factory=dict)
+    v: Dict[str, Tensor] = field(default_factory=dict)
+
+
+def adam_update(sd: SD, grads: Dict[str, Tensor], st: AdamState, lr: float, betas=(0.5, 0.999), eps=1e-8) -> None:
+    """torch.optim.Adam (no weight decay, no amsgrad): p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
+    Parameters whose grad is None are skipped, as torch does."""
+    st.step += 1
+    b1, b2 = betas
+    bc1 = 1 - b1 ** st.step
+    bc2 = 1 - b2 ** st.step
+    for k, g in grads.items():
+        if g is None:
+            continue
+        if k not in st.m:
+            st.m[k] = torch.zeros_like(g)
+            st.v[k] = torch.zeros_like(g)
+        st.m[k].mul_(b1).add_(g, alpha=1 - b1)
+        st.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (st.v[k].sqrt() / math.sqrt(bc2)).add_(eps)
+        sd[k].data.addcdiv_(st.m[k], denom, value=-lr / bc1)
+        # keep the reference's aliased TCN keys in sync
+        if '.conv1.' in k or '.conv2.' in k:
+            alias = k.replace('.conv1.', '.net.0.').replace('.conv2.', '.net.4.')
+            if alias in sd and alias != k:
+                sd[alias] = sd[k]
+
+
+def make_pre_seq(target: Tensor, n_pre: int) -> Tensor:
+    """processor_v2.py:784-788."""
+    pre = target.new_zeros(target.shape[0], target.shape[1], target.shape[2] + 1)
+    pre[:, :n_pre, :-1] = target[:, :n_pre]
+    pre[:, :n_pre, -1] = 1
+    return pre
+
+
+def dis_loss(dis_real: Tensor, dis_fake: Tensor) -> Tensor:
+    """processor_v2.py:811 (non-saturating GAN)."""
+    return torch.sum(-torch.mean(torch.log(dis_real + 1e-8) + torch.log(1 - dis_fake + 1e-8)))
+
+
+def gen_losses(scfg: StepCfg, out, target, dis_out, out_rand, z, z_rand, mu, log_var, use_gan: bool):
+    """processor_v2.py:893-937.  Returns (total, dict of unweighted components)."""
+    huber = F.smooth_l1_loss(out / 0.1, target / 0.1) * 0.1
+    gen_error = -torch.mean(torch.log(dis_out + 1e-8))
+    pose_l1 = (F.smooth_l1_loss(out / 0.05, out_rand.detach() / 0.05, reduction='none') * 0.05).sum(dim=(1, 2))
+    z_l1 = (z.detach() - z_rand.detach()).abs().mean(1)
+    div_reg = torch.clamp(-(pose_l1 / (z_l1 + 1.0e-5)), min=-1000).mean()
+    kld = -0.5 * torch.mean(1 + log_var - mu.pow(2) - log_var.exp())
+    loss = scfg.loss_regression_weight * huber + scfg.loss_kld_weight * kld + scfg.loss_reg_weight * div_reg
+    if use_gan:
+        loss = loss + scfg.loss_gan_weight * gen_error
+    return loss, dict(huber=huber, gen=gen_error, div_reg=div_reg, kld=kld)
+
+
+def _leaf(sd: SD, keys: Sequence[str]) -> SD:
+    """Detach-and-require-grad view of a model for autograd; buffers are shared (BN updates land in sd)."""
+    out = dict(sd)
+    for k in keys:
+        out[k] = sd[k].detach().requires_grad_(True)
+    for k in list(out):
+        if '.net.0.' in k or '.net.4.' in k:
+            out[k] = out[k.replace('.net.0.', '.conv1.').replace('.net.4.', '.conv2.')]
+    return out
+
+
+@dataclass
+class StepNoise:
+    """Noise for the seven forward passes of one step.  ``perm`` is the speaker permutation (:905)."""
+    g_dis: Noise
+    d_real: Noise
+    d_fake: Noise
+    pgt: Noise
+    g_main: Noise
+    d_gen: Noise
+    g_rand: Noise
+    perm: Optional[Tensor] = None
+
+    @staticmethod
+    def fresh() -> 'StepNoise':
+        return StepNoise(*[Noise(None) for _ in range(7)])
+
+    @staticmethod
+    def off(batch: int) -> 'StepNoise':
+        return StepNoise(*[Noise('off') for _ in range(7)], perm=torch.arange(batch).flip(0))
+
+
+def gan_step(G: SD, D: SD, PGT: SD, g_opt: AdamState, d_opt: AdamState, mcfg: ModelCfg, scfg: StepCfg,
+             in_text, in_audio, in_mfcc, target, vid, epoch: int, noise: StepNoise, train: bool = True,
+             fast: bool = False, d_drop_noise_off: bool = False):
+    """Processor.forward_pass_s2ag (processor_v2.py:776-957), train branch, use_mfcc = True.
+
+    G and D run in train mode (per_train_epoch :961-962); the frozen tri-modal baseline PGT is never
+    put in eval mode by the reference either, so it also runs in train mode (BN batch stats, dropout).
+    Returns (metric, loss_dict, grads) where metric is the 7-tuple's first element.
+    """
+    pre_seq = make_pre_seq(target, scfg.n_pre_poses)
+    use_gan = epoch > scfg.loss_warmup and scfg.loss_gan_weight > 0.0
+    losses: Dict[str, float] = {}
+    grads_out: Dict[str, Dict[str, Tensor]] = {}
+    gk, dk = param_keys(G), param_keys(D)
+
+    if use_gan:
+        Gl, Dl = _leaf(G, gk), _leaf(D, dk)
+        with torch.no_grad():
+            fake, *_ = pose_generator(Gl, mcfg, pre_seq, in_text, in_mfcc, vid, train, noise.g_dis, fast)
+        d_real = aff_discriminator(Dl, target, train, noise.d_real, fast)
+        d_fake = aff_discriminator(Dl, fake.detach(), train, noise.d_fake, fast)
+        d_err = dis_loss(d_real, d_fake)
+        losses['dis'] = float(d_err.detach())
+        if train:
+            gd = torch.autograd.grad(d_err, [Dl[k] for k in dk], allow_unused=True)
+            grads_out['D'] = dict(zip(dk, gd))
+            adam_update(D, grads_out['D'], d_opt, scfg.lr_dis, scfg.betas, scfg.adam_eps)
+
+    Gl, Dl = _leaf(G, gk), _leaf(D, dk)
+    with torch.no_grad():
+        out_tri, *_ = pose_generator_trimodal(PGT, mcfg, pre_seq, in_text, in_audio, vid, True, noise.pgt, fast)
+    out, z, mu, log_var = pose_generator(Gl, mcfg, pre_seq, in_text, in_mfcc, vid, train, noise.g_main, fast)
+    d_out = aff_discriminator(Dl, out, train, noise.d_gen, fast)
+    perm = noise.perm if noise.perm is not None else torch.randperm(vid.shape[0])
+    with torch.no_grad():
+        out_rand, z_rand, _, _ = pose_generator(Gl, mcfg, pre_seq, in_text, in_mfcc, vid[perm], train,
+                                                noise.g_rand, fast)
+    loss, comp = gen_losses(scfg, out, target, d_out, out_rand, z, z_rand, mu, log_var,
+                            epoch > scfg.loss_warmup)
+    losses.update(loss=scfg.loss_regression_weight * float(comp['huber'].detach()),
+                  KLD=scfg.loss_kld_weight * float(comp['kld'].detach()),
+                  DIV_REG=scfg.loss_reg_weight * float(comp['div_reg'].detach()))
+    if use_gan:
+        losses['gen'] = scfg.loss_gan_weight * float(comp['gen'].detach())
+    losses['total'] = float(loss.detach())
+    if train:
+        gg = torch.autograd.grad(loss, [Gl[k] for k in gk], allow_unused=True)
+        grads_out['G'] = dict(zip(gk, gg))
+        adam_update(G, grads_out['G'], g_opt, scfg.lr_gen, scfg.betas, scfg.adam_eps)
+    metric = float(F.l1_loss(out.detach(), target)) - float(F.l1_loss(out_tri, target))
+    return metric, losses, grads_out
+
+
+# ----------------------------------------------------------------------------------------------
+# model construction helpers (test/bench side): shapes of every state_dict entry
+# ----------------------------------------------------------------------------------------------
+def _bn_entries(p: str, c: int) -> Dict[str, Tuple[int, ...]]:
+    return {p + 'weight': (c,), p + 'bias': (c,), p + 'running_mean': (c,), p + 'running_var': (c,),
+            p + 'num_batches_tracked': ()}
+
+
+def _aff_encoder_shapes(p: str) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    for name, cin, ks in (('st_gcn1.', 3, 5), ('st_gcn2.', 48, 3)):
+        q = p + name
+        s[q + 'gcn.conv.weight'] = (80, cin, 9, 1)
+        s[q + 'gcn.conv.bias'] = (80,)
+        s.update(_bn_entries(q + 'tcn.0.', 16))
+        s[q + 'tcn.2.weight'] = (16, 16, 9, ks)
+        s[q + 'tcn.2.bias'] = (16,)
+        s.update(_bn_entries(q + 'tcn.3.', 16))
+        s[q + 'residual.0.weight'] = (16, cin, 1, 1)
+        s[q + 'residual.0.bias'] = (16,)
+        s.update(_bn_entries(q + 'residual.1.', 16))
+        if name == 'st_gcn1.':
+            s.update(_bn_entries(p + 'batch_norm1.', 144))
+    s.update(_bn_entries(p + 'batch_norm2.', 48))
+    s[p + 'conv3.weight'] = (16, 48, 5)
+    s[p + 'conv3.bias'] = (16,)
+    s.update(_bn_entries(p + 'batch_norm3.', 16))
+    s[p + 'conv4.weight'] = (8, 16, 3)
+    s[p + 'conv4.bias'] = (8,)
+    s.update(_bn_entries(p + 'batch_norm4.', 8))
+    return s
+
+
+def _gru_shapes(p: str, in_size: int, H: int, layers: int) -> Dict[str, Tuple[int, ...]]:
+    s = {}
+    for l in range(layers):
+        for suf in ('', '_reverse'):
+            s[f'{p}weight_ih_l{l}{suf}'] = (3 * H, in_size if l == 0 else 2 * H)
+            s[f'{p}weight_hh_l{l}{suf}'] = (3 * H, H)
+            s[f'{p}bias_ih_l{l}{suf}'] = (3 * H,)
+            s[f'{p}bias_hh_l{l}{suf}'] = (3 * H,)
+    return s
+
+
+def _text_encoder_shapes(p: str, n_words: int, embed: int, hidden: int, layers: int):
+    s = {p + 'embedding.weight': (n_words, embed)}
+    for i in range(layers):
+        cin = embed if i == 0 else hidden
+        for tag, alias, ci in (('conv1', 'net.0', cin), ('conv2', 'net.4', hidden)):
+            for t in (tag, alias):
+                q = f'{p}tcn.network.{i}.{t}.'
+                s[q + 'bias'] = (hidden,)
+                s[q + 'weight_g'] = (hidden, 1, 1)
+                s[q + 'weight_v'] = (hidden, ci, 2)
+        if cin != hidden:
+            s[f'{p}tcn.network.{i}.downsample.weight'] = (hidden, cin, 1)
+            s[f'{p}tcn.network.{i}.downsample.bias'] = (hidden,)
+    s[p + 'decoder.weight'] = (32, hidden)
+    s[p + 'decoder.bias'] = (32,)
+    return s
+
+
+def _wav_encoder_shapes(p: str):
+    s = {}
+    fe = p + 'feat_extractor.'
+    for idx, (co, ci) in zip((0, 3, 6, 9), ((16, 1), (32, 16), (64, 32), (32, 64))):
+        s[f'{fe}{idx}.weight'] = (co, ci, 15)
+        s[f'{fe}{idx}.bias'] = (co,)
+    for idx, c in zip((1, 4, 7), (16, 32, 64)):
+        s.update(_bn_entries(f'{fe}{idx}.', c))
+    return s
+
+
+def _speaker_shapes(n_spk: int):
+    return {'speaker_embedding.0.weight': (n_spk, 16), 'speaker_embedding.1.weight': (16, 16),
+            'speaker_embedding.1.bias': (16,), 'speaker_mu.weight': (16, 16), 'speaker_mu.bias': (16,),
+            'speaker_log_var.weight': (16, 16), 'speaker_log_var.bias': (16,)}
+
+
+def generator_shapes(cfg: ModelCfg, n_words: int, n_spk: int, mfcc_length: int = 71, num_mfcc: int = 37,
+                     pose_dim: int = 27, embed: int = 300, audio: str = 'mfcc'):
+    """state_dict layout of PoseGenerator ('mfcc') / _abl_audio.PoseGenerator ('wav')."""
+    s: Dict[str, Tuple[int, ...]] = {}
+    if audio == 'mfcc':
+        chans = [mfcc_length, 64, 64, 48, cfg.n_poses]
+        for i, k in zip(range(1, 5), (5, 5, 3, 3)):
+            s[f'audio_encoder.conv{i}.weight'] = (chans[i], chans[i - 1], k)
+            s[f'audio_encoder.conv{i}.bias'] = (chans[i],)
+            s.update(_bn_entries(f'audio_encoder.batch_norm{i}.', chans[i]))
+        s['audio_encoder.linear1.weight'] = (32, num_mfcc)
+        s['audio_encoder.linear1.bias'] = (32,)
+    else:
+        s.update(_wav_encoder_shapes('audio_encoder.'))
+    s.update(_text_encoder_shapes('text_encoder.', n_words, embed, cfg.hidden_size, cfg.n_layers))
+    s.update(_aff_encoder_shapes('aff_encoder.'))
+    s.update(_speaker_shapes(n_spk))
+    H = cfg.hidden_size_s2eg
+    s.update(_gru_shapes('gru.', 8 + 32 + 32 + 16, H, cfg.n_layers))
+    s['out.0.weight'] = (H // 2, H)
+    s['out.0.bias'] = (H // 2,)
+    s['out.2.weight'] = (pose_dim, H // 2)
+    s['out.2.bias'] = (pose_dim,)
+    return s
+
+
+def trimodal_shapes(cfg: ModelCfg, n_words: int, n_spk: int, pose_dim: int = 27, embed: int = 300):
+    s: Dict[str, Tuple[int, ...]] = {}
+    s.update(_wav_encoder_shapes('audio_encoder.'))
+    s.update(_text_encoder_shapes('text_encoder.', n_words, embed, cfg.hidden_size, cfg.n_layers))
+    s.update(_speaker_shapes(n_spk))
+    H = cfg.hidden_size
+    s.update(_gru_shapes('gru.', pose_dim + 1 + 32 + 32 + 16, H, cfg.n_layers))
+    s['out.0.weight'] = (H // 2, H)
+    s['out.0.bias'] = (H // 2,)
+    s['out.2.weight'] = (pose_dim, H // 2)
+    s['out.2.bias'] = (pose_dim,)
+    return s
+
+
+def aff_discriminator_shapes(n_poses: int = 34):
+    s = _aff_encoder_shapes('aff_encoder.')
+    s.update(_gru_shapes('gru.', 8, 64, 4))
+    s.update({'out.weight': (1, 64), 'out.bias': (1,), 'out2.weight': (1, n_poses), 'out2.bias': (1,)})
+    return s
+
+
+def conv_discriminator_shapes(pose_dim: int = 27, n_poses: int = 34):
+    s = {'pre_conv.0.weight': (16, pose_dim, 3), 'pre_conv.0.bias': (16,),
+         'pre_conv.3.weight': (8, 16, 3), 'pre_conv.3.bias': (8,),
+         'pre_conv.6.weight': (8, 8, 3), 'pre_conv.6.bias': (8,)}
+    s.update(_bn_entries('pre_conv.1.', 16))
+    s.update(_bn_entries('pre_conv.4.', 8))
+    s.update(_gru_shapes('gru.', 8, 64, 4))
+    s.update({'out.weight': (1, 64), 'out.bias': (1,), 'out2.weight': (1, n_poses - 6), 'out2.bias': (1,)})
+    return s
+
+
+def recipe_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, scale: float = 1.0) -> SD:
+    """Frozen weight recipe shared by the golden generator and the tests: one legacy
+    ``np.random.RandomState(seed)`` stream (version-stable), consumed in sorted-key order.
+    Fan-in scaled uniform weights; BN gamma in [0.5,1.5], running_var in [0.5,1.5];
+    the TCN's aliased keys (net.0/net.4) share the tensor of conv1/conv2."""
+    rs = np.random.RandomState(seed)
+    sd: SD = {}
+    for k in sorted(shapes):
+        shp = shapes[k]
+        if '.net.0.' in k or '.net.4.' in k:
+            continue
+        if k.endswith('num_batches_tracked'):
+            sd[k] = torch.zeros((), dtype=torch.int64)
+            continue
+        n = int(np.prod(shp)) if len(shp) else 1
+        u = rs.uniform(-1.0, 1.0, size=n).astype(np.float32).reshape(shp)
+        if k.endswith('running_var') or (k.endswith('.weight') and len(shp) == 1) or k.endswith('weight_g'):
+            t = 1.0 + 0.5 * u
+        elif k.endswith('running_mean') or k.endswith('bias'):
+            t = 0.1 * u
+        elif k.endswith('embedding.weight') or k.endswith('embedding.0.weight'):
+            t = u
+        else:
+            fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else shp[0]
+            t = u * (scale / math.sqrt(fan_in))
+        sd[k] = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+    for k in shapes:
+        if '.net.0.' in k or '.net.4.' in k:
+            sd[k] = sd[k.replace('.net.0.', '.conv1.').replace('.net.4.', '.conv2.')]
+    return sd
+
+
+def recipe_inputs(B: int, T: int, seed: int, n_words: int, n_spk: int, audio_len: int = 36267,
+                  mfcc_len: int = 71, num_mfcc: int = 37) -> Dict[str, Tensor]:
+    """Synthetic TED-shaped batch of SURVEY.md section 8(d), from a legacy RandomState stream."""
+    rs = np.random.RandomState(seed)
+    text = np.zeros((B, T), dtype=np.int64)
+    for b in range(B):
+        k = rs.randint(2, 9)
+        pos = rs.choice(T, size=k, replace=False)
+        text[b, pos] = rs.randint(4, n_words, size=k)
+    audio = np.clip(rs.standard_normal((B, audio_len)) * 0.05, -1, 1).astype(np.float32)
+    mfcc = (rs.standard_normal((B, num_mfcc, mfcc_len)) * 0.1).astype(np.float32)
+    target = (rs.standard_normal((B, T, 27)) * 0.2).astype(np.float32)
+    vid = rs.randint(0, n_spk, size=B).astype(np.int64)
+    return dict(in_text=torch.from_numpy(text), in_audio=torch.from_numpy(audio), in_mfcc=torch.from_numpy(mfcc),
+                target=torch.from_numpy(target), vid=torch.from_numpy(vid))

@@ -1,0 +1,166 @@
+"""Pins oracle/s2ag_oracle.py against the fixtures generated from the reference itself
+(tests/golden/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import s2ag_oracle as O
+
+torch.set_num_threads(8)
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name), allow_pickle=False))
+
+
+def _close(a, b, tol=2e-5):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b.detach().numpy() if torch.is_tensor(b) else b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() / max(1e-6, np.abs(a).max())
+    assert err < tol, err
+
+
+def test_adjacency_matches_reference(golden_dir):
+    g = _load(golden_dir, 'misc.npz')
+    A1, A2 = O.aff_adjacencies()
+    np.testing.assert_allclose(A1.numpy(), g['A1'], atol=1e-7)
+    np.testing.assert_allclose(A2.numpy(), g['A2'], atol=1e-7)
+    assert A1.shape == (5, 9, 9) and A2.shape == (5, 3, 3)
+    assert float(A2[4].abs().sum()) == 0.0          # 5th slice all zero
+
+
+CASES = {'small': dict(hidden=32, n_words=64, n_spk=12, B=2, seed0=1000),
+         'full': dict(hidden=300, n_words=2000, n_spk=1371, B=4, seed0=2000)}
+
+
+def _models(c):
+    oc = O.ModelCfg(hidden_size=c['hidden'], hidden_size_s2eg=c['hidden'], dropout_prob=0.0)
+    s0 = c['seed0']
+    return oc, dict(G=O.recipe_state_dict(O.generator_shapes(oc, c['n_words'], c['n_spk']), s0 + 1),
+                    D=O.recipe_state_dict(O.aff_discriminator_shapes(), s0 + 2),
+                    CD=O.recipe_state_dict(O.conv_discriminator_shapes(), s0 + 3),
+                    T3=O.recipe_state_dict(O.trimodal_shapes(oc, c['n_words'], c['n_spk']), s0 + 4),
+                    GA=O.recipe_state_dict(O.generator_shapes(oc, c['n_words'], c['n_spk'], audio='wav'), s0 + 5))
+
+
+@pytest.mark.parametrize('tag', ['small', 'full'])
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_modules_match_reference(golden_dir, tag, mode):
+    c = CASES[tag]
+    g = _load(golden_dir, f'modules_{tag}.npz')
+    inp = O.recipe_inputs(c['B'], 34, c['seed0'] + 10, c['n_words'], c['n_spk'])
+    pre_seq = O.make_pre_seq(inp['target'], 4)
+    eps = torch.from_numpy(g['eps'])
+    tr = mode == 'train'
+    with torch.no_grad():
+        oc, m = _models(c)
+        _close(g[f'{mode}.wav_encoder'], O.wav_encoder(m['T3'], 'audio_encoder.', inp['in_audio'], tr))
+        _close(g[f'{mode}.mfcc_encoder'], O.mfcc_encoder(m['G'], 'audio_encoder.', inp['in_mfcc'], tr))
+        _close(g[f'{mode}.text_encoder'],
+               O.text_encoder_tcn(m['G'], 'text_encoder.', inp['in_text'], tr, 0.0, O.Noise('off'), 0.0))
+        _close(g[f'{mode}.aff_encoder'], O.aff_encoder(m['G'], 'aff_encoder.', inp['target'], tr))
+        oc, m = _models(c)
+
+        def nz():
+            return O.Noise({'eps': eps}) if not tr else _TrainNoise(eps)
+        o, z, mu, lv = O.pose_generator(m['G'], oc, pre_seq, inp['in_text'], inp['in_mfcc'], inp['vid'], tr, nz())
+        _close(g[f'{mode}.G.out'], o)
+        _close(g[f'{mode}.G.z'], z)
+        _close(g[f'{mode}.G.mu'], mu)
+        _close(g[f'{mode}.G.log_var'], lv)
+        _close(g[f'{mode}.T3.out'], O.pose_generator_trimodal(m['T3'], oc, pre_seq, inp['in_text'], inp['in_audio'],
+                                                              inp['vid'], tr, nz())[0])
+        _close(g[f'{mode}.GA.out'], O.pose_generator_abl_audio(m['GA'], oc, pre_seq, inp['in_text'], inp['in_audio'],
+                                                               inp['vid'], tr, nz())[0])
+        _close(g[f'{mode}.D.out'], O.aff_discriminator(m['D'], inp['target'], tr, O.Noise('off')))
+        _close(g[f'{mode}.CD.out'], O.conv_discriminator(m['CD'], inp['target'], tr, O.Noise('off')))
+        if tr:
+            for k in g:
+                if k.startswith('train.G.') and k != 'train.G.out' and k[8:] in m['G']:
+                    _close(g[k], m['G'][k[8:]].float())
+            _close(g['train.T3.audio_encoder.feat_extractor.1.running_var'],
+                   m['T3']['audio_encoder.feat_extractor.1.running_var'])
+
+
+class _TrainNoise(O.Noise):
+    """dropout disabled (the golden run sets every p to 0) but eps pinned."""
+
+    def __init__(self, eps):
+        super().__init__({'eps': eps})
+
+    def dropout(self, name, x, p):
+        return x
+
+
+def test_tcn_pinned_dropout_matches_reference(golden_dir):
+    g = _load(golden_dir, 'tcn_dropout.npz')
+    c = CASES['small']
+    oc = O.ModelCfg(hidden_size=32, hidden_size_s2eg=32, dropout_prob=0.3)
+    G = O.recipe_state_dict(O.generator_shapes(oc, c['n_words'], c['n_spk']), 3000 + 1)
+    inp = O.recipe_inputs(2, 34, 3000 + 10, c['n_words'], c['n_spk'])
+    names = ['text_encoder.emb_drop'] + [f'text_encoder.tcn.{i}.drop{j}' for i in range(4) for j in (1, 2)]
+    pinned = {n: torch.from_numpy(g['m%d' % i]) for i, n in enumerate(names)}
+    assert list(g['ps']) == pytest.approx([0.1] + [0.3] * 8)
+    with torch.no_grad():
+        y = O.text_encoder_tcn(G, 'text_encoder.', inp['in_text'], True, 0.3, O.Noise(pinned), 0.1)
+    _close(g['y'], y)
+
+
+def test_gru_fast_equals_cellwise():
+    torch.manual_seed(0)
+    sd = {k: torch.randn(s) * 0.2 for k, s in O._gru_shapes('gru.', 11, 24, 3).items()}
+    x = torch.randn(3, 7, 11)
+    a = O.gru(sd, 'gru.', x, False, 0.0, O.Noise('off'), 'gru')
+    b = O.gru_fast(sd, 'gru.', x, False, 0.0)
+    assert (a - b).abs().max() < 1e-5
+
+
+def test_three_step_trace_matches_reference(golden_dir):
+    g = _load(golden_dir, 'step_small.npz')
+    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 4, 4000
+    oc = O.ModelCfg(hidden_size=hidden, hidden_size_s2eg=hidden, dropout_prob=0.0)
+    G = O.recipe_state_dict(O.generator_shapes(oc, n_words, n_spk), s0 + 1)
+    D = O.recipe_state_dict(O.aff_discriminator_shapes(), s0 + 2)
+    T3 = O.recipe_state_dict(O.trimodal_shapes(oc, n_words, n_spk), s0 + 4)
+    gopt, dopt = O.AdamState(), O.AdamState()
+    scfg = O.StepCfg()
+    for s in range(3):
+        inp = O.recipe_inputs(B, 34, s0 + 100 + s, n_words, n_spk)
+        eps = torch.from_numpy(g[f's{s}.eps'])
+        nz = O.StepNoise(g_dis=_TrainNoise(eps[0]), d_real=O.Noise('off'), d_fake=O.Noise('off'),
+                         pgt=_TrainNoise(eps[1]), g_main=_TrainNoise(eps[2]), d_gen=O.Noise('off'),
+                         g_rand=_TrainNoise(eps[3]), perm=torch.from_numpy(g[f's{s}.perm']))
+        metric, losses, grads = O.gan_step(G, D, T3, gopt, dopt, oc, scfg, inp['in_text'], inp['in_audio'],
+                                           inp['in_mfcc'], inp['target'], inp['vid'], epoch=1, noise=nz)
+        assert losses['dis'] == pytest.approx(float(g[f's{s}.dis_error']), rel=2e-5)
+        assert losses['total'] == pytest.approx(float(g[f's{s}.loss']), rel=2e-5)
+        assert metric == pytest.approx(float(g[f's{s}.metric']), rel=1e-3, abs=1e-6)
+        if s == 0:
+            for k in g:
+                if k.startswith('s0.grad.G.'):
+                    _close(g[k], grads['G'][k[10:]], tol=2e-4)
+        for tagm, sd in (('G', G), ('D', D)):
+            groups = {}
+            for k, v in sd.items():
+                if '.net.' in k or k.endswith('num_batches_tracked'):
+                    continue
+                top = k.split('.')[0]
+                groups[top] = groups.get(top, 0.0) + float(v.double().abs().sum())
+            for top, val in groups.items():
+                assert val == pytest.approx(float(g[f's{s}.abs.{tagm}.{top}']), rel=1e-5), (s, tagm, top)
+    for k in g:
+        if k.startswith('final.G.'):
+            _close(g[k], G[k[8:]], tol=1e-4)
+        if k.startswith('final.D.'):
+            _close(g[k], D[k[8:]], tol=1e-4)
+
+
+def test_checkpoint_name_protocol(golden_dir):
+    """get_epoch_and_loss fixture (processor_v2.py:53-83) -- checked again against the product in
+    test_host_logic.py; here we only make sure the fixture is self-consistent."""
+    g = _load(golden_dir, 'misc.npz')
+    assert str(g['best'][0]) == 'epoch_000020_loss_0.2500_model.pth.tar'     # 2nd smallest, argpartition(…,2)[1]
+    assert str(g['at20'][1]) == '20' and str(g['missing'][0]) == ''
