@@ -1,0 +1,202 @@
+"""bench.py -- S2AG GAN train-step throughput on MI355X (BASELINE.json metric: train-step clips/s, 34-frame clips).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = Processor.train_step: 3 generator + 3 discriminator + 1 tri-modal forward, 2 backward, 2 Adam
+(processor_v2.py:776-957 of the reference), on configs[1] of BASELINE.json: batch 128 per GPU, T = 34,
+n_words 20000, 1371 speakers, synthetic TED-shaped inputs resident in HBM.  Arithmetic is fp32
+end to end (fp32 MFMA / FMA), i.e. at least the precision BASELINE names.  N > 1: one process per GPU, weak
+scaling, RCCL all-reduce of the flat gradient arenas.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- the dominant kernel of the step (the persistent GRU recurrence at H = 300), timed live with HIP
+                  events on the launch stream around direct launches at the workload's exact shapes; `achieved`
+                  = algorithmic FLOPs per launch / mean duration; peak = 157.3 TFLOP/s (fp32 MFMA == fp32 vector).
+  cpu_baseline -- the CPU oracle (the pinned restatement of the reference, kind "port") timed on this host's
+                  cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_WORDS, N_SPK, T, POSE_DIM, AUDIO_LEN, MFCC_LEN, NUM_MFCC = 20000, 1371, 34, 27, 36267, 71, 37
+
+
+class Vocab:                       # duck-typed speaker model (utils/vocab.py): class name must be 'Vocab'
+    def __init__(self, n):
+        self.n_words = n
+        self.word2index = {'v%d' % i: i for i in range(n)}
+
+
+def synthetic_batch(B, seed, device):
+    """CPU generator seeded per rank, then copied."""
+    g = torch.Generator().manual_seed(seed)
+    text = torch.zeros(B, T, dtype=torch.int64)
+    for b in range(B):
+        k = int(torch.randint(2, 9, (1,), generator=g))
+        pos = torch.randperm(T, generator=g)[:k]
+        text[b, pos] = torch.randint(4, N_WORDS, (k,), generator=g)
+    audio = (torch.randn(B, AUDIO_LEN, generator=g) * 0.05).clamp_(-1, 1)
+    mfcc = torch.randn(B, NUM_MFCC, MFCC_LEN, generator=g) * 0.1
+    target = torch.randn(B, T, POSE_DIM, generator=g) * 0.2
+    vid = torch.randint(0, N_SPK, (B,), generator=g)
+    return [t.to(device) for t in (text, audio, mfcc, target, vid)]
+
+
+def make_cfg():
+    return types.SimpleNamespace(n_pre_poses=4, n_poses=T, input_context='both', hidden_size=300,
+                                 hidden_size_s2eg=300, n_layers=4, dropout_prob=0.3, freeze_wordembed=False,
+                                 loss_warmup=0, loss_gan_weight=5.0, z_type='speaker', loss_reg_weight=0.05,
+                                 loss_regression_weight=500, loss_kld_weight=0.1, wordembed_dim=300,
+                                 learning_rate=5e-4, discriminator_lr_weight=0.2)
+
+
+def build_processor(B, hip_graph):
+    from speech2affective_gestures_amd import processor_v2 as P
+    lang = types.SimpleNamespace(n_words=N_WORDS, word_embedding_weights=None)
+    meta = types.SimpleNamespace(n_poses=T, expected_audio_length=AUDIO_LEN, num_mfcc_combined=NUM_MFCC,
+                                 lang_model=lang, speaker_model=Vocab(N_SPK), n_samples=0)
+    args = types.SimpleNamespace(batch_size=B, train_s2ag=True, work_dir_s2ag=None, save_log=False, print_log=False,
+                                 hip_graph=hip_graph)
+    pr = P.Processor(ROOT, args, make_cfg(), {'train_data_s2ag': meta, 'val_data_s2ag': meta, 'test_data_s2ag': meta},
+                     POSE_DIM, 3, 16000)
+    pr.meta_info['epoch'] = 1            # discriminator branch active (epoch > loss_warmup)
+    for m in (pr.s2ag_generator, pr.s2ag_discriminator, pr.trimodal_generator):
+        m.train()
+    return pr
+
+
+def gru_roofline(B, iters=20):
+    """Time the dominant kernel (gru_seq_fwd, H=300, both directions, T=34) with HIP events on its stream."""
+    import ctypes as C
+    from speech2affective_gestures_amd import _lib as L
+    lib = L.load()
+    H = 300
+    dev = 'cuda'
+    gi = torch.randn(B * T, 6 * H, device=dev) * 0.5
+    whhT = torch.randn(2, H, 3 * H, device=dev) * 0.05
+    bhh = torch.randn(2, 3 * H, device=dev) * 0.05
+    y = torch.empty(B * T, 2 * H, device=dev)
+    yd = torch.empty_like(y)
+    gates = torch.empty(2, B * T, 4 * H, device=dev)
+    rng = torch.tensor([1, 0], dtype=torch.int64, device=dev)
+    e = L.Epilogue(0, 1.0, 0.3, C.c_void_p(rng.data_ptr()), 1)
+    s = torch.cuda.current_stream()
+    sp = C.c_void_p(s.cuda_stream)
+
+    def launch():
+        L.check(lib.s2ag_gru_seq_fwd(C.c_void_p(gi.data_ptr()), C.c_void_p(whhT.data_ptr()), C.c_void_p(bhh.data_ptr()),
+                                     C.c_void_p(y.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(gates.data_ptr()),
+                                     B, T, H, C.byref(e), sp), 'gru_seq_fwd')
+    for _ in range(3):
+        launch()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(s)
+        launch()
+        b.record(s)
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in evs) / iters
+    flops = 2.0 * B * T * 2 * H * 3 * H           # recurrent mat-vec MACs x2, both directions
+    achieved = flops / (ms * 1e-3) / 1e12
+    return dict(bound='mfma', kernel='gru_seq_fwd_k<8> (H=300, T=34, 2 directions)', achieved=achieved, peak=157.3,
+                unit='TFLOP/s', frac=achieved / 157.3, traffic=None, ms_per_launch=ms,
+                algorithmic_flops_per_launch=flops)
+
+
+def cpu_baseline(B, steps=2):
+    """The oracle's gan_step (ATen fused GRU, drawn dropout) on the host cores -- bounded sample."""
+    from oracle import s2ag_oracle as O
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    oc = O.ModelCfg()
+    G = O.recipe_state_dict(O.generator_shapes(oc, N_WORDS, N_SPK), 1)
+    D = O.recipe_state_dict(O.aff_discriminator_shapes(), 2)
+    T3 = O.recipe_state_dict(O.trimodal_shapes(oc, N_WORDS, N_SPK), 3)
+    gopt, dopt, scfg = O.AdamState(), O.AdamState(), O.StepCfg()
+    inp = O.recipe_inputs(B, T, 7, N_WORDS, N_SPK)
+
+    def one():
+        O.gan_step(G, D, T3, gopt, dopt, oc, scfg, inp['in_text'], inp['in_audio'], inp['in_mfcc'], inp['target'],
+                   inp['vid'], epoch=1, noise=O.StepNoise.fresh(), fast=True)
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return dict(value=B / dt, unit='clips/s', cores=cores, kind='port',
+                sample=f'{steps} timed GAN steps (+1 warm-up) of the CPU oracle at batch {B}, T=34, fp32, '
+                       f'torch {torch.__version__}, {cores} threads; {dt * 1e3:.0f} ms/step')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=128, help='clips per GPU')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X; the product has no CPU path')
+    pr = build_processor(a.batch, not a.no_graph)
+    dp = pr.dp
+    assert dp.world_size == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={dp.world_size}'
+    from speech2affective_gestures_amd import noise
+    noise.manual_seed(1234 + dp.rank)
+    batch = synthetic_batch(a.batch, dp.rank, pr.device)
+    text, audio, mfcc, target, vid = batch
+
+    for _ in range(max(1, a.warmup)):       # also triggers graph capture (3 internal warm-up steps) on the 1st call
+        pr.train_step(text, audio, mfcc, target, vid, sync=False)
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pr.train_step(text, audio, mfcc, target, vid, sync=False)
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0, pr.device)
+    metric = pr._finish(pr._graphed['out']['comps'], pr._graphed['out']['dis']) if pr._graphed else None
+    ms = elapsed / a.steps * 1e3
+    value = a.batch * dp.world_size * a.steps / elapsed
+
+    if dp.rank == 0:
+        line = {
+            'metric': 'gan_train_step_clips_per_sec', 'value': value, 'unit': 'clips/s', 'n_gpus': dp.world_size,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: full G+D GAN step (3 G fwd, 3 D fwd, 1 tri-modal fwd, 2 bwd, '
+                                   '2 Adam), 34-frame TED-shaped clips', 'batch_per_gpu': a.batch,
+                       'global_batch': a.batch * dp.world_size, 'frames': T, 'n_words': N_WORDS, 'n_speakers': N_SPK,
+                       'parallelism': f'dp{dp.world_size}', 'hip_graph': not a.no_graph,
+                       'last_step_losses': pr.last_losses if metric is not None else None},
+        }
+        line['roofline'] = gru_roofline(a.batch)
+        if dp.world_size == 1 and not a.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(a.batch)
+            line['gpu_over_cpu'] = value / line['cpu_baseline']['value']
+        print(json.dumps(line), flush=True)
+    dp.barrier()
+
+
+if __name__ == '__main__':
+    main()

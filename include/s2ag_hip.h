@@ -1,0 +1,194 @@
+/*
+ * s2ag_hip.h -- C ABI of libs2ag_hip.so: the MI355X (gfx950) kernels of the Speech2AffectiveGestures
+ * GAN training step.
+ *
+ * The reference (UttaranB127/speech2affective_gestures) is pure Python/PyTorch and has no FFI of its
+ * own, so these entry points replace the ATen operators that the reference's hot path
+ * dispatches.  Each declaration cites the reference call site(s) it stands in for (paths relative to
+ * the reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless marked "host".
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream, allocates
+ *     nothing and never synchronises (safe under hipGraph capture).
+ *   - all activations are fp32, row-major, CHANNELS-LAST: a (clips, frames, channels) tensor is a
+ *     matrix of clips*frames rows; `ld*` is the row pitch in floats (lets a call read/write a column
+ *     slice of a wider matrix).
+ *   - weights stay in the reference's state_dict layout: conv (Cout, Cin, k), linear (out, in).
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative S2AG_E_* code.
+ *   - random sites (dropout, re-parametrisation noise) are counter based: the keep mask / normal
+ *     deviate of element i of site s is a pure function of (rng[0] = seed, rng[1] = step counter, s, i),
+ *     where `rng` is a 2-word device array.  s2ag_dropout_mask / s2ag_normal_noise materialise the
+ *     exact values a kernel will use, which is how the parity tests feed identical noise to the oracle.
+ */
+#ifndef S2AG_HIP_H
+#define S2AG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2AG_ABI_VERSION 1
+
+#define S2AG_E_BADARG (-1)
+#define S2AG_E_UNSUPPORTED (-2)
+
+/* activation kinds for fused epilogues */
+#define S2AG_ACT_NONE 0
+#define S2AG_ACT_LEAKY 1   /* x>0 ? x : slope*x   (slope 0 = ReLU, slope 1 = identity) */
+#define S2AG_ACT_SIGMOID 2
+
+int s2ag_abi_version(void);
+
+/* 1-D convolution geometry, channels-last.  Input rows (n*Lin + pos), output rows (n*Lout + l),
+ * pos = l*stride + tap*dil - pad (pad may be negative).  A Linear layer is ksize=1, Lin=Lout=1, N=rows. */
+typedef struct {
+    int N, Lin, Lout, Cin, Cout, ksize, stride, pad, dil;
+    int ldx; /* row pitch of the input matrix  */
+    int ldy; /* row pitch of the output matrix */
+} s2ag_conv_geom;
+
+/* fused epilogue of the forward conv: y = dropout(act(acc + bias)) */
+typedef struct {
+    int act;                         /* S2AG_ACT_*                                  */
+    float slope;                     /* for S2AG_ACT_LEAKY                          */
+    float drop_p;                    /* 0 = no dropout                              */
+    const unsigned long long* rng;   /* device {seed, counter}; may be NULL if drop_p == 0 */
+    unsigned site;                   /* random-site id                              */
+} s2ag_epilogue;
+
+/* y[(n,l), co] = epi( sum_{tap,ci} x[(n,pos), ci] * w[co,ci,tap] + bias[co] )      (fp32 MFMA implicit GEMM)
+ * replaces: nn.Conv1d / nn.Linear forward -- net/multimodal_context_net_v2.py:18-27 (WavEncoder),
+ * :39-48 (MFCCEncoder), :78 (TextEncoderTCN.decoder), :143-148 (AffEncoder conv3/4), :397-403 (pre_conv),
+ * :273-276,:284-286,:483-485,:561-562 (Linear); net/tcn.py:19,25 (dilated causal conv; chomp = Lout);
+ * net/utils/tgcn.py:56,181,200 (Conv2d of the ST-GCN blocks, after the host folds A / the vertex kernel
+ * into a (V*Cout, V*Cin, kt) weight, see s2ag_spmv); the W_ih projections of nn.GRU (:281,:406,:480,:558). */
+int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* bias /*nullable*/, float* y,
+                        const s2ag_conv_geom* g /*host*/, const s2ag_epilogue* e /*host, nullable*/, void* stream);
+
+/* dx[(n,pos), ci] (+)= sum_{tap,co} gy[(n,l), co] * w[co,ci,tap];  g->ldx pitches dx, g->ldy pitches gy.
+ * replaces: ConvolutionBackward / AddmmBackward (input grad) of the same call sites. */
+int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* dx, const s2ag_conv_geom* g /*host*/,
+                             int accumulate, void* stream);
+
+/* dw[co,ci,tap] (+)= sum_{n,l} gy[(n,l), co] * x[(n,pos), ci]   (split over rows, fp32 atomics)
+ * replaces: ConvolutionBackward / AddmmBackward (weight grad); also dW_hh of nn.GRU with x = shifted h. */
+int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw, const s2ag_conv_geom* g /*host*/,
+                               int accumulate, void* stream);
+
+/* out[c] (+)= sum_r x[r*ld + c]; if sq != NULL also sq[c] (+)= sum_r x^2.   (bias grads, BN batch statistics) */
+int s2ag_colsum(const float* x, int rows, int cols, int ld, float* out, float* sq /*nullable*/, int accumulate,
+                void* stream);
+
+/* BatchNorm over a channels-last matrix whose COLUMNS map onto BN channels through chan_of_col
+ * (identity for BatchNorm1d on (B,C,L); many-to-one for BatchNorm2d on the folded ST-GCN layout).
+ * replaces: nn.BatchNorm1d/2d -- net/multimodal_context_net_v2.py:19,22,25 (Wav), :40-46 (MFCC),
+ * :128,:139,:144,:149 (AffEncoder), :398,:401 (pre_conv); net/utils/tgcn.py:180,189,206.
+ *
+ * s2ag_bn_coeffs: training != 0: from column sums/sumsq (s2ag_colsum) compute per-channel batch mean and
+ *   biased variance, update running_mean/var (momentum, unbiased var) and num_batches_tracked (int64),
+ *   and emit per-COLUMN scale/shift/mean/invstd.  training == 0: coefficients from the running statistics. */
+int s2ag_bn_coeffs(const float* colsum, const float* colsq, const int* chan_of_col, int ncols, int nchan,
+                   int rows, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   long long* num_batches_tracked /*nullable*/, float eps, float momentum, int training,
+                   float* scale_col, float* shift_col, float* mean_col, float* invstd_col, void* stream);
+/* y = leaky(x*scale_col + shift_col, slope) */
+int s2ag_bn_apply(const float* x, int rows, int cols, int ldx, const float* scale_col, const float* shift_col,
+                  float slope, float* y, int ldy, void* stream);
+/* backward, 3 stages: (1) column sums of dpre and dpre*xhat, dpre = dy*leaky'(pre);
+ * (2) fold columns into channels: dgamma/dbeta (+= if accumulate) and per-column c1 = S1/n, c2 = S2/n;
+ * (3) dx = scale_col * (dpre - c1 - xhat*c2). */
+int s2ag_bn_bwd_reduce(const float* x, const float* dy, int rows, int cols, int ldx, int lddy,
+                       const float* scale_col, const float* shift_col, const float* mean_col,
+                       const float* invstd_col, float slope, float* s1_col, float* s2_col, void* stream);
+int s2ag_bn_bwd_coeffs(const float* s1_col, const float* s2_col, const int* chan_of_col, int ncols, int nchan,
+                       int rows, float* dgamma, float* dbeta, int accumulate, float* c1_col, float* c2_col,
+                       void* stream);
+int s2ag_bn_bwd_apply(const float* x, const float* dy, int rows, int cols, int ldx, int lddy,
+                      const float* scale_col, const float* shift_col, const float* mean_col,
+                      const float* invstd_col, float slope, const float* c1_col, const float* c2_col, float* dx,
+                      int lddx, void* stream);
+
+/* y = leaky(a + b, slope) on column slices; b may be NULL (y = leaky(a)).
+ * replaces: residual adds -- net/tcn.py:46, net/utils/tgcn.py:216-218, the bidirectional sum
+ * net/multimodal_context_net_v2.py:542,:578. */
+int s2ag_add_act(const float* a, int lda, const float* b /*nullable*/, int ldb, float* y, int ldy, int rows,
+                 int cols, float slope, void* stream);
+/* g = dy * dropmask(site) * act'(y)  -- backward of the conv epilogue / of s2ag_add_act (drop_p = 0). */
+int s2ag_epilogue_bwd(const float* dy, int lddy, const float* y, int ldy, float* g, int ldg, int rows, int cols,
+                      const s2ag_epilogue* e /*host*/, void* stream);
+
+/* out[r, :] = table[ids[r], :] * dropmask;   replaces nn.Embedding + nn.Dropout --
+ * net/multimodal_context_net_v2.py:70-73,:80,:88 and the speaker embedding :272,:471. */
+int s2ag_embedding_fwd(const long long* ids, const float* table, int rows, int dim, int n_entries, float* out,
+                       int ldo, const s2ag_epilogue* e /*host, nullable: only drop_p/rng/site used*/, void* stream);
+/* dtable[ids[r], :] (+)= g[r, :] * dropmask   (dense gradient, fp32 atomics) */
+int s2ag_embedding_bwd(const long long* ids, const float* g, int ldg, int rows, int dim, int n_entries,
+                       float* dtable, int accumulate, const s2ag_epilogue* e /*host, nullable*/, void* stream);
+
+/* torch.nn.utils.weight_norm (dim 0): w[r,:] = g[r] * v[r,:] / ||v[r,:]||;  net/tcn.py:19,25. */
+int s2ag_weight_norm_fwd(const float* v, const float* g, int rows, int cols, float* w, float* norm, void* stream);
+int s2ag_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, int rows, int cols,
+                         float* dv, float* dg, void* stream);
+
+/* y[i] (+)= sum_{j in row i} val[j] * x[col[j]]   (CSR).  Used to fold the ST-GCN adjacency / vertex kernel
+ * into dense channels-last conv weights each step and to un-fold their gradients:
+ * net/utils/tgcn.py:64-71 (einsum 'nkctv,kvw->nctw'), :181 (Conv2d (kt, kv)), :200 (1x1 residual). */
+int s2ag_spmv(const int* rowptr, const int* col, const float* val, const float* x, float* y, int nrows,
+              int accumulate, void* stream);
+
+/* dst (cols x rows) = src (rows x cols)^T */
+int s2ag_transpose(const float* src, int rows, int cols, float* dst, void* stream);
+
+/* One bidirectional GRU layer, recurrent part (PyTorch gate order r,z,n).  nn.GRU --
+ * net/multimodal_context_net_v2.py:281,:406,:480,:558 (forward :333,:425,:541,:574).
+ *  gi    (B*T, 6H): W_ih x + b_ih for [forward | reverse] direction (from s2ag_conv1d_nlc_fwd)
+ *  whhT  (2, H, 3H): W_hh^T per direction;  bhh (2, 3H)
+ *  y     (B*T, 2H): raw hidden states [forward | reverse]
+ *  ydrop (B*T, 2H): nullable; y * keep-mask(site)/(1-p) -- the next layer's input in train mode
+ *  gates (2, B*T, 4H): nullable; saved (r, z, n, W_hn h + b_hn) for the backward pass */
+int s2ag_gru_seq_fwd(const float* gi, const float* whhT, const float* bhh, float* y, float* ydrop, float* gates,
+                     int B, int T, int H, const s2ag_epilogue* e /*host, nullable: dropout of ydrop*/, void* stream);
+/* backward through time of one layer.
+ *  dy    (B*T, lddy): grad w.r.t. the layer output the consumer saw; dir d reads columns [d*dy_dir_stride, +H)
+ *        (dy_dir_stride = H for a (B*T,2H) grad, 0 when the consumer summed the two directions);
+ *        if e->drop_p > 0 the keep mask of `site` is re-applied (consumer saw ydrop).
+ *  whh   (2, 3H, H) reference layout; y, gates as saved by the forward.
+ *  dgi   (B*T, 6H): grad of gi;  dgh (2, B*T, 3H): grad of (W_hh h + b_hh) */
+int s2ag_gru_seq_bwd(const float* dy, int lddy, int dy_dir_stride, const float* whh, const float* y,
+                     const float* gates, float* dgi, float* dgh, int B, int T, int H,
+                     const s2ag_epilogue* e /*host, nullable*/, void* stream);
+
+/* z = mu + eps*exp(0.5*log_var), eps ~ N(0,1) from (rng, site);  net/embedding_net.py:10-13. */
+int s2ag_reparam_fwd(const float* mu, const float* log_var, int n, const unsigned long long* rng, unsigned site,
+                     float* z, void* stream);
+/* dmu += dz ; dlog_var += dz * eps * 0.5 * exp(0.5*log_var) */
+int s2ag_reparam_bwd(const float* dz, const float* log_var, int n, const unsigned long long* rng, unsigned site,
+                     float* dmu, float* dlog_var, void* stream);
+
+/* Discriminator loss -mean(log(d_real+1e-8) + log(1-d_fake+1e-8)) and its gradient; processor_v2.py:811. */
+int s2ag_dis_loss(const float* d_real, const float* d_fake, int B, float* loss /*1*/, float* g_real, float* g_fake,
+                  void* stream);
+/* Generator losses of processor_v2.py:893-937 (+ the L1 metric of :956) fused in two launches.
+ *  comps[8] = {total, huber, gen_error, div_reg, kld, l1(out,target), l1(out_tri,target), 0}
+ *  weights  = {loss_regression_weight, loss_gan_weight (0 during warm-up), loss_reg_weight, loss_kld_weight}
+ *  gradients of `total`: g_out (B,TP), g_dis (B), g_mu (B,16), g_logvar (B,16).  scratch: B*8 floats. */
+int s2ag_gen_loss(const float* out, const float* target, const float* out_tri /*nullable*/, const float* dis_out,
+                  const float* out_rand, const float* z, const float* z_rand, const float* mu, const float* log_var,
+                  int B, int TP, int ZD, const float* weights /*host[4]*/, float* scratch, float* comps,
+                  float* g_out, float* g_dis, float* g_mu, float* g_logvar, void* stream);
+
+/* torch.optim.Adam (no weight decay / amsgrad) over a flat parameter arena; processor_v2.py:215-220.
+ * `step` is a device int32 holding the number of steps already taken (bumped by s2ag_counter_inc). */
+int s2ag_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                   float eps, const int* step, float grad_scale, void* stream);
+int s2ag_counter_inc(int* counter /*nullable*/, unsigned long long* rng /*nullable: rng[1] += 1*/, void* stream);
+
+/* materialise the noise a kernel will use (parity tests / debugging only) */
+int s2ag_dropout_mask(const unsigned long long* rng, unsigned site, float p, long long n, float* mask, void* stream);
+int s2ag_normal_noise(const unsigned long long* rng, unsigned site, long long n, float* eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2AG_HIP_H */

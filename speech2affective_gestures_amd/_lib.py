@@ -1,0 +1,88 @@
+"""ctypes binding of include/s2ag_hip.h.  There is NO fallback: if libs2ag_hip.so is missing or a
+symbol is absent, importing the compute path raises."""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, 'libs2ag_hip.so')
+
+vp, ci, cf, cu, cll = C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_longlong
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, ci) for n in ('N', 'Lin', 'Lout', 'Cin', 'Cout', 'ksize', 'stride', 'pad', 'dil', 'ldx', 'ldy')]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [('act', ci), ('slope', cf), ('drop_p', cf), ('rng', vp), ('site', cu)]
+
+
+ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
+PG, PE = C.POINTER(ConvGeom), C.POINTER(Epilogue)
+
+# name -> argtypes (every function returns int); mirrors include/s2ag_hip.h one to one
+SIGNATURES = {
+    's2ag_abi_version': [],
+    's2ag_conv1d_nlc_fwd': [vp, vp, vp, vp, PG, PE, vp],
+    's2ag_conv1d_nlc_bwd_data': [vp, vp, vp, PG, ci, vp],
+    's2ag_conv1d_nlc_bwd_weight': [vp, vp, vp, PG, ci, vp],
+    's2ag_colsum': [vp, ci, ci, ci, vp, vp, ci, vp],
+    's2ag_bn_coeffs': [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp],
+    's2ag_bn_apply': [vp, ci, ci, ci, vp, vp, cf, vp, ci, vp],
+    's2ag_bn_bwd_reduce': [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp],
+    's2ag_bn_bwd_coeffs': [vp, vp, vp, ci, ci, ci, vp, vp, ci, vp, vp, vp],
+    's2ag_bn_bwd_apply': [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, ci, vp],
+    's2ag_add_act': [vp, ci, vp, ci, vp, ci, ci, ci, cf, vp],
+    's2ag_epilogue_bwd': [vp, ci, vp, ci, vp, ci, ci, ci, PE, vp],
+    's2ag_embedding_fwd': [vp, vp, ci, ci, ci, vp, ci, PE, vp],
+    's2ag_embedding_bwd': [vp, vp, ci, ci, ci, ci, vp, ci, PE, vp],
+    's2ag_weight_norm_fwd': [vp, vp, ci, ci, vp, vp, vp],
+    's2ag_weight_norm_bwd': [vp, vp, vp, vp, ci, ci, vp, vp, vp],
+    's2ag_spmv': [vp, vp, vp, vp, vp, ci, ci, vp],
+    's2ag_transpose': [vp, ci, ci, vp, vp],
+    's2ag_gru_seq_fwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],
+    's2ag_gru_seq_bwd': [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],
+    's2ag_reparam_fwd': [vp, vp, ci, vp, cu, vp, vp],
+    's2ag_reparam_bwd': [vp, vp, ci, vp, cu, vp, vp, vp],
+    's2ag_dis_loss': [vp, vp, ci, vp, vp, vp, vp],
+    's2ag_gen_loss': [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, C.POINTER(cf), vp, vp, vp, vp, vp, vp, vp],
+    's2ag_adam_step': [vp, vp, vp, vp, cll, cf, cf, cf, cf, vp, cf, vp],
+    's2ag_counter_inc': [vp, vp, vp],
+    's2ag_dropout_mask': [vp, cu, cf, cll, vp, vp],
+    's2ag_normal_noise': [vp, cu, cll, vp, vp],
+}
+
+_lib = None
+
+
+class S2AGLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type-check the shared library.  Raises S2AGLibraryError loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise S2AGLibraryError(
+            f'{LIB_PATH} not found: the S2AG HIP kernels are not built. Run '
+            f'`python -m speech2affective_gestures_amd.build` (hipcc, gfx950). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise S2AGLibraryError(f'{LIB_PATH} lacks symbol {name}; rebuild it') from e
+        fn.argtypes = args
+        fn.restype = ci
+    if lib.s2ag_abi_version() != 1:
+        raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: 'bad argument', -2: 'unsupported shape'}.get(rc, f'hipError {rc}')
+        raise RuntimeError(f'{what} failed: {kind}')

@@ -1,0 +1,416 @@
+// Implicit-GEMM 1-D convolution family on channels-last fp32 matrices, on the f32 MFMA pipe
+// (v_mfma_f32_16x16x4_f32: exact f32, bitwise an fmaf chain -- keeps the 1e-3 parity bar with margin).
+//
+// One tiling serves every contraction of the S2AG step (Conv1d, dilated causal TCN conv, Linear,
+// folded ST-GCN Conv2d, GRU input projections) in its three forms:
+//   fwd        out[(n,l),co]   = sum_{tap,ci} x[(n,pos),ci]   * w[co,ci,tap]     (+bias, act, dropout)
+//   bwd_data   dx[(n,pos),ci]  = sum_{tap,co} gy[(n,l),co]    * w[co,ci,tap]
+//   bwd_weight dw[co,ci,tap]  += sum_{(n,l)}  gy[(n,l),co]    * x[(n,pos),ci]    (split over rows, atomics)
+//
+// Block = 256 threads = 4 waves; block tile 64x64, K step 16; wave (wm,wn) owns a 32x32 quadrant as
+// 2x2 MFMA 16x16 tiles.  Operands are staged k-major in LDS with an 80-float pitch so the four k-rows
+// a wave reads in one ds_read_b32 fall on disjoint bank groups.  The next K tile is fetched into
+// registers while the current one is multiplied.
+#include "s2ag_common.h"
+
+namespace {
+using namespace s2ag;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BM = 64, BN = 64, BK = 16, PITCH = 80;
+
+struct GemmP {
+    const float* a;     // x (fwd) or gy (bwd_data)
+    const float* w;
+    const float* bias;
+    float* out;
+    int M, K, NC;       // output rows, contraction length, output cols
+    int Lr, Lsrc;       // rows per clip of out / of a
+    int CK;             // channels per tap in the contraction (Cin fwd, Cout bwd)
+    int Cin;            // conv Cin (weight indexing)
+    int ks, stride, pad, dil;
+    int lda, ldo;
+    int act;
+    float slope, drop_p, inv_keep;
+    const unsigned long long* rng;
+    unsigned site;
+    int accumulate;
+};
+
+template <bool BWD>
+__device__ __forceinline__ bool src_pos(const GemmP& p, int l, int tap, int& pos) {
+    if (!BWD) {
+        pos = l * p.stride + tap * p.dil - p.pad;
+    } else {
+        const int t = l + p.pad - tap * p.dil;
+        if (t < 0) return false;
+        if (p.stride == 1) {
+            pos = t;
+        } else {
+            pos = t / p.stride;
+            if (pos * p.stride != t) return false;
+        }
+    }
+    return pos >= 0 && pos < p.Lsrc;
+}
+
+template <bool BWD, bool VEC>
+__global__ __launch_bounds__(256) void conv_gemm_k(GemmP p) {
+    __shared__ float As[BK][PITCH];
+    __shared__ float Bs[BK][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kq = tid & 3, r = tid >> 2;
+
+    const int m = m0 + r;
+    const bool mvalid = m < p.M;
+    int nclip = 0, l = 0;
+    if (mvalid) {
+        nclip = m / p.Lr;
+        l = m - nclip * p.Lr;
+    }
+    const long long arow0 = (long long)nclip * p.Lsrc;
+    const int col = n0 + r;
+    const bool cvalid = col < p.NC;
+
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        const int kk0 = k0 + kq * 4;
+        if (VEC) {
+            // CK % 4 == 0: the four k's share one tap and are contiguous channels
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int tap = 0, c = 0;
+            const bool kval = kk0 < p.K;
+            if (kval) {
+                tap = kk0 / p.CK;
+                c = kk0 - tap * p.CK;
+                int pos;
+                if (mvalid && src_pos<BWD>(p, l, tap, pos))
+                    v = *reinterpret_cast<const float4*>(p.a + (arow0 + pos) * p.lda + c);
+            }
+            ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float b = 0.f;
+                if (kval && cvalid) {
+                    const int cc = c + j;
+                    b = BWD ? p.w[((long long)cc * p.Cin + col) * p.ks + tap]
+                            : p.w[((long long)col * p.Cin + cc) * p.ks + tap];
+                }
+                rb[j] = b;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = kk0 + j;
+                float a = 0.f, b = 0.f;
+                if (kk < p.K) {
+                    const int tap = kk / p.CK;
+                    const int c = kk - tap * p.CK;
+                    int pos;
+                    if (mvalid && src_pos<BWD>(p, l, tap, pos)) a = p.a[(arow0 + pos) * p.lda + c];
+                    if (cvalid)
+                        b = BWD ? p.w[((long long)c * p.Cin + col) * p.ks + tap]
+                                : p.w[((long long)col * p.Cin + c) * p.ks + tap];
+                }
+                ra[j] = a;
+                rb[j] = b;
+            }
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    // wave-uniform tile liveness: skip MFMAs of 16-wide tiles that lie outside the matrix
+    bool rowlive[2], collive[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        rowlive[t] = (m0 + wm * 32 + t * 16) < p.M;
+        collive[t] = (n0 + wn * 32 + t * 16) < p.NC;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            As[kq * 4 + j][r] = ra[j];
+            Bs[kq * 4 + j][r] = rb[j];
+        }
+        __syncthreads();
+        if (k0 + BK < p.K) fetch(k0 + BK);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kr = s * 4 + (lane >> 4);
+            const int li = lane & 15;
+            const float a0 = As[kr][wm * 32 + li], a1 = As[kr][wm * 32 + 16 + li];
+            const float b0 = Bs[kr][wn * 32 + li], b1 = Bs[kr][wn * 32 + 16 + li];
+            if (rowlive[0] && collive[0]) acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            if (rowlive[0] && collive[1]) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            if (rowlive[1] && collive[0]) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            if (rowlive[1] && collive[1]) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+    SiteKey key{0, 0};
+    const bool drop = (!BWD) && p.drop_p > 0.f;
+    if (drop) key = site_key(p.rng, p.site);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int c = n0 + wn * 32 + tj * 16 + (lane & 15);
+            if (c >= p.NC) continue;
+            const float bias = (!BWD && p.bias) ? p.bias[c] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = m0 + wm * 32 + ti * 16 + (lane >> 4) * 4 + q;
+                if (row >= p.M) continue;
+                float v = acc[ti][tj][q];
+                float* dst = p.out + (long long)row * p.ldo + c;
+                if (!BWD) {
+                    v = apply_act(v + bias, p.act, p.slope);
+                    if (drop) v *= keep_scale(key, (unsigned long long)row * p.NC + c, p.drop_p, p.inv_keep);
+                    *dst = v;
+                } else {
+                    *dst = p.accumulate ? (*dst + v) : v;
+                }
+            }
+        }
+}
+
+// ---- weight gradient: dw[co, ci, tap] += sum_m gy[m, co] * xwin[m, (tap, ci)] -----------------------
+struct WgradP {
+    const float* gy;
+    const float* x;
+    float* dw;
+    int Mtot, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg;
+    int chunk;   // rows per z-slice, multiple of BK
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_k(WgradP p) {
+    __shared__ float As[BK][PITCH];   // [m][co]
+    __shared__ float Bs[BK][PITCH];   // [m][j = tap*Cin+ci]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    const int mbeg = blockIdx.z * p.chunk;
+    const int mend = min(p.Mtot, mbeg + p.chunk);
+    const int cidx = tid & 63, mq = tid >> 6;
+    const int NCW = p.ks * p.Cin;
+
+    const int co = co0 + cidx;
+    const bool covalid = co < p.Cout;
+    const int jcol = j0 + cidx;
+    const bool jvalid = jcol < NCW;
+    int tap = 0, ci = 0;
+    if (jvalid) {
+        tap = jcol / p.Cin;
+        ci = jcol - tap * p.Cin;
+    }
+    const int tapoff = tap * p.dil - p.pad;
+
+    float ra[4], rb[4];
+    auto fetch = [&](int mb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mm = mb + mq * 4 + j;
+            float a = 0.f, b = 0.f;
+            if (mm < mend) {
+                if (covalid) a = p.gy[(long long)mm * p.ldg + co];
+                if (jvalid) {
+                    const int nclip = mm / p.Lout;
+                    const int l = mm - nclip * p.Lout;
+                    const int pos = l * p.stride + tapoff;
+                    if (pos >= 0 && pos < p.Lin) b = p.x[((long long)nclip * p.Lin + pos) * p.ldx + ci];
+                }
+            }
+            ra[j] = a;
+            rb[j] = b;
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    bool rowlive[2], collive[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        rowlive[t] = (co0 + wm * 32 + t * 16) < p.Cout;
+        collive[t] = (j0 + wn * 32 + t * 16) < NCW;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (mbeg < mend) fetch(mbeg);
+    for (int mb = mbeg; mb < mend; mb += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            As[mq * 4 + j][cidx] = ra[j];
+            Bs[mq * 4 + j][cidx] = rb[j];
+        }
+        __syncthreads();
+        if (mb + BK < mend) fetch(mb + BK);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kr = s * 4 + (lane >> 4);
+            const int li = lane & 15;
+            const float a0 = As[kr][wm * 32 + li], a1 = As[kr][wm * 32 + 16 + li];
+            const float b0 = Bs[kr][wn * 32 + li], b1 = Bs[kr][wn * 32 + 16 + li];
+            if (rowlive[0] && collive[0]) acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            if (rowlive[0] && collive[1]) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            if (rowlive[1] && collive[0]) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            if (rowlive[1] && collive[1]) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int jc = j0 + wn * 32 + tj * 16 + (lane & 15);
+            if (jc >= NCW) continue;
+            const int t2 = jc / p.Cin, c2 = jc - t2 * p.Cin;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = co0 + wm * 32 + ti * 16 + (lane >> 4) * 4 + q;
+                if (row >= p.Cout) continue;
+                atomicAdd(p.dw + ((long long)row * p.Cin + c2) * p.ks + t2, acc[ti][tj][q]);
+            }
+        }
+}
+
+// ---- column sums (bias gradients, BatchNorm batch statistics) ---------------------------------------
+__global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ x, int rows, int cols, int ld,
+                                                int rows_per_block, float* out, float* sq) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    const int rbeg = blockIdx.y * rows_per_block;
+    const int rend = min(rows, rbeg + rows_per_block);
+    float a = 0.f, b = 0.f;
+    if (c < cols)
+        for (int r = rbeg + ry; r < rend; r += 4) {
+            const float v = x[(long long)r * ld + c];
+            a += v;
+            b += v * v;
+        }
+    s1[ry][threadIdx.x & 63] = a;
+    s2[ry][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        const int i = threadIdx.x;
+        atomicAdd(out + c, s1[0][i] + s1[1][i] + s1[2][i] + s1[3][i]);
+        if (sq) atomicAdd(sq + c, s2[0][i] + s2[1][i] + s2[2][i] + s2[3][i]);
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool bad_geom(const s2ag_conv_geom* g) {
+    return !g || g->N <= 0 || g->Lin <= 0 || g->Lout <= 0 || g->Cin <= 0 || g->Cout <= 0 || g->ksize <= 0 ||
+           g->stride <= 0 || g->dil <= 0 || g->ldx < g->Cin || g->ldy < g->Cout;
+}
+}  // namespace
+
+extern "C" int s2ag_abi_version(void) { return S2AG_ABI_VERSION; }
+
+extern "C" int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* bias, float* y,
+                                   const s2ag_conv_geom* g, const s2ag_epilogue* e, void* stream) {
+    if (bad_geom(g) || !x || !w || !y) return S2AG_E_BADARG;
+    if (e && e->drop_p > 0.f && !e->rng) return S2AG_E_BADARG;
+    if (e && (e->drop_p < 0.f || e->drop_p >= 1.f)) return S2AG_E_BADARG;
+    GemmP p{};
+    p.a = x; p.w = w; p.bias = bias; p.out = y;
+    p.M = g->N * g->Lout; p.K = g->ksize * g->Cin; p.NC = g->Cout;
+    p.Lr = g->Lout; p.Lsrc = g->Lin; p.CK = g->Cin; p.Cin = g->Cin;
+    p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
+    p.lda = g->ldx; p.ldo = g->ldy;
+    p.act = e ? e->act : S2AG_ACT_NONE;
+    p.slope = e ? e->slope : 1.f;
+    p.drop_p = e ? e->drop_p : 0.f;
+    p.inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+    p.rng = e ? e->rng : nullptr;
+    p.site = e ? e->site : 0;
+    p.accumulate = 0;
+    dim3 grid(cdiv(p.M, BM), cdiv(p.NC, BN));
+    const bool vec = (g->Cin % 4 == 0) && (g->ldx % 4 == 0) && aligned16(x);
+    if (vec)
+        hipLaunchKernelGGL((conv_gemm_k<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((conv_gemm_k<false, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* dx, const s2ag_conv_geom* g,
+                                        int accumulate, void* stream) {
+    if (bad_geom(g) || !gy || !w || !dx) return S2AG_E_BADARG;
+    GemmP p{};
+    p.a = gy; p.w = w; p.bias = nullptr; p.out = dx;
+    p.M = g->N * g->Lin; p.K = g->ksize * g->Cout; p.NC = g->Cin;
+    p.Lr = g->Lin; p.Lsrc = g->Lout; p.CK = g->Cout; p.Cin = g->Cin;
+    p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
+    p.lda = g->ldy; p.ldo = g->ldx;
+    p.act = S2AG_ACT_NONE; p.slope = 1.f; p.drop_p = 0.f; p.inv_keep = 1.f; p.rng = nullptr; p.site = 0;
+    p.accumulate = accumulate;
+    dim3 grid(cdiv(p.M, BM), cdiv(p.NC, BN));
+    const bool vec = (g->Cout % 4 == 0) && (g->ldy % 4 == 0) && aligned16(gy);
+    if (vec)
+        hipLaunchKernelGGL((conv_gemm_k<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((conv_gemm_k<true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw, const s2ag_conv_geom* g,
+                                          int accumulate, void* stream) {
+    if (bad_geom(g) || !gy || !x || !dw) return S2AG_E_BADARG;
+    WgradP p{};
+    p.gy = gy; p.x = x; p.dw = dw;
+    p.Mtot = g->N * g->Lout; p.Lin = g->Lin; p.Lout = g->Lout; p.Cin = g->Cin; p.Cout = g->Cout;
+    p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil; p.ldx = g->ldx; p.ldg = g->ldy;
+    const int tiles = cdiv(g->Cout, BM) * cdiv(g->ksize * g->Cin, BN);
+    int nsplit = cdiv(1024, tiles);
+    const int max_split = cdiv(p.Mtot, 4 * BK);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    p.chunk = cdiv(cdiv(p.Mtot, nsplit), BK) * BK;
+    nsplit = cdiv(p.Mtot, p.chunk);
+    if (!accumulate) {
+        hipError_t me = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)g->Cout * g->Cin * g->ksize, (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+    }
+    dim3 grid(cdiv(g->Cout, BM), cdiv(g->ksize * g->Cin, BN), nsplit);
+    hipLaunchKernelGGL(conv_wgrad_k, grid, dim3(256), 0, (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_colsum(const float* x, int rows, int cols, int ld, float* out, float* sq, int accumulate,
+                           void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0 || ld < cols) return S2AG_E_BADARG;
+    if (!accumulate) {
+        hipError_t me = hipMemsetAsync(out, 0, sizeof(float) * cols, (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+        if (sq) {
+            me = hipMemsetAsync(sq, 0, sizeof(float) * cols, (hipStream_t)stream);
+            if (me != hipSuccess) return (int)me;
+        }
+    }
+    int rpb = 256;
+    const int colblocks = cdiv(cols, 64);
+    // aim for >= ~1024 blocks on long matrices, but at least 64 rows each
+    while (rpb > 64 && (long long)cdiv(rows, rpb) * colblocks < 1024) rpb >>= 1;
+    dim3 grid(colblocks, cdiv(rows, rpb));
+    hipLaunchKernelGGL(colsum_k, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, rpb, out, sq);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}

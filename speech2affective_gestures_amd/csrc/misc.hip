@@ -1,0 +1,450 @@
+// Embedding gather/scatter, weight-norm, CSR fold, transpose, re-parametrisation, fused GAN losses,
+// flat-arena Adam and the noise materialisers.
+#include "s2ag_common.h"
+
+namespace {
+using namespace s2ag;
+
+inline int ew_grid(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---- embedding -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embedding_fwd_k(const long long* ids, const float* __restrict__ table, int rows,
+                                                       int dim, int n_entries, float* __restrict__ out, int ldo,
+                                                       float drop_p, float inv_keep, const unsigned long long* rng,
+                                                       unsigned site) {
+    const long long total = (long long)rows * dim;
+    SiteKey key{0, 0};
+    if (drop_p > 0.f) key = site_key(rng, site);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / dim), c = (int)(i - (long long)r * dim);
+        long long id = ids[r];
+        id = id < 0 ? 0 : (id >= n_entries ? n_entries - 1 : id);
+        float v = table[id * dim + c];
+        if (drop_p > 0.f) v *= keep_scale(key, (unsigned long long)i, drop_p, inv_keep);
+        out[(long long)r * ldo + c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void embedding_bwd_k(const long long* ids, const float* __restrict__ g, int ldg,
+                                                       int rows, int dim, int n_entries, float* dtable, float drop_p,
+                                                       float inv_keep, const unsigned long long* rng, unsigned site) {
+    const long long total = (long long)rows * dim;
+    SiteKey key{0, 0};
+    if (drop_p > 0.f) key = site_key(rng, site);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / dim), c = (int)(i - (long long)r * dim);
+        long long id = ids[r];
+        id = id < 0 ? 0 : (id >= n_entries ? n_entries - 1 : id);
+        float v = g[(long long)r * ldg + c];
+        if (drop_p > 0.f) v *= keep_scale(key, (unsigned long long)i, drop_p, inv_keep);
+        atomicAdd(dtable + id * dim + c, v);
+    }
+}
+
+// ---- weight norm: one wave per output row ------------------------------------------------------------
+__global__ __launch_bounds__(256) void weight_norm_fwd_k(const float* __restrict__ v, const float* __restrict__ g,
+                                                         int rows, int cols, float* __restrict__ w, float* norm) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* vr = v + (long long)row * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += vr[c] * vr[c];
+    s = wave_sum(s);
+    const float nrm = sqrtf(s);
+    const float f = g[row] / nrm;
+    for (int c = lane; c < cols; c += 64) w[(long long)row * cols + c] = vr[c] * f;
+    if (lane == 0) norm[row] = nrm;
+}
+
+__global__ __launch_bounds__(256) void weight_norm_bwd_k(const float* __restrict__ dw, const float* __restrict__ v,
+                                                         const float* __restrict__ g, const float* __restrict__ norm,
+                                                         int rows, int cols, float* __restrict__ dv, float* dg) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* vr = v + (long long)row * cols;
+    const float* dr = dw + (long long)row * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += dr[c] * vr[c];
+    s = wave_sum(s);
+    const float nrm = norm[row], gg = g[row];
+    const float dgv = s / nrm;
+    const float a = gg / nrm, b = gg * s / (nrm * nrm * nrm);
+    for (int c = lane; c < cols; c += 64) dv[(long long)row * cols + c] = a * dr[c] - b * vr[c];
+    if (lane == 0) dg[row] = dgv;
+}
+
+// ---- CSR sparse linear map -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spmv_k(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                              const float* __restrict__ val, const float* __restrict__ x, float* y,
+                                              int nrows, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows) return;
+    float s = 0.f;
+    for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) s += val[j] * x[col[j]];
+    y[i] = accumulate ? y[i] + s : s;
+}
+
+__global__ void transpose_k(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? src[(long long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (r < rows && c < cols) dst[(long long)c * rows + r] = tile[tx][j];
+    }
+}
+
+// ---- re-parametrisation ----------------------------------------------------------------------------------
+__global__ void reparam_fwd_k(const float* mu, const float* lv, int n, const unsigned long long* rng, unsigned site,
+                              float* z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SiteKey key = site_key(rng, site);
+    z[i] = mu[i] + normal_dev(key, i) * expf(0.5f * lv[i]);
+}
+
+__global__ void reparam_bwd_k(const float* dz, const float* lv, int n, const unsigned long long* rng, unsigned site,
+                              float* dmu, float* dlv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SiteKey key = site_key(rng, site);
+    const float d = dz[i];
+    dmu[i] += d;
+    dlv[i] += d * normal_dev(key, i) * 0.5f * expf(0.5f * lv[i]);
+}
+
+// ---- losses ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += sm[i];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void dis_loss_k(const float* dr, const float* df, int B, float* loss, float* gr,
+                                                  float* gf) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    const float invB = 1.f / (float)B;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float a = dr[i] + 1e-8f, b = 1.f - df[i] + 1e-8f;
+        s += logf(a) + logf(b);
+        gr[i] = -invB / a;
+        gf[i] = invB / b;
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) loss[0] = -s * invB;
+}
+
+__device__ __forceinline__ float smooth_l1(float d) {
+    const float a = fabsf(d);
+    return a < 1.f ? 0.5f * d * d : a - 0.5f;
+}
+
+// one block per sample: partial sums into scratch[b*8 + {huber, pose_l1, z_l1, div, kld, gen, l1, l1tri}]
+__global__ __launch_bounds__(256) void gen_loss_partial_k(const float* out, const float* target, const float* out_tri,
+                                                          const float* dis_out, const float* out_rand, const float* z,
+                                                          const float* z_rand, const float* mu, const float* lv,
+                                                          int TP, int ZD, float* scratch) {
+    __shared__ float sm[4];
+    const int b = blockIdx.x;
+    const float* o = out + (long long)b * TP;
+    const float* t = target + (long long)b * TP;
+    const float* rr = out_rand + (long long)b * TP;
+    const float* tri = out_tri ? out_tri + (long long)b * TP : nullptr;
+    float hub = 0.f, pl1 = 0.f, l1 = 0.f, l1t = 0.f;
+    for (int i = threadIdx.x; i < TP; i += blockDim.x) {
+        const float ov = o[i], tv = t[i];
+        hub += smooth_l1((ov - tv) * 10.f);
+        pl1 += smooth_l1((ov - rr[i]) * 20.f) * 0.05f;
+        l1 += fabsf(ov - tv);
+        if (tri) l1t += fabsf(tri[i] - tv);
+    }
+    float zl = 0.f, kl = 0.f;
+    for (int i = threadIdx.x; i < ZD; i += blockDim.x) {
+        zl += fabsf(z[b * ZD + i] - z_rand[b * ZD + i]);
+        const float m = mu[b * ZD + i], l = lv[b * ZD + i];
+        kl += 1.f + l - m * m - expf(l);
+    }
+    hub = block_sum(hub, sm);
+    pl1 = block_sum(pl1, sm);
+    l1 = block_sum(l1, sm);
+    l1t = block_sum(l1t, sm);
+    zl = block_sum(zl, sm);
+    kl = block_sum(kl, sm);
+    if (threadIdx.x == 0) {
+        float* s = scratch + (long long)b * 8;
+        const float zmean = zl / (float)ZD;
+        float div = -(pl1 / (zmean + 1.0e-5f));
+        s[0] = hub;
+        s[1] = pl1;
+        s[2] = zmean;
+        s[3] = div;
+        s[4] = kl;
+        s[5] = logf(dis_out[b] + 1e-8f);
+        s[6] = l1;
+        s[7] = l1t;
+    }
+}
+
+__global__ __launch_bounds__(256) void gen_loss_final_k(const float* scratch, int B, int TP, int ZD, float w_reg,
+                                                        float w_gan, float w_div, float w_kld, float* comps) {
+    __shared__ float sm[4];
+    float hub = 0.f, div = 0.f, kl = 0.f, gen = 0.f, l1 = 0.f, l1t = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* s = scratch + (long long)b * 8;
+        hub += s[0];
+        div += fmaxf(s[3], -1000.f);
+        kl += s[4];
+        gen += s[5];
+        l1 += s[6];
+        l1t += s[7];
+    }
+    hub = block_sum(hub, sm);
+    div = block_sum(div, sm);
+    kl = block_sum(kl, sm);
+    gen = block_sum(gen, sm);
+    l1 = block_sum(l1, sm);
+    l1t = block_sum(l1t, sm);
+    if (threadIdx.x == 0) {
+        const float n = (float)B * (float)TP;
+        const float huber = 0.1f * hub / n;
+        const float gen_error = -gen / (float)B;
+        const float div_reg = div / (float)B;
+        const float kld = -0.5f * kl / ((float)B * (float)ZD);
+        comps[0] = w_reg * huber + w_kld * kld + w_div * div_reg + w_gan * gen_error;
+        comps[1] = huber;
+        comps[2] = gen_error;
+        comps[3] = div_reg;
+        comps[4] = kld;
+        comps[5] = l1 / n;
+        comps[6] = l1t / n;
+        comps[7] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void gen_loss_grad_k(const float* out, const float* target, const float* dis_out,
+                                                       const float* out_rand, const float* mu, const float* lv,
+                                                       const float* scratch, int B, int TP, int ZD, float w_reg,
+                                                       float w_gan, float w_div, float w_kld, float* g_out,
+                                                       float* g_dis, float* g_mu, float* g_lv) {
+    const int b = blockIdx.x;
+    const float* s = scratch + (long long)b * 8;
+    const float n = (float)B * (float)TP;
+    // d div_b / d out = -(1/(zmean+1e-5)) * clamp((out-rand)/0.05, -1, 1), unless clamped at -1000
+    const float dcoef = (s[3] >= -1000.f) ? -(w_div / (float)B) / (s[2] + 1.0e-5f) : 0.f;
+    for (int i = threadIdx.x; i < TP; i += blockDim.x) {
+        const long long k = (long long)b * TP + i;
+        const float ov = out[k];
+        const float h = fminf(fmaxf((ov - target[k]) * 10.f, -1.f), 1.f);
+        const float d = fminf(fmaxf((ov - out_rand[k]) * 20.f, -1.f), 1.f);
+        g_out[k] = w_reg * h / n + dcoef * d;
+    }
+    for (int i = threadIdx.x; i < ZD; i += blockDim.x) {
+        const float m = mu[b * ZD + i], l = lv[b * ZD + i];
+        const float c = w_kld * (-0.5f) / ((float)B * (float)ZD);
+        g_mu[b * ZD + i] = c * (-2.f * m);
+        g_lv[b * ZD + i] = c * (1.f - expf(l));
+    }
+    if (threadIdx.x == 0) g_dis[b] = -w_gan / ((float)B * (dis_out[b] + 1e-8f));
+}
+
+// ---- Adam over a flat arena ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                                              float b1, float b2, float eps, const int* step, float gscale) {
+    const float t = (float)(*step);
+    const float bc1 = 1.f - powf(b1, t);
+    const float bc2s = sqrtf(1.f - powf(b2, t));
+    const float step_size = lr / bc1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float gv = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gv;
+        const float vi = b2 * v[i] + (1.f - b2) * gv * gv;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+
+__global__ void counter_inc_k(int* counter, unsigned long long* rng) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (counter) *counter += 1;
+        if (rng) rng[1] += 1ULL;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_k(const unsigned long long* rng, unsigned site, float p,
+                                                      float inv_keep, long long n, float* mask) {
+    const SiteKey key = site_key(rng, site);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        mask[i] = keep_scale(key, (unsigned long long)i, p, inv_keep);
+}
+
+__global__ __launch_bounds__(256) void normal_noise_k(const unsigned long long* rng, unsigned site, long long n,
+                                                      float* eps) {
+    const SiteKey key = site_key(rng, site);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        eps[i] = normal_dev(key, (unsigned long long)i);
+}
+}  // namespace
+
+extern "C" int s2ag_embedding_fwd(const long long* ids, const float* table, int rows, int dim, int n_entries,
+                                  float* out, int ldo, const s2ag_epilogue* e, void* stream) {
+    if (!ids || !table || !out || rows <= 0 || dim <= 0 || n_entries <= 0 || ldo < dim) return S2AG_E_BADARG;
+    const float p = e ? e->drop_p : 0.f;
+    if (p > 0.f && !e->rng) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(embedding_fwd_k, dim3(ew_grid((long long)rows * dim)), dim3(256), 0, (hipStream_t)stream, ids,
+                       table, rows, dim, n_entries, out, ldo, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
+                       e ? e->rng : nullptr, e ? e->site : 0u);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_embedding_bwd(const long long* ids, const float* g, int ldg, int rows, int dim, int n_entries,
+                                  float* dtable, int accumulate, const s2ag_epilogue* e, void* stream) {
+    if (!ids || !g || !dtable || rows <= 0 || dim <= 0 || n_entries <= 0 || ldg < dim) return S2AG_E_BADARG;
+    const float p = e ? e->drop_p : 0.f;
+    if (p > 0.f && !e->rng) return S2AG_E_BADARG;
+    if (!accumulate) {
+        hipError_t me = hipMemsetAsync(dtable, 0, sizeof(float) * (size_t)n_entries * dim, (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+    }
+    hipLaunchKernelGGL(embedding_bwd_k, dim3(ew_grid((long long)rows * dim)), dim3(256), 0, (hipStream_t)stream, ids,
+                       g, ldg, rows, dim, n_entries, dtable, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
+                       e ? e->rng : nullptr, e ? e->site : 0u);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_weight_norm_fwd(const float* v, const float* g, int rows, int cols, float* w, float* norm,
+                                    void* stream) {
+    if (!v || !g || !w || !norm || rows <= 0 || cols <= 0) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(weight_norm_fwd_k, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, v, g, rows, cols, w,
+                       norm);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, int rows,
+                                    int cols, float* dv, float* dg, void* stream) {
+    if (!dw || !v || !g || !norm || !dv || !dg || rows <= 0 || cols <= 0) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(weight_norm_bwd_k, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dw, v, g, norm, rows,
+                       cols, dv, dg);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_spmv(const int* rowptr, const int* col, const float* val, const float* x, float* y, int nrows,
+                         int accumulate, void* stream) {
+    if (!rowptr || !col || !val || !x || !y || nrows <= 0) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(spmv_k, dim3(cdiv(nrows, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, val, x, y,
+                       nrows, accumulate);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_transpose(const float* src, int rows, int cols, float* dst, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(transpose_k, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, src, rows,
+                       cols, dst);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_reparam_fwd(const float* mu, const float* log_var, int n, const unsigned long long* rng,
+                                unsigned site, float* z, void* stream) {
+    if (!mu || !log_var || !rng || !z || n <= 0) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(reparam_fwd_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, mu, log_var, n, rng, site,
+                       z);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_reparam_bwd(const float* dz, const float* log_var, int n, const unsigned long long* rng,
+                                unsigned site, float* dmu, float* dlog_var, void* stream) {
+    if (!dz || !log_var || !rng || !dmu || !dlog_var || n <= 0) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(reparam_bwd_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dz, log_var, n, rng, site,
+                       dmu, dlog_var);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_dis_loss(const float* d_real, const float* d_fake, int B, float* loss, float* g_real,
+                             float* g_fake, void* stream) {
+    if (!d_real || !d_fake || !loss || !g_real || !g_fake || B <= 0) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(dis_loss_k, dim3(1), dim3(256), 0, (hipStream_t)stream, d_real, d_fake, B, loss, g_real, g_fake);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_gen_loss(const float* out, const float* target, const float* out_tri, const float* dis_out,
+                             const float* out_rand, const float* z, const float* z_rand, const float* mu,
+                             const float* log_var, int B, int TP, int ZD, const float* weights, float* scratch,
+                             float* comps, float* g_out, float* g_dis, float* g_mu, float* g_logvar, void* stream) {
+    if (!out || !target || !dis_out || !out_rand || !z || !z_rand || !mu || !log_var || !weights || !scratch ||
+        !comps || !g_out || !g_dis || !g_mu || !g_logvar || B <= 0 || TP <= 0 || ZD <= 0)
+        return S2AG_E_BADARG;
+    const float w_reg = weights[0], w_gan = weights[1], w_div = weights[2], w_kld = weights[3];
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gen_loss_partial_k, dim3(B), dim3(256), 0, s, out, target, out_tri, dis_out, out_rand, z, z_rand,
+                       mu, log_var, TP, ZD, scratch);
+    hipLaunchKernelGGL(gen_loss_final_k, dim3(1), dim3(256), 0, s, scratch, B, TP, ZD, w_reg, w_gan, w_div, w_kld,
+                       comps);
+    hipLaunchKernelGGL(gen_loss_grad_k, dim3(B), dim3(256), 0, s, out, target, dis_out, out_rand, mu, log_var, scratch,
+                       B, TP, ZD, w_reg, w_gan, w_div, w_kld, g_out, g_dis, g_mu, g_logvar);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                              float beta2, float eps, const int* step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || !step || n <= 0) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(adam_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                       eps, step, grad_scale);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_counter_inc(int* counter, unsigned long long* rng, void* stream) {
+    hipLaunchKernelGGL(counter_inc_k, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, rng);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_dropout_mask(const unsigned long long* rng, unsigned site, float p, long long n, float* mask,
+                                 void* stream) {
+    if (!rng || !mask || n <= 0 || p < 0.f || p >= 1.f) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(dropout_mask_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, rng, site, p,
+                       1.f / (1.f - p), n, mask);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_normal_noise(const unsigned long long* rng, unsigned site, long long n, float* eps, void* stream) {
+    if (!rng || !eps || n <= 0) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(normal_noise_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, rng, site, n, eps);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}

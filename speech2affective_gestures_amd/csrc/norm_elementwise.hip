@@ -1,0 +1,286 @@
+// BatchNorm (training + eval), residual/activation glue and their backward passes on channels-last
+// fp32 matrices.  All of these are HBM/latency-bound streaming kernels: consecutive lanes walk
+// consecutive columns of a row (coalesced), grid-stride over rows.
+#include "s2ag_common.h"
+
+namespace {
+using namespace s2ag;
+
+// One block.  Folds per-COLUMN sums into per-CHANNEL statistics through chan_of_col (LDS atomics),
+// updates the running estimates, then scatters the per-channel coefficients back to columns.
+__global__ __launch_bounds__(256) void bn_coeffs_k(const float* colsum, const float* colsq, const int* chan_of_col,
+                                                   int ncols, int nchan, int rows, const float* gamma,
+                                                   const float* beta, float* rmean, float* rvar, long long* nbt,
+                                                   float eps, float momentum, int training, float* scale_col,
+                                                   float* shift_col, float* mean_col, float* invstd_col) {
+    extern __shared__ float sm[];
+    float* cs = sm;               // nchan
+    float* cq = sm + nchan;       // nchan
+    float* cn = sm + 2 * nchan;   // nchan (columns per channel)
+    for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    if (training) {
+        for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+            const int ch = chan_of_col ? chan_of_col[c] : c;
+            atomicAdd(&cs[ch], colsum[c]);
+            atomicAdd(&cq[ch], colsq[c]);
+            atomicAdd(&cn[ch], 1.0f);
+        }
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < nchan; ch += blockDim.x) {
+            const float n = cn[ch] * (float)rows;
+            const float mean = cs[ch] / n;
+            float var = cq[ch] / n - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            const float unbiased = n > 1.f ? var * n / (n - 1.f) : var;
+            rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * mean;
+            rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * unbiased;
+            cs[ch] = mean;
+            cq[ch] = rsqrtf(var + eps);
+        }
+        if (threadIdx.x == 0 && nbt) *nbt += 1;
+    } else {
+        for (int ch = threadIdx.x; ch < nchan; ch += blockDim.x) {
+            cs[ch] = rmean[ch];
+            cq[ch] = rsqrtf(rvar[ch] + eps);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+        const int ch = chan_of_col ? chan_of_col[c] : c;
+        const float mean = cs[ch], invstd = cq[ch];
+        const float sc = gamma[ch] * invstd;
+        scale_col[c] = sc;
+        shift_col[c] = beta[ch] - mean * sc;
+        mean_col[c] = mean;
+        invstd_col[c] = invstd;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, int rows, int cols, int ldx,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                  float slope, float* __restrict__ y, int ldy) {
+    const long long total = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+        y[(long long)r * ldy + c] = leaky(x[(long long)r * ldx + c] * scale[c] + shift[c], slope);
+    }
+}
+
+// column sums of dpre and dpre * xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       int rows, int cols, int ldx, int lddy, int rows_per_block,
+                                                       const float* scale, const float* shift, const float* mean,
+                                                       const float* invstd, float slope, float* s1, float* s2) {
+    __shared__ float a1[4][64], a2[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    const int rbeg = blockIdx.y * rows_per_block;
+    const int rend = min(rows, rbeg + rows_per_block);
+    float p = 0.f, q = 0.f;
+    if (c < cols) {
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        for (int r = rbeg + ry; r < rend; r += 4) {
+            const float xv = x[(long long)r * ldx + c];
+            const float pre = xv * sc + sh;
+            const float d = dy[(long long)r * lddy + c] * (pre > 0.f ? 1.f : slope);
+            p += d;
+            q += d * (xv - mu) * is;
+        }
+    }
+    a1[ry][threadIdx.x & 63] = p;
+    a2[ry][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        const int i = threadIdx.x;
+        atomicAdd(s1 + c, a1[0][i] + a1[1][i] + a1[2][i] + a1[3][i]);
+        atomicAdd(s2 + c, a2[0][i] + a2[1][i] + a2[2][i] + a2[3][i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_k(const float* s1, const float* s2, const int* chan_of_col,
+                                                       int ncols, int nchan, int rows, float* dgamma, float* dbeta,
+                                                       int accumulate, float* c1, float* c2) {
+    extern __shared__ float sm[];
+    float* t1 = sm;
+    float* t2 = sm + nchan;
+    float* cn = sm + 2 * nchan;
+    for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+        const int ch = chan_of_col ? chan_of_col[c] : c;
+        atomicAdd(&t1[ch], s1[c]);
+        atomicAdd(&t2[ch], s2[c]);
+        atomicAdd(&cn[ch], 1.0f);
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < nchan; ch += blockDim.x) {
+        if (accumulate) {
+            dgamma[ch] += t2[ch];
+            dbeta[ch] += t1[ch];
+        } else {
+            dgamma[ch] = t2[ch];
+            dbeta[ch] = t1[ch];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+        const int ch = chan_of_col ? chan_of_col[c] : c;
+        const float n = cn[ch] * (float)rows;
+        c1[c] = t1[ch] / n;
+        c2[c] = t2[ch] / n;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      int rows, int cols, int ldx, int lddy, const float* scale,
+                                                      const float* shift, const float* mean, const float* invstd,
+                                                      float slope, const float* c1, const float* c2,
+                                                      float* __restrict__ dx, int lddx) {
+    const long long total = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+        const float xv = x[(long long)r * ldx + c];
+        const float pre = xv * scale[c] + shift[c];
+        const float d = dy[(long long)r * lddy + c] * (pre > 0.f ? 1.f : slope);
+        const float xhat = (xv - mean[c]) * invstd[c];
+        dx[(long long)r * lddx + c] = scale[c] * (d - c1[c] - xhat * c2[c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void add_act_k(const float* __restrict__ a, int lda, const float* __restrict__ b,
+                                                 int ldb, float* __restrict__ y, int ldy, int rows, int cols,
+                                                 float slope) {
+    const long long total = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+        float v = a[(long long)r * lda + c];
+        if (b) v += b[(long long)r * ldb + c];
+        y[(long long)r * ldy + c] = leaky(v, slope);
+    }
+}
+
+__global__ __launch_bounds__(256) void epilogue_bwd_k(const float* __restrict__ dy, int lddy,
+                                                      const float* __restrict__ y, int ldy, float* __restrict__ g,
+                                                      int ldg, int rows, int cols, int act, float slope, float drop_p,
+                                                      float inv_keep, const unsigned long long* rng, unsigned site) {
+    const long long total = (long long)rows * cols;
+    SiteKey key{0, 0};
+    if (drop_p > 0.f) key = site_key(rng, site);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+        float d = dy[(long long)r * lddy + c];
+        float ks = 1.f;
+        if (drop_p > 0.f) ks = keep_scale(key, (unsigned long long)i, drop_p, inv_keep);
+        d *= ks;
+        if (act == S2AG_ACT_LEAKY) {
+            if (slope != 1.f) {
+                // y is the post-dropout output: its sign is that of the activation where the unit was kept
+                const float yv = y[(long long)r * ldy + c];
+                d *= (yv > 0.f ? 1.f : slope);
+            }
+        } else if (act == S2AG_ACT_SIGMOID) {
+            const float yv = (ks != 0.f) ? y[(long long)r * ldy + c] / ks : 0.f;
+            d *= yv * (1.f - yv);
+        }
+        g[(long long)r * ldg + c] = d;
+    }
+}
+
+inline int ew_grid(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 4096) b = 4096;   // 16 blocks per CU, grid-stride beyond
+    if (b < 1) b = 1;
+    return (int)b;
+}
+}  // namespace
+
+extern "C" int s2ag_bn_coeffs(const float* colsum, const float* colsq, const int* chan_of_col, int ncols, int nchan,
+                              int rows, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, long long* nbt, float eps, float momentum, int training,
+                              float* scale_col, float* shift_col, float* mean_col, float* invstd_col, void* stream) {
+    if (ncols <= 0 || nchan <= 0 || rows <= 0 || !gamma || !beta || !running_mean || !running_var || !scale_col ||
+        !shift_col || !mean_col || !invstd_col)
+        return S2AG_E_BADARG;
+    if (training && (!colsum || !colsq)) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(bn_coeffs_k, dim3(1), dim3(256), sizeof(float) * 3 * nchan, (hipStream_t)stream, colsum, colsq,
+                       chan_of_col, ncols, nchan, rows, gamma, beta, running_mean, running_var, nbt, eps, momentum,
+                       training, scale_col, shift_col, mean_col, invstd_col);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_bn_apply(const float* x, int rows, int cols, int ldx, const float* scale_col,
+                             const float* shift_col, float slope, float* y, int ldy, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || ldx < cols || ldy < cols) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(bn_apply_k, dim3(ew_grid((long long)rows * cols)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       cols, ldx, scale_col, shift_col, slope, y, ldy);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_bn_bwd_reduce(const float* x, const float* dy, int rows, int cols, int ldx, int lddy,
+                                  const float* scale_col, const float* shift_col, const float* mean_col,
+                                  const float* invstd_col, float slope, float* s1_col, float* s2_col, void* stream) {
+    if (!x || !dy || rows <= 0 || cols <= 0 || !s1_col || !s2_col) return S2AG_E_BADARG;
+    hipError_t me = hipMemsetAsync(s1_col, 0, sizeof(float) * cols, (hipStream_t)stream);
+    if (me != hipSuccess) return (int)me;
+    me = hipMemsetAsync(s2_col, 0, sizeof(float) * cols, (hipStream_t)stream);
+    if (me != hipSuccess) return (int)me;
+    int rpb = 256;
+    const int colblocks = cdiv(cols, 64);
+    while (rpb > 64 && (long long)cdiv(rows, rpb) * colblocks < 1024) rpb >>= 1;
+    hipLaunchKernelGGL(bn_bwd_reduce_k, dim3(colblocks, cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, x, dy,
+                       rows, cols, ldx, lddy, rpb, scale_col, shift_col, mean_col, invstd_col, slope, s1_col, s2_col);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_bn_bwd_coeffs(const float* s1_col, const float* s2_col, const int* chan_of_col, int ncols,
+                                  int nchan, int rows, float* dgamma, float* dbeta, int accumulate, float* c1_col,
+                                  float* c2_col, void* stream) {
+    if (!s1_col || !s2_col || ncols <= 0 || nchan <= 0 || rows <= 0 || !dgamma || !dbeta || !c1_col || !c2_col)
+        return S2AG_E_BADARG;
+    hipLaunchKernelGGL(bn_bwd_coeffs_k, dim3(1), dim3(256), sizeof(float) * 3 * nchan, (hipStream_t)stream, s1_col,
+                       s2_col, chan_of_col, ncols, nchan, rows, dgamma, dbeta, accumulate, c1_col, c2_col);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_bn_bwd_apply(const float* x, const float* dy, int rows, int cols, int ldx, int lddy,
+                                 const float* scale_col, const float* shift_col, const float* mean_col,
+                                 const float* invstd_col, float slope, const float* c1_col, const float* c2_col,
+                                 float* dx, int lddx, void* stream) {
+    if (!x || !dy || !dx || rows <= 0 || cols <= 0) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid((long long)rows * cols)), dim3(256), 0, (hipStream_t)stream, x, dy,
+                       rows, cols, ldx, lddy, scale_col, shift_col, mean_col, invstd_col, slope, c1_col, c2_col, dx,
+                       lddx);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_add_act(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int rows, int cols,
+                            float slope, void* stream) {
+    if (!a || !y || rows <= 0 || cols <= 0 || lda < cols || ldy < cols || (b && ldb < cols)) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(add_act_k, dim3(ew_grid((long long)rows * cols)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
+                       ldb, y, ldy, rows, cols, slope);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_epilogue_bwd(const float* dy, int lddy, const float* y, int ldy, float* g, int ldg, int rows,
+                                 int cols, const s2ag_epilogue* e, void* stream) {
+    if (!dy || !g || !e || rows <= 0 || cols <= 0) return S2AG_E_BADARG;
+    const bool needs_y = (e->act == S2AG_ACT_LEAKY && e->slope != 1.f) || e->act == S2AG_ACT_SIGMOID;
+    if (needs_y && !y) return S2AG_E_BADARG;
+    if (e->drop_p > 0.f && !e->rng) return S2AG_E_BADARG;
+    const float inv_keep = e->drop_p > 0.f ? 1.f / (1.f - e->drop_p) : 1.f;
+    hipLaunchKernelGGL(epilogue_bwd_k, dim3(ew_grid((long long)rows * cols)), dim3(256), 0, (hipStream_t)stream, dy,
+                       lddy, y, ldy, g, ldg, rows, cols, e->act, e->slope, e->drop_p, inv_keep, e->rng, e->site);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,78 @@
+// Shared device helpers for the gfx950 kernels of libs2ag_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "s2ag_hip.h"
+
+#define S2AG_LAUNCH_CHECK()                  \
+    do {                                     \
+        hipError_t e__ = hipGetLastError();  \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+namespace s2ag {
+
+constexpr int WAVE = 64;
+
+__host__ __device__ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- counter-based randomness -----------------------------------------------------------------
+// 32-bit avalanche (two multiply/xorshift rounds).  The stream of a site is keyed by
+// (seed, step counter, site); element i of the site hashes (key, i) twice.  Stateless, so the
+// backward pass regenerates a forward keep-mask instead of storing it.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+struct SiteKey {
+    uint32_t k0, k1;
+};
+
+__device__ __forceinline__ SiteKey site_key(const unsigned long long* rng, unsigned site) {
+    const unsigned long long seed = rng[0], ctr = rng[1];
+    SiteKey k;
+    k.k0 = mix32((uint32_t)seed ^ mix32((uint32_t)(ctr & 0xffffffffULL) + 0x9e3779b9U * (site + 1)));
+    k.k1 = mix32((uint32_t)(seed >> 32) ^ mix32((uint32_t)(ctr >> 32) + 0x85ebca6bU * (site + 0x632be5abU)));
+    return k;
+}
+
+__device__ __forceinline__ uint32_t rand_u32(SiteKey k, unsigned long long idx) {
+    uint32_t x = mix32((uint32_t)idx * 0x9e3779b1U + k.k0);
+    x = mix32(x ^ k.k1 ^ (uint32_t)(idx >> 32) * 0xc2b2ae35U);
+    return x;
+}
+
+// keep mask already scaled by 1/(1-p)
+__device__ __forceinline__ float keep_scale(SiteKey k, unsigned long long idx, float p, float inv_keep) {
+    const float u = (float)(rand_u32(k, idx) >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.0f;
+}
+
+__device__ __forceinline__ float normal_dev(SiteKey k, unsigned long long idx) {
+    const uint32_t a = rand_u32(k, 2 * idx), b = rand_u32(k, 2 * idx + 1);
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);            // [0,1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+__device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+__device__ __forceinline__ float apply_act(float x, int act, float slope) {
+    if (act == S2AG_ACT_LEAKY) return leaky(x, slope);
+    if (act == S2AG_ACT_SIGMOID) return 1.0f / (1.0f + expf(-x));
+    return x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace s2ag

@@ -1,0 +1,86 @@
+"""Temporal convolutional network.  Mirrors ``net.tcn`` of the reference (net/tcn.py:7-64): Chomp1d,
+TemporalBlock, TemporalConvNet with identical constructors and ``state_dict`` keys (including the
+``net.0`` / ``net.4`` aliases of ``conv1`` / ``conv2`` and the weight_g / weight_v split of weight_norm).
+
+MI355X formulation: activations stay channels-last (B, T, C); the causal dilated conv + chomp is ONE
+implicit GEMM whose two taps read frames t-d and t (left padding only, output length T), with bias,
+ReLU and the counter-based dropout fused in the epilogue.  The torch modules below are parameter
+containers; their own ``forward`` is never used.
+"""
+import torch
+import torch.nn as nn
+from torch.nn.utils import weight_norm
+
+from .. import ops
+from .._lib import ACT_LEAKY
+from ..noise import new_site, noise_pass
+
+
+class Chomp1d(nn.Module):
+    def __init__(self, chomp_size):
+        super().__init__()
+        self.chomp_size = chomp_size
+
+    def forward(self, x):
+        return x[:, :, :-self.chomp_size].contiguous()
+
+
+class TemporalBlock(nn.Module):
+    def __init__(self, n_inputs, n_outputs, kernel_size, stride, dilation, padding, dropout=0.2):
+        super().__init__()
+        if stride != 1 or padding != (kernel_size - 1) * dilation:
+            raise NotImplementedError('causal TCN block: stride 1, padding (k-1)*dilation (net/tcn.py:57-59)')
+        self.dilation, self.kernel_size, self.p = dilation, kernel_size, dropout
+        self.conv1 = weight_norm(nn.Conv1d(n_inputs, n_outputs, kernel_size, stride=stride, padding=padding,
+                                           dilation=dilation))
+        self.chomp1 = Chomp1d(padding)
+        self.relu1 = nn.ReLU()
+        self.dropout1 = nn.Dropout(dropout)
+        self.conv2 = weight_norm(nn.Conv1d(n_outputs, n_outputs, kernel_size, stride=stride, padding=padding,
+                                           dilation=dilation))
+        self.chomp2 = Chomp1d(padding)
+        self.relu2 = nn.ReLU()
+        self.dropout2 = nn.Dropout(dropout)
+        self.net = nn.Sequential(self.conv1, self.chomp1, self.relu1, self.dropout1,
+                                 self.conv2, self.chomp2, self.relu2, self.dropout2)
+        self.downsample = nn.Conv1d(n_inputs, n_outputs, 1) if n_inputs != n_outputs else None
+        self.relu = nn.ReLU()
+        self.sites = (new_site(), new_site())
+
+    def forward_nlc(self, x, noise):
+        """x (B, T, C) channels-last."""
+        out = x
+        pad = (self.kernel_size - 1) * self.dilation
+        for conv, site in ((self.conv1, self.sites[0]), (self.conv2, self.sites[1])):
+            w = ops.weight_norm(conv.weight_v, conv.weight_g)
+            p = self.p if self.training else 0.0
+            out = ops.conv1d_nlc(out, w, conv.bias, pad=pad, dil=self.dilation, lout=x.shape[1], act=ACT_LEAKY,
+                                 slope=0.0, drop_p=p, noise=noise, site=site)
+        res = x if self.downsample is None else ops.conv1d_nlc(x, self.downsample.weight, self.downsample.bias)
+        return ops.add_act(out, res, 0.0)
+
+    def forward(self, x):
+        """reference layout (B, C, T)"""
+        with noise_pass(x.device) as nz:
+            return self.forward_nlc(x.transpose(1, 2).contiguous(), nz).transpose(1, 2).contiguous()
+
+
+class TemporalConvNet(nn.Module):
+    def __init__(self, num_inputs, num_channels, kernel_size=2, dropout=0.2):
+        super().__init__()
+        layers = []
+        for i, out_channels in enumerate(num_channels):
+            d = 2 ** i
+            in_channels = num_inputs if i == 0 else num_channels[i - 1]
+            layers.append(TemporalBlock(in_channels, out_channels, kernel_size, stride=1, dilation=d,
+                                        padding=(kernel_size - 1) * d, dropout=dropout))
+        self.network = nn.Sequential(*layers)
+
+    def forward_nlc(self, x, noise):
+        for blk in self.network:
+            x = blk.forward_nlc(x, noise)
+        return x
+
+    def forward(self, x):
+        with noise_pass(x.device) as nz:
+            return self.forward_nlc(x.transpose(1, 2).contiguous(), nz).transpose(1, 2).contiguous()

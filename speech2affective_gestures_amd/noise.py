@@ -1,0 +1,66 @@
+"""Device-resident random state.
+
+``rng`` is a 2-word device array {seed, pass counter} (see include/s2ag_hip.h).  Every top-level forward
+pass takes a *snapshot* of it (a 16-byte device copy) and bumps the counter with a one-thread kernel, so
+  * consecutive passes (the three generator forwards of one GAN step) see different noise,
+  * the backward pass of a forward regenerates exactly that forward's masks from its snapshot,
+  * a captured hipGraph keeps advancing the noise on every replay (the counter lives on the device).
+Random *sites* (one per dropout / noise call site) are small integers handed out at module construction.
+"""
+import ctypes as C
+import threading
+from contextlib import contextmanager
+
+import torch
+
+from . import _lib as L
+
+_state = {}
+_site_counter = [0]
+_tls = threading.local()
+
+
+def new_site(n: int = 1) -> int:
+    s = _site_counter[0]
+    _site_counter[0] += n
+    return s
+
+
+def _dev_state(device) -> torch.Tensor:
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise RuntimeError('S2AG noise state lives on the GPU; no CPU fallback')
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _state:
+        _state[idx] = torch.tensor([0x5EED5EED, 0], dtype=torch.int64, device=f'cuda:{idx}')
+    return _state[idx]
+
+
+def manual_seed(seed: int, device='cuda') -> None:
+    st = _dev_state(device)
+    st.copy_(torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
+
+
+def begin_pass(device) -> torch.Tensor:
+    st = _dev_state(device)
+    snap = st.clone()
+    L.check(L.load().s2ag_counter_inc(None, C.c_void_p(st.data_ptr()),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'counter_inc')
+    return snap
+
+
+@contextmanager
+def noise_pass(device):
+    """Scope of one forward pass: nested module forwards share the outermost pass's snapshot."""
+    stack = getattr(_tls, 'stack', None)
+    if stack is None:
+        stack = _tls.stack = []
+    if stack:
+        yield stack[-1]
+        return
+    snap = begin_pass(device)
+    stack.append(snap)
+    try:
+        yield snap
+    finally:
+        stack.pop()

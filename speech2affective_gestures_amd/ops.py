@@ -1,0 +1,625 @@
+"""Autograd-level operators of the S2AG step, each a thin ``torch.autograd.Function`` whose forward and
+backward call the C ABI of ``libs2ag_hip.so`` (include/s2ag_hip.h) on torch's current HIP stream.
+
+PyTorch is plumbing here: it owns device memory (caching allocator, so everything is hipGraph-capturable),
+streams and the autograd tape.  Every arithmetic operation is one of our gfx950 kernels.  There is no CPU
+path: a non-CUDA tensor raises.
+
+Layout: all activations are fp32 channels-last, i.e. a (clips, frames, channels) tensor is treated as a
+row matrix; column slices of wider matrices are passed by pointer + row pitch, never copied.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+def _lib():
+    return L.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('S2AG ops run on MI355X only (HIP kernels); got a CPU tensor and there is no CPU '
+                               'fallback by design')
+
+
+def as_rows(t: Tensor) -> Tuple[Tensor, int, int, int]:
+    """(tensor, rows, cols, ld): view ``t`` as a row matrix with unit column stride and uniform row pitch.
+    Copies only if the leading dims do not collapse (never for the slices this package creates)."""
+    if t.dtype != torch.float32:
+        raise TypeError(f'expected float32, got {t.dtype}')
+    if t.dim() == 0:
+        t = t.reshape(1, 1)
+    if t.dim() == 1:
+        t = t.unsqueeze(0)
+    cols = t.shape[-1]
+    rows = t.numel() // max(cols, 1)
+    ok = (t.stride(-1) == 1 or cols == 1) and t.numel() > 0
+    ld = cols
+    if ok:
+        ld = t.stride(-2) if t.shape[-2] > 1 else cols
+        exp = ld
+        for d in range(t.dim() - 2, -1, -1):
+            if t.shape[d] > 1 and t.stride(d) != exp:
+                ok = False
+                break
+            exp *= t.shape[d]
+        if ld < cols:
+            ok = False
+    if not ok:
+        t = t.contiguous()
+        ld = cols
+    return t, rows, cols, ld
+
+
+def _epi(act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise: Optional[Tensor] = None, site=0):
+    return L.Epilogue(act, float(slope), float(drop_p), _p(noise) if drop_p > 0 else None, int(site))
+
+
+def _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy):
+    return L.ConvGeom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy)
+
+
+# ----------------------------------------------------------------------------------------------------
+# raw (non-autograd) launch helpers
+# ----------------------------------------------------------------------------------------------------
+def conv_fwd_raw(x: Tensor, w: Tensor, bias: Optional[Tensor], y: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad,
+                 dil, act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0):
+    x, xr, xc, ldx = as_rows(x)
+    _, yr, yc, ldy = as_rows(y)
+    assert xr == N * Lin and xc == Cin, (xr, xc, N, Lin, Cin)
+    assert yr == N * Lout and yc == Cout, (yr, yc, N, Lout, Cout)
+    assert w.is_contiguous() and w.numel() == Cout * Cin * ks
+    g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy)
+    e = _epi(act, slope, drop_p, noise, site)
+    L.check(_lib().s2ag_conv1d_nlc_fwd(_p(x), _p(w), _p(bias), _p(y), C.byref(g), C.byref(e), _stream()), 'conv_fwd')
+
+
+def conv_bwd_data_raw(gy: Tensor, w: Tensor, dx: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, accumulate):
+    gy, gr, gc, ldg = as_rows(gy)
+    _, xr, xc, ldx = as_rows(dx)
+    assert gr == N * Lout and gc == Cout and xr == N * Lin and xc == Cin
+    g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg)
+    L.check(_lib().s2ag_conv1d_nlc_bwd_data(_p(gy), _p(w), _p(dx), C.byref(g), int(accumulate), _stream()),
+            'conv_bwd_data')
+
+
+def conv_bwd_weight_raw(gy: Tensor, x: Tensor, dw: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, accumulate):
+    gy, gr, gc, ldg = as_rows(gy)
+    x, xr, xc, ldx = as_rows(x)
+    assert gr == N * Lout and gc == Cout and xr == N * Lin and xc == Cin, (gr, gc, xr, xc)
+    assert dw.is_contiguous() and dw.numel() == Cout * Cin * ks
+    g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg)
+    L.check(_lib().s2ag_conv1d_nlc_bwd_weight(_p(gy), _p(x), _p(dw), C.byref(g), int(accumulate), _stream()),
+            'conv_bwd_weight')
+
+
+def colsum_raw(x: Tensor, out: Tensor, sq: Optional[Tensor] = None, accumulate=False):
+    x, r, c, ld = as_rows(x)
+    L.check(_lib().s2ag_colsum(_p(x), r, c, ld, _p(out), _p(sq), int(accumulate), _stream()), 'colsum')
+
+
+def add_act_raw(a: Tensor, b: Optional[Tensor], y: Tensor, slope: float):
+    a, r, c, lda = as_rows(a)
+    ldb = 0
+    if b is not None:
+        b, rb, cb, ldb = as_rows(b)
+        assert (rb, cb) == (r, c)
+    _, ry, cy, ldy = as_rows(y)
+    assert (ry, cy) == (r, c)
+    L.check(_lib().s2ag_add_act(_p(a), lda, _p(b), ldb, _p(y), ldy, r, c, float(slope), _stream()), 'add_act')
+
+
+def epilogue_bwd_raw(dy: Tensor, y: Optional[Tensor], g: Tensor, act, slope, drop_p, noise, site):
+    dy, r, c, lddy = as_rows(dy)
+    ldy = 0
+    if y is not None:
+        y, _, _, ldy = as_rows(y)
+    _, _, _, ldg = as_rows(g)
+    e = _epi(act, slope, drop_p, noise, site)
+    L.check(_lib().s2ag_epilogue_bwd(_p(dy), lddy, _p(y), ldy, _p(g), ldg, r, c, C.byref(e), _stream()),
+            'epilogue_bwd')
+
+
+def transpose_raw(src: Tensor, dst: Tensor):
+    assert src.is_contiguous() and dst.is_contiguous() and src.dim() == 2
+    L.check(_lib().s2ag_transpose(_p(src), src.shape[0], src.shape[1], _p(dst), _stream()), 'transpose')
+
+
+# ----------------------------------------------------------------------------------------------------
+# noise materialisers (tests / debugging)
+# ----------------------------------------------------------------------------------------------------
+def dropout_mask(noise: Tensor, site: int, p: float, shape: Sequence[int]) -> Tensor:
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=noise.device)
+    L.check(_lib().s2ag_dropout_mask(_p(noise), int(site), float(p), out.numel(), _p(out), _stream()), 'dropout_mask')
+    return out
+
+
+def normal_noise(noise: Tensor, site: int, shape: Sequence[int]) -> Tensor:
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=noise.device)
+    L.check(_lib().s2ag_normal_noise(_p(noise), int(site), out.numel(), _p(out), _stream()), 'normal_noise')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# conv / linear
+# ----------------------------------------------------------------------------------------------------
+class _ConvNLC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, geom, act, slope, drop_p, noise, site):
+        _need_cuda(x, w, bias)
+        N, Lin, Lout, Cin, Cout, ks, stride, pad, dil = geom
+        x, _, _, _ = as_rows(x)
+        w = w.contiguous()
+        y = torch.empty(N * Lout, Cout, dtype=torch.float32, device=x.device)
+        conv_fwd_raw(x, w, bias, y, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, act, slope, drop_p, noise, site)
+        ctx.geom, ctx.epi = geom, (act, slope, drop_p, site)
+        ctx.noise = noise
+        ctx.has_bias = bias is not None
+        needs_y = (act == L.ACT_LEAKY and slope != 1.0) or act == L.ACT_SIGMOID
+        ctx.save_for_backward(x, w, y if needs_y else None)
+        return y.view(N, Lout, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        N, Lin, Lout, Cin, Cout, ks, stride, pad, dil = ctx.geom
+        act, slope, drop_p, site = ctx.epi
+        dy = dy.reshape(N * Lout, Cout)
+        if (act != L.ACT_NONE and not (act == L.ACT_LEAKY and slope == 1.0)) or drop_p > 0:
+            g = torch.empty(N * Lout, Cout, dtype=torch.float32, device=dy.device)
+            epilogue_bwd_raw(dy, y, g, act, slope, drop_p, ctx.noise, site)
+        else:
+            g, _, _, _ = as_rows(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(N * Lin, Cin, dtype=torch.float32, device=dy.device)
+            conv_bwd_data_raw(g, w, dx, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False)
+            dx = dx.view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            conv_bwd_weight_raw(g, x, dw, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+            colsum_raw(g, db)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def conv1d_nlc(x: Tensor, w: Tensor, bias: Optional[Tensor], stride=1, pad=0, dil=1, lout: Optional[int] = None,
+               act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0) -> Tensor:
+    """x (N, Lin, Cin) channels-last, w (Cout, Cin, k) -> (N, Lout, Cout).  ``lout`` overrides the usual
+    output length (the TCN's causal conv + chomp is pad = (k-1)*dil on the left with lout = Lin)."""
+    N, Lin, Cin = x.shape
+    Cout, Cin_w, ks = w.shape
+    assert Cin_w == Cin, (w.shape, x.shape)
+    if lout is None:
+        lout = (Lin + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+    out = _ConvNLC.apply(x, w, bias, (N, Lin, lout, Cin, Cout, ks, stride, pad, dil), act, float(slope),
+                         float(drop_p), noise, site)
+    return out.view(N, lout, Cout)
+
+
+def linear(x: Tensor, w: Tensor, bias: Optional[Tensor], act=L.ACT_NONE, slope=1.0) -> Tensor:
+    """x (..., in) @ w(out, in)^T + bias -> (..., out) with a fused activation."""
+    shp = x.shape
+    rows = x.numel() // shp[-1]
+    y = _ConvNLC.apply(x, w.view(w.shape[0], w.shape[1], 1), bias, (rows, 1, 1, shp[-1], w.shape[0], 1, 1, 0, 1),
+                       act, float(slope), 0.0, None, 0)
+    return y.view(*shp[:-1], w.shape[0])
+
+
+# ----------------------------------------------------------------------------------------------------
+# batch norm (+ leaky activation)
+# ----------------------------------------------------------------------------------------------------
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, nbt, chan_map, slope, training, eps, momentum):
+        _need_cuda(x, gamma)
+        lib = _lib()
+        x, rows, cols, ldx = as_rows(x)
+        nchan = gamma.numel()
+        dev = x.device
+        coef = torch.empty(4, cols, dtype=torch.float32, device=dev)
+        s = sq = None
+        if training:
+            stats = torch.empty(2, cols, dtype=torch.float32, device=dev)
+            s, sq = stats[0], stats[1]
+            colsum_raw(x, s, sq)
+        L.check(lib.s2ag_bn_coeffs(_p(s), _p(sq), _p(chan_map), cols, nchan, rows, _p(gamma), _p(beta), _p(rmean),
+                                   _p(rvar), _p(nbt), float(eps), float(momentum), int(training), _p(coef[0]),
+                                   _p(coef[1]), _p(coef[2]), _p(coef[3]), _stream()), 'bn_coeffs')
+        y = torch.empty(rows, cols, dtype=torch.float32, device=dev)
+        L.check(lib.s2ag_bn_apply(_p(x), rows, cols, ldx, _p(coef[0]), _p(coef[1]), float(slope), _p(y), cols,
+                                  _stream()), 'bn_apply')
+        ctx.save_for_backward(x, coef, chan_map)
+        ctx.meta = (rows, cols, ldx, nchan, float(slope), bool(training))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, coef, chan_map = ctx.saved_tensors
+        rows, cols, ldx, nchan, slope, training = ctx.meta
+        lib = _lib()
+        dy, _, _, lddy = as_rows(dy.reshape(rows, cols))
+        dev = dy.device
+        dx = torch.empty(rows, cols, dtype=torch.float32, device=dev)
+        dgamma = dbeta = None
+        if training:
+            tmp = torch.empty(4, cols, dtype=torch.float32, device=dev)
+            dgb = torch.empty(2, nchan, dtype=torch.float32, device=dev)
+            L.check(lib.s2ag_bn_bwd_reduce(_p(x), _p(dy), rows, cols, ldx, lddy, _p(coef[0]), _p(coef[1]),
+                                           _p(coef[2]), _p(coef[3]), slope, _p(tmp[0]), _p(tmp[1]), _stream()),
+                    'bn_bwd_reduce')
+            L.check(lib.s2ag_bn_bwd_coeffs(_p(tmp[0]), _p(tmp[1]), _p(chan_map), cols, nchan, rows, _p(dgb[0]),
+                                           _p(dgb[1]), 0, _p(tmp[2]), _p(tmp[3]), _stream()), 'bn_bwd_coeffs')
+            dgamma, dbeta = dgb[0], dgb[1]
+            c1, c2 = tmp[2], tmp[3]
+        else:
+            z = torch.zeros(2, cols, dtype=torch.float32, device=dev)
+            c1, c2 = z[0], z[1]
+        L.check(lib.s2ag_bn_bwd_apply(_p(x), _p(dy), rows, cols, ldx, lddy, _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                      _p(coef[3]), slope, _p(c1), _p(c2), _p(dx), cols, _stream()), 'bn_bwd_apply')
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x: Tensor, bn: torch.nn.Module, slope: float = 1.0, chan_map: Optional[Tensor] = None,
+                   training: Optional[bool] = None) -> Tensor:
+    """BatchNorm over the last (column) axis of a channels-last tensor + leaky(slope).  ``bn`` is a
+    torch BatchNorm module used purely as the parameter/buffer container (state_dict compatibility)."""
+    tr = bn.training if training is None else training
+    shp = x.shape
+    y = _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                     bn.num_batches_tracked if tr else None, chan_map, float(slope), bool(tr), float(bn.eps),
+                     float(bn.momentum))
+    return y.view(shp)
+
+
+# ----------------------------------------------------------------------------------------------------
+# residual add + activation
+# ----------------------------------------------------------------------------------------------------
+class _AddAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, slope):
+        _need_cuda(a, b)
+        a_, r, c, _ = as_rows(a)
+        y = torch.empty(r, c, dtype=torch.float32, device=a.device)
+        add_act_raw(a_, b, y, slope)
+        ctx.slope = slope
+        ctx.has_b = b is not None
+        ctx.save_for_backward(y if slope != 1.0 else None)
+        return y.view(a.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        if ctx.slope == 1.0:
+            g = dy
+        else:
+            g = torch.empty(y.shape, dtype=torch.float32, device=dy.device)
+            epilogue_bwd_raw(dy.reshape(y.shape), y, g, L.ACT_LEAKY, ctx.slope, 0.0, None, 0)
+            g = g.view(dy.shape)
+        return g, (g if ctx.has_b else None), None
+
+
+def add_act(a: Tensor, b: Optional[Tensor], slope: float) -> Tensor:
+    return _AddAct.apply(a, b, float(slope))
+
+
+# ----------------------------------------------------------------------------------------------------
+# embedding (+ dropout)
+# ----------------------------------------------------------------------------------------------------
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, table, drop_p, noise, site):
+        _need_cuda(ids, table)
+        ids = ids.contiguous().view(-1)
+        rows, dim = ids.numel(), table.shape[1]
+        out = torch.empty(rows, dim, dtype=torch.float32, device=table.device)
+        e = _epi(L.ACT_NONE, 1.0, drop_p, noise, site)
+        L.check(_lib().s2ag_embedding_fwd(_p(ids), _p(table), rows, dim, table.shape[0], _p(out), dim, C.byref(e),
+                                          _stream()), 'embedding_fwd')
+        ctx.save_for_backward(ids)
+        ctx.meta = (table.shape[0], dim, drop_p, site)
+        ctx.noise = noise
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        n_entries, dim, drop_p, site = ctx.meta
+        dy, rows, _, ldg = as_rows(dy)
+        dt = torch.empty(n_entries, dim, dtype=torch.float32, device=dy.device)
+        e = _epi(L.ACT_NONE, 1.0, drop_p, ctx.noise, site)
+        L.check(_lib().s2ag_embedding_bwd(_p(ids), _p(dy), ldg, rows, dim, n_entries, _p(dt), 0, C.byref(e),
+                                          _stream()), 'embedding_bwd')
+        return None, dt, None, None, None
+
+
+def embedding(ids: Tensor, table: Tensor, drop_p: float = 0.0, noise=None, site=0) -> Tensor:
+    out = _Embedding.apply(ids, table, float(drop_p), noise, site)
+    return out.view(*ids.shape, table.shape[1])
+
+
+# ----------------------------------------------------------------------------------------------------
+# weight norm
+# ----------------------------------------------------------------------------------------------------
+class _WeightNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, g):
+        _need_cuda(v, g)
+        rows, cols = v.shape[0], v.numel() // v.shape[0]
+        v = v.contiguous()
+        w = torch.empty_like(v)
+        norm = torch.empty(rows, dtype=torch.float32, device=v.device)
+        L.check(_lib().s2ag_weight_norm_fwd(_p(v), _p(g), rows, cols, _p(w), _p(norm), _stream()), 'weight_norm_fwd')
+        ctx.save_for_backward(v, g, norm)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, g, norm = ctx.saved_tensors
+        rows, cols = v.shape[0], v.numel() // v.shape[0]
+        dw = dw.contiguous()
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(g)
+        L.check(_lib().s2ag_weight_norm_bwd(_p(dw), _p(v), _p(g), _p(norm), rows, cols, _p(dv), _p(dg), _stream()),
+                'weight_norm_bwd')
+        return dv, dg
+
+
+def weight_norm(v: Tensor, g: Tensor) -> Tensor:
+    return _WeightNorm.apply(v, g)
+
+
+# ----------------------------------------------------------------------------------------------------
+# CSR fold (ST-GCN weights)
+# ----------------------------------------------------------------------------------------------------
+class CSR:
+    """Device CSR pair (M and M^T) of a fixed sparse linear map."""
+
+    def __init__(self, mat, device):
+        import scipy.sparse as sp
+        m = sp.csr_matrix(mat)
+        m.sort_indices()
+        mt = sp.csr_matrix(m.T)
+        mt.sort_indices()
+        self.shape = m.shape
+
+        def dev(a, dt):
+            return torch.as_tensor(a, dtype=dt).to(device)
+        self.fwd = (dev(m.indptr, torch.int32), dev(m.indices, torch.int32), dev(m.data, torch.float32))
+        self.bwd = (dev(mt.indptr, torch.int32), dev(mt.indices, torch.int32), dev(mt.data, torch.float32))
+
+
+class _Fold(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, csr: CSR):
+        _need_cuda(w)
+        w = w.contiguous()
+        rp, ci_, va = csr.fwd
+        y = torch.empty(csr.shape[0], dtype=torch.float32, device=w.device)
+        L.check(_lib().s2ag_spmv(_p(rp), _p(ci_), _p(va), _p(w), _p(y), csr.shape[0], 0, _stream()), 'spmv')
+        ctx.csr = csr
+        ctx.wshape = w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        csr = ctx.csr
+        rp, ci_, va = csr.bwd
+        dy = dy.contiguous()
+        dw = torch.empty(csr.shape[1], dtype=torch.float32, device=dy.device)
+        L.check(_lib().s2ag_spmv(_p(rp), _p(ci_), _p(va), _p(dy), _p(dw), csr.shape[1], 0, _stream()), 'spmv^T')
+        return dw.view(ctx.wshape), None
+
+
+def fold(w: Tensor, csr: CSR) -> Tensor:
+    return _Fold.apply(w, csr)
+
+
+# ----------------------------------------------------------------------------------------------------
+# multi-layer bidirectional GRU
+# ----------------------------------------------------------------------------------------------------
+class _GRU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, Lyr, training, drop_p, noise, site0, sum_dirs, need_grad, *weights):
+        _need_cuda(x, *weights)
+        lib = _lib()
+        B, T, I = x.shape
+        dev = x.device
+        inp, _, _, _ = as_rows(x)
+        saved = []
+        H3 = 3 * H
+        y = None
+        for l in range(Lyr):
+            wih, whh, bih, bhh, wih_r, whh_r, bih_r, bhh_r = weights[8 * l:8 * l + 8]
+            In = wih.shape[1]
+            gi = torch.empty(B * T, 2 * H3, dtype=torch.float32, device=dev)
+            conv_fwd_raw(inp, wih, bih, gi[:, :H3], B * T, 1, 1, In, H3, 1, 1, 0, 1)
+            conv_fwd_raw(inp, wih_r, bih_r, gi[:, H3:], B * T, 1, 1, In, H3, 1, 1, 0, 1)
+            whhT = torch.empty(2, H, H3, dtype=torch.float32, device=dev)
+            transpose_raw(whh, whhT[0])
+            transpose_raw(whh_r, whhT[1])
+            bhh2 = torch.stack((bhh, bhh_r))
+            y = torch.empty(B * T, 2 * H, dtype=torch.float32, device=dev)
+            gates = torch.empty(2, B * T, 4 * H, dtype=torch.float32, device=dev) if need_grad else None
+            last = l == Lyr - 1
+            use_drop = bool(training) and drop_p > 0 and not last
+            ydrop = torch.empty_like(y) if use_drop else None
+            e = _epi(L.ACT_NONE, 1.0, drop_p if use_drop else 0.0, noise, site0 + l)
+            L.check(lib.s2ag_gru_seq_fwd(_p(gi), _p(whhT), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T, H, C.byref(e),
+                                         _stream()), 'gru_seq_fwd')
+            saved += [inp, y, gates]
+            inp = ydrop if use_drop else y
+        if sum_dirs:
+            out = torch.empty(B * T, H, dtype=torch.float32, device=dev)
+            add_act_raw(y[:, :H], y[:, H:], out, 1.0)
+            out = out.view(B, T, H)
+        else:
+            out = y.view(B, T, 2 * H)
+        ctx.meta = (B, T, H, Lyr, bool(training), float(drop_p), site0, bool(sum_dirs))
+        ctx.noise = noise
+        ctx.n_w = len(weights)
+        ctx.save_for_backward(*weights, *[s for s in saved])
+        ctx.none_mask = [s is None for s in saved]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, H, Lyr, training, drop_p, site0, sum_dirs = ctx.meta
+        lib = _lib()
+        tens = ctx.saved_tensors
+        weights, saved = tens[:ctx.n_w], tens[ctx.n_w:]
+        dev = dout.device
+        H3 = 3 * H
+        grads = [None] * ctx.n_w
+        dy, _, _, lddy = as_rows(dout.reshape(B * T, -1))
+        dir_stride = 0 if sum_dirs else H
+        dx = None
+        for l in range(Lyr - 1, -1, -1):
+            wih, whh, bih, bhh, wih_r, whh_r, bih_r, bhh_r = weights[8 * l:8 * l + 8]
+            inp, y, gates = saved[3 * l:3 * l + 3]
+            In = wih.shape[1]
+            last = l == Lyr - 1
+            use_drop = training and drop_p > 0 and not last
+            whh2 = torch.stack((whh, whh_r))
+            dgi = torch.empty(B * T, 2 * H3, dtype=torch.float32, device=dev)
+            dgh = torch.empty(2, B * T, H3, dtype=torch.float32, device=dev)
+            e = _epi(L.ACT_NONE, 1.0, drop_p if use_drop else 0.0, ctx.noise, site0 + l)
+            L.check(lib.s2ag_gru_seq_bwd(_p(dy), lddy, dir_stride, _p(whh2), _p(y), _p(gates), _p(dgi), _p(dgh), B, T,
+                                         H, C.byref(e), _stream()), 'gru_seq_bwd')
+            # parameter gradients
+            for d, (w_ih, w_hh) in enumerate(((wih, whh), (wih_r, whh_r))):
+                gsl = dgi[:, d * H3:(d + 1) * H3]
+                dwi = torch.empty_like(w_ih)
+                conv_bwd_weight_raw(gsl, inp, dwi, B * T, 1, 1, In, H3, 1, 1, 0, 1, False)
+                dbi = torch.empty(H3, dtype=torch.float32, device=dev)
+                colsum_raw(gsl, dbi)
+                # dW_hh = sum_t dgh_t^T h_{t-1}: h_{prev} is y shifted by one frame (zero at the boundary)
+                dwh = torch.empty_like(w_hh)
+                conv_bwd_weight_raw(dgh[d], y[:, d * H:(d + 1) * H], dwh, B, T, T, H, H3, 1, 1, 1 if d == 0 else -1, 1,
+                                    False)
+                dbh = torch.empty(H3, dtype=torch.float32, device=dev)
+                colsum_raw(dgh[d], dbh)
+                base = 8 * l + 4 * d
+                grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = dwi, dwh, dbi, dbh
+            # input gradient
+            if l > 0 or ctx.needs_input_grad[0]:
+                dx = torch.empty(B * T, In, dtype=torch.float32, device=dev)
+                conv_bwd_data_raw(dgi[:, :H3], wih, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, False)
+                conv_bwd_data_raw(dgi[:, H3:], wih_r, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, True)
+            dy, lddy, dir_stride = dx, 2 * H, H
+        dxo = dx.view(B, T, -1) if ctx.needs_input_grad[0] else None
+        return (dxo, None, None, None, None, None, None, None, None, *grads)
+
+
+def gru(x: Tensor, weights: Sequence[Tensor], hidden: int, layers: int, training: bool, drop_p: float, noise,
+        site0: int, sum_dirs: bool) -> Tensor:
+    """weights: per layer [w_ih, w_hh, b_ih, b_hh, w_ih_reverse, w_hh_reverse, b_ih_reverse, b_hh_reverse]."""
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights))
+    return _GRU.apply(x, hidden, layers, bool(training), float(drop_p), noise, site0, bool(sum_dirs), need_grad,
+                      *weights)
+
+
+# ----------------------------------------------------------------------------------------------------
+# re-parametrisation and losses
+# ----------------------------------------------------------------------------------------------------
+class _Reparam(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, log_var, noise, site):
+        _need_cuda(mu, log_var)
+        mu, log_var = mu.contiguous(), log_var.contiguous()
+        z = torch.empty_like(mu)
+        L.check(_lib().s2ag_reparam_fwd(_p(mu), _p(log_var), mu.numel(), _p(noise), site, _p(z), _stream()),
+                'reparam_fwd')
+        ctx.save_for_backward(log_var)
+        ctx.noise, ctx.site = noise, site
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (log_var,) = ctx.saved_tensors
+        dz = dz.contiguous()
+        dmu = torch.zeros_like(log_var)
+        dlv = torch.zeros_like(log_var)
+        L.check(_lib().s2ag_reparam_bwd(_p(dz), _p(log_var), dz.numel(), _p(ctx.noise), ctx.site, _p(dmu), _p(dlv),
+                                        _stream()), 'reparam_bwd')
+        return dmu, dlv, None, None
+
+
+def reparametrize(mu: Tensor, log_var: Tensor, noise: Tensor, site: int) -> Tensor:
+    return _Reparam.apply(mu, log_var, noise, site)
+
+
+class _DisLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d_real, d_fake):
+        _need_cuda(d_real, d_fake)
+        d_real, d_fake = d_real.contiguous(), d_fake.contiguous()
+        B = d_real.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=d_real.device)
+        gr, gf = torch.empty_like(d_real), torch.empty_like(d_fake)
+        L.check(_lib().s2ag_dis_loss(_p(d_real), _p(d_fake), B, _p(loss), _p(gr), _p(gf), _stream()), 'dis_loss')
+        ctx.save_for_backward(gr, gf)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        gr, gf = ctx.saved_tensors
+        return gr * dl, gf * dl
+
+
+def dis_loss(d_real: Tensor, d_fake: Tensor) -> Tensor:
+    return _DisLoss.apply(d_real, d_fake)
+
+
+class _GenLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, dis_out, mu, log_var, target, out_tri, out_rand, z, z_rand, weights):
+        _need_cuda(out, dis_out, mu, log_var)
+        c = [t.contiguous() for t in (out, dis_out, mu, log_var, target, out_rand, z, z_rand)]
+        out, dis_out, mu, log_var, target, out_rand, z, z_rand = c
+        out_tri = out_tri.contiguous() if out_tri is not None else None
+        B = out.shape[0]
+        TP = out.numel() // B
+        ZD = mu.numel() // B
+        dev = out.device
+        scratch = torch.empty(B, 8, dtype=torch.float32, device=dev)
+        comps = torch.empty(8, dtype=torch.float32, device=dev)
+        g_out, g_dis = torch.empty_like(out), torch.empty_like(dis_out)
+        g_mu, g_lv = torch.empty_like(mu), torch.empty_like(log_var)
+        w = (C.c_float * 4)(*[float(v) for v in weights])
+        L.check(_lib().s2ag_gen_loss(_p(out), _p(target), _p(out_tri), _p(dis_out), _p(out_rand), _p(z), _p(z_rand),
+                                     _p(mu), _p(log_var), B, TP, ZD, w, _p(scratch), _p(comps), _p(g_out), _p(g_dis),
+                                     _p(g_mu), _p(g_lv), _stream()), 'gen_loss')
+        ctx.save_for_backward(g_out, g_dis, g_mu, g_lv)
+        ctx.mark_non_differentiable(comps)
+        return comps[0].clone().view(()), comps
+
+    @staticmethod
+    def backward(ctx, dl, _dc):
+        g_out, g_dis, g_mu, g_lv = ctx.saved_tensors
+        return g_out * dl, g_dis * dl, g_mu * dl, g_lv * dl, None, None, None, None, None, None
+
+
+def gen_loss(out, dis_out, mu, log_var, target, out_tri, out_rand, z, z_rand, weights):
+    """Returns (total, comps[8]); comps = {total, huber, gen_error, div_reg, kld, l1, l1_tri, 0}.
+    weights = (regression, gan, div_reg, kld)."""
+    return _GenLoss.apply(out, dis_out, mu, log_var, target.detach(), None if out_tri is None else out_tri.detach(),
+                          out_rand.detach(), z.detach(), z_rand.detach(), tuple(weights))

@@ -1,0 +1,453 @@
+"""Trainer of the S2AG GAN step on MI355X.  Drop-in for the hot-path surface of ``processor_v2`` of the
+reference (processor_v2.py:53-83 get_epoch_and_loss, :86-220 Processor.__init__, :351-365 load_model_at_epoch,
+:589-638 yield_batch, :776-957 forward_pass_s2ag, :959-1069 epoch loops / train / checkpoint naming).
+
+What is MI355X-first here (DESIGN.md has the full story):
+  * one process per GPU; parameters and gradients of each network live in one flat arena, so the two
+    gradient exchanges of a step are two RCCL all-reduces over xGMI (D: 1.25 MB, G: ~53 MB) and each Adam
+    is a single launch;
+  * the whole step (3 generator, 3 discriminator and 1 tri-modal forward, 2 backward, 2 Adam) is captured
+    once into HIP graphs (three segments separated by the two collectives) and replayed -- the step is
+    launch/latency bound, not bandwidth bound;
+  * losses stay on the device; one 32-byte read-back per step replaces the reference's 5-7 ``.item()`` syncs.
+Rendering, FGD evaluation and the LMDB/npz data pipeline of the reference are outside this path.
+"""
+import os
+import time
+from os.path import join as jn
+
+import numpy as np
+import torch
+import torch.nn.functional as F  # noqa: F401  (kept for API familiarity; no functional op is used on the path)
+
+from . import ops
+from .net.multimodal_context_net_v2 import (AffDiscriminator, ConvDiscriminatorTriModal as CDT, PoseGenerator,
+                                            PoseGeneratorTriModal as PGT)
+from .optim import FusedAdam, ParamArena
+from .parallel import DataParallelContext
+
+
+def find_all_substr(a_str, sub):
+    start = 0
+    while True:
+        start = a_str.find(sub, start)
+        if start == -1:
+            return
+        yield start
+        start += len(sub)
+
+
+def get_epoch_and_loss(path_to_model_files, epoch='best'):
+    """File-name protocol ``epoch_{E:06d}_loss_{L:.4f}_model.pth.tar`` (processor_v2.py:53-83), including the
+    upstream quirk that 'best' picks the SECOND smallest loss (``argpartition(.., 2)[1]``) once >= 3 files exist."""
+    all_models = os.listdir(path_to_model_files)
+    if len(all_models) < 2:
+        return '', None, np.inf
+
+    def parse(name):
+        us = list(find_all_substr(name, '_'))
+        return name, int(name[us[0] + 1:us[1]]), float(name[us[2] + 1:us[3]])
+    if epoch == 'best':
+        losses = -1. * np.ones(len(all_models))
+        for i, name in enumerate(all_models):
+            parts = name.split('_')
+            if len(parts) > 1:
+                losses[i] = float(parts[3])
+        if len(losses) < 3:
+            pick = all_models[np.argwhere(losses == min(v for v in losses if v > 0))[0, 0]]
+        else:
+            pick = all_models[np.argpartition(losses, 2)[1]]
+        return parse(pick)
+    assert isinstance(epoch, int)
+    for name in all_models:
+        parts = name.split('_')
+        if len(parts) > 1 and epoch == int(parts[1]):
+            return parse(name)
+    return '', None, np.inf
+
+
+class _Log:
+    """Stand-in for torchlight IO.print_log (torchlight/io.py:121-130): stdout + work_dir/log.txt."""
+
+    def __init__(self, work_dir, save_log=True, print_log=True, rank=0):
+        self.work_dir, self.save_log, self.print_to_screen, self.rank = work_dir, save_log, print_log, rank
+
+    def print_log(self, s, print_time=True):
+        if self.rank != 0:
+            return
+        if print_time:
+            s = time.strftime('[%m.%d.%y|%X] ', time.localtime()) + s
+        if self.print_to_screen:
+            print(s)
+        if self.save_log and self.work_dir:
+            os.makedirs(self.work_dir, exist_ok=True)
+            with open(jn(self.work_dir, 'log.txt'), 'a') as f:
+                print(s, file=f)
+
+    def print_timer(self):
+        pass
+
+
+class _GraphSegments:
+    """Capture ``fns`` as consecutive HIP graphs sharing one memory pool; ``between[i]`` runs eagerly after
+    segment i (the RCCL all-reduces).  Static shapes; inputs are copied into the buffers captured."""
+
+    def __init__(self, fns, between, warmup=3):
+        self.fns, self.between = fns, between
+        self.graphs = []
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        for i, fn in enumerate(fns):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            self.graphs.append(g)      # nothing executes during capture, so no collective here
+
+    def _eager(self):
+        for fn, btw in zip(self.fns, self.between):
+            fn()
+            if btw is not None:
+                btw()
+
+    def replay(self):
+        for g, btw in zip(self.graphs, self.between):
+            g.replay()
+            if btw is not None:
+                btw()
+
+
+class Processor(object):
+    """Processor for emotive gesture generation (hot-path subset)."""
+
+    def __init__(self, base_path, args, s2ag_config_args, data_loader, pose_dim, coords, audio_sr,
+                 min_train_epochs=20, zfill=6):
+        if not torch.cuda.is_available():
+            raise RuntimeError('speech2affective_gestures_amd.Processor needs an MI355X (HIP); there is no CPU path')
+        self.base_path = base_path
+        self.args = args
+        self.dp = DataParallelContext.from_env()
+        self.device = torch.device('cuda', self.dp.local_rank)
+        torch.cuda.set_device(self.device)
+        self.s2ag_config_args = s2ag_config_args
+        self.data_loader = data_loader
+        self.result, self.iter_info, self.epoch_info = dict(), dict(), dict()
+        self.meta_info = dict(epoch=0, iter=0)
+        self.io = _Log(getattr(args, 'work_dir_s2ag', None), getattr(args, 'save_log', False),
+                       getattr(args, 'print_log', True), self.dp.rank)
+        self.pose_dim, self.coords, self.audio_sr = pose_dim, coords, audio_sr
+
+        key = 'train_data_s2ag' if getattr(args, 'train_s2ag', True) else 'test_data_s2ag'
+        meta = data_loader[key]
+        self.time_steps = meta.n_poses
+        self.audio_length = meta.expected_audio_length
+        self.num_mfcc = meta.num_mfcc_combined
+        self.lang_model = meta.lang_model
+        self.mfcc_length = int(np.ceil(self.audio_length / 512))
+
+        self.best_s2ag_loss = np.inf
+        self.best_s2ag_loss_epoch = None
+        self.s2ag_loss_updated = False
+        self.min_train_epochs = min_train_epochs
+        self.zfill = zfill
+
+        self.train_speaker_model = data_loader['train_data_s2ag'].speaker_model
+        self.val_speaker_model = getattr(data_loader.get('val_data_s2ag', meta), 'speaker_model', None)
+        wemb = getattr(self.lang_model, 'word_embedding_weights', None)
+        cfg = self.s2ag_config_args
+        self.trimodal_generator = PGT(cfg, pose_dim=pose_dim, n_words=self.lang_model.n_words,
+                                      word_embed_size=cfg.wordembed_dim, word_embeddings=wemb,
+                                      z_obj=self.train_speaker_model)
+        self.trimodal_discriminator = CDT(pose_dim, n_poses=self.time_steps)
+        self.use_mfcc = True
+        self.s2ag_generator = PoseGenerator(cfg, pose_dim=pose_dim, n_words=self.lang_model.n_words,
+                                            word_embed_size=cfg.wordembed_dim, word_embeddings=wemb,
+                                            mfcc_length=self.mfcc_length, num_mfcc=self.num_mfcc,
+                                            time_steps=self.time_steps, z_obj=self.train_speaker_model)
+        self.s2ag_discriminator = AffDiscriminator(pose_dim, n_poses=self.time_steps)
+        for m in (self.trimodal_generator, self.trimodal_discriminator, self.s2ag_generator,
+                  self.s2ag_discriminator):
+            m.to(self.device)
+        for p in self.trimodal_generator.parameters():      # frozen baseline (processor_v2.py:1033-1034)
+            p.requires_grad_(False)
+
+        # flat arenas (must come after .to(device)); identical initial weights on every rank
+        self.gen_arena = ParamArena(self.s2ag_generator.parameters())
+        self.dis_arena = ParamArena(self.s2ag_discriminator.parameters())
+        self.dp.broadcast_module(self.s2ag_generator, self.gen_arena)
+        self.dp.broadcast_module(self.s2ag_discriminator, self.dis_arena)
+        self.dp.broadcast_module(self.trimodal_generator, None)
+
+        self.train_samples = getattr(data_loader['train_data_s2ag'], 'samples', None)
+        self.val_samples = getattr(data_loader.get('val_data_s2ag', meta), 'samples', None)
+        self.num_train_samples = getattr(data_loader['train_data_s2ag'], 'n_samples', 0)
+        self.num_val_samples = getattr(data_loader.get('val_data_s2ag', meta), 'n_samples', 0)
+
+        self.lr_s2ag_gen = cfg.learning_rate
+        self.lr_s2ag_dis = cfg.learning_rate * cfg.discriminator_lr_weight
+        self.s2ag_gen_optimizer = FusedAdam(self.gen_arena, lr=self.lr_s2ag_gen, betas=(0.5, 0.999))
+        self.s2ag_dis_optimizer = FusedAdam(self.dis_arena, lr=self.lr_s2ag_dis, betas=(0.5, 0.999))
+
+        self.use_hip_graph = bool(getattr(args, 'hip_graph', True))
+        self._graphed = None
+        self.last_losses = {}
+
+    # ------------------------------------------------------------------------------------------------
+    def count_parameters(self):
+        return sum(p.numel() for p in self.s2ag_generator.parameters() if p.requires_grad)
+
+    def load_model_at_epoch(self, epoch='best'):
+        model_name, self.best_s2ag_loss_epoch, self.best_s2ag_loss = \
+            get_epoch_and_loss(self.args.work_dir_s2ag, epoch=epoch)
+        try:
+            loaded_vars = torch.load(jn(self.args.work_dir_s2ag, model_name), map_location=self.device)
+            self.s2ag_generator.load_state_dict(loaded_vars['gen_model_dict'])
+            self.s2ag_discriminator.load_state_dict(loaded_vars['dis_model_dict'])
+            return True
+        except (FileNotFoundError, IsADirectoryError):
+            print('Warning! No saved model found.' if epoch == 'best'
+                  else 'Warning! No saved model found at epoch {}.'.format(epoch))
+            return False
+
+    def save_model(self, epoch, loss):
+        if self.dp.rank != 0:
+            return None
+        os.makedirs(self.args.work_dir_s2ag, exist_ok=True)
+        path = jn(self.args.work_dir_s2ag, 'epoch_{:06d}_loss_{:.4f}_model.pth.tar'.format(epoch, loss))
+        torch.save({'gen_model_dict': self.s2ag_generator.state_dict(),
+                    'dis_model_dict': self.s2ag_discriminator.state_dict()}, path)
+        return path
+
+    # ------------------------------------------------------------------------------------------------
+    def yield_batch(self, train):
+        """processor_v2.py:589-638: B indices drawn WITH replacement per pseudo pass; audio int16 * max / 32767;
+        mfcc fp16 -> fp32; speaker ids drawn from the speakers NOT present in the batch (vectorised)."""
+        samples = self.train_samples if train else self.val_samples
+        num_data = self.num_train_samples if train else self.num_val_samples
+        spk = self.train_speaker_model if train else self.val_speaker_model
+        B = self.args.batch_size
+        for _ in range((num_data + B - 1) // B):
+            keys = np.random.choice(num_data, size=B, replace=True)
+            text = torch.from_numpy(samples['extended_word_seq'][keys]).to(self.device, non_blocking=True)
+            vec = torch.from_numpy(samples['vec_seq'][keys]).float().to(self.device, non_blocking=True)
+            audio = torch.from_numpy(samples['audio'][keys] * samples['audio_max'][keys, None] / 32767).float() \
+                .to(self.device, non_blocking=True)
+            mfcc = torch.from_numpy(samples['mfcc_features'][keys]).float().to(self.device, non_blocking=True)
+            vids = None
+            if spk is not None and spk.__class__.__name__ == 'Vocab':
+                others = np.setdiff1d(np.fromiter(spk.word2index.values(), dtype=np.int64), samples['vid_indices'][keys])
+                vids = torch.from_numpy(np.random.choice(others, size=B)).long().to(self.device, non_blocking=True)
+            yield text, vec, audio, mfcc, vids
+
+    # ------------------------------------------------------------------------------------------------
+    def _use_gan(self):
+        return self.meta_info['epoch'] > self.s2ag_config_args.loss_warmup and \
+            self.s2ag_config_args.loss_gan_weight > 0.0
+
+    def _make_pre_seq(self, target_poses):
+        n_pre = self.s2ag_config_args.n_pre_poses
+        pre_seq = target_poses.new_zeros((target_poses.shape[0], target_poses.shape[1], target_poses.shape[2] + 1))
+        pre_seq[:, 0:n_pre, :-1] = target_poses[:, 0:n_pre]
+        pre_seq[:, 0:n_pre, -1] = 1
+        return pre_seq
+
+    def _dis_phase(self, in_text, in_mfcc, target_poses, vid_indices, pre_seq, train):
+        """processor_v2.py:792-814 up to (and including) dis_error.backward()."""
+        self.s2ag_dis_optimizer.zero_grad()
+        with torch.no_grad():        # upstream builds this graph and never uses it
+            out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
+        dis_real = self.s2ag_discriminator(target_poses, in_text)
+        dis_fake = self.s2ag_discriminator(out_dir_vec.detach(), in_text)
+        dis_error = ops.dis_loss(dis_real, dis_fake)
+        if train:
+            dis_error.backward()
+        return dis_error.detach()
+
+    def _gen_phase(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, pre_seq, train):
+        """processor_v2.py:816-941 up to (and including) loss.backward()."""
+        cfg = self.s2ag_config_args
+        self.s2ag_gen_optimizer.zero_grad()
+        with torch.no_grad():
+            out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
+        out, z, z_mu, z_log_var = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
+        # upstream lets loss.backward() also fill D's .grad, which the next D step zeroes unread;
+        # skipping those weight-gradient kernels changes nothing observable
+        flags = [p.requires_grad for p in self.dis_arena.params]
+        for p in self.dis_arena.params:
+            p.requires_grad_(False)
+        try:
+            dis_output = self.s2ag_discriminator(out, in_text)
+        finally:
+            for p, f in zip(self.dis_arena.params, flags):
+                p.requires_grad_(f)
+        rand_idx = torch.randperm(vid_indices.shape[0], device=vid_indices.device)
+        with torch.no_grad():
+            out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices[rand_idx])
+        w_gan = cfg.loss_gan_weight if self.meta_info['epoch'] > cfg.loss_warmup else 0.0
+        total, comps = ops.gen_loss(out, dis_output, z_mu, z_log_var, target_poses, out_tri, out_rand, z, z_rand,
+                                    (cfg.loss_regression_weight, w_gan, cfg.loss_reg_weight, cfg.loss_kld_weight))
+        if train:
+            total.backward()
+        return comps
+
+    def _finish(self, comps, dis_error):
+        """ONE device->host read per step (upstream: 5-7 .item() syncs, processor_v2.py:943-956)."""
+        cfg = self.s2ag_config_args
+        host = torch.cat((comps, dis_error.reshape(1) if dis_error is not None else comps.new_zeros(1))).tolist()
+        total, huber, gen_error, div_reg, kld, l1, l1_tri, _, dis = host
+        d = {'loss': cfg.loss_regression_weight * huber, 'KLD': cfg.loss_kld_weight * kld,
+             'DIV_REG': cfg.loss_reg_weight * div_reg, 'total': total}
+        if self._use_gan():
+            d['gen'] = cfg.loss_gan_weight * gen_error
+            d['dis'] = dis
+        self.last_losses = d
+        return l1 - l1_tri
+
+    def forward_pass_s2ag(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, train, target_seq=None,
+                          words=None, aux_info=None, save_path=None, make_video=False, calculate_metrics=False,
+                          losses_all_trimodal=None, joint_mae_trimodal=None, accel_trimodal=None, losses_all=None,
+                          joint_mae=None, accel=None):
+        """One GAN step (processor_v2.py:776-957).  Returns the reference's 7-tuple; the loss components of the
+        step are left in ``self.last_losses``.  ``make_video`` / ``calculate_metrics`` belong to the rendering /
+        FGD paths that are out of scope here."""
+        if make_video or calculate_metrics:
+            raise NotImplementedError('rendering / FGD evaluation are outside the MI355X hot path')
+        pre_seq = self._make_pre_seq(target_poses)
+        dis_error = None
+        if self._use_gan():
+            dis_error = self._dis_phase(in_text, in_mfcc, target_poses, vid_indices, pre_seq, train)
+            if train:
+                self.dp.all_reduce_grads(self.dis_arena)
+                self.s2ag_dis_optimizer.step(self.dp.grad_scale)
+        comps = self._gen_phase(in_text, in_audio, in_mfcc, target_poses, vid_indices, pre_seq, train)
+        if train:
+            self.dp.all_reduce_grads(self.gen_arena)
+            self.s2ag_gen_optimizer.step(self.dp.grad_scale)
+        metric = self._finish(comps, dis_error)
+        return metric, losses_all_trimodal, joint_mae_trimodal, accel_trimodal, losses_all, joint_mae, accel
+
+    # ---- hipGraph replay of the training step (static shapes) ---------------------------------------------
+    def _build_graphed(self, in_text, in_audio, in_mfcc, target_poses, vid_indices):
+        st = dict(text=in_text.clone(), audio=in_audio.clone(), mfcc=in_mfcc.clone(), target=target_poses.clone(),
+                  vid=vid_indices.clone())
+        out = {}
+        use_gan = self._use_gan()
+
+        def seg_dis():
+            out['pre'] = self._make_pre_seq(st['target'])
+            out['dis'] = self._dis_phase(st['text'], st['mfcc'], st['target'], st['vid'], out['pre'], True) \
+                if use_gan else None
+
+        def seg_gen():
+            if use_gan:
+                self.s2ag_dis_optimizer.step(self.dp.grad_scale)
+            out['comps'] = self._gen_phase(st['text'], st['audio'], st['mfcc'], st['target'], st['vid'], out['pre'],
+                                           True)
+
+        def seg_opt():
+            self.s2ag_gen_optimizer.step(self.dp.grad_scale)
+
+        between = [(lambda: self.dp.all_reduce_grads(self.dis_arena)) if (use_gan and self.dp.world_size > 1) else None,
+                   (lambda: self.dp.all_reduce_grads(self.gen_arena)) if self.dp.world_size > 1 else None,
+                   None]
+        segs = _GraphSegments([seg_dis, seg_gen, seg_opt], between)
+        self._graphed = dict(st=st, out=out, segs=segs, key=self._graph_key(in_text, in_audio, in_mfcc, target_poses))
+
+    def _graph_key(self, in_text, in_audio, in_mfcc, target_poses):
+        return (tuple(in_text.shape), tuple(in_audio.shape), tuple(in_mfcc.shape), tuple(target_poses.shape),
+                self._use_gan(), self.meta_info['epoch'] > self.s2ag_config_args.loss_warmup)
+
+    def train_step(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, sync=True):
+        """The training branch of forward_pass_s2ag, replayed from HIP graphs when shapes are static.
+        NOTE: capturing runs three un-timed warm-up steps (they DO update the weights)."""
+        if not self.use_hip_graph:
+            return self.forward_pass_s2ag(in_text, in_audio, in_mfcc, target_poses, vid_indices, True)[0]
+        key = self._graph_key(in_text, in_audio, in_mfcc, target_poses)
+        if self._graphed is None or self._graphed['key'] != key:
+            self._build_graphed(in_text, in_audio, in_mfcc, target_poses, vid_indices)
+        g = self._graphed
+        for name, t in (('text', in_text), ('audio', in_audio), ('mfcc', in_mfcc), ('target', target_poses),
+                        ('vid', vid_indices)):
+            g['st'][name].copy_(t, non_blocking=True)
+        g['segs'].replay()
+        if not sync:
+            return None
+        return self._finish(g['out']['comps'], g['out']['dis'])
+
+    # ------------------------------------------------------------------------------------------------
+    def per_train_epoch(self):
+        self.s2ag_generator.train()
+        self.s2ag_discriminator.train()
+        batch_s2ag_loss = 0.
+        num_batches = self.num_train_samples // self.args.batch_size + 1
+        self.meta_info['iter'] = 0
+        log_interval = getattr(self.args, 'log_interval', 200)
+        for extended_word_seq, vec_seq, audio, mfcc_features, vid_indices in self.yield_batch(train=True):
+            loss = self.train_step(extended_word_seq, audio, mfcc_features, vec_seq, vid_indices)
+            batch_s2ag_loss += loss
+            self.iter_info['s2ag_loss'] = loss
+            self.iter_info['lr_gen'] = '{}'.format(self.lr_s2ag_gen)
+            self.iter_info['lr_dis'] = '{}'.format(self.lr_s2ag_dis)
+            if self.meta_info['iter'] % log_interval == 0:
+                self.io.print_log('\tIter {} Done.'.format(self.meta_info['iter']) + ''.join(
+                    ' | {}: {:.4f}'.format(k, v) if isinstance(v, float) else ' | {}: {}'.format(k, v)
+                    for k, v in self.iter_info.items()))
+            self.meta_info['iter'] += 1
+        batch_s2ag_loss /= num_batches
+        self.epoch_info['mean_s2ag_loss'] = batch_s2ag_loss
+        self.io.print_log('\tmean_s2ag_loss: {}. Best so far: {:.4f}.'.format(batch_s2ag_loss, self.best_s2ag_loss))
+
+    def per_val_epoch(self):
+        self.s2ag_generator.eval()
+        self.s2ag_discriminator.eval()
+        batch_s2ag_loss = 0.
+        num_batches = self.num_val_samples // self.args.batch_size + 1
+        self.meta_info['iter'] = 0
+        for extended_word_seq, vec_seq, audio, mfcc_features, vid_indices in self.yield_batch(train=False):
+            with torch.no_grad():
+                loss, *_ = self.forward_pass_s2ag(extended_word_seq, audio, mfcc_features, vec_seq, vid_indices,
+                                                  train=False)
+            batch_s2ag_loss += loss
+            self.meta_info['iter'] += 1
+        batch_s2ag_loss /= num_batches
+        self.epoch_info['mean_s2ag_loss'] = batch_s2ag_loss
+        if batch_s2ag_loss < self.best_s2ag_loss and self.meta_info['epoch'] > self.min_train_epochs:
+            self.best_s2ag_loss = batch_s2ag_loss
+            self.best_s2ag_loss_epoch = self.meta_info['epoch']
+            self.s2ag_loss_updated = True
+        else:
+            self.s2ag_loss_updated = False
+        self.io.print_log('\tval mean_s2ag_loss: {}. Best so far: {:.4f}.'.format(batch_s2ag_loss,
+                                                                                 self.best_s2ag_loss))
+
+    def train(self):
+        """processor_v2.py:1032-1069 (frozen tri-modal weights, resume protocol, save cadence)."""
+        tri_path = jn(self.base_path, 'outputs', 'trimodal_gen.pth.tar')
+        if os.path.exists(tri_path):
+            ckpt = torch.load(tri_path, map_location=self.device)
+            self.trimodal_generator.load_state_dict(ckpt['trimodal_gen_dict'])
+        else:
+            self.io.print_log('Warning! {} not found: tri-modal baseline keeps its random init.'.format(tri_path))
+        if getattr(self.args, 's2ag_load_last_best', False):
+            found = self.load_model_at_epoch(epoch=self.args.s2ag_start_epoch)
+            if not found and self.args.s2ag_start_epoch != 'best':
+                found = self.load_model_at_epoch(epoch='best')
+                self.args.s2ag_start_epoch = self.best_s2ag_loss_epoch if found else 0
+        else:
+            self.args.s2ag_start_epoch = 0
+        for epoch in range(self.args.s2ag_start_epoch, self.args.s2ag_num_epoch):
+            self.meta_info['epoch'] = epoch
+            self.io.print_log('s2ag training epoch: {}'.format(epoch))
+            self.per_train_epoch()
+            self.io.print_log('Done.')
+            if (epoch % self.args.val_interval == 0) or (epoch + 1 == self.args.s2ag_num_epoch):
+                self.io.print_log('s2ag val epoch: {}'.format(epoch))
+                self.per_val_epoch()
+                self.io.print_log('Done.')
+            if self.s2ag_loss_updated or (epoch % self.args.save_interval == 0 and epoch > self.min_train_epochs):
+                self.save_model(epoch, self.epoch_info['mean_s2ag_loss'])

@@ -59,6 +59,12 @@ import processor_v2 as P                                   # noqa: E402
 from utils.vocab import Vocab                              # noqa: E402
 
 from oracle import s2ag_oracle as O                        # noqa: E402  (recipes only)
+sys.path.insert(2, HERE)
+import s2ag_rng                                            # noqa: E402
+
+# the product's step consumes one noise pass per forward, in this order (processor_v2.py of the product):
+# 0 G(dis) 1 D(real) 2 D(fake) 3 PGT 4 G(main) 5 D(gen) 6 G(rand); the tests pin these ids on the modules
+STEP_SEED, G_Z_SITE, PGT_Z_SITE, PASSES_PER_STEP = 1234, 9001, 9002, 7
 
 
 class Cfg:
@@ -140,8 +146,9 @@ def module_goldens(tag, hidden, n_words, n_spk, B, seed0):
     out = {}
     cfg, mods = build(hidden, n_words, n_spk, 0.0, seed0)
     inp = O.recipe_inputs(B, 34, seed0 + 10, n_words, n_spk)
-    rs = np.random.RandomState(seed0 + 11)
-    eps = torch.from_numpy(rs.standard_normal((B, 16)).astype(np.float32))
+    # eps as libs2ag_hip.so draws it for (seed, pass counter 0, site G_Z_SITE): the GPU tests reset the noise
+    # state before every module forward and pin z_site, so product and reference see the same deviates
+    eps = torch.from_numpy(s2ag_rng.normal(STEP_SEED, 0, G_Z_SITE, B * 16).reshape(B, 16))
     pre_seq = O.make_pre_seq(inp['target'], 4)
     out['eps'] = npy(eps)
     for mode in ('eval', 'train'):
@@ -259,7 +266,9 @@ def step_golden(seed0, n_steps=3):
     try:
         for s in range(n_steps):
             inp = O.recipe_inputs(B, 34, seed0 + 100 + s, n_words, n_spk)
-            eps = [torch.from_numpy(rs.standard_normal((B, 16)).astype(np.float32)) for _ in range(4)]
+            # eps exactly as libs2ag_hip.so will draw them: (seed, pass counter, site) -> normal deviates
+            eps = [torch.from_numpy(s2ag_rng.normal(STEP_SEED, PASSES_PER_STEP * s + k, site, B * 16).reshape(B, 16))
+                   for k, site in ((0, G_Z_SITE), (3, PGT_Z_SITE), (4, G_Z_SITE), (6, G_Z_SITE))]
             perm = torch.from_numpy(rs.permutation(B))
             out[f's{s}.eps'] = np.stack([npy(e) for e in eps])     # order: G(dis), PGT, G(main), G(rand)
             out[f's{s}.perm'] = npy(perm)

@@ -1,0 +1,72 @@
+"""Shared helpers of the GPU parity tests: reference-shaped configs, recipe weights, product module builders."""
+import types
+
+import torch
+
+from oracle import s2ag_oracle as O
+
+STEP_SEED, G_Z_SITE, PGT_Z_SITE, PASSES_PER_STEP = 1234, 9001, 9002, 7     # must equal tests/golden/gen_golden.py
+
+
+class Vocab:                       # duck-typed like utils/vocab.py: class name 'Vocab', .n_words, .word2index
+    def __init__(self, n):
+        self.n_words = n
+        self.word2index = {'v%d' % i: i for i in range(n)}
+        self.word_embedding_weights = None
+
+
+def make_cfg(hidden, drop):
+    return types.SimpleNamespace(n_pre_poses=4, n_poses=34, input_context='both', hidden_size=hidden,
+                                 hidden_size_s2eg=hidden, n_layers=4, dropout_prob=drop, freeze_wordembed=False,
+                                 loss_warmup=0, loss_gan_weight=5.0, z_type='speaker', loss_reg_weight=0.05,
+                                 loss_regression_weight=500, loss_kld_weight=0.1, wordembed_dim=300,
+                                 learning_rate=5e-4, discriminator_lr_weight=0.2)
+
+
+def oracle_cfg(hidden, drop):
+    return O.ModelCfg(hidden_size=hidden, hidden_size_s2eg=hidden, dropout_prob=drop)
+
+
+def recipe_sds(hidden, n_words, n_spk, seed0):
+    oc = oracle_cfg(hidden, 0.0)
+    return dict(G=O.recipe_state_dict(O.generator_shapes(oc, n_words, n_spk), seed0 + 1),
+                D=O.recipe_state_dict(O.aff_discriminator_shapes(), seed0 + 2),
+                CD=O.recipe_state_dict(O.conv_discriminator_shapes(), seed0 + 3),
+                T3=O.recipe_state_dict(O.trimodal_shapes(oc, n_words, n_spk), seed0 + 4),
+                GA=O.recipe_state_dict(O.generator_shapes(oc, n_words, n_spk, audio='wav'), seed0 + 5))
+
+
+def build_product(hidden, n_words, n_spk, drop, seed0, which=('G', 'D', 'CD', 'T3', 'GA')):
+    from speech2affective_gestures_amd.net import multimodal_context_net_v2 as m2
+    from speech2affective_gestures_amd.net import multimodal_context_net_v2_abl_audio as m2a
+    cfg, spk = make_cfg(hidden, drop), Vocab(n_spk)
+    sds = recipe_sds(hidden, n_words, n_spk, seed0)
+    mk = dict(G=lambda: m2.PoseGenerator(cfg, 27, n_words, 300, None, 71, 37, 34, z_obj=spk),
+              D=lambda: m2.AffDiscriminator(27), CD=lambda: m2.ConvDiscriminatorTriModal(27),
+              T3=lambda: m2.PoseGeneratorTriModal(cfg, 27, n_words, 300, None, z_obj=spk),
+              GA=lambda: m2a.PoseGenerator(cfg, 27, n_words, 300, None, 71, 37, 34, z_obj=spk))
+    mods = {}
+    for k in which:
+        m = mk[k]()
+        m.load_state_dict(sds[k], strict=True)          # same keys / shapes as the reference, by construction
+        mods[k] = m.cuda()
+        if hasattr(m, 'z_site'):
+            m.z_site = PGT_Z_SITE if k == 'T3' else G_Z_SITE
+    return cfg, mods, sds
+
+
+def set_dropout(module, p_tcn=None, p_emb=None, p_gru=None):
+    """Override the dropout probabilities of a product module tree (None = leave)."""
+    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import GRU, TextEncoderTCN
+    from speech2affective_gestures_amd.net.tcn import TemporalBlock
+    for sub in module.modules():
+        if isinstance(sub, TemporalBlock) and p_tcn is not None:
+            sub.p = p_tcn
+        if isinstance(sub, TextEncoderTCN) and p_emb is not None:
+            sub.drop.p = p_emb
+        if isinstance(sub, GRU) and p_gru is not None:
+            sub.dropout = p_gru
+
+
+def to_cuda(d):
+    return {k: v.cuda() for k, v in d.items()}

@@ -1,0 +1,207 @@
+"""Module-level parity on the GPU: the product nets (HIP kernels, channels-last) against
+  (1) the golden vectors produced by the REFERENCE itself (tests/golden/modules_*.npz), eval and train mode,
+  (2) the oracle with the product's own materialised dropout masks / eps (forward AND every parameter gradient).
+Tolerance 2e-4 relative-to-max (north-star bar: 1e-3 rel fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import s2ag_oracle as O  # noqa: E402
+from s2ag_testing import (G_Z_SITE, STEP_SEED, build_product, oracle_cfg, set_dropout, to_cuda)  # noqa: E402
+
+TOL = 2e-4
+CASES = {'small': dict(hidden=32, n_words=64, n_spk=12, B=2, seed0=1000),
+         'full': dict(hidden=300, n_words=2000, n_spk=1371, B=4, seed0=2000)}
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
+
+
+def _reset_noise():
+    from speech2affective_gestures_amd import noise
+    noise.manual_seed(STEP_SEED)
+
+
+@pytest.mark.parametrize('tag', ['small', 'full'])
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_modules_match_reference_goldens(golden_dir, tag, mode):
+    c = CASES[tag]
+    g = dict(np.load(os.path.join(golden_dir, f'modules_{tag}.npz')))
+    inp = to_cuda(O.recipe_inputs(c['B'], 34, c['seed0'] + 10, c['n_words'], c['n_spk']))
+    pre_seq = O.make_pre_seq(inp['target'], 4)
+
+    def fresh():
+        _, mods, _ = build_product(c['hidden'], c['n_words'], c['n_spk'], 0.0, c['seed0'])
+        for m in mods.values():
+            m.train(mode == 'train')
+            set_dropout(m, 0.0, 0.0, 0.0)
+        return mods
+    with torch.no_grad():
+        m = fresh()
+        assert rel(m['T3'].audio_encoder(inp['in_audio']), g[f'{mode}.wav_encoder']) < TOL
+        assert rel(m['G'].audio_encoder(inp['in_mfcc']), g[f'{mode}.mfcc_encoder']) < TOL
+        assert rel(m['G'].text_encoder(inp['in_text'])[0], g[f'{mode}.text_encoder']) < TOL
+        assert rel(m['G'].aff_encoder(inp['target']), g[f'{mode}.aff_encoder']) < TOL
+        m = fresh()
+        _reset_noise()
+        o, z, mu, lv = m['G'](pre_seq, inp['in_text'], inp['in_mfcc'], inp['vid'])
+        assert rel(o, g[f'{mode}.G.out']) < TOL and rel(z, g[f'{mode}.G.z']) < TOL
+        assert rel(mu, g[f'{mode}.G.mu']) < TOL and rel(lv, g[f'{mode}.G.log_var']) < TOL
+        m['T3'].z_site = G_Z_SITE
+        _reset_noise()
+        assert rel(m['T3'](pre_seq, inp['in_text'], inp['in_audio'], inp['vid'])[0], g[f'{mode}.T3.out']) < TOL
+        _reset_noise()
+        assert rel(m['GA'](pre_seq, inp['in_text'], inp['in_audio'], inp['vid'])[0], g[f'{mode}.GA.out']) < TOL
+        assert rel(m['D'](inp['target']), g[f'{mode}.D.out']) < TOL
+        assert rel(m['CD'](inp['target']), g[f'{mode}.CD.out']) < TOL
+        if mode == 'train':
+            sd = m['G'].state_dict()
+            for k in g:
+                if k.startswith('train.G.') and k[8:] in sd:
+                    assert rel(sd[k[8:]].float(), g[k]) < TOL, k
+            assert rel(m['T3'].state_dict()['audio_encoder.feat_extractor.1.running_var'],
+                       g['train.T3.audio_encoder.feat_extractor.1.running_var']) < TOL
+
+
+def test_reference_layout_entry_points():
+    """STGraphConv / TemporalConvNet keep the reference's (N,C,T,V) / (B,C,T) call signatures."""
+    import torch.nn.functional as F
+    from speech2affective_gestures_amd.net.tcn import TemporalConvNet
+    from speech2affective_gestures_amd.net.utils.tgcn import STGraphConv
+    torch.manual_seed(0)
+    A1, _ = O.aff_adjacencies()
+    blk = STGraphConv(3, 16, 5, (9, 5), stride=(1, 1), padding=(4, 2)).cuda().eval()
+    x = torch.randn(3, 3, 34, 9)
+    sd = {'p.' + k: v.cpu() for k, v in blk.state_dict().items()}
+    ref = O.st_graph_conv(sd, 'p.', x, A1, False)
+    y, A = blk(x.cuda(), A1.cuda())
+    assert y.shape == (3, 16, 34, 9) and rel(y, ref) < TOL
+    tcn = TemporalConvNet(20, [24, 24], 2, dropout=0.0).cuda().eval()
+    xt = torch.randn(2, 20, 34)
+    sdt = {'t.' + k: v.cpu() for k, v in tcn.state_dict().items()}
+    yr = xt
+    for i in range(2):
+        yr = O.temporal_block(sdt, f't.network.{i}.', yr, 2 ** i, False, 0.0, O.Noise('off'), 'n')
+    assert rel(tcn(xt.cuda()), yr) < TOL
+
+
+def _g_noise(G, nz, B, T, hidden, p, p_emb):
+    """Materialise the masks / eps the generator's kernels draw in the pass ``nz`` and name them for the oracle."""
+    from speech2affective_gestures_amd import ops
+    pin = {'eps': ops.normal_noise(nz, G.z_site, (B, 16)).cpu()}
+    te = G.text_encoder
+    pin['text_encoder.emb_drop'] = ops.dropout_mask(nz, te.site, p_emb, (B, T, 300)).cpu()
+    for i, blk in enumerate(te.tcn.network):
+        for j in (0, 1):      # oracle applies TCN masks in (B, C, T) layout
+            pin[f'text_encoder.tcn.{i}.drop{j + 1}'] = \
+                ops.dropout_mask(nz, blk.sites[j], p, (B, T, hidden)).cpu().transpose(1, 2)
+    for l in range(G.gru.num_layers - 1):
+        pin[f'gru.drop{l}'] = ops.dropout_mask(nz, G.gru.site0 + l, G.gru.dropout, (B, T, 2 * G.gru.hidden_size)).cpu()
+    return pin
+
+
+@pytest.mark.parametrize('which', ['G', 'GA'])
+def test_generator_train_mode_with_dropout_forward_and_all_gradients(which):
+    from speech2affective_gestures_amd import noise
+    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 3, 5000
+    cfg, mods, sds = build_product(hidden, n_words, n_spk, 0.3, s0, which=(which,))
+    G = mods[which].train()
+    inp = O.recipe_inputs(B, 34, s0 + 10, n_words, n_spk)
+    gi = to_cuda(inp)
+    pre_seq = O.make_pre_seq(inp['target'], 4)
+    noise.manual_seed(77)
+    nz = torch.tensor([77, 0], dtype=torch.int64, device='cuda')        # the snapshot the next pass will take
+    audio_in = gi['in_mfcc'] if which == 'G' else gi['in_audio']
+    out, z, mu, lv = G(pre_seq.cuda(), gi['in_text'], audio_in, gi['vid'])
+    pin = _g_noise(G, nz, B, 34, hidden, 0.3, 0.1)
+    sd = {k: (v.clone().requires_grad_(True) if O.is_param(k) and '.net.' not in k else v.clone())
+          for k, v in sds[which].items()}
+    fn = O.pose_generator if which == 'G' else O.pose_generator_abl_audio
+    o_r, z_r, mu_r, lv_r = fn(sd, oracle_cfg(hidden, 0.3), pre_seq, inp['in_text'],
+                              inp['in_mfcc'] if which == 'G' else inp['in_audio'], inp['vid'], True, O.Noise(pin))
+    assert rel(out, o_r) < TOL and rel(z, z_r) < TOL and rel(mu, mu_r) < TOL and rel(lv, lv_r) < TOL
+    gen = torch.Generator().manual_seed(1)
+    d_out, d_mu = torch.randn(o_r.shape, generator=gen), torch.randn(mu_r.shape, generator=gen)
+    (o_r * d_out).sum().add((mu_r * d_mu).sum()).add((lv_r * d_mu).sum()).backward()
+    (out * d_out.cuda()).sum().add((mu * d_mu.cuda()).sum()).add((lv * d_mu.cuda()).sum()).backward()
+    worst = 0.0
+    for k, p in G.named_parameters():
+        if '.net.' in k:
+            continue
+        assert p.grad is not None, k
+        e = rel(p.grad, sd[k].grad)
+        worst = max(worst, e)
+        assert e < 5 * TOL, (k, e)
+    # BN running statistics were updated identically
+    for k in ('aff_encoder.batch_norm1.running_mean', 'aff_encoder.st_gcn2.tcn.3.running_var'):
+        assert rel(G.state_dict()[k], sd[k]) < TOL
+
+
+def test_discriminators_train_mode_with_dropout_gradients():
+    from speech2affective_gestures_amd import noise, ops
+    B, s0 = 5, 6000
+    _, mods, sds = build_product(32, 64, 12, 0.3, s0, which=('D', 'CD'))
+    inp = O.recipe_inputs(B, 34, s0 + 10, 64, 12)
+    for key, fn in (('D', O.aff_discriminator), ('CD', O.conv_discriminator)):
+        D = mods[key].train()
+        noise.manual_seed(5)
+        nz = torch.tensor([5, 0], dtype=torch.int64, device='cuda')
+        poses = inp['target'].cuda().requires_grad_(True)
+        y = D(poses)
+        Tq = 34 if key == 'D' else 28
+        pin = {f'gru.drop{l}': ops.dropout_mask(nz, D.gru.site0 + l, 0.3, (B, Tq, 128)).cpu() for l in range(3)}
+        sd = {k: (v.clone().requires_grad_(True) if O.is_param(k) else v.clone()) for k, v in sds[key].items()}
+        pr = inp['target'].clone().requires_grad_(True)
+        yr = fn(sd, pr, True, O.Noise(pin))
+        assert rel(y, yr) < TOL
+        yr.log().sum().backward()
+        y.log().sum().backward()
+        assert rel(poses.grad, pr.grad) < 5 * TOL
+        for k, p in D.named_parameters():
+            assert rel(p.grad, sd[k].grad) < 5 * TOL, (key, k)
+
+
+def test_long_clip_136_frames_matches_oracle():
+    """BASELINE config 5 shape: T = 136, audio 146000 samples, mfcc_length 284; out2 sized from n_poses."""
+    from speech2affective_gestures_amd import noise
+    from speech2affective_gestures_amd.net import multimodal_context_net_v2 as m2
+    from s2ag_testing import Vocab, make_cfg
+    T, B, hidden, n_words, n_spk = 136, 2, 32, 64, 12
+    cfg = make_cfg(hidden, 0.0)
+    cfg.n_poses = T
+    oc = O.ModelCfg(n_poses=T, hidden_size=hidden, hidden_size_s2eg=hidden, dropout_prob=0.0)
+    sdG = O.recipe_state_dict(O.generator_shapes(oc, n_words, n_spk, mfcc_length=284), 7001)
+    sdD = O.recipe_state_dict(O.aff_discriminator_shapes(T), 7002)
+    sdT = O.recipe_state_dict(O.trimodal_shapes(oc, n_words, n_spk), 7003)
+    spk = Vocab(n_spk)
+    G = m2.PoseGenerator(cfg, 27, n_words, 300, None, 284, 37, T, z_obj=spk)
+    D = m2.AffDiscriminator(27, n_poses=T)
+    T3 = m2.PoseGeneratorTriModal(cfg, 27, n_words, 300, None, z_obj=spk)
+    for m, sd in ((G, sdG), (D, sdD), (T3, sdT)):
+        m.load_state_dict(sd, strict=True)
+        m.cuda().eval()
+    inp = O.recipe_inputs(B, T, 7010, n_words, n_spk, audio_len=146000, mfcc_len=284)
+    gi = to_cuda(inp)
+    pre = O.make_pre_seq(inp['target'], 4)
+    with torch.no_grad():
+        noise.manual_seed(9)
+        G.z_site = T3.z_site = 4242
+        from speech2affective_gestures_amd import ops
+        eps = ops.normal_noise(torch.tensor([9, 0], dtype=torch.int64, device='cuda'), 4242, (B, 16)).cpu()
+        o = G(pre.cuda(), gi['in_text'], gi['in_mfcc'], gi['vid'])[0]
+        assert rel(o, O.pose_generator(sdG, oc, pre, inp['in_text'], inp['in_mfcc'], inp['vid'], False,
+                                       O.Noise({'eps': eps}))[0]) < TOL
+        assert rel(D(gi['target']), O.aff_discriminator(sdD, inp['target'], False, O.Noise('off'))) < TOL
+        noise.manual_seed(9)
+        ot = T3(pre.cuda(), gi['in_text'], gi['in_audio'], gi['vid'])[0]
+        assert ot.shape == (B, T, 27)
+        assert rel(ot, O.pose_generator_trimodal(sdT, oc, pre, inp['in_text'], inp['in_audio'], inp['vid'], False,
+                                                 O.Noise({'eps': eps}))[0]) < TOL

@@ -1,0 +1,384 @@
+"""Kernel-level parity: every C-ABI entry point (through ops.py) against a plain torch-CPU fp32 restatement
+or the oracle.  Tolerance: 1e-4 relative-to-max (the north-star bar is 1e-3 rel fp32)."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+import s2ag_rng  # noqa: E402
+from oracle import s2ag_oracle as O  # noqa: E402
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def S():
+    from speech2affective_gestures_amd import noise, ops, optim
+    from speech2affective_gestures_amd import _lib
+    return dict(ops=ops, noise=noise, optim=optim, lib=_lib)
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
+
+
+def test_library_is_loaded_in_process(S):
+    S['lib'].load()
+    with open('/proc/self/maps') as f:
+        assert 'libs2ag_hip.so' in f.read()
+
+
+def test_cpu_tensor_raises(S):
+    with pytest.raises(RuntimeError):
+        S['ops'].linear(torch.randn(3, 4), torch.randn(5, 4), None)
+
+
+def test_rng_matches_numpy_restatement(S):
+    ops, noise = S['ops'], S['noise']
+    st = torch.tensor([1234, 5], dtype=torch.int64, device='cuda')
+    m = ops.dropout_mask(st, 77, 0.3, (1000,)).cpu().numpy()
+    np.testing.assert_array_equal(m, s2ag_rng.keep_mask(1234, 5, 77, 0.3, 1000))
+    e = ops.normal_noise(st, 9001, (4096,)).cpu().numpy()
+    np.testing.assert_allclose(e, s2ag_rng.normal(1234, 5, 9001, 4096), atol=3e-6)
+    big = ops.normal_noise(st, 3, (1 << 20,))
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1.0) < 5e-3
+    keep = (ops.dropout_mask(st, 4, 0.3, (1 << 20,)) > 0).float().mean()
+    assert abs(float(keep) - 0.7) < 3e-3
+    # passes advance the device counter
+    noise.manual_seed(42)
+    a, b = noise.begin_pass('cuda'), noise.begin_pass('cuda')
+    assert a.tolist() == [42, 0] and b.tolist() == [42, 1]
+
+
+# (N, Lin, Cin, Cout, k, stride, pad, dil, causal)
+CONV_CASES = [
+    (3, 700, 1, 16, 15, 5, 160, 1, False),     # WavEncoder conv1 shape family (Cin = 1, big padding)
+    (3, 300, 16, 32, 15, 6, 0, 1, False),      # strided
+    (2, 37, 71, 64, 5, 1, 2, 1, False),        # MFCCEncoder conv1 (odd channel count -> scalar loads)
+    (4, 34, 300, 300, 2, 1, 4, 4, True),       # TCN block, dilation 4, causal + chomp
+    (5, 34, 27, 16, 3, 1, 0, 1, False),        # ConvDiscriminator pre_conv
+    (70, 1, 37, 32, 1, 1, 0, 1, False),        # Linear
+    (1, 5, 8, 1, 1, 1, 0, 1, False),           # single output column
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv1d_nlc_forward_backward(S, case):
+    ops = S['ops']
+    N, Lin, Cin, Cout, k, stride, pad, dil, causal = case
+    g = torch.Generator().manual_seed(sum(case[:8]))
+    x = torch.randn(N, Lin, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    if causal:
+        yr = F.conv1d(xr.transpose(1, 2), wr, br, padding=pad, dilation=dil)[:, :, :-pad].transpose(1, 2)
+    else:
+        yr = F.conv1d(xr.transpose(1, 2), wr, br, stride=stride, padding=pad, dilation=dil).transpose(1, 2)
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    yg = ops.conv1d_nlc(xg, wg, bg, stride=stride, pad=pad, dil=dil, lout=Lin if causal else None)
+    assert rel(yg, yr) < TOL
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.cuda())
+    assert rel(xg.grad, xr.grad) < TOL
+    assert rel(wg.grad, wr.grad) < TOL
+    assert rel(bg.grad, br.grad) < TOL
+
+
+def test_conv_reads_and_writes_column_slices(S):
+    ops = S['ops']
+    g = torch.Generator().manual_seed(3)
+    wide = torch.randn(6, 10, 40, generator=g)
+    w = torch.randn(12, 16, 3, generator=g)
+    ref = F.conv1d(wide[..., 8:24].transpose(1, 2), w, padding=1).transpose(1, 2)
+    out = ops.conv1d_nlc(wide.cuda()[..., 8:24], w.cuda(), None, pad=1)
+    assert rel(out, ref) < TOL
+
+
+@pytest.mark.parametrize('act,slope', [('leaky', 0.3), ('leaky', 0.0), ('sigmoid', 0.0)])
+def test_linear_fused_activation(S, act, slope):
+    ops, lib = S['ops'], S['lib']
+    g = torch.Generator().manual_seed(5)
+    x, w, b = torch.randn(9, 34, generator=g), torch.randn(7, 34, generator=g), torch.randn(7, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    z = F.linear(xr, wr, b)
+    yr = torch.sigmoid(z) if act == 'sigmoid' else F.leaky_relu(z, slope)
+    xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    yg = ops.linear(xg, wg, b.cuda(), act=lib.ACT_SIGMOID if act == 'sigmoid' else lib.ACT_LEAKY, slope=slope)
+    assert rel(yg, yr) < TOL
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.cuda())
+    assert rel(xg.grad, xr.grad) < TOL and rel(wg.grad, wr.grad) < TOL
+
+
+def test_conv_epilogue_dropout_uses_materialised_mask(S):
+    ops, noise, lib = S['ops'], S['noise'], S['lib']
+    g = torch.Generator().manual_seed(7)
+    x, w, b = torch.randn(3, 20, 24, generator=g), torch.randn(40, 24, 2, generator=g) / 7, torch.randn(40, generator=g)
+    noise.manual_seed(11)
+    nz = noise.begin_pass('cuda')
+    xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    y = ops.conv1d_nlc(xg, wg, b.cuda(), pad=2, dil=2, lout=20, act=lib.ACT_LEAKY, slope=0.0, drop_p=0.3, noise=nz,
+                       site=17)
+    mask = ops.dropout_mask(nz, 17, 0.3, (3, 20, 40)).cpu()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.relu(F.conv1d(xr.transpose(1, 2), wr, b, padding=2, dilation=2)[:, :, :-2].transpose(1, 2)) * mask
+    assert rel(y, yr) < TOL
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    y.backward(dy.cuda())
+    assert rel(xg.grad, xr.grad) < TOL and rel(wg.grad, wr.grad) < TOL
+
+
+@pytest.mark.parametrize('slope', [0.3, 1.0, 0.0])
+def test_batch_norm_act_train_and_eval(S, slope):
+    ops = S['ops']
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(6, 37, 48, generator=g) * 2 + 0.5
+    bn_r = torch.nn.BatchNorm1d(48)
+    with torch.no_grad():
+        bn_r.weight.uniform_(0.5, 1.5, generator=g)
+        bn_r.bias.uniform_(-0.5, 0.5, generator=g)
+    bn_g = torch.nn.BatchNorm1d(48)
+    bn_g.load_state_dict(bn_r.state_dict())
+    bn_g.cuda()
+    xr = x.clone().requires_grad_(True)
+    yr = F.leaky_relu(bn_r(xr.transpose(1, 2)), slope).transpose(1, 2)
+    xg = x.cuda().requires_grad_(True)
+    yg = ops.batch_norm_act(xg, bn_g, slope=slope)
+    assert rel(yg, yr) < TOL
+    assert rel(bn_g.running_mean, bn_r.running_mean) < TOL and rel(bn_g.running_var, bn_r.running_var) < TOL
+    assert int(bn_g.num_batches_tracked) == 1
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.cuda())
+    assert rel(xg.grad, xr.grad) < 5 * TOL
+    assert rel(bn_g.weight.grad, bn_r.weight.grad) < TOL and rel(bn_g.bias.grad, bn_r.bias.grad) < TOL
+    bn_r.eval(), bn_g.eval()
+    assert rel(ops.batch_norm_act(x.cuda(), bn_g, slope=slope), F.leaky_relu(bn_r(x.transpose(1, 2)), slope).transpose(1, 2)) < TOL
+
+
+def test_batch_norm_channel_map_is_batchnorm2d(S):
+    ops = S['ops']
+    g = torch.Generator().manual_seed(10)
+    N, T, V, Cc = 4, 11, 9, 16
+    x = torch.randn(N, Cc, T, V, generator=g)
+    bn_r, bn_g = torch.nn.BatchNorm2d(Cc), torch.nn.BatchNorm2d(Cc).cuda()
+    cmap = torch.arange(V * Cc, dtype=torch.int32) % Cc          # columns ordered (v, c)
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(bn_r(xr))
+    xg = x.permute(0, 2, 3, 1).reshape(N, T, V * Cc).cuda().requires_grad_(True)
+    yg = ops.batch_norm_act(xg, bn_g, slope=0.0, chan_map=cmap.cuda())
+    assert rel(yg.view(N, T, V, Cc).permute(0, 3, 1, 2), yr) < TOL
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.permute(0, 2, 3, 1).reshape(N, T, V * Cc).cuda())
+    assert rel(xg.grad.view(N, T, V, Cc).permute(0, 3, 1, 2), xr.grad) < 5 * TOL
+    assert rel(bn_g.weight.grad, bn_r.weight.grad) < TOL
+    assert rel(bn_g.running_var, bn_r.running_var) < TOL
+
+
+def _gru_sd(I, H, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    k = 1 / math.sqrt(H)
+    return {n: (torch.rand(s, generator=g) * 2 - 1) * k for n, s in O._gru_shapes('gru.', I, H, L).items()}
+
+
+def _flat(sd, L):
+    out = []
+    for l in range(L):
+        for suf in ('', '_reverse'):
+            out += [sd[f'gru.weight_ih_l{l}{suf}'], sd[f'gru.weight_hh_l{l}{suf}'], sd[f'gru.bias_ih_l{l}{suf}'],
+                    sd[f'gru.bias_hh_l{l}{suf}']]
+    return out
+
+
+@pytest.mark.parametrize('B,T,I,H,L,sum_dirs,p', [(5, 7, 11, 32, 3, False, 0.0), (9, 6, 88, 300, 2, True, 0.0),
+                                                   (10, 34, 8, 64, 4, True, 0.3), (3, 5, 20, 32, 2, False, 0.3)])
+def test_gru_forward_backward(S, B, T, I, H, L, sum_dirs, p):
+    ops, noise = S['ops'], S['noise']
+    sd = _gru_sd(I, H, L, B * 100 + H)
+    g = torch.Generator().manual_seed(B + T)
+    x = torch.randn(B, T, I, generator=g)
+    noise.manual_seed(5)
+    nz = noise.begin_pass('cuda')
+    site0 = 300
+    wg = [w.cuda().requires_grad_(True) for w in _flat(sd, L)]
+    xg = x.cuda().requires_grad_(True)
+    yg = ops.gru(xg, wg, H, L, True, p, nz, site0, sum_dirs)
+    pinned = {f'gru.drop{l}': ops.dropout_mask(nz, site0 + l, p, (B, T, 2 * H)).cpu() for l in range(L - 1)} \
+        if p > 0 else 'off'
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.gru(sdr, 'gru.', xr, True, p, O.Noise(pinned), 'gru')
+    if sum_dirs:
+        yr = yr[..., :H] + yr[..., H:]
+    assert rel(yg, yr) < TOL
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.cuda())
+    assert rel(xg.grad, xr.grad) < 2 * TOL
+    names = []
+    for l in range(L):
+        for suf in ('', '_reverse'):
+            names += [f'gru.weight_ih_l{l}{suf}', f'gru.weight_hh_l{l}{suf}', f'gru.bias_ih_l{l}{suf}',
+                      f'gru.bias_hh_l{l}{suf}']
+    for n, w in zip(names, wg):
+        assert rel(w.grad, sdr[n].grad) < 2 * TOL, n
+
+
+def test_embedding_dropout_and_dense_gradient(S):
+    ops, noise = S['ops'], S['noise']
+    g = torch.Generator().manual_seed(12)
+    table = torch.randn(50, 300, generator=g)
+    ids = torch.randint(0, 50, (4, 34), generator=g)
+    ids[0, :5] = 3                                    # repeated rows exercise the atomics
+    noise.manual_seed(2)
+    nz = noise.begin_pass('cuda')
+    tg = table.cuda().requires_grad_(True)
+    out = ops.embedding(ids.cuda(), tg, 0.1, nz, 21)
+    mask = ops.dropout_mask(nz, 21, 0.1, (4, 34, 300)).cpu()
+    tr = table.clone().requires_grad_(True)
+    ref = F.embedding(ids, tr) * mask
+    assert rel(out, ref) < 1e-6
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    out.backward(dy.cuda())
+    assert rel(tg.grad, tr.grad) < TOL
+
+
+def test_weight_norm(S):
+    ops = S['ops']
+    g = torch.Generator().manual_seed(13)
+    v, gg = torch.randn(300, 300, 2, generator=g), torch.rand(300, 1, 1, generator=g) + 0.5
+    vr, gr = v.clone().requires_grad_(True), gg.clone().requires_grad_(True)
+    wr = O.weight_norm_weight(gr, vr)
+    vg, g2 = v.cuda().requires_grad_(True), gg.cuda().requires_grad_(True)
+    wg = ops.weight_norm(vg, g2)
+    assert rel(wg, wr) < TOL
+    dw = torch.randn(wr.shape, generator=g)
+    wr.backward(dw)
+    wg.backward(dw.cuda())
+    assert rel(vg.grad, vr.grad) < TOL and rel(g2.grad, gr.grad) < TOL
+
+
+def test_csr_fold_and_its_transpose(S):
+    import scipy.sparse as sp
+    ops = S['ops']
+    rs = np.random.RandomState(0)
+    m = sp.random(700, 90, density=0.05, random_state=rs, format='csr', dtype=np.float64)
+    csr = ops.CSR(m, 'cuda')
+    w = torch.randn(90, dtype=torch.float32)
+    wg = w.cuda().requires_grad_(True)
+    y = ops.fold(wg, csr)
+    dense = torch.from_numpy(m.toarray()).float()
+    assert rel(y, dense @ w) < TOL
+    dy = torch.randn(700)
+    y.backward(dy.cuda())
+    assert rel(wg.grad, dense.t() @ dy) < TOL
+
+
+def test_add_act_and_transposed_slices(S):
+    ops = S['ops']
+    g = torch.Generator().manual_seed(14)
+    a, b = torch.randn(5, 9, 30, generator=g), torch.randn(5, 9, 30, generator=g)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.leaky_relu(ar + br, 0.01)
+    ag, bg = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yg = ops.add_act(ag, bg, 0.01)
+    assert rel(yg, yr) < 1e-6
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.cuda())
+    assert rel(ag.grad, ar.grad) < 1e-6 and rel(bg.grad, br.grad) < 1e-6
+
+
+def test_reparametrize(S):
+    ops, noise = S['ops'], S['noise']
+    g = torch.Generator().manual_seed(15)
+    mu, lv = torch.randn(6, 16, generator=g), torch.randn(6, 16, generator=g) * 0.3
+    noise.manual_seed(3)
+    nz = noise.begin_pass('cuda')
+    mg, lg = mu.cuda().requires_grad_(True), lv.cuda().requires_grad_(True)
+    z = ops.reparametrize(mg, lg, nz, 33)
+    eps = ops.normal_noise(nz, 33, (6, 16)).cpu()
+    mr, lr_ = mu.clone().requires_grad_(True), lv.clone().requires_grad_(True)
+    zr = O.re_parametrize(mr, lr_, O.Noise({'eps': eps}))
+    assert rel(z, zr) < TOL
+    dz = torch.randn(6, 16, generator=g)
+    zr.backward(dz)
+    z.backward(dz.cuda())
+    assert rel(mg.grad, mr.grad) < TOL and rel(lg.grad, lr_.grad) < TOL
+
+
+def test_losses_and_gradients(S):
+    ops = S['ops']
+    g = torch.Generator().manual_seed(16)
+    B, T, P = 6, 34, 27
+    dr, df = torch.rand(B, 1, generator=g) * 0.9 + 0.05, torch.rand(B, 1, generator=g) * 0.9 + 0.05
+    drr, dfr = dr.clone().requires_grad_(True), df.clone().requires_grad_(True)
+    lr_ = O.dis_loss(drr, dfr)
+    drg, dfg = dr.cuda().requires_grad_(True), df.cuda().requires_grad_(True)
+    lg = ops.dis_loss(drg, dfg)
+    assert rel(lg, lr_) < TOL
+    lr_.backward()
+    lg.backward()
+    assert rel(drg.grad, drr.grad) < TOL and rel(dfg.grad, dfr.grad) < TOL
+
+    out, tgt = torch.randn(B, T, P, generator=g) * 0.3, torch.randn(B, T, P, generator=g) * 0.2
+    out_rand = out + torch.randn(B, T, P, generator=g) * 0.02
+    out_rand[0] = out[0] + 5.0                         # forces the clamp(-1000) branch for one clip
+    out_tri = torch.randn(B, T, P, generator=g) * 0.2
+    z, z_rand = torch.randn(B, 16, generator=g), torch.randn(B, 16, generator=g)
+    z_rand[0] = z[0] + 1e-4
+    mu, lv = torch.randn(B, 16, generator=g), torch.randn(B, 16, generator=g) * 0.3
+    dis_out = torch.rand(B, 1, generator=g) * 0.9 + 0.05
+    scfg = O.StepCfg()
+    req = [t.clone().requires_grad_(True) for t in (out, dis_out, mu, lv)]
+    loss_r, comp = O.gen_losses(scfg, req[0], tgt, req[1], out_rand, z, z_rand, req[2], req[3], True)
+    loss_r.backward()
+    gq = [t.cuda().requires_grad_(True) for t in (out, dis_out, mu, lv)]
+    total, comps = ops.gen_loss(gq[0], gq[1], gq[2], gq[3], tgt.cuda(), out_tri.cuda(), out_rand.cuda(), z.cuda(),
+                                z_rand.cuda(), (scfg.loss_regression_weight, scfg.loss_gan_weight,
+                                                scfg.loss_reg_weight, scfg.loss_kld_weight))
+    total.backward()
+    c = comps.cpu()
+    assert rel(total, loss_r) < TOL
+    for i, k in ((1, 'huber'), (2, 'gen'), (3, 'div_reg'), (4, 'kld')):
+        assert abs(float(c[i]) - float(comp[k])) < TOL * max(1.0, abs(float(comp[k]))), k
+    assert abs(float(c[5]) - float(F.l1_loss(out, tgt))) < 1e-6
+    assert abs(float(c[6]) - float(F.l1_loss(out_tri, tgt))) < 1e-6
+    for a, b in zip(gq, req):
+        assert rel(a.grad, b.grad) < TOL
+
+
+def test_fused_adam_matches_torch_adam(S):
+    optim = S['optim']
+    g = torch.Generator().manual_seed(17)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in ((7, 5), (13,), (3, 4, 2))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt_r = torch.optim.Adam(ref, lr=5e-4, betas=(0.5, 0.999))
+    gp = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ps]
+    arena = optim.ParamArena(gp)
+    opt_g = optim.FusedAdam(arena, lr=5e-4, betas=(0.5, 0.999))
+    for _ in range(5):
+        opt_g.zero_grad()
+        for p, q in zip(ref, gp):
+            gr = torch.randn(p.shape, generator=g)
+            p.grad = gr.clone()
+            q.grad.add_(gr.cuda())
+        opt_r.step()
+        opt_g.step()
+    for p, q in zip(ref, gp):
+        assert rel(q, p) < 1e-5

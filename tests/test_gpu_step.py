@@ -1,0 +1,195 @@
+"""The GAN training step on the GPU (Processor.forward_pass_s2ag / train_step):
+  (1) against the 3-step trace recorded from the REFERENCE's Processor.forward_pass_s2ag (dropout off, the eps the
+      product draws were fed to the reference through tests/golden/s2ag_rng.py),
+  (2) with dropout ON against the oracle's gan_step fed with the product's materialised masks,
+  (3) HIP-graph replay == eager execution from the same state."""
+import copy
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import s2ag_oracle as O  # noqa: E402
+from s2ag_testing import (G_Z_SITE, PASSES_PER_STEP, PGT_Z_SITE, STEP_SEED, Vocab, make_cfg, oracle_cfg,  # noqa: E402
+                          recipe_sds, set_dropout, to_cuda)
+
+TOL = 3e-4
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
+
+
+def make_processor(hidden, n_words, n_spk, B, seed0, drop, hip_graph=False):
+    from speech2affective_gestures_amd import processor_v2 as P
+    cfg = make_cfg(hidden, drop)
+    lang = types.SimpleNamespace(n_words=n_words, word_embedding_weights=None)
+    meta = types.SimpleNamespace(n_poses=34, expected_audio_length=36267, num_mfcc_combined=37, lang_model=lang,
+                                 speaker_model=Vocab(n_spk), n_samples=0)
+    args = types.SimpleNamespace(batch_size=B, train_s2ag=True, work_dir_s2ag=None, save_log=False, print_log=False,
+                                 hip_graph=hip_graph)
+    pr = P.Processor('.', args, cfg, {'train_data_s2ag': meta, 'val_data_s2ag': meta, 'test_data_s2ag': meta}, 27, 3,
+                     16000)
+    sds = recipe_sds(hidden, n_words, n_spk, seed0)
+    pr.s2ag_generator.load_state_dict(sds['G'], strict=True)
+    pr.s2ag_discriminator.load_state_dict(sds['D'], strict=True)
+    pr.trimodal_generator.load_state_dict(sds['T3'], strict=True)
+    pr.s2ag_generator.z_site, pr.trimodal_generator.z_site = G_Z_SITE, PGT_Z_SITE
+    pr.meta_info['epoch'] = 1
+    for m in (pr.s2ag_generator, pr.s2ag_discriminator, pr.trimodal_generator):
+        m.train()
+    return pr, sds
+
+
+def _abs_groups(sd):
+    groups = {}
+    for k, v in sd.items():
+        if '.net.' in k or k.endswith('num_batches_tracked'):
+            continue
+        top = k.split('.')[0]
+        groups[top] = groups.get(top, 0.0) + float(v.double().abs().sum())
+    return groups
+
+
+def test_three_steps_match_the_reference_trace(golden_dir, monkeypatch):
+    from speech2affective_gestures_amd import noise
+    from speech2affective_gestures_amd import processor_v2 as P
+    g = dict(np.load(os.path.join(golden_dir, 'step_small.npz')))
+    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 4, 4000
+    pr, _ = make_processor(hidden, n_words, n_spk, B, s0, 0.0)
+    for m in (pr.s2ag_generator, pr.s2ag_discriminator, pr.trimodal_generator):
+        set_dropout(m, 0.0, 0.0, 0.0)
+    noise.manual_seed(STEP_SEED)
+    real_randperm = torch.randperm
+    for s in range(3):
+        perm = torch.from_numpy(g[f's{s}.perm']).cuda()
+        monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm)
+        inp = to_cuda(O.recipe_inputs(B, 34, s0 + 100 + s, n_words, n_spk))
+        ret = pr.forward_pass_s2ag(inp['in_text'], inp['in_audio'], inp['in_mfcc'], inp['target'], inp['vid'], True)
+        monkeypatch.setattr(P.torch, 'randperm', real_randperm)
+        L = pr.last_losses
+        assert L['dis'] == pytest.approx(float(g[f's{s}.dis_error']), rel=TOL)
+        assert L['total'] == pytest.approx(float(g[f's{s}.loss']), rel=TOL)
+        assert ret[0] == pytest.approx(float(g[f's{s}.metric']), rel=5e-3, abs=2e-6)
+        assert len(ret) == 7 and all(r is None for r in ret[1:])
+        if s == 0:
+            named = dict(pr.s2ag_generator.named_parameters())
+            for k in g:
+                if k.startswith('s0.grad.G.'):
+                    assert rel(named[k[10:]].grad, g[k]) < 5 * TOL, k
+        for tag, mod in (('G', pr.s2ag_generator), ('D', pr.s2ag_discriminator)):
+            for top, val in _abs_groups(mod.state_dict()).items():
+                assert val == pytest.approx(float(g[f's{s}.abs.{tag}.{top}']), rel=2e-5), (s, tag, top)
+    sdG, sdD = pr.s2ag_generator.state_dict(), pr.s2ag_discriminator.state_dict()
+    for k in g:
+        if k.startswith('final.G.'):
+            assert rel(sdG[k[8:]], g[k]) < TOL, k
+        if k.startswith('final.D.'):
+            assert rel(sdD[k[8:]], g[k]) < TOL, k
+
+
+def _materialise_step_noise(pr, counter0, B, T, hidden):
+    """Pinned noise of the 7 passes of one product step, named for the oracle."""
+    from speech2affective_gestures_amd import ops
+
+    def snap(k):
+        return torch.tensor([STEP_SEED, counter0 + k], dtype=torch.int64, device='cuda')
+
+    def gen_noise(G, nz, with_aff):
+        pin = {'eps': ops.normal_noise(nz, G.z_site, (B, 16)).cpu()}
+        te = G.text_encoder
+        pin['text_encoder.emb_drop'] = ops.dropout_mask(nz, te.site, te.drop.p, (B, T, 300)).cpu()
+        for i, blk in enumerate(te.tcn.network):
+            for j in (0, 1):
+                pin[f'text_encoder.tcn.{i}.drop{j + 1}'] = \
+                    ops.dropout_mask(nz, blk.sites[j], blk.p, (B, T, hidden)).cpu().transpose(1, 2)
+        for l in range(G.gru.num_layers - 1):
+            pin[f'gru.drop{l}'] = ops.dropout_mask(nz, G.gru.site0 + l, G.gru.dropout,
+                                                   (B, T, 2 * G.gru.hidden_size)).cpu()
+        return O.Noise(pin)
+
+    def dis_noise(D, nz):
+        return O.Noise({f'gru.drop{l}': ops.dropout_mask(nz, D.gru.site0 + l, 0.3, (B, T, 128)).cpu()
+                        for l in range(3)})
+    G, D, T3 = pr.s2ag_generator, pr.s2ag_discriminator, pr.trimodal_generator
+    return O.StepNoise(g_dis=gen_noise(G, snap(0), True), d_real=dis_noise(D, snap(1)), d_fake=dis_noise(D, snap(2)),
+                       pgt=gen_noise(T3, snap(3), False), g_main=gen_noise(G, snap(4), True),
+                       d_gen=dis_noise(D, snap(5)), g_rand=gen_noise(G, snap(6), True))
+
+
+def test_two_steps_with_dropout_match_the_oracle(monkeypatch):
+    from speech2affective_gestures_amd import noise
+    from speech2affective_gestures_amd import processor_v2 as P
+    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 6, 8000
+    pr, sds = make_processor(hidden, n_words, n_spk, B, s0, 0.3)
+    G, D, T3 = ({k: v.clone() for k, v in sds[n].items()} for n in ('G', 'D', 'T3'))
+    gopt, dopt, scfg, oc = O.AdamState(), O.AdamState(), O.StepCfg(), oracle_cfg(hidden, 0.3)
+    noise.manual_seed(STEP_SEED)
+    for s in range(2):
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(s))
+        monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm.cuda())
+        inp = O.recipe_inputs(B, 34, s0 + 100 + s, n_words, n_spk)
+        gi = to_cuda(inp)
+        nz = _materialise_step_noise(pr, PASSES_PER_STEP * s, B, 34, hidden)
+        nz.perm = perm
+        ret = pr.forward_pass_s2ag(gi['in_text'], gi['in_audio'], gi['in_mfcc'], gi['target'], gi['vid'], True)
+        monkeypatch.undo()
+        metric, losses, grads = O.gan_step(G, D, T3, gopt, dopt, oc, scfg, inp['in_text'], inp['in_audio'],
+                                           inp['in_mfcc'], inp['target'], inp['vid'], epoch=1, noise=nz)
+        for k in ('dis', 'total', 'loss', 'KLD', 'DIV_REG', 'gen'):
+            assert pr.last_losses[k] == pytest.approx(losses[k], rel=TOL, abs=1e-6), (s, k)
+        assert ret[0] == pytest.approx(metric, rel=5e-3, abs=2e-6)
+        for k, p in pr.s2ag_generator.named_parameters():
+            if '.net.' not in k:
+                assert rel(p.grad, grads['G'][k]) < 10 * TOL, (s, k)
+    for k, v in pr.s2ag_generator.state_dict().items():
+        if not k.endswith('num_batches_tracked'):
+            assert rel(v, G[k]) < TOL, k
+    for k, v in pr.s2ag_discriminator.state_dict().items():
+        if not k.endswith('num_batches_tracked'):
+            assert rel(v, D[k]) < TOL, k
+    assert int(pr.s2ag_generator.state_dict()['aff_encoder.batch_norm1.num_batches_tracked']) == 6
+
+
+def test_hip_graph_replay_equals_eager(monkeypatch):
+    from speech2affective_gestures_amd import noise
+    from speech2affective_gestures_amd import processor_v2 as P
+    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 8, 9000
+    perm = torch.arange(B - 1, -1, -1).cuda()
+    monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm)
+    batches = [to_cuda(O.recipe_inputs(B, 34, s0 + 100 + s, n_words, n_spk)) for s in range(3)]
+
+    def run(graph):
+        pr, _ = make_processor(hidden, n_words, n_spk, B, s0, 0.3, hip_graph=graph)
+        if graph:       # capture (3 warm-up steps touch the state) ... then rewind everything to the start state
+            state = dict(G=copy.deepcopy(pr.s2ag_generator.state_dict()), D=copy.deepcopy(pr.s2ag_discriminator.state_dict()),
+                         T=copy.deepcopy(pr.trimodal_generator.state_dict()),
+                         og=copy.deepcopy(pr.s2ag_gen_optimizer.state_dict()), od=copy.deepcopy(pr.s2ag_dis_optimizer.state_dict()))
+            b = batches[0]
+            pr._build_graphed(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'])
+            pr.s2ag_generator.load_state_dict(state['G'])
+            pr.s2ag_discriminator.load_state_dict(state['D'])
+            pr.trimodal_generator.load_state_dict(state['T'])
+            pr.s2ag_gen_optimizer.load_state_dict(state['og'])
+            pr.s2ag_dis_optimizer.load_state_dict(state['od'])
+        noise.manual_seed(STEP_SEED)
+        out = []
+        for b in batches:
+            m = pr.train_step(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'])
+            out.append((m, dict(pr.last_losses)))
+        return out, {k: v.clone() for k, v in pr.s2ag_generator.state_dict().items()}
+    eager, sd_e = run(False)
+    graphed, sd_g = run(True)
+    for (me, le), (mg, lg) in zip(eager, graphed):
+        assert mg == pytest.approx(me, rel=1e-3, abs=1e-6)
+        for k in le:
+            assert lg[k] == pytest.approx(le[k], rel=1e-4, abs=1e-6), k
+    for k in sd_e:
+        if not k.endswith('num_batches_tracked'):
+            assert rel(sd_g[k], sd_e[k]) < 1e-4, k
