@@ -119,10 +119,12 @@ def cpu_baseline(B, steps=2):
     from oracle import s2ag_oracle as O
     try:
         import psutil
-        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+        phys = psutil.cpu_count(logical=False) or os.cpu_count()
     except Exception:
-        cores = os.cpu_count()
-    torch.set_num_threads(cores)
+        phys = os.cpu_count()
+    # the step is a chain of small ops: oversubscribing a many-core host makes it SLOWER, so the baseline uses the
+    # fastest of a few thread counts (1 probe step each) -- the number reported is the best the host can do
+    cand = sorted({c for c in (8, 16, 32, 64, phys) if c <= phys})
     oc = O.ModelCfg()
     G = O.recipe_state_dict(O.generator_shapes(oc, N_WORDS, N_SPK), 1)
     D = O.recipe_state_dict(O.aff_discriminator_shapes(), 2)
@@ -133,14 +135,24 @@ def cpu_baseline(B, steps=2):
     def one():
         O.gan_step(G, D, T3, gopt, dopt, oc, scfg, inp['in_text'], inp['in_audio'], inp['in_mfcc'], inp['target'],
                    inp['vid'], epoch=1, noise=O.StepNoise.fresh(), fast=True)
-    one()
+    torch.set_num_threads(cand[0])
+    one()                                             # warm-up (allocator, lazy inits)
+    best, cores = None, cand[0]
+    for c in cand:
+        torch.set_num_threads(c)
+        t0 = time.perf_counter()
+        one()
+        d = time.perf_counter() - t0
+        if best is None or d < best:
+            best, cores = d, c
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     for _ in range(steps):
         one()
     dt = (time.perf_counter() - t0) / steps
-    return dict(value=B / dt, unit='clips/s', cores=cores, kind='port',
+    return dict(value=B / dt, unit='clips/s', cores=cores, kind='port', physical_cores=phys,
                 sample=f'{steps} timed GAN steps (+1 warm-up) of the CPU oracle at batch {B}, T=34, fp32, '
-                       f'torch {torch.__version__}, {cores} threads; {dt * 1e3:.0f} ms/step')
+                       f'torch {torch.__version__}, {cores} threads (fastest of {cand}); {dt * 1e3:.0f} ms/step')
 
 
 def main():

@@ -79,16 +79,19 @@ int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw, const
 /* out[c] (+)= sum_r x[r*ld + c]; if sq != NULL also sq[c] (+)= sum_r x^2.   (bias grads, BN batch statistics) */
 int s2ag_colsum(const float* x, int rows, int cols, int ld, float* out, float* sq /*nullable*/, int accumulate,
                 void* stream);
+/* fp64 column sums of x and x^2 for the BatchNorm batch statistics: E[x^2]-E[x]^2 is only safe in double
+ * (a nearly constant channel -- e.g. the mostly-zero seed-pose input -- cancels catastrophically in fp32). */
+int s2ag_colstats_f64(const float* x, int rows, int cols, int ld, double* sum, double* sq, void* stream);
 
 /* BatchNorm over a channels-last matrix whose COLUMNS map onto BN channels through chan_of_col
  * (identity for BatchNorm1d on (B,C,L); many-to-one for BatchNorm2d on the folded ST-GCN layout).
  * replaces: nn.BatchNorm1d/2d -- net/multimodal_context_net_v2.py:19,22,25 (Wav), :40-46 (MFCC),
  * :128,:139,:144,:149 (AffEncoder), :398,:401 (pre_conv); net/utils/tgcn.py:180,189,206.
  *
- * s2ag_bn_coeffs: training != 0: from column sums/sumsq (s2ag_colsum) compute per-channel batch mean and
+ * s2ag_bn_coeffs: training != 0: from fp64 column sums/sumsq (s2ag_colstats_f64) compute per-channel batch mean and
  *   biased variance, update running_mean/var (momentum, unbiased var) and num_batches_tracked (int64),
  *   and emit per-COLUMN scale/shift/mean/invstd.  training == 0: coefficients from the running statistics. */
-int s2ag_bn_coeffs(const float* colsum, const float* colsq, const int* chan_of_col, int ncols, int nchan,
+int s2ag_bn_coeffs(const double* colsum, const double* colsq, const int* chan_of_col, int ncols, int nchan,
                    int rows, const float* gamma, const float* beta, float* running_mean, float* running_var,
                    long long* num_batches_tracked /*nullable*/, float eps, float momentum, int training,
                    float* scale_col, float* shift_col, float* mean_col, float* invstd_col, void* stream);

@@ -27,6 +27,7 @@ SIGNATURES = {
     's2ag_conv1d_nlc_bwd_data': [vp, vp, vp, PG, ci, vp],
     's2ag_conv1d_nlc_bwd_weight': [vp, vp, vp, PG, ci, vp],
     's2ag_colsum': [vp, ci, ci, ci, vp, vp, ci, vp],
+    's2ag_colstats_f64': [vp, ci, ci, ci, vp, vp, vp],
     's2ag_bn_coeffs': [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp],
     's2ag_bn_apply': [vp, ci, ci, ci, vp, vp, cf, vp, ci, vp],
     's2ag_bn_bwd_reduce': [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp],

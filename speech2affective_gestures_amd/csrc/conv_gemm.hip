@@ -311,6 +311,30 @@ __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ x, int
     }
 }
 
+__global__ __launch_bounds__(256) void colstats_f64_k(const float* __restrict__ x, int rows, int cols, int ld,
+                                                      int rows_per_block, double* out, double* sq) {
+    __shared__ double s1[4][64], s2[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    const int rbeg = blockIdx.y * rows_per_block;
+    const int rend = min(rows, rbeg + rows_per_block);
+    double a = 0.0, b = 0.0;
+    if (c < cols)
+        for (int r = rbeg + ry; r < rend; r += 4) {
+            const double v = (double)x[(long long)r * ld + c];
+            a += v;
+            b += v * v;
+        }
+    s1[ry][threadIdx.x & 63] = a;
+    s2[ry][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        const int i = threadIdx.x;
+        atomicAdd(out + c, s1[0][i] + s1[1][i] + s1[2][i] + s1[3][i]);
+        atomicAdd(sq + c, s2[0][i] + s2[1][i] + s2[2][i] + s2[3][i]);
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool bad_geom(const s2ag_conv_geom* g) {
@@ -411,6 +435,21 @@ extern "C" int s2ag_colsum(const float* x, int rows, int cols, int ld, float* ou
     while (rpb > 64 && (long long)cdiv(rows, rpb) * colblocks < 1024) rpb >>= 1;
     dim3 grid(colblocks, cdiv(rows, rpb));
     hipLaunchKernelGGL(colsum_k, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, rpb, out, sq);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_colstats_f64(const float* x, int rows, int cols, int ld, double* sum, double* sq, void* stream) {
+    if (!x || !sum || !sq || rows <= 0 || cols <= 0 || ld < cols) return S2AG_E_BADARG;
+    hipError_t me = hipMemsetAsync(sum, 0, sizeof(double) * cols, (hipStream_t)stream);
+    if (me != hipSuccess) return (int)me;
+    me = hipMemsetAsync(sq, 0, sizeof(double) * cols, (hipStream_t)stream);
+    if (me != hipSuccess) return (int)me;
+    int rpb = 256;
+    const int colblocks = cdiv(cols, 64);
+    while (rpb > 64 && (long long)cdiv(rows, rpb) * colblocks < 1024) rpb >>= 1;
+    dim3 grid(colblocks, cdiv(rows, rpb));
+    hipLaunchKernelGGL(colstats_f64_k, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, rpb, sum, sq);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -13,7 +13,7 @@
 namespace {
 using namespace s2ag;
 
-constexpr int NT = 512;
+constexpr int NT = 1024;   // 16 waves: enough loads in flight to cover the L2 latency of the W_hh stream
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_k(const float* __restrict__ gi
 #pragma unroll
             for (int b = 0; b < BS; ++b) acc[b][0] = acc[b][1] = acc[b][2] = acc[b][3] = 0.f;
             const float* wp = W + (long long)kbeg * H3 + cg * 4;
-#pragma unroll 4
+#pragma unroll 8
             for (int k = kbeg; k < kend; ++k) {
                 const float4 w = *reinterpret_cast<const float4*>(wp);
                 wp += H3;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_k(const float* __restrict__ dy
 #pragma unroll
             for (int b = 0; b < BS; ++b) acc[b][0] = acc[b][1] = acc[b][2] = acc[b][3] = 0.f;
             const float* wp = W + (long long)kbeg * H + cg * 4;
-#pragma unroll 4
+#pragma unroll 8
             for (int k = kbeg; k < kend; ++k) {
                 const float4 w = *reinterpret_cast<const float4*>(wp);
                 wp += H;

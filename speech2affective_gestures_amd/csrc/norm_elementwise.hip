@@ -8,47 +8,47 @@ using namespace s2ag;
 
 // One block.  Folds per-COLUMN sums into per-CHANNEL statistics through chan_of_col (LDS atomics),
 // updates the running estimates, then scatters the per-channel coefficients back to columns.
-__global__ __launch_bounds__(256) void bn_coeffs_k(const float* colsum, const float* colsq, const int* chan_of_col,
+__global__ __launch_bounds__(256) void bn_coeffs_k(const double* colsum, const double* colsq, const int* chan_of_col,
                                                    int ncols, int nchan, int rows, const float* gamma,
                                                    const float* beta, float* rmean, float* rvar, long long* nbt,
                                                    float eps, float momentum, int training, float* scale_col,
                                                    float* shift_col, float* mean_col, float* invstd_col) {
-    extern __shared__ float sm[];
-    float* cs = sm;               // nchan
-    float* cq = sm + nchan;       // nchan
-    float* cn = sm + 2 * nchan;   // nchan (columns per channel)
-    for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) sm[i] = 0.f;
+    extern __shared__ double smd[];
+    double* cs = smd;               // nchan: sum  -> mean
+    double* cq = smd + nchan;       // nchan: sumsq -> invstd
+    double* cn = smd + 2 * nchan;   // nchan: columns per channel
+    for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) smd[i] = 0.0;
     __syncthreads();
     if (training) {
         for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
             const int ch = chan_of_col ? chan_of_col[c] : c;
             atomicAdd(&cs[ch], colsum[c]);
             atomicAdd(&cq[ch], colsq[c]);
-            atomicAdd(&cn[ch], 1.0f);
+            atomicAdd(&cn[ch], 1.0);
         }
         __syncthreads();
         for (int ch = threadIdx.x; ch < nchan; ch += blockDim.x) {
-            const float n = cn[ch] * (float)rows;
-            const float mean = cs[ch] / n;
-            float var = cq[ch] / n - mean * mean;
-            var = var < 0.f ? 0.f : var;
-            const float unbiased = n > 1.f ? var * n / (n - 1.f) : var;
-            rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * mean;
-            rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * unbiased;
+            const double n = cn[ch] * (double)rows;
+            const double mean = cs[ch] / n;
+            double var = cq[ch] / n - mean * mean;      // fp64: safe against cancellation
+            var = var < 0.0 ? 0.0 : var;
+            const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+            rmean[ch] = (float)((1.0 - (double)momentum) * (double)rmean[ch] + (double)momentum * mean);
+            rvar[ch] = (float)((1.0 - (double)momentum) * (double)rvar[ch] + (double)momentum * unbiased);
             cs[ch] = mean;
-            cq[ch] = rsqrtf(var + eps);
+            cq[ch] = 1.0 / sqrt(var + (double)eps);
         }
         if (threadIdx.x == 0 && nbt) *nbt += 1;
     } else {
         for (int ch = threadIdx.x; ch < nchan; ch += blockDim.x) {
-            cs[ch] = rmean[ch];
-            cq[ch] = rsqrtf(rvar[ch] + eps);
+            cs[ch] = (double)rmean[ch];
+            cq[ch] = 1.0 / sqrt((double)rvar[ch] + (double)eps);
         }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
         const int ch = chan_of_col ? chan_of_col[c] : c;
-        const float mean = cs[ch], invstd = cq[ch];
+        const float mean = (float)cs[ch], invstd = (float)cq[ch];
         const float sc = gamma[ch] * invstd;
         scale_col[c] = sc;
         shift_col[c] = beta[ch] - mean * sc;
@@ -199,7 +199,7 @@ inline int ew_grid(long long total) {
 }
 }  // namespace
 
-extern "C" int s2ag_bn_coeffs(const float* colsum, const float* colsq, const int* chan_of_col, int ncols, int nchan,
+extern "C" int s2ag_bn_coeffs(const double* colsum, const double* colsq, const int* chan_of_col, int ncols, int nchan,
                               int rows, const float* gamma, const float* beta, float* running_mean,
                               float* running_var, long long* nbt, float eps, float momentum, int training,
                               float* scale_col, float* shift_col, float* mean_col, float* invstd_col, void* stream) {
@@ -207,7 +207,7 @@ extern "C" int s2ag_bn_coeffs(const float* colsum, const float* colsq, const int
         !shift_col || !mean_col || !invstd_col)
         return S2AG_E_BADARG;
     if (training && (!colsum || !colsq)) return S2AG_E_BADARG;
-    hipLaunchKernelGGL(bn_coeffs_k, dim3(1), dim3(256), sizeof(float) * 3 * nchan, (hipStream_t)stream, colsum, colsq,
+    hipLaunchKernelGGL(bn_coeffs_k, dim3(1), dim3(256), sizeof(double) * 3 * nchan, (hipStream_t)stream, colsum, colsq,
                        chan_of_col, ncols, nchan, rows, gamma, beta, running_mean, running_var, nbt, eps, momentum,
                        training, scale_col, shift_col, mean_col, invstd_col);
     S2AG_LAUNCH_CHECK();

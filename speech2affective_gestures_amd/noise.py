@@ -26,6 +26,11 @@ def new_site(n: int = 1) -> int:
     return s
 
 
+def reset_sites(start: int = 0) -> None:
+    """Restart site numbering (tests: two identically constructed models then draw identical noise)."""
+    _site_counter[0] = start
+
+
 def _dev_state(device) -> torch.Tensor:
     device = torch.device(device)
     if device.type != 'cuda':

@@ -232,15 +232,16 @@ class _BNAct(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, rmean, rvar, nbt, chan_map, slope, training, eps, momentum):
         _need_cuda(x, gamma)
         lib = _lib()
+        ctx.in_shape = x.shape
         x, rows, cols, ldx = as_rows(x)
         nchan = gamma.numel()
         dev = x.device
         coef = torch.empty(4, cols, dtype=torch.float32, device=dev)
         s = sq = None
         if training:
-            stats = torch.empty(2, cols, dtype=torch.float32, device=dev)
+            stats = torch.empty(2, cols, dtype=torch.float64, device=dev)       # fp64 batch statistics
             s, sq = stats[0], stats[1]
-            colsum_raw(x, s, sq)
+            L.check(lib.s2ag_colstats_f64(_p(x), rows, cols, ldx, _p(s), _p(sq), _stream()), 'colstats_f64')
         L.check(lib.s2ag_bn_coeffs(_p(s), _p(sq), _p(chan_map), cols, nchan, rows, _p(gamma), _p(beta), _p(rmean),
                                    _p(rvar), _p(nbt), float(eps), float(momentum), int(training), _p(coef[0]),
                                    _p(coef[1]), _p(coef[2]), _p(coef[3]), _stream()), 'bn_coeffs')
@@ -275,7 +276,7 @@ class _BNAct(torch.autograd.Function):
             c1, c2 = z[0], z[1]
         L.check(lib.s2ag_bn_bwd_apply(_p(x), _p(dy), rows, cols, ldx, lddy, _p(coef[0]), _p(coef[1]), _p(coef[2]),
                                       _p(coef[3]), slope, _p(c1), _p(c2), _p(dx), cols, _stream()), 'bn_bwd_apply')
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx.view(ctx.in_shape), dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x: Tensor, bn: torch.nn.Module, slope: float = 1.0, chan_map: Optional[Tensor] = None,

@@ -70,3 +70,45 @@ def set_dropout(module, p_tcn=None, p_emb=None, p_gru=None):
 
 def to_cuda(d):
     return {k: v.cuda() for k, v in d.items()}
+
+
+import re as _re
+
+_DEAD = _re.compile(r'(audio_encoder\.conv[1-4]\.bias|audio_encoder\.feat_extractor\.[036]\.bias|'
+                    r'st_gcn[12]\.tcn\.2\.bias|st_gcn[12]\.residual\.0\.bias|aff_encoder\.conv[34]\.bias|'
+                    r'pre_conv\.[013]\.bias)$')
+
+
+def is_dead_bias(key: str) -> bool:
+    """Conv biases that feed a BatchNorm directly: the batch mean removes them, so their true gradient is exactly
+    zero (both implementations hold ~1e-8 rounding noise there) and Adam then moves them by +-lr per step in a
+    noise-determined direction -- in the reference too.  They cannot influence any output."""
+    return _DEAD.search(key) is not None
+
+
+def is_noise_driven_after_adam(key: str) -> bool:
+    """State that legitimately random-walks under Adam (update = lr * m / sqrt(v) turns ~1e-8 rounding noise into
+    +-lr steps): dead biases, the st_gcn2 graph-conv bias (its k = 0 slice only adds a per-channel constant, which the
+    following BatchNorm2d removes) and the running means that track such biases.  Excluded from after-step WEIGHT
+    comparisons only; their gradients and every loss/metric are still compared."""
+    return is_dead_bias(key) or key.endswith('running_mean') or key.endswith('st_gcn2.gcn.conv.bias')
+
+
+def grad_err(a, b, key=''):
+    """max |a-b| / max |b|; for dead biases (see is_dead_bias) only require both sides to be ~0."""
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if is_dead_bias(key):
+        assert float(a.abs().max()) < 1e-3 and float(b.abs().max()) < 1e-3, key
+        return 0.0
+    return float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
+
+
+def adam_close(v, ref, lr, steps):
+    """Weights after a few Adam steps.  Adam turns a gradient element g into a step lr*m/sqrt(v), i.e. ~lr*sign(g)
+    early on, so elements whose true gradient is at rounding-noise level may legitimately differ by a fraction of
+    lr per step.  Require: almost every element within 0.1*lr, and none beyond what sign flips can produce."""
+    d = (torch.as_tensor(v).detach().cpu().double() - torch.as_tensor(ref).detach().cpu().double()).abs()
+    frac_off = float((d > 0.1 * lr).double().mean())
+    return frac_off < 5e-3 and float(d.max()) <= 2.05 * lr * steps, (frac_off, float(d.max()))
