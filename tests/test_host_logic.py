@@ -1,0 +1,178 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol the header
+declares, the import surface mirrors the reference, host logic (checkpoint naming, Graph, row-matrix views),
+and that compute entry points refuse CPU tensors instead of falling back."""
+import os
+import re
+import tempfile
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shared_library_exports_every_declared_symbol():
+    from speech2affective_gestures_amd import _lib, build
+    build.build(force=False, verbose=False)          # hipcc cross-compiles gfx950 without a GPU
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, 'include', 's2ag_hip.h')).read()
+    declared = set(re.findall(r'^int (s2ag_\w+)\(', header, flags=re.M))
+    assert declared and declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.s2ag_abi_version() == 1
+
+
+def test_header_cites_the_reference_for_every_entry_point():
+    header = open(os.path.join(ROOT, 'include', 's2ag_hip.h')).read()
+    assert header.count('.py:') >= 15            # reference file:line citations
+
+
+def test_no_cpu_fallback():
+    from speech2affective_gestures_amd import ops
+    with pytest.raises(RuntimeError, match='no CPU'):
+        ops.linear(torch.randn(2, 3), torch.randn(4, 3), None)
+    with pytest.raises(RuntimeError):
+        ops.gru(torch.randn(1, 2, 3), [torch.randn(3)], 4, 1, False, 0.0, None, 0, False)
+    if not torch.cuda.is_available():
+        from speech2affective_gestures_amd import processor_v2 as P
+        with pytest.raises(RuntimeError, match='no CPU path'):
+            P.Processor('.', types.SimpleNamespace(), None, {}, 27, 3, 16000)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'speech2affective_gestures_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dp, f)).read()
+                assert 'oracle' not in src, os.path.join(dp, f)
+
+
+def test_import_surface_and_state_dict_contract():
+    from oracle import s2ag_oracle as O
+    from speech2affective_gestures_amd.net import multimodal_context_net_v2 as m2
+    from speech2affective_gestures_amd.net import multimodal_context_net_v2_abl_audio as m2a
+    from speech2affective_gestures_amd.net import tcn
+    from speech2affective_gestures_amd.net.utils import graph, tgcn
+    for name in ('WavEncoder', 'MFCCEncoder', 'TextEncoderTCN', 'AffEncoder', 'PoseGeneratorTriModal',
+                 'ConvDiscriminatorTriModal', 'ConvDiscriminator', 'PoseGenerator', 'AffDiscriminator'):
+        assert hasattr(m2, name)
+    assert all(hasattr(tcn, n) for n in ('Chomp1d', 'TemporalBlock', 'TemporalConvNet'))
+    assert hasattr(tgcn, 'STGraphConv') and hasattr(tgcn, 'ConvTemporalGraphical') and hasattr(graph, 'Graph')
+
+    class Vocab:
+        n_words = 21
+    cfg = types.SimpleNamespace(n_pre_poses=4, n_poses=34, input_context='both', hidden_size=32, hidden_size_s2eg=32,
+                                n_layers=4, dropout_prob=0.3, freeze_wordembed=False)
+    oc = O.ModelCfg(hidden_size=32, hidden_size_s2eg=32)
+    pairs = [(m2.PoseGenerator(cfg, 27, 50, 300, None, 71, 37, 34, z_obj=Vocab()), O.generator_shapes(oc, 50, 21)),
+             (m2a.PoseGenerator(cfg, 27, 50, 300, None, 71, 37, 34, z_obj=Vocab()),
+              O.generator_shapes(oc, 50, 21, audio='wav')),
+             (m2.PoseGeneratorTriModal(cfg, 27, 50, 300, None, z_obj=Vocab()), O.trimodal_shapes(oc, 50, 21)),
+             (m2.AffDiscriminator(27), O.aff_discriminator_shapes()),
+             (m2.ConvDiscriminatorTriModal(27), O.conv_discriminator_shapes())]
+    for mod, shapes in pairs:               # the oracle's tables were loaded strict=True into the reference
+        sd = mod.state_dict()
+        assert set(sd) == set(shapes)
+        assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
+    g = pairs[0][0]
+    assert hasattr(g, 'gru') and g.hidden_size == 32 and g.z_obj is not None
+    pre = np.random.rand(50, 300).astype(np.float32)
+    te = m2.TextEncoderTCN(cfg, 50, 300, pre_trained_embedding=pre)
+    assert torch.equal(te.embedding.weight.detach(), torch.from_numpy(pre))
+
+
+def test_graph_adjacency_matches_reference_fixture(golden_dir):
+    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import AffEncoder
+    g = np.load(os.path.join(golden_dir, 'misc.npz'))
+    enc = AffEncoder()
+    np.testing.assert_allclose(enc.A1.numpy(), g['A1'], atol=1e-7)
+    np.testing.assert_allclose(enc.A2.numpy(), g['A2'], atol=1e-7)
+    assert 'A1' not in enc.state_dict()          # not in the reference's state_dict either
+
+
+def test_checkpoint_name_protocol_matches_reference_fixture(golden_dir, monkeypatch):
+    from speech2affective_gestures_amd import processor_v2 as P
+    g = np.load(os.path.join(golden_dir, 'misc.npz'))
+    names = [str(n) for n in g['ckpt_names']]
+    monkeypatch.setattr(P.os, 'listdir', lambda p: list(names))
+    for key, arg in (('best', 'best'), ('at20', 20), ('missing', 7)):
+        got = P.get_epoch_and_loss('/nonexistent', arg)
+        assert [got[0], str(got[1]), repr(got[2])] == [str(v) for v in g[key]], key
+    monkeypatch.setattr(P.os, 'listdir', lambda p: names[:1])
+    assert P.get_epoch_and_loss('/nonexistent')[0] == ''
+    assert 'epoch_{:06d}_loss_{:.4f}_model.pth.tar'.format(20, 0.25) == names[1]
+
+
+def test_as_rows_views_slices_without_copying():
+    from speech2affective_gestures_amd.ops import as_rows
+    wide = torch.randn(4, 6, 40)
+    t, rows, cols, ld = as_rows(wide[..., 8:24])
+    assert (rows, cols, ld) == (24, 16, 40) and t.data_ptr() == wide[..., 8:24].data_ptr()
+    t, rows, cols, ld = as_rows(wide.transpose(1, 2))             # does not collapse -> one copy
+    assert (rows, cols, ld) == (160, 6, 6) and t.is_contiguous()
+    t, rows, cols, ld = as_rows(torch.randn(5, 1, 7))
+    assert (rows, cols, ld) == (5, 7, 7)
+    with pytest.raises(TypeError):
+        as_rows(torch.zeros(3, dtype=torch.int64))
+
+
+def test_yield_batch_semantics_on_host():
+    """processor_v2.py:589-638: audio int16*max/32767 decode, dtypes, 'other speaker' ids not in the batch."""
+    from speech2affective_gestures_amd import processor_v2 as P
+    pr = object.__new__(P.Processor)
+    n = 40
+
+    class Vocab:
+        word2index = {'v%d' % i: i for i in range(12)}
+    pr.train_samples = dict(extended_word_seq=np.random.randint(0, 9, (n, 34)).astype(np.int64),
+                            vec_seq=np.random.randn(n, 34, 27), audio=np.random.randint(-3000, 3000, (n, 100)).astype(np.int16),
+                            audio_max=np.random.rand(n) + 0.5, mfcc_features=np.random.randn(n, 37, 71).astype(np.float16),
+                            vid_indices=np.full(n, 3))
+    pr.val_samples, pr.num_train_samples, pr.num_val_samples = None, n, 0
+    pr.train_speaker_model = pr.val_speaker_model = Vocab()
+    pr.args = types.SimpleNamespace(batch_size=8)
+    pr.device = torch.device('cpu')
+    batches = list(pr.yield_batch(train=True))
+    assert len(batches) == 5
+    text, vec, audio, mfcc, vids = batches[0]
+    assert text.dtype == torch.int64 and vec.dtype == audio.dtype == mfcc.dtype == torch.float32
+    assert text.shape == (8, 34) and vec.shape == (8, 34, 27) and audio.shape == (8, 100) and mfcc.shape == (8, 37, 71)
+    assert float(audio.abs().max()) <= 1.5 * 3000 / 32767 + 1e-6
+    assert vids.dtype == torch.int64 and 3 not in vids.tolist() and set(vids.tolist()) <= set(range(12))
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from speech2affective_gestures_amd.parallel import DataParallelContext
+    dp = DataParallelContext.from_env(backend='gloo')
+    torch.manual_seed(rank)
+    lin = torch.nn.Linear(4, 3)
+    arena = types.SimpleNamespace(data=torch.nn.utils.parameters_to_vector(lin.parameters()).detach().clone(),
+                                  grad=torch.full((15,), float(rank + 1)))
+    dp.broadcast_module(lin, arena)
+    dp.all_reduce_grads(arena)
+    t = dp.max_over_ranks(float(rank), 'cpu')
+    dp.barrier()
+    q.put((rank, arena.data.tolist(), arena.grad.tolist(), dp.grad_scale, t))
+
+
+def test_data_parallel_context_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29611 + os.getpid() % 200
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    (r0, d0, g0, s0, t0), (r1, d1, g1, s1, t1) = res
+    assert d0 == d1                               # rank 0's parameters everywhere
+    assert g0 == g1 == [3.0] * 15                 # SUM all-reduce of the flat gradient arena (1 + 2)
+    assert s0 == s1 == 0.5 and t0 == t1 == 1.0    # Adam consumes grad/world; timing is the max over ranks
