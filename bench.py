@@ -94,10 +94,16 @@ def gru_roofline(B, iters=20):
     s = torch.cuda.current_stream()
     sp = C.c_void_p(s.cuda_stream)
 
+    coop = bool(lib.s2ag_gru_coop_supported(H))
+    ws = torch.empty(max(1, lib.s2ag_gru_coop_workspace_bytes(B, T, H, 0)), dtype=torch.uint8, device=dev)
+
     def launch():
-        L.check(lib.s2ag_gru_seq_fwd(C.c_void_p(gi.data_ptr()), C.c_void_p(whhT.data_ptr()), C.c_void_p(bhh.data_ptr()),
-                                     C.c_void_p(y.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(gates.data_ptr()),
-                                     B, T, H, C.byref(e), sp), 'gru_seq_fwd')
+        args = (C.c_void_p(gi.data_ptr()), C.c_void_p(whhT.data_ptr()), C.c_void_p(bhh.data_ptr()),
+                C.c_void_p(y.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(gates.data_ptr()), B, T, H, C.byref(e))
+        if coop:
+            L.check(lib.s2ag_gru_coop_fwd(*args, C.c_void_p(ws.data_ptr()), sp), 'gru_coop_fwd')
+        else:
+            L.check(lib.s2ag_gru_seq_fwd(*args, sp), 'gru_seq_fwd')
     for _ in range(3):
         launch()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
@@ -109,7 +115,7 @@ def gru_roofline(B, iters=20):
     ms = sum(a.elapsed_time(b) for a, b in evs) / iters
     flops = 2.0 * B * T * 2 * H * 3 * H           # recurrent mat-vec MACs x2, both directions
     achieved = flops / (ms * 1e-3) / 1e12
-    return dict(bound='mfma', kernel='gru_seq_fwd_k<8> (H=300, T=34, 2 directions)', achieved=achieved, peak=157.3,
+    return dict(bound='mfma', kernel=('gru_coop_fwd_k<300>' if coop else 'gru_seq_fwd_k<8>') + ' (H=300, T=34, 2 directions)', achieved=achieved, peak=157.3,
                 unit='TFLOP/s', frac=achieved / 157.3, traffic=None, ms_per_launch=ms,
                 algorithmic_flops_per_launch=flops)
 

@@ -162,6 +162,21 @@ int s2ag_gru_seq_bwd(const float* dy, int lddy, int dy_dir_stride, const float* 
                      const float* gates, float* dgi, float* dgh, int B, int T, int H,
                      const s2ag_epilogue* e /*host, nullable*/, void* stream);
 
+/* Cooperative variant of the two calls above for large H (s2ag_gru_coop_supported(H) != 0; H = 300 on this path):
+ * W_hh stays on chip (MFMA B-operands in registers); a group of ceil(H/32) workgroups shares one (direction,
+ * 16-clip slice) and exchanges h_t (forward) / d(gh)_t (backward) once per step through `workspace` with
+ * write-through stores + a per-step arrival counter (agent scope).  Same arguments and results as the
+ * streaming kernels; `workspace` needs s2ag_gru_coop_workspace_bytes() bytes and may be uninitialised. */
+int s2ag_gru_coop_supported(int H);
+long long s2ag_gru_coop_workspace_bytes(int B, int T, int H, int backward);
+int s2ag_gru_coop_fwd(const float* gi, const float* whhT, const float* bhh, float* y, float* ydrop, float* gates,
+                      int B, int T, int H, const s2ag_epilogue* e /*host, nullable*/, void* workspace, void* stream);
+int s2ag_gru_coop_bwd(const float* dy, int lddy, int dy_dir_stride, const float* whh, const float* y,
+                      const float* gates, float* dgi, float* dgh, int B, int T, int H,
+                      const s2ag_epilogue* e /*host, nullable*/, void* workspace, void* stream);
+/* byte offset inside `workspace` of the int32 word a launch sets to 1 if it timed out waiting for a peer */
+int s2ag_gru_coop_error_word_offset(int B, int T, int H, int backward, long long* offset /*host*/);
+
 /* z = mu + eps*exp(0.5*log_var), eps ~ N(0,1) from (rng, site);  net/embedding_net.py:10-13. */
 int s2ag_reparam_fwd(const float* mu, const float* log_var, int n, const unsigned long long* rng, unsigned site,
                      float* z, void* stream);

@@ -43,6 +43,11 @@ SIGNATURES = {
     's2ag_transpose': [vp, ci, ci, vp, vp],
     's2ag_gru_seq_fwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],
     's2ag_gru_seq_bwd': [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],
+    's2ag_gru_coop_supported': [ci],
+    's2ag_gru_coop_workspace_bytes': [ci, ci, ci, ci],
+    's2ag_gru_coop_fwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp, vp],
+    's2ag_gru_coop_bwd': [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp, vp],
+    's2ag_gru_coop_error_word_offset': [ci, ci, ci, ci, C.POINTER(cll)],
     's2ag_reparam_fwd': [vp, vp, ci, vp, cu, vp, vp],
     's2ag_reparam_bwd': [vp, vp, ci, vp, cu, vp, vp, vp],
     's2ag_dis_loss': [vp, vp, ci, vp, vp, vp, vp],
@@ -76,7 +81,7 @@ def load():
         except AttributeError as e:
             raise S2AGLibraryError(f'{LIB_PATH} lacks symbol {name}; rebuild it') from e
         fn.argtypes = args
-        fn.restype = ci
+        fn.restype = cll if name == 's2ag_gru_coop_workspace_bytes' else ci
     if lib.s2ag_abi_version() != 1:
         raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
     _lib = lib

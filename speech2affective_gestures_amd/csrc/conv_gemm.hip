@@ -409,7 +409,7 @@ extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float
     p.chunk = cdiv(cdiv(p.Mtot, nsplit), BK) * BK;
     nsplit = cdiv(p.Mtot, p.chunk);
     if (!accumulate) {
-        hipError_t me = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)g->Cout * g->Cin * g->ksize, (hipStream_t)stream);
+        hipError_t me = zero_async(dw, sizeof(float) * (size_t)g->Cout * g->Cin * g->ksize, (hipStream_t)stream);
         if (me != hipSuccess) return (int)me;
     }
     dim3 grid(cdiv(g->Cout, BM), cdiv(g->ksize * g->Cin, BN), nsplit);
@@ -422,10 +422,10 @@ extern "C" int s2ag_colsum(const float* x, int rows, int cols, int ld, float* ou
                            void* stream) {
     if (!x || !out || rows <= 0 || cols <= 0 || ld < cols) return S2AG_E_BADARG;
     if (!accumulate) {
-        hipError_t me = hipMemsetAsync(out, 0, sizeof(float) * cols, (hipStream_t)stream);
+        hipError_t me = zero_async(out, sizeof(float) * cols, (hipStream_t)stream);
         if (me != hipSuccess) return (int)me;
         if (sq) {
-            me = hipMemsetAsync(sq, 0, sizeof(float) * cols, (hipStream_t)stream);
+            me = zero_async(sq, sizeof(float) * cols, (hipStream_t)stream);
             if (me != hipSuccess) return (int)me;
         }
     }
@@ -441,9 +441,9 @@ extern "C" int s2ag_colsum(const float* x, int rows, int cols, int ld, float* ou
 
 extern "C" int s2ag_colstats_f64(const float* x, int rows, int cols, int ld, double* sum, double* sq, void* stream) {
     if (!x || !sum || !sq || rows <= 0 || cols <= 0 || ld < cols) return S2AG_E_BADARG;
-    hipError_t me = hipMemsetAsync(sum, 0, sizeof(double) * cols, (hipStream_t)stream);
+    hipError_t me = zero_async(sum, sizeof(double) * cols, (hipStream_t)stream);
     if (me != hipSuccess) return (int)me;
-    me = hipMemsetAsync(sq, 0, sizeof(double) * cols, (hipStream_t)stream);
+    me = zero_async(sq, sizeof(double) * cols, (hipStream_t)stream);
     if (me != hipSuccess) return (int)me;
     int rpb = 256;
     const int colblocks = cdiv(cols, 64);

@@ -328,7 +328,7 @@ extern "C" int s2ag_embedding_bwd(const long long* ids, const float* g, int ldg,
     const float p = e ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
     if (!accumulate) {
-        hipError_t me = hipMemsetAsync(dtable, 0, sizeof(float) * (size_t)n_entries * dim, (hipStream_t)stream);
+        hipError_t me = zero_async(dtable, sizeof(float) * (size_t)n_entries * dim, (hipStream_t)stream);
         if (me != hipSuccess) return (int)me;
     }
     hipLaunchKernelGGL(embedding_bwd_k, dim3(ew_grid((long long)rows * dim)), dim3(256), 0, (hipStream_t)stream, ids,

@@ -69,6 +69,22 @@ __device__ __forceinline__ float apply_act(float x, int act, float slope) {
     return x;
 }
 
+// Accumulators are cleared by a KERNEL, never by hipMemsetAsync: inside a replayed hipGraph (ROCm 7.2) a memset node
+// was observed not to be ordered against the kernel that follows it (see gru_coop.hip), which would silently drop
+// atomically accumulated sums.
+static __global__ void zero_words_k(unsigned* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t stream) {
+    const size_t n = (bytes + 3) / 4;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(zero_words_k, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<unsigned*>(p), n);
+    return hipGetLastError();
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

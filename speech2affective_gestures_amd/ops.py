@@ -437,6 +437,21 @@ def fold(w: Tensor, csr: CSR) -> Tensor:
 # ----------------------------------------------------------------------------------------------------
 # multi-layer bidirectional GRU
 # ----------------------------------------------------------------------------------------------------
+USE_COOP_GRU = True          # cooperative on-chip-W_hh recurrence where supported (H = 300); else L2-streaming kernels
+_COOP_WS = __import__('collections').deque(maxlen=64)   # recent cooperative workspaces (error words, debugging)
+
+
+def coop_gru_timeouts() -> int:
+    """Number of recent cooperative GRU launches whose peer wait timed out (synchronises; tests/debug only)."""
+    lib, bad = _lib(), 0
+    torch.cuda.synchronize()
+    for ws, B, T, H, bwd in list(_COOP_WS):
+        off = C.c_longlong(0)
+        L.check(lib.s2ag_gru_coop_error_word_offset(B, T, H, bwd, C.byref(off)), 'error_word_offset')
+        bad += int(ws[off.value:off.value + 4].view(torch.int32).item() != 0)
+    return bad
+
+
 class _GRU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, H, Lyr, training, drop_p, noise, site0, sum_dirs, need_grad, *weights):
@@ -464,8 +479,14 @@ class _GRU(torch.autograd.Function):
             use_drop = bool(training) and drop_p > 0 and not last
             ydrop = torch.empty_like(y) if use_drop else None
             e = _epi(L.ACT_NONE, 1.0, drop_p if use_drop else 0.0, noise, site0 + l)
-            L.check(lib.s2ag_gru_seq_fwd(_p(gi), _p(whhT), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T, H, C.byref(e),
-                                         _stream()), 'gru_seq_fwd')
+            if USE_COOP_GRU and lib.s2ag_gru_coop_supported(H):
+                ws = torch.empty(lib.s2ag_gru_coop_workspace_bytes(B, T, H, 0), dtype=torch.uint8, device=dev)
+                L.check(lib.s2ag_gru_coop_fwd(_p(gi), _p(whhT), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T, H,
+                                              C.byref(e), _p(ws), _stream()), 'gru_coop_fwd')
+                _COOP_WS.append((ws, B, T, H, 0))
+            else:
+                L.check(lib.s2ag_gru_seq_fwd(_p(gi), _p(whhT), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T, H,
+                                             C.byref(e), _stream()), 'gru_seq_fwd')
             saved += [inp, y, gates]
             inp = ydrop if use_drop else y
         if sum_dirs:
@@ -503,8 +524,14 @@ class _GRU(torch.autograd.Function):
             dgi = torch.empty(B * T, 2 * H3, dtype=torch.float32, device=dev)
             dgh = torch.empty(2, B * T, H3, dtype=torch.float32, device=dev)
             e = _epi(L.ACT_NONE, 1.0, drop_p if use_drop else 0.0, ctx.noise, site0 + l)
-            L.check(lib.s2ag_gru_seq_bwd(_p(dy), lddy, dir_stride, _p(whh2), _p(y), _p(gates), _p(dgi), _p(dgh), B, T,
-                                         H, C.byref(e), _stream()), 'gru_seq_bwd')
+            if USE_COOP_GRU and lib.s2ag_gru_coop_supported(H):
+                ws = torch.empty(lib.s2ag_gru_coop_workspace_bytes(B, T, H, 1), dtype=torch.uint8, device=dev)
+                L.check(lib.s2ag_gru_coop_bwd(_p(dy), lddy, dir_stride, _p(whh2), _p(y), _p(gates), _p(dgi), _p(dgh),
+                                              B, T, H, C.byref(e), _p(ws), _stream()), 'gru_coop_bwd')
+                _COOP_WS.append((ws, B, T, H, 1))
+            else:
+                L.check(lib.s2ag_gru_seq_bwd(_p(dy), lddy, dir_stride, _p(whh2), _p(y), _p(gates), _p(dgi), _p(dgh),
+                                             B, T, H, C.byref(e), _stream()), 'gru_seq_bwd')
             # parameter gradients
             for d, (w_ih, w_hh) in enumerate(((wih, whh), (wih_r, whh_r))):
                 gsl = dgi[:, d * H3:(d + 1) * H3]

@@ -205,7 +205,8 @@ def _flat(sd, L):
 
 
 @pytest.mark.parametrize('B,T,I,H,L,sum_dirs,p', [(5, 7, 11, 32, 3, False, 0.0), (9, 6, 88, 300, 2, True, 0.0),
-                                                   (10, 34, 8, 64, 4, True, 0.3), (3, 5, 20, 32, 2, False, 0.3)])
+                                                   (10, 34, 8, 64, 4, True, 0.3), (3, 5, 20, 32, 2, False, 0.3),
+                                                   (37, 34, 88, 300, 3, True, 0.3), (128, 34, 108, 300, 2, False, 0.3)])
 def test_gru_forward_backward(S, B, T, I, H, L, sum_dirs, p):
     ops, noise = S['ops'], S['noise']
     sd = _gru_sd(I, H, L, B * 100 + H)
@@ -236,6 +237,7 @@ def test_gru_forward_backward(S, B, T, I, H, L, sum_dirs, p):
                       f'gru.bias_hh_l{l}{suf}']
     for n, w in zip(names, wg):
         assert rel(w.grad, sdr[n].grad) < 2 * TOL, n
+    assert ops.coop_gru_timeouts() == 0          # cooperative (H = 300) launches never timed out on a peer
 
 
 def test_embedding_dropout_and_dense_gradient(S):
