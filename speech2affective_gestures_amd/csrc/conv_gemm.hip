@@ -184,6 +184,236 @@ __global__ __launch_bounds__(256) void conv_gemm_k(GemmP p) {
         }
 }
 
+
+// ---- second-generation tile kernel ---------------------------------------------------------------------------
+// K step 32 with double-buffered LDS (ONE barrier per K tile), the next tile's global loads in flight under the
+// current tile's MFMAs, and an intra-block 2-way K split (KG = 2: two groups of waves take alternate halves of every
+// K tile and are summed through LDS once at the end) -- twice the waves per CU to hide the L2/HBM latency that
+// bounds these small-grid GEMMs.  BM in {64, 32}: 32-row tiles when 64-row tiles would leave CUs idle.
+constexpr int BK2 = 32;
+
+// LDS tiles are ROW-major [row][k] with a pitch of 34 floats: the loader's 8-byte stores (8 lanes cover one row's 32
+// k's, rows 2 banks apart) and the MFMA fragment reads (16 rows x 2 k's per 32-lane group -> banks 2*row + k) are
+// both bank-conflict free.  (A k-major image with an 80-float pitch made the loader's stores 8-way conflicted:
+// 4*80 = 0 mod 32 -- LDS writes, not MFMA, bounded the first version.)
+constexpr int PK = BK2 + 2;
+
+template <bool BWD, bool VEC, int BM_, int WM, int WN, int KG>
+__global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
+    constexpr int NT = 64 * WM * WN * KG;
+    constexpr int TM = BM_ / (16 * WM), TN = 64 / (16 * WN);
+    constexpr int CA = (BM_ * (BK2 / 4) + NT - 1) / NT;          // 4-wide K chunks of A per thread
+    constexpr int CB = (64 * (BK2 / 4) + NT - 1) / NT;
+    constexpr int KSG = (BK2 / 4) / KG;                          // MFMA k-steps per wave group per tile
+    __shared__ __attribute__((aligned(16))) float As[2][BM_][PK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][64][PK];
+    static_assert(2 * BM_ * PK >= BM_ * 64 || KG == 1, "reduction scratch must fit in As");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave / (WM * WN), wr = (wave % (WM * WN)) / WN, wc = wave % WN;
+    const int m0 = blockIdx.x * BM_, n0 = blockIdx.y * 64;
+
+    // per-thread loader coordinates (fixed across the K loop)
+    int a_r[CA], a_kq[CA], a_l[CA];
+    long long a_row0[CA];
+    bool a_ok[CA];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+        const int c = tid + i * NT;
+        a_kq[i] = c % (BK2 / 4);
+        a_r[i] = c / (BK2 / 4);
+        const int m = m0 + a_r[i];
+        a_ok[i] = (a_r[i] < BM_) && (m < p.M);
+        int nclip = 0, l = 0;
+        if (a_ok[i]) {
+            nclip = m / p.Lr;
+            l = m - nclip * p.Lr;
+        }
+        a_l[i] = l;
+        a_row0[i] = (long long)nclip * p.Lsrc;
+    }
+    int b_c[CB], b_kq[CB];
+    bool b_ok[CB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const int c = tid + i * NT;
+        b_kq[i] = c % (BK2 / 4);
+        b_c[i] = c / (BK2 / 4);
+        b_ok[i] = (b_c[i] < 64) && (n0 + b_c[i] < p.NC);
+    }
+
+    float ra[CA][4], rb[CB][4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+            const int kk0 = k0 + a_kq[i] * 4;
+            if (VEC) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a_ok[i] && kk0 < p.K) {
+                    const int tap = kk0 / p.CK, c = kk0 - tap * p.CK;
+                    int pos;
+                    if (src_pos<BWD>(p, a_l[i], tap, pos))
+                        v = *reinterpret_cast<const float4*>(p.a + (a_row0[i] + pos) * p.lda + c);
+                }
+                ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = kk0 + j;
+                    float a = 0.f;
+                    if (a_ok[i] && kk < p.K) {
+                        const int tap = kk / p.CK, c = kk - tap * p.CK;
+                        int pos;
+                        if (src_pos<BWD>(p, a_l[i], tap, pos)) a = p.a[(a_row0[i] + pos) * p.lda + c];
+                    }
+                    ra[i][j] = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            const int kk0 = k0 + b_kq[i] * 4;
+            const int col = n0 + b_c[i];
+            int tap = 0, c = 0;
+            if (VEC && kk0 < p.K) {
+                tap = kk0 / p.CK;
+                c = kk0 - tap * p.CK;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = kk0 + j;
+                float b = 0.f;
+                if (b_ok[i] && kk < p.K) {
+                    int t2 = tap, c2 = c + j;
+                    if (!VEC) {
+                        t2 = kk / p.CK;
+                        c2 = kk - t2 * p.CK;
+                    }
+                    b = BWD ? p.w[((long long)c2 * p.Cin + col) * p.ks + t2]
+                            : p.w[((long long)col * p.Cin + c2) * p.ks + t2];
+                }
+                rb[i][j] = b;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CA; ++i)
+            if (a_r[i] < BM_) {
+                float* d = &As[buf][a_r[i]][a_kq[i] * 4];
+                *reinterpret_cast<float2*>(d) = make_float2(ra[i][0], ra[i][1]);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(ra[i][2], ra[i][3]);
+            }
+#pragma unroll
+        for (int i = 0; i < CB; ++i)
+            if (b_c[i] < 64) {
+                float* d = &Bs[buf][b_c[i]][b_kq[i] * 4];
+                *reinterpret_cast<float2*>(d) = make_float2(rb[i][0], rb[i][1]);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(rb[i][2], rb[i][3]);
+            }
+    };
+
+    bool rowlive[TM], collive[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) rowlive[t] = (m0 + (wr * TM + t) * 16) < p.M;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) collive[t] = (n0 + (wc * TN + t) * 16) < p.NC;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (p.K + BK2 - 1) / BK2;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) fetch((kt + 1) * BK2);
+#pragma unroll
+        for (int s = 0; s < KSG; ++s) {
+            const int kr = (kg * KSG + s) * 4 + (lane >> 4);
+            const int li = lane & 15;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = As[cur][(wr * TM + t) * 16 + li][kr];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = Bs[cur][(wc * TN + t) * 16 + li][kr];
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TN; ++tj)
+                    if (rowlive[ti] && collive[tj])
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+    if (KG == 2) {       // sum the two K halves: group 1 parks its accumulators in LDS, group 0 finishes
+        float* red = &As[0][0][0];
+        if (kg == 1) {
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        red[((wr * TM + ti) * 16 + (lane >> 4) * 4 + q) * 64 + (wc * TN + tj) * 16 + (lane & 15)] =
+                            acc[ti][tj][q];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[ti][tj][q] +=
+                        red[((wr * TM + ti) * 16 + (lane >> 4) * 4 + q) * 64 + (wc * TN + tj) * 16 + (lane & 15)];
+    }
+
+    SiteKey key{0, 0};
+    const bool drop = (!BWD) && p.drop_p > 0.f;
+    if (drop) key = site_key(p.rng, p.site);
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj) {
+            const int c = n0 + (wc * TN + tj) * 16 + (lane & 15);
+            if (c >= p.NC) continue;
+            const float bias = (!BWD && p.bias) ? p.bias[c] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = m0 + (wr * TM + ti) * 16 + (lane >> 4) * 4 + q;
+                if (row >= p.M) continue;
+                float v = acc[ti][tj][q];
+                float* dst = p.out + (long long)row * p.ldo + c;
+                if (!BWD) {
+                    v = apply_act(v + bias, p.act, p.slope);
+                    if (drop) v *= keep_scale(key, (unsigned long long)row * p.NC + c, p.drop_p, p.inv_keep);
+                    *dst = v;
+                } else {
+                    *dst = p.accumulate ? (*dst + v) : v;
+                }
+            }
+        }
+}
+
+template <bool BWD, bool VEC>
+void launch_gemm2(const GemmP& p, hipStream_t stream) {
+    const long long colb = cdiv(p.NC, 64);
+    // largest row tile that still gives >= 512 blocks (2 per CU); narrow problems fall through to 16-row tiles
+    if ((long long)cdiv(p.M, 64) * colb >= 512) {
+        hipLaunchKernelGGL((conv_gemm2_k<BWD, VEC, 64, 2, 2, 2>), dim3(cdiv(p.M, 64), (unsigned)colb), dim3(512), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((conv_gemm2_k<BWD, VEC, 32, 2, 2, 2>), dim3(cdiv(p.M, 32), (unsigned)colb), dim3(512), 0, stream, p);
+    }
+}
+
 // ---- weight gradient: dw[co, ci, tap] += sum_m gy[m, co] * xwin[m, (tap, ci)] -----------------------
 struct WgradP {
     const float* gy;
@@ -363,12 +593,11 @@ extern "C" int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* 
     p.rng = e ? e->rng : nullptr;
     p.site = e ? e->site : 0;
     p.accumulate = 0;
-    dim3 grid(cdiv(p.M, BM), cdiv(p.NC, BN));
     const bool vec = (g->Cin % 4 == 0) && (g->ldx % 4 == 0) && aligned16(x);
     if (vec)
-        hipLaunchKernelGGL((conv_gemm_k<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        launch_gemm2<false, true>(p, (hipStream_t)stream);
     else
-        hipLaunchKernelGGL((conv_gemm_k<false, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        launch_gemm2<false, false>(p, (hipStream_t)stream);
     S2AG_LAUNCH_CHECK();
     return 0;
 }
@@ -384,12 +613,11 @@ extern "C" int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* 
     p.lda = g->ldy; p.ldo = g->ldx;
     p.act = S2AG_ACT_NONE; p.slope = 1.f; p.drop_p = 0.f; p.inv_keep = 1.f; p.rng = nullptr; p.site = 0;
     p.accumulate = accumulate;
-    dim3 grid(cdiv(p.M, BM), cdiv(p.NC, BN));
     const bool vec = (g->Cout % 4 == 0) && (g->ldy % 4 == 0) && aligned16(gy);
     if (vec)
-        hipLaunchKernelGGL((conv_gemm_k<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        launch_gemm2<true, true>(p, (hipStream_t)stream);
     else
-        hipLaunchKernelGGL((conv_gemm_k<true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        launch_gemm2<true, false>(p, (hipStream_t)stream);
     S2AG_LAUNCH_CHECK();
     return 0;
 }
@@ -441,10 +669,16 @@ extern "C" int s2ag_colsum(const float* x, int rows, int cols, int ld, float* ou
 
 extern "C" int s2ag_colstats_f64(const float* x, int rows, int cols, int ld, double* sum, double* sq, void* stream) {
     if (!x || !sum || !sq || rows <= 0 || cols <= 0 || ld < cols) return S2AG_E_BADARG;
-    hipError_t me = zero_async(sum, sizeof(double) * cols, (hipStream_t)stream);
-    if (me != hipSuccess) return (int)me;
-    me = zero_async(sq, sizeof(double) * cols, (hipStream_t)stream);
-    if (me != hipSuccess) return (int)me;
+    hipError_t me;
+    if (sq == sum + cols) {      // one contiguous (2, cols) buffer: a single clear
+        me = zero_async(sum, sizeof(double) * 2 * cols, (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+    } else {
+        me = zero_async(sum, sizeof(double) * cols, (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+        me = zero_async(sq, sizeof(double) * cols, (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+    }
     int rpb = 256;
     const int colblocks = cdiv(cols, 64);
     while (rpb > 64 && (long long)cdiv(rows, rpb) * colblocks < 1024) rpb >>= 1;

@@ -227,10 +227,16 @@ extern "C" int s2ag_bn_bwd_reduce(const float* x, const float* dy, int rows, int
                                   const float* scale_col, const float* shift_col, const float* mean_col,
                                   const float* invstd_col, float slope, float* s1_col, float* s2_col, void* stream) {
     if (!x || !dy || rows <= 0 || cols <= 0 || !s1_col || !s2_col) return S2AG_E_BADARG;
-    hipError_t me = zero_async(s1_col, sizeof(float) * cols, (hipStream_t)stream);
-    if (me != hipSuccess) return (int)me;
-    me = zero_async(s2_col, sizeof(float) * cols, (hipStream_t)stream);
-    if (me != hipSuccess) return (int)me;
+    hipError_t me;
+    if (s2_col == s1_col + cols) {
+        me = zero_async(s1_col, sizeof(float) * 2 * cols, (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+    } else {
+        me = zero_async(s1_col, sizeof(float) * cols, (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+        me = zero_async(s2_col, sizeof(float) * cols, (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+    }
     int rpb = 256;
     const int colblocks = cdiv(cols, 64);
     while (rpb > 64 && (long long)cdiv(rows, rpb) * colblocks < 1024) rpb >>= 1;

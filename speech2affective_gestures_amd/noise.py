@@ -69,3 +69,17 @@ def noise_pass(device):
         yield snap
     finally:
         stack.pop()
+
+
+@contextmanager
+def use_pass(snapshot: torch.Tensor):
+    """Run the enclosed forward pass with a snapshot drawn earlier by ``begin_pass`` -- lets the trainer draw the
+    snapshots of several passes in program order on the main stream and then run the passes on forked streams."""
+    stack = getattr(_tls, 'stack', None)
+    if stack is None:
+        stack = _tls.stack = []
+    stack.append(snapshot)
+    try:
+        yield snapshot
+    finally:
+        stack.pop()

@@ -158,6 +158,21 @@ def normal_noise(noise: Tensor, site: int, shape: Sequence[int]) -> Tensor:
 
 
 # ----------------------------------------------------------------------------------------------------
+# direct gradient accumulation
+# ----------------------------------------------------------------------------------------------------
+def _grad_slot(p: Optional[Tensor]):
+    """If ``p`` is a leaf parameter whose ``.grad`` already exists (the flat arena of optim.ParamArena, zeroed once per
+    step), return that tensor: the backward kernel then ACCUMULATES into it and autograd is handed ``None`` --
+    no temporary, no zero-fill launch, no AccumulateGrad add.  Otherwise None (ordinary autograd path)."""
+    if p is None or not p.is_leaf or not p.requires_grad or p.grad is None:
+        return None
+    g = p.grad
+    if not g.is_contiguous() or g.dtype != torch.float32:
+        return None
+    return g
+
+
+# ----------------------------------------------------------------------------------------------------
 # conv / linear
 # ----------------------------------------------------------------------------------------------------
 class _ConvNLC(torch.autograd.Function):
@@ -166,6 +181,7 @@ class _ConvNLC(torch.autograd.Function):
         _need_cuda(x, w, bias)
         N, Lin, Lout, Cin, Cout, ks, stride, pad, dil = geom
         x, _, _, _ = as_rows(x)
+        ctx.w_leaf, ctx.b_leaf = w, bias                   # for direct accumulation into .grad (see _grad_slot)
         w = w.contiguous()
         y = torch.empty(N * Lout, Cout, dtype=torch.float32, device=x.device)
         conv_fwd_raw(x, w, bias, y, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, act, slope, drop_p, noise, site)
@@ -193,11 +209,19 @@ class _ConvNLC(torch.autograd.Function):
             conv_bwd_data_raw(g, w, dx, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False)
             dx = dx.view(x.shape)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            conv_bwd_weight_raw(g, x, dw, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False)
+            slot = _grad_slot(ctx.w_leaf)
+            if slot is not None:
+                conv_bwd_weight_raw(g, x, slot, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, True)
+            else:
+                dw = torch.empty_like(w)
+                conv_bwd_weight_raw(g, x, dw, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
-            colsum_raw(g, db)
+            slot = _grad_slot(ctx.b_leaf)
+            if slot is not None:
+                colsum_raw(g, slot, accumulate=True)
+            else:
+                db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+                colsum_raw(g, db)
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -219,8 +243,8 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor], act=L.ACT_NONE, slope=1
     """x (..., in) @ w(out, in)^T + bias -> (..., out) with a fused activation."""
     shp = x.shape
     rows = x.numel() // shp[-1]
-    y = _ConvNLC.apply(x, w.view(w.shape[0], w.shape[1], 1), bias, (rows, 1, 1, shp[-1], w.shape[0], 1, 1, 0, 1),
-                       act, float(slope), 0.0, None, 0)
+    # w is passed as the leaf itself (not a view) so its gradient can be accumulated straight into the arena
+    y = _ConvNLC.apply(x, w, bias, (rows, 1, 1, shp[-1], w.shape[0], 1, 1, 0, 1), act, float(slope), 0.0, None, 0)
     return y.view(*shp[:-1], w.shape[0])
 
 
@@ -250,6 +274,7 @@ class _BNAct(torch.autograd.Function):
                                   _stream()), 'bn_apply')
         ctx.save_for_backward(x, coef, chan_map)
         ctx.meta = (rows, cols, ldx, nchan, float(slope), bool(training))
+        ctx.leaves = (gamma, beta)
         return y
 
     @staticmethod
@@ -263,13 +288,18 @@ class _BNAct(torch.autograd.Function):
         dgamma = dbeta = None
         if training:
             tmp = torch.empty(4, cols, dtype=torch.float32, device=dev)
-            dgb = torch.empty(2, nchan, dtype=torch.float32, device=dev)
             L.check(lib.s2ag_bn_bwd_reduce(_p(x), _p(dy), rows, cols, ldx, lddy, _p(coef[0]), _p(coef[1]),
                                            _p(coef[2]), _p(coef[3]), slope, _p(tmp[0]), _p(tmp[1]), _stream()),
                     'bn_bwd_reduce')
-            L.check(lib.s2ag_bn_bwd_coeffs(_p(tmp[0]), _p(tmp[1]), _p(chan_map), cols, nchan, rows, _p(dgb[0]),
-                                           _p(dgb[1]), 0, _p(tmp[2]), _p(tmp[3]), _stream()), 'bn_bwd_coeffs')
-            dgamma, dbeta = dgb[0], dgb[1]
+            sg, sb = _grad_slot(ctx.leaves[0]), _grad_slot(ctx.leaves[1])
+            if sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+                L.check(lib.s2ag_bn_bwd_coeffs(_p(tmp[0]), _p(tmp[1]), _p(chan_map), cols, nchan, rows, _p(sg), _p(sb),
+                                               1, _p(tmp[2]), _p(tmp[3]), _stream()), 'bn_bwd_coeffs')
+            else:
+                dgb = torch.empty(2, nchan, dtype=torch.float32, device=dev)
+                L.check(lib.s2ag_bn_bwd_coeffs(_p(tmp[0]), _p(tmp[1]), _p(chan_map), cols, nchan, rows, _p(dgb[0]),
+                                               _p(dgb[1]), 0, _p(tmp[2]), _p(tmp[3]), _stream()), 'bn_bwd_coeffs')
+                dgamma, dbeta = dgb[0], dgb[1]
             c1, c2 = tmp[2], tmp[3]
         else:
             z = torch.zeros(2, cols, dtype=torch.float32, device=dev)
@@ -338,6 +368,7 @@ class _Embedding(torch.autograd.Function):
         ctx.save_for_backward(ids)
         ctx.meta = (table.shape[0], dim, drop_p, site)
         ctx.noise = noise
+        ctx.table_leaf = table
         return out
 
     @staticmethod
@@ -345,8 +376,13 @@ class _Embedding(torch.autograd.Function):
         (ids,) = ctx.saved_tensors
         n_entries, dim, drop_p, site = ctx.meta
         dy, rows, _, ldg = as_rows(dy)
-        dt = torch.empty(n_entries, dim, dtype=torch.float32, device=dy.device)
         e = _epi(L.ACT_NONE, 1.0, drop_p, ctx.noise, site)
+        slot = _grad_slot(ctx.table_leaf)
+        if slot is not None:        # dense (n_words x dim) gradient: scatter straight into the arena
+            L.check(_lib().s2ag_embedding_bwd(_p(ids), _p(dy), ldg, rows, dim, n_entries, _p(slot), 1, C.byref(e),
+                                              _stream()), 'embedding_bwd')
+            return None, None, None, None, None
+        dt = torch.empty(n_entries, dim, dtype=torch.float32, device=dy.device)
         L.check(_lib().s2ag_embedding_bwd(_p(ids), _p(dy), ldg, rows, dim, n_entries, _p(dt), 0, C.byref(e),
                                           _stream()), 'embedding_bwd')
         return None, dt, None, None, None
@@ -498,6 +534,7 @@ class _GRU(torch.autograd.Function):
         ctx.meta = (B, T, H, Lyr, bool(training), float(drop_p), site0, bool(sum_dirs))
         ctx.noise = noise
         ctx.n_w = len(weights)
+        ctx.w_leaves = weights
         ctx.save_for_backward(*weights, *[s for s in saved])
         ctx.none_mask = [s is None for s in saved]
         return out
@@ -535,18 +572,24 @@ class _GRU(torch.autograd.Function):
             # parameter gradients
             for d, (w_ih, w_hh) in enumerate(((wih, whh), (wih_r, whh_r))):
                 gsl = dgi[:, d * H3:(d + 1) * H3]
-                dwi = torch.empty_like(w_ih)
-                conv_bwd_weight_raw(gsl, inp, dwi, B * T, 1, 1, In, H3, 1, 1, 0, 1, False)
-                dbi = torch.empty(H3, dtype=torch.float32, device=dev)
-                colsum_raw(gsl, dbi)
-                # dW_hh = sum_t dgh_t^T h_{t-1}: h_{prev} is y shifted by one frame (zero at the boundary)
-                dwh = torch.empty_like(w_hh)
-                conv_bwd_weight_raw(dgh[d], y[:, d * H:(d + 1) * H], dwh, B, T, T, H, H3, 1, 1, 1 if d == 0 else -1, 1,
-                                    False)
-                dbh = torch.empty(H3, dtype=torch.float32, device=dev)
-                colsum_raw(dgh[d], dbh)
                 base = 8 * l + 4 * d
-                grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = dwi, dwh, dbi, dbh
+                if not any(ctx.needs_input_grad[9 + base + i] for i in range(4)):
+                    continue                      # frozen weights (D inside the generator step): no weight-grad kernels
+                slots = [_grad_slot(ctx.w_leaves[base + i]) if ctx.needs_input_grad[9 + base + i] else None
+                         for i in range(4)]
+                direct = all(sl is not None for sl in slots)
+                dwi = slots[0] if direct else torch.empty_like(w_ih)
+                conv_bwd_weight_raw(gsl, inp, dwi, B * T, 1, 1, In, H3, 1, 1, 0, 1, direct)
+                dbi = slots[2] if direct else torch.empty(H3, dtype=torch.float32, device=dev)
+                colsum_raw(gsl, dbi, accumulate=direct)
+                # dW_hh = sum_t dgh_t^T h_{t-1}: h_{prev} is y shifted by one frame (zero at the boundary)
+                dwh = slots[1] if direct else torch.empty_like(w_hh)
+                conv_bwd_weight_raw(dgh[d], y[:, d * H:(d + 1) * H], dwh, B, T, T, H, H3, 1, 1, 1 if d == 0 else -1, 1,
+                                    direct)
+                dbh = slots[3] if direct else torch.empty(H3, dtype=torch.float32, device=dev)
+                colsum_raw(dgh[d], dbh, accumulate=direct)
+                if not direct:
+                    grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = dwi, dwh, dbi, dbh
             # input gradient
             if l > 0 or ctx.needs_input_grad[0]:
                 dx = torch.empty(B * T, In, dtype=torch.float32, device=dev)

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F  # noqa: F401  (kept for API familiarity; no functional op is used on the path)
 
-from . import ops
+from . import noise, ops
 from .net.multimodal_context_net_v2 import (AffDiscriminator, ConvDiscriminatorTriModal as CDT, PoseGenerator,
                                             PoseGeneratorTriModal as PGT)
 from .optim import FusedAdam, ParamArena
@@ -194,6 +194,9 @@ class Processor(object):
         self.s2ag_dis_optimizer = FusedAdam(self.dis_arena, lr=self.lr_s2ag_dis, betas=(0.5, 0.999))
 
         self.use_hip_graph = bool(getattr(args, 'hip_graph', True))
+        # independent forward passes of a step run on forked streams (every kernel here fills only part of the chip)
+        self.overlap_passes = bool(getattr(args, 'overlap_passes', True))
+        self._side = [torch.cuda.Stream(device=self.device) for _ in range(2)]
         self._graphed = None
         self.last_losses = {}
 
@@ -256,13 +259,35 @@ class Processor(object):
         pre_seq[:, 0:n_pre, -1] = 1
         return pre_seq
 
+    def _fork(self, idx):
+        """side stream ``idx`` picks up after everything queued on the current stream"""
+        s = self._side[idx]
+        s.wait_stream(torch.cuda.current_stream())
+        return s
+
     def _dis_phase(self, in_text, in_mfcc, target_poses, vid_indices, pre_seq, train):
-        """processor_v2.py:792-814 up to (and including) dis_error.backward()."""
+        """processor_v2.py:792-814 up to (and including) dis_error.backward().
+
+        Noise snapshots are drawn in the reference's pass order (G, D(real), D(fake)) on the main stream; D(real) then
+        runs on a forked stream beside the generator forward.  D(fake) starts after both, so D's BatchNorm running
+        statistics are still updated real-then-fake."""
         self.s2ag_dis_optimizer.zero_grad()
-        with torch.no_grad():        # upstream builds this graph and never uses it
+        dev = pre_seq.device
+        nz_g, nz_real, nz_fake = noise.begin_pass(dev), noise.begin_pass(dev), noise.begin_pass(dev)
+        cur = torch.cuda.current_stream()
+        if self.overlap_passes:
+            side = self._fork(0)
+            with torch.cuda.stream(side), noise.use_pass(nz_real):
+                dis_real = self.s2ag_discriminator(target_poses, in_text)
+        with torch.no_grad(), noise.use_pass(nz_g):        # upstream builds this graph and never uses it
             out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
-        dis_real = self.s2ag_discriminator(target_poses, in_text)
-        dis_fake = self.s2ag_discriminator(out_dir_vec.detach(), in_text)
+        if self.overlap_passes:
+            cur.wait_stream(side)
+        else:
+            with noise.use_pass(nz_real):
+                dis_real = self.s2ag_discriminator(target_poses, in_text)
+        with noise.use_pass(nz_fake):
+            dis_fake = self.s2ag_discriminator(out_dir_vec.detach(), in_text)
         dis_error = ops.dis_loss(dis_real, dis_fake)
         if train:
             dis_error.backward()
@@ -272,22 +297,42 @@ class Processor(object):
         """processor_v2.py:816-941 up to (and including) loss.backward()."""
         cfg = self.s2ag_config_args
         self.s2ag_gen_optimizer.zero_grad()
-        with torch.no_grad():
-            out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
-        out, z, z_mu, z_log_var = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
+        dev = pre_seq.device
+        # pass order of the reference: tri-modal baseline, G(main), D(gen), G(rand)
+        nz_tri, nz_main, nz_dgen, nz_rand = (noise.begin_pass(dev) for _ in range(4))
+        rand_idx = torch.randperm(vid_indices.shape[0], device=vid_indices.device)
+        rand_vids = vid_indices[rand_idx]
+        cur = torch.cuda.current_stream()
+        if self.overlap_passes:      # the frozen baseline shares nothing with G/D: run it beside the main forward
+            side0 = self._fork(0)
+            with torch.cuda.stream(side0), torch.no_grad(), noise.use_pass(nz_tri):
+                out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
+        else:
+            with torch.no_grad(), noise.use_pass(nz_tri):
+                out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
+        with noise.use_pass(nz_main):
+            out, z, z_mu, z_log_var = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
+        if self.overlap_passes:      # G(rand) follows G(main) (BatchNorm running stats order) but runs beside D(gen)
+            side1 = self._fork(1)
+            with torch.cuda.stream(side1), torch.no_grad(), noise.use_pass(nz_rand):
+                out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, rand_vids)
         # upstream lets loss.backward() also fill D's .grad, which the next D step zeroes unread;
         # skipping those weight-gradient kernels changes nothing observable
         flags = [p.requires_grad for p in self.dis_arena.params]
         for p in self.dis_arena.params:
             p.requires_grad_(False)
         try:
-            dis_output = self.s2ag_discriminator(out, in_text)
+            with noise.use_pass(nz_dgen):
+                dis_output = self.s2ag_discriminator(out, in_text)
         finally:
             for p, f in zip(self.dis_arena.params, flags):
                 p.requires_grad_(f)
-        rand_idx = torch.randperm(vid_indices.shape[0], device=vid_indices.device)
-        with torch.no_grad():
-            out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices[rand_idx])
+        if self.overlap_passes:
+            cur.wait_stream(side0)
+            cur.wait_stream(side1)
+        else:
+            with torch.no_grad(), noise.use_pass(nz_rand):
+                out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, rand_vids)
         w_gan = cfg.loss_gan_weight if self.meta_info['epoch'] > cfg.loss_warmup else 0.0
         total, comps = ops.gen_loss(out, dis_output, z_mu, z_log_var, target_poses, out_tri, out_rand, z, z_rand,
                                     (cfg.loss_regression_weight, w_gan, cfg.loss_reg_weight, cfg.loss_kld_weight))
