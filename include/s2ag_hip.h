@@ -46,6 +46,8 @@ typedef struct {
     int N, Lin, Lout, Cin, Cout, ksize, stride, pad, dil;
     int ldx; /* row pitch of the input matrix  */
     int ldy; /* row pitch of the output matrix */
+    int w_tap_major; /* 0: weight (Cout, Cin, k) as in the reference's state_dict;  1: (Cout, k, Cin) -- the layout the
+                        weight-norm kernel and the ST-GCN fold emit, K-contiguous for the tile loader */
 } s2ag_conv_geom;
 
 /* fused epilogue of the forward conv: y = dropout(act(acc + bias)) */
@@ -130,9 +132,12 @@ int s2ag_embedding_bwd(const long long* ids, const float* g, int ldg, int rows, 
                        float* dtable, int accumulate, const s2ag_epilogue* e /*host, nullable*/, void* stream);
 
 /* torch.nn.utils.weight_norm (dim 0): w[r,:] = g[r] * v[r,:] / ||v[r,:]||;  net/tcn.py:19,25. */
-int s2ag_weight_norm_fwd(const float* v, const float* g, int rows, int cols, float* w, float* norm, void* stream);
+/* ksize > 1: v is (rows, cols/ksize, ksize) and w / dw are written / read tap-major (rows, ksize, cols/ksize);
+ * ksize <= 1: same layout in and out. */
+int s2ag_weight_norm_fwd(const float* v, const float* g, int rows, int cols, int ksize, float* w, float* norm,
+                         void* stream);
 int s2ag_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, int rows, int cols,
-                         float* dv, float* dg, void* stream);
+                         int ksize, float* dv, float* dg, void* stream);
 
 /* y[i] (+)= sum_{j in row i} val[j] * x[col[j]]   (CSR).  Used to fold the ST-GCN adjacency / vertex kernel
  * into dense channels-last conv weights each step and to un-fold their gradients:

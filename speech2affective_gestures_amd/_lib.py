@@ -10,7 +10,8 @@ vp, ci, cf, cu, cll = C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_longlong
 
 
 class ConvGeom(C.Structure):
-    _fields_ = [(n, ci) for n in ('N', 'Lin', 'Lout', 'Cin', 'Cout', 'ksize', 'stride', 'pad', 'dil', 'ldx', 'ldy')]
+    _fields_ = [(n, ci) for n in ('N', 'Lin', 'Lout', 'Cin', 'Cout', 'ksize', 'stride', 'pad', 'dil', 'ldx', 'ldy',
+                                   'w_tap_major')]
 
 
 class Epilogue(C.Structure):
@@ -37,8 +38,8 @@ SIGNATURES = {
     's2ag_epilogue_bwd': [vp, ci, vp, ci, vp, ci, ci, ci, PE, vp],
     's2ag_embedding_fwd': [vp, vp, ci, ci, ci, vp, ci, PE, vp],
     's2ag_embedding_bwd': [vp, vp, ci, ci, ci, ci, vp, ci, PE, vp],
-    's2ag_weight_norm_fwd': [vp, vp, ci, ci, vp, vp, vp],
-    's2ag_weight_norm_bwd': [vp, vp, vp, vp, ci, ci, vp, vp, vp],
+    's2ag_weight_norm_fwd': [vp, vp, ci, ci, ci, vp, vp, vp],
+    's2ag_weight_norm_bwd': [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp],
     's2ag_spmv': [vp, vp, vp, vp, vp, ci, ci, vp],
     's2ag_transpose': [vp, ci, ci, vp, vp],
     's2ag_gru_seq_fwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],

@@ -30,6 +30,7 @@ struct GemmP {
     int Cin;            // conv Cin (weight indexing)
     int ks, stride, pad, dil;
     int lda, ldo;
+    int wtm;            // weight is tap-major (Cout, k, Cin)
     int act;
     float slope, drop_p, inv_keep;
     const unsigned long long* rng;
@@ -243,61 +244,78 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
         b_ok[i] = (b_c[i] < 64) && (n0 + b_c[i] < p.NC);
     }
 
-    float ra[CA][4], rb[CB][4];
-    auto fetch = [&](int k0) {
+    float ra0[CA][4], rb0[CB][4], ra1[CA][4], rb1[CB][4];   // two tiles in flight
+    // (tap, channel) of each chunk's first k, advanced by BK2 per tile instead of dividing every time
+    int a_tap[CA], a_c[CA], b_tap[CB], b_cc[CB];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+        a_tap[i] = (a_kq[i] * 4) / p.CK;
+        a_c[i] = a_kq[i] * 4 - a_tap[i] * p.CK;
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        b_tap[i] = (b_kq[i] * 4) / p.CK;
+        b_cc[i] = b_kq[i] * 4 - b_tap[i] * p.CK;
+    }
+    const bool b_contig = (!BWD) && VEC && (p.ks == 1 || p.wtm) && ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0);
+    auto fetch = [&](float (&ra)[CA][4], float (&rb)[CB][4], int k0) {   // call with k0 = 0, BK2, 2*BK2, ... in order
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
             const int kk0 = k0 + a_kq[i] * 4;
             if (VEC) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (a_ok[i] && kk0 < p.K) {
-                    const int tap = kk0 / p.CK, c = kk0 - tap * p.CK;
                     int pos;
-                    if (src_pos<BWD>(p, a_l[i], tap, pos))
-                        v = *reinterpret_cast<const float4*>(p.a + (a_row0[i] + pos) * p.lda + c);
+                    if (src_pos<BWD>(p, a_l[i], a_tap[i], pos))
+                        v = *reinterpret_cast<const float4*>(p.a + (a_row0[i] + pos) * p.lda + a_c[i]);
                 }
                 ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
             } else {
+                int tap = a_tap[i], c = a_c[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int kk = kk0 + j;
                     float a = 0.f;
-                    if (a_ok[i] && kk < p.K) {
-                        const int tap = kk / p.CK, c = kk - tap * p.CK;
+                    if (a_ok[i] && kk0 + j < p.K) {
                         int pos;
                         if (src_pos<BWD>(p, a_l[i], tap, pos)) a = p.a[(a_row0[i] + pos) * p.lda + c];
                     }
                     ra[i][j] = a;
+                    if (++c == p.CK) { c = 0; ++tap; }
                 }
             }
+            a_c[i] += BK2;
+            while (a_c[i] >= p.CK) { a_c[i] -= p.CK; ++a_tap[i]; }
         }
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
             const int kk0 = k0 + b_kq[i] * 4;
             const int col = n0 + b_c[i];
-            int tap = 0, c = 0;
-            if (VEC && kk0 < p.K) {
-                tap = kk0 / p.CK;
-                c = kk0 - tap * p.CK;
-            }
+            if (b_contig) {             // Linear / GRU projection: the weight row is K-contiguous -> one 16-byte load
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b_ok[i] && kk0 < p.K) v = *reinterpret_cast<const float4*>(p.w + (long long)col * p.K + kk0);
+                rb[i][0] = v.x; rb[i][1] = v.y; rb[i][2] = v.z; rb[i][3] = v.w;
+            } else {
+                int tap = b_tap[i], c = b_cc[i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kk = kk0 + j;
-                float b = 0.f;
-                if (b_ok[i] && kk < p.K) {
-                    int t2 = tap, c2 = c + j;
-                    if (!VEC) {
-                        t2 = kk / p.CK;
-                        c2 = kk - t2 * p.CK;
+                for (int j = 0; j < 4; ++j) {
+                    float b = 0.f;
+                    if (b_ok[i] && kk0 + j < p.K) {
+                        if (p.wtm)
+                            b = BWD ? p.w[((long long)c * p.ks + tap) * p.Cin + col]
+                                    : p.w[((long long)col * p.ks + tap) * p.Cin + c];
+                        else
+                            b = BWD ? p.w[((long long)c * p.Cin + col) * p.ks + tap]
+                                    : p.w[((long long)col * p.Cin + c) * p.ks + tap];
                     }
-                    b = BWD ? p.w[((long long)c2 * p.Cin + col) * p.ks + t2]
-                            : p.w[((long long)col * p.Cin + c2) * p.ks + t2];
+                    rb[i][j] = b;
+                    if (++c == p.CK) { c = 0; ++tap; }
                 }
-                rb[i][j] = b;
             }
+            b_cc[i] += BK2;
+            while (b_cc[i] >= p.CK) { b_cc[i] -= p.CK; ++b_tap[i]; }
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](const float (&ra)[CA][4], const float (&rb)[CB][4], int buf) {
 #pragma unroll
         for (int i = 0; i < CA; ++i)
             if (a_r[i] < BM_) {
@@ -326,12 +344,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nkt = (p.K + BK2 - 1) / BK2;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) fetch((kt + 1) * BK2);
+    auto mma = [&](int cur) {
 #pragma unroll
         for (int s = 0; s < KSG; ++s) {
             const int kr = (kg * KSG + s) * 4 + (lane >> 4);
@@ -348,7 +361,22 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
                     if (rowlive[ti] && collive[tj])
                         acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
         }
-        if (kt + 1 < nkt) stash(cur ^ 1);
+    };
+    // software pipeline, two tiles deep: tile kt+2 is requested while tile kt is multiplied and tile kt+1 (requested
+    // one iteration earlier, so it has had a full iteration to land) is moved from registers into the idle LDS buffer
+    fetch(ra0, rb0, 0);
+    stash(ra0, rb0, 0);
+    if (nkt > 1) fetch(ra0, rb0, BK2);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        if (kt + 2 < nkt) fetch(ra1, rb1, (kt + 2) * BK2);
+        mma(0);
+        if (kt + 1 < nkt) stash(ra0, rb0, 1);
+        __syncthreads();
+        if (kt + 1 >= nkt) break;
+        if (kt + 3 < nkt) fetch(ra0, rb0, (kt + 3) * BK2);
+        mma(1);
+        if (kt + 2 < nkt) stash(ra1, rb1, 0);
         __syncthreads();
     }
 
@@ -419,7 +447,7 @@ struct WgradP {
     const float* gy;
     const float* x;
     float* dw;
-    int Mtot, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg;
+    int Mtot, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg, wtm;
     int chunk;   // rows per z-slice, multiple of BK
 };
 
@@ -511,7 +539,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradP p) {
             for (int q = 0; q < 4; ++q) {
                 const int row = co0 + wm * 32 + ti * 16 + (lane >> 4) * 4 + q;
                 if (row >= p.Cout) continue;
-                atomicAdd(p.dw + ((long long)row * p.Cin + c2) * p.ks + t2, acc[ti][tj][q]);
+                atomicAdd(p.dw + (p.wtm ? ((long long)row * p.ks + t2) * p.Cin + c2
+                                        : ((long long)row * p.Cin + c2) * p.ks + t2), acc[ti][tj][q]);
             }
         }
 }
@@ -585,7 +614,7 @@ extern "C" int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* 
     p.M = g->N * g->Lout; p.K = g->ksize * g->Cin; p.NC = g->Cout;
     p.Lr = g->Lout; p.Lsrc = g->Lin; p.CK = g->Cin; p.Cin = g->Cin;
     p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
-    p.lda = g->ldx; p.ldo = g->ldy;
+    p.lda = g->ldx; p.ldo = g->ldy; p.wtm = g->w_tap_major;
     p.act = e ? e->act : S2AG_ACT_NONE;
     p.slope = e ? e->slope : 1.f;
     p.drop_p = e ? e->drop_p : 0.f;
@@ -610,7 +639,7 @@ extern "C" int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* 
     p.M = g->N * g->Lin; p.K = g->ksize * g->Cout; p.NC = g->Cin;
     p.Lr = g->Lin; p.Lsrc = g->Lout; p.CK = g->Cout; p.Cin = g->Cin;
     p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
-    p.lda = g->ldy; p.ldo = g->ldx;
+    p.lda = g->ldy; p.ldo = g->ldx; p.wtm = g->w_tap_major;
     p.act = S2AG_ACT_NONE; p.slope = 1.f; p.drop_p = 0.f; p.inv_keep = 1.f; p.rng = nullptr; p.site = 0;
     p.accumulate = accumulate;
     const bool vec = (g->Cout % 4 == 0) && (g->ldy % 4 == 0) && aligned16(gy);
@@ -629,6 +658,7 @@ extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float
     p.gy = gy; p.x = x; p.dw = dw;
     p.Mtot = g->N * g->Lout; p.Lin = g->Lin; p.Lout = g->Lout; p.Cin = g->Cin; p.Cout = g->Cout;
     p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil; p.ldx = g->ldx; p.ldg = g->ldy;
+    p.wtm = g->w_tap_major;
     const int tiles = cdiv(g->Cout, BM) * cdiv(g->ksize * g->Cin, BN);
     int nsplit = cdiv(1024, tiles);
     const int max_split = cdiv(p.Mtot, 4 * BK);

@@ -49,8 +49,16 @@ __global__ __launch_bounds__(256) void embedding_bwd_k(const long long* ids, con
 }
 
 // ---- weight norm: one wave per output row ------------------------------------------------------------
+// column c of v's row (reference order: channel-major, tap fastest) -> column of the tap-major image
+__device__ __forceinline__ int tm_col(int c, int cin, int ks) {
+    if (ks <= 1) return c;
+    const int ci = c / ks, tap = c - ci * ks;
+    return tap * cin + ci;
+}
+
 __global__ __launch_bounds__(256) void weight_norm_fwd_k(const float* __restrict__ v, const float* __restrict__ g,
-                                                         int rows, int cols, float* __restrict__ w, float* norm) {
+                                                         int rows, int cols, int ks, float* __restrict__ w,
+                                                         float* norm) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -60,25 +68,28 @@ __global__ __launch_bounds__(256) void weight_norm_fwd_k(const float* __restrict
     s = wave_sum(s);
     const float nrm = sqrtf(s);
     const float f = g[row] / nrm;
-    for (int c = lane; c < cols; c += 64) w[(long long)row * cols + c] = vr[c] * f;
+    const int cin = ks > 1 ? cols / ks : cols;
+    for (int c = lane; c < cols; c += 64) w[(long long)row * cols + tm_col(c, cin, ks)] = vr[c] * f;
     if (lane == 0) norm[row] = nrm;
 }
 
 __global__ __launch_bounds__(256) void weight_norm_bwd_k(const float* __restrict__ dw, const float* __restrict__ v,
                                                          const float* __restrict__ g, const float* __restrict__ norm,
-                                                         int rows, int cols, float* __restrict__ dv, float* dg) {
+                                                         int rows, int cols, int ks, float* __restrict__ dv,
+                                                         float* dg) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* vr = v + (long long)row * cols;
     const float* dr = dw + (long long)row * cols;
+    const int cin = ks > 1 ? cols / ks : cols;
     float s = 0.f;
-    for (int c = lane; c < cols; c += 64) s += dr[c] * vr[c];
+    for (int c = lane; c < cols; c += 64) s += dr[tm_col(c, cin, ks)] * vr[c];
     s = wave_sum(s);
     const float nrm = norm[row], gg = g[row];
     const float dgv = s / nrm;
     const float a = gg / nrm, b = gg * s / (nrm * nrm * nrm);
-    for (int c = lane; c < cols; c += 64) dv[(long long)row * cols + c] = a * dr[c] - b * vr[c];
+    for (int c = lane; c < cols; c += 64) dv[(long long)row * cols + c] = a * dr[tm_col(c, cin, ks)] - b * vr[c];
     if (lane == 0) dg[row] = dgv;
 }
 
@@ -338,20 +349,21 @@ extern "C" int s2ag_embedding_bwd(const long long* ids, const float* g, int ldg,
     return 0;
 }
 
-extern "C" int s2ag_weight_norm_fwd(const float* v, const float* g, int rows, int cols, float* w, float* norm,
+extern "C" int s2ag_weight_norm_fwd(const float* v, const float* g, int rows, int cols, int ksize, float* w, float* norm,
                                     void* stream) {
-    if (!v || !g || !w || !norm || rows <= 0 || cols <= 0) return S2AG_E_BADARG;
-    hipLaunchKernelGGL(weight_norm_fwd_k, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, v, g, rows, cols, w,
-                       norm);
+    if (!v || !g || !w || !norm || rows <= 0 || cols <= 0 || (ksize > 1 && cols % ksize)) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(weight_norm_fwd_k, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, v, g, rows, cols,
+                       ksize, w, norm);
     S2AG_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int s2ag_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, int rows,
-                                    int cols, float* dv, float* dg, void* stream) {
-    if (!dw || !v || !g || !norm || !dv || !dg || rows <= 0 || cols <= 0) return S2AG_E_BADARG;
+                                    int cols, int ksize, float* dv, float* dg, void* stream) {
+    if (!dw || !v || !g || !norm || !dv || !dg || rows <= 0 || cols <= 0 || (ksize > 1 && cols % ksize))
+        return S2AG_E_BADARG;
     hipLaunchKernelGGL(weight_norm_bwd_k, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dw, v, g, norm, rows,
-                       cols, dv, dg);
+                       cols, ksize, dv, dg);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -52,10 +52,10 @@ class TemporalBlock(nn.Module):
         out = x
         pad = (self.kernel_size - 1) * self.dilation
         for conv, site in ((self.conv1, self.sites[0]), (self.conv2, self.sites[1])):
-            w = ops.weight_norm(conv.weight_v, conv.weight_g)
+            w = ops.weight_norm(conv.weight_v, conv.weight_g, tap_major=True)          # (Cout, k, Cin)
             p = self.p if self.training else 0.0
             out = ops.conv1d_nlc(out, w, conv.bias, pad=pad, dil=self.dilation, lout=x.shape[1], act=ACT_LEAKY,
-                                 slope=0.0, drop_p=p, noise=noise, site=site)
+                                 slope=0.0, drop_p=p, noise=noise, site=site, w_tap_major=True)
         res = x if self.downsample is None else ops.conv1d_nlc(x, self.downsample.weight, self.downsample.bias)
         return ops.add_act(out, res, 0.0)
 

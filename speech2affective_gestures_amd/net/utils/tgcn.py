@@ -5,7 +5,7 @@
 
 MI355X formulation.  With x kept channels-last as (N, T, V*C) every piece of the block is a 1-D
 convolution over T with a dense (V*Cout, V*Cin, kt) weight:
-  * gcn conv (kt x 1) followed by einsum('nkctv,kvw->nctw'):  W'[(w,c),(v,ci),dt] = sum_k W[k*Cout+c,ci,dt] A[k,v,w]
+  * gcn conv (kt x 1) followed by einsum('nkctv,kvw->nctw'):  W'[(w,c),dt,(v,ci)] = sum_k W[k*Cout+c,ci,dt] A[k,v,w]
   * tcn conv (kt x kv, zero padded over vertices):             W'[(w,c),(v,ci),dt] = W[c,ci,dt,v-w+kv//2]
   * residual 1x1 conv:                                         W'[(w,c),(v,ci)]    = [v==w] W[c,ci]
 so the whole block runs on the one MFMA implicit-GEMM kernel family (ops.conv1d_nlc).  The maps
@@ -54,9 +54,9 @@ class ConvTemporalGraphical(nn.Module):
     def forward_nlc(self, x, A, in_col, out_col):
         wf, bf = self.folds(A, in_col, out_col)
         V = A.shape[1]
-        w = ops.fold(self.conv.weight, wf).view(V * self.out_channels, V * self.in_channels, self.kt)
+        w = ops.fold(self.conv.weight, wf).view(V * self.out_channels, self.kt, V * self.in_channels)
         b = ops.fold(self.conv.bias, bf) if self.conv.bias is not None else None
-        return ops.conv1d_nlc(x, w, b, pad=self.pad)
+        return ops.conv1d_nlc(x, w, b, pad=self.pad, w_tap_major=True)
 
     def forward(self, x, A):
         n, c, t, v = x.shape
@@ -78,7 +78,7 @@ def _gcn_fold(A, Cin, Cout, kt, in_col, out_col, device):
     for k, v, w in zip(ks, vs, ws):
         a = A[k, v, w]
         c, ci, d = np.meshgrid(np.arange(Cout), np.arange(Cin), dt, indexing='ij')
-        dst = (out_col[w, c] * (V * Cin) + in_col[v, ci]) * kt + d
+        dst = (out_col[w, c] * kt + d) * (V * Cin) + in_col[v, ci]          # tap-major (V*Cout, kt, V*Cin)
         src = ((k * Cout + c) * Cin + ci) * kt + d
         rows.append(dst.ravel())
         cols.append(src.ravel())
@@ -105,7 +105,7 @@ def _vertex_conv_fold(V, Cin, Cout, kt, kv, in_col, out_col, device):
             if v < 0 or v >= V:
                 continue
             c, ci, d = np.meshgrid(np.arange(Cout), np.arange(Cin), np.arange(kt), indexing='ij')
-            rows.append(((out_col[w, c] * (V * Cin) + in_col[v, ci]) * kt + d).ravel())
+            rows.append(((out_col[w, c] * kt + d) * (V * Cin) + in_col[v, ci]).ravel())   # tap-major
             cols.append((((c * Cin + ci) * kt + d) * kv + dv).ravel())
     r, cc = np.concatenate(rows), np.concatenate(cols)
     wmat = sp.coo_matrix((np.ones(r.size), (r, cc)), shape=(V * Cout * V * Cin * kt, Cout * Cin * kt * kv))
@@ -170,16 +170,16 @@ class STGraphConv(nn.Module):
         g = self.gcn.forward_nlc(x, A, in_col, out_col)
         h = ops.batch_norm_act(g, self.tcn[0], slope=0.0, chan_map=cmap)                       # BN2d + ReLU
         conv = self.tcn[2]
-        wt = ops.fold(conv.weight, tw).view(V * Co, V * Co, self.kt)
+        wt = ops.fold(conv.weight, tw).view(V * Co, self.kt, V * Co)
         bt = ops.fold(conv.bias, tb)
-        h = ops.conv1d_nlc(h, wt, bt, pad=self.kt // 2)
+        h = ops.conv1d_nlc(h, wt, bt, pad=self.kt // 2, w_tap_major=True)
         h = ops.batch_norm_act(h, self.tcn[3], slope=1.0, chan_map=cmap)
         if isinstance(self.residual, nn.Module):
             rw, rb = rf
             rconv = self.residual[0]
-            wr = ops.fold(rconv.weight, rw).view(V * Co, V * Ci, 1)
+            wr = ops.fold(rconv.weight, rw).view(V * Co, 1, V * Ci)
             br = ops.fold(rconv.bias, rb)
-            r = ops.conv1d_nlc(x, wr, br)
+            r = ops.conv1d_nlc(x, wr, br, w_tap_major=True)
             r = ops.batch_norm_act(r, self.residual[1], slope=1.0, chan_map=cmap)
             return ops.add_act(h, r, self.slope)
         return ops.add_act(h, None, self.slope)

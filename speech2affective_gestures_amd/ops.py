@@ -72,40 +72,42 @@ def _epi(act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise: Optional[Tensor] = None, 
     return L.Epilogue(act, float(slope), float(drop_p), _p(noise) if drop_p > 0 else None, int(site))
 
 
-def _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy):
-    return L.ConvGeom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy)
+def _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy, wtm=0):
+    return L.ConvGeom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy, int(wtm))
 
 
 # ----------------------------------------------------------------------------------------------------
 # raw (non-autograd) launch helpers
 # ----------------------------------------------------------------------------------------------------
 def conv_fwd_raw(x: Tensor, w: Tensor, bias: Optional[Tensor], y: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad,
-                 dil, act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0):
+                 dil, act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0, wtm=0):
     x, xr, xc, ldx = as_rows(x)
     _, yr, yc, ldy = as_rows(y)
     assert xr == N * Lin and xc == Cin, (xr, xc, N, Lin, Cin)
     assert yr == N * Lout and yc == Cout, (yr, yc, N, Lout, Cout)
     assert w.is_contiguous() and w.numel() == Cout * Cin * ks
-    g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy)
+    g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy, wtm)
     e = _epi(act, slope, drop_p, noise, site)
     L.check(_lib().s2ag_conv1d_nlc_fwd(_p(x), _p(w), _p(bias), _p(y), C.byref(g), C.byref(e), _stream()), 'conv_fwd')
 
 
-def conv_bwd_data_raw(gy: Tensor, w: Tensor, dx: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, accumulate):
+def conv_bwd_data_raw(gy: Tensor, w: Tensor, dx: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, accumulate,
+                      wtm=0):
     gy, gr, gc, ldg = as_rows(gy)
     _, xr, xc, ldx = as_rows(dx)
     assert gr == N * Lout and gc == Cout and xr == N * Lin and xc == Cin
-    g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg)
+    g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg, wtm)
     L.check(_lib().s2ag_conv1d_nlc_bwd_data(_p(gy), _p(w), _p(dx), C.byref(g), int(accumulate), _stream()),
             'conv_bwd_data')
 
 
-def conv_bwd_weight_raw(gy: Tensor, x: Tensor, dw: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, accumulate):
+def conv_bwd_weight_raw(gy: Tensor, x: Tensor, dw: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, accumulate,
+                        wtm=0):
     gy, gr, gc, ldg = as_rows(gy)
     x, xr, xc, ldx = as_rows(x)
     assert gr == N * Lout and gc == Cout and xr == N * Lin and xc == Cin, (gr, gc, xr, xc)
     assert dw.is_contiguous() and dw.numel() == Cout * Cin * ks
-    g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg)
+    g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg, wtm)
     L.check(_lib().s2ag_conv1d_nlc_bwd_weight(_p(gy), _p(x), _p(dw), C.byref(g), int(accumulate), _stream()),
             'conv_bwd_weight')
 
@@ -179,12 +181,12 @@ class _ConvNLC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, geom, act, slope, drop_p, noise, site):
         _need_cuda(x, w, bias)
-        N, Lin, Lout, Cin, Cout, ks, stride, pad, dil = geom
+        N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, wtm = geom
         x, _, _, _ = as_rows(x)
         ctx.w_leaf, ctx.b_leaf = w, bias                   # for direct accumulation into .grad (see _grad_slot)
         w = w.contiguous()
         y = torch.empty(N * Lout, Cout, dtype=torch.float32, device=x.device)
-        conv_fwd_raw(x, w, bias, y, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, act, slope, drop_p, noise, site)
+        conv_fwd_raw(x, w, bias, y, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, act, slope, drop_p, noise, site, wtm)
         ctx.geom, ctx.epi = geom, (act, slope, drop_p, site)
         ctx.noise = noise
         ctx.has_bias = bias is not None
@@ -195,7 +197,7 @@ class _ConvNLC(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        N, Lin, Lout, Cin, Cout, ks, stride, pad, dil = ctx.geom
+        N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, wtm = ctx.geom
         act, slope, drop_p, site = ctx.epi
         dy = dy.reshape(N * Lout, Cout)
         if (act != L.ACT_NONE and not (act == L.ACT_LEAKY and slope == 1.0)) or drop_p > 0:
@@ -206,15 +208,15 @@ class _ConvNLC(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(N * Lin, Cin, dtype=torch.float32, device=dy.device)
-            conv_bwd_data_raw(g, w, dx, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False)
+            conv_bwd_data_raw(g, w, dx, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False, wtm)
             dx = dx.view(x.shape)
         if ctx.needs_input_grad[1]:
             slot = _grad_slot(ctx.w_leaf)
             if slot is not None:
-                conv_bwd_weight_raw(g, x, slot, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, True)
+                conv_bwd_weight_raw(g, x, slot, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, True, wtm)
             else:
                 dw = torch.empty_like(w)
-                conv_bwd_weight_raw(g, x, dw, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False)
+                conv_bwd_weight_raw(g, x, dw, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False, wtm)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             slot = _grad_slot(ctx.b_leaf)
             if slot is not None:
@@ -226,16 +228,20 @@ class _ConvNLC(torch.autograd.Function):
 
 
 def conv1d_nlc(x: Tensor, w: Tensor, bias: Optional[Tensor], stride=1, pad=0, dil=1, lout: Optional[int] = None,
-               act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0) -> Tensor:
-    """x (N, Lin, Cin) channels-last, w (Cout, Cin, k) -> (N, Lout, Cout).  ``lout`` overrides the usual
-    output length (the TCN's causal conv + chomp is pad = (k-1)*dil on the left with lout = Lin)."""
+               act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0, w_tap_major=False) -> Tensor:
+    """x (N, Lin, Cin) channels-last, w (Cout, Cin, k) [or (Cout, k, Cin) if ``w_tap_major``] -> (N, Lout, Cout).
+    ``lout`` overrides the usual output length (the TCN's causal conv + chomp is pad = (k-1)*dil on the left with
+    lout = Lin)."""
     N, Lin, Cin = x.shape
-    Cout, Cin_w, ks = w.shape
+    if w_tap_major:
+        Cout, ks, Cin_w = w.shape
+    else:
+        Cout, Cin_w, ks = w.shape
     assert Cin_w == Cin, (w.shape, x.shape)
     if lout is None:
         lout = (Lin + 2 * pad - dil * (ks - 1) - 1) // stride + 1
-    out = _ConvNLC.apply(x, w, bias, (N, Lin, lout, Cin, Cout, ks, stride, pad, dil), act, float(slope),
-                         float(drop_p), noise, site)
+    out = _ConvNLC.apply(x, w, bias, (N, Lin, lout, Cin, Cout, ks, stride, pad, dil, int(w_tap_major)), act,
+                         float(slope), float(drop_p), noise, site)
     return out.view(N, lout, Cout)
 
 
@@ -244,7 +250,7 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor], act=L.ACT_NONE, slope=1
     shp = x.shape
     rows = x.numel() // shp[-1]
     # w is passed as the leaf itself (not a view) so its gradient can be accumulated straight into the arena
-    y = _ConvNLC.apply(x, w, bias, (rows, 1, 1, shp[-1], w.shape[0], 1, 1, 0, 1), act, float(slope), 0.0, None, 0)
+    y = _ConvNLC.apply(x, w, bias, (rows, 1, 1, shp[-1], w.shape[0], 1, 1, 0, 1, 0), act, float(slope), 0.0, None, 0)
     return y.view(*shp[:-1], w.shape[0])
 
 
@@ -398,14 +404,18 @@ def embedding(ids: Tensor, table: Tensor, drop_p: float = 0.0, noise=None, site=
 # ----------------------------------------------------------------------------------------------------
 class _WeightNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, v, g):
+    def forward(ctx, v, g, tap_major):
         _need_cuda(v, g)
         rows, cols = v.shape[0], v.numel() // v.shape[0]
         v = v.contiguous()
-        w = torch.empty_like(v)
+        ks = v.shape[2] if (tap_major and v.dim() == 3) else 1
+        w = torch.empty((v.shape[0], v.shape[2], v.shape[1]) if ks > 1 else v.shape, dtype=torch.float32,
+                        device=v.device)
         norm = torch.empty(rows, dtype=torch.float32, device=v.device)
-        L.check(_lib().s2ag_weight_norm_fwd(_p(v), _p(g), rows, cols, _p(w), _p(norm), _stream()), 'weight_norm_fwd')
+        L.check(_lib().s2ag_weight_norm_fwd(_p(v), _p(g), rows, cols, ks, _p(w), _p(norm), _stream()),
+                'weight_norm_fwd')
         ctx.save_for_backward(v, g, norm)
+        ctx.ks = ks
         return w
 
     @staticmethod
@@ -415,13 +425,15 @@ class _WeightNorm(torch.autograd.Function):
         dw = dw.contiguous()
         dv = torch.empty_like(v)
         dg = torch.empty_like(g)
-        L.check(_lib().s2ag_weight_norm_bwd(_p(dw), _p(v), _p(g), _p(norm), rows, cols, _p(dv), _p(dg), _stream()),
-                'weight_norm_bwd')
-        return dv, dg
+        L.check(_lib().s2ag_weight_norm_bwd(_p(dw), _p(v), _p(g), _p(norm), rows, cols, ctx.ks, _p(dv), _p(dg),
+                                            _stream()), 'weight_norm_bwd')
+        return dv, dg, None
 
 
-def weight_norm(v: Tensor, g: Tensor) -> Tensor:
-    return _WeightNorm.apply(v, g)
+def weight_norm(v: Tensor, g: Tensor, tap_major: bool = False) -> Tensor:
+    """w = g * v / ||v|| per output row.  ``tap_major``: v is (Cout, Cin, k) and w comes out as (Cout, k, Cin), the
+    K-contiguous layout the conv tile loader reads with 16-byte loads."""
+    return _WeightNorm.apply(v, g, bool(tap_major))
 
 
 # ----------------------------------------------------------------------------------------------------

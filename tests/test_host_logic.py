@@ -18,7 +18,7 @@ def test_shared_library_exports_every_declared_symbol():
     build.build(force=False, verbose=False)          # hipcc cross-compiles gfx950 without a GPU
     lib = _lib.load()
     header = open(os.path.join(ROOT, 'include', 's2ag_hip.h')).read()
-    declared = set(re.findall(r'^int (s2ag_\w+)\(', header, flags=re.M))
+    declared = set(re.findall(r'^(?:int|long long) (s2ag_\w+)\(', header, flags=re.M))
     assert declared and declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
