@@ -58,28 +58,33 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
-template <int H>
+template <int H, int HW_>
 __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ gi, const float* __restrict__ whhT,
                                                       const float* __restrict__ bhh, float* __restrict__ y,
                                                       float* __restrict__ ydrop, float* __restrict__ gates,
                                                       float* xbuf, int* cnt, int* err, int B, int T, float drop_p,
                                                       float inv_keep, const unsigned long long* rng, unsigned site) {
     constexpr int H3 = 3 * H;
+    constexpr int NW_ = 3 * HW_;                   // gate columns owned by this workgroup
+    constexpr int NTILES = NW_ / 16;               // MFMA column tiles
+    constexpr int KSPLIT = 12 / NTILES;            // wave groups splitting K (12 waves)
     constexpr int KSTEPS = (H + 3) / 4;            // MFMA k-steps over the whole K = H
-    constexpr int KH0 = (KSTEPS + 1) / 2;          // k-steps of the first wave half
-    constexpr int S = (H + HW - 1) / HW;
+    constexpr int KPW = (KSTEPS + KSPLIT - 1) / KSPLIT;
+    constexpr int S = (H + HW_ - 1) / HW_;         // workgroups per group (1: no exchange at all)
+    constexpr int GT = CBS * HW_ / 2;              // gate-phase threads (2 units x 1 clip each)
+    static_assert(NTILES * KSPLIT == 12 && GT <= CNT, "12 waves must tile (column tiles x K groups)");
     __shared__ float hT[H * CBS];                  // state, k-major [k][clip]
-    __shared__ float red[2][CBS][NW];              // partial products of the two K halves
+    __shared__ float red[KSPLIT][CBS][NW_];        // partial products of the K groups
     __shared__ int ok_flag;
 
     const int s = blockIdx.x, bsl = blockIdx.y, dir = blockIdx.z;
     const int nbs = gridDim.y;
     const int b0 = bsl * CBS;
     const int nb = min(CBS, B - b0);
-    const int u0 = s * HW;
+    const int u0 = s * HW_;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = wave % 6, kh = wave / 6;        // MFMA tile column block / K half
+    const int nt = wave % NTILES, kh = wave / NTILES;
     const int group = dir * nbs + bsl;
     float* X = xbuf + (size_t)group * 2 * H * CBS; // [parity][H/2][CBS][2]
     int* C = cnt + (size_t)group * T;
@@ -87,17 +92,16 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
     const float* bh = bhh + dir * H3;
 
     // B operands of this wave, resident for the whole launch: B[k][j] = W_hh[gate col(nt*16 + j)][k]
-    const int kbeg = kh ? KH0 : 0;
-    const int nks = kh ? (KSTEPS - KH0) : KH0;
-    float breg[KH0];
+    const int kbeg = kh * KPW;
+    float breg[KPW];
     {
-        const int cl = nt * 16 + (lane & 15);      // local gate column 0..95
-        const int g = cl / HW, ul = cl - g * HW;
+        const int cl = nt * 16 + (lane & 15);      // local gate column
+        const int g = cl / HW_, ul = cl - g * HW_;
         const int u = u0 + ul;
 #pragma unroll
-        for (int i = 0; i < KH0; ++i) {
+        for (int i = 0; i < KPW; ++i) {
             const int k = (kbeg + i) * 4 + (lane >> 4);
-            breg[i] = (i < nks && k < H && u < H) ? W[(size_t)k * H3 + g * H + u] : 0.f;
+            breg[i] = (kbeg + i < KSTEPS && k < H && u < H) ? W[(size_t)k * H3 + g * H + u] : 0.f;
         }
     }
     for (int i = tid; i < H * CBS; i += CNT) hT[i] = 0.f;
@@ -107,10 +111,18 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
     if (tid == 0) ok_flag = 1;
     __syncthreads();
 
-    // gate-phase mapping: 256 threads, clip fastest (coalesced exchange stores)
-    const int gb = tid & 15, gup = (tid >> 4) & 15;
+    // gate-phase mapping: clip fastest (coalesced exchange stores)
+    const int gb = tid & 15, gup = tid >> 4;
     const int gu = u0 + 2 * gup;                   // first of the two units of this thread
-    const bool gate_thread = tid < 256 && gb < nb && gu < H;
+    const bool gate_lane = tid < GT && gu < H;
+    const bool gate_thread = gate_lane && gb < nb;
+    float bias_r[2], bias_z[2], bias_n[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bias_r[j] = gate_lane ? bh[gu + j] : 0.f;
+        bias_z[j] = gate_lane ? bh[H + gu + j] : 0.f;
+        bias_n[j] = gate_lane ? bh[2 * H + gu + j] : 0.f;
+    }
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
             giz = *reinterpret_cast<const float2*>(gp + H);
             gin = *reinterpret_cast<const float2*>(gp + 2 * H);
         }
-        if (step > 0) {
+        if (S > 1 && step > 0) {
             if (tid == 0 && ok_flag) {
                 if (!wait_count(C + (step - 1), S, err)) ok_flag = 0;
             }
@@ -140,9 +152,9 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
         // ---- 16 x H times H x 16 per wave on the f32 MFMA pipe
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < KH0; ++i) {
+        for (int i = 0; i < KPW; ++i) {
             const int k = (kbeg + i) * 4 + (lane >> 4);
-            const float a = (i < nks && k < H) ? hT[k * CBS + (lane & 15)] : 0.f;
+            const float a = (kbeg + i < KSTEPS && k < H) ? hT[k * CBS + (lane & 15)] : 0.f;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[i], acc, 0, 0, 0);
         }
 #pragma unroll
@@ -155,9 +167,13 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int u = gu + j, c = ul + j;
-                const float ghr = red[0][gb][c] + red[1][gb][c] + bh[u];
-                const float ghz = red[0][gb][HW + c] + red[1][gb][HW + c] + bh[H + u];
-                const float ghn = red[0][gb][2 * HW + c] + red[1][gb][2 * HW + c] + bh[2 * H + u];
+                float ghr = bias_r[j], ghz = bias_z[j], ghn = bias_n[j];
+#pragma unroll
+                for (int q = 0; q < KSPLIT; ++q) {
+                    ghr += red[q][gb][c];
+                    ghz += red[q][gb][HW_ + c];
+                    ghn += red[q][gb][2 * HW_ + c];
+                }
                 const float r = sigmoidf_((j ? gir.y : gir.x) + ghr);
                 const float z = sigmoidf_((j ? giz.y : giz.x) + ghz);
                 const float n = tanhf((j ? gin.y : gin.x) + r * ghn);
@@ -174,17 +190,22 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
                     gs[2 * H + u] = n;
                     gs[3 * H + u] = ghn;
                 }
+                if (S == 1) hT[u * CBS + gb] = hnew;          // single workgroup per group: the state never leaves LDS
             }
-            if (step + 1 < T)
+            if (S > 1 && step + 1 < T)
                 st_sc1(X + (size_t)(step & 1) * H * CBS + ((size_t)(gu >> 1) * CBS + gb) * 2, hn2[0], hn2[1]);
-        } else if (tid < 256 && gu < H && step + 1 < T) {
+        } else if (S > 1 && gate_lane && step + 1 < T) {
             // clips beyond B: publish zeros so the group's state stays defined
             st_sc1(X + (size_t)(step & 1) * H * CBS + ((size_t)(gu >> 1) * CBS + gb) * 2, 0.f, 0.f);
         }
-        if (step + 1 < T) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores
+        if (S > 1) {
+            if (step + 1 < T) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(C + step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
             __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(C + step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -192,7 +213,7 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------
 // backward through time
 // ---------------------------------------------------------------------------------------------------------
-template <int H>
+template <int H, int HW_>
 __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ dy, int lddy, int dy_dir_stride,
                                                       const float* __restrict__ whh, const float* __restrict__ y,
                                                       const float* __restrict__ gates, float* __restrict__ dgi,
@@ -200,24 +221,26 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
                                                       int T, float drop_p, float inv_keep,
                                                       const unsigned long long* rng, unsigned site) {
     constexpr int H3 = 3 * H;
+    constexpr int NT_B = HW_ / 16;                 // dh column tiles
+    constexpr int NKS = 12 / NT_B;                 // K slices (12 waves)
     constexpr int KSTEPS = (H3 + 3) / 4;           // k-steps over K = 3H
-    constexpr int NKS = 6;                         // K slices (12 waves = 2 column tiles x 6 slices)
     constexpr int KPW = (KSTEPS + NKS - 1) / NKS;  // k-steps per wave
-    constexpr int S = (H + HW - 1) / HW;
-    extern __shared__ __attribute__((aligned(16))) float smem_bwd[];   // 72 KB: above the 64 KB static limit
+    constexpr int S = (H + HW_ - 1) / HW_;
+    constexpr int GT = CBS * HW_ / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem_bwd[];   // up to 72 KB: above the static limit
     float* gT = smem_bwd;                                      // [3H][CBS] d(gh) of this step, whole group, k-major
-    float (*red)[CBS][HW] = reinterpret_cast<float (*)[CBS][HW]>(gT + H3 * CBS);          // [NKS][CBS][HW]
-    float (*dh)[HW] = reinterpret_cast<float (*)[HW]>(gT + H3 * CBS + NKS * CBS * HW);    // [CBS][HW] running dL/dh
+    float (*red)[CBS][HW_] = reinterpret_cast<float (*)[CBS][HW_]>(gT + H3 * CBS);          // [NKS][CBS][HW_]
+    float (*dh)[HW_] = reinterpret_cast<float (*)[HW_]>(gT + H3 * CBS + NKS * CBS * HW_);   // [CBS][HW_] running dL/dh
     __shared__ int ok_flag;
 
     const int s = blockIdx.x, bsl = blockIdx.y, dir = blockIdx.z;
     const int nbs = gridDim.y;
     const int b0 = bsl * CBS;
     const int nb = min(CBS, B - b0);
-    const int u0 = s * HW;
+    const int u0 = s * HW_;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = wave & 1, ksl = wave >> 1;
+    const int nt = wave % NT_B, ksl = wave / NT_B;
     const int group = dir * nbs + bsl;
     float* X = xbuf + (size_t)group * 2 * H3 * CBS;   // [parity][3H/2][CBS][2]
     int* C = cnt + (size_t)group * T;
@@ -233,7 +256,7 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
             breg[i] = (kbeg + i < KSTEPS && k < H3 && j < H) ? W[(size_t)k * H + j] : 0.f;
         }
     }
-    for (int i = tid; i < CBS * HW; i += CNT) (&dh[0][0])[i] = 0.f;   // dh is contiguous [CBS][HW]
+    for (int i = tid; i < CBS * HW_; i += CNT) (&dh[0][0])[i] = 0.f;   // dh is contiguous [CBS][HW_]
     for (int i = tid; i < H3 * CBS; i += CNT) gT[i] = 0.f;
     SiteKey key{0, 0};
     const bool drop = drop_p > 0.f;
@@ -241,15 +264,16 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
     if (tid == 0) ok_flag = 1;
     __syncthreads();
 
-    const int gb = tid & 15, gup = (tid >> 4) & 15;
+    const int gb = tid & 15, gup = tid >> 4;
     const int gu = u0 + 2 * gup;
-    const bool gate_thread = tid < 256 && gb < nb && gu < H;
+    const bool gate_lane = tid < GT && gu < H;
+    const bool gate_thread = gate_lane && gb < nb;
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? step : (T - 1 - step);
         const int tprev = dir ? t + 1 : t - 1;
         // ---- phase A: gate gradients of this workgroup's units, published to the group
-        if (tid < 256 && gu < H) {
+        if (gate_lane) {
             float o[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
             if (gate_thread) {
                 const long long row = (long long)(b0 + gb) * T + t;
@@ -281,29 +305,39 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
                 }
             }
             if (step + 1 < T) {
-                float* Xp = X + (size_t)(step & 1) * H3 * CBS;
+                if (S > 1) {
+                    float* Xp = X + (size_t)(step & 1) * H3 * CBS;
 #pragma unroll
-                for (int gI = 0; gI < 3; ++gI)
-                    st_sc1(Xp + ((size_t)((gI * H + gu) >> 1) * CBS + gb) * 2, o[gI][0], o[gI][1]);
+                    for (int gI = 0; gI < 3; ++gI)
+                        st_sc1(Xp + ((size_t)((gI * H + gu) >> 1) * CBS + gb) * 2, o[gI][0], o[gI][1]);
+                } else {
+#pragma unroll
+                    for (int gI = 0; gI < 3; ++gI) {
+                        gT[(gI * H + gu) * CBS + gb] = o[gI][0];
+                        gT[(gI * H + gu + 1) * CBS + gb] = o[gI][1];
+                    }
+                }
             }
         }
         if (step + 1 == T) break;                   // the last step's dh is never consumed
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(C + step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ok_flag && !wait_count(C + step, S, err)) ok_flag = 0;
+        if (S > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(C + step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ok_flag && !wait_count(C + step, S, err)) ok_flag = 0;
+            }
+            __syncthreads();
+            const float* Xp = X + (size_t)(step & 1) * H3 * CBS;
+            for (int i = tid; i < (H3 / 2) * CBS; i += CNT) {
+                const float2 v = ld_sc1(Xp + 2 * i);
+                const int kp = i / CBS, c = i - kp * CBS;
+                gT[(2 * kp) * CBS + c] = v.x;
+                gT[(2 * kp + 1) * CBS + c] = v.y;
+            }
         }
         __syncthreads();
-        const float* Xp = X + (size_t)(step & 1) * H3 * CBS;
-        for (int i = tid; i < (H3 / 2) * CBS; i += CNT) {
-            const float2 v = ld_sc1(Xp + 2 * i);
-            const int kp = i / CBS, c = i - kp * CBS;
-            gT[(2 * kp) * CBS + c] = v.x;
-            gT[(2 * kp + 1) * CBS + c] = v.y;
-        }
-        __syncthreads();
-        // ---- phase B: dh[16 x 32] += d(gh)[16 x 3H] . W_hh[3H x 32]
+        // ---- phase B: dh[16 x HW] += d(gh)[16 x 3H] . W_hh[3H x HW]
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
@@ -314,8 +348,8 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 4; ++q) red[ksl][(lane >> 4) * 4 + q][nt * 16 + (lane & 15)] = acc[q];
         __syncthreads();
-        for (int e = tid; e < CBS * HW; e += CNT) {
-            const int b = e / HW, c = e - b * HW;
+        for (int e = tid; e < CBS * HW_; e += CNT) {
+            const int b = e / HW_, c = e - b * HW_;
             float v = dh[b][c];
 #pragma unroll
             for (int q = 0; q < NKS; ++q) v += red[q][b][c];
@@ -334,7 +368,9 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // ---------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------
-extern "C" int s2ag_gru_coop_supported(int H) { return H == 300 ? 1 : 0; }
+// H = 300: groups of 10 workgroups (32 units each) exchanging h per step;  H = 64: one workgroup per group
+// (64 units, no exchange at all -- the small discriminator GRU simply lives in registers + LDS)
+extern "C" int s2ag_gru_coop_supported(int H) { return (H == 300 || H == 64) ? 1 : 0; }
 
 extern "C" long long s2ag_gru_coop_workspace_bytes(int B, int T, int H, int backward) {
     if (B <= 0 || T <= 0 || !s2ag_gru_coop_supported(H)) return 0;
@@ -373,11 +409,19 @@ extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whhT, const float
     const float p = (e && ydrop) ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
     Ws w = carve(workspace, B, T, H, 0);
-    { hipError_t ze = zero_async(w.cnt, w.zero_bytes, (hipStream_t)stream); if (ze != hipSuccess) return (int)ze; }
-    dim3 grid((H + HW - 1) / HW, cdiv(B, CBS), 2);
-    hipLaunchKernelGGL(gru_coop_fwd_k<300>, grid, dim3(CNT), 0, (hipStream_t)stream, gi, whhT, bhh, y, ydrop, gates,
-                       w.x, w.cnt, w.err, B, T, p, p > 0.f ? 1.f / (1.f - p) : 1.f, e ? e->rng : nullptr,
-                       e ? e->site : 0u);
+    if (H == 300) {   // H = 64 runs one workgroup per group: no counters to re-arm
+        hipError_t ze = zero_async(w.cnt, w.zero_bytes, (hipStream_t)stream);
+        if (ze != hipSuccess) return (int)ze;
+    }
+    const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const unsigned long long* rg = e ? e->rng : nullptr;
+    const unsigned site = e ? e->site : 0u;
+    if (H == 300)
+        hipLaunchKernelGGL((gru_coop_fwd_k<300, 32>), dim3(10, cdiv(B, CBS), 2), dim3(CNT), 0, (hipStream_t)stream, gi,
+                           whhT, bhh, y, ydrop, gates, w.x, w.cnt, w.err, B, T, p, ik, rg, site);
+    else
+        hipLaunchKernelGGL((gru_coop_fwd_k<64, 64>), dim3(1, cdiv(B, CBS), 2), dim3(CNT), 0, (hipStream_t)stream, gi,
+                           whhT, bhh, y, ydrop, gates, w.x, w.cnt, w.err, B, T, p, ik, rg, site);
     S2AG_LAUNCH_CHECK();
     return 0;
 }
@@ -390,19 +434,29 @@ extern "C" int s2ag_gru_coop_bwd(const float* dy, int lddy, int dy_dir_stride, c
     const float p = e ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
     Ws w = carve(workspace, B, T, H, 1);
-    { hipError_t ze = zero_async(w.cnt, w.zero_bytes, (hipStream_t)stream); if (ze != hipSuccess) return (int)ze; }
-    dim3 grid((H + HW - 1) / HW, cdiv(B, CBS), 2);
-    constexpr size_t smem = sizeof(float) * (3 * 300 * CBS + 6 * CBS * HW + CBS * HW);
-    static bool granted = false;
-    if (!granted) {
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_coop_bwd_k<300>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (ae != hipSuccess) return (int)ae;
-        granted = true;
+    if (H == 300) {   // H = 64 runs one workgroup per group: no counters to re-arm
+        hipError_t ze = zero_async(w.cnt, w.zero_bytes, (hipStream_t)stream);
+        if (ze != hipSuccess) return (int)ze;
     }
-    hipLaunchKernelGGL(gru_coop_bwd_k<300>, grid, dim3(CNT), smem, (hipStream_t)stream, dy, lddy, dy_dir_stride, whh, y,
-                       gates, dgi, dgh, w.x, w.cnt, w.err, B, T, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
-                       e ? e->rng : nullptr, e ? e->site : 0u);
+    const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const unsigned long long* rg = e ? e->rng : nullptr;
+    const unsigned site = e ? e->site : 0u;
+    if (H == 300) {
+        constexpr size_t smem = sizeof(float) * (3 * 300 * CBS + 6 * CBS * 32 + CBS * 32);
+        static bool granted = false;
+        if (!granted) {
+            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (ae != hipSuccess) return (int)ae;
+            granted = true;
+        }
+        hipLaunchKernelGGL((gru_coop_bwd_k<300, 32>), dim3(10, cdiv(B, CBS), 2), dim3(CNT), smem, (hipStream_t)stream,
+                           dy, lddy, dy_dir_stride, whh, y, gates, dgi, dgh, w.x, w.cnt, w.err, B, T, p, ik, rg, site);
+    } else {
+        constexpr size_t smem = sizeof(float) * (3 * 64 * CBS + 3 * CBS * 64 + CBS * 64);
+        hipLaunchKernelGGL((gru_coop_bwd_k<64, 64>), dim3(1, cdiv(B, CBS), 2), dim3(CNT), smem, (hipStream_t)stream, dy,
+                           lddy, dy_dir_stride, whh, y, gates, dgi, dgh, w.x, w.cnt, w.err, B, T, p, ik, rg, site);
+    }
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -485,7 +485,9 @@ def fold(w: Tensor, csr: CSR) -> Tensor:
 # ----------------------------------------------------------------------------------------------------
 # multi-layer bidirectional GRU
 # ----------------------------------------------------------------------------------------------------
-USE_COOP_GRU = True          # cooperative on-chip-W_hh recurrence where supported (H = 300); else L2-streaming kernels
+USE_COOP_GRU = True          # cooperative on-chip-W_hh recurrence where supported (H = 300, 64); else L2-streaming kernels
+COOP_GRU_MIN_H = 128         # forward: below this the streaming kernels are used (H = 64 variant exists, measured slower in the full step)
+COOP_GRU_BWD_MIN_H = 128     # backward: at H = 64 the streaming BPTT kernel measured faster (tools/bench_gru.py)
 _COOP_WS = __import__('collections').deque(maxlen=64)   # recent cooperative workspaces (error words, debugging)
 
 
@@ -527,11 +529,12 @@ class _GRU(torch.autograd.Function):
             use_drop = bool(training) and drop_p > 0 and not last
             ydrop = torch.empty_like(y) if use_drop else None
             e = _epi(L.ACT_NONE, 1.0, drop_p if use_drop else 0.0, noise, site0 + l)
-            if USE_COOP_GRU and lib.s2ag_gru_coop_supported(H):
+            if USE_COOP_GRU and H >= COOP_GRU_MIN_H and lib.s2ag_gru_coop_supported(H):
                 ws = torch.empty(lib.s2ag_gru_coop_workspace_bytes(B, T, H, 0), dtype=torch.uint8, device=dev)
                 L.check(lib.s2ag_gru_coop_fwd(_p(gi), _p(whhT), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T, H,
                                               C.byref(e), _p(ws), _stream()), 'gru_coop_fwd')
-                _COOP_WS.append((ws, B, T, H, 0))
+                if H > 64:                       # H = 64 runs without an exchange: its error word is never written
+                    _COOP_WS.append((ws, B, T, H, 0))
             else:
                 L.check(lib.s2ag_gru_seq_fwd(_p(gi), _p(whhT), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T, H,
                                              C.byref(e), _stream()), 'gru_seq_fwd')
@@ -573,11 +576,12 @@ class _GRU(torch.autograd.Function):
             dgi = torch.empty(B * T, 2 * H3, dtype=torch.float32, device=dev)
             dgh = torch.empty(2, B * T, H3, dtype=torch.float32, device=dev)
             e = _epi(L.ACT_NONE, 1.0, drop_p if use_drop else 0.0, ctx.noise, site0 + l)
-            if USE_COOP_GRU and lib.s2ag_gru_coop_supported(H):
+            if USE_COOP_GRU and H >= COOP_GRU_BWD_MIN_H and lib.s2ag_gru_coop_supported(H):
                 ws = torch.empty(lib.s2ag_gru_coop_workspace_bytes(B, T, H, 1), dtype=torch.uint8, device=dev)
                 L.check(lib.s2ag_gru_coop_bwd(_p(dy), lddy, dir_stride, _p(whh2), _p(y), _p(gates), _p(dgi), _p(dgh),
                                               B, T, H, C.byref(e), _p(ws), _stream()), 'gru_coop_bwd')
-                _COOP_WS.append((ws, B, T, H, 1))
+                if H > 64:
+                    _COOP_WS.append((ws, B, T, H, 1))
             else:
                 L.check(lib.s2ag_gru_seq_bwd(_p(dy), lddy, dir_stride, _p(whh2), _p(y), _p(gates), _p(dgi), _p(dgh),
                                              B, T, H, C.byref(e), _stream()), 'gru_seq_bwd')
