@@ -120,6 +120,77 @@ def gru_roofline(B, iters=20):
                 algorithmic_flops_per_launch=flops)
 
 
+def _graph_timer(fn, iters, warm=3):
+    """Capture ``fn`` into a HIP graph and return the median replay time in ms (HIP events on the launch stream)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def gen_forward_ms(pr, device):
+    """BASELINE metric tail 'gen fwd ms': PoseGenerator forward, eval mode, B = 4 and B = 128, median of 100 replays."""
+    out = {}
+    G = pr.s2ag_generator
+    was = G.training
+    G.eval()
+    try:
+        for B in (4, 128):
+            text, audio, mfcc, target, vid = synthetic_batch(B, 99, device)
+            pre = pr._make_pre_seq(target)
+
+            def fn():
+                with torch.no_grad():
+                    G(pre, text, mfcc, vid)
+            out[f'b{B}'] = _graph_timer(fn, 100)
+    finally:
+        G.train(was)
+    return out
+
+
+def conv1d_roofline_run(device, B=256, iters=30):
+    """BASELINE configs[3] (the 'Conv1d roofline run'): WavEncoder + TextEncoderTCN forward + backward, train mode,
+    dropout on, isolated, B = 256, fp32.  HBM-bound by design: algorithmic traffic 5.75 MB/clip (SURVEY.md 8d:
+    every layer reads its input and writes its output once forward; backward re-reads x, reads dy, writes dx)."""
+    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import TextEncoderTCN, WavEncoder
+    from speech2affective_gestures_amd.optim import ParamArena
+    cfg = make_cfg()
+    wav, txt = WavEncoder().to(device).train(), TextEncoderTCN(cfg, N_WORDS, 300, dropout=cfg.dropout_prob).to(device).train()
+    arena = ParamArena(list(wav.parameters()) + list(txt.parameters()))
+    text, audio, _, _, _ = synthetic_batch(B, 5, device)
+
+    def fn():
+        arena.zero_grad()
+        (wav(audio).sum() + txt(text)[0].sum()).backward()
+    ms = _graph_timer(fn, iters)
+    clips = B / (ms * 1e-3)
+    bytes_per_clip, flops_per_clip = 5.75e6, 413.8e6
+    return dict(workload='BASELINE configs[3]: WavEncoder + TextEncoderTCN fwd+bwd, B=256, T=34, fp32, dropout on',
+                ms_per_iter=ms, clips_per_s=clips,
+                roofline=dict(bound='hbm', achieved=clips * bytes_per_clip / 1e9, peak=8000.0, unit='GB/s',
+                              frac=clips * bytes_per_clip / 8e12, traffic=None,
+                              note='fp32 MFMA (157.3 TF) caps this path at ~27% of the HBM roofline: '
+                                   f'{clips * flops_per_clip / 1e12:.1f} TFLOP/s achieved of 157.3'))
+
+
 def cpu_baseline(B, steps=2):
     """The oracle's gan_step (ATen fused GRU, drawn dropout) on the host cores -- bounded sample."""
     from oracle import s2ag_oracle as O
@@ -169,6 +240,7 @@ def main():
     ap.add_argument('--batch', type=int, default=128, help='clips per GPU')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip gen-forward latency and the Conv1d roofline run')
     a = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -209,6 +281,9 @@ def main():
                        'last_step_losses': pr.last_losses if metric is not None else None},
         }
         line['roofline'] = gru_roofline(a.batch)
+        if dp.world_size == 1 and not a.no_extras:
+            line['gen_fwd_ms'] = gen_forward_ms(pr, pr.device)
+            line['conv1d_roofline_run'] = conv1d_roofline_run(pr.device)
         if dp.world_size == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(a.batch)
             line['gpu_over_cpu'] = value / line['cpu_baseline']['value']

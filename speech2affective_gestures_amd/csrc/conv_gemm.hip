@@ -545,6 +545,143 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradP p) {
         }
 }
 
+// ---- weight gradient, second generation --------------------------------------------------------------------
+// Same pipeline as conv_gemm2_k: 32 contraction rows per tile, double-buffered LDS (one barrier per tile), next-but-
+// one tile in flight, 8 waves with a 2-way in-block split of every tile.  Both operands are read along their
+// contiguous channel axis (gy rows over co, x rows over ci), so every global load is coalesced and the k-major LDS
+// image is written conflict-free.  Blocks split the clips*frames axis (grid.z) and merge with fp32 atomics.
+__global__ __launch_bounds__(512) void conv_wgrad2_k(WgradP p) {
+    constexpr int PW = 64 + 16;                       // k-major pitch: fragment reads of 4 k-rows hit disjoint banks
+    __shared__ float As[2][BK2][PW];                  // [m][co]
+    __shared__ float Bs[2][BK2][PW];                  // [m][j = tap*Cin + ci]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int co0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int mbeg = blockIdx.z * p.chunk;
+    const int mend = min(p.Mtot, mbeg + p.chunk);
+    const int cidx = tid & 63, mq = tid >> 6;         // mq 0..7 -> rows mq*4 .. mq*4+3 of the 32-row tile
+    const int NCW = p.ks * p.Cin;
+    const int co = co0 + cidx;
+    const bool covalid = co < p.Cout;
+    const int jcol = j0 + cidx;
+    const bool jvalid = jcol < NCW;
+    int tap = 0, ci = 0;
+    if (jvalid) {
+        tap = jcol / p.Cin;
+        ci = jcol - tap * p.Cin;
+    }
+    const int tapoff = tap * p.dil - p.pad;
+
+    float ra0[4], rb0[4], ra1[4], rb1[4];
+    auto fetch = [&](float (&ra)[4], float (&rb)[4], int mb) {
+        int mm = mb + mq * 4;
+        int nclip = mm / p.Lout;
+        int l = mm - nclip * p.Lout;
+#pragma unroll
+        for (int j = 0; j < 4; ++j, ++mm) {
+            float a = 0.f, b = 0.f;
+            if (mm < mend) {
+                if (covalid) a = p.gy[(long long)mm * p.ldg + co];
+                if (jvalid) {
+                    const int pos = l * p.stride + tapoff;
+                    if (pos >= 0 && pos < p.Lin) b = p.x[((long long)nclip * p.Lin + pos) * p.ldx + ci];
+                }
+            }
+            ra[j] = a;
+            rb[j] = b;
+            if (++l == p.Lout) { l = 0; ++nclip; }
+        }
+    };
+    auto stash = [&](const float (&ra)[4], const float (&rb)[4], int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            As[buf][mq * 4 + j][cidx] = ra[j];
+            Bs[buf][mq * 4 + j][cidx] = rb[j];
+        }
+    };
+    bool rowlive[2], collive[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        rowlive[t] = (co0 + wm * 32 + t * 16) < p.Cout;
+        collive[t] = (j0 + wn * 32 + t * 16) < NCW;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](int cur) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kr = (kg * 4 + s) * 4 + (lane >> 4);
+            const int li = lane & 15;
+            const float a0 = As[cur][kr][wm * 32 + li], a1 = As[cur][kr][wm * 32 + 16 + li];
+            const float b0 = Bs[cur][kr][wn * 32 + li], b1 = Bs[cur][kr][wn * 32 + 16 + li];
+            if (rowlive[0] && collive[0]) acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            if (rowlive[0] && collive[1]) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            if (rowlive[1] && collive[0]) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            if (rowlive[1] && collive[1]) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    };
+    const int nkt = (mend - mbeg + BK2 - 1) / BK2;
+    if (nkt <= 0) return;
+    fetch(ra0, rb0, mbeg);
+    stash(ra0, rb0, 0);
+    if (nkt > 1) fetch(ra0, rb0, mbeg + BK2);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        if (kt + 2 < nkt) fetch(ra1, rb1, mbeg + (kt + 2) * BK2);
+        mma(0);
+        if (kt + 1 < nkt) stash(ra0, rb0, 1);
+        __syncthreads();
+        if (kt + 1 >= nkt) break;
+        if (kt + 3 < nkt) fetch(ra0, rb0, mbeg + (kt + 3) * BK2);
+        mma(1);
+        if (kt + 2 < nkt) stash(ra1, rb1, 0);
+        __syncthreads();
+    }
+    // merge the two wave groups through LDS so only one of them issues the (cross-block) atomics
+    {
+        float* redw = &As[0][0][0];                   // 2*32*80 floats >= 64*64
+        if (kg == 1) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        redw[(wm * 32 + ti * 16 + (lane >> 4) * 4 + q) * 64 + wn * 32 + tj * 16 + (lane & 15)] =
+                            acc[ti][tj][q];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[ti][tj][q] +=
+                        redw[(wm * 32 + ti * 16 + (lane >> 4) * 4 + q) * 64 + wn * 32 + tj * 16 + (lane & 15)];
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int jc = j0 + wn * 32 + tj * 16 + (lane & 15);
+            if (jc >= NCW) continue;
+            const int t2 = jc / p.Cin, c2 = jc - t2 * p.Cin;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = co0 + wm * 32 + ti * 16 + (lane >> 4) * 4 + q;
+                if (row >= p.Cout) continue;
+                atomicAdd(p.dw + (p.wtm ? ((long long)row * p.ks + t2) * p.Cin + c2
+                                        : ((long long)row * p.Cin + c2) * p.ks + t2), acc[ti][tj][q]);
+            }
+        }
+}
+
 // ---- column sums (bias gradients, BatchNorm batch statistics) ---------------------------------------
 __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ x, int rows, int cols, int ld,
                                                 int rows_per_block, float* out, float* sq) {
@@ -664,14 +801,20 @@ extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float
     const int max_split = cdiv(p.Mtot, 4 * BK);
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
-    p.chunk = cdiv(cdiv(p.Mtot, nsplit), BK) * BK;
+    p.chunk = cdiv(cdiv(p.Mtot, nsplit), BK2) * BK2;
     nsplit = cdiv(p.Mtot, p.chunk);
+    // the 8-wave pipelined kernel pays off when a block contracts many rows (GRU / Linear weight gradients);
+    // short contractions into big outputs are bound by the merge atomics and keep the lighter 4-wave kernel
+    const bool v2 = g->ksize == 1 && p.chunk >= 256;
     if (!accumulate) {
         hipError_t me = zero_async(dw, sizeof(float) * (size_t)g->Cout * g->Cin * g->ksize, (hipStream_t)stream);
         if (me != hipSuccess) return (int)me;
     }
     dim3 grid(cdiv(g->Cout, BM), cdiv(g->ksize * g->Cin, BN), nsplit);
-    hipLaunchKernelGGL(conv_wgrad_k, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (v2)
+        hipLaunchKernelGGL(conv_wgrad2_k, grid, dim3(512), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv_wgrad_k, grid, dim3(256), 0, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }
