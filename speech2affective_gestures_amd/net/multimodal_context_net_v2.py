@@ -287,15 +287,19 @@ class PoseGeneratorTriModal(nn.Module, _SpeakerZ):
         self.out = nn.Sequential(nn.Linear(self.hidden_size, self.hidden_size // 2), nn.LeakyReLU(True),
                                  nn.Linear(self.hidden_size // 2, pose_dim))
         self.do_flatten_parameters = False
+        self._branches = ops.BranchStreams(2)
 
     def forward(self, pre_seq, in_text, in_audio, vid_indices=None):
         with noise_pass(pre_seq.device) as nz:
             audio = text = None
+            fns = [lambda: self._z(in_text, vid_indices, nz)]
             if self.input_context != 'none':
-                audio = self.audio_encoder(in_audio)
-                text, _ = self.text_encoder(in_text)
+                fns = [lambda: self.audio_encoder(in_audio), lambda: self.text_encoder(in_text)[0]] + fns
+            res = self._branches.run(fns, pre_seq.device, ops.PARALLEL_BRANCHES)
+            z_context, z_mu, z_log_var = res[-1]
+            if self.input_context != 'none':
+                audio, text = res[0], res[1]
                 assert audio.shape[1] == text.shape[1]
-            z_context, z_mu, z_log_var = self._z(in_text, vid_indices, nz)
             out = self._decode(self._context(pre_seq, audio, text), z_context, nz, out_slope=1.0)
         return out, z_context, z_mu, z_log_var
 
@@ -368,6 +372,7 @@ class PoseGenerator(nn.Module, _SpeakerZ):
         self.out = nn.Sequential(nn.Linear(self.hidden_size, self.hidden_size // 2), nn.LeakyReLU(inplace=True),
                                  nn.Linear(self.hidden_size // 2, pose_dim))
         self.do_flatten_parameters = False
+        self._branches = ops.BranchStreams(3)
 
     def _make_audio_encoder(self, mfcc_length, num_mfcc, time_steps):
         return MFCCEncoder(mfcc_length, num_mfcc, time_steps)
@@ -375,14 +380,17 @@ class PoseGenerator(nn.Module, _SpeakerZ):
     def forward(self, pre_seq, in_text, in_mfcc, vid_indices=None):
         with noise_pass(pre_seq.device) as nz:
             audio = text = None
+            # four independent encoder branches -> four streams (joined before the concat that feeds the GRU)
+            fns = [lambda: self.aff_encoder(pre_seq[..., :-1]), lambda: self._z(in_text, vid_indices, nz)]
             if self.input_context != 'none':
-                audio = self.audio_encoder(in_mfcc)
-                text, _ = self.text_encoder(in_text)
+                fns += [lambda: self.text_encoder(in_text)[0], lambda: self.audio_encoder(in_mfcc)]
+            res = self._branches.run(fns, pre_seq.device, ops.PARALLEL_BRANCHES)
+            pre, (z_context, z_mu, z_log_var) = res[0], res[1]
+            if self.input_context != 'none':
+                text, audio = res[2], res[3]
                 assert audio.shape[1] == text.shape[1], \
                     'Audio and text features must have the same number of time steps. ' \
                     'Found time steps: audio features: {}, text features: {}.'.format(audio.shape[1], text.shape[1])
-            z_context, z_mu, z_log_var = self._z(in_text, vid_indices, nz)
-            pre = self.aff_encoder(pre_seq[..., :-1])
             out = self._decode(self._context(pre, audio, text), z_context, nz, out_slope=0.01)
         return out, z_context, z_mu, z_log_var
 

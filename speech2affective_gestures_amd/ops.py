@@ -710,3 +710,77 @@ def gen_loss(out, dis_out, mu, log_var, target, out_tri, out_rand, z, z_rand, we
     weights = (regression, gan, div_reg, kld)."""
     return _GenLoss.apply(out, dis_out, mu, log_var, target.detach(), None if out_tri is None else out_tri.detach(),
                           out_rand.detach(), z.detach(), z_rand.detach(), tuple(weights))
+
+
+# ----------------------------------------------------------------------------------------------------
+# stream-level parallelism of independent branches
+# ----------------------------------------------------------------------------------------------------
+_DIRTY_STREAMS = []      # side streams that carried work since the last join_side_streams()
+
+
+def mark_side_stream(s) -> None:
+    if not any(s is t for t in _DIRTY_STREAMS):
+        _DIRTY_STREAMS.append(s)
+
+
+def join_side_streams() -> None:
+    """Make the current stream wait for every side stream used since the last call.  Needed after ``backward()``:
+    backward kernels run on the stream of their forward op, and because weight gradients are accumulated in place
+    (no AccumulateGrad node) autograd does not join those streams itself."""
+    cur = torch.cuda.current_stream()
+    while _DIRTY_STREAMS:
+        s = _DIRTY_STREAMS.pop()
+        if s is not cur:
+            cur.wait_stream(s)
+
+
+class BranchStreams:
+    """A few side streams owned by one module.  ``run([f0, f1, ...])`` executes f0 on the current stream and the
+    others on the side streams (forked after everything queued so far, joined before returning) -- the encoder
+    branches of a generator are chains of small kernels that each fill a fraction of the chip.  Capturable: forks
+    and joins are event waits that hipGraph records as edges."""
+
+    def __init__(self, n_side: int):
+        self.n_side = n_side
+        self._streams = {}
+
+    def _get(self, device):
+        key = (device.index if device.index is not None else torch.cuda.current_device())
+        if key not in self._streams:
+            self._streams[key] = [torch.cuda.Stream(device=device) for _ in range(self.n_side)]
+        return self._streams[key]
+
+    def run(self, fns, device, enabled=True):
+        if not enabled or len(fns) <= 1 or _NO_BRANCH_DEPTH[0] > 0:
+            return [f() for f in fns]
+        cur = torch.cuda.current_stream(device)
+        sides = self._get(device)
+        out = [None] * len(fns)
+        used = []
+        for i, f in enumerate(fns[1:]):
+            s = sides[i % len(sides)]
+            s.wait_stream(cur)
+            mark_side_stream(s)
+            with torch.cuda.stream(s):
+                out[i + 1] = f()
+            used.append(s)
+        out[0] = fns[0]()
+        for s in used:
+            cur.wait_stream(s)
+        return out
+
+
+PARALLEL_BRANCHES = False     # measured: fork/join overhead exceeds the overlap gained (20.9 vs 19.0 ms/step); kept for study
+_NO_BRANCH_DEPTH = [0]
+
+
+class sequential_branches:
+    """Context: modules inside run their branches sequentially.  The trainer wraps passes that already run on a forked
+    stream with it -- forking again from a fork (the same module's branch streams entered from two different parent
+    streams inside one capture) crashes hipGraph capture on ROCm 7.2."""
+
+    def __enter__(self):
+        _NO_BRANCH_DEPTH[0] += 1
+
+    def __exit__(self, *a):
+        _NO_BRANCH_DEPTH[0] -= 1

@@ -263,6 +263,7 @@ class Processor(object):
         """side stream ``idx`` picks up after everything queued on the current stream"""
         s = self._side[idx]
         s.wait_stream(torch.cuda.current_stream())
+        ops.mark_side_stream(s)
         return s
 
     def _dis_phase(self, in_text, in_mfcc, target_poses, vid_indices, pre_seq, train):
@@ -277,7 +278,7 @@ class Processor(object):
         cur = torch.cuda.current_stream()
         if self.overlap_passes:
             side = self._fork(0)
-            with torch.cuda.stream(side), noise.use_pass(nz_real):
+            with torch.cuda.stream(side), noise.use_pass(nz_real), ops.sequential_branches():
                 dis_real = self.s2ag_discriminator(target_poses, in_text)
         with torch.no_grad(), noise.use_pass(nz_g):        # upstream builds this graph and never uses it
             out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
@@ -291,6 +292,7 @@ class Processor(object):
         dis_error = ops.dis_loss(dis_real, dis_fake)
         if train:
             dis_error.backward()
+        ops.join_side_streams()      # backward kernels ran on the forked streams too
         return dis_error.detach()
 
     def _gen_phase(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, pre_seq, train):
@@ -305,7 +307,7 @@ class Processor(object):
         cur = torch.cuda.current_stream()
         if self.overlap_passes:      # the frozen baseline shares nothing with G/D: run it beside the main forward
             side0 = self._fork(0)
-            with torch.cuda.stream(side0), torch.no_grad(), noise.use_pass(nz_tri):
+            with torch.cuda.stream(side0), torch.no_grad(), noise.use_pass(nz_tri), ops.sequential_branches():
                 out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
         else:
             with torch.no_grad(), noise.use_pass(nz_tri):
@@ -314,7 +316,7 @@ class Processor(object):
             out, z, z_mu, z_log_var = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
         if self.overlap_passes:      # G(rand) follows G(main) (BatchNorm running stats order) but runs beside D(gen)
             side1 = self._fork(1)
-            with torch.cuda.stream(side1), torch.no_grad(), noise.use_pass(nz_rand):
+            with torch.cuda.stream(side1), torch.no_grad(), noise.use_pass(nz_rand), ops.sequential_branches():
                 out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, rand_vids)
         # upstream lets loss.backward() also fill D's .grad, which the next D step zeroes unread;
         # skipping those weight-gradient kernels changes nothing observable
@@ -338,6 +340,7 @@ class Processor(object):
                                     (cfg.loss_regression_weight, w_gan, cfg.loss_reg_weight, cfg.loss_kld_weight))
         if train:
             total.backward()
+        ops.join_side_streams()
         return comps
 
     def _finish(self, comps, dis_error):
