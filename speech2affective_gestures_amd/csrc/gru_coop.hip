@@ -58,12 +58,16 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
-template <int H, int HW_>
+template <int H, int HW_, int NSL>
 __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ gi, const float* __restrict__ whhT,
                                                       const float* __restrict__ bhh, float* __restrict__ y,
                                                       float* __restrict__ ydrop, float* __restrict__ gates,
                                                       float* xbuf, int* cnt, int* err, int B, int T, float drop_p,
                                                       float inv_keep, const unsigned long long* rng, unsigned site) {
+    // NSL independent 16-clip slices per workgroup, visited round-robin inside every time step: while slice A's h_t is
+    // travelling to its peers (store drain -> counter -> peers' polls -> their sc1 loads), the workgroup multiplies
+    // slice B -- the exchange latency of one slice hides behind the MFMA + gate phase of the other.  The W_hh
+    // registers are shared by the slices; only the LDS state is per slice.
     constexpr int H3 = 3 * H;
     constexpr int NW_ = 3 * HW_;                   // gate columns owned by this workgroup
     constexpr int NTILES = NW_ / 16;               // MFMA column tiles
@@ -73,21 +77,16 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
     constexpr int S = (H + HW_ - 1) / HW_;         // workgroups per group (1: no exchange at all)
     constexpr int GT = CBS * HW_ / 2;              // gate-phase threads (2 units x 1 clip each)
     static_assert(NTILES * KSPLIT == 12 && GT <= CNT, "12 waves must tile (column tiles x K groups)");
-    __shared__ float hT[H * CBS];                  // state, k-major [k][clip]
-    __shared__ float red[KSPLIT][CBS][NW_];        // partial products of the K groups
+    __shared__ float hT[NSL][H * CBS];             // state per slice, k-major [k][clip]
+    __shared__ float red[KSPLIT][CBS][NW_];        // partial products of the K groups (one slice at a time)
     __shared__ int ok_flag;
 
-    const int s = blockIdx.x, bsl = blockIdx.y, dir = blockIdx.z;
-    const int nbs = gridDim.y;
-    const int b0 = bsl * CBS;
-    const int nb = min(CBS, B - b0);
+    const int s = blockIdx.x, dir = blockIdx.z;
+    const int nbs = (B + CBS - 1) / CBS;           // 16-clip slices in the batch
     const int u0 = s * HW_;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = wave % NTILES, kh = wave / NTILES;
-    const int group = dir * nbs + bsl;
-    float* X = xbuf + (size_t)group * 2 * H * CBS; // [parity][H/2][CBS][2]
-    int* C = cnt + (size_t)group * T;
     const float* W = whhT + (size_t)dir * H * H3;  // (H, 3H): W^T[k][gate col]
     const float* bh = bhh + dir * H3;
 
@@ -104,7 +103,7 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
             breg[i] = (kbeg + i < KSTEPS && k < H && u < H) ? W[(size_t)k * H3 + g * H + u] : 0.f;
         }
     }
-    for (int i = tid; i < H * CBS; i += CNT) hT[i] = 0.f;
+    for (int i = tid; i < NSL * H * CBS; i += CNT) (&hT[0][0])[i] = 0.f;
     SiteKey key{0, 0};
     const bool drop = ydrop != nullptr && drop_p > 0.f;
     if (drop) key = site_key(rng, site);
@@ -115,7 +114,6 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
     const int gb = tid & 15, gup = tid >> 4;
     const int gu = u0 + 2 * gup;                   // first of the two units of this thread
     const bool gate_lane = tid < GT && gu < H;
-    const bool gate_thread = gate_lane && gb < nb;
     float bias_r[2], bias_z[2], bias_n[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -126,86 +124,101 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
-        const long long row = (long long)(b0 + gb) * T + t;
-        // prefetch this step's input projections (latency hides behind the wait + MFMA)
-        float2 gir = make_float2(0.f, 0.f), giz = gir, gin = gir;
-        if (gate_thread) {
-            const float* gp = gi + row * (2 * H3) + dir * H3 + gu;
-            gir = *reinterpret_cast<const float2*>(gp);
-            giz = *reinterpret_cast<const float2*>(gp + H);
-            gin = *reinterpret_cast<const float2*>(gp + 2 * H);
-        }
-        if (S > 1 && step > 0) {
-            if (tid == 0 && ok_flag) {
-                if (!wait_count(C + (step - 1), S, err)) ok_flag = 0;
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+            const int bsl = blockIdx.y * NSL + sl;
+            if (bsl >= nbs) continue;              // uniform per workgroup
+            const int b0 = bsl * CBS;
+            const int nb = min(CBS, B - b0);
+            const bool gate_thread = gate_lane && gb < nb;
+            const int group = dir * nbs + bsl;
+            float* X = xbuf + (size_t)group * 2 * H * CBS; // [parity][H/2][CBS][2]
+            int* C = cnt + (size_t)group * T;
+            float* hs = hT[sl];
+            const long long row = (long long)(b0 + gb) * T + t;
+            // prefetch this step's input projections (latency hides behind the wait + MFMA)
+            float2 gir = make_float2(0.f, 0.f), giz = gir, gin = gir;
+            if (gate_thread) {
+                const float* gp = gi + row * (2 * H3) + dir * H3 + gu;
+                gir = *reinterpret_cast<const float2*>(gp);
+                giz = *reinterpret_cast<const float2*>(gp + H);
+                gin = *reinterpret_cast<const float2*>(gp + 2 * H);
             }
-            __syncthreads();
-            const float* Xp = X + (size_t)((step - 1) & 1) * H * CBS;
-            for (int i = tid; i < (H / 2) * CBS; i += CNT) {
-                const float2 v = ld_sc1(Xp + 2 * i);          // i = kp*CBS + clip
-                const int kp = i / CBS, c = i - kp * CBS;
-                hT[(2 * kp) * CBS + c] = v.x;
-                hT[(2 * kp + 1) * CBS + c] = v.y;
-            }
-            __syncthreads();
-        }
-        // ---- 16 x H times H x 16 per wave on the f32 MFMA pipe
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            const int k = (kbeg + i) * 4 + (lane >> 4);
-            const float a = (kbeg + i < KSTEPS && k < H) ? hT[k * CBS + (lane & 15)] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[i], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) red[kh][(lane >> 4) * 4 + q][nt * 16 + (lane & 15)] = acc[q];
-        __syncthreads();
-        // ---- gates for 2 units x 1 clip per thread
-        if (gate_thread) {
-            const int ul = 2 * gup;
-            float hn2[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int u = gu + j, c = ul + j;
-                float ghr = bias_r[j], ghz = bias_z[j], ghn = bias_n[j];
-#pragma unroll
-                for (int q = 0; q < KSPLIT; ++q) {
-                    ghr += red[q][gb][c];
-                    ghz += red[q][gb][HW_ + c];
-                    ghn += red[q][gb][2 * HW_ + c];
+            if (S > 1 && step > 0) {
+                if (tid == 0 && ok_flag) {
+                    if (!wait_count(C + (step - 1), S, err)) ok_flag = 0;
                 }
-                const float r = sigmoidf_((j ? gir.y : gir.x) + ghr);
-                const float z = sigmoidf_((j ? giz.y : giz.x) + ghz);
-                const float n = tanhf((j ? gin.y : gin.x) + r * ghn);
-                const float hp = hT[u * CBS + gb];
-                const float hnew = (1.f - z) * n + z * hp;
-                hn2[j] = hnew;
-                const long long yi = row * (2 * H) + dir * H + u;
-                y[yi] = hnew;
-                if (ydrop) ydrop[yi] = drop ? hnew * keep_scale(key, (unsigned long long)yi, drop_p, inv_keep) : hnew;
-                if (gates) {
-                    float* gs = gates + ((long long)dir * B * T + row) * (4 * H);
-                    gs[u] = r;
-                    gs[H + u] = z;
-                    gs[2 * H + u] = n;
-                    gs[3 * H + u] = ghn;
-                }
-                if (S == 1) hT[u * CBS + gb] = hnew;          // single workgroup per group: the state never leaves LDS
-            }
-            if (S > 1 && step + 1 < T)
-                st_sc1(X + (size_t)(step & 1) * H * CBS + ((size_t)(gu >> 1) * CBS + gb) * 2, hn2[0], hn2[1]);
-        } else if (S > 1 && gate_lane && step + 1 < T) {
-            // clips beyond B: publish zeros so the group's state stays defined
-            st_sc1(X + (size_t)(step & 1) * H * CBS + ((size_t)(gu >> 1) * CBS + gb) * 2, 0.f, 0.f);
-        }
-        if (S > 1) {
-            if (step + 1 < T) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores
                 __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(C + step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float* Xp = X + (size_t)((step - 1) & 1) * H * CBS;
+                for (int i = tid; i < (H / 2) * CBS; i += CNT) {
+                    const float2 v = ld_sc1(Xp + 2 * i);          // i = kp*CBS + clip
+                    const int kp = i / CBS, c = i - kp * CBS;
+                    hs[(2 * kp) * CBS + c] = v.x;
+                    hs[(2 * kp + 1) * CBS + c] = v.y;
+                }
+                __syncthreads();
             }
-        } else {
+            // ---- 16 x H times H x 16 per wave on the f32 MFMA pipe
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+                const int k = (kbeg + i) * 4 + (lane >> 4);
+                const float a = (kbeg + i < KSTEPS && k < H) ? hs[k * CBS + (lane & 15)] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[i], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[kh][(lane >> 4) * 4 + q][nt * 16 + (lane & 15)] = acc[q];
             __syncthreads();
+            // ---- gates for 2 units x 1 clip per thread
+            if (gate_thread) {
+                const int ul = 2 * gup;
+                float hn2[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int u = gu + j, c = ul + j;
+                    float ghr = bias_r[j], ghz = bias_z[j], ghn = bias_n[j];
+#pragma unroll
+                    for (int q = 0; q < KSPLIT; ++q) {
+                        ghr += red[q][gb][c];
+                        ghz += red[q][gb][HW_ + c];
+                        ghn += red[q][gb][2 * HW_ + c];
+                    }
+                    const float r = sigmoidf_((j ? gir.y : gir.x) + ghr);
+                    const float z = sigmoidf_((j ? giz.y : giz.x) + ghz);
+                    const float n = tanhf((j ? gin.y : gin.x) + r * ghn);
+                    const float hp = hs[u * CBS + gb];
+                    const float hnew = (1.f - z) * n + z * hp;
+                    hn2[j] = hnew;
+                    const long long yi = row * (2 * H) + dir * H + u;
+                    y[yi] = hnew;
+                    if (ydrop)
+                        ydrop[yi] = drop ? hnew * keep_scale(key, (unsigned long long)yi, drop_p, inv_keep) : hnew;
+                    if (gates) {
+                        float* gs = gates + ((long long)dir * B * T + row) * (4 * H);
+                        gs[u] = r;
+                        gs[H + u] = z;
+                        gs[2 * H + u] = n;
+                        gs[3 * H + u] = ghn;
+                    }
+                    if (S == 1) hs[u * CBS + gb] = hnew;      // single workgroup per group: the state never leaves LDS
+                }
+                if (S > 1 && step + 1 < T)
+                    st_sc1(X + (size_t)(step & 1) * H * CBS + ((size_t)(gu >> 1) * CBS + gb) * 2, hn2[0], hn2[1]);
+            } else if (S > 1 && gate_lane && step + 1 < T) {
+                // clips beyond B: publish zeros so the group's state stays defined
+                st_sc1(X + (size_t)(step & 1) * H * CBS + ((size_t)(gu >> 1) * CBS + gb) * 2, 0.f, 0.f);
+            }
+            if (S > 1) {
+                if (step + 1 < T) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_fetch_add(C + step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    __syncthreads();                                  // red[] is reused by the next slice
+                }
+            } else {
+                __syncthreads();
+            }
         }
     }
 }
@@ -417,10 +430,12 @@ extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whhT, const float
     const unsigned long long* rg = e ? e->rng : nullptr;
     const unsigned site = e ? e->site : 0u;
     if (H == 300)
-        hipLaunchKernelGGL((gru_coop_fwd_k<300, 32>), dim3(10, cdiv(B, CBS), 2), dim3(CNT), 0, (hipStream_t)stream, gi,
-                           whhT, bhh, y, ydrop, gates, w.x, w.cnt, w.err, B, T, p, ik, rg, site);
+        // NSL = 1: interleaving two slices per workgroup (NSL = 2) measured 0.46 vs 0.25 ms -- the step is bound by the
+        // workgroup's own dependent chain (sc1 loads -> MFMA -> gates -> store drain), not by waiting for peers
+        hipLaunchKernelGGL((gru_coop_fwd_k<300, 32, 1>), dim3(10, cdiv(B, CBS), 2), dim3(CNT), 0,
+                           (hipStream_t)stream, gi, whhT, bhh, y, ydrop, gates, w.x, w.cnt, w.err, B, T, p, ik, rg, site);
     else
-        hipLaunchKernelGGL((gru_coop_fwd_k<64, 64>), dim3(1, cdiv(B, CBS), 2), dim3(CNT), 0, (hipStream_t)stream, gi,
+        hipLaunchKernelGGL((gru_coop_fwd_k<64, 64, 1>), dim3(1, cdiv(B, CBS), 2), dim3(CNT), 0, (hipStream_t)stream, gi,
                            whhT, bhh, y, ydrop, gates, w.x, w.cnt, w.err, B, T, p, ik, rg, site);
     S2AG_LAUNCH_CHECK();
     return 0;

@@ -210,20 +210,21 @@ class _ConvNLC(torch.autograd.Function):
             dx = torch.empty(N * Lin, Cin, dtype=torch.float32, device=dy.device)
             conv_bwd_data_raw(g, w, dx, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False, wtm)
             dx = dx.view(x.shape)
-        if ctx.needs_input_grad[1]:
-            slot = _grad_slot(ctx.w_leaf)
-            if slot is not None:
-                conv_bwd_weight_raw(g, x, slot, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, True, wtm)
-            else:
-                dw = torch.empty_like(w)
-                conv_bwd_weight_raw(g, x, dw, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False, wtm)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            slot = _grad_slot(ctx.b_leaf)
-            if slot is not None:
-                colsum_raw(g, slot, accumulate=True)
-            else:
-                db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
-                colsum_raw(g, db)
+        wslot = _grad_slot(ctx.w_leaf) if ctx.needs_input_grad[1] else None
+        bslot = _grad_slot(ctx.b_leaf) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if ctx.needs_input_grad[1] and wslot is None:
+            dw = torch.empty_like(w)
+            conv_bwd_weight_raw(g, x, dw, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False, wtm)
+        if ctx.has_bias and ctx.needs_input_grad[2] and bslot is None:
+            db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+            colsum_raw(g, db)
+        if wslot is not None or bslot is not None:
+            def leaves():
+                if wslot is not None:
+                    conv_bwd_weight_raw(g, x, wslot, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, True, wtm)
+                if bslot is not None:
+                    colsum_raw(g, bslot, accumulate=True)
+            run_wgrad(leaves, keep=(g, x))
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -595,16 +596,22 @@ class _GRU(torch.autograd.Function):
                          for i in range(4)]
                 direct = all(sl is not None for sl in slots)
                 dwi = slots[0] if direct else torch.empty_like(w_ih)
-                conv_bwd_weight_raw(gsl, inp, dwi, B * T, 1, 1, In, H3, 1, 1, 0, 1, direct)
                 dbi = slots[2] if direct else torch.empty(H3, dtype=torch.float32, device=dev)
-                colsum_raw(gsl, dbi, accumulate=direct)
-                # dW_hh = sum_t dgh_t^T h_{t-1}: h_{prev} is y shifted by one frame (zero at the boundary)
                 dwh = slots[1] if direct else torch.empty_like(w_hh)
-                conv_bwd_weight_raw(dgh[d], y[:, d * H:(d + 1) * H], dwh, B, T, T, H, H3, 1, 1, 1 if d == 0 else -1, 1,
-                                    direct)
                 dbh = slots[3] if direct else torch.empty(H3, dtype=torch.float32, device=dev)
-                colsum_raw(dgh[d], dbh, accumulate=direct)
-                if not direct:
+
+                def leaves(gsl=gsl, dwi=dwi, dbi=dbi, dwh=dwh, dbh=dbh, d=d, direct=direct, dgh=dgh, y=y, inp=inp,
+                           In=In):
+                    conv_bwd_weight_raw(gsl, inp, dwi, B * T, 1, 1, In, H3, 1, 1, 0, 1, direct)
+                    colsum_raw(gsl, dbi, accumulate=direct)
+                    # dW_hh = sum_t dgh_t^T h_{t-1}: h_{prev} is y shifted by one frame (zero at the boundary)
+                    conv_bwd_weight_raw(dgh[d], y[:, d * H:(d + 1) * H], dwh, B, T, T, H, H3, 1, 1,
+                                        1 if d == 0 else -1, 1, direct)
+                    colsum_raw(dgh[d], dbh, accumulate=direct)
+                if direct:       # parameter-gradient leaves: off the dx critical path
+                    run_wgrad(leaves, keep=(dgi, dgh, y, inp))
+                else:
+                    leaves()
                     grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = dwi, dwh, dbi, dbh
             # input gradient
             if l > 0 or ctx.needs_input_grad[0]:
@@ -716,6 +723,36 @@ def gen_loss(out, dis_out, mu, log_var, target, out_tri, out_rand, z, z_rand, we
 # stream-level parallelism of independent branches
 # ----------------------------------------------------------------------------------------------------
 _DIRTY_STREAMS = []      # side streams that carried work since the last join_side_streams()
+_KEEPALIVE = []          # tensors read by side-stream kernels: released only after the join
+ASYNC_WGRAD = True       # weight/bias gradient kernels (leaves of the backward graph) run beside the dx chain
+_WGRAD_STREAMS = {}
+_MAIN_STREAM = [None]
+
+
+def set_main_stream(stream=None) -> None:
+    """The trainer names the stream its step runs on; only from there are weight-gradient kernels forked (forking
+    again from an already forked stream crashes hipGraph capture on ROCm 7.2)."""
+    _MAIN_STREAM[0] = stream if stream is not None else torch.cuda.current_stream()
+
+
+def run_wgrad(fn, keep=()) -> None:
+    """Launch ``fn`` (kernels that only ACCUMULATE into parameter gradients) on the weight-gradient stream if we are
+    on the main stream, else inline.  Nothing downstream in the backward pass depends on them; the trainer joins the
+    stream (join_side_streams) before the optimizer reads the gradient arena."""
+    cur = torch.cuda.current_stream()
+    main = _MAIN_STREAM[0]
+    if not ASYNC_WGRAD or main is None or cur != main:
+        fn()
+        return
+    dev = cur.device_index
+    if dev not in _WGRAD_STREAMS:
+        _WGRAD_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    s = _WGRAD_STREAMS[dev]
+    s.wait_stream(cur)
+    mark_side_stream(s)
+    _KEEPALIVE.extend(keep)
+    with torch.cuda.stream(s):
+        fn()
 
 
 def mark_side_stream(s) -> None:
@@ -732,6 +769,7 @@ def join_side_streams() -> None:
         s = _DIRTY_STREAMS.pop()
         if s is not cur:
             cur.wait_stream(s)
+    _KEEPALIVE.clear()
 
 
 class BranchStreams:

@@ -272,6 +272,7 @@ class Processor(object):
         Noise snapshots are drawn in the reference's pass order (G, D(real), D(fake)) on the main stream; D(real) then
         runs on a forked stream beside the generator forward.  D(fake) starts after both, so D's BatchNorm running
         statistics are still updated real-then-fake."""
+        ops.set_main_stream()
         self.s2ag_dis_optimizer.zero_grad()
         dev = pre_seq.device
         nz_g, nz_real, nz_fake = noise.begin_pass(dev), noise.begin_pass(dev), noise.begin_pass(dev)
@@ -298,6 +299,7 @@ class Processor(object):
     def _gen_phase(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, pre_seq, train):
         """processor_v2.py:816-941 up to (and including) loss.backward()."""
         cfg = self.s2ag_config_args
+        ops.set_main_stream()
         self.s2ag_gen_optimizer.zero_grad()
         dev = pre_seq.device
         # pass order of the reference: tri-modal baseline, G(main), D(gen), G(rand)
