@@ -31,6 +31,8 @@ struct GemmP {
     int ks, stride, pad, dil;
     int lda, ldo;
     int wtm;            // weight is tap-major (Cout, k, Cin)
+    int rs;             // data-grad of a strided conv in residue mode (see conv_gemm2_k); rs_lq = ceil(Lin/stride)
+    int rs_lq;
     int act;
     float slope, drop_p, inv_keep;
     const unsigned long long* rng;
@@ -42,6 +44,8 @@ template <bool BWD>
 __device__ __forceinline__ bool src_pos(const GemmP& p, int l, int tap, int& pos) {
     if (!BWD) {
         pos = l * p.stride + tap * p.dil - p.pad;
+    } else if (p.rs) {
+        pos = l - tap;                 // l already holds i + q0; tap is the slot index
     } else {
         const int t = l + p.pad - tap * p.dil;
         if (t < 0) return false;
@@ -213,7 +217,35 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wave / (WM * WN), wr = (wave % (WM * WN)) / WN, wc = wave % WN;
-    const int m0 = blockIdx.x * BM_, n0 = blockIdx.y * 64;
+    const int n0 = blockIdx.y * 64;
+    // Residue mode (data-grad of a conv with stride s > 1, dilation 1): an input position pos only receives taps
+    // t = (pos + pad) mod s, t + s, ...  A block therefore owns BM_ positions of ONE residue class of one clip
+    // (pos = rr + s*i), and the contraction runs over ceil(k/s) tap slots instead of k taps (15 -> 3 for the wave
+    // encoder): "tap" in the loaders below is the slot j, the real tap is rs_t0 + j*s and l = i + rs_q0 - j.
+    const bool rs = BWD && p.rs;
+    int m0 = blockIdx.x * BM_;
+    int rs_clip = 0, rs_rr = 0, rs_i0 = 0, rs_t0 = 0, rs_q0 = 0;
+    if (rs) {
+        const int nib = (p.rs_lq + BM_ - 1) / BM_;
+        const int bx = blockIdx.x;
+        const int ib = bx % nib;
+        rs_rr = (bx / nib) % p.stride;
+        rs_clip = bx / (nib * p.stride);
+        rs_i0 = ib * BM_;
+        rs_t0 = (rs_rr + p.pad) % p.stride;
+        rs_q0 = (rs_rr + p.pad - rs_t0) / p.stride;
+        m0 = 0;
+    }
+    // global output row of tile row rl, or -1
+    auto out_row = [&](int rl) -> long long {
+        if (rs) {
+            const int i = rs_i0 + rl;
+            const int pos = rs_rr + p.stride * i;
+            return (i < p.rs_lq && pos < p.Lr) ? (long long)rs_clip * p.Lr + pos : -1;
+        }
+        const int m = m0 + rl;
+        return m < p.M ? (long long)m : -1;
+    };
 
     // per-thread loader coordinates (fixed across the K loop)
     int a_r[CA], a_kq[CA], a_l[CA];
@@ -224,12 +256,17 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
         const int c = tid + i * NT;
         a_kq[i] = c % (BK2 / 4);
         a_r[i] = c / (BK2 / 4);
-        const int m = m0 + a_r[i];
-        a_ok[i] = (a_r[i] < BM_) && (m < p.M);
+        a_ok[i] = (a_r[i] < BM_) && out_row(a_r[i]) >= 0;
         int nclip = 0, l = 0;
         if (a_ok[i]) {
-            nclip = m / p.Lr;
-            l = m - nclip * p.Lr;
+            if (rs) {
+                nclip = rs_clip;
+                l = rs_i0 + a_r[i] + rs_q0;
+            } else {
+                const int m = m0 + a_r[i];
+                nclip = m / p.Lr;
+                l = m - nclip * p.Lr;
+            }
         }
         a_l[i] = l;
         a_row0[i] = (long long)nclip * p.Lsrc;
@@ -300,12 +337,15 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
                 for (int j = 0; j < 4; ++j) {
                     float b = 0.f;
                     if (b_ok[i] && kk0 + j < p.K) {
-                        if (p.wtm)
-                            b = BWD ? p.w[((long long)c * p.ks + tap) * p.Cin + col]
-                                    : p.w[((long long)col * p.ks + tap) * p.Cin + c];
-                        else
-                            b = BWD ? p.w[((long long)c * p.Cin + col) * p.ks + tap]
-                                    : p.w[((long long)col * p.Cin + c) * p.ks + tap];
+                        const int tp = rs ? rs_t0 + tap * p.stride : tap;      // residue mode: slot -> real tap
+                        if (tp < p.ks) {
+                            if (p.wtm)
+                                b = BWD ? p.w[((long long)c * p.ks + tp) * p.Cin + col]
+                                        : p.w[((long long)col * p.ks + tp) * p.Cin + c];
+                            else
+                                b = BWD ? p.w[((long long)c * p.Cin + col) * p.ks + tp]
+                                        : p.w[((long long)col * p.Cin + c) * p.ks + tp];
+                        }
                     }
                     rb[i][j] = b;
                     if (++c == p.CK) { c = 0; ++tap; }
@@ -334,7 +374,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
 
     bool rowlive[TM], collive[TN];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) rowlive[t] = (m0 + (wr * TM + t) * 16) < p.M;
+    for (int t = 0; t < TM; ++t) rowlive[t] = rs ? (rs_i0 + (wr * TM + t) * 16) < p.rs_lq : (m0 + (wr * TM + t) * 16) < p.M;
 #pragma unroll
     for (int t = 0; t < TN; ++t) collive[t] = (n0 + (wc * TN + t) * 16) < p.NC;
     f32x4 acc[TM][TN];
@@ -416,10 +456,10 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
             const float bias = (!BWD && p.bias) ? p.bias[c] : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int row = m0 + (wr * TM + ti) * 16 + (lane >> 4) * 4 + q;
-                if (row >= p.M) continue;
+                const long long row = out_row((wr * TM + ti) * 16 + (lane >> 4) * 4 + q);
+                if (row < 0) continue;
                 float v = acc[ti][tj][q];
-                float* dst = p.out + (long long)row * p.ldo + c;
+                float* dst = p.out + row * p.ldo + c;
                 if (!BWD) {
                     v = apply_act(v + bias, p.act, p.slope);
                     if (drop) v *= keep_scale(key, (unsigned long long)row * p.NC + c, p.drop_p, p.inv_keep);
@@ -434,11 +474,16 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
 template <bool BWD, bool VEC>
 void launch_gemm2(const GemmP& p, hipStream_t stream) {
     const long long colb = cdiv(p.NC, 64);
-    // largest row tile that still gives >= 512 blocks (2 per CU); narrow problems fall through to 16-row tiles
-    if ((long long)cdiv(p.M, 64) * colb >= 512) {
-        hipLaunchKernelGGL((conv_gemm2_k<BWD, VEC, 64, 2, 2, 2>), dim3(cdiv(p.M, 64), (unsigned)colb), dim3(512), 0, stream, p);
+    // row blocks: plain mode tiles the M rows; residue mode tiles (clip, residue, ceil(Lin/stride)) separately
+    const long long nclips = p.rs ? p.M / p.Lr : 1;
+    auto rowblocks = [&](int bm) -> long long {
+        return p.rs ? nclips * p.stride * cdiv(p.rs_lq, bm) : (long long)cdiv(p.M, bm);
+    };
+    // largest row tile that still gives >= 512 blocks (2 per CU)
+    if (rowblocks(64) * colb >= 512) {
+        hipLaunchKernelGGL((conv_gemm2_k<BWD, VEC, 64, 2, 2, 2>), dim3((unsigned)rowblocks(64), (unsigned)colb), dim3(512), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((conv_gemm2_k<BWD, VEC, 32, 2, 2, 2>), dim3(cdiv(p.M, 32), (unsigned)colb), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((conv_gemm2_k<BWD, VEC, 32, 2, 2, 2>), dim3((unsigned)rowblocks(32), (unsigned)colb), dim3(512), 0, stream, p);
     }
 }
 
@@ -731,6 +776,54 @@ __global__ __launch_bounds__(256) void colstats_f64_k(const float* __restrict__ 
     }
 }
 
+// ---- lane-dense reductions for narrow contiguous matrices (cols in {1,2,4,...,32}, ld == cols) ----------------------
+// The matrix is walked as a flat array with a stride that is a multiple of 256, so a thread always sees the same
+// column (tid % cols) and every lane is busy -- the column-per-lane kernels above use 16 of 64 lanes on the wave
+// encoder's 16-channel activations (1 M rows).
+template <typename T>
+__device__ __forceinline__ void block_col_merge(T v, int cols, T* sm, T* out) {
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    if ((int)threadIdx.x < cols) {
+        T s = 0;
+        for (int i = threadIdx.x; i < 256; i += cols) s += sm[i];
+        atomicAdd(out + threadIdx.x, s);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void colsum_flat_k(const float* __restrict__ x, long long total, int cols, float* out,
+                                                     float* sq) {
+    __shared__ float sm[256];
+    float a = 0.f, b = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        a += v;
+        b += v * v;
+    }
+    block_col_merge(a, cols, sm, out);
+    if (sq) block_col_merge(b, cols, sm, sq);
+}
+
+__global__ __launch_bounds__(256) void colstats_flat_k(const float* __restrict__ x, long long total, int cols,
+                                                       double* out, double* sq) {
+    __shared__ double sm[256];
+    double a = 0.0, b = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const double v = (double)x[i];
+        a += v;
+        b += v * v;
+    }
+    block_col_merge(a, cols, sm, out);
+    block_col_merge(b, cols, sm, sq);
+}
+
+inline bool narrow_ok(int cols, int ld) { return ld == cols && cols <= 32 && (cols & (cols - 1)) == 0; }
+inline int flat_blocks(long long total) {
+    long long b = (total + 256 * 16 - 1) / (256 * 16);
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool bad_geom(const s2ag_conv_geom* g) {
@@ -777,6 +870,11 @@ extern "C" int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* 
     p.Lr = g->Lin; p.Lsrc = g->Lout; p.CK = g->Cout; p.Cin = g->Cin;
     p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
     p.lda = g->ldy; p.ldo = g->ldx; p.wtm = g->w_tap_major;
+    if (g->stride > 1 && g->dil == 1 && g->pad >= 0) {      // residue mode: contract over ceil(k/stride) tap slots
+        p.rs = 1;
+        p.rs_lq = cdiv(g->Lin, g->stride);
+        p.K = cdiv(g->ksize, g->stride) * g->Cout;
+    }
     p.act = S2AG_ACT_NONE; p.slope = 1.f; p.drop_p = 0.f; p.inv_keep = 1.f; p.rng = nullptr; p.site = 0;
     p.accumulate = accumulate;
     const bool vec = (g->Cout % 4 == 0) && (g->ldy % 4 == 0) && aligned16(gy);
@@ -830,6 +928,12 @@ extern "C" int s2ag_colsum(const float* x, int rows, int cols, int ld, float* ou
             if (me != hipSuccess) return (int)me;
         }
     }
+    if (narrow_ok(cols, ld)) {
+        const long long total = (long long)rows * cols;
+        hipLaunchKernelGGL(colsum_flat_k, dim3(flat_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, total, cols, out, sq);
+        S2AG_LAUNCH_CHECK();
+        return 0;
+    }
     int rpb = 256;
     const int colblocks = cdiv(cols, 64);
     // aim for >= ~1024 blocks on long matrices, but at least 64 rows each
@@ -851,6 +955,12 @@ extern "C" int s2ag_colstats_f64(const float* x, int rows, int cols, int ld, dou
         if (me != hipSuccess) return (int)me;
         me = zero_async(sq, sizeof(double) * cols, (hipStream_t)stream);
         if (me != hipSuccess) return (int)me;
+    }
+    if (narrow_ok(cols, ld)) {
+        const long long total = (long long)rows * cols;
+        hipLaunchKernelGGL(colstats_flat_k, dim3(flat_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, total, cols, sum, sq);
+        S2AG_LAUNCH_CHECK();
+        return 0;
     }
     int rpb = 256;
     const int colblocks = cdiv(cols, 64);

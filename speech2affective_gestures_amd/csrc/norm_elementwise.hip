@@ -99,6 +99,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__
     }
 }
 
+// lane-dense variant for narrow contiguous matrices (cols a power of two <= 32, ldx == lddy == cols)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_flat_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            long long total, int cols, const float* scale,
+                                                            const float* shift, const float* mean, const float* invstd,
+                                                            float slope, float* s1, float* s2) {
+    __shared__ float sm[256];
+    const int c = threadIdx.x % cols;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    float p = 0.f, q = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const float xv = x[i];
+        const float pre = xv * sc + sh;
+        const float d = dy[i] * (pre > 0.f ? 1.f : slope);
+        p += d;
+        q += d * (xv - mu) * is;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        sm[threadIdx.x] = pass ? q : p;
+        __syncthreads();
+        if ((int)threadIdx.x < cols) {
+            float s = 0.f;
+            for (int i = threadIdx.x; i < 256; i += cols) s += sm[i];
+            atomicAdd((pass ? s2 : s1) + threadIdx.x, s);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_coeffs_k(const float* s1, const float* s2, const int* chan_of_col,
                                                        int ncols, int nchan, int rows, float* dgamma, float* dbeta,
                                                        int accumulate, float* c1, float* c2) {
@@ -236,6 +264,15 @@ extern "C" int s2ag_bn_bwd_reduce(const float* x, const float* dy, int rows, int
         if (me != hipSuccess) return (int)me;
         me = zero_async(s2_col, sizeof(float) * cols, (hipStream_t)stream);
         if (me != hipSuccess) return (int)me;
+    }
+    if (ldx == cols && lddy == cols && cols <= 32 && (cols & (cols - 1)) == 0) {
+        const long long total = (long long)rows * cols;
+        long long nb = (total + 256 * 16 - 1) / (256 * 16);
+        nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+        hipLaunchKernelGGL(bn_bwd_reduce_flat_k, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, dy, total, cols,
+                           scale_col, shift_col, mean_col, invstd_col, slope, s1_col, s2_col);
+        S2AG_LAUNCH_CHECK();
+        return 0;
     }
     int rpb = 256;
     const int colblocks = cdiv(cols, 64);

@@ -770,6 +770,7 @@ def join_side_streams() -> None:
         if s is not cur:
             cur.wait_stream(s)
     _KEEPALIVE.clear()
+    _MAIN_STREAM[0] = None       # forking is armed per trainer phase: set_main_stream() ... join_side_streams()
 
 
 class BranchStreams:

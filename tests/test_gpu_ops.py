@@ -169,6 +169,24 @@ def test_batch_norm_act_train_and_eval(S, slope):
     assert rel(ops.batch_norm_act(x.cuda(), bn_g, slope=slope), F.leaky_relu(bn_r(x.transpose(1, 2)), slope).transpose(1, 2)) < TOL
 
 
+def test_batch_norm_narrow_matrix_lane_dense_path(S):
+    """16 columns x many rows (the wave encoder's first activation): the flat lane-dense reduction kernels."""
+    ops = S['ops']
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(3, 5000, 16, generator=g) * 1.5 - 0.3
+    bn_r, bn_g = torch.nn.BatchNorm1d(16), torch.nn.BatchNorm1d(16).cuda()
+    xr = x.clone().requires_grad_(True)
+    yr = F.leaky_relu(bn_r(xr.transpose(1, 2)), 0.3).transpose(1, 2)
+    xg = x.cuda().requires_grad_(True)
+    yg = ops.batch_norm_act(xg, bn_g, slope=0.3)
+    assert rel(yg, yr) < TOL and rel(bn_g.running_var, bn_r.running_var) < TOL
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.cuda())
+    assert rel(xg.grad, xr.grad) < 5 * TOL and rel(bn_g.weight.grad, bn_r.weight.grad) < TOL
+    assert rel(bn_g.bias.grad, bn_r.bias.grad) < TOL
+
+
 def test_batch_norm_channel_map_is_batchnorm2d(S):
     ops = S['ops']
     g = torch.Generator().manual_seed(10)
