@@ -84,7 +84,7 @@ def gru_roofline(B, iters=20):
     H = 300
     dev = 'cuda'
     gi = torch.randn(B * T, 6 * H, device=dev) * 0.5
-    whhT = torch.randn(2, H, 3 * H, device=dev) * 0.05
+    whh = torch.randn(2, 3 * H, H, device=dev) * 0.05          # reference (state_dict) layout, both directions
     bhh = torch.randn(2, 3 * H, device=dev) * 0.05
     y = torch.empty(B * T, 2 * H, device=dev)
     yd = torch.empty_like(y)
@@ -95,15 +95,18 @@ def gru_roofline(B, iters=20):
     sp = C.c_void_p(s.cuda_stream)
 
     coop = bool(lib.s2ag_gru_coop_supported(H))
+    whhT = whh.transpose(1, 2).contiguous()
     ws = torch.empty(max(1, lib.s2ag_gru_coop_workspace_bytes(B, T, H, 0)), dtype=torch.uint8, device=dev)
 
     def launch():
-        args = (C.c_void_p(gi.data_ptr()), C.c_void_p(whhT.data_ptr()), C.c_void_p(bhh.data_ptr()),
-                C.c_void_p(y.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(gates.data_ptr()), B, T, H, C.byref(e))
+        tail = (C.c_void_p(bhh.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(yd.data_ptr()),
+                C.c_void_p(gates.data_ptr()), B, T, H, C.byref(e))
         if coop:
-            L.check(lib.s2ag_gru_coop_fwd(*args, C.c_void_p(ws.data_ptr()), sp), 'gru_coop_fwd')
+            L.check(lib.s2ag_gru_coop_fwd(C.c_void_p(gi.data_ptr()), C.c_void_p(whh.data_ptr()), *tail,
+                                          C.c_void_p(ws.data_ptr()), sp), 'gru_coop_fwd')
         else:
-            L.check(lib.s2ag_gru_seq_fwd(*args, sp), 'gru_seq_fwd')
+            L.check(lib.s2ag_gru_seq_fwd(C.c_void_p(gi.data_ptr()), C.c_void_p(whh.data_ptr()),
+                                         C.c_void_p(whhT.data_ptr()), *tail, sp), 'gru_seq_fwd')
     for _ in range(3):
         launch()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]

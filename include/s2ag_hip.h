@@ -151,12 +151,16 @@ int s2ag_transpose(const float* src, int rows, int cols, float* dst, void* strea
 /* One bidirectional GRU layer, recurrent part (PyTorch gate order r,z,n).  nn.GRU --
  * net/multimodal_context_net_v2.py:281,:406,:480,:558 (forward :333,:425,:541,:574).
  *  gi    (B*T, 6H): W_ih x + b_ih for [forward | reverse] direction (from s2ag_conv1d_nlc_fwd)
- *  whhT  (2, H, 3H): W_hh^T per direction;  bhh (2, 3H)
+ *  whh   (2, 3H, H): W_hh per direction in the reference's state_dict layout;  bhh (2, 3H)
+ *  whhT  (2, H, 3H): W_hh^T, needed only when s2ag_gru_seq_needs_transposed(H) != 0 (the L2-streaming kernel;
+ *        the register-resident small-H kernels read `whh` directly), else NULL
  *  y     (B*T, 2H): raw hidden states [forward | reverse]
  *  ydrop (B*T, 2H): nullable; y * keep-mask(site)/(1-p) -- the next layer's input in train mode
  *  gates (2, B*T, 4H): nullable; saved (r, z, n, W_hn h + b_hn) for the backward pass */
-int s2ag_gru_seq_fwd(const float* gi, const float* whhT, const float* bhh, float* y, float* ydrop, float* gates,
-                     int B, int T, int H, const s2ag_epilogue* e /*host, nullable: dropout of ydrop*/, void* stream);
+int s2ag_gru_seq_needs_transposed(int H);
+int s2ag_gru_seq_fwd(const float* gi, const float* whh, const float* whhT /*nullable*/, const float* bhh, float* y,
+                     float* ydrop, float* gates, int B, int T, int H,
+                     const s2ag_epilogue* e /*host, nullable: dropout of ydrop*/, void* stream);
 /* backward through time of one layer.
  *  dy    (B*T, lddy): grad w.r.t. the layer output the consumer saw; dir d reads columns [d*dy_dir_stride, +H)
  *        (dy_dir_stride = H for a (B*T,2H) grad, 0 when the consumer summed the two directions);
@@ -174,7 +178,7 @@ int s2ag_gru_seq_bwd(const float* dy, int lddy, int dy_dir_stride, const float* 
  * streaming kernels; `workspace` needs s2ag_gru_coop_workspace_bytes() bytes and may be uninitialised. */
 int s2ag_gru_coop_supported(int H);
 long long s2ag_gru_coop_workspace_bytes(int B, int T, int H, int backward);
-int s2ag_gru_coop_fwd(const float* gi, const float* whhT, const float* bhh, float* y, float* ydrop, float* gates,
+int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* ydrop, float* gates,
                       int B, int T, int H, const s2ag_epilogue* e /*host, nullable*/, void* workspace, void* stream);
 int s2ag_gru_coop_bwd(const float* dy, int lddy, int dy_dir_stride, const float* whh, const float* y,
                       const float* gates, float* dgi, float* dgh, int B, int T, int H,

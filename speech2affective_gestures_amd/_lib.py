@@ -42,7 +42,8 @@ SIGNATURES = {
     's2ag_weight_norm_bwd': [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp],
     's2ag_spmv': [vp, vp, vp, vp, vp, ci, ci, vp],
     's2ag_transpose': [vp, ci, ci, vp, vp],
-    's2ag_gru_seq_fwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],
+    's2ag_gru_seq_needs_transposed': [ci],
+    's2ag_gru_seq_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],
     's2ag_gru_seq_bwd': [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],
     's2ag_gru_coop_supported': [ci],
     's2ag_gru_coop_workspace_bytes': [ci, ci, ci, ci],

@@ -231,21 +231,24 @@ int allow_smem(K kernel, size_t bytes) {
 
 // small-H specialisation (gru_small.hip): W_hh in registers, one thread per (clip, unit)
 int s2ag_gru_small_supported(int H);
-int s2ag_gru_small_fwd(const float* gi, const float* whhT, const float* bhh, float* y, float* ydrop, float* gates, int B,
+int s2ag_gru_small_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* ydrop, float* gates, int B,
                        int T, int H, float p, const unsigned long long* rng, unsigned site, hipStream_t stream);
 int s2ag_gru_small_bwd(const float* dy, int lddy, int dy_dir_stride, const float* whh, const float* y,
                        const float* gates, float* dgi, float* dgh, int B, int T, int H, float p,
                        const unsigned long long* rng, unsigned site, hipStream_t stream);
 
-extern "C" int s2ag_gru_seq_fwd(const float* gi, const float* whhT, const float* bhh, float* y, float* ydrop,
-                                float* gates, int B, int T, int H, const s2ag_epilogue* e, void* stream) {
-    if (!gi || !whhT || !bhh || !y || B <= 0 || T <= 0 || H <= 0) return S2AG_E_BADARG;
+extern "C" int s2ag_gru_seq_needs_transposed(int H) { return s2ag_gru_small_supported(H) ? 0 : 1; }
+
+extern "C" int s2ag_gru_seq_fwd(const float* gi, const float* whh, const float* whhT, const float* bhh, float* y,
+                                float* ydrop, float* gates, int B, int T, int H, const s2ag_epilogue* e, void* stream) {
+    if (!gi || !whh || !bhh || !y || B <= 0 || T <= 0 || H <= 0) return S2AG_E_BADARG;
     if (H % 4 != 0 || (3 * H) / 4 > NT) return S2AG_E_UNSUPPORTED;
     const float p = (e && ydrop) ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
     if (s2ag_gru_small_supported(H))
-        return s2ag_gru_small_fwd(gi, whhT, bhh, y, ydrop, gates, B, T, H, p, e ? e->rng : nullptr, e ? e->site : 0u,
+        return s2ag_gru_small_fwd(gi, whh, bhh, y, ydrop, gates, B, T, H, p, e ? e->rng : nullptr, e ? e->site : 0u,
                                   (hipStream_t)stream);
+    if (!whhT) return S2AG_E_BADARG;     // the L2-streaming kernel wants W_hh^T for coalesced 16-byte loads
     constexpr int BS = 8;
     const size_t sm = fwd_smem(BS, H);
     int rc = allow_smem(gru_seq_fwd_k<BS>, sm);

@@ -59,7 +59,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // forward
 // ---------------------------------------------------------------------------------------------------------
 template <int H, int HW_, int NSL>
-__global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ gi, const float* __restrict__ whhT,
+__global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ gi, const float* __restrict__ whh,
                                                       const float* __restrict__ bhh, float* __restrict__ y,
                                                       float* __restrict__ ydrop, float* __restrict__ gates,
                                                       float* xbuf, int* cnt, int* err, int B, int T, float drop_p,
@@ -87,10 +87,11 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = wave % NTILES, kh = wave / NTILES;
-    const float* W = whhT + (size_t)dir * H * H3;  // (H, 3H): W^T[k][gate col]
+    const float* W = whh + (size_t)dir * H3 * H;   // (3H, H) reference layout: W[gate row][k]
     const float* bh = bhh + dir * H3;
 
     // B operands of this wave, resident for the whole launch: B[k][j] = W_hh[gate col(nt*16 + j)][k]
+    // (read once per launch straight from the state_dict layout -- no transposed copy of W_hh is ever made)
     const int kbeg = kh * KPW;
     float breg[KPW];
     {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
             const int k = (kbeg + i) * 4 + (lane >> 4);
-            breg[i] = (kbeg + i < KSTEPS && k < H && u < H) ? W[(size_t)k * H3 + g * H + u] : 0.f;
+            breg[i] = (kbeg + i < KSTEPS && k < H && u < H) ? W[(size_t)(g * H + u) * H + k] : 0.f;
         }
     }
     for (int i = tid; i < NSL * H * CBS; i += CNT) (&hT[0][0])[i] = 0.f;
@@ -414,10 +415,10 @@ Ws carve(void* ws, int B, int T, int H, int backward) {
 }
 }  // namespace
 
-extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whhT, const float* bhh, float* y, float* ydrop,
+extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* ydrop,
                                  float* gates, int B, int T, int H, const s2ag_epilogue* e, void* workspace,
                                  void* stream) {
-    if (!gi || !whhT || !bhh || !y || !workspace || B <= 0 || T <= 0) return S2AG_E_BADARG;
+    if (!gi || !whh || !bhh || !y || !workspace || B <= 0 || T <= 0) return S2AG_E_BADARG;
     if (!s2ag_gru_coop_supported(H)) return S2AG_E_UNSUPPORTED;
     const float p = (e && ydrop) ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
@@ -433,10 +434,10 @@ extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whhT, const float
         // NSL = 1: interleaving two slices per workgroup (NSL = 2) measured 0.46 vs 0.25 ms -- the step is bound by the
         // workgroup's own dependent chain (sc1 loads -> MFMA -> gates -> store drain), not by waiting for peers
         hipLaunchKernelGGL((gru_coop_fwd_k<300, 32, 1>), dim3(10, cdiv(B, CBS), 2), dim3(CNT), 0,
-                           (hipStream_t)stream, gi, whhT, bhh, y, ydrop, gates, w.x, w.cnt, w.err, B, T, p, ik, rg, site);
+                           (hipStream_t)stream, gi, whh, bhh, y, ydrop, gates, w.x, w.cnt, w.err, B, T, p, ik, rg, site);
     else
         hipLaunchKernelGGL((gru_coop_fwd_k<64, 64, 1>), dim3(1, cdiv(B, CBS), 2), dim3(CNT), 0, (hipStream_t)stream, gi,
-                           whhT, bhh, y, ydrop, gates, w.x, w.cnt, w.err, B, T, p, ik, rg, site);
+                           whh, bhh, y, ydrop, gates, w.x, w.cnt, w.err, B, T, p, ik, rg, site);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -19,7 +19,7 @@ constexpr int SNT = 256;  // threads per workgroup = 4 waves = one per SIMD, so 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 template <int H>
-__global__ __launch_bounds__(SNT) void gru_small_fwd_k(const float* __restrict__ gi, const float* __restrict__ whhT,
+__global__ __launch_bounds__(SNT) void gru_small_fwd_k(const float* __restrict__ gi, const float* __restrict__ whh,
                                                           const float* __restrict__ bhh, float* __restrict__ y,
                                                           float* __restrict__ ydrop, float* __restrict__ gates, int B,
                                                           int T, float drop_p, float inv_keep,
@@ -32,13 +32,16 @@ __global__ __launch_bounds__(SNT) void gru_small_fwd_k(const float* __restrict__
     const int tid = threadIdx.x;
     const int b = tid / H, i = tid - b * H;
     const bool valid = (b0 + b) < B;
-    const float* W = whhT + (size_t)dir * H * H3;      // W^T[k][gate col]
-    float wr[H], wz[H], wn[H];                          // this unit's three gate columns, resident for the launch
+    const float* W = whh + (size_t)dir * H3 * H;       // (3H, H) reference layout
+    float wr[H], wz[H], wn[H];                          // this unit's three gate rows, resident for the launch
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-        wr[k] = W[k * H3 + i];
-        wz[k] = W[k * H3 + H + i];
-        wn[k] = W[k * H3 + 2 * H + i];
+    for (int k = 0; k < H; k += 4) {                    // 16-byte loads along the contiguous k axis
+        const float4 a = *reinterpret_cast<const float4*>(W + (size_t)i * H + k);
+        const float4 bq = *reinterpret_cast<const float4*>(W + (size_t)(H + i) * H + k);
+        const float4 c = *reinterpret_cast<const float4*>(W + (size_t)(2 * H + i) * H + k);
+        wr[k] = a.x; wr[k + 1] = a.y; wr[k + 2] = a.z; wr[k + 3] = a.w;
+        wz[k] = bq.x; wz[k + 1] = bq.y; wz[k + 2] = bq.z; wz[k + 3] = bq.w;
+        wn[k] = c.x; wn[k + 1] = c.y; wn[k + 2] = c.z; wn[k + 3] = c.w;
     }
     const float bhr = bhh[dir * H3 + i], bhz = bhh[dir * H3 + H + i], bhn = bhh[dir * H3 + 2 * H + i];
     hs[0][b][i] = 0.f;
@@ -160,15 +163,15 @@ __global__ __launch_bounds__(SNT) void gru_small_bwd_k(const float* __restrict__
 // internal entry points used by s2ag_gru_seq_fwd / s2ag_gru_seq_bwd (gru.hip)
 int s2ag_gru_small_supported(int H) { return (H == 64 || H == 32) ? 1 : 0; }
 
-int s2ag_gru_small_fwd(const float* gi, const float* whhT, const float* bhh, float* y, float* ydrop, float* gates, int B,
+int s2ag_gru_small_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* ydrop, float* gates, int B,
                        int T, int H, float p, const unsigned long long* rng, unsigned site, hipStream_t stream) {
     const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
     dim3 grid(s2ag::cdiv(B, SNT / H), 2);
     if (H == 64)
-        hipLaunchKernelGGL(gru_small_fwd_k<64>, grid, dim3(SNT), 0, stream, gi, whhT, bhh, y, ydrop, gates, B, T, p, ik, rng,
+        hipLaunchKernelGGL(gru_small_fwd_k<64>, grid, dim3(SNT), 0, stream, gi, whh, bhh, y, ydrop, gates, B, T, p, ik, rng,
                            site);
     else
-        hipLaunchKernelGGL(gru_small_fwd_k<32>, grid, dim3(SNT), 0, stream, gi, whhT, bhh, y, ydrop, gates, B, T, p, ik, rng,
+        hipLaunchKernelGGL(gru_small_fwd_k<32>, grid, dim3(SNT), 0, stream, gi, whh, bhh, y, ydrop, gates, B, T, p, ik, rng,
                            site);
     S2AG_LAUNCH_CHECK();
     return 0;

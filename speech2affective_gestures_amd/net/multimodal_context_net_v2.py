@@ -38,16 +38,33 @@ class GRU(nn.Module):
             raise NotImplementedError('the S2AG nets only use batch_first bidirectional GRUs')
         self.input_size, self.hidden_size, self.num_layers, self.dropout = input_size, hidden_size, num_layers, dropout
         self.batch_first, self.bidirectional = True, True
+        self._packed_checked = False
         k = 1.0 / math.sqrt(hidden_size)
+        # registration order = arena order (optim.ParamArena follows .parameters()): the two directions of every
+        # tensor are adjacent, so ops.gru runs both directions' projections / weight gradients as single GEMMs
         for l in range(num_layers):
-            for suf in ('', '_reverse'):
-                in_l = input_size if l == 0 else 2 * hidden_size
-                for name, shape in ((f'weight_ih_l{l}{suf}', (3 * hidden_size, in_l)),
-                                    (f'weight_hh_l{l}{suf}', (3 * hidden_size, hidden_size)),
-                                    (f'bias_ih_l{l}{suf}', (3 * hidden_size,)),
-                                    (f'bias_hh_l{l}{suf}', (3 * hidden_size,))):
-                    self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
+            in_l = input_size if l == 0 else 2 * hidden_size
+            for kind, shape in (('weight_ih', (3 * hidden_size, in_l)), ('weight_hh', (3 * hidden_size, hidden_size)),
+                                ('bias_ih', (3 * hidden_size,)), ('bias_hh', (3 * hidden_size,))):
+                for suf in ('', '_reverse'):
+                    self.register_parameter(f'{kind}_l{l}{suf}', nn.Parameter(torch.empty(shape).uniform_(-k, k)))
         self.site0 = new_site(num_layers)
+
+    def _pack_frozen(self):
+        """A GRU outside any arena (the frozen tri-modal baseline): move its tensors into one buffer, pairs adjacent,
+        the first time it runs on the GPU.  Trainable (arena-managed) tensors are never touched."""
+        ps = list(self.parameters())
+        if any(p.requires_grad or p.grad is not None for p in ps) or not ps[0].is_cuda:
+            return
+        if all(ps[i].data_ptr() + 4 * ps[i].numel() == ps[i + 1].data_ptr() for i in range(0, len(ps), 2)):
+            return
+        flat = torch.empty(sum(p.numel() for p in ps), dtype=torch.float32, device=ps[0].device)
+        off = 0
+        for p in ps:
+            v = flat[off:off + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            off += p.numel()
 
     def flatten_parameters(self):
         pass
@@ -61,6 +78,9 @@ class GRU(nn.Module):
         return out
 
     def run(self, x, noise, sum_dirs):
+        if not self._packed_checked:
+            self._pack_frozen()
+            self._packed_checked = True
         return ops.gru(x, self.flat_weights(), self.hidden_size, self.num_layers, self.training, self.dropout, noise,
                        self.site0, sum_dirs)
 

@@ -503,6 +503,19 @@ def coop_gru_timeouts() -> int:
     return bad
 
 
+def _pair(a: Optional[Tensor], b: Optional[Tensor]) -> Optional[Tensor]:
+    """If ``b`` lies directly behind ``a`` in memory (the two directions of a GRU tensor in a parameter arena, see
+    net.GRU), return the (2, *shape) view over both -- one GEMM / one reduction then serves both directions."""
+    if a is None or b is None or a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+        return None
+    if a.data_ptr() + 4 * a.numel() != b.data_ptr():
+        return None
+    if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+        return None
+    with torch.no_grad():
+        return torch.as_strided(a.detach(), (2,) + tuple(a.shape), (a.numel(),) + tuple(a.stride()))
+
+
 class _GRU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, H, Lyr, training, drop_p, noise, site0, sum_dirs, need_grad, *weights):
@@ -518,12 +531,18 @@ class _GRU(torch.autograd.Function):
             wih, whh, bih, bhh, wih_r, whh_r, bih_r, bhh_r = weights[8 * l:8 * l + 8]
             In = wih.shape[1]
             gi = torch.empty(B * T, 2 * H3, dtype=torch.float32, device=dev)
-            conv_fwd_raw(inp, wih, bih, gi[:, :H3], B * T, 1, 1, In, H3, 1, 1, 0, 1)
-            conv_fwd_raw(inp, wih_r, bih_r, gi[:, H3:], B * T, 1, 1, In, H3, 1, 1, 0, 1)
-            whhT = torch.empty(2, H, H3, dtype=torch.float32, device=dev)
-            transpose_raw(whh, whhT[0])
-            transpose_raw(whh_r, whhT[1])
-            bhh2 = torch.stack((bhh, bhh_r))
+            wih2, bih2 = _pair(wih, wih_r), _pair(bih, bih_r)
+            if wih2 is not None and bih2 is not None:            # both directions' input projections: one GEMM
+                conv_fwd_raw(inp, wih2, bih2, gi, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1)
+            else:
+                conv_fwd_raw(inp, wih, bih, gi[:, :H3], B * T, 1, 1, In, H3, 1, 1, 0, 1)
+                conv_fwd_raw(inp, wih_r, bih_r, gi[:, H3:], B * T, 1, 1, In, H3, 1, 1, 0, 1)
+            whh2 = _pair(whh, whh_r)
+            if whh2 is None:
+                whh2 = torch.stack((whh, whh_r))
+            bhh2 = _pair(bhh, bhh_r)
+            if bhh2 is None:
+                bhh2 = torch.stack((bhh, bhh_r))
             y = torch.empty(B * T, 2 * H, dtype=torch.float32, device=dev)
             gates = torch.empty(2, B * T, 4 * H, dtype=torch.float32, device=dev) if need_grad else None
             last = l == Lyr - 1
@@ -532,13 +551,18 @@ class _GRU(torch.autograd.Function):
             e = _epi(L.ACT_NONE, 1.0, drop_p if use_drop else 0.0, noise, site0 + l)
             if USE_COOP_GRU and H >= COOP_GRU_MIN_H and lib.s2ag_gru_coop_supported(H):
                 ws = torch.empty(lib.s2ag_gru_coop_workspace_bytes(B, T, H, 0), dtype=torch.uint8, device=dev)
-                L.check(lib.s2ag_gru_coop_fwd(_p(gi), _p(whhT), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T, H,
+                L.check(lib.s2ag_gru_coop_fwd(_p(gi), _p(whh2), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T, H,
                                               C.byref(e), _p(ws), _stream()), 'gru_coop_fwd')
                 if H > 64:                       # H = 64 runs without an exchange: its error word is never written
                     _COOP_WS.append((ws, B, T, H, 0))
             else:
-                L.check(lib.s2ag_gru_seq_fwd(_p(gi), _p(whhT), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T, H,
-                                             C.byref(e), _stream()), 'gru_seq_fwd')
+                whhT = None
+                if lib.s2ag_gru_seq_needs_transposed(H):
+                    whhT = torch.empty(2, H, H3, dtype=torch.float32, device=dev)
+                    transpose_raw(whh2[0], whhT[0])
+                    transpose_raw(whh2[1], whhT[1])
+                L.check(lib.s2ag_gru_seq_fwd(_p(gi), _p(whh2), _p(whhT), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T,
+                                             H, C.byref(e), _stream()), 'gru_seq_fwd')
             saved += [inp, y, gates]
             inp = ydrop if use_drop else y
         if sum_dirs:
@@ -573,7 +597,9 @@ class _GRU(torch.autograd.Function):
             In = wih.shape[1]
             last = l == Lyr - 1
             use_drop = training and drop_p > 0 and not last
-            whh2 = torch.stack((whh, whh_r))
+            whh2 = _pair(whh, whh_r)
+            if whh2 is None:
+                whh2 = torch.stack((whh, whh_r))
             dgi = torch.empty(B * T, 2 * H3, dtype=torch.float32, device=dev)
             dgh = torch.empty(2, B * T, H3, dtype=torch.float32, device=dev)
             e = _epi(L.ACT_NONE, 1.0, drop_p if use_drop else 0.0, ctx.noise, site0 + l)
@@ -587,37 +613,56 @@ class _GRU(torch.autograd.Function):
                 L.check(lib.s2ag_gru_seq_bwd(_p(dy), lddy, dir_stride, _p(whh2), _p(y), _p(gates), _p(dgi), _p(dgh),
                                              B, T, H, C.byref(e), _stream()), 'gru_seq_bwd')
             # parameter gradients
-            for d, (w_ih, w_hh) in enumerate(((wih, whh), (wih_r, whh_r))):
-                gsl = dgi[:, d * H3:(d + 1) * H3]
-                base = 8 * l + 4 * d
-                if not any(ctx.needs_input_grad[9 + base + i] for i in range(4)):
-                    continue                      # frozen weights (D inside the generator step): no weight-grad kernels
-                slots = [_grad_slot(ctx.w_leaves[base + i]) if ctx.needs_input_grad[9 + base + i] else None
-                         for i in range(4)]
-                direct = all(sl is not None for sl in slots)
-                dwi = slots[0] if direct else torch.empty_like(w_ih)
-                dbi = slots[2] if direct else torch.empty(H3, dtype=torch.float32, device=dev)
-                dwh = slots[1] if direct else torch.empty_like(w_hh)
-                dbh = slots[3] if direct else torch.empty(H3, dtype=torch.float32, device=dev)
+            base = 8 * l
+            need = [ctx.needs_input_grad[9 + base + i] for i in range(8)]
+            slots = [_grad_slot(ctx.w_leaves[base + i]) if need[i] else None for i in range(8)]
+            pair_ih = _pair(slots[0], slots[4]) if all(need) else None         # (2, 3H, In) gradient of both W_ih
+            pair_bi = _pair(slots[2], slots[6]) if all(need) else None
+            if all(sl is not None for sl in slots) and pair_ih is not None and pair_bi is not None:
+                # arena layout: the two directions are adjacent, so dW_ih / db_ih of both are one launch each
+                def leaves(dgi=dgi, dgh=dgh, y=y, inp=inp, In=In, pair_ih=pair_ih, pair_bi=pair_bi, slots=slots):
+                    conv_bwd_weight_raw(dgi, inp, pair_ih, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1, True)
+                    colsum_raw(dgi, pair_bi.view(-1), accumulate=True)
+                    for d in range(2):
+                        # dW_hh = sum_t dgh_t^T h_{t-1}: h_{prev} is y shifted by one frame (zero at the boundary)
+                        conv_bwd_weight_raw(dgh[d], y[:, d * H:(d + 1) * H], slots[4 * d + 1], B, T, T, H, H3, 1, 1,
+                                            1 if d == 0 else -1, 1, True)
+                        colsum_raw(dgh[d], slots[4 * d + 3], accumulate=True)
+                run_wgrad(leaves, keep=(dgi, dgh, y, inp))
+            else:
+                for d, (w_ih, w_hh) in enumerate(((wih, whh), (wih_r, whh_r))):
+                    gsl = dgi[:, d * H3:(d + 1) * H3]
+                    bd = base + 4 * d
+                    if not any(need[4 * d:4 * d + 4]):
+                        continue                  # frozen weights (D inside the generator step): no weight-grad kernels
+                    sl = slots[4 * d:4 * d + 4]
+                    direct = all(q is not None for q in sl)
+                    dwi = sl[0] if direct else torch.empty_like(w_ih)
+                    dbi = sl[2] if direct else torch.empty(H3, dtype=torch.float32, device=dev)
+                    dwh = sl[1] if direct else torch.empty_like(w_hh)
+                    dbh = sl[3] if direct else torch.empty(H3, dtype=torch.float32, device=dev)
 
-                def leaves(gsl=gsl, dwi=dwi, dbi=dbi, dwh=dwh, dbh=dbh, d=d, direct=direct, dgh=dgh, y=y, inp=inp,
-                           In=In):
-                    conv_bwd_weight_raw(gsl, inp, dwi, B * T, 1, 1, In, H3, 1, 1, 0, 1, direct)
-                    colsum_raw(gsl, dbi, accumulate=direct)
-                    # dW_hh = sum_t dgh_t^T h_{t-1}: h_{prev} is y shifted by one frame (zero at the boundary)
-                    conv_bwd_weight_raw(dgh[d], y[:, d * H:(d + 1) * H], dwh, B, T, T, H, H3, 1, 1,
-                                        1 if d == 0 else -1, 1, direct)
-                    colsum_raw(dgh[d], dbh, accumulate=direct)
-                if direct:       # parameter-gradient leaves: off the dx critical path
-                    run_wgrad(leaves, keep=(dgi, dgh, y, inp))
-                else:
-                    leaves()
-                    grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = dwi, dwh, dbi, dbh
+                    def leaves(gsl=gsl, dwi=dwi, dbi=dbi, dwh=dwh, dbh=dbh, d=d, direct=direct, dgh=dgh, y=y, inp=inp,
+                               In=In):
+                        conv_bwd_weight_raw(gsl, inp, dwi, B * T, 1, 1, In, H3, 1, 1, 0, 1, direct)
+                        colsum_raw(gsl, dbi, accumulate=direct)
+                        conv_bwd_weight_raw(dgh[d], y[:, d * H:(d + 1) * H], dwh, B, T, T, H, H3, 1, 1,
+                                            1 if d == 0 else -1, 1, direct)
+                        colsum_raw(dgh[d], dbh, accumulate=direct)
+                    if direct:       # parameter-gradient leaves: off the dx critical path
+                        run_wgrad(leaves, keep=(dgi, dgh, y, inp))
+                    else:
+                        leaves()
+                        grads[bd], grads[bd + 1], grads[bd + 2], grads[bd + 3] = dwi, dwh, dbi, dbh
             # input gradient
             if l > 0 or ctx.needs_input_grad[0]:
                 dx = torch.empty(B * T, In, dtype=torch.float32, device=dev)
-                conv_bwd_data_raw(dgi[:, :H3], wih, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, False)
-                conv_bwd_data_raw(dgi[:, H3:], wih_r, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, True)
+                wih2 = _pair(wih, wih_r)
+                if wih2 is not None:
+                    conv_bwd_data_raw(dgi, wih2, dx, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1, False)
+                else:
+                    conv_bwd_data_raw(dgi[:, :H3], wih, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, False)
+                    conv_bwd_data_raw(dgi[:, H3:], wih_r, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, True)
             dy, lddy, dir_stride = dx, 2 * H, H
         dxo = dx.view(B, T, -1) if ctx.needs_input_grad[0] else None
         return (dxo, None, None, None, None, None, None, None, None, *grads)
