@@ -97,6 +97,22 @@ int s2ag_bn_coeffs(const double* colsum, const double* colsq, const int* chan_of
                    int rows, const float* gamma, const float* beta, float* running_mean, float* running_var,
                    long long* num_batches_tracked /*nullable*/, float eps, float momentum, int training,
                    float* scale_col, float* shift_col, float* mean_col, float* invstd_col, void* stream);
+/* Training-mode statistics + coefficients in ONE launch (= s2ag_colstats_f64 + s2ag_bn_coeffs(training=1), without
+ * the accumulator clear): row blocks write fp64 partial column sums to `partials` (2 * s2ag_bn_partial_rows(rows,
+ * cols, ld) * cols doubles, contents irrelevant on entry), the block that finishes last folds them and writes the
+ * coefficients.  `ticket`: one int that is 0 on entry and is left 0 on return (self re-arming); two launches that may
+ * run concurrently must not share a ticket word. */
+int s2ag_bn_partial_rows(int rows, int cols, int ld);
+int s2ag_bn_fwd_stats(const float* x, int rows, int cols, int ldx, const int* chan_of_col /*nullable*/, int nchan,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      long long* num_batches_tracked /*nullable*/, float eps, float momentum, double* partials,
+                      int* ticket, float* scale_col, float* shift_col, float* mean_col, float* invstd_col,
+                      void* stream);
+/* backward stages (1)+(2) below in one launch; `partials`: 2 * s2ag_bn_partial_rows * cols floats */
+int s2ag_bn_bwd_stats(const float* x, const float* dy, int rows, int cols, int ldx, int lddy, const float* scale_col,
+                      const float* shift_col, const float* mean_col, const float* invstd_col, float slope,
+                      const int* chan_of_col /*nullable*/, int nchan, float* dgamma, float* dbeta, int accumulate,
+                      float* partials, int* ticket, float* c1_col, float* c2_col, void* stream);
 /* y = leaky(x*scale_col + shift_col, slope) */
 int s2ag_bn_apply(const float* x, int rows, int cols, int ldx, const float* scale_col, const float* shift_col,
                   float slope, float* y, int ldy, void* stream);

@@ -6,27 +6,96 @@
 namespace {
 using namespace s2ag;
 
-// One block.  Folds per-COLUMN sums into per-CHANNEL statistics through chan_of_col (LDS atomics),
-// updates the running estimates, then scatters the per-channel coefficients back to columns.
-__global__ __launch_bounds__(256) void bn_coeffs_k(const double* colsum, const double* colsq, const int* chan_of_col,
-                                                   int ncols, int nchan, int rows, const float* gamma,
-                                                   const float* beta, float* rmean, float* rvar, long long* nbt,
-                                                   float eps, float momentum, int training, float* scale_col,
-                                                   float* shift_col, float* mean_col, float* invstd_col) {
-    extern __shared__ double smd[];
-    double* cs = smd;               // nchan: sum  -> mean
-    double* cq = smd + nchan;       // nchan: sumsq -> invstd
-    double* cn = smd + 2 * nchan;   // nchan: columns per channel
-    for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) smd[i] = 0.0;
+// ---- agent-scope publish / consume (write-through stores, L1-bypassing loads), as in gru_coop.hip -------------
+__device__ __forceinline__ void st_agent(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// "Last block finalises": every block has published its partial sums with st_agent.  Drain them (vmcnt(0) per wave),
+// barrier, then one lane takes a ticket; the block that draws the last ticket re-arms the ticket word (so the NEXT
+// launch on this word needs no clearing kernel) and returns true.  No fences: the payload is write-through and the
+// consumer reads it with agent-scope loads (CDNA4 guide, publish/consume recipe).
+__device__ __forceinline__ bool last_block_done(int* ticket, int nblocks) {
+    __shared__ int is_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (training) {
-        for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
-            const int ch = chan_of_col ? chan_of_col[c] : c;
-            atomicAdd(&cs[ch], colsum[c]);
-            atomicAdd(&cq[ch], colsq[c]);
-            atomicAdd(&cn[ch], 1.0);
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == nblocks - 1);
+        if (is_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return is_last != 0;
+}
+
+// Per-column totals from the (2, nrb, cols) partial sums, folded straight into per-channel LDS accumulators.
+// NT threads: G = NT/cols groups share the partial rows of a column, one thread per column if cols >= NT.
+template <typename T, typename A>
+__device__ __forceinline__ void fold_column(const T* part, int nrb, int cols, int c, int r0, int rstep, A* a_out,
+                                            A* b_out) {
+    // 16 partial rows = 32 independent L1-bypassing loads in flight per thread, then the adds (a load-use chain per row
+    // costs one fabric round trip per row)
+    A a = 0, b = 0;
+    for (int r = r0; r < nrb; r += 16 * rstep) {
+        T va[16], vb[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int rr = min(r + j * rstep, nrb - 1);
+            va[j] = ld_agent(part + (size_t)rr * cols + c);
+            vb[j] = ld_agent(part + (size_t)(nrb + rr) * cols + c);
         }
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (r + j * rstep < nrb) {
+                a += (A)va[j];
+                b += (A)vb[j];
+            }
+    }
+    *a_out = a;
+    *b_out = b;
+}
+
+template <typename T, typename A, int NT>
+__device__ __forceinline__ void fold_partials(const T* part, int nrb, int cols, const int* chan_of_col, A* c0, A* c1,
+                                              A* cn) {
+    const int t = threadIdx.x;
+    const int G = cols >= NT ? 1 : NT / cols;
+    if (G == 1) {
+        for (int c = t; c < cols; c += NT) {
+            A a, b;
+            fold_column<T, A>(part, nrb, cols, c, 0, 1, &a, &b);
+            const int ch = chan_of_col ? chan_of_col[c] : c;
+            atomicAdd(&c0[ch], a);
+            atomicAdd(&c1[ch], b);
+            atomicAdd(&cn[ch], (A)1);
+        }
+    } else if (t < G * cols) {
+        const int c = t % cols, sub = t / cols;
+        A a, b;
+        fold_column<T, A>(part, nrb, cols, c, sub, G, &a, &b);
+        const int ch = chan_of_col ? chan_of_col[c] : c;
+        atomicAdd(&c0[ch], a);
+        atomicAdd(&c1[ch], b);
+        if (sub == 0) atomicAdd(&cn[ch], (A)1);
+    }
+}
+
+// Channel statistics (already summed into cs / cq / cn in LDS) -> running estimates and per-COLUMN coefficients.
+__device__ __forceinline__ void bn_finish_coeffs(double* cs, double* cq, const double* cn, const int* chan_of_col,
+                                                 int ncols, int nchan, int rows, const float* gamma, const float* beta,
+                                                 float* rmean, float* rvar, long long* nbt, float eps, float momentum,
+                                                 int training, float* scale_col, float* shift_col, float* mean_col,
+                                                 float* invstd_col) {
+    if (training) {
         for (int ch = threadIdx.x; ch < nchan; ch += blockDim.x) {
             const double n = cn[ch] * (double)rows;
             const double mean = cs[ch] / n;
@@ -55,6 +124,111 @@ __global__ __launch_bounds__(256) void bn_coeffs_k(const double* colsum, const d
         mean_col[c] = mean;
         invstd_col[c] = invstd;
     }
+}
+
+// One block.  Folds per-COLUMN sums into per-CHANNEL statistics through chan_of_col (LDS atomics),
+// updates the running estimates, then scatters the per-channel coefficients back to columns.
+__global__ __launch_bounds__(256) void bn_coeffs_k(const double* colsum, const double* colsq, const int* chan_of_col,
+                                                   int ncols, int nchan, int rows, const float* gamma,
+                                                   const float* beta, float* rmean, float* rvar, long long* nbt,
+                                                   float eps, float momentum, int training, float* scale_col,
+                                                   float* shift_col, float* mean_col, float* invstd_col) {
+    extern __shared__ double smd[];
+    double* cs = smd;               // nchan: sum  -> mean
+    double* cq = smd + nchan;       // nchan: sumsq -> invstd
+    double* cn = smd + 2 * nchan;   // nchan: columns per channel
+    for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) smd[i] = 0.0;
+    __syncthreads();
+    if (training) {
+        for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+            const int ch = chan_of_col ? chan_of_col[c] : c;
+            atomicAdd(&cs[ch], colsum[c]);
+            atomicAdd(&cq[ch], colsq[c]);
+            atomicAdd(&cn[ch], 1.0);
+        }
+        __syncthreads();
+    }
+    bn_finish_coeffs(cs, cq, cn, chan_of_col, ncols, nchan, rows, gamma, beta, rmean, rvar, nbt, eps, momentum, training,
+                     scale_col, shift_col, mean_col, invstd_col);
+}
+
+// Training-mode BatchNorm statistics in ONE launch: fp64 partial column sums per row block -> (2, nrb, cols) scratch,
+// and the block that finishes last folds them into channel statistics, updates the running estimates and writes the
+// per-column coefficients.  No accumulator to clear, no separate single-block kernel: BN forward = this + bn_apply.
+// FLAT: narrow contiguous matrices (cols a power of two <= 32): lane-dense grid-stride walk, column = tid % cols.
+template <bool FLAT, int NT>
+__global__ __launch_bounds__(NT) void bn_fwd_stats_k(const float* __restrict__ x, int rows, int cols, int ldx, int rpb,
+                                                      double* part, int* ticket, const int* chan_of_col, int nchan,
+                                                      const float* gamma, const float* beta, float* rmean,
+                                                      float* rvar, long long* nbt, float eps, float momentum,
+                                                      float* scale_col, float* shift_col, float* mean_col,
+                                                      float* invstd_col) {
+    extern __shared__ double smd[];           // 3 * nchan doubles (finalising block)
+    constexpr int RL = NT / 64;               // row lanes of the column-per-lane walk
+    __shared__ double s1[RL][64], s2[RL][64];
+    const int nrb = gridDim.y;
+    if (FLAT) {
+        static_assert(!FLAT || NT == 256, "flat walk: 256 threads");
+        const long long total = (long long)rows * cols;
+        double a = 0.0, b = 0.0;
+        for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long long)nrb * 256) {
+            const double v = (double)x[i];
+            a += v;
+            b += v * v;
+        }
+        double* f1 = &s1[0][0];
+        double* f2 = &s2[0][0];
+        f1[threadIdx.x] = a;
+        f2[threadIdx.x] = b;
+        __syncthreads();
+        if ((int)threadIdx.x < cols) {
+            double p = 0.0, q = 0.0;
+            for (int i = threadIdx.x; i < 256; i += cols) {
+                p += f1[i];
+                q += f2[i];
+            }
+            st_agent(part + (size_t)blockIdx.y * cols + threadIdx.x, p);
+            st_agent(part + (size_t)(nrb + blockIdx.y) * cols + threadIdx.x, q);
+        }
+    } else {
+        const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+        const int ry = threadIdx.x >> 6;
+        const int rbeg = blockIdx.y * rpb;
+        const int rend = min(rows, rbeg + rpb);
+        double a = 0.0, b = 0.0;
+        if (c < cols) {
+#pragma unroll 4
+            for (int r = rbeg + ry; r < rend; r += RL) {
+                const double v = (double)x[(long long)r * ldx + c];
+                a += v;
+                b += v * v;
+            }
+        }
+        s1[ry][threadIdx.x & 63] = a;
+        s2[ry][threadIdx.x & 63] = b;
+        __syncthreads();
+        if (ry == 0 && c < cols) {
+            const int i = threadIdx.x;
+            double p = 0.0, q = 0.0;
+#pragma unroll
+            for (int j = 0; j < RL; ++j) {
+                p += s1[j][i];
+                q += s2[j][i];
+            }
+            st_agent(part + (size_t)blockIdx.y * cols + c, p);
+            st_agent(part + (size_t)(nrb + blockIdx.y) * cols + c, q);
+        }
+    }
+    if (!last_block_done(ticket, gridDim.x * gridDim.y)) return;
+    double* cs = smd;
+    double* cq = smd + nchan;
+    double* cn = smd + 2 * nchan;
+    for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) smd[i] = 0.0;
+    __syncthreads();
+    fold_partials<double, double, NT>(part, nrb, cols, chan_of_col, cs, cq, cn);
+    __syncthreads();
+    bn_finish_coeffs(cs, cq, cn, chan_of_col, cols, nchan, rows, gamma, beta, rmean, rvar, nbt, eps, momentum, 1,
+                     scale_col, shift_col, mean_col, invstd_col);
 }
 
 __global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, int rows, int cols, int ldx,
@@ -127,6 +301,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_flat_k(const float* __restr
     }
 }
 
+__device__ __forceinline__ void bn_bwd_finish(const float* t1, const float* t2, const float* cn,
+                                              const int* chan_of_col, int ncols, int nchan, int rows, float* dgamma,
+                                              float* dbeta, int accumulate, float* c1, float* c2) {
+    for (int ch = threadIdx.x; ch < nchan; ch += blockDim.x) {
+        if (accumulate) {
+            dgamma[ch] += t2[ch];
+            dbeta[ch] += t1[ch];
+        } else {
+            dgamma[ch] = t2[ch];
+            dbeta[ch] = t1[ch];
+        }
+    }
+    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+        const int ch = chan_of_col ? chan_of_col[c] : c;
+        const float n = cn[ch] * (float)rows;
+        c1[c] = t1[ch] / n;
+        c2[c] = t2[ch] / n;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_coeffs_k(const float* s1, const float* s2, const int* chan_of_col,
                                                        int ncols, int nchan, int rows, float* dgamma, float* dbeta,
                                                        int accumulate, float* c1, float* c2) {
@@ -143,22 +337,89 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_k(const float* s1, const fl
         atomicAdd(&cn[ch], 1.0f);
     }
     __syncthreads();
-    for (int ch = threadIdx.x; ch < nchan; ch += blockDim.x) {
-        if (accumulate) {
-            dgamma[ch] += t2[ch];
-            dbeta[ch] += t1[ch];
-        } else {
-            dgamma[ch] = t2[ch];
-            dbeta[ch] = t1[ch];
+    bn_bwd_finish(t1, t2, cn, chan_of_col, ncols, nchan, rows, dgamma, dbeta, accumulate, c1, c2);
+}
+
+// BatchNorm backward statistics in ONE launch (see bn_fwd_stats_k): partial column sums of dpre and dpre*xhat per row
+// block, folded by the last block into dgamma / dbeta (+=) and the per-column c1, c2 of the dx formula.
+template <bool FLAT, int NT>
+__global__ __launch_bounds__(NT) void bn_bwd_stats_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      int rows, int cols, int ldx, int lddy, int rpb,
+                                                      const float* scale, const float* shift, const float* mean,
+                                                      const float* invstd, float slope, float* part, int* ticket,
+                                                      const int* chan_of_col, int nchan, float* dgamma, float* dbeta,
+                                                      int accumulate, float* c1, float* c2) {
+    extern __shared__ float sm[];            // 3 * nchan floats (finalising block)
+    constexpr int RL = NT / 64;
+    __shared__ float a1[RL][64], a2[RL][64];
+    const int nrb = gridDim.y;
+    if (FLAT) {
+        const long long total = (long long)rows * cols;
+        const int c = threadIdx.x % cols;
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        float p = 0.f, q = 0.f;
+        for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long long)nrb * 256) {
+            const float xv = x[i];
+            const float pre = xv * sc + sh;
+            const float d = dy[i] * (pre > 0.f ? 1.f : slope);
+            p += d;
+            q += d * (xv - mu) * is;
+        }
+        float* f1 = &a1[0][0];
+        float* f2 = &a2[0][0];
+        f1[threadIdx.x] = p;
+        f2[threadIdx.x] = q;
+        __syncthreads();
+        if ((int)threadIdx.x < cols) {
+            float u = 0.f, v = 0.f;
+            for (int i = threadIdx.x; i < 256; i += cols) {
+                u += f1[i];
+                v += f2[i];
+            }
+            st_agent(part + (size_t)blockIdx.y * cols + threadIdx.x, u);
+            st_agent(part + (size_t)(nrb + blockIdx.y) * cols + threadIdx.x, v);
+        }
+    } else {
+        const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+        const int ry = threadIdx.x >> 6;
+        const int rbeg = blockIdx.y * rpb;
+        const int rend = min(rows, rbeg + rpb);
+        float p = 0.f, q = 0.f;
+        if (c < cols) {
+            const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+#pragma unroll 4
+            for (int r = rbeg + ry; r < rend; r += RL) {
+                const float xv = x[(long long)r * ldx + c];
+                const float pre = xv * sc + sh;
+                const float d = dy[(long long)r * lddy + c] * (pre > 0.f ? 1.f : slope);
+                p += d;
+                q += d * (xv - mu) * is;
+            }
+        }
+        a1[ry][threadIdx.x & 63] = p;
+        a2[ry][threadIdx.x & 63] = q;
+        __syncthreads();
+        if (ry == 0 && c < cols) {
+            const int i = threadIdx.x;
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int j = 0; j < RL; ++j) {
+                u += a1[j][i];
+                v += a2[j][i];
+            }
+            st_agent(part + (size_t)blockIdx.y * cols + c, u);
+            st_agent(part + (size_t)(nrb + blockIdx.y) * cols + c, v);
         }
     }
+    if (!last_block_done(ticket, gridDim.x * gridDim.y)) return;
+    float* t1 = sm;
+    float* t2 = sm + nchan;
+    float* cn = sm + 2 * nchan;
+    for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
-    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
-        const int ch = chan_of_col ? chan_of_col[c] : c;
-        const float n = cn[ch] * (float)rows;
-        c1[c] = t1[ch] / n;
-        c2[c] = t2[ch] / n;
-    }
+    fold_partials<float, float, NT>(part, nrb, cols, chan_of_col, t1, t2, cn);
+    __syncthreads();
+    bn_bwd_finish(t1, t2, cn, chan_of_col, cols, nchan, rows, dgamma, dbeta, accumulate, c1, c2);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ x, const float* __restrict__ dy,
@@ -238,6 +499,85 @@ extern "C" int s2ag_bn_coeffs(const double* colsum, const double* colsq, const i
     hipLaunchKernelGGL(bn_coeffs_k, dim3(1), dim3(256), sizeof(double) * 3 * nchan, (hipStream_t)stream, colsum, colsq,
                        chan_of_col, ncols, nchan, rows, gamma, beta, running_mean, running_var, nbt, eps, momentum,
                        training, scale_col, shift_col, mean_col, invstd_col);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+// row-block plan shared by the fused statistics kernels and the scratch sizing query
+static inline bool bn_flat(int cols, int ldx, int lddy) {
+    return ldx == cols && lddy == cols && cols <= 32 && (cols & (cols - 1)) == 0;
+}
+static inline void bn_plan(int rows, int cols, bool flat, int* colblocks, int* nrb, int* rpb) {
+    // The finalising block reads 2 * nrb * cols partial sums with 256 threads: cap that at ~128 loads per thread
+    // (4 batches of 32 in flight), i.e. nrb <= 16384 / cols -- which still gives ~256 workgroups at every width.
+    int cap = 16384 / cols;
+    cap = cap < 1 ? 1 : (cap > 1024 ? 1024 : cap);
+    if (flat) {
+        long long nb = ((long long)rows * cols + 256 * 16 - 1) / (256 * 16);
+        *colblocks = 1;
+        *nrb = (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
+        *rpb = 0;
+        return;
+    }
+    *colblocks = cdiv(cols, 64);
+    int r = 64;      // 1024 threads = 16 row lanes per block: 4+ rows per lane, more while that still leaves ~256 blocks
+    while (cdiv(rows, r) > cap || (long long)cdiv(rows, 2 * r) * *colblocks >= 256) r *= 2;
+    *rpb = r;
+    *nrb = cdiv(rows, r);
+}
+
+extern "C" int s2ag_bn_partial_rows(int rows, int cols, int ld) {
+    if (rows <= 0 || cols <= 0 || ld < cols) return S2AG_E_BADARG;
+    // the forward pass plans with ldx, the backward pass with (ldx, lddy): size for whichever plan is larger
+    int cb, nrb, rpb, cb2, nrb2, rpb2;
+    bn_plan(rows, cols, bn_flat(cols, ld, ld), &cb, &nrb, &rpb);
+    bn_plan(rows, cols, false, &cb2, &nrb2, &rpb2);
+    return nrb > nrb2 ? nrb : nrb2;
+}
+
+extern "C" int s2ag_bn_fwd_stats(const float* x, int rows, int cols, int ldx, const int* chan_of_col, int nchan,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 long long* nbt, float eps, float momentum, double* partials, int* ticket,
+                                 float* scale_col, float* shift_col, float* mean_col, float* invstd_col, void* stream) {
+    if (!x || rows <= 0 || cols <= 0 || ldx < cols || nchan <= 0 || !gamma || !beta || !running_mean || !running_var ||
+        !partials || !ticket || !scale_col || !shift_col || !mean_col || !invstd_col)
+        return S2AG_E_BADARG;
+    const bool flat = bn_flat(cols, ldx, ldx);
+    int cb, nrb, rpb;
+    bn_plan(rows, cols, flat, &cb, &nrb, &rpb);
+    const size_t smem = sizeof(double) * 3 * nchan;
+    if (flat)
+        hipLaunchKernelGGL((bn_fwd_stats_k<true, 256>), dim3(cb, nrb), dim3(256), smem, (hipStream_t)stream, x, rows, cols, ldx,
+                           rpb, partials, ticket, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt, eps,
+                           momentum, scale_col, shift_col, mean_col, invstd_col);
+    else
+        hipLaunchKernelGGL((bn_fwd_stats_k<false, 1024>), dim3(cb, nrb), dim3(1024), smem, (hipStream_t)stream, x, rows, cols,
+                           ldx, rpb, partials, ticket, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt,
+                           eps, momentum, scale_col, shift_col, mean_col, invstd_col);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_bn_bwd_stats(const float* x, const float* dy, int rows, int cols, int ldx, int lddy,
+                                 const float* scale_col, const float* shift_col, const float* mean_col,
+                                 const float* invstd_col, float slope, const int* chan_of_col, int nchan,
+                                 float* dgamma, float* dbeta, int accumulate, float* partials, int* ticket,
+                                 float* c1_col, float* c2_col, void* stream) {
+    if (!x || !dy || rows <= 0 || cols <= 0 || ldx < cols || lddy < cols || nchan <= 0 || !dgamma || !dbeta ||
+        !partials || !ticket || !c1_col || !c2_col)
+        return S2AG_E_BADARG;
+    const bool flat = bn_flat(cols, ldx, lddy);
+    int cb, nrb, rpb;
+    bn_plan(rows, cols, flat, &cb, &nrb, &rpb);
+    const size_t smem = sizeof(float) * 3 * nchan;
+    if (flat)
+        hipLaunchKernelGGL((bn_bwd_stats_k<true, 256>), dim3(cb, nrb), dim3(256), smem, (hipStream_t)stream, x, dy, rows, cols,
+                           ldx, lddy, rpb, scale_col, shift_col, mean_col, invstd_col, slope, partials, ticket,
+                           chan_of_col, nchan, dgamma, dbeta, accumulate, c1_col, c2_col);
+    else
+        hipLaunchKernelGGL((bn_bwd_stats_k<false, 1024>), dim3(cb, nrb), dim3(1024), smem, (hipStream_t)stream, x, dy, rows, cols,
+                           ldx, lddy, rpb, scale_col, shift_col, mean_col, invstd_col, slope, partials, ticket,
+                           chan_of_col, nchan, dgamma, dbeta, accumulate, c1_col, c2_col);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -160,6 +160,37 @@ def normal_noise(noise: Tensor, site: int, shape: Sequence[int]) -> Tensor:
 
 
 # ----------------------------------------------------------------------------------------------------
+# ticket words of the "last block finalises" reductions
+# ----------------------------------------------------------------------------------------------------
+_TICKETS = {}
+_TICKET_POOL = 1 << 15
+
+
+def init_tickets(device) -> None:
+    """Allocate the per-device pool of ticket words (zero once; every kernel leaves its word at zero again).  Called
+    outside stream capture (Processor.__init__); a lazy first use inside a capture would put the pool in the graph's
+    private memory."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _TICKETS:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('ops.init_tickets(device) must run before hipGraph capture (run one eager step first)')
+        _TICKETS[key] = [torch.zeros(_TICKET_POOL, dtype=torch.int32, device=dev), 0]
+
+
+def _ticket(dev):
+    """Next ticket word, round robin: launches that can be in flight together (a few streams x a few kernels) are
+    always far fewer than the pool, and a hipGraph replays each launch with the word it captured."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _TICKETS:
+        init_tickets(dev)
+    ent = _TICKETS[key]
+    i = ent[1]
+    ent[1] = (i + 1) % _TICKET_POOL
+    return C.c_void_p(ent[0].data_ptr() + 4 * i)
+
+
+# ----------------------------------------------------------------------------------------------------
 # direct gradient accumulation
 # ----------------------------------------------------------------------------------------------------
 def _grad_slot(p: Optional[Tensor]):
@@ -268,14 +299,18 @@ class _BNAct(torch.autograd.Function):
         nchan = gamma.numel()
         dev = x.device
         coef = torch.empty(4, cols, dtype=torch.float32, device=dev)
-        s = sq = None
         if training:
-            stats = torch.empty(2, cols, dtype=torch.float64, device=dev)       # fp64 batch statistics
-            s, sq = stats[0], stats[1]
-            L.check(lib.s2ag_colstats_f64(_p(x), rows, cols, ldx, _p(s), _p(sq), _stream()), 'colstats_f64')
-        L.check(lib.s2ag_bn_coeffs(_p(s), _p(sq), _p(chan_map), cols, nchan, rows, _p(gamma), _p(beta), _p(rmean),
-                                   _p(rvar), _p(nbt), float(eps), float(momentum), int(training), _p(coef[0]),
-                                   _p(coef[1]), _p(coef[2]), _p(coef[3]), _stream()), 'bn_coeffs')
+            # one launch: fp64 partial column sums per row block, folded into coefficients by the last block
+            nrb = lib.s2ag_bn_partial_rows(rows, cols, ldx)
+            part = torch.empty(2 * nrb * cols, dtype=torch.float64, device=dev)
+            L.check(lib.s2ag_bn_fwd_stats(_p(x), rows, cols, ldx, _p(chan_map), nchan, _p(gamma), _p(beta), _p(rmean),
+                                          _p(rvar), _p(nbt), float(eps), float(momentum), _p(part), _ticket(dev),
+                                          _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _stream()),
+                    'bn_fwd_stats')
+        else:
+            L.check(lib.s2ag_bn_coeffs(None, None, _p(chan_map), cols, nchan, rows, _p(gamma), _p(beta), _p(rmean),
+                                       _p(rvar), None, float(eps), float(momentum), 0, _p(coef[0]),
+                                       _p(coef[1]), _p(coef[2]), _p(coef[3]), _stream()), 'bn_coeffs')
         y = torch.empty(rows, cols, dtype=torch.float32, device=dev)
         L.check(lib.s2ag_bn_apply(_p(x), rows, cols, ldx, _p(coef[0]), _p(coef[1]), float(slope), _p(y), cols,
                                   _stream()), 'bn_apply')
@@ -294,20 +329,19 @@ class _BNAct(torch.autograd.Function):
         dx = torch.empty(rows, cols, dtype=torch.float32, device=dev)
         dgamma = dbeta = None
         if training:
-            tmp = torch.empty(4, cols, dtype=torch.float32, device=dev)
-            L.check(lib.s2ag_bn_bwd_reduce(_p(x), _p(dy), rows, cols, ldx, lddy, _p(coef[0]), _p(coef[1]),
-                                           _p(coef[2]), _p(coef[3]), slope, _p(tmp[0]), _p(tmp[1]), _stream()),
-                    'bn_bwd_reduce')
+            tmp = torch.empty(2, cols, dtype=torch.float32, device=dev)
+            nrb = lib.s2ag_bn_partial_rows(rows, cols, max(ldx, lddy))
+            part = torch.empty(2 * nrb * cols, dtype=torch.float32, device=dev)
             sg, sb = _grad_slot(ctx.leaves[0]), _grad_slot(ctx.leaves[1])
-            if sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
-                L.check(lib.s2ag_bn_bwd_coeffs(_p(tmp[0]), _p(tmp[1]), _p(chan_map), cols, nchan, rows, _p(sg), _p(sb),
-                                               1, _p(tmp[2]), _p(tmp[3]), _stream()), 'bn_bwd_coeffs')
-            else:
+            direct = sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+            if not direct:
                 dgb = torch.empty(2, nchan, dtype=torch.float32, device=dev)
-                L.check(lib.s2ag_bn_bwd_coeffs(_p(tmp[0]), _p(tmp[1]), _p(chan_map), cols, nchan, rows, _p(dgb[0]),
-                                               _p(dgb[1]), 0, _p(tmp[2]), _p(tmp[3]), _stream()), 'bn_bwd_coeffs')
+                sg, sb = dgb[0], dgb[1]
                 dgamma, dbeta = dgb[0], dgb[1]
-            c1, c2 = tmp[2], tmp[3]
+            L.check(lib.s2ag_bn_bwd_stats(_p(x), _p(dy), rows, cols, ldx, lddy, _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                          _p(coef[3]), slope, _p(chan_map), nchan, _p(sg), _p(sb), int(direct),
+                                          _p(part), _ticket(dev), _p(tmp[0]), _p(tmp[1]), _stream()), 'bn_bwd_stats')
+            c1, c2 = tmp[0], tmp[1]
         else:
             z = torch.zeros(2, cols, dtype=torch.float32, device=dev)
             c1, c2 = z[0], z[1]

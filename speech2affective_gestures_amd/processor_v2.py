@@ -176,6 +176,7 @@ class Processor(object):
         for p in self.trimodal_generator.parameters():      # frozen baseline (processor_v2.py:1033-1034)
             p.requires_grad_(False)
 
+        ops.init_tickets(self.device)
         # flat arenas (must come after .to(device)); identical initial weights on every rank
         self.gen_arena = ParamArena(self.s2ag_generator.parameters())
         self.dis_arena = ParamArena(self.s2ag_discriminator.parameters())

@@ -187,6 +187,44 @@ def test_batch_norm_narrow_matrix_lane_dense_path(S):
     assert rel(bn_g.bias.grad, bn_r.bias.grad) < TOL
 
 
+@pytest.mark.parametrize('rows,cols,strided', [(4352, 900, False), (70000, 64, False), (300000, 8, False),
+                                               (4352, 96, True), (33, 257, False), (1, 5, False)])
+def test_batch_norm_fused_statistics_shapes_and_ticket_rearm(S, rows, cols, strided):
+    """The one-launch statistics kernels (row-block partial sums, last block folds them): wide / tall / narrow / strided
+    matrices, launched repeatedly on the same ticket words (each launch must leave its ticket at zero)."""
+    ops = S['ops']
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g) * 1.7 + 0.4
+    bn_r, bn_g = torch.nn.BatchNorm1d(cols), torch.nn.BatchNorm1d(cols).cuda()
+    dy = torch.randn(rows, cols, generator=g)
+    if rows > 1:
+        xr = x.clone().requires_grad_(True)
+        yr = F.leaky_relu(bn_r(xr), 0.2)
+        yr.backward(dy)
+    for rep in range(3):
+        bn_g.reset_running_stats()
+        bn_g.weight.grad = bn_g.bias.grad = None
+        if strided:
+            big = torch.zeros(rows, cols + 32, device='cuda')
+            big[:, 16:16 + cols] = x.cuda()
+            xg = big.requires_grad_(True)
+            yg = ops.batch_norm_act(xg[:, 16:16 + cols], bn_g, slope=0.2)
+        else:
+            xg = x.cuda().requires_grad_(True)
+            yg = ops.batch_norm_act(xg, bn_g, slope=0.2)
+        yg.backward(dy.cuda())
+        if rows == 1:
+            assert torch.isfinite(yg).all()
+            continue
+        gx = xg.grad[:, 16:16 + cols] if strided else xg.grad
+        assert rel(yg, yr) < TOL, rep
+        assert rel(bn_g.running_mean, bn_r.running_mean) < TOL and rel(bn_g.running_var, bn_r.running_var) < TOL
+        assert rel(gx, xr.grad) < 5 * TOL
+        assert rel(bn_g.weight.grad, bn_r.weight.grad) < 2 * TOL and rel(bn_g.bias.grad, bn_r.bias.grad) < 2 * TOL
+    pool = ops._TICKETS[torch.cuda.current_device()][0]
+    assert int(pool.abs().sum()) == 0
+
+
 def test_batch_norm_channel_map_is_batchnorm2d(S):
     ops = S['ops']
     g = torch.Generator().manual_seed(10)
