@@ -296,17 +296,6 @@ def test_gru_forward_backward(S, B, T, I, H, L, sum_dirs, p):
     assert ops.coop_gru_timeouts() == 0          # cooperative (H = 300) launches never timed out on a peer
 
 
-def test_gru_small_hidden_cooperative_backward_variant(S):
-    """H = 64 single-workgroup kernels (shipped, not the default at H = 64): same numbers as the oracle."""
-    ops, noise = S['ops'], S['noise']
-    old = (ops.COOP_GRU_MIN_H, ops.COOP_GRU_BWD_MIN_H)
-    ops.COOP_GRU_MIN_H = ops.COOP_GRU_BWD_MIN_H = 64
-    try:
-        test_gru_forward_backward(S, 21, 9, 8, 64, 2, True, 0.3)
-    finally:
-        ops.COOP_GRU_MIN_H, ops.COOP_GRU_BWD_MIN_H = old
-
-
 def test_embedding_dropout_and_dense_gradient(S):
     ops, noise = S['ops'], S['noise']
     g = torch.Generator().manual_seed(12)
