@@ -155,6 +155,34 @@ int s2ag_weight_norm_fwd(const float* v, const float* g, int rows, int cols, int
 int s2ag_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, int rows, int cols,
                          int ksize, float* dv, float* dg, void* stream);
 
+/* Several derived-parameter maps per launch (one ST-GCN block's six folds, all weight-normed convs of a TCN).
+ * flush == 0: forward (y = M x;  w = g v/||v||).
+ * flush != 0: route the STAGED gradient back and clear the stage: x += M^T y, y = 0   (x = gradient of the source
+ *   tensor, y = staged gradient of the derived tensor);  dv += ..., dg += ..., dw = 0 for weight norm.
+ * The stage is a persistent buffer that the weight-gradient kernels accumulate into (accumulate = 1): it is zero
+ * before the first use and every flush leaves it zero, so no clearing launch is ever needed. */
+#define S2AG_MAX_JOBS 8
+typedef struct s2ag_spmv_job {
+    const int* rowptr;
+    const int* col;
+    const float* val;
+    float* x;   /* forward: source (read);  flush: gradient of the source (+=) */
+    float* y;   /* forward: derived tensor (written);  flush: staged gradient (read, then cleared) */
+    int nrows;
+} s2ag_spmv_job;
+typedef struct s2ag_wn_job {
+    const float* v;
+    const float* g;
+    float* w;      /* forward: out */
+    float* norm;   /* forward: out;  flush: in */
+    float* dw;     /* flush: staged gradient of w (read, then cleared) */
+    float* dv;     /* flush: += */
+    float* dg;     /* flush: += */
+    int rows, cols, ksize;
+} s2ag_wn_job;
+int s2ag_spmv_multi(const s2ag_spmv_job* jobs /*host*/, int njobs, int flush, void* stream);
+int s2ag_weight_norm_multi(const s2ag_wn_job* jobs /*host*/, int njobs, int flush, void* stream);
+
 /* y[i] (+)= sum_{j in row i} val[j] * x[col[j]]   (CSR).  Used to fold the ST-GCN adjacency / vertex kernel
  * into dense channels-last conv weights each step and to un-fold their gradients:
  * net/utils/tgcn.py:64-71 (einsum 'nkctv,kvw->nctw'), :181 (Conv2d (kt, kv)), :200 (1x1 residual). */

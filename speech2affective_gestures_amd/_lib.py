@@ -22,6 +22,18 @@ ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 PG, PE = C.POINTER(ConvGeom), C.POINTER(Epilogue)
 
 # name -> argtypes (every function returns int); mirrors include/s2ag_hip.h one to one
+class SpmvJob(C.Structure):
+    _fields_ = [('rowptr', C.c_void_p), ('col', C.c_void_p), ('val', C.c_void_p), ('x', C.c_void_p), ('y', C.c_void_p),
+                ('nrows', C.c_int)]
+
+
+class WnJob(C.Structure):
+    _fields_ = [('v', C.c_void_p), ('g', C.c_void_p), ('w', C.c_void_p), ('norm', C.c_void_p), ('dw', C.c_void_p),
+                ('dv', C.c_void_p), ('dg', C.c_void_p), ('rows', C.c_int), ('cols', C.c_int), ('ksize', C.c_int)]
+
+
+MAX_JOBS = 8
+
 SIGNATURES = {
     's2ag_abi_version': [],
     's2ag_conv1d_nlc_fwd': [vp, vp, vp, vp, PG, PE, vp],
@@ -44,6 +56,8 @@ SIGNATURES = {
     's2ag_weight_norm_fwd': [vp, vp, ci, ci, ci, vp, vp, vp],
     's2ag_weight_norm_bwd': [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp],
     's2ag_spmv': [vp, vp, vp, vp, vp, ci, ci, vp],
+    's2ag_spmv_multi': [vp, ci, ci, vp],
+    's2ag_weight_norm_multi': [vp, ci, ci, vp],
     's2ag_transpose': [vp, ci, ci, vp, vp],
     's2ag_gru_seq_needs_transposed': [ci],
     's2ag_gru_seq_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],
@@ -75,16 +89,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('S2AG_HIP_LIB', LIB_PATH)     # override: A/B-testing another build of the same ABI
+    if not os.path.exists(path):
         raise S2AGLibraryError(
-            f'{LIB_PATH} not found: the S2AG HIP kernels are not built. Run '
+            f'{path} not found: the S2AG HIP kernels are not built. Run '
             f'`python -m speech2affective_gestures_amd.build` (hipcc, gfx950). There is no CPU fallback.')
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, args in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise S2AGLibraryError(f'{LIB_PATH} lacks symbol {name}; rebuild it') from e
+            raise S2AGLibraryError(f'{path} lacks symbol {name}; rebuild it') from e
         fn.argtypes = args
         fn.restype = cll if name == 's2ag_gru_coop_workspace_bytes' else ci
     if lib.s2ag_abi_version() != 1:

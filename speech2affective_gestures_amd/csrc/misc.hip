@@ -119,6 +119,95 @@ __global__ void transpose_k(const float* __restrict__ src, int rows, int cols, f
     }
 }
 
+// ---- derived parameters: several maps per launch ------------------------------------------------------------
+// The ST-GCN blocks and the weight-normed TCN convs consume tensors DERIVED from the trainable ones (folded / normalised
+// weights).  They are recomputed once per optimizer step (not once per forward pass) and a whole block's worth per
+// launch; their gradients are staged in persistent zero-on-entry buffers that the conv weight-gradient kernels
+// accumulate into, and one "flush" launch routes the staged gradients to the trainable tensors and leaves the stage
+// zeroed for the next step.
+constexpr int MAX_JOBS = S2AG_MAX_JOBS;
+struct SpmvJobs {
+    s2ag_spmv_job j[MAX_JOBS];
+    int first_block[MAX_JOBS + 1];
+    int n;
+};
+
+__device__ __forceinline__ int find_job(const int* first_block, int n) {
+    int k = 0;
+    while (k + 1 < n && (int)blockIdx.x >= first_block[k + 1]) ++k;
+    return k;
+}
+
+__global__ __launch_bounds__(256) void spmv_multi_k(SpmvJobs js) {
+    const int k = find_job(js.first_block, js.n);
+    const s2ag_spmv_job& J = js.j[k];
+    const int i = ((int)blockIdx.x - js.first_block[k]) * 256 + threadIdx.x;
+    if (i >= J.nrows) return;
+    float s = 0.f;
+    for (int q = J.rowptr[i]; q < J.rowptr[i + 1]; ++q) s += J.val[q] * J.x[J.col[q]];
+    J.y[i] = s;
+}
+
+// transpose of spmv_multi_k in scatter form: row i of the map takes the staged gradient y[i], clears it, and adds
+// val * y[i] to the gradient of every source element of the row (few per row; atomics because rows share sources)
+__global__ __launch_bounds__(256) void spmv_multi_flush_k(SpmvJobs js) {
+    const int k = find_job(js.first_block, js.n);
+    const s2ag_spmv_job& J = js.j[k];
+    const int i = ((int)blockIdx.x - js.first_block[k]) * 256 + threadIdx.x;
+    if (i >= J.nrows) return;
+    const float g = J.y[i];
+    if (g == 0.f) return;
+    J.y[i] = 0.f;
+    for (int q = J.rowptr[i]; q < J.rowptr[i + 1]; ++q) atomicAdd(J.x + J.col[q], J.val[q] * g);
+}
+
+struct WnJobs {
+    s2ag_wn_job j[MAX_JOBS];
+    int first_block[MAX_JOBS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void weight_norm_multi_fwd_k(WnJobs js) {
+    const int k = find_job(js.first_block, js.n);
+    const s2ag_wn_job& J = js.j[k];
+    const int row = ((int)blockIdx.x - js.first_block[k]) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= J.rows) return;
+    const float* vr = J.v + (long long)row * J.cols;
+    float s = 0.f;
+    for (int c = lane; c < J.cols; c += 64) s += vr[c] * vr[c];
+    s = wave_sum(s);
+    const float nrm = sqrtf(s);
+    const float f = J.g[row] / nrm;
+    const int cin = J.ksize > 1 ? J.cols / J.ksize : J.cols;
+    for (int c = lane; c < J.cols; c += 64) J.w[(long long)row * J.cols + tm_col(c, cin, J.ksize)] = vr[c] * f;
+    if (lane == 0) J.norm[row] = nrm;
+}
+
+// dv += ..., dg += ... from the staged dw, which is cleared behind the second read (a row belongs to one wave and every
+// lane re-reads exactly the elements it read first)
+__global__ __launch_bounds__(256) void weight_norm_multi_flush_k(WnJobs js) {
+    const int k = find_job(js.first_block, js.n);
+    const s2ag_wn_job& J = js.j[k];
+    const int row = ((int)blockIdx.x - js.first_block[k]) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= J.rows) return;
+    const float* vr = J.v + (long long)row * J.cols;
+    float* dr = J.dw + (long long)row * J.cols;
+    const int cin = J.ksize > 1 ? J.cols / J.ksize : J.cols;
+    float s = 0.f;
+    for (int c = lane; c < J.cols; c += 64) s += dr[tm_col(c, cin, J.ksize)] * vr[c];
+    s = wave_sum(s);
+    const float nrm = J.norm[row], gg = J.g[row];
+    const float a = gg / nrm, b = gg * s / (nrm * nrm * nrm);
+    for (int c = lane; c < J.cols; c += 64) {
+        const int t = tm_col(c, cin, J.ksize);
+        J.dv[(long long)row * J.cols + c] += a * dr[t] - b * vr[c];
+        dr[t] = 0.f;
+    }
+    if (lane == 0) J.dg[row] += s / nrm;
+}
+
 // ---- re-parametrisation ----------------------------------------------------------------------------------
 __global__ void reparam_fwd_k(const float* mu, const float* lv, int n, const unsigned long long* rng, unsigned site,
                               float* z) {
@@ -373,6 +462,50 @@ extern "C" int s2ag_spmv(const int* rowptr, const int* col, const float* val, co
     if (!rowptr || !col || !val || !x || !y || nrows <= 0) return S2AG_E_BADARG;
     hipLaunchKernelGGL(spmv_k, dim3(cdiv(nrows, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, val, x, y,
                        nrows, accumulate);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_spmv_multi(const s2ag_spmv_job* jobs, int njobs, int flush, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > MAX_JOBS) return S2AG_E_BADARG;
+    SpmvJobs js;
+    js.n = njobs;
+    int nb = 0;
+    for (int k = 0; k < njobs; ++k) {
+        if (!jobs[k].rowptr || !jobs[k].col || !jobs[k].val || !jobs[k].x || !jobs[k].y || jobs[k].nrows <= 0)
+            return S2AG_E_BADARG;
+        js.j[k] = jobs[k];
+        js.first_block[k] = nb;
+        nb += cdiv(jobs[k].nrows, 256);
+    }
+    js.first_block[njobs] = nb;
+    if (flush)
+        hipLaunchKernelGGL(spmv_multi_flush_k, dim3(nb), dim3(256), 0, (hipStream_t)stream, js);
+    else
+        hipLaunchKernelGGL(spmv_multi_k, dim3(nb), dim3(256), 0, (hipStream_t)stream, js);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_weight_norm_multi(const s2ag_wn_job* jobs, int njobs, int flush, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > MAX_JOBS) return S2AG_E_BADARG;
+    WnJobs js;
+    js.n = njobs;
+    int nb = 0;
+    for (int k = 0; k < njobs; ++k) {
+        const s2ag_wn_job& J = jobs[k];
+        if (!J.v || !J.g || !J.norm || J.rows <= 0 || J.cols <= 0 || (J.ksize > 1 && J.cols % J.ksize))
+            return S2AG_E_BADARG;
+        if (flush ? (!J.dw || !J.dv || !J.dg) : !J.w) return S2AG_E_BADARG;
+        js.j[k] = J;
+        js.first_block[k] = nb;
+        nb += cdiv(J.rows, 4);
+    }
+    js.first_block[njobs] = nb;
+    if (flush)
+        hipLaunchKernelGGL(weight_norm_multi_flush_k, dim3(nb), dim3(256), 0, (hipStream_t)stream, js);
+    else
+        hipLaunchKernelGGL(weight_norm_multi_fwd_k, dim3(nb), dim3(256), 0, (hipStream_t)stream, js);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -47,12 +47,14 @@ class TemporalBlock(nn.Module):
         self.relu = nn.ReLU()
         self.sites = (new_site(), new_site())
 
-    def forward_nlc(self, x, noise):
-        """x (B, T, C) channels-last."""
+    def forward_nlc(self, x, noise, weights=None):
+        """x (B, T, C) channels-last.  ``weights``: the two normalised (Cout, k, Cin) weights if the caller already
+        has them (TemporalConvNet computes all of its blocks' in one launch per optimizer step)."""
         out = x
         pad = (self.kernel_size - 1) * self.dilation
-        for conv, site in ((self.conv1, self.sites[0]), (self.conv2, self.sites[1])):
-            w = ops.weight_norm(conv.weight_v, conv.weight_g, tap_major=True)          # (Cout, k, Cin)
+        for i, (conv, site) in enumerate(((self.conv1, self.sites[0]), (self.conv2, self.sites[1]))):
+            w = weights[i] if weights is not None else \
+                ops.weight_norm(conv.weight_v, conv.weight_g, tap_major=True)          # (Cout, k, Cin)
             p = self.p if self.training else 0.0
             out = ops.conv1d_nlc(out, w, conv.bias, pad=pad, dil=self.dilation, lout=x.shape[1], act=ACT_LEAKY,
                                  slope=0.0, drop_p=p, noise=noise, site=site, w_tap_major=True)
@@ -75,10 +77,21 @@ class TemporalConvNet(nn.Module):
             layers.append(TemporalBlock(in_channels, out_channels, kernel_size, stride=1, dilation=d,
                                         padding=(kernel_size - 1) * d, dropout=dropout))
         self.network = nn.Sequential(*layers)
+        self._groups = None
+
+    def _weight_groups(self):
+        """ops.WeightNormGroup per <= 8 convs: w = g v/||v|| of every block, recomputed once per optimizer step."""
+        if self._groups is None:
+            convs = [c for blk in self.network for c in (blk.conv1, blk.conv2)]
+            n = ops.L.MAX_JOBS
+            self._groups = [ops.WeightNormGroup([c.weight_v for c in convs[i:i + n]],
+                                                [c.weight_g for c in convs[i:i + n]]) for i in range(0, len(convs), n)]
+        return self._groups
 
     def forward_nlc(self, x, noise):
-        for blk in self.network:
-            x = blk.forward_nlc(x, noise)
+        ws = [w for g in self._weight_groups() for w in g.tensors()]
+        for i, blk in enumerate(self.network):
+            x = blk.forward_nlc(x, noise, weights=ws[2 * i:2 * i + 2])
         return x
 
     def forward(self, x):

@@ -150,6 +150,7 @@ class STGraphConv(nn.Module):
         else:
             raise ValueError(activation)
         self._cache = {}
+        self._groups = {}
 
     def _aux(self, V, in_col, out_col, device):
         key = (V, in_col.tobytes(), out_col.tobytes(), str(device))
@@ -163,23 +164,34 @@ class STGraphConv(nn.Module):
             self._cache[key] = (tf, rf, torch.from_numpy(cmap).to(device))
         return self._cache[key]
 
+    def _fold_group(self, A, in_col, out_col, device):
+        """All folded tensors of the block as ONE ops.FoldGroup (one launch per optimizer step, shared by every
+        forward pass in between; gradients staged and flushed in one launch)."""
+        key = (A.data_ptr(), in_col.tobytes(), out_col.tobytes(), str(device))
+        if key not in self._groups:
+            V, Co, Ci = A.shape[1], self.out_channels, self.in_channels
+            (tw, tb), rf, cmap = self._aux(V, in_col, out_col, device)
+            gw, gb = self.gcn.folds(A, in_col, out_col)
+            params = [self.gcn.conv.weight, self.gcn.conv.bias, self.tcn[2].weight, self.tcn[2].bias]
+            csrs = [gw, gb, tw, tb]
+            shapes = [(V * Co, self.kt, V * Ci), (V * Co,), (V * Co, self.kt, V * Co), (V * Co,)]
+            if isinstance(self.residual, nn.Module):
+                params += [self.residual[0].weight, self.residual[0].bias]
+                csrs += list(rf)
+                shapes += [(V * Co, 1, V * Ci), (V * Co,)]
+            self._groups[key] = (ops.FoldGroup(params, csrs, shapes), cmap)
+        return self._groups[key]
+
     def forward_nlc(self, x, A, in_col, out_col):
         """x (N, T, V*Cin) with column order ``in_col`` -> (N, T, V*Cout) in column order ``out_col``."""
-        V, Co, Ci = A.shape[1], self.out_channels, self.in_channels
-        (tw, tb), rf, cmap = self._aux(V, in_col, out_col, x.device)
-        g = self.gcn.forward_nlc(x, A, in_col, out_col)
+        grp, cmap = self._fold_group(A, in_col, out_col, x.device)
+        f = grp.tensors()
+        g = ops.conv1d_nlc(x, f[0], f[1], pad=self.gcn.pad, w_tap_major=True)                  # graph conv + einsum
         h = ops.batch_norm_act(g, self.tcn[0], slope=0.0, chan_map=cmap)                       # BN2d + ReLU
-        conv = self.tcn[2]
-        wt = ops.fold(conv.weight, tw).view(V * Co, self.kt, V * Co)
-        bt = ops.fold(conv.bias, tb)
-        h = ops.conv1d_nlc(h, wt, bt, pad=self.kt // 2, w_tap_major=True)
+        h = ops.conv1d_nlc(h, f[2], f[3], pad=self.kt // 2, w_tap_major=True)
         h = ops.batch_norm_act(h, self.tcn[3], slope=1.0, chan_map=cmap)
         if isinstance(self.residual, nn.Module):
-            rw, rb = rf
-            rconv = self.residual[0]
-            wr = ops.fold(rconv.weight, rw).view(V * Co, 1, V * Ci)
-            br = ops.fold(rconv.bias, rb)
-            r = ops.conv1d_nlc(x, wr, br, w_tap_major=True)
+            r = ops.conv1d_nlc(x, f[4], f[5], w_tap_major=True)
             r = ops.batch_norm_act(r, self.residual[1], slope=1.0, chan_map=cmap)
             return ops.add_act(h, r, self.slope)
         return ops.add_act(h, None, self.slope)

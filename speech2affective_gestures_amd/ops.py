@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -256,6 +257,10 @@ class _ConvNLC(torch.autograd.Function):
                 if bslot is not None:
                     colsum_raw(g, bslot, accumulate=True)
             run_wgrad(leaves, keep=(g, x))
+            if wslot is not None:
+                _note_staged(ctx.w_leaf)        # derived tensors (folded / weight-normed): flush when backward ends
+            if bslot is not None:
+                _note_staged(ctx.b_leaf)
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -515,6 +520,176 @@ class _Fold(torch.autograd.Function):
 
 def fold(w: Tensor, csr: CSR) -> Tensor:
     return _Fold.apply(w, csr)
+
+
+# ----------------------------------------------------------------------------------------------------
+# derived parameters: folded / weight-normed tensors cached per optimizer step, gradients staged and flushed
+# ----------------------------------------------------------------------------------------------------
+_PENDING_FLUSH = []
+_GENERATION = [0]
+
+
+def begin_step() -> None:
+    """Trainer hook at the start of every step: derived tensors are never carried across a step boundary.  (Inside a
+    step the producer always precedes its consumers -- also across the hipGraph segments of the step -- so a captured
+    graph never reads a derived tensor that only an earlier, un-captured launch wrote.)"""
+    _GENERATION[0] += 1
+
+
+def _source_key(p: Tensor):
+    """Identity of a source tensor's current value: its arena's step counter (the fused Adam kernel updates the arena
+    through a raw pointer, so torch's version counter does not see it), torch's version counter (copy_,
+    load_state_dict, ...), and the storage."""
+    ar = getattr(p, '_s2ag_arena', None)
+    return (ar.epoch if ar is not None else -1, p._version, p.data_ptr())
+
+
+def _note_staged(t: Optional[Tensor]) -> None:
+    """Called by a backward kernel that has just accumulated into the staging gradient of a derived tensor: the owner
+    is flushed when the running backward pass ends (autograd engine callback -- also under hipGraph capture)."""
+    owner = getattr(t, '_s2ag_owner', None)
+    if owner is None:
+        return
+    if not _PENDING_FLUSH:
+        torch.autograd.Variable._execution_engine.queue_callback(flush_derived)
+    if not any(owner is o for o in _PENDING_FLUSH):
+        _PENDING_FLUSH.append(owner)
+
+
+def flush_derived() -> None:
+    """Route every staged gradient to its trainable sources (and leave the stages zeroed)."""
+    if not _PENDING_FLUSH:
+        return
+    join_side_streams()          # weight-gradient kernels that fill the stages may still run on forked streams
+    while _PENDING_FLUSH:
+        _PENDING_FLUSH.pop().flush()
+
+
+def _leaf_grad(p: Tensor) -> Tensor:
+    g = _grad_slot(p)
+    if g is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        g = p.grad
+    return g
+
+
+class _DerivedGroup:
+    """Tensors computed from trainable tensors by a fixed map.  ``tensors()`` returns them, recomputing (ONE launch for
+    the whole group) only when a source changed -- every forward pass between two optimizer steps shares them.  To the
+    autograd ops they are leaves whose ``.grad`` is a persistent staging buffer (zero on entry): weight-gradient
+    kernels accumulate into it exactly as into an arena slot, and ``flush()`` (ONE launch) adds the mapped-back
+    gradient to the sources' ``.grad`` and clears the stage."""
+
+    def __init__(self, sources):
+        self.sources = list(sources)
+        self._key = None
+        self._out = None
+        self._stage = None
+
+    def _alloc(self, shapes, device):
+        n = sum(int(np.prod(sh)) for sh in shapes)
+        # new values -> new tensors over fresh memory (earlier passes / captured graphs keep the old ones); the stage
+        # is allocated (and zeroed) once: every flush leaves it zero
+        flat = torch.empty(n, dtype=torch.float32, device=device)
+        stage = self._stage
+        if stage is None or stage.device != flat.device or stage.numel() != n:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('derived-parameter stages must be created before hipGraph capture '
+                                   '(run one eager step first)')
+            stage = torch.zeros(n, dtype=torch.float32, device=device)
+        out, off = [], 0
+        for sh in shapes:
+            k = int(np.prod(sh))
+            t = flat[off:off + k].view(sh)
+            t.requires_grad_(True)
+            t.grad = stage[off:off + k].view(sh)
+            t._s2ag_owner = self
+            out.append(t)
+            off += k
+        self._out, self._stage = out, stage
+
+    def tensors(self):
+        key = (_GENERATION[0],) + tuple(_source_key(p) for p in self.sources)
+        if key != self._key:
+            with torch.no_grad():
+                self._compute()
+            self._key = key
+        if torch.is_grad_enabled():       # under no_grad no graph is built either way: leave the flags alone
+            want = any(p.requires_grad for p in self.sources)
+            for t in self._out:
+                if t.requires_grad != want:
+                    t.requires_grad_(want)
+        return self._out
+
+
+class FoldGroup(_DerivedGroup):
+    """y_k = M_k x_k for up to 8 (CSR map, parameter) pairs -- one ST-GCN block's folded weights and biases."""
+
+    def __init__(self, params, csrs, shapes):
+        super().__init__(params)
+        assert len(params) == len(csrs) == len(shapes) <= L.MAX_JOBS
+        self.csrs, self.shapes = list(csrs), [tuple(sh) for sh in shapes]
+
+    def _jobs(self, xs):
+        jobs = (L.SpmvJob * len(self.csrs))()
+        for k, (csr, x, y) in enumerate(zip(self.csrs, xs, self._out)):
+            rp, ci_, va = csr.fwd
+            jobs[k] = L.SpmvJob(rp.data_ptr(), ci_.data_ptr(), va.data_ptr(), x.data_ptr(), 0, csr.shape[0])
+        return jobs
+
+    def _compute(self):
+        dev = self.sources[0].device
+        _need_cuda(*self.sources)
+        self._alloc(self.shapes, dev)
+        srcs = [p.detach().contiguous() for p in self.sources]
+        jobs = self._jobs(srcs)
+        for k, y in enumerate(self._out):
+            jobs[k].y = y.data_ptr()
+        L.check(_lib().s2ag_spmv_multi(jobs, len(jobs), 0, _stream()), 'spmv_multi')
+
+    def flush(self):
+        grads = [_leaf_grad(p) for p in self.sources]
+        jobs = self._jobs(grads)
+        for k, y in enumerate(self._out):
+            jobs[k].y = y.grad.data_ptr()
+        L.check(_lib().s2ag_spmv_multi(jobs, len(jobs), 1, _stream()), 'spmv_multi_flush')
+
+
+class WeightNormGroup(_DerivedGroup):
+    """w_k = g_k v_k / ||v_k|| (torch weight_norm, dim 0) for up to 8 convs; w comes out tap-major (Cout, k, Cin)."""
+
+    def __init__(self, vs, gs):
+        super().__init__(list(vs) + list(gs))
+        assert len(vs) == len(gs) <= L.MAX_JOBS
+        self.vs, self.gs = list(vs), list(gs)
+        self._norms = None
+
+    def _jobs(self):
+        jobs = (L.WnJob * len(self.vs))()
+        for k, (v, g) in enumerate(zip(self.vs, self.gs)):
+            rows, cols = v.shape[0], v.numel() // v.shape[0]
+            ks = v.shape[2] if v.dim() == 3 else 1
+            jobs[k] = L.WnJob(v.data_ptr(), g.data_ptr(), self._out[k].data_ptr(), self._norms[k].data_ptr(), 0, 0, 0,
+                              rows, cols, ks)
+        return jobs
+
+    def _compute(self):
+        dev = self.vs[0].device
+        _need_cuda(*self.sources)
+        shapes = [(v.shape[0], v.shape[2], v.shape[1]) if v.dim() == 3 else tuple(v.shape) for v in self.vs]
+        self._alloc(shapes, dev)
+        self._norms = [torch.empty(v.shape[0], dtype=torch.float32, device=dev) for v in self.vs]
+        assert all(v.is_contiguous() for v in self.vs)
+        jobs = self._jobs()
+        L.check(_lib().s2ag_weight_norm_multi(jobs, len(jobs), 0, _stream()), 'weight_norm_multi')
+
+    def flush(self):
+        jobs = self._jobs()
+        for k, (v, g) in enumerate(zip(self.vs, self.gs)):
+            jobs[k].dw = self._out[k].grad.data_ptr()
+            jobs[k].dv = _leaf_grad(v).data_ptr()
+            jobs[k].dg = _leaf_grad(g).data_ptr()
+        L.check(_lib().s2ag_weight_norm_multi(jobs, len(jobs), 1, _stream()), 'weight_norm_multi_flush')
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -26,6 +26,7 @@ class ParamArena:
         if dev.type != 'cuda':
             raise RuntimeError('ParamArena needs parameters on the GPU (no CPU fallback)')
         self.params: List[torch.nn.Parameter] = uniq
+        self.epoch = 0          # bumped whenever the arena's values change behind torch's back (FusedAdam.step)
         sizes = [(p.numel() + 3) // 4 * 4 for p in uniq]          # keep every view 16-byte aligned
         self.numel = sum(sizes)
         self.data = torch.zeros(self.numel, dtype=torch.float32, device=dev)
@@ -37,6 +38,7 @@ class ParamArena:
             view.copy_(p.data)
             p.data = view
             p.grad = self.grad[off:off + p.numel()].view(p.shape)
+            p._s2ag_arena = self
             self.offsets.append(off)
             off += n
 
@@ -71,6 +73,7 @@ class FusedAdam:
                                    C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
                                    a.numel, lr, self.betas[0], self.betas[1], self.eps,
                                    C.c_void_p(self.step_count.data_ptr()), float(grad_scale), s), 'adam_step')
+        a.epoch += 1            # tensors derived from these parameters (ops._DerivedGroup) are stale now
 
     def state_dict(self):
         return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, step=self.step_count, lr=self.param_groups[0]['lr'])

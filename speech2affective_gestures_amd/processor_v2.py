@@ -270,8 +270,8 @@ class Processor(object):
     def _dis_phase(self, in_text, in_mfcc, target_poses, vid_indices, pre_seq, train):
         """processor_v2.py:792-814 up to (and including) dis_error.backward().
 
-        Noise snapshots are drawn in the reference's pass order (G, D(real), D(fake)) on the main stream; D(real) then
-        runs on a forked stream beside the generator forward.  D(fake) starts after both, so D's BatchNorm running
+        Noise snapshots are drawn in the reference's pass order (G, D(real), D(fake)) on the main stream; the generator
+        forward then runs on a forked stream beside D(real).  D(fake) starts after both, so D's BatchNorm running
         statistics are still updated real-then-fake."""
         ops.set_main_stream()
         self.s2ag_dis_optimizer.zero_grad()
@@ -279,14 +279,17 @@ class Processor(object):
         nz_g, nz_real, nz_fake = noise.begin_pass(dev), noise.begin_pass(dev), noise.begin_pass(dev)
         cur = torch.cuda.current_stream()
         if self.overlap_passes:
+            # The generator forward is the long pole of this phase (D(fake) needs its output): it stays on the main
+            # stream and is issued FIRST; D(real) is issued after it on a stream forked from the phase start.
             side = self._fork(0)
+            with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
+                out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
             with torch.cuda.stream(side), noise.use_pass(nz_real), ops.sequential_branches():
                 dis_real = self.s2ag_discriminator(target_poses, in_text)
-        with torch.no_grad(), noise.use_pass(nz_g):        # upstream builds this graph and never uses it
-            out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
-        if self.overlap_passes:
             cur.wait_stream(side)
         else:
+            with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
+                out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
             with noise.use_pass(nz_real):
                 dis_real = self.s2ag_discriminator(target_poses, in_text)
         with noise.use_pass(nz_fake):
@@ -368,6 +371,7 @@ class Processor(object):
         FGD paths that are out of scope here."""
         if make_video or calculate_metrics:
             raise NotImplementedError('rendering / FGD evaluation are outside the MI355X hot path')
+        ops.begin_step()
         pre_seq = self._make_pre_seq(target_poses)
         dis_error = None
         if self._use_gan():
@@ -390,6 +394,7 @@ class Processor(object):
         use_gan = self._use_gan()
 
         def seg_dis():
+            ops.begin_step()
             out['pre'] = self._make_pre_seq(st['target'])
             out['dis'] = self._dis_phase(st['text'], st['mfcc'], st['target'], st['vid'], out['pre'], True) \
                 if use_gan else None

@@ -347,6 +347,62 @@ def test_csr_fold_and_its_transpose(S):
     assert rel(wg.grad, dense.t() @ dy) < TOL
 
 
+def test_derived_groups_cache_stage_and_flush(S):
+    """ops.FoldGroup / ops.WeightNormGroup: one-launch recompute per parameter version, shared by several forward passes,
+    gradients of all uses staged and flushed once at the end of backward == the plain autograd ops."""
+    import scipy.sparse as sp
+    ops = S['ops']
+    rs = np.random.RandomState(3)
+    g = torch.Generator().manual_seed(31)
+    Cout, Cin, k = 24, 12, 3
+    m_w = sp.random(Cout * k * Cin, 40, density=0.08, random_state=rs, format='csr', dtype=np.float64)
+    m_b = sp.random(Cout, 7, density=0.5, random_state=rs, format='csr', dtype=np.float64)
+    csr_w, csr_b = ops.CSR(m_w, 'cuda'), ops.CSR(m_b, 'cuda')
+    pw, pb = torch.randn(40, generator=g), torch.randn(7, generator=g)
+    v, gg = torch.randn(Cout, Cin, k, generator=g), torch.rand(Cout, 1, 1, generator=g) + 0.5
+    x1, x2 = torch.randn(3, 11, Cin, generator=g).cuda(), torch.randn(3, 11, Cin, generator=g).cuda()
+
+    def leaves():
+        return [t.clone().cuda().requires_grad_(True) for t in (pw, pb, v, gg)]
+    # reference: the autograd ops, two forward passes sharing the parameters
+    a = leaves()
+    wf = ops.fold(a[0], csr_w).view(Cout, k, Cin)
+    bf = ops.fold(a[1], csr_b)
+    wn = ops.weight_norm(a[2], a[3], tap_major=True)
+    ref = sum((ops.conv1d_nlc(x, wf, bf, pad=1, w_tap_major=True) * ops.conv1d_nlc(x, wn, None, pad=1, w_tap_major=True)).sum()
+              for x in (x1, x2))
+    ref.backward()
+    # derived groups
+    b = leaves()
+    fg = ops.FoldGroup([b[0], b[1]], [csr_w, csr_b], [(Cout, k, Cin), (Cout,)])
+    wg = ops.WeightNormGroup([b[2]], [b[3]])
+    outs = []
+    for x in (x1, x2):
+        f, (w2,) = fg.tensors(), wg.tensors()
+        outs.append((ops.conv1d_nlc(x, f[0], f[1], pad=1, w_tap_major=True) * ops.conv1d_nlc(x, w2, None, pad=1, w_tap_major=True)).sum())
+    f_again = fg.tensors()
+    assert f_again[0] is f[0] and wg.tensors()[0] is w2              # cached: same tensors for both passes
+    assert rel(f[0], wf) < 1e-6 and rel(f[1], bf) < 1e-6 and rel(w2, wn) < 1e-6
+    tot = outs[0] + outs[1]
+    assert rel(tot, ref) < 1e-5
+    tot.backward()                                                   # flush runs as an autograd engine callback
+    for i, name in enumerate(('fold w', 'fold b', 'weight_v', 'weight_g')):
+        assert rel(b[i].grad, a[i].grad) < TOL, name
+    assert float(f[0].grad.abs().sum()) == 0.0 and float(w2.grad.abs().sum()) == 0.0     # stages left zeroed
+    # a changed source invalidates the cache (torch version counter); a second backward accumulates into .grad
+    with torch.no_grad():
+        b[0].mul_(2.0)
+    f2 = fg.tensors()
+    assert f2[0] is not f[0] and rel(f2[0], 2 * wf) < 1e-6
+    g0 = b[1].grad.clone()
+    ops.conv1d_nlc(x1, f2[0], f2[1], pad=1, w_tap_major=True).sum().backward()
+    assert rel(b[1].grad - g0, torch.from_numpy(m_b.toarray().T).float().cuda() @ torch.full((Cout,), 33.0).cuda()) < TOL
+    # frozen sources: the derived tensors do not ask for gradients
+    for t in b:
+        t.requires_grad_(False)
+    assert not fg.tensors()[0].requires_grad and not wg.tensors()[0].requires_grad
+
+
 def test_add_act_and_transposed_slices(S):
     ops = S['ops']
     g = torch.Generator().manual_seed(14)
