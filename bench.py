@@ -67,7 +67,8 @@ def build_processor(B, hip_graph):
     meta = types.SimpleNamespace(n_poses=T, expected_audio_length=AUDIO_LEN, num_mfcc_combined=NUM_MFCC,
                                  lang_model=lang, speaker_model=Vocab(N_SPK), n_samples=0)
     args = types.SimpleNamespace(batch_size=B, train_s2ag=True, work_dir_s2ag=None, save_log=False, print_log=False,
-                                 hip_graph=hip_graph)
+                                 hip_graph=hip_graph,
+                                 overlap_passes=os.environ.get('S2AG_OVERLAP_PASSES', '1') != '0')
     pr = P.Processor(ROOT, args, make_cfg(), {'train_data_s2ag': meta, 'val_data_s2ag': meta, 'test_data_s2ag': meta},
                      POSE_DIM, 3, 16000)
     pr.meta_info['epoch'] = 1            # discriminator branch active (epoch > loss_warmup)

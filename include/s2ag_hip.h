@@ -75,8 +75,9 @@ int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* dx, const s
 
 /* dw[co,ci,tap] (+)= sum_{n,l} gy[(n,l), co] * x[(n,pos), ci]   (split over rows, fp32 atomics)
  * replaces: ConvolutionBackward / AddmmBackward (weight grad); also dW_hh of nn.GRU with x = shifted h. */
-int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw, const s2ag_conv_geom* g /*host*/,
-                               int accumulate, void* stream);
+int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw,
+                               float* dbias /*nullable: dbias[co] (+)= sum_m gy[m, co], folded into the same launch*/,
+                               const s2ag_conv_geom* g /*host*/, int accumulate, void* stream);
 
 /* out[c] (+)= sum_r x[r*ld + c]; if sq != NULL also sq[c] (+)= sum_r x^2.   (bias grads, BN batch statistics) */
 int s2ag_colsum(const float* x, int rows, int cols, int ld, float* out, float* sq /*nullable*/, int accumulate,
@@ -161,6 +162,9 @@ int s2ag_weight_norm_bwd(const float* dw, const float* v, const float* g, const 
  *   tensor, y = staged gradient of the derived tensor);  dv += ..., dg += ..., dw = 0 for weight norm.
  * The stage is a persistent buffer that the weight-gradient kernels accumulate into (accumulate = 1): it is zero
  * before the first use and every flush leaves it zero, so no clearing launch is ever needed. */
+/* diagnostics: *out = device wall clock (100 MHz ticks) when the stream reaches this point (capturable) */
+int s2ag_timestamp(unsigned long long* out, void* stream);
+
 #define S2AG_MAX_JOBS 8
 typedef struct s2ag_spmv_job {
     const int* rowptr;

@@ -38,7 +38,7 @@ SIGNATURES = {
     's2ag_abi_version': [],
     's2ag_conv1d_nlc_fwd': [vp, vp, vp, vp, PG, PE, vp],
     's2ag_conv1d_nlc_bwd_data': [vp, vp, vp, PG, ci, vp],
-    's2ag_conv1d_nlc_bwd_weight': [vp, vp, vp, PG, ci, vp],
+    's2ag_conv1d_nlc_bwd_weight': [vp, vp, vp, vp, PG, ci, vp],
     's2ag_colsum': [vp, ci, ci, ci, vp, vp, ci, vp],
     's2ag_colstats_f64': [vp, ci, ci, ci, vp, vp, vp],
     's2ag_bn_coeffs': [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp],
@@ -56,6 +56,7 @@ SIGNATURES = {
     's2ag_weight_norm_fwd': [vp, vp, ci, ci, ci, vp, vp, vp],
     's2ag_weight_norm_bwd': [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp],
     's2ag_spmv': [vp, vp, vp, vp, vp, ci, ci, vp],
+    's2ag_timestamp': [vp, vp],
     's2ag_spmv_multi': [vp, ci, ci, vp],
     's2ag_weight_norm_multi': [vp, ci, ci, vp],
     's2ag_transpose': [vp, ci, ci, vp, vp],

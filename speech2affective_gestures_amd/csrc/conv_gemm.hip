@@ -492,6 +492,7 @@ struct WgradP {
     const float* gy;
     const float* x;
     float* dw;
+    float* db;   // nullable: bias gradient, db[co] += sum_m gy[m, co] (folded into the blocks of the first column tile)
     int Mtot, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg, wtm;
     int chunk;   // rows per z-slice, multiple of BK
 };
@@ -519,6 +520,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradP p) {
     const int tapoff = tap * p.dil - p.pad;
 
     float ra[4], rb[4];
+    const bool want_db = p.db != nullptr && blockIdx.y == 0;     // the gy tile passes through this thread anyway
+    float bsum = 0.f;
     auto fetch = [&](int mb) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -535,6 +538,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradP p) {
             }
             ra[j] = a;
             rb[j] = b;
+            bsum += a;
         }
     };
 
@@ -572,6 +576,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradP p) {
             if (rowlive[1] && collive[0]) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
             if (rowlive[1] && collive[1]) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+    }
+    if (want_db) {                                    // block-uniform: the four row groups of a column meet in LDS
+        __syncthreads();
+        As[mq][cidx] = bsum;
+        __syncthreads();
+        if (mq == 0 && covalid) atomicAdd(p.db + co, As[0][cidx] + As[1][cidx] + As[2][cidx] + As[3][cidx]);
     }
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
@@ -619,6 +629,8 @@ __global__ __launch_bounds__(512) void conv_wgrad2_k(WgradP p) {
     const int tapoff = tap * p.dil - p.pad;
 
     float ra0[4], rb0[4], ra1[4], rb1[4];
+    const bool want_db = p.db != nullptr && blockIdx.y == 0;
+    float bsum = 0.f;
     auto fetch = [&](float (&ra)[4], float (&rb)[4], int mb) {
         int mm = mb + mq * 4;
         int nclip = mm / p.Lout;
@@ -635,6 +647,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_k(WgradP p) {
             }
             ra[j] = a;
             rb[j] = b;
+            bsum += a;
             if (++l == p.Lout) { l = 0; ++nclip; }
         }
     };
@@ -687,6 +700,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_k(WgradP p) {
         __syncthreads();
     }
     // merge the two wave groups through LDS so only one of them issues the (cross-block) atomics
+    if (want_db) Bs[0][mq][cidx] = bsum;              // Bs is idle after the last tile; read behind the barrier below
     {
         float* redw = &As[0][0][0];                   // 2*32*80 floats >= 64*64
         if (kg == 1) {
@@ -700,6 +714,12 @@ __global__ __launch_bounds__(512) void conv_wgrad2_k(WgradP p) {
                             acc[ti][tj][q];
         }
         __syncthreads();
+        if (want_db && mq == 0 && covalid) {          // wave 0 (kg = 0): eight row groups per column
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += Bs[0][q][cidx];
+            atomicAdd(p.db + co, t);
+        }
         if (kg == 1) return;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
@@ -886,11 +906,11 @@ extern "C" int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* 
     return 0;
 }
 
-extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw, const s2ag_conv_geom* g,
-                                          int accumulate, void* stream) {
+extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw, float* dbias,
+                                          const s2ag_conv_geom* g, int accumulate, void* stream) {
     if (bad_geom(g) || !gy || !x || !dw) return S2AG_E_BADARG;
     WgradP p{};
-    p.gy = gy; p.x = x; p.dw = dw;
+    p.gy = gy; p.x = x; p.dw = dw; p.db = dbias;
     p.Mtot = g->N * g->Lout; p.Lin = g->Lin; p.Lout = g->Lout; p.Cin = g->Cin; p.Cout = g->Cout;
     p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil; p.ldx = g->ldx; p.ldg = g->ldy;
     p.wtm = g->w_tap_major;
@@ -907,6 +927,10 @@ extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float
     if (!accumulate) {
         hipError_t me = zero_async(dw, sizeof(float) * (size_t)g->Cout * g->Cin * g->ksize, (hipStream_t)stream);
         if (me != hipSuccess) return (int)me;
+        if (dbias) {
+            me = zero_async(dbias, sizeof(float) * (size_t)g->Cout, (hipStream_t)stream);
+            if (me != hipSuccess) return (int)me;
+        }
     }
     dim3 grid(cdiv(g->Cout, BM), cdiv(g->ksize * g->Cin, BN), nsplit);
     if (v2)

@@ -510,6 +510,18 @@ extern "C" int s2ag_weight_norm_multi(const s2ag_wn_job* jobs, int njobs, int fl
     return 0;
 }
 
+// ---- device-side wall clock (100 MHz) for scheduling diagnostics inside captured graphs ------------------------
+namespace {
+__global__ void timestamp_k(unsigned long long* out) { *out = wall_clock64(); }
+}  // namespace
+
+extern "C" int s2ag_timestamp(unsigned long long* out, void* stream) {
+    if (!out) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(timestamp_k, dim3(1), dim3(1), 0, (hipStream_t)stream, out);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int s2ag_transpose(const float* src, int rows, int cols, float* dst, void* stream) {
     if (!src || !dst || rows <= 0 || cols <= 0) return S2AG_E_BADARG;
     hipLaunchKernelGGL(transpose_k, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, src, rows,

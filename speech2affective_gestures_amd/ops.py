@@ -103,14 +103,17 @@ def conv_bwd_data_raw(gy: Tensor, w: Tensor, dx: Tensor, N, Lin, Lout, Cin, Cout
 
 
 def conv_bwd_weight_raw(gy: Tensor, x: Tensor, dw: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, accumulate,
-                        wtm=0):
+                        wtm=0, dbias: Optional[Tensor] = None):
+    """dw (+)= gy^T x_windows; ``dbias`` (+)= column sums of gy in the same launch (the gy tiles pass through the
+    kernel anyway -- a separate bias-gradient reduction was 69 launches per step)."""
     gy, gr, gc, ldg = as_rows(gy)
     x, xr, xc, ldx = as_rows(x)
     assert gr == N * Lout and gc == Cout and xr == N * Lin and xc == Cin, (gr, gc, xr, xc)
     assert dw.is_contiguous() and dw.numel() == Cout * Cin * ks
+    assert dbias is None or (dbias.is_contiguous() and dbias.numel() == Cout)
     g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg, wtm)
-    L.check(_lib().s2ag_conv1d_nlc_bwd_weight(_p(gy), _p(x), _p(dw), C.byref(g), int(accumulate), _stream()),
-            'conv_bwd_weight')
+    L.check(_lib().s2ag_conv1d_nlc_bwd_weight(_p(gy), _p(x), _p(dw), _p(dbias), C.byref(g), int(accumulate),
+                                              _stream()), 'conv_bwd_weight')
 
 
 def colsum_raw(x: Tensor, out: Tensor, sq: Optional[Tensor] = None, accumulate=False):
@@ -143,6 +146,36 @@ def epilogue_bwd_raw(dy: Tensor, y: Optional[Tensor], g: Tensor, act, slope, dro
 def transpose_raw(src: Tensor, dst: Tensor):
     assert src.is_contiguous() and dst.is_contiguous() and src.dim() == 2
     L.check(_lib().s2ag_transpose(_p(src), src.shape[0], src.shape[1], _p(dst), _stream()), 'transpose')
+
+
+# ----------------------------------------------------------------------------------------------------
+# scheduling diagnostics: device wall-clock stamps that can sit inside a captured graph
+# ----------------------------------------------------------------------------------------------------
+_STAMPS = {'buf': None, 'names': []}
+TRACE_PHASES = False
+
+
+def stamp(name: str) -> None:
+    """If ops.TRACE_PHASES: record the device wall clock when the current stream reaches this point."""
+    if not TRACE_PHASES:
+        return
+    if _STAMPS['buf'] is None:
+        _STAMPS['buf'] = torch.zeros(256, dtype=torch.int64, device='cuda')
+    names = _STAMPS['names']
+    if name not in names:
+        names.append(name)
+    i = names.index(name)
+    L.check(_lib().s2ag_timestamp(C.c_void_p(_STAMPS['buf'].data_ptr() + 8 * i), _stream()), 'timestamp')
+
+
+def read_stamps():
+    """{name: microseconds since the earliest stamp} (synchronises)."""
+    if _STAMPS['buf'] is None:
+        return {}
+    torch.cuda.synchronize()
+    v = _STAMPS['buf'][:len(_STAMPS['names'])].tolist()
+    t0 = min(v)
+    return {n: (x - t0) / 100.0 for n, x in zip(_STAMPS['names'], v)}
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -244,19 +277,23 @@ class _ConvNLC(torch.autograd.Function):
             dx = dx.view(x.shape)
         wslot = _grad_slot(ctx.w_leaf) if ctx.needs_input_grad[1] else None
         bslot = _grad_slot(ctx.b_leaf) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        need_db = ctx.has_bias and ctx.needs_input_grad[2] and bslot is None
+        if need_db:
+            db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
         if ctx.needs_input_grad[1] and wslot is None:
             dw = torch.empty_like(w)
-            conv_bwd_weight_raw(g, x, dw, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False, wtm)
-        if ctx.has_bias and ctx.needs_input_grad[2] and bslot is None:
-            db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+            conv_bwd_weight_raw(g, x, dw, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False, wtm,
+                                dbias=db if need_db else None)
+        elif need_db:
             colsum_raw(g, db)
         if wslot is not None or bslot is not None:
             def leaves():
-                if wslot is not None:
-                    conv_bwd_weight_raw(g, x, wslot, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, True, wtm)
-                if bslot is not None:
+                if wslot is not None:      # the bias gradient rides along in the same launch
+                    conv_bwd_weight_raw(g, x, wslot, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, True, wtm,
+                                        dbias=bslot)
+                elif bslot is not None:
                     colsum_raw(g, bslot, accumulate=True)
-            run_wgrad(leaves, keep=(g, x))
+            run_wgrad(leaves, keep=(g, x), flops=2.0 * N * Lout * Cout * Cin * ks)
             if wslot is not None:
                 _note_staged(ctx.w_leaf)        # derived tensors (folded / weight-normed): flush when backward ends
             if bslot is not None:
@@ -830,14 +867,13 @@ class _GRU(torch.autograd.Function):
             if all(sl is not None for sl in slots) and pair_ih is not None and pair_bi is not None:
                 # arena layout: the two directions are adjacent, so dW_ih / db_ih of both are one launch each
                 def leaves(dgi=dgi, dgh=dgh, y=y, inp=inp, In=In, pair_ih=pair_ih, pair_bi=pair_bi, slots=slots):
-                    conv_bwd_weight_raw(dgi, inp, pair_ih, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1, True)
-                    colsum_raw(dgi, pair_bi.view(-1), accumulate=True)
+                    conv_bwd_weight_raw(dgi, inp, pair_ih, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1, True,
+                                        dbias=pair_bi.view(-1))
                     for d in range(2):
                         # dW_hh = sum_t dgh_t^T h_{t-1}: h_{prev} is y shifted by one frame (zero at the boundary)
                         conv_bwd_weight_raw(dgh[d], y[:, d * H:(d + 1) * H], slots[4 * d + 1], B, T, T, H, H3, 1, 1,
-                                            1 if d == 0 else -1, 1, True)
-                        colsum_raw(dgh[d], slots[4 * d + 3], accumulate=True)
-                run_wgrad(leaves, keep=(dgi, dgh, y, inp))
+                                            1 if d == 0 else -1, 1, True, dbias=slots[4 * d + 3])
+                run_wgrad(leaves, keep=(dgi, dgh, y, inp), flops=2.0 * B * T * 2 * H3 * (In + H))
             else:
                 for d, (w_ih, w_hh) in enumerate(((wih, whh), (wih_r, whh_r))):
                     gsl = dgi[:, d * H3:(d + 1) * H3]
@@ -853,13 +889,11 @@ class _GRU(torch.autograd.Function):
 
                     def leaves(gsl=gsl, dwi=dwi, dbi=dbi, dwh=dwh, dbh=dbh, d=d, direct=direct, dgh=dgh, y=y, inp=inp,
                                In=In):
-                        conv_bwd_weight_raw(gsl, inp, dwi, B * T, 1, 1, In, H3, 1, 1, 0, 1, direct)
-                        colsum_raw(gsl, dbi, accumulate=direct)
+                        conv_bwd_weight_raw(gsl, inp, dwi, B * T, 1, 1, In, H3, 1, 1, 0, 1, direct, dbias=dbi)
                         conv_bwd_weight_raw(dgh[d], y[:, d * H:(d + 1) * H], dwh, B, T, T, H, H3, 1, 1,
-                                            1 if d == 0 else -1, 1, direct)
-                        colsum_raw(dgh[d], dbh, accumulate=direct)
+                                            1 if d == 0 else -1, 1, direct, dbias=dbh)
                     if direct:       # parameter-gradient leaves: off the dx critical path
-                        run_wgrad(leaves, keep=(dgi, dgh, y, inp))
+                        run_wgrad(leaves, keep=(dgi, dgh, y, inp), flops=2.0 * B * T * 2 * H3 * (In + H))
                     else:
                         leaves()
                         grads[bd], grads[bd + 1], grads[bd + 2], grads[bd + 3] = dwi, dwh, dbi, dbh
@@ -989,13 +1023,16 @@ def set_main_stream(stream=None) -> None:
     _MAIN_STREAM[0] = stream if stream is not None else torch.cuda.current_stream()
 
 
-def run_wgrad(fn, keep=()) -> None:
+ASYNC_WGRAD_MIN_FLOPS = float(__import__('os').environ.get('S2AG_ASYNC_WGRAD_MIN_FLOPS', '3e9'))
+
+
+def run_wgrad(fn, keep=(), flops=float('inf')) -> None:
     """Launch ``fn`` (kernels that only ACCUMULATE into parameter gradients) on the weight-gradient stream if we are
     on the main stream, else inline.  Nothing downstream in the backward pass depends on them; the trainer joins the
     stream (join_side_streams) before the optimizer reads the gradient arena."""
     cur = torch.cuda.current_stream()
     main = _MAIN_STREAM[0]
-    if not ASYNC_WGRAD or main is None or cur != main:
+    if not ASYNC_WGRAD or main is None or cur != main or flops < ASYNC_WGRAD_MIN_FLOPS:
         fn()
         return
     dev = cur.device_index

@@ -274,6 +274,7 @@ class Processor(object):
         forward then runs on a forked stream beside D(real).  D(fake) starts after both, so D's BatchNorm running
         statistics are still updated real-then-fake."""
         ops.set_main_stream()
+        ops.stamp('D:start')
         self.s2ag_dis_optimizer.zero_grad()
         dev = pre_seq.device
         nz_g, nz_real, nz_fake = noise.begin_pass(dev), noise.begin_pass(dev), noise.begin_pass(dev)
@@ -282,10 +283,14 @@ class Processor(object):
             # The generator forward is the long pole of this phase (D(fake) needs its output): it stays on the main
             # stream and is issued FIRST; D(real) is issued after it on a stream forked from the phase start.
             side = self._fork(0)
+            ops.stamp('D:G(dis) begin [main]')
             with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
                 out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
+            ops.stamp('D:G(dis) end [main]')
             with torch.cuda.stream(side), noise.use_pass(nz_real), ops.sequential_branches():
+                ops.stamp('D:D(real) begin [side]')
                 dis_real = self.s2ag_discriminator(target_poses, in_text)
+                ops.stamp('D:D(real) end [side]')
             cur.wait_stream(side)
         else:
             with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
@@ -295,15 +300,18 @@ class Processor(object):
         with noise.use_pass(nz_fake):
             dis_fake = self.s2ag_discriminator(out_dir_vec.detach(), in_text)
         dis_error = ops.dis_loss(dis_real, dis_fake)
+        ops.stamp('D:D(fake) end, backward begins')
         if train:
             dis_error.backward()
         ops.join_side_streams()      # backward kernels ran on the forked streams too
+        ops.stamp('D:end')
         return dis_error.detach()
 
     def _gen_phase(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, pre_seq, train):
         """processor_v2.py:816-941 up to (and including) loss.backward()."""
         cfg = self.s2ag_config_args
         ops.set_main_stream()
+        ops.stamp('G:start')
         self.s2ag_gen_optimizer.zero_grad()
         dev = pre_seq.device
         # pass order of the reference: tri-modal baseline, G(main), D(gen), G(rand)
@@ -314,16 +322,22 @@ class Processor(object):
         if self.overlap_passes:      # the frozen baseline shares nothing with G/D: run it beside the main forward
             side0 = self._fork(0)
             with torch.cuda.stream(side0), torch.no_grad(), noise.use_pass(nz_tri), ops.sequential_branches():
+                ops.stamp('G:tri-modal begin [side0]')
                 out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
+                ops.stamp('G:tri-modal end [side0]')
         else:
             with torch.no_grad(), noise.use_pass(nz_tri):
                 out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
+        ops.stamp('G:G(main) begin [main]')
         with noise.use_pass(nz_main):
             out, z, z_mu, z_log_var = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
+        ops.stamp('G:G(main) fwd end [main]')
         if self.overlap_passes:      # G(rand) follows G(main) (BatchNorm running stats order) but runs beside D(gen)
             side1 = self._fork(1)
             with torch.cuda.stream(side1), torch.no_grad(), noise.use_pass(nz_rand), ops.sequential_branches():
+                ops.stamp('G:G(rand) begin [side1]')
                 out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, rand_vids)
+                ops.stamp('G:G(rand) end [side1]')
         # upstream lets loss.backward() also fill D's .grad, which the next D step zeroes unread;
         # skipping those weight-gradient kernels changes nothing observable
         flags = [p.requires_grad for p in self.dis_arena.params]
@@ -344,9 +358,11 @@ class Processor(object):
         w_gan = cfg.loss_gan_weight if self.meta_info['epoch'] > cfg.loss_warmup else 0.0
         total, comps = ops.gen_loss(out, dis_output, z_mu, z_log_var, target_poses, out_tri, out_rand, z, z_rand,
                                     (cfg.loss_regression_weight, w_gan, cfg.loss_reg_weight, cfg.loss_kld_weight))
+        ops.stamp('G:losses done, backward begins')
         if train:
             total.backward()
         ops.join_side_streams()
+        ops.stamp('G:end')
         return comps
 
     def _finish(self, comps, dis_error):
@@ -407,6 +423,7 @@ class Processor(object):
 
         def seg_opt():
             self.s2ag_gen_optimizer.step(self.dp.grad_scale)
+            ops.stamp('step end (G-Adam done)')
 
         between = [(lambda: self.dp.all_reduce_grads(self.dis_arena)) if (use_gan and self.dp.world_size > 1) else None,
                    (lambda: self.dp.all_reduce_grads(self.gen_arena)) if self.dp.world_size > 1 else None,
