@@ -276,9 +276,17 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
         const int c = tid + i * NT;
-        b_kq[i] = c % (BK2 / 4);
-        b_c[i] = c / (BK2 / 4);
-        b_ok[i] = (b_c[i] < 64) && (n0 + b_c[i] < p.NC);
+        if (BWD) {
+            // data gradient: the weight element of (k = co, n = ci) lies ci-contiguous, so consecutive lanes take
+            // consecutive COLUMNS (256-byte runs per k); with the forward mapping (lanes along k) every lane touched its
+            // own cache line -- the GRU input-gradient GEMM ran at 27 TFLOP/s
+            b_c[i] = c % 64;
+            b_kq[i] = c / 64;
+        } else {
+            b_kq[i] = c % (BK2 / 4);
+            b_c[i] = c / (BK2 / 4);
+        }
+        b_ok[i] = (b_c[i] < 64) && (b_kq[i] < BK2 / 4) && (n0 + b_c[i] < p.NC);
     }
 
     float ra0[CA][4], rb0[CB][4], ra1[CA][4], rb1[CB][4];   // two tiles in flight

@@ -858,6 +858,17 @@ class _GRU(torch.autograd.Function):
             else:
                 L.check(lib.s2ag_gru_seq_bwd(_p(dy), lddy, dir_stride, _p(whh2), _p(y), _p(gates), _p(dgi), _p(dgh),
                                              B, T, H, C.byref(e), _stream()), 'gru_seq_bwd')
+            # input gradient FIRST: it is the critical path (the next layer's recurrence waits for it).  The weight
+            # gradients are forked after it, so they run beside the next layer's cooperative recurrence (which leaves
+            # 96 CUs idle) instead of competing with this GEMM.
+            if l > 0 or ctx.needs_input_grad[0]:
+                dx = torch.empty(B * T, In, dtype=torch.float32, device=dev)
+                wih2 = _pair(wih, wih_r)
+                if wih2 is not None:
+                    conv_bwd_data_raw(dgi, wih2, dx, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1, False)
+                else:
+                    conv_bwd_data_raw(dgi[:, :H3], wih, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, False)
+                    conv_bwd_data_raw(dgi[:, H3:], wih_r, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, True)
             # parameter gradients
             base = 8 * l
             need = [ctx.needs_input_grad[9 + base + i] for i in range(8)]
@@ -897,15 +908,6 @@ class _GRU(torch.autograd.Function):
                     else:
                         leaves()
                         grads[bd], grads[bd + 1], grads[bd + 2], grads[bd + 3] = dwi, dwh, dbi, dbh
-            # input gradient
-            if l > 0 or ctx.needs_input_grad[0]:
-                dx = torch.empty(B * T, In, dtype=torch.float32, device=dev)
-                wih2 = _pair(wih, wih_r)
-                if wih2 is not None:
-                    conv_bwd_data_raw(dgi, wih2, dx, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1, False)
-                else:
-                    conv_bwd_data_raw(dgi[:, :H3], wih, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, False)
-                    conv_bwd_data_raw(dgi[:, H3:], wih_r, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, True)
             dy, lddy, dir_stride = dx, 2 * H, H
         dxo = dx.view(B, T, -1) if ctx.needs_input_grad[0] else None
         return (dxo, None, None, None, None, None, None, None, None, *grads)
@@ -1100,7 +1102,7 @@ class BranchStreams:
         return out
 
 
-PARALLEL_BRANCHES = False     # measured: fork/join overhead exceeds the overlap gained (20.9 vs 19.0 ms/step); kept for study
+PARALLEL_BRANCHES = __import__('os').environ.get('S2AG_PARALLEL_BRANCHES', '0') == '1'     # measured: fork/join overhead exceeds the overlap gained (20.9 vs 19.0 ms/step); kept for study
 _NO_BRANCH_DEPTH = [0]
 
 
