@@ -106,9 +106,11 @@ int s2ag_bn_coeffs(const double* colsum, const double* colsq, const int* chan_of
 int s2ag_bn_partial_rows(int rows, int cols, int ld);
 int s2ag_bn_fwd_stats(const float* x, int rows, int cols, int ldx, const int* chan_of_col /*nullable*/, int nchan,
                       const float* gamma, const float* beta, float* running_mean, float* running_var,
-                      long long* num_batches_tracked /*nullable*/, float eps, float momentum, double* partials,
-                      int* ticket, float* scale_col, float* shift_col, float* mean_col, float* invstd_col,
-                      void* stream);
+                      long long* num_batches_tracked /*nullable*/, float eps, float momentum,
+                      int repeat /* >= 1: advance the running estimates (and the batch counter) this many times -- the
+                                    forward passes of one step that see the same input and weights share one launch */,
+                      double* partials, int* ticket, float* scale_col, float* shift_col, float* mean_col,
+                      float* invstd_col, void* stream);
 /* backward stages (1)+(2) below in one launch; `partials`: 2 * s2ag_bn_partial_rows * cols floats */
 int s2ag_bn_bwd_stats(const float* x, const float* dy, int rows, int cols, int ldx, int lddy, const float* scale_col,
                       const float* shift_col, const float* mean_col, const float* invstd_col, float slope,

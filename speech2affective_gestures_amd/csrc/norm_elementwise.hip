@@ -94,7 +94,7 @@ __device__ __forceinline__ void bn_finish_coeffs(double* cs, double* cq, const d
                                                  int ncols, int nchan, int rows, const float* gamma, const float* beta,
                                                  float* rmean, float* rvar, long long* nbt, float eps, float momentum,
                                                  int training, float* scale_col, float* shift_col, float* mean_col,
-                                                 float* invstd_col) {
+                                                 float* invstd_col, int repeat = 1) {
     if (training) {
         for (int ch = threadIdx.x; ch < nchan; ch += blockDim.x) {
             const double n = cn[ch] * (double)rows;
@@ -102,12 +102,19 @@ __device__ __forceinline__ void bn_finish_coeffs(double* cs, double* cq, const d
             double var = cq[ch] / n - mean * mean;      // fp64: safe against cancellation
             var = var < 0.0 ? 0.0 : var;
             const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-            rmean[ch] = (float)((1.0 - (double)momentum) * (double)rmean[ch] + (double)momentum * mean);
-            rvar[ch] = (float)((1.0 - (double)momentum) * (double)rvar[ch] + (double)momentum * unbiased);
+            // `repeat` forward passes of one step saw this very batch (same input, same weights): one statistics pass,
+            // the running estimates advance once per pass, rounded to fp32 each time exactly as separate passes would
+            float rm = rmean[ch], rv = rvar[ch];
+            for (int it = 0; it < repeat; ++it) {
+                rm = (float)((1.0 - (double)momentum) * (double)rm + (double)momentum * mean);
+                rv = (float)((1.0 - (double)momentum) * (double)rv + (double)momentum * unbiased);
+            }
+            rmean[ch] = rm;
+            rvar[ch] = rv;
             cs[ch] = mean;
             cq[ch] = 1.0 / sqrt(var + (double)eps);
         }
-        if (threadIdx.x == 0 && nbt) *nbt += 1;
+        if (threadIdx.x == 0 && nbt) *nbt += repeat;
     } else {
         for (int ch = threadIdx.x; ch < nchan; ch += blockDim.x) {
             cs[ch] = (double)rmean[ch];
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_stats_k(const float* __restrict__ x
                                                       const float* gamma, const float* beta, float* rmean,
                                                       float* rvar, long long* nbt, float eps, float momentum,
                                                       float* scale_col, float* shift_col, float* mean_col,
-                                                      float* invstd_col) {
+                                                      float* invstd_col, int repeat) {
     extern __shared__ double smd[];           // 3 * nchan doubles (finalising block)
     constexpr int RL = NT / 64;               // row lanes of the column-per-lane walk
     __shared__ double s1[RL][64], s2[RL][64];
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_stats_k(const float* __restrict__ x
     fold_partials<double, double, NT>(part, nrb, cols, chan_of_col, cs, cq, cn);
     __syncthreads();
     bn_finish_coeffs(cs, cq, cn, chan_of_col, cols, nchan, rows, gamma, beta, rmean, rvar, nbt, eps, momentum, 1,
-                     scale_col, shift_col, mean_col, invstd_col);
+                     scale_col, shift_col, mean_col, invstd_col, repeat);
 }
 
 __global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, int rows, int cols, int ldx,
@@ -537,8 +544,9 @@ extern "C" int s2ag_bn_partial_rows(int rows, int cols, int ld) {
 
 extern "C" int s2ag_bn_fwd_stats(const float* x, int rows, int cols, int ldx, const int* chan_of_col, int nchan,
                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                 long long* nbt, float eps, float momentum, double* partials, int* ticket,
+                                 long long* nbt, float eps, float momentum, int repeat, double* partials, int* ticket,
                                  float* scale_col, float* shift_col, float* mean_col, float* invstd_col, void* stream) {
+    if (repeat < 1) return S2AG_E_BADARG;
     if (!x || rows <= 0 || cols <= 0 || ldx < cols || nchan <= 0 || !gamma || !beta || !running_mean || !running_var ||
         !partials || !ticket || !scale_col || !shift_col || !mean_col || !invstd_col)
         return S2AG_E_BADARG;
@@ -549,11 +557,11 @@ extern "C" int s2ag_bn_fwd_stats(const float* x, int rows, int cols, int ldx, co
     if (flat)
         hipLaunchKernelGGL((bn_fwd_stats_k<true, 256>), dim3(cb, nrb), dim3(256), smem, (hipStream_t)stream, x, rows, cols, ldx,
                            rpb, partials, ticket, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt, eps,
-                           momentum, scale_col, shift_col, mean_col, invstd_col);
+                           momentum, scale_col, shift_col, mean_col, invstd_col, repeat);
     else
         hipLaunchKernelGGL((bn_fwd_stats_k<false, 1024>), dim3(cb, nrb), dim3(1024), smem, (hipStream_t)stream, x, rows, cols,
                            ldx, rpb, partials, ticket, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt,
-                           eps, momentum, scale_col, shift_col, mean_col, invstd_col);
+                           eps, momentum, scale_col, shift_col, mean_col, invstd_col, repeat);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -397,13 +397,41 @@ class PoseGenerator(nn.Module, _SpeakerZ):
     def _make_audio_encoder(self, mfcc_length, num_mfcc, time_steps):
         return MFCCEncoder(mfcc_length, num_mfcc, time_steps)
 
+    # The trainer runs this generator three times per step on the SAME (pre_seq, in_mfcc) with the same weights
+    # (processor_v2.py:792-941: for D, for the loss, with shuffled speakers).  The pose and audio encoders have no
+    # dropout, so all three passes compute identical tensors there: ``share_passes = k`` (set by the trainer, None =
+    # off) runs them once per step -- with autograd on, because the loss pass back-propagates through them -- and lets
+    # their BatchNorm running statistics advance k times (ops.bn_repeat), exactly as k separate passes would.
+    share_passes = None
+
+    def _shared_encoders(self, pre_seq, in_mfcc):
+        k = self.share_passes
+        if not k or self.input_context == 'none':
+            return None
+        key = (ops.generation(), pre_seq.data_ptr(), in_mfcc.data_ptr(), self.training, int(k))
+        if getattr(self, '_shared', None) is None or self._shared[0] != key:
+            with torch.set_grad_enabled(self.training), ops.bn_repeat(k if self.training else 1):
+                pre = self.aff_encoder(pre_seq[..., :-1])
+                audio = self.audio_encoder(in_mfcc)
+            self._shared = (key, pre, audio)
+        _, pre, audio = self._shared
+        if not torch.is_grad_enabled():
+            pre, audio = pre.detach(), audio.detach()
+        return pre, audio
+
     def forward(self, pre_seq, in_text, in_mfcc, vid_indices=None):
         with noise_pass(pre_seq.device) as nz:
             audio = text = None
             # four independent encoder branches -> four streams (joined before the concat that feeds the GRU)
-            fns = [lambda: self.aff_encoder(pre_seq[..., :-1]), lambda: self._z(in_text, vid_indices, nz)]
-            if self.input_context != 'none':
-                fns += [lambda: self.text_encoder(in_text)[0], lambda: self.audio_encoder(in_mfcc)]
+            shared = self._shared_encoders(pre_seq, in_mfcc)
+            if shared is not None:       # pose + audio encoders of this step already exist (or were just made)
+                fns = [lambda: shared[0], lambda: self._z(in_text, vid_indices, nz)]
+                if self.input_context != 'none':
+                    fns += [lambda: self.text_encoder(in_text)[0], lambda: shared[1]]
+            else:
+                fns = [lambda: self.aff_encoder(pre_seq[..., :-1]), lambda: self._z(in_text, vid_indices, nz)]
+                if self.input_context != 'none':
+                    fns += [lambda: self.text_encoder(in_text)[0], lambda: self.audio_encoder(in_mfcc)]
             res = self._branches.run(fns, pre_seq.device, ops.PARALLEL_BRANCHES)
             pre, (z_context, z_mu, z_log_var) = res[0], res[1]
             if self.input_context != 'none':

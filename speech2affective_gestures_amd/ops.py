@@ -331,6 +331,29 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor], act=L.ACT_NONE, slope=1
 # ----------------------------------------------------------------------------------------------------
 # batch norm (+ leaky activation)
 # ----------------------------------------------------------------------------------------------------
+_BN_REPEAT = [1]
+
+
+class bn_repeat:
+    """Context: training-mode BatchNorms inside advance their running estimates ``k`` times.  Used where ``k`` forward
+    passes of one step would see the very same batch (same input, same weights): the sub-network runs once and the
+    running statistics end up exactly where ``k`` separate passes leave them."""
+
+    def __init__(self, k: int):
+        self.k = int(k)
+
+    def __enter__(self):
+        self.prev = _BN_REPEAT[0]
+        _BN_REPEAT[0] = self.k
+
+    def __exit__(self, *a):
+        _BN_REPEAT[0] = self.prev
+
+
+def generation() -> int:
+    return _GENERATION[0]
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, nbt, chan_map, slope, training, eps, momentum):
@@ -346,7 +369,8 @@ class _BNAct(torch.autograd.Function):
             nrb = lib.s2ag_bn_partial_rows(rows, cols, ldx)
             part = torch.empty(2 * nrb * cols, dtype=torch.float64, device=dev)
             L.check(lib.s2ag_bn_fwd_stats(_p(x), rows, cols, ldx, _p(chan_map), nchan, _p(gamma), _p(beta), _p(rmean),
-                                          _p(rvar), _p(nbt), float(eps), float(momentum), _p(part), _ticket(dev),
+                                          _p(rvar), _p(nbt), float(eps), float(momentum), int(_BN_REPEAT[0]), _p(part),
+                                          _ticket(dev),
                                           _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _stream()),
                     'bn_fwd_stats')
         else:

@@ -197,6 +197,8 @@ class Processor(object):
         self.use_hip_graph = bool(getattr(args, 'hip_graph', True))
         # independent forward passes of a step run on forked streams (every kernel here fills only part of the chip)
         self.overlap_passes = bool(getattr(args, 'overlap_passes', True))
+        # the generator's dropout-free encoders run once per step instead of once per pass (see PoseGenerator)
+        self.share_encoders = bool(getattr(args, 'share_encoders', True))
         self._side = [torch.cuda.Stream(device=self.device) for _ in range(2)]
         self._graphed = None
         self.last_losses = {}
@@ -388,6 +390,7 @@ class Processor(object):
         if make_video or calculate_metrics:
             raise NotImplementedError('rendering / FGD evaluation are outside the MI355X hot path')
         ops.begin_step()
+        self.s2ag_generator.share_passes = (3 if self._use_gan() else 2) if self.share_encoders else None
         pre_seq = self._make_pre_seq(target_poses)
         dis_error = None
         if self._use_gan():
@@ -411,6 +414,7 @@ class Processor(object):
 
         def seg_dis():
             ops.begin_step()
+            self.s2ag_generator.share_passes = (3 if use_gan else 2) if self.share_encoders else None
             out['pre'] = self._make_pre_seq(st['target'])
             out['dis'] = self._dis_phase(st['text'], st['mfcc'], st['target'], st['vid'], out['pre'], True) \
                 if use_gan else None

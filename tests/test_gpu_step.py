@@ -26,14 +26,14 @@ def rel(a, b):
     return float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
 
 
-def make_processor(hidden, n_words, n_spk, B, seed0, drop, hip_graph=False):
+def make_processor(hidden, n_words, n_spk, B, seed0, drop, hip_graph=False, **extra):
     from speech2affective_gestures_amd import processor_v2 as P
     cfg = make_cfg(hidden, drop)
     lang = types.SimpleNamespace(n_words=n_words, word_embedding_weights=None)
     meta = types.SimpleNamespace(n_poses=34, expected_audio_length=36267, num_mfcc_combined=37, lang_model=lang,
                                  speaker_model=Vocab(n_spk), n_samples=0)
     args = types.SimpleNamespace(batch_size=B, train_s2ag=True, work_dir_s2ag=None, save_log=False, print_log=False,
-                                 hip_graph=hip_graph)
+                                 hip_graph=hip_graph, **extra)
     pr = P.Processor('.', args, cfg, {'train_data_s2ag': meta, 'val_data_s2ag': meta, 'test_data_s2ag': meta}, 27, 3,
                      16000)
     sds = recipe_sds(hidden, n_words, n_spk, seed0)
@@ -197,3 +197,42 @@ def test_hip_graph_replay_equals_eager(monkeypatch):
         if not k.endswith('num_batches_tracked') and not is_noise_driven_after_adam(k):
             ok, info = adam_close(sd_g[k], sd_e[k], 5e-4, 3) if 'running' not in k else (rel(sd_g[k], sd_e[k]) < 3e-4, None)
             assert ok, (k, info)
+
+
+def test_shared_encoder_pass_equals_three_separate_passes(monkeypatch):
+    """The dropout-free pose / audio encoders run once per step for the generator's three forward passes
+    (PoseGenerator.share_passes): losses, weights and -- the point of ops.bn_repeat -- the BatchNorm running statistics
+    and batch counters end up where three separate passes leave them."""
+    from speech2affective_gestures_amd import noise
+    from speech2affective_gestures_amd import processor_v2 as P
+    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 6, 7000
+    perm = torch.tensor([3, 0, 5, 1, 2, 4]).cuda()
+    monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm)
+    batches = [to_cuda(O.recipe_inputs(B, 34, s0 + 50 + s, n_words, n_spk)) for s in range(2)]
+
+    def run(share):
+        noise.reset_sites(100)
+        pr, _ = make_processor(hidden, n_words, n_spk, B, s0, 0.3, share_encoders=share)
+        noise.manual_seed(STEP_SEED)
+        losses, states = [], []
+        for b in batches:
+            pr.train_step(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'])
+            losses.append(dict(pr.last_losses))
+            states.append({k: v.clone() for k, v in pr.s2ag_generator.state_dict().items()})
+        return losses, states
+    l1, st1 = run(True)
+    l0, st0 = run(False)
+    for a, b in zip(l1, l0):
+        for k in a:
+            assert a[k] == pytest.approx(b[k], rel=1e-4, abs=1e-6), k
+    for step, (sd1, sd0) in enumerate(zip(st1, st0)):
+        for k in sd0:
+            shared = 'aff_encoder' in k or 'audio_encoder' in k
+            if k.endswith('num_batches_tracked'):
+                assert int(sd1[k]) == int(sd0[k]) == 3 * (step + 1), k
+            elif k.endswith('running_var') or (k.endswith('running_mean') and step == 0):
+                # (running means follow Adam's random walk of the dead conv biases from the second step on)
+                assert rel(sd1[k], sd0[k]) < (2e-6 if step == 0 else 1e-4), (step, k, shared)
+            elif not is_noise_driven_after_adam(k):
+                ok, info = adam_close(sd1[k], sd0[k], 5e-4, step + 1)
+                assert ok, (step, k, info)
