@@ -88,6 +88,10 @@ class _Log:
         pass
 
 
+PASSES_PER_STEP = 7      # forward passes (= noise snapshots) of one GAN step, in the reference's order: G(dis), D(real),
+                         # D(fake), tri-modal baseline, G(main), D(gen), G(rand)
+
+
 class _GraphSegments:
     """Capture ``fns`` as consecutive HIP graphs sharing one memory pool; ``between[i]`` runs eagerly after
     segment i (the RCCL all-reduces).  Static shapes; inputs are copied into the buffers captured."""
@@ -276,6 +280,7 @@ class Processor(object):
         forward then runs on a forked stream beside D(real).  D(fake) starts after both, so D's BatchNorm running
         statistics are still updated real-then-fake."""
         ops.set_main_stream()
+        self._early_rand = None
         ops.stamp('D:start')
         self.s2ag_dis_optimizer.zero_grad()
         dev = pre_seq.device
@@ -294,6 +299,22 @@ class Processor(object):
                 dis_real = self.s2ag_discriminator(target_poses, in_text)
                 ops.stamp('D:D(real) end [side]')
             cur.wait_stream(side)
+            if self.s2ag_generator.share_passes:
+                # The generator's third forward (shuffled speakers, no_grad) depends on nothing the D step changes, and
+                # with the pose/audio encoders shared it contains no BatchNorm (no ordering of running statistics): it
+                # runs HERE, beside D(fake) and D's backward (small kernels that leave most CUs idle), instead of on
+                # the critical path of the generator phase.  Its noise is that of pass 7 of the step, as upstream.
+                nz_rand = nz_g.clone()
+                nz_rand[1] += PASSES_PER_STEP - 1
+                rand_vids = vid_indices[torch.randperm(vid_indices.shape[0], device=vid_indices.device)]
+                side1 = self._fork(1)
+                with torch.cuda.stream(side1), torch.no_grad(), noise.use_pass(nz_rand), ops.sequential_branches():
+                    ops.stamp('D:G(rand) begin [side1]')
+                    out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, rand_vids)
+                    ops.stamp('D:G(rand) end [side1]')
+                out_rand.record_stream(cur)
+                z_rand.record_stream(cur)
+                self._early_rand = (out_rand, z_rand)
         else:
             with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
                 out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
@@ -318,8 +339,11 @@ class Processor(object):
         dev = pre_seq.device
         # pass order of the reference: tri-modal baseline, G(main), D(gen), G(rand)
         nz_tri, nz_main, nz_dgen, nz_rand = (noise.begin_pass(dev) for _ in range(4))
-        rand_idx = torch.randperm(vid_indices.shape[0], device=vid_indices.device)
-        rand_vids = vid_indices[rand_idx]
+        early = getattr(self, '_early_rand', None)        # G(rand) already ran beside the D step (see _dis_phase)
+        self._early_rand = None
+        if early is None:
+            rand_idx = torch.randperm(vid_indices.shape[0], device=vid_indices.device)
+            rand_vids = vid_indices[rand_idx]
         cur = torch.cuda.current_stream()
         if self.overlap_passes:      # the frozen baseline shares nothing with G/D: run it beside the main forward
             side0 = self._fork(0)
@@ -334,7 +358,9 @@ class Processor(object):
         with noise.use_pass(nz_main):
             out, z, z_mu, z_log_var = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
         ops.stamp('G:G(main) fwd end [main]')
-        if self.overlap_passes:      # G(rand) follows G(main) (BatchNorm running stats order) but runs beside D(gen)
+        if early is not None:
+            out_rand, z_rand = early
+        elif self.overlap_passes:    # G(rand) follows G(main) (BatchNorm running stats order) but runs beside D(gen)
             side1 = self._fork(1)
             with torch.cuda.stream(side1), torch.no_grad(), noise.use_pass(nz_rand), ops.sequential_branches():
                 ops.stamp('G:G(rand) begin [side1]')
@@ -353,8 +379,9 @@ class Processor(object):
                 p.requires_grad_(f)
         if self.overlap_passes:
             cur.wait_stream(side0)
-            cur.wait_stream(side1)
-        else:
+            if early is None:
+                cur.wait_stream(side1)
+        elif early is None:
             with torch.no_grad(), noise.use_pass(nz_rand):
                 out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, rand_vids)
         w_gan = cfg.loss_gan_weight if self.meta_info['epoch'] > cfg.loss_warmup else 0.0
