@@ -203,6 +203,20 @@ constexpr int BK2 = 32;
 // 4*80 = 0 mod 32 -- LDS writes, not MFMA, bounded the first version.)
 constexpr int PK = BK2 + 2;
 
+// cycle accounting of one block for tools/diag_gemm_trace.py (compiled only with -DS2AG_GEMM_TRACE)
+#ifdef S2AG_GEMM_TRACE
+__device__ unsigned long long g_gemm_trace[8];
+#define GEMM_TR_BEGIN() const unsigned long long tr0__ = clock64()
+#define GEMM_TR_ADD(slot)                                                                      \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                              \
+        const unsigned long long t__ = clock64();                                               \
+        g_gemm_trace[slot] += t__ - trl__;                                                      \
+        trl__ = t__;                                                                            \
+    }
+#else
+#define GEMM_TR_ADD(slot)
+#endif
+
 template <bool BWD, bool VEC, int BM_, int WM, int WN, int KG>
 __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
     constexpr int NT = 64 * WM * WN * KG;
@@ -303,17 +317,33 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
         b_cc[i] = b_kq[i] * 4 - b_tap[i] * p.CK;
     }
     const bool b_contig = (!BWD) && VEC && (p.ks == 1 || p.wtm) && ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0);
+    const bool b_lin_bwd = BWD && p.ks == 1 && !rs;     // data gradient of a Linear / GRU projection: w[k = co][n = ci]
+    // Operand pointers are carried from tile to tile (+= BK2 per tile) and re-derived only when a chunk crosses into the
+    // next tap: computing (row, position, channel) -> address from scratch for every chunk of every tile was a third
+    // of the block's cycles (tools/diag_gemm_trace.py: "load issue" 31-46 %).
+    const float* a_ptr[CA];
+    auto a_setup = [&](int i) {
+        int pos;
+        a_ptr[i] = (a_ok[i] && src_pos<BWD>(p, a_l[i], a_tap[i], pos)) ? p.a + (a_row0[i] + pos) * p.lda + a_c[i]
+                                                                        : nullptr;
+    };
+    const float* b_ptr[CB];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) a_setup(i);
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const long long col = n0 + b_c[i];
+        b_ptr[i] = !b_ok[i] ? nullptr
+                            : (b_contig ? p.w + col * p.K + b_kq[i] * 4
+                                        : (b_lin_bwd ? p.w + (long long)(b_kq[i] * 4) * p.Cin + col : p.w));
+    }
     auto fetch = [&](float (&ra)[CA][4], float (&rb)[CB][4], int k0) {   // call with k0 = 0, BK2, 2*BK2, ... in order
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
             const int kk0 = k0 + a_kq[i] * 4;
             if (VEC) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a_ok[i] && kk0 < p.K) {
-                    int pos;
-                    if (src_pos<BWD>(p, a_l[i], a_tap[i], pos))
-                        v = *reinterpret_cast<const float4*>(p.a + (a_row0[i] + pos) * p.lda + a_c[i]);
-                }
+                if (a_ptr[i] && kk0 < p.K) v = *reinterpret_cast<const float4*>(a_ptr[i]);
                 ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
             } else {
                 int tap = a_tap[i], c = a_c[i];
@@ -329,7 +359,12 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
                 }
             }
             a_c[i] += BK2;
-            while (a_c[i] >= p.CK) { a_c[i] -= p.CK; ++a_tap[i]; }
+            if (a_c[i] >= p.CK) {
+                do { a_c[i] -= p.CK; ++a_tap[i]; } while (a_c[i] >= p.CK);
+                if (VEC) a_setup(i);
+            } else if (VEC && a_ptr[i]) {
+                a_ptr[i] += BK2;
+            }
         }
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
@@ -337,8 +372,14 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
             const int col = n0 + b_c[i];
             if (b_contig) {             // Linear / GRU projection: the weight row is K-contiguous -> one 16-byte load
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b_ok[i] && kk0 < p.K) v = *reinterpret_cast<const float4*>(p.w + (long long)col * p.K + kk0);
+                if (b_ptr[i] && kk0 < p.K) v = *reinterpret_cast<const float4*>(b_ptr[i]);
                 rb[i][0] = v.x; rb[i][1] = v.y; rb[i][2] = v.z; rb[i][3] = v.w;
+                if (b_ptr[i]) b_ptr[i] += BK2;
+            } else if (b_lin_bwd) {     // four k rows of W, lanes along the contiguous input-channel axis
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    rb[i][j] = (b_ptr[i] && kk0 + j < p.K) ? b_ptr[i][(long long)j * p.Cin] : 0.f;
+                if (b_ptr[i]) b_ptr[i] += (long long)BK2 * p.Cin;
             } else {
                 int tap = b_tap[i], c = b_cc[i];
 #pragma unroll
@@ -412,20 +453,32 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
     };
     // software pipeline, two tiles deep: tile kt+2 is requested while tile kt is multiplied and tile kt+1 (requested
     // one iteration earlier, so it has had a full iteration to land) is moved from registers into the idle LDS buffer
+#ifdef S2AG_GEMM_TRACE
+    unsigned long long trl__ = clock64();
+#endif
     fetch(ra0, rb0, 0);
     stash(ra0, rb0, 0);
     if (nkt > 1) fetch(ra0, rb0, BK2);
     __syncthreads();
+    GEMM_TR_ADD(0);                                   // prologue
     for (int kt = 0; kt < nkt; kt += 2) {
         if (kt + 2 < nkt) fetch(ra1, rb1, (kt + 2) * BK2);
+        GEMM_TR_ADD(1);                               // issue of the global loads
         mma(0);
+        GEMM_TR_ADD(2);                               // LDS reads + MFMAs
         if (kt + 1 < nkt) stash(ra0, rb0, 1);
+        GEMM_TR_ADD(3);                               // wait for the tile in flight + LDS stores
         __syncthreads();
+        GEMM_TR_ADD(4);                               // barrier
         if (kt + 1 >= nkt) break;
         if (kt + 3 < nkt) fetch(ra0, rb0, (kt + 3) * BK2);
+        GEMM_TR_ADD(1);
         mma(1);
+        GEMM_TR_ADD(2);
         if (kt + 2 < nkt) stash(ra1, rb1, 0);
+        GEMM_TR_ADD(3);
         __syncthreads();
+        GEMM_TR_ADD(4);
     }
 
     if (KG == 2) {       // sum the two K halves: group 1 parks its accumulators in LDS, group 0 finishes
@@ -477,6 +530,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_gemm2_k(GemmP p) {
                 }
             }
         }
+    GEMM_TR_ADD(5);                                   // K-group merge + epilogue
 }
 
 template <bool BWD, bool VEC>
@@ -1002,3 +1056,14 @@ extern "C" int s2ag_colstats_f64(const float* x, int rows, int cols, int ld, dou
     S2AG_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef S2AG_GEMM_TRACE
+extern "C" int s2ag_gemm_trace_read(unsigned long long* host8, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 8);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
