@@ -914,6 +914,13 @@ bool bad_geom(const s2ag_conv_geom* g) {
 }
 }  // namespace
 
+// gemm_lin.hip
+int s2ag_gemm_lin_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int ldx, int ldy,
+                      int act, float slope, float drop_p, const unsigned long long* rng, unsigned site,
+                      hipStream_t stream);
+int s2ag_gemm_lin_bwd_data(const float* gy, const float* w, float* dx, int M, int Cout, int Cin, int ldg, int ldx,
+                           int accumulate, hipStream_t stream);
+
 extern "C" int s2ag_abi_version(void) { return S2AG_ABI_VERSION; }
 
 extern "C" int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* bias, float* y,
@@ -934,6 +941,13 @@ extern "C" int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* 
     p.rng = e ? e->rng : nullptr;
     p.site = e ? e->site : 0;
     p.accumulate = 0;
+    // 1-tap layers (Linear, GRU projections, 1x1 convs): the straight-line kernel of gemm_lin.hip
+    if (g->ksize == 1 && g->stride == 1 && g->pad == 0 && g->Lin == g->Lout &&
+        s2ag_gemm_lin_fwd(x, w, bias, y, p.M, g->Cin, g->Cout, g->ldx, g->ldy, p.act, p.slope, p.drop_p, p.rng, p.site,
+                          (hipStream_t)stream)) {
+        S2AG_LAUNCH_CHECK();
+        return 0;
+    }
     const bool vec = (g->Cin % 4 == 0) && (g->ldx % 4 == 0) && aligned16(x);
     if (vec)
         launch_gemm2<false, true>(p, (hipStream_t)stream);
@@ -952,6 +966,11 @@ extern "C" int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* 
     p.Lr = g->Lin; p.Lsrc = g->Lout; p.CK = g->Cout; p.Cin = g->Cin;
     p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
     p.lda = g->ldy; p.ldo = g->ldx; p.wtm = g->w_tap_major;
+    if (g->ksize == 1 && g->stride == 1 && g->pad == 0 && g->Lin == g->Lout &&
+        s2ag_gemm_lin_bwd_data(gy, w, dx, p.M, g->Cout, g->Cin, g->ldy, g->ldx, accumulate, (hipStream_t)stream)) {
+        S2AG_LAUNCH_CHECK();
+        return 0;
+    }
     if (g->stride > 1 && g->dil == 1 && g->pad >= 0) {      // residue mode: contract over ceil(k/stride) tap slots
         p.rs = 1;
         p.rs_lq = cdiv(g->Lin, g->stride);

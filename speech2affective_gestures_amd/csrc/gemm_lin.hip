@@ -1,0 +1,234 @@
+// Straight-line fp32-MFMA GEMM for the 1-tap layers (Linear, GRU input projections, 1x1 convs):
+//   fwd  out[m, n] = act( sum_k a[m, k] * w[n, k] + bias[n] ) (x dropout)        a = x,  w = (N, K) row-major
+//   bwd  out[m, n] (+)= sum_k a[m, k] * w[k, n]                                   a = gy, w = (K, N) row-major
+//
+// Same tiling and pipeline as conv_gemm2_k (conv_gemm.hip): BM x 64 block tile, K step 32, double-buffered row-major
+// LDS with a 34-float pitch, two K tiles in flight in registers, 8 waves with a 2-way in-block K split.  What differs is
+// what is NOT there: the general kernel resolves (tap, position, channel), padding, residue mode, weight layouts and
+// dead-tile tests at run time inside the K loop -- hardware counters showed 14 vector-ALU and 8 scalar instructions per
+// MFMA (SQ_INSTS_VALU / SQ_INSTS_MFMA), i.e. the loop was bound by instruction issue, not by the matrix pipe or memory.
+// Here every operand chunk is one pointer that advances by a constant per tile, the only predicate in the loop is the
+// K tail, and every MFMA is unconditional (rows / columns outside the matrix are zero in LDS; the epilogue masks them).
+// Requirements (checked by the host, else the general kernel runs): K % 4 == 0, lda % 4 == 0, 16-byte aligned a and w,
+// and for bwd N-contiguous W rows.
+#include "s2ag_common.h"
+
+namespace {
+using namespace s2ag;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int LBK = 32;          // K step
+constexpr int LPK = LBK + 2;     // LDS row pitch (see conv_gemm.hip)
+
+struct LinP {
+    const float* a;
+    const float* w;
+    const float* bias;
+    float* out;
+    int M, K, N;
+    int lda, ldo, ldw;           // ldw: fwd = K (row n of W), bwd = N (row k of W)
+    int act;
+    float slope, drop_p, inv_keep;
+    const unsigned long long* rng;
+    unsigned site;
+    int accumulate;
+};
+
+template <bool BWD, int BM_>
+__global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
+    constexpr int NT = 512;
+    constexpr int WM = 2, WN = 2, KG = 2;
+    constexpr int TM = BM_ / (16 * WM), TN = 64 / (16 * WN);
+    constexpr int CA = (BM_ * (LBK / 4)) / NT;                    // float4 chunks of A per thread (1 at BM=64)
+    constexpr int KSG = (LBK / 4) / KG;
+    static_assert(BM_ == 64 || BM_ == 32, "row tile");
+    __shared__ __attribute__((aligned(16))) float As[2][BM_][LPK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][64][LPK];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave / (WM * WN), wr = (wave % (WM * WN)) / WN, wc = wave % WN;
+    const int m0 = blockIdx.x * BM_, n0 = blockIdx.y * 64;
+
+    // ---- loader coordinates: A chunk = (row a_r, k quad a_kq); at BM = 32 only the first 256 threads carry one
+    const bool has_a = CA > 0 || tid < BM_ * (LBK / 4);
+    const int a_kq = tid % (LBK / 4), a_r = tid / (LBK / 4);
+    const float* a_ptr = (has_a && m0 + a_r < p.M) ? p.a + (long long)(m0 + a_r) * p.lda + a_kq * 4 : nullptr;
+    // B chunk: fwd = (col b_c, k quad b_kq) one float4 along k;  bwd = (col b_c, k quad b_kq) four k rows of W
+    int b_c, b_kq;
+    if (BWD) {
+        b_c = tid % 64;          // lanes along the contiguous N axis of W
+        b_kq = tid / 64;
+    } else {
+        b_kq = tid % (LBK / 4);
+        b_c = tid / (LBK / 4);
+    }
+    const bool b_ok = n0 + b_c < p.N;
+    const float* b_ptr = !b_ok ? nullptr
+                               : (BWD ? p.w + (long long)(b_kq * 4) * p.ldw + n0 + b_c
+                                      : p.w + (long long)(n0 + b_c) * p.ldw + b_kq * 4);
+    const long long b_step = BWD ? (long long)LBK * p.ldw : LBK;
+
+    float4 ra0, rb0, ra1, rb1;
+    auto fetch = [&](float4& ra, float4& rb, int k0) {
+        const int ka = k0 + a_kq * 4, kb = k0 + b_kq * 4;
+        ra = make_float4(0.f, 0.f, 0.f, 0.f);
+        rb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a_ptr && ka < p.K) ra = *reinterpret_cast<const float4*>(a_ptr + k0);
+        if (BWD) {
+            if (b_ptr) {
+                const float* q = b_ptr + (long long)(k0 / LBK) * b_step;
+                if (kb < p.K) rb.x = q[0];
+                if (kb + 1 < p.K) rb.y = q[p.ldw];
+                if (kb + 2 < p.K) rb.z = q[2 * (long long)p.ldw];
+                if (kb + 3 < p.K) rb.w = q[3 * (long long)p.ldw];
+            }
+        } else {
+            if (b_ptr && kb < p.K) rb = *reinterpret_cast<const float4*>(b_ptr + k0);
+        }
+    };
+    float* const a_dst = &As[0][has_a ? a_r : 0][a_kq * 4];
+    float* const b_dst = &Bs[0][b_c][b_kq * 4];
+    auto stash = [&](const float4& ra, const float4& rb, int buf) {
+        if (has_a) {
+            float* d = a_dst + buf * (BM_ * LPK);
+            *reinterpret_cast<float2*>(d) = make_float2(ra.x, ra.y);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(ra.z, ra.w);
+        }
+        float* d = b_dst + buf * (64 * LPK);
+        *reinterpret_cast<float2*>(d) = make_float2(rb.x, rb.y);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(rb.z, rb.w);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int li = lane & 15;
+    const float* a_frag = &As[0][wr * TM * 16 + li][kg * KSG * 4 + (lane >> 4)];
+    const float* b_frag = &Bs[0][wc * TN * 16 + li][kg * KSG * 4 + (lane >> 4)];
+    auto mma = [&](int cur) {
+        const float* af = a_frag + cur * (BM_ * LPK);
+        const float* bf = b_frag + cur * (64 * LPK);
+        float a[KSG][TM], b[KSG][TN];
+#pragma unroll
+        for (int s = 0; s < KSG; ++s) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[s][t] = af[t * 16 * LPK + s * 4];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[s][t] = bf[t * 16 * LPK + s * 4];
+        }
+#pragma unroll
+        for (int s = 0; s < KSG; ++s)
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TN; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][ti], b[s][tj], acc[ti][tj], 0, 0, 0);
+    };
+
+    const int nkt = (p.K + LBK - 1) / LBK;
+    fetch(ra0, rb0, 0);
+    stash(ra0, rb0, 0);
+    if (nkt > 1) fetch(ra0, rb0, LBK);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        if (kt + 2 < nkt) fetch(ra1, rb1, (kt + 2) * LBK);
+        mma(0);
+        if (kt + 1 < nkt) stash(ra0, rb0, 1);
+        __syncthreads();
+        if (kt + 1 >= nkt) break;
+        if (kt + 3 < nkt) fetch(ra0, rb0, (kt + 3) * LBK);
+        mma(1);
+        if (kt + 2 < nkt) stash(ra1, rb1, 0);
+        __syncthreads();
+    }
+
+    // sum the two K halves: group 1 parks its accumulators in LDS, group 0 finishes
+    {
+        float* red = &As[0][0][0];
+        static_assert(2 * BM_ * LPK >= BM_ * 64, "reduction scratch must fit in As");
+        if (kg == 1) {
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        red[((wr * TM + ti) * 16 + (lane >> 4) * 4 + q) * 64 + (wc * TN + tj) * 16 + li] = acc[ti][tj][q];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[ti][tj][q] += red[((wr * TM + ti) * 16 + (lane >> 4) * 4 + q) * 64 + (wc * TN + tj) * 16 + li];
+    }
+
+    SiteKey key{0, 0};
+    const bool drop = (!BWD) && p.drop_p > 0.f;
+    if (drop) key = site_key(p.rng, p.site);
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj) {
+            const int c = n0 + (wc * TN + tj) * 16 + li;
+            if (c >= p.N) continue;
+            const float bias = (!BWD && p.bias) ? p.bias[c] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = m0 + (wr * TM + ti) * 16 + (lane >> 4) * 4 + q;
+                if (row >= p.M) continue;
+                float v = acc[ti][tj][q];
+                float* dst = p.out + (long long)row * p.ldo + c;
+                if (!BWD) {
+                    v = apply_act(v + bias, p.act, p.slope);
+                    if (drop) v *= keep_scale(key, (unsigned long long)row * p.N + c, p.drop_p, p.inv_keep);
+                    *dst = v;
+                } else {
+                    *dst = p.accumulate ? (*dst + v) : v;
+                }
+            }
+        }
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+}  // namespace
+
+// Internal entry points used by s2ag_conv1d_nlc_fwd / s2ag_conv1d_nlc_bwd_data (conv_gemm.hip) for 1-tap geometries.
+// Return 1 if the launch was taken, 0 if the shape / alignment is not covered (caller falls back to the general kernel).
+int s2ag_gemm_lin_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int ldx, int ldy,
+                      int act, float slope, float drop_p, const unsigned long long* rng, unsigned site,
+                      hipStream_t stream) {
+    if ((K & 3) || (ldx & 3) || !al16(x) || !al16(w)) return 0;
+    LinP p{};
+    p.a = x; p.w = w; p.bias = bias; p.out = y; p.M = M; p.K = K; p.N = N; p.lda = ldx; p.ldo = ldy; p.ldw = K;
+    p.act = act; p.slope = slope; p.drop_p = drop_p; p.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    p.rng = rng; p.site = site; p.accumulate = 0;
+    const int colb = cdiv(N, 64);
+    if ((long long)cdiv(M, 64) * colb >= 512)
+        hipLaunchKernelGGL((gemm_lin_k<false, 64>), dim3(cdiv(M, 64), colb), dim3(512), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_lin_k<false, 32>), dim3(cdiv(M, 32), colb), dim3(512), 0, stream, p);
+    return 1;
+}
+
+int s2ag_gemm_lin_bwd_data(const float* gy, const float* w, float* dx, int M, int Cout, int Cin, int ldg, int ldx,
+                           int accumulate, hipStream_t stream) {
+    // dx[m, ci] = sum_co gy[m, co] * w[co, ci]: K = Cout, N = Cin, W rows are N-contiguous
+    if ((Cout & 3) || (ldg & 3) || !al16(gy)) return 0;
+    LinP p{};
+    p.a = gy; p.w = w; p.bias = nullptr; p.out = dx; p.M = M; p.K = Cout; p.N = Cin; p.lda = ldg; p.ldo = ldx; p.ldw = Cin;
+    p.act = 0; p.slope = 1.f; p.drop_p = 0.f; p.inv_keep = 1.f; p.rng = nullptr; p.site = 0; p.accumulate = accumulate;
+    const int colb = cdiv(Cin, 64);
+    if ((long long)cdiv(M, 64) * colb >= 512)
+        hipLaunchKernelGGL((gemm_lin_k<true, 64>), dim3(cdiv(M, 64), colb), dim3(512), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_lin_k<true, 32>), dim3(cdiv(M, 32), colb), dim3(512), 0, stream, p);
+    return 1;
+}
