@@ -11,6 +11,8 @@
 // 2x2 MFMA 16x16 tiles.  Operands are staged k-major in LDS with an 80-float pitch so the four k-rows
 // a wave reads in one ds_read_b32 fall on disjoint bank groups.  The next K tile is fetched into
 // registers while the current one is multiplied.
+#include <stdlib.h>
+
 #include "s2ag_common.h"
 
 namespace {
@@ -914,6 +916,15 @@ bool bad_geom(const s2ag_conv_geom* g) {
 }
 }  // namespace
 
+// S2AG_GEMM_LIN=0: route 1-tap layers through the general kernel (A/B switch)
+static bool use_gemm_lin() {
+    static const bool v = [] {
+        const char* e = getenv("S2AG_GEMM_LIN");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 // gemm_lin.hip
 int s2ag_gemm_lin_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int ldx, int ldy,
                       int act, float slope, float drop_p, const unsigned long long* rng, unsigned site,
@@ -942,7 +953,7 @@ extern "C" int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* 
     p.site = e ? e->site : 0;
     p.accumulate = 0;
     // 1-tap layers (Linear, GRU projections, 1x1 convs): the straight-line kernel of gemm_lin.hip
-    if (g->ksize == 1 && g->stride == 1 && g->pad == 0 && g->Lin == g->Lout &&
+    if (use_gemm_lin() && g->ksize == 1 && g->stride == 1 && g->pad == 0 && g->Lin == g->Lout &&
         s2ag_gemm_lin_fwd(x, w, bias, y, p.M, g->Cin, g->Cout, g->ldx, g->ldy, p.act, p.slope, p.drop_p, p.rng, p.site,
                           (hipStream_t)stream)) {
         S2AG_LAUNCH_CHECK();
@@ -966,7 +977,7 @@ extern "C" int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* 
     p.Lr = g->Lin; p.Lsrc = g->Lout; p.CK = g->Cout; p.Cin = g->Cin;
     p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
     p.lda = g->ldy; p.ldo = g->ldx; p.wtm = g->w_tap_major;
-    if (g->ksize == 1 && g->stride == 1 && g->pad == 0 && g->Lin == g->Lout &&
+    if (use_gemm_lin() && g->ksize == 1 && g->stride == 1 && g->pad == 0 && g->Lin == g->Lout &&
         s2ag_gemm_lin_bwd_data(gy, w, dx, p.M, g->Cout, g->Cin, g->ldy, g->ldx, accumulate, (hipStream_t)stream)) {
         S2AG_LAUNCH_CHECK();
         return 0;

@@ -313,8 +313,10 @@ __device__ __forceinline__ void bn_bwd_finish(const float* t1, const float* t2, 
                                               float* dbeta, int accumulate, float* c1, float* c2) {
     for (int ch = threadIdx.x; ch < nchan; ch += blockDim.x) {
         if (accumulate) {
-            dgamma[ch] += t2[ch];
-            dbeta[ch] += t1[ch];
+            // atomic: the backward passes of D(real) and D(fake) run on two streams and meet in the same gradient slots
+            // (a plain += lost updates now and then -- graph replay only, where the two chains really overlap)
+            atomicAdd(dgamma + ch, t2[ch]);
+            atomicAdd(dbeta + ch, t1[ch]);
         } else {
             dgamma[ch] = t2[ch];
             dbeta[ch] = t1[ch];

@@ -202,7 +202,8 @@ class Processor(object):
         # independent forward passes of a step run on forked streams (every kernel here fills only part of the chip)
         self.overlap_passes = bool(getattr(args, 'overlap_passes', True))
         # the generator's dropout-free encoders run once per step instead of once per pass (see PoseGenerator)
-        self.share_encoders = bool(getattr(args, 'share_encoders', True))
+        self.share_encoders = bool(getattr(args, 'share_encoders', os.environ.get('S2AG_SHARE_ENCODERS', '1') != '0'))
+        self.early_rand = bool(getattr(args, 'early_rand', os.environ.get('S2AG_EARLY_RAND', '1') != '0'))
         self._side = [torch.cuda.Stream(device=self.device) for _ in range(2)]
         self._graphed = None
         self.last_losses = {}
@@ -299,7 +300,7 @@ class Processor(object):
                 dis_real = self.s2ag_discriminator(target_poses, in_text)
                 ops.stamp('D:D(real) end [side]')
             cur.wait_stream(side)
-            if self.s2ag_generator.share_passes:
+            if self.s2ag_generator.share_passes and self.early_rand:
                 # The generator's third forward (shuffled speakers, no_grad) depends on nothing the D step changes, and
                 # with the pose/audio encoders shared it contains no BatchNorm (no ordering of running statistics): it
                 # runs HERE, beside D(fake) and D's backward (small kernels that leave most CUs idle), instead of on
