@@ -931,6 +931,11 @@ int s2ag_gemm_lin_fwd(const float* x, const float* w, const float* bias, float* 
                       hipStream_t stream);
 int s2ag_gemm_lin_bwd_data(const float* gy, const float* w, float* dx, int M, int Cout, int Cin, int ldg, int ldx,
                            int accumulate, hipStream_t stream);
+int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, float* y, int nclips, int L, int Cin,
+                          int Cout, int ks, int pad, int dil, int ldx, int ldy, int act, float slope, float drop_p,
+                          const unsigned long long* rng, unsigned site, hipStream_t stream);
+int s2ag_gemm_conv_tm_bwd_data(const float* gy, const float* w, float* dx, int nclips, int L, int Cin, int Cout, int ks,
+                               int pad, int dil, int ldg, int ldx, int accumulate, hipStream_t stream);
 
 extern "C" int s2ag_abi_version(void) { return S2AG_ABI_VERSION; }
 
@@ -959,6 +964,13 @@ extern "C" int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* 
         S2AG_LAUNCH_CHECK();
         return 0;
     }
+    // stride-1 convs with tap-major weights (TCN, folded ST-GCN): the same straight-line kernel with (tap, channel) tracking
+    if (use_gemm_lin() && g->ksize > 1 && g->w_tap_major && g->stride == 1 && g->Lin == g->Lout &&
+        s2ag_gemm_conv_tm_fwd(x, w, bias, y, g->N, g->Lin, g->Cin, g->Cout, g->ksize, g->pad, g->dil, g->ldx, g->ldy,
+                              p.act, p.slope, p.drop_p, p.rng, p.site, (hipStream_t)stream)) {
+        S2AG_LAUNCH_CHECK();
+        return 0;
+    }
     const bool vec = (g->Cin % 4 == 0) && (g->ldx % 4 == 0) && aligned16(x);
     if (vec)
         launch_gemm2<false, true>(p, (hipStream_t)stream);
@@ -979,6 +991,12 @@ extern "C" int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* 
     p.lda = g->ldy; p.ldo = g->ldx; p.wtm = g->w_tap_major;
     if (use_gemm_lin() && g->ksize == 1 && g->stride == 1 && g->pad == 0 && g->Lin == g->Lout &&
         s2ag_gemm_lin_bwd_data(gy, w, dx, p.M, g->Cout, g->Cin, g->ldy, g->ldx, accumulate, (hipStream_t)stream)) {
+        S2AG_LAUNCH_CHECK();
+        return 0;
+    }
+    if (use_gemm_lin() && g->ksize > 1 && g->w_tap_major && g->stride == 1 && g->Lin == g->Lout &&
+        s2ag_gemm_conv_tm_bwd_data(gy, w, dx, g->N, g->Lin, g->Cin, g->Cout, g->ksize, g->pad, g->dil, g->ldy, g->ldx,
+                                   accumulate, (hipStream_t)stream)) {
         S2AG_LAUNCH_CHECK();
         return 0;
     }

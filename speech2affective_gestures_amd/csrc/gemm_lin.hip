@@ -27,6 +27,11 @@ struct LinP {
     float* out;
     int M, K, N;
     int lda, ldo, ldw;           // ldw: fwd = K (row n of W), bwd = N (row k of W)
+    // CONV (tap-major weights (Cout, ks, Cin), stride 1): K = ks * CK, the contraction index is (tap, channel)
+    int CK;                      // channels per tap of the contraction (Cin fwd, Cout bwd), >= 32, % 4 == 0
+    int ks, dil;
+    int L;                       // frames per clip (Lin == Lout)
+    int off;                     // source frame of tap 0 for output frame 0: fwd -pad, bwd +pad (bwd steps by -dil)
     int act;
     float slope, drop_p, inv_keep;
     const unsigned long long* rng;
@@ -34,7 +39,7 @@ struct LinP {
     int accumulate;
 };
 
-template <bool BWD, int BM_>
+template <bool BWD, int BM_, bool CONV>
 __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
     constexpr int NT = 512;
     constexpr int WM = 2, WN = 2, KG = 2;
@@ -54,6 +59,16 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
     const bool has_a = CA > 0 || tid < BM_ * (LBK / 4);
     const int a_kq = tid % (LBK / 4), a_r = tid / (LBK / 4);
     const float* a_ptr = (has_a && m0 + a_r < p.M) ? p.a + (long long)(m0 + a_r) * p.lda + a_kq * 4 : nullptr;
+    // CONV: the A row of tap t is the clip's frame (l + off +- t*dil); (a_tap, a_c) = (tap, channel) of this thread's
+    // chunk, advanced by LBK per tile (CK >= 32: at most one wrap per tile)
+    int a_tap = 0, a_c = a_kq * 4, a_l = 0;
+    const float* a_clip = nullptr;              // row 0 of the clip
+    if (CONV && has_a && m0 + a_r < p.M) {
+        const int m = m0 + a_r;
+        const int nclip = m / p.L;
+        a_l = m - nclip * p.L + p.off;
+        a_clip = p.a + (long long)nclip * p.L * p.lda;
+    }
     // B chunk: fwd = (col b_c, k quad b_kq) one float4 along k;  bwd = (col b_c, k quad b_kq) four k rows of W
     int b_c, b_kq;
     if (BWD) {
@@ -68,15 +83,38 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
                                : (BWD ? p.w + (long long)(b_kq * 4) * p.ldw + n0 + b_c
                                       : p.w + (long long)(n0 + b_c) * p.ldw + b_kq * 4);
     const long long b_step = BWD ? (long long)LBK * p.ldw : LBK;
+    // CONV bwd: k = (tap, co) lives in W row co*ks + tap, i.e. rows of one tap are ks*Cin floats apart
+    int b_tap = 0, b_co = b_kq * 4;
+    const long long b_row = (long long)p.ks * p.ldw;     // bwd CONV: distance of consecutive co at a fixed tap
 
     float4 ra0, rb0, ra1, rb1;
-    auto fetch = [&](float4& ra, float4& rb, int k0) {
+    auto fetch = [&](float4& ra, float4& rb, int k0) {        // call with k0 = 0, LBK, 2*LBK, ... in order
         const int ka = k0 + a_kq * 4, kb = k0 + b_kq * 4;
         ra = make_float4(0.f, 0.f, 0.f, 0.f);
         rb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a_ptr && ka < p.K) ra = *reinterpret_cast<const float4*>(a_ptr + k0);
+        if (CONV) {
+            if (a_clip && ka < p.K) {
+                const int pos = BWD ? a_l - a_tap * p.dil : a_l + a_tap * p.dil;
+                if ((unsigned)pos < (unsigned)p.L)
+                    ra = *reinterpret_cast<const float4*>(a_clip + (long long)pos * p.lda + a_c);
+            }
+            a_c += LBK;
+            if (a_c >= p.CK) { a_c -= p.CK; ++a_tap; }
+        } else {
+            if (a_ptr && ka < p.K) ra = *reinterpret_cast<const float4*>(a_ptr + k0);
+        }
         if (BWD) {
-            if (b_ptr) {
+            if (CONV) {
+                if (b_ptr && kb < p.K) {          // CK % 4 == 0: the four k of a chunk share the tap
+                    const float* q = p.w + ((long long)b_co * p.ks + b_tap) * p.ldw + n0 + b_c;
+                    rb.x = q[0];
+                    rb.y = q[b_row];
+                    rb.z = q[2 * b_row];
+                    rb.w = q[3 * b_row];
+                }
+                b_co += LBK;
+                if (b_co >= p.CK) { b_co -= p.CK; ++b_tap; }
+            } else if (b_ptr) {
                 const float* q = b_ptr + (long long)(k0 / LBK) * b_step;
                 if (kb < p.K) rb.x = q[0];
                 if (kb + 1 < p.K) rb.y = q[p.ldw];
@@ -212,9 +250,9 @@ int s2ag_gemm_lin_fwd(const float* x, const float* w, const float* bias, float* 
     p.rng = rng; p.site = site; p.accumulate = 0;
     const int colb = cdiv(N, 64);
     if ((long long)cdiv(M, 64) * colb >= 512)
-        hipLaunchKernelGGL((gemm_lin_k<false, 64>), dim3(cdiv(M, 64), colb), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((gemm_lin_k<false, 64, false>), dim3(cdiv(M, 64), colb), dim3(512), 0, stream, p);
     else
-        hipLaunchKernelGGL((gemm_lin_k<false, 32>), dim3(cdiv(M, 32), colb), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((gemm_lin_k<false, 32, false>), dim3(cdiv(M, 32), colb), dim3(512), 0, stream, p);
     return 1;
 }
 
@@ -227,8 +265,46 @@ int s2ag_gemm_lin_bwd_data(const float* gy, const float* w, float* dx, int M, in
     p.act = 0; p.slope = 1.f; p.drop_p = 0.f; p.inv_keep = 1.f; p.rng = nullptr; p.site = 0; p.accumulate = accumulate;
     const int colb = cdiv(Cin, 64);
     if ((long long)cdiv(M, 64) * colb >= 512)
-        hipLaunchKernelGGL((gemm_lin_k<true, 64>), dim3(cdiv(M, 64), colb), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((gemm_lin_k<true, 64, false>), dim3(cdiv(M, 64), colb), dim3(512), 0, stream, p);
     else
-        hipLaunchKernelGGL((gemm_lin_k<true, 32>), dim3(cdiv(M, 32), colb), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((gemm_lin_k<true, 32, false>), dim3(cdiv(M, 32), colb), dim3(512), 0, stream, p);
+    return 1;
+}
+
+// Stride-1 convolutions with TAP-MAJOR weights (Cout, ks, Cin) -- the weight-normed TCN convs and the folded ST-GCN convs
+// (both produced in that layout by their derived-parameter kernels) -- with at least 32 channels per tap:
+//   fwd  y[(n,l), co]   = epi( sum_{t,ci} x[(n, l - pad + t*dil), ci] w[co, t, ci] + b[co] )
+//   bwd  dx[(n,p), ci] (+)= sum_{t,co} gy[(n, p + pad - t*dil), co] w[co, t, ci]
+int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, float* y, int nclips, int L, int Cin,
+                          int Cout, int ks, int pad, int dil, int ldx, int ldy, int act, float slope, float drop_p,
+                          const unsigned long long* rng, unsigned site, hipStream_t stream) {
+    if ((Cin & 3) || Cin < LBK || (ldx & 3) || !al16(x) || !al16(w)) return 0;
+    LinP p{};
+    p.a = x; p.w = w; p.bias = bias; p.out = y; p.M = nclips * L; p.K = ks * Cin; p.N = Cout;
+    p.lda = ldx; p.ldo = ldy; p.ldw = ks * Cin;
+    p.CK = Cin; p.ks = ks; p.dil = dil; p.L = L; p.off = -pad;
+    p.act = act; p.slope = slope; p.drop_p = drop_p; p.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    p.rng = rng; p.site = site; p.accumulate = 0;
+    const int colb = cdiv(Cout, 64);
+    if ((long long)cdiv(p.M, 64) * colb >= 512)
+        hipLaunchKernelGGL((gemm_lin_k<false, 64, true>), dim3(cdiv(p.M, 64), colb), dim3(512), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_lin_k<false, 32, true>), dim3(cdiv(p.M, 32), colb), dim3(512), 0, stream, p);
+    return 1;
+}
+
+int s2ag_gemm_conv_tm_bwd_data(const float* gy, const float* w, float* dx, int nclips, int L, int Cin, int Cout, int ks,
+                               int pad, int dil, int ldg, int ldx, int accumulate, hipStream_t stream) {
+    if ((Cout & 3) || Cout < LBK || (ldg & 3) || !al16(gy)) return 0;
+    LinP p{};
+    p.a = gy; p.w = w; p.bias = nullptr; p.out = dx; p.M = nclips * L; p.K = ks * Cout; p.N = Cin;
+    p.lda = ldg; p.ldo = ldx; p.ldw = Cin;
+    p.CK = Cout; p.ks = ks; p.dil = dil; p.L = L; p.off = pad;
+    p.act = 0; p.slope = 1.f; p.drop_p = 0.f; p.inv_keep = 1.f; p.rng = nullptr; p.site = 0; p.accumulate = accumulate;
+    const int colb = cdiv(Cin, 64);
+    if ((long long)cdiv(p.M, 64) * colb >= 512)
+        hipLaunchKernelGGL((gemm_lin_k<true, 64, true>), dim3(cdiv(p.M, 64), colb), dim3(512), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_lin_k<true, 32, true>), dim3(cdiv(p.M, 32), colb), dim3(512), 0, stream, p);
     return 1;
 }
