@@ -931,6 +931,8 @@ int s2ag_gemm_lin_fwd(const float* x, const float* w, const float* bias, float* 
                       hipStream_t stream);
 int s2ag_gemm_lin_bwd_data(const float* gy, const float* w, float* dx, int M, int Cout, int Cin, int ldg, int ldx,
                            int accumulate, hipStream_t stream);
+int s2ag_wgrad_lin(const float* gy, const float* x, float* dw, float* db, int nclips, int L, int Cin, int Cout, int ks,
+                   int pad, int dil, int ldx, int ldg, int wtm, int chunk, int nsplit, hipStream_t stream);
 int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, float* y, int nclips, int L, int Cin,
                           int Cout, int ks, int pad, int dil, int ldx, int ldy, int act, float slope, float drop_p,
                           const unsigned long long* rng, unsigned site, hipStream_t stream);
@@ -1041,6 +1043,12 @@ extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float
             me = zero_async(dbias, sizeof(float) * (size_t)g->Cout, (hipStream_t)stream);
             if (me != hipSuccess) return (int)me;
         }
+    }
+    if (use_gemm_lin() && g->stride == 1 && g->Lin == g->Lout && p.chunk % BK2 == 0 &&
+        s2ag_wgrad_lin(gy, x, dw, dbias, g->N, g->Lin, g->Cin, g->Cout, g->ksize, g->pad, g->dil, g->ldx, g->ldy,
+                       g->w_tap_major, p.chunk, nsplit, (hipStream_t)stream)) {
+        S2AG_LAUNCH_CHECK();
+        return 0;
     }
     dim3 grid(cdiv(g->Cout, BM), cdiv(g->ksize * g->Cin, BN), nsplit);
     if (v2)

@@ -308,3 +308,187 @@ int s2ag_gemm_conv_tm_bwd_data(const float* gy, const float* w, float* dx, int n
         hipLaunchKernelGGL((gemm_lin_k<true, 32, true>), dim3(cdiv(p.M, 32), colb), dim3(512), 0, stream, p);
     return 1;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Straight-line weight gradient for stride-1 layers:  dw[co, (tap, ci)] += sum_m gy[m, co] * x[m + tap*dil - pad, ci]
+// (rows of one clip only), db[co] += sum_m gy[m, co].  Same tiling as conv_wgrad2_k (64 x 64 output tile, 32 contraction
+// rows per K tile, double-buffered k-major LDS, 8 waves with a 2-way in-block split, clips*frames split over grid.z and
+// merged with fp32 atomics) without the per-row clip/position arithmetic of the general kernel (10-15 vector-ALU
+// instructions per MFMA there): a thread owns one output column for the whole launch, so its operand rows are two
+// pointers that advance by 32 rows per tile; the only per-row work is the frame-boundary test of shifted taps.
+namespace {
+struct WgP {
+    const float* gy;
+    const float* x;
+    float* dw;
+    float* db;
+    int M, L, Cin, Cout, ks, pad, dil, ldx, ldg, wtm;
+    int chunk;
+};
+
+constexpr int WPW = 64 + 16;          // k-major LDS pitch (fragment reads of 4 k-rows hit disjoint banks)
+
+template <bool SHIFT>
+__global__ __launch_bounds__(512) void wgrad_lin_k(WgP p) {
+    __shared__ float As[2][LBK][WPW];                 // [m][co]
+    __shared__ float Bs[2][LBK][WPW];                 // [m][j = tap*Cin + ci]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int co0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int mbeg = blockIdx.z * p.chunk;
+    const int mend = min(p.M, mbeg + p.chunk);
+    const int cidx = tid & 63, mq = tid >> 6;         // rows mq*4 .. mq*4+3 of the 32-row tile
+    const int NCW = p.ks * p.Cin;
+    const int co = co0 + cidx, jcol = j0 + cidx;
+    int tap = 0, ci = 0;
+    if (jcol < NCW) {
+        tap = jcol / p.Cin;
+        ci = jcol - tap * p.Cin;
+    }
+    const int tapoff = tap * p.dil - p.pad;
+    const long long r0 = mbeg + mq * 4;
+    const float* g_ptr = co < p.Cout ? p.gy + r0 * p.ldg + co : nullptr;
+    const float* x_ptr = jcol < NCW ? p.x + (r0 + tapoff) * p.ldx + ci : nullptr;   // dereferenced only at valid frames
+    int l = SHIFT ? (int)(r0 % p.L) : 0;              // frame of this thread's first row inside its clip
+    const bool want_db = p.db != nullptr && blockIdx.y == 0;
+    float bsum = 0.f;
+
+    float ra0[4], rb0[4], ra1[4], rb1[4];
+    auto fetch = [&](float (&ra)[4], float (&rb)[4], int mb) {       // call with mb = mbeg, mbeg+32, ... in order
+        const bool full = mb + LBK <= mend;           // block-uniform: only the last tile of the last chunk is ragged
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool okrow = full || (mb + mq * 4 + j < mend);
+            bool okx = okrow;
+            if (SHIFT) {
+                int lj = l + j;
+                lj -= (lj >= p.L) ? p.L : 0;
+                okx = okrow && (unsigned)(lj + tapoff) < (unsigned)p.L;
+            }
+            ra[j] = (g_ptr && okrow) ? g_ptr[(long long)j * p.ldg] : 0.f;
+            rb[j] = (x_ptr && okx) ? x_ptr[(long long)j * p.ldx] : 0.f;
+            bsum += ra[j];
+        }
+        if (g_ptr) g_ptr += (long long)LBK * p.ldg;
+        if (x_ptr) x_ptr += (long long)LBK * p.ldx;
+        if (SHIFT) {
+            l += LBK;
+            if (l >= p.L) l -= p.L;                   // host guarantees L >= 32
+        }
+    };
+    float* const a_dst = &As[0][mq * 4][cidx];
+    float* const b_dst = &Bs[0][mq * 4][cidx];
+    auto stash = [&](const float (&ra)[4], const float (&rb)[4], int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a_dst[buf * (LBK * WPW) + j * WPW] = ra[j];
+            b_dst[buf * (LBK * WPW) + j * WPW] = rb[j];
+        }
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15;
+    const float* a_frag = &As[0][kg * 16 + (lane >> 4)][wm * 32 + li];
+    const float* b_frag = &Bs[0][kg * 16 + (lane >> 4)][wn * 32 + li];
+    auto mma = [&](int cur) {                          // every MFMA unconditional: rows / columns outside hold zeros
+        const float* af = a_frag + cur * (LBK * WPW);
+        const float* bf = b_frag + cur * (LBK * WPW);
+        float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a0[s] = af[s * 4 * WPW];
+            a1[s] = af[s * 4 * WPW + 16];
+            b0[s] = bf[s * 4 * WPW];
+            b1[s] = bf[s * 4 * WPW + 16];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+        }
+    };
+    const int nkt = (mend - mbeg + LBK - 1) / LBK;
+    if (nkt <= 0) return;
+    fetch(ra0, rb0, mbeg);
+    stash(ra0, rb0, 0);
+    if (nkt > 1) fetch(ra0, rb0, mbeg + LBK);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        if (kt + 2 < nkt) fetch(ra1, rb1, mbeg + (kt + 2) * LBK);
+        mma(0);
+        if (kt + 1 < nkt) stash(ra0, rb0, 1);
+        __syncthreads();
+        if (kt + 1 >= nkt) break;
+        if (kt + 3 < nkt) fetch(ra0, rb0, mbeg + (kt + 3) * LBK);
+        mma(1);
+        if (kt + 2 < nkt) stash(ra1, rb1, 0);
+        __syncthreads();
+    }
+    if (want_db) Bs[0][mq][cidx] = bsum;              // Bs is idle after the last tile; read behind the barrier below
+    {   // merge the two wave groups through LDS so only one of them issues the (cross-block) atomics
+        float* redw = &As[0][0][0];                   // 2*32*80 floats >= 64*64
+        if (kg == 1) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        redw[(wm * 32 + ti * 16 + (lane >> 4) * 4 + q) * 64 + wn * 32 + tj * 16 + li] = acc[ti][tj][q];
+        }
+        __syncthreads();
+        if (want_db && mq == 0 && co < p.Cout) {      // wave 0 (kg = 0): eight row groups per column
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += Bs[0][q][cidx];
+            atomicAdd(p.db + co, t);
+        }
+        if (kg == 1) return;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[ti][tj][q] += redw[(wm * 32 + ti * 16 + (lane >> 4) * 4 + q) * 64 + wn * 32 + tj * 16 + li];
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int jc = j0 + wn * 32 + tj * 16 + li;
+            if (jc >= NCW) continue;
+            const int t2 = jc / p.Cin, c2 = jc - t2 * p.Cin;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = co0 + wm * 32 + ti * 16 + (lane >> 4) * 4 + q;
+                if (row >= p.Cout) continue;
+                atomicAdd(p.dw + (p.wtm ? ((long long)row * p.ks + t2) * p.Cin + c2
+                                        : ((long long)row * p.Cin + c2) * p.ks + t2), acc[ti][tj][q]);
+            }
+        }
+}
+}  // namespace
+
+// Returns 1 if the launch was taken (stride 1, Lin == Lout, and either one frame per clip without padding -- Linear --
+// or at least 32 frames per clip); dw / db must already hold the values to accumulate into.
+int s2ag_wgrad_lin(const float* gy, const float* x, float* dw, float* db, int nclips, int L, int Cin, int Cout, int ks,
+                   int pad, int dil, int ldx, int ldg, int wtm, int chunk, int nsplit, hipStream_t stream) {
+    const bool linear = (L == 1 && pad == 0 && ks == 1);
+    if (!linear && L < LBK) return 0;
+    WgP p{};
+    p.gy = gy; p.x = x; p.dw = dw; p.db = db; p.M = nclips * L; p.L = L; p.Cin = Cin; p.Cout = Cout; p.ks = ks;
+    p.pad = pad; p.dil = dil; p.ldx = ldx; p.ldg = ldg; p.wtm = wtm; p.chunk = chunk;
+    dim3 grid(cdiv(Cout, 64), cdiv(ks * Cin, 64), nsplit);
+    if (linear)
+        hipLaunchKernelGGL(wgrad_lin_k<false>, grid, dim3(512), 0, stream, p);
+    else
+        hipLaunchKernelGGL(wgrad_lin_k<true>, grid, dim3(512), 0, stream, p);
+    return 1;
+}
