@@ -404,6 +404,11 @@ class PoseGenerator(nn.Module, _SpeakerZ):
     # their BatchNorm running statistics advance k times (ops.bn_repeat), exactly as k separate passes would.
     share_passes = None
 
+    def prepare_shared(self, pre_seq, in_mfcc):
+        """Compute this step's shared encoder outputs on the CURRENT stream (the trainer calls this on a forked stream,
+        beside the text encoder of the first pass); later passes wait for the event recorded here before using them."""
+        self._shared_encoders(pre_seq, in_mfcc)
+
     def _shared_encoders(self, pre_seq, in_mfcc):
         k = self.share_passes
         if not k or self.input_context == 'none':
@@ -413,8 +418,12 @@ class PoseGenerator(nn.Module, _SpeakerZ):
             with torch.set_grad_enabled(self.training), ops.bn_repeat(k if self.training else 1):
                 pre = self.aff_encoder(pre_seq[..., :-1])
                 audio = self.audio_encoder(in_mfcc)
-            self._shared = (key, pre, audio)
-        _, pre, audio = self._shared
+            ev = torch.cuda.Event()
+            ev.record()
+            self._shared = (key, pre, audio, ev, torch.cuda.current_stream())
+        _, pre, audio, ev, made_on = self._shared
+        if torch.cuda.current_stream() != made_on:
+            torch.cuda.current_stream().wait_event(ev)
         if not torch.is_grad_enabled():
             pre, audio = pre.detach(), audio.detach()
         return pre, audio
@@ -423,16 +432,20 @@ class PoseGenerator(nn.Module, _SpeakerZ):
         with noise_pass(pre_seq.device) as nz:
             audio = text = None
             # four independent encoder branches -> four streams (joined before the concat that feeds the GRU)
-            shared = self._shared_encoders(pre_seq, in_mfcc)
-            if shared is not None:       # pose + audio encoders of this step already exist (or were just made)
-                fns = [lambda: shared[0], lambda: self._z(in_text, vid_indices, nz)]
-                if self.input_context != 'none':
-                    fns += [lambda: self.text_encoder(in_text)[0], lambda: shared[1]]
+            if self.share_passes and self.input_context != 'none':
+                # pose + audio encoders of this step exist already or are made now; they are fetched LAST, so that a
+                # wait for the stream that produced them sits behind this pass's own text encoder
+                fns = [lambda: None, lambda: self._z(in_text, vid_indices, nz), lambda: self.text_encoder(in_text)[0],
+                       lambda: self._shared_encoders(pre_seq, in_mfcc)]
+                res = [f() for f in fns]
+                res[0], res[3] = res[3][0], res[3][1]
+                fns = None
             else:
                 fns = [lambda: self.aff_encoder(pre_seq[..., :-1]), lambda: self._z(in_text, vid_indices, nz)]
                 if self.input_context != 'none':
                     fns += [lambda: self.text_encoder(in_text)[0], lambda: self.audio_encoder(in_mfcc)]
-            res = self._branches.run(fns, pre_seq.device, ops.PARALLEL_BRANCHES)
+            if fns is not None:
+                res = self._branches.run(fns, pre_seq.device, ops.PARALLEL_BRANCHES)
             pre, (z_context, z_mu, z_log_var) = res[0], res[1]
             if self.input_context != 'none':
                 text, audio = res[2], res[3]

@@ -203,6 +203,7 @@ class Processor(object):
         self.overlap_passes = bool(getattr(args, 'overlap_passes', True))
         # the generator's dropout-free encoders run once per step instead of once per pass (see PoseGenerator)
         self.share_encoders = bool(getattr(args, 'share_encoders', os.environ.get('S2AG_SHARE_ENCODERS', '1') != '0'))
+        self.encoders_aside = bool(getattr(args, 'encoders_aside', os.environ.get('S2AG_ENCODERS_ASIDE', '1') != '0'))
         self.early_rand = bool(getattr(args, 'early_rand', os.environ.get('S2AG_EARLY_RAND', '1') != '0'))
         self._side = [torch.cuda.Stream(device=self.device) for _ in range(2)]
         self._graphed = None
@@ -291,6 +292,11 @@ class Processor(object):
             # The generator forward is the long pole of this phase (D(fake) needs its output): it stays on the main
             # stream and is issued FIRST; D(real) is issued after it on a stream forked from the phase start.
             side = self._fork(0)
+            if self.s2ag_generator.share_passes and self.encoders_aside:
+                # the generator's shared pose/audio encoders run on a forked stream beside its text encoder
+                enc = self._fork(1)
+                with torch.cuda.stream(enc), ops.sequential_branches():
+                    self.s2ag_generator.prepare_shared(pre_seq, in_mfcc)
             ops.stamp('D:G(dis) begin [main]')
             with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
                 out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
@@ -389,6 +395,8 @@ class Processor(object):
         total, comps = ops.gen_loss(out, dis_output, z_mu, z_log_var, target_poses, out_tri, out_rand, z, z_rand,
                                     (cfg.loss_regression_weight, w_gan, cfg.loss_reg_weight, cfg.loss_kld_weight))
         ops.stamp('G:losses done, backward begins')
+        if self.overlap_passes and self.encoders_aside and self.s2ag_generator.share_passes and self._use_gan():
+            ops.mark_side_stream(self._side[1])      # the shared encoders' backward runs on the stream of their forward
         if train:
             total.backward()
         ops.join_side_streams()
