@@ -263,6 +263,13 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------
 // backward through time
 // ---------------------------------------------------------------------------------------------------------
+// dL/dh_{t-1}[16 x H] = carry + d(gh)_t[16 x 3H] . W_hh[3H x H].  The contraction is partitioned over K, not over the
+// output: a workgroup multiplies ITS OWN 96 rows of d(gh)_t (the gate gradients of its 32 units, which it has just
+// computed -- no exchange needed for them) by W_hh[own rows, all H columns] and the group reduce-scatters the 16 x H
+// partial sums: every workgroup publishes 16 x 300 tagged cells and reads the 10 x 16 x 32 cells of its own columns
+// (41 KB per workgroup and step).  The output-partitioned first version had every workgroup read the whole group's
+// d(gh) -- 14 400 cells, 115 KB, 18 MB per step over all groups: the gather ran at the memory-side fabric's ~4 TB/s and
+// was 4 of the step's 8.8 us.
 template <int H, int HW_>
 __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ dy, int lddy, int dy_dir_stride,
                                                       const float* __restrict__ whh, const float* __restrict__ y,
@@ -271,42 +278,46 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
                                                       int T, float drop_p, float inv_keep,
                                                       const unsigned long long* rng, unsigned site) {
     constexpr int H3 = 3 * H;
-    constexpr int NT_B = HW_ / 16;                 // dh column tiles
-    constexpr int NKS = 12 / NT_B;                 // K slices (12 waves)
-    constexpr int KSTEPS = (H3 + 3) / 4;           // k-steps over K = 3H
-    constexpr int KPW = (KSTEPS + NKS - 1) / NKS;  // k-steps per wave
+    constexpr int S = (H + HW_ - 1) / HW_;         // workgroups (= producers) per group
+    constexpr int NTL = (H + 15) / 16;             // 16-column tiles of the partial product (19)
+    constexpr int NITEM = NTL * 3;                 // work items: (column tile, gate) = 8 MFMAs each
+    constexpr int IPW = (NITEM + 11) / 12;         // items per wave (5)
+    constexpr int KS = HW_ / 4;                    // k-steps per gate (8)
     constexpr int GT = CBS * HW_;
-    constexpr int GP = lds_pitch(NKS * KPW * 4);   // LDS row pitch of d(gh) (covers the padded K range)
-    constexpr int RP = HW_ + 4;
-    constexpr int NLB = (H3 * CBS + CNT - 1) / CNT;            // exchange cells per thread
+    constexpr int GOP = lds_pitch(3 * HW_);        // LDS pitch of the own d(gh) rows (132)
+    constexpr int RP = NTL * 16 + 4;               // pitch of the per-gate partial products (308)
     static_assert(HW_ == 32 && GT <= CNT, "one (clip, unit) per gate thread");
-    extern __shared__ __attribute__((aligned(16))) float smem_bwd[];   // ~75 KB: above the static limit
-    float* gT = smem_bwd;                                      // [CBS][GP] d(gh) of this step, whole group
-    float (*red)[CBS][RP] = reinterpret_cast<float (*)[CBS][RP]>(gT + CBS * GP);   // [NKS][CBS][RP]
+    extern __shared__ __attribute__((aligned(16))) float smem_bwd[];
+    float* gO = smem_bwd;                                       // [CBS][GOP]: own d(gh), k' = gate*32 + unit
+    float (*red)[CBS][RP] = reinterpret_cast<float (*)[CBS][RP]>(gO + CBS * GOP);   // [3][CBS][RP]
 
     const int s = blockIdx.x, bsl = blockIdx.y, dir = blockIdx.z;
     const int nbs = gridDim.y;
-    const int group = dir * nbs + bsl;
     const int b0 = bsl * CBS;
     const int nb = min(CBS, B - b0);
     const int u0 = s * HW_;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = wave % NT_B, ksl = wave / NT_B;
-    u64* X = xbuf + (size_t)group * 2 * H3 * CBS;     // [parity][clip][3H] cells
+    const int group = dir * nbs + bsl;
+    constexpr size_t XPAR = (size_t)S * CBS * H;      // cells per parity: [producer][clip][column]
+    u64* X = xbuf + (size_t)group * 2 * XPAR;
     const float* W = whh + (size_t)dir * H3 * H;      // (3H, H) row-major
 
-    const int kbeg = ksl * KPW;
-    float breg[KPW];
-    {
-        const int j = u0 + nt * 16 + (lane & 15);     // dh column owned by this lane
+    // B operands: item it = wave + 12*i -> (column tile nt = it / 3, gate g = it % 3); B[k][j] = W[g*H + u0 + k][nt*16 + j]
+    float breg[IPW][KS];
 #pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            const int k = (kbeg + i) * 4 + (lane >> 4);
-            breg[i] = (kbeg + i < KSTEPS && k < H3 && j < H) ? W[(size_t)k * H + j] : 0.f;
+    for (int i = 0; i < IPW; ++i) {
+        const int it = wave + 12 * i;
+        const int nt = it / 3, g = it - nt * 3;
+        const int col = nt * 16 + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int ul = ks * 4 + (lane >> 4);
+            const int u = u0 + ul;
+            breg[i][ks] = (it < NITEM && u < H && col < H) ? W[(size_t)(g * H + u) * H + col] : 0.f;
         }
     }
-    for (int i = tid; i < CBS * GP; i += CNT) gT[i] = 0.f;     // the pad columns stay zero for the whole launch
+    for (int i = tid; i < CBS * GOP; i += CNT) gO[i] = 0.f;    // pad columns / clips beyond B stay zero
     SiteKey key{0, 0};
     const bool drop = drop_p > 0.f;
     if (drop) key = site_key(rng, site);
@@ -340,10 +351,11 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
         return p;
     };
     Pre cur = fetch(0);
+    __syncthreads();
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? step : (T - 1 - step);
-        // ---- phase A: gate gradients of this workgroup's units, published to the group
+        // ---- phase A: gate gradients of this workgroup's units -> global (dgi, dgh) and LDS (own rows of d(gh))
         COOP_TR(0);
         float carry = 0.f;
         if (gate_lane) {
@@ -359,15 +371,6 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
                 dr = dn * hn * r * (1.f - r);
                 dnr = dn * r;
                 carry = dht * z;
-            }
-            COOP_TR(1);
-            if (step + 1 < T) {                       // publish first: the peers are waiting for exactly these cells
-                u64* Xp = X + (size_t)(step & 1) * H3 * CBS + (size_t)gc * H3 + u;
-                st_cell(Xp, dr, (unsigned)(step + 1));
-                st_cell(Xp + H, dz, (unsigned)(step + 1));
-                st_cell(Xp + 2 * H, dnr, (unsigned)(step + 1));
-            }
-            if (gate_thread) {
                 float* gi_o = dgi + row * (2 * H3) + dir * H3;
                 gi_o[u] = dr;
                 gi_o[H + u] = dz;
@@ -377,39 +380,69 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
                 gh_o[H + u] = dz;
                 gh_o[2 * H + u] = dnr;
             }
+            gO[gc * GOP + ul] = dr;
+            gO[gc * GOP + HW_ + ul] = dz;
+            gO[gc * GOP + 2 * HW_ + ul] = dnr;
         }
         if (step + 1 == T) break;                   // the last step's dh is never consumed
+        COOP_TR(1);
+        __syncthreads();
         COOP_TR(2);
-        // d(gh)_t of the whole group: cells tagged step+1
-        unsigned rounds = 0;
-        if (ok)
-            ok = gather_cells<NLB, H3, GP>(X + (size_t)(step & 1) * H3 * CBS, (unsigned)(step + 1), gT, err, &rounds);
+        cur = fetch(step + 1);                      // latency hides under the MFMA phase
+        // ---- phase B: partial[16 x H] of this workgroup = own d(gh)[16 x 96] . W_hh[own 96 rows, :]
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int it = wave + 12 * i;
+            if (it >= NITEM) break;                 // wave-uniform
+            const int nt = it / 3, g = it - nt * 3;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float a = gO[(lane & 15) * GOP + g * HW_ + ks * 4 + (lane >> 4)];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[i][ks], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[g][(lane >> 4) * 4 + q][nt * 16 + (lane & 15)] = acc[q];
+        }
+        __syncthreads();
         COOP_TR(3);
-        COOP_TRV(7, rounds);
-        __syncthreads();
+        // ---- publish the 16 x H partial sums (three gate slabs added) as cells tagged step+1: [producer][clip][column]
+        {
+            u64* Xp = X + (size_t)(step & 1) * XPAR + (size_t)s * CBS * H;
+            for (int i = tid; i < CBS * H; i += CNT) {
+                const int c = i / H, j = i - c * H;
+                st_cell(Xp + i, red[0][c][j] + red[1][c][j] + red[2][c][j], (unsigned)(step + 1));
+            }
+        }
         COOP_TR(4);
-        // next step's gate operands: issued AFTER the gather (vector memory returns in order -- ahead of the gather they
-        // would sit in front of the exchange loads), their latency hides under the MFMA phase
-        cur = fetch(step + 1);
-        // ---- phase B: dh[16 x HW] = carry + d(gh)[16 x 3H] . W_hh[3H x HW]
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // ---- reduce-scatter: this thread's (clip, unit) column from every producer of the group
+        if (gate_lane) {
+            const u64* Xc = X + (size_t)(step & 1) * XPAR + (size_t)gc * H + u;
+            u64 v[S];
+            unsigned spins = 0;
+            while (ok) {
+                bool all = true;
 #pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            const int k = (kbeg + i) * 4 + (lane >> 4);
-            const float a = gT[(lane & 15) * GP + k];     // k >= 3H: zero pad columns (never written), breg = 0 too
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[i], acc, 0, 0, 0);
+                for (int q = 0; q < S; ++q) v[q] = ld_cell(Xc + (size_t)q * CBS * H);
+#pragma unroll
+                for (int q = 0; q < S; ++q) all = all && ((unsigned)(v[q] >> 32) == (unsigned)(step + 1));
+                if (all) break;
+                if (++spins > SPIN_LIMIT) {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            float acc = carry;
+#pragma unroll
+            for (int q = 0; q < S; ++q) acc += __uint_as_float((unsigned)v[q]);
+            dh = acc;
+            COOP_TRV(7, spins);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) red[ksl][(lane >> 4) * 4 + q][nt * 16 + (lane & 15)] = acc[q];
-        __syncthreads();
         COOP_TR(5);
-        // no barrier closes the step: red[] / gT[] are next written after the post-gather barrier of step+1
-        if (tid < GT) {
-            float v = carry;
-#pragma unroll
-            for (int q = 0; q < NKS; ++q) v += red[q][gc][ul];
-            dh = v;
-        }
+        // no barrier closes the step: gO[] is rewritten in phase A of step+1, after every wave finished phase B (barrier
+        // above); red[] is rewritten in phase B of step+1, behind that step's first barrier, which a thread reaches only
+        // after its part of the publish loop
     }
 }
 
@@ -420,7 +453,8 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 inline size_t coop_payload_bytes(int B, int H, int backward) {
     const size_t groups = (size_t)2 * cdiv(B, CBS);
-    return align_up(groups * (backward ? 3 : 1) * 2 * (size_t)H * CBS * sizeof(u64), 256);   // [group][parity][n] cells
+    const size_t producers = backward ? (size_t)((H + 31) / 32) : 1;      // backward: a 16 x H slab per producer
+    return align_up(groups * producers * 2 * (size_t)H * CBS * sizeof(u64), 256);   // [group][parity][...] cells
 }
 
 struct Ws {
@@ -482,7 +516,7 @@ extern "C" int s2ag_gru_coop_bwd(const float* dy, int lddy, int dy_dir_stride, c
     const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
     const unsigned long long* rg = e ? e->rng : nullptr;
     const unsigned site = e ? e->site : 0u;
-    constexpr size_t smem = sizeof(float) * (CBS * lds_pitch(6 * 38 * 4) + 6 * CBS * 36);   // gT + red
+    constexpr size_t smem = sizeof(float) * (CBS * lds_pitch(96) + 3 * CBS * (19 * 16 + 4));   // gO + red
     static bool granted = false;
     if (!granted) {
         hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32>),

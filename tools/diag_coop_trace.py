@@ -61,7 +61,7 @@ for _ in range(3):
 tr = np.zeros(64 * 8, dtype=np.uint64)
 assert lib.s2ag_gru_coop_trace_read(tr.ctypes.data_as(C.c_void_p)) == 0
 tr = tr.reshape(64, 8)[:T].astype(np.int64)
-names = ['gate grads', 'publish+stores', 'gather', 'barrier', 'mfma+red']
+names = ['gate grads+stores', 'barrier', 'mfma', 'publish', 'gather']
 print('BACKWARD\nstep  rounds ' + ' '.join(f'{n:>14s}' for n in names) + '   step total (us)')
 for s in range(1, T - 2):
     d = [(tr[s, i + 1] - tr[s, i]) / 100.0 for i in range(5)]
