@@ -1027,7 +1027,11 @@ extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float
     p.ks = g->ksize; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil; p.ldx = g->ldx; p.ldg = g->ldy;
     p.wtm = g->w_tap_major;
     const int tiles = cdiv(g->Cout, BM) * cdiv(g->ksize * g->Cin, BN);
-    int nsplit = cdiv(1024, tiles);
+    // split of the clips*frames axis: the straight-line kernel (stride-1 layers) likes ~384 blocks -- longer K loops, a
+    // third of the merge atomics (sweep 256...1024 in the full step); the general kernels keep ~1024
+    const bool lin_ok = use_gemm_lin() && g->stride == 1 && g->Lin == g->Lout &&
+                        ((g->Lin == 1 && g->pad == 0 && g->ksize == 1) || g->Lin >= BK2);
+    int nsplit = cdiv(lin_ok ? 384 : 1024, tiles);
     const int max_split = cdiv(p.Mtot, 4 * BK);
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;

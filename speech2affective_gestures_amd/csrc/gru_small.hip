@@ -20,6 +20,10 @@ constexpr int KSPLIT = 2; // unit's W_hh rows (96 registers at H = 64) and half 
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. every
+// step would wait for the acknowledgement of its own y / gate stores (~1 us) although the threads only talk through LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int H>
 __global__ __launch_bounds__(SNT) void gru_small_fwd_k(const float* __restrict__ gi, const float* __restrict__ whh,
                                                           const float* __restrict__ bhh, float* __restrict__ y,
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(SNT) void gru_small_fwd_k(const float* __restrict__
         gir = gir_n;
         giz = giz_n;
         gin = gin_n;
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(SNT) void gru_small_bwd_k(const float* __restrict__
             gs[b][H + i] = dz;
             gs[b][2 * H + i] = dnr;
         }
-        __syncthreads();
+        lds_barrier();
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < HK3; k += 4) {
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(SNT) void gru_small_bwd_k(const float* __restrict__
         acc += __shfl_xor(acc, 1, 64);
         dh = carry + acc;
         cu = nx;
-        __syncthreads();
+        lds_barrier();
     }
 }
 }  // namespace
