@@ -11,6 +11,8 @@
 // K tail, and every MFMA is unconditional (rows / columns outside the matrix are zero in LDS; the epilogue masks them).
 // Requirements (checked by the host, else the general kernel runs): K % 4 == 0, lda % 4 == 0, 16-byte aligned a and w,
 // and for bwd N-contiguous W rows.
+#include <stdlib.h>
+
 #include "s2ag_common.h"
 
 namespace {
@@ -236,6 +238,10 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+inline long long bm64_min_blocks() {
+    static const long long v = [] { const char* e = getenv("S2AG_BM64_MIN"); return e ? atoll(e) : 512LL; }();
+    return v;
+}
 }  // namespace
 
 // Internal entry points used by s2ag_conv1d_nlc_fwd / s2ag_conv1d_nlc_bwd_data (conv_gemm.hip) for 1-tap geometries.
@@ -249,7 +255,7 @@ int s2ag_gemm_lin_fwd(const float* x, const float* w, const float* bias, float* 
     p.act = act; p.slope = slope; p.drop_p = drop_p; p.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     p.rng = rng; p.site = site; p.accumulate = 0;
     const int colb = cdiv(N, 64);
-    if ((long long)cdiv(M, 64) * colb >= 512)
+    if ((long long)cdiv(M, 64) * colb >= bm64_min_blocks())
         hipLaunchKernelGGL((gemm_lin_k<false, 64, false>), dim3(cdiv(M, 64), colb), dim3(512), 0, stream, p);
     else
         hipLaunchKernelGGL((gemm_lin_k<false, 32, false>), dim3(cdiv(M, 32), colb), dim3(512), 0, stream, p);
@@ -264,7 +270,7 @@ int s2ag_gemm_lin_bwd_data(const float* gy, const float* w, float* dx, int M, in
     p.a = gy; p.w = w; p.bias = nullptr; p.out = dx; p.M = M; p.K = Cout; p.N = Cin; p.lda = ldg; p.ldo = ldx; p.ldw = Cin;
     p.act = 0; p.slope = 1.f; p.drop_p = 0.f; p.inv_keep = 1.f; p.rng = nullptr; p.site = 0; p.accumulate = accumulate;
     const int colb = cdiv(Cin, 64);
-    if ((long long)cdiv(M, 64) * colb >= 512)
+    if ((long long)cdiv(M, 64) * colb >= bm64_min_blocks())
         hipLaunchKernelGGL((gemm_lin_k<true, 64, false>), dim3(cdiv(M, 64), colb), dim3(512), 0, stream, p);
     else
         hipLaunchKernelGGL((gemm_lin_k<true, 32, false>), dim3(cdiv(M, 32), colb), dim3(512), 0, stream, p);
@@ -286,7 +292,7 @@ int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, flo
     p.act = act; p.slope = slope; p.drop_p = drop_p; p.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     p.rng = rng; p.site = site; p.accumulate = 0;
     const int colb = cdiv(Cout, 64);
-    if ((long long)cdiv(p.M, 64) * colb >= 512)
+    if ((long long)cdiv(p.M, 64) * colb >= bm64_min_blocks())
         hipLaunchKernelGGL((gemm_lin_k<false, 64, true>), dim3(cdiv(p.M, 64), colb), dim3(512), 0, stream, p);
     else
         hipLaunchKernelGGL((gemm_lin_k<false, 32, true>), dim3(cdiv(p.M, 32), colb), dim3(512), 0, stream, p);
@@ -302,7 +308,7 @@ int s2ag_gemm_conv_tm_bwd_data(const float* gy, const float* w, float* dx, int n
     p.CK = Cout; p.ks = ks; p.dil = dil; p.L = L; p.off = pad;
     p.act = 0; p.slope = 1.f; p.drop_p = 0.f; p.inv_keep = 1.f; p.rng = nullptr; p.site = 0; p.accumulate = accumulate;
     const int colb = cdiv(Cin, 64);
-    if ((long long)cdiv(p.M, 64) * colb >= 512)
+    if ((long long)cdiv(p.M, 64) * colb >= bm64_min_blocks())
         hipLaunchKernelGGL((gemm_lin_k<true, 64, true>), dim3(cdiv(p.M, 64), colb), dim3(512), 0, stream, p);
     else
         hipLaunchKernelGGL((gemm_lin_k<true, 32, true>), dim3(cdiv(p.M, 32), colb), dim3(512), 0, stream, p);
