@@ -116,6 +116,18 @@ int s2ag_bn_bwd_stats(const float* x, const float* dy, int rows, int cols, int l
                       const float* shift_col, const float* mean_col, const float* invstd_col, float slope,
                       const int* chan_of_col /*nullable*/, int nchan, float* dgamma, float* dbeta, int accumulate,
                       float* partials, int* ticket, float* c1_col, float* c2_col, void* stream);
+/* A layer that is followed by a training-mode BatchNorm can leave the batch statistics behind: the forward kernel
+ * writes per-row-block column sums of its output and of its square to `partials` ((2, *stat_rows, Cout) doubles, sized
+ * with s2ag_conv_stats_rows) and s2ag_bn_fold turns them into the coefficients -- no separate pass over the matrix.
+ * *stat_rows == 0 on return: this geometry has no statistics epilogue, use s2ag_bn_fwd_stats. */
+int s2ag_conv_stats_rows(const s2ag_conv_geom* g /*host*/);
+int s2ag_conv1d_nlc_fwd_stats(const float* x, const float* w, const float* bias, float* y, const s2ag_conv_geom* g,
+                              const s2ag_epilogue* e /*host, nullable*/, double* partials, int* stat_rows /*host*/,
+                              void* stream);
+int s2ag_bn_fold(const double* partials, int partial_rows, int rows, int cols, const int* chan_of_col /*nullable*/,
+                 int nchan, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                 long long* num_batches_tracked /*nullable*/, float eps, float momentum, int repeat, float* scale_col,
+                 float* shift_col, float* mean_col, float* invstd_col, void* stream);
 /* y = leaky(x*scale_col + shift_col, slope) */
 int s2ag_bn_apply(const float* x, int rows, int cols, int ldx, const float* scale_col, const float* shift_col,
                   float slope, float* y, int ldy, void* stream);

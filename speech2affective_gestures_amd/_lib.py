@@ -45,6 +45,9 @@ SIGNATURES = {
     's2ag_bn_partial_rows': [ci, ci, ci],
     's2ag_bn_fwd_stats': [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp],
     's2ag_bn_bwd_stats': [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp],
+    's2ag_conv_stats_rows': [PG],
+    's2ag_conv1d_nlc_fwd_stats': [vp, vp, vp, vp, PG, PE, vp, vp, vp],
+    's2ag_bn_fold': [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp],
     's2ag_bn_apply': [vp, ci, ci, ci, vp, vp, cf, vp, ci, vp],
     's2ag_bn_bwd_reduce': [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp],
     's2ag_bn_bwd_coeffs': [vp, vp, vp, ci, ci, ci, vp, vp, ci, vp, vp, vp],

@@ -927,7 +927,7 @@ static bool use_gemm_lin() {
 
 // gemm_lin.hip
 int s2ag_gemm_lin_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int ldx, int ldy,
-                      int act, float slope, float drop_p, const unsigned long long* rng, unsigned site,
+                      int act, float slope, float drop_p, const unsigned long long* rng, unsigned site, double* stats,
                       hipStream_t stream);
 int s2ag_gemm_lin_bwd_data(const float* gy, const float* w, float* dx, int M, int Cout, int Cin, int ldg, int ldx,
                            int accumulate, hipStream_t stream);
@@ -935,14 +935,15 @@ int s2ag_wgrad_lin(const float* gy, const float* x, float* dw, float* db, int nc
                    int pad, int dil, int ldx, int ldg, int wtm, int chunk, int nsplit, hipStream_t stream);
 int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, float* y, int nclips, int L, int Cin,
                           int Cout, int ks, int pad, int dil, int ldx, int ldy, int act, float slope, float drop_p,
-                          const unsigned long long* rng, unsigned site, hipStream_t stream);
+                          const unsigned long long* rng, unsigned site, double* stats, hipStream_t stream);
 int s2ag_gemm_conv_tm_bwd_data(const float* gy, const float* w, float* dx, int nclips, int L, int Cin, int Cout, int ks,
                                int pad, int dil, int ldg, int ldx, int accumulate, hipStream_t stream);
 
 extern "C" int s2ag_abi_version(void) { return S2AG_ABI_VERSION; }
 
-extern "C" int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* bias, float* y,
-                                   const s2ag_conv_geom* g, const s2ag_epilogue* e, void* stream) {
+static int conv1d_nlc_fwd_impl(const float* x, const float* w, const float* bias, float* y, const s2ag_conv_geom* g,
+                               const s2ag_epilogue* e, double* stats, int* stat_rows, void* stream) {
+    if (stat_rows) *stat_rows = 0;
     if (bad_geom(g) || !x || !w || !y) return S2AG_E_BADARG;
     if (e && e->drop_p > 0.f && !e->rng) return S2AG_E_BADARG;
     if (e && (e->drop_p < 0.f || e->drop_p >= 1.f)) return S2AG_E_BADARG;
@@ -959,18 +960,21 @@ extern "C" int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* 
     p.rng = e ? e->rng : nullptr;
     p.site = e ? e->site : 0;
     p.accumulate = 0;
+    int rows_ = 0;
     // 1-tap layers (Linear, GRU projections, 1x1 convs): the straight-line kernel of gemm_lin.hip
     if (use_gemm_lin() && g->ksize == 1 && g->stride == 1 && g->pad == 0 && g->Lin == g->Lout &&
-        s2ag_gemm_lin_fwd(x, w, bias, y, p.M, g->Cin, g->Cout, g->ldx, g->ldy, p.act, p.slope, p.drop_p, p.rng, p.site,
-                          (hipStream_t)stream)) {
+        (rows_ = s2ag_gemm_lin_fwd(x, w, bias, y, p.M, g->Cin, g->Cout, g->ldx, g->ldy, p.act, p.slope, p.drop_p, p.rng,
+                                   p.site, stats, (hipStream_t)stream))) {
         S2AG_LAUNCH_CHECK();
+        if (stat_rows && stats) *stat_rows = rows_;
         return 0;
     }
     // stride-1 convs with tap-major weights (TCN, folded ST-GCN): the same straight-line kernel with (tap, channel) tracking
     if (use_gemm_lin() && g->ksize > 1 && g->w_tap_major && g->stride == 1 && g->Lin == g->Lout &&
-        s2ag_gemm_conv_tm_fwd(x, w, bias, y, g->N, g->Lin, g->Cin, g->Cout, g->ksize, g->pad, g->dil, g->ldx, g->ldy,
-                              p.act, p.slope, p.drop_p, p.rng, p.site, (hipStream_t)stream)) {
+        (rows_ = s2ag_gemm_conv_tm_fwd(x, w, bias, y, g->N, g->Lin, g->Cin, g->Cout, g->ksize, g->pad, g->dil, g->ldx,
+                                       g->ldy, p.act, p.slope, p.drop_p, p.rng, p.site, stats, (hipStream_t)stream))) {
         S2AG_LAUNCH_CHECK();
+        if (stat_rows && stats) *stat_rows = rows_;
         return 0;
     }
     const bool vec = (g->Cin % 4 == 0) && (g->ldx % 4 == 0) && aligned16(x);
@@ -980,6 +984,23 @@ extern "C" int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* 
         launch_gemm2<false, false>(p, (hipStream_t)stream);
     S2AG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int s2ag_conv1d_nlc_fwd(const float* x, const float* w, const float* bias, float* y,
+                                   const s2ag_conv_geom* g, const s2ag_epilogue* e, void* stream) {
+    return conv1d_nlc_fwd_impl(x, w, bias, y, g, e, nullptr, nullptr, stream);
+}
+
+extern "C" int s2ag_conv_stats_rows(const s2ag_conv_geom* g) {
+    if (bad_geom(g)) return S2AG_E_BADARG;
+    return 2 * cdiv((long long)g->N * g->Lout, 32);
+}
+
+extern "C" int s2ag_conv1d_nlc_fwd_stats(const float* x, const float* w, const float* bias, float* y,
+                                         const s2ag_conv_geom* g, const s2ag_epilogue* e, double* partials,
+                                         int* stat_rows, void* stream) {
+    if (!partials || !stat_rows) return S2AG_E_BADARG;
+    return conv1d_nlc_fwd_impl(x, w, bias, y, g, e, partials, stat_rows, stream);
 }
 
 extern "C" int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* dx, const s2ag_conv_geom* g,

@@ -34,6 +34,8 @@ struct LinP {
     int ks, dil;
     int L;                       // frames per clip (Lin == Lout)
     int off;                     // source frame of tap 0 for output frame 0: fwd -pad, bwd +pad (bwd steps by -dil)
+    double* stats;               // fwd, nullable: per-row-block column sums of the output and of its square,
+                                 // layout (2, gridDim.x, N) -- the BatchNorm that follows folds them (s2ag_bn_fold)
     int act;
     float slope, drop_p, inv_keep;
     const unsigned long long* rng;
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
     SiteKey key{0, 0};
     const bool drop = (!BWD) && p.drop_p > 0.f;
     if (drop) key = site_key(p.rng, p.site);
+    const bool want_stats = (!BWD) && p.stats != nullptr;       // block-uniform
 #pragma unroll
     for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
@@ -230,11 +233,42 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
                     v = apply_act(v + bias, p.act, p.slope);
                     if (drop) v *= keep_scale(key, (unsigned long long)row * p.N + c, p.drop_p, p.inv_keep);
                     *dst = v;
+                    acc[ti][tj][q] = v;                          // what the statistics are taken of
                 } else {
                     *dst = p.accumulate ? (*dst + v) : v;
                 }
             }
         }
+    if (want_stats) {
+        // Column sums of this wave's output rows (fp64 from the first add: E[x^2] - E[x]^2 cancels in fp32) for the
+        // BatchNorm that follows the layer -- saves it a pass over the matrix.  One partial row per (row block, row
+        // wave); lanes that share a column (lane >> 4 = 0..3) meet in two DPP steps.
+        const size_t R = (size_t)gridDim.x * WM, r = (size_t)blockIdx.x * WM + wr;
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = m0 + (wr * TM + ti) * 16 + (lane >> 4) * 4 + q;
+                    if (row < p.M) {
+                        const double v = (double)acc[ti][tj][q];
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                }
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const int c = n0 + (wc * TN + tj) * 16 + lane;
+            if (lane < 16 && c < p.N) {
+                p.stats[r * p.N + c] = s1;
+                p.stats[(R + r) * p.N + c] = s2;
+            }
+        }
+    }
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -246,20 +280,22 @@ inline long long bm64_min_blocks() {
 
 // Internal entry points used by s2ag_conv1d_nlc_fwd / s2ag_conv1d_nlc_bwd_data (conv_gemm.hip) for 1-tap geometries.
 // Return 1 if the launch was taken, 0 if the shape / alignment is not covered (caller falls back to the general kernel).
+// `stats` (nullable): (2, rows, N) doubles, rows = the return value: per-partial-row column sums of y and y^2.
 int s2ag_gemm_lin_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int ldx, int ldy,
-                      int act, float slope, float drop_p, const unsigned long long* rng, unsigned site,
+                      int act, float slope, float drop_p, const unsigned long long* rng, unsigned site, double* stats,
                       hipStream_t stream) {
     if ((K & 3) || (ldx & 3) || !al16(x) || !al16(w)) return 0;
     LinP p{};
     p.a = x; p.w = w; p.bias = bias; p.out = y; p.M = M; p.K = K; p.N = N; p.lda = ldx; p.ldo = ldy; p.ldw = K;
     p.act = act; p.slope = slope; p.drop_p = drop_p; p.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    p.rng = rng; p.site = site; p.accumulate = 0;
+    p.rng = rng; p.site = site; p.accumulate = 0; p.stats = stats;
     const int colb = cdiv(N, 64);
-    if ((long long)cdiv(M, 64) * colb >= bm64_min_blocks())
+    if ((long long)cdiv(M, 64) * colb >= bm64_min_blocks()) {
         hipLaunchKernelGGL((gemm_lin_k<false, 64, false>), dim3(cdiv(M, 64), colb), dim3(512), 0, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_lin_k<false, 32, false>), dim3(cdiv(M, 32), colb), dim3(512), 0, stream, p);
-    return 1;
+        return 2 * cdiv(M, 64);
+    }
+    hipLaunchKernelGGL((gemm_lin_k<false, 32, false>), dim3(cdiv(M, 32), colb), dim3(512), 0, stream, p);
+    return 2 * cdiv(M, 32);
 }
 
 int s2ag_gemm_lin_bwd_data(const float* gy, const float* w, float* dx, int M, int Cout, int Cin, int ldg, int ldx,
@@ -283,20 +319,21 @@ int s2ag_gemm_lin_bwd_data(const float* gy, const float* w, float* dx, int M, in
 //   bwd  dx[(n,p), ci] (+)= sum_{t,co} gy[(n, p + pad - t*dil), co] w[co, t, ci]
 int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, float* y, int nclips, int L, int Cin,
                           int Cout, int ks, int pad, int dil, int ldx, int ldy, int act, float slope, float drop_p,
-                          const unsigned long long* rng, unsigned site, hipStream_t stream) {
+                          const unsigned long long* rng, unsigned site, double* stats, hipStream_t stream) {
     if ((Cin & 3) || Cin < LBK || (ldx & 3) || !al16(x) || !al16(w)) return 0;
     LinP p{};
     p.a = x; p.w = w; p.bias = bias; p.out = y; p.M = nclips * L; p.K = ks * Cin; p.N = Cout;
     p.lda = ldx; p.ldo = ldy; p.ldw = ks * Cin;
     p.CK = Cin; p.ks = ks; p.dil = dil; p.L = L; p.off = -pad;
     p.act = act; p.slope = slope; p.drop_p = drop_p; p.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    p.rng = rng; p.site = site; p.accumulate = 0;
+    p.rng = rng; p.site = site; p.accumulate = 0; p.stats = stats;
     const int colb = cdiv(Cout, 64);
-    if ((long long)cdiv(p.M, 64) * colb >= bm64_min_blocks())
+    if ((long long)cdiv(p.M, 64) * colb >= bm64_min_blocks()) {
         hipLaunchKernelGGL((gemm_lin_k<false, 64, true>), dim3(cdiv(p.M, 64), colb), dim3(512), 0, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_lin_k<false, 32, true>), dim3(cdiv(p.M, 32), colb), dim3(512), 0, stream, p);
-    return 1;
+        return 2 * cdiv(p.M, 64);
+    }
+    hipLaunchKernelGGL((gemm_lin_k<false, 32, true>), dim3(cdiv(p.M, 32), colb), dim3(512), 0, stream, p);
+    return 2 * cdiv(p.M, 32);
 }
 
 int s2ag_gemm_conv_tm_bwd_data(const float* gy, const float* w, float* dx, int nclips, int L, int Cin, int Cout, int ks,

@@ -351,6 +351,24 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_k(const float* s1, const fl
 
 // BatchNorm backward statistics in ONE launch (see bn_fwd_stats_k): partial column sums of dpre and dpre*xhat per row
 // block, folded by the last block into dgamma / dbeta (+=) and the per-column c1, c2 of the dx formula.
+// The producing layer already left per-row-block column sums (conv_gemm / gemm_lin epilogue): only the fold is left.
+__global__ __launch_bounds__(1024) void bn_fold_k(const double* part, int prow, int rows, int cols, const int* chan_of_col,
+                                                  int nchan, const float* gamma, const float* beta, float* rmean,
+                                                  float* rvar, long long* nbt, float eps, float momentum, int repeat,
+                                                  float* scale_col, float* shift_col, float* mean_col,
+                                                  float* invstd_col) {
+    extern __shared__ double smd[];
+    double* cs = smd;
+    double* cq = smd + nchan;
+    double* cn = smd + 2 * nchan;
+    for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) smd[i] = 0.0;
+    __syncthreads();
+    fold_partials<double, double, 1024>(part, prow, cols, chan_of_col, cs, cq, cn);
+    __syncthreads();
+    bn_finish_coeffs(cs, cq, cn, chan_of_col, cols, nchan, rows, gamma, beta, rmean, rvar, nbt, eps, momentum, 1,
+                     scale_col, shift_col, mean_col, invstd_col, repeat);
+}
+
 template <bool FLAT, int NT>
 __global__ __launch_bounds__(NT) void bn_bwd_stats_k(const float* __restrict__ x, const float* __restrict__ dy,
                                                       int rows, int cols, int ldx, int lddy, int rpb,
@@ -564,6 +582,20 @@ extern "C" int s2ag_bn_fwd_stats(const float* x, int rows, int cols, int ldx, co
         hipLaunchKernelGGL((bn_fwd_stats_k<false, 1024>), dim3(cb, nrb), dim3(1024), smem, (hipStream_t)stream, x, rows, cols,
                            ldx, rpb, partials, ticket, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt,
                            eps, momentum, scale_col, shift_col, mean_col, invstd_col, repeat);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_bn_fold(const double* partials, int partial_rows, int rows, int cols, const int* chan_of_col,
+                            int nchan, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            long long* nbt, float eps, float momentum, int repeat, float* scale_col, float* shift_col,
+                            float* mean_col, float* invstd_col, void* stream) {
+    if (!partials || partial_rows <= 0 || rows <= 0 || cols <= 0 || nchan <= 0 || repeat < 1 || !gamma || !beta ||
+        !running_mean || !running_var || !scale_col || !shift_col || !mean_col || !invstd_col)
+        return S2AG_E_BADARG;
+    hipLaunchKernelGGL(bn_fold_k, dim3(1), dim3(1024), sizeof(double) * 3 * nchan, (hipStream_t)stream, partials,
+                       partial_rows, rows, cols, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt, eps,
+                       momentum, repeat, scale_col, shift_col, mean_col, invstd_col);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

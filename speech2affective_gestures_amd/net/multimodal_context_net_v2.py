@@ -142,7 +142,7 @@ class MFCCEncoder(nn.Module):
         x = mfcc_data
         for conv, bn, pad in ((self.conv1, self.batch_norm1, 2), (self.conv2, self.batch_norm2, 2),
                               (self.conv3, self.batch_norm3, 1), (self.conv4, self.batch_norm4, 1)):
-            x = ops.batch_norm_act(ops.conv1d_nlc(x, conv.weight, conv.bias, pad=pad), bn, slope=0.3)
+            x = ops.batch_norm_act(ops.conv1d_nlc(x, conv.weight, conv.bias, pad=pad, bn_stats=True), bn, slope=0.3)
         x = x.transpose(1, 2).contiguous()                            # (B, time_steps, num_mfcc): layout glue only
         return ops.linear(x, self.linear1.weight, self.linear1.bias, act=ACT_LEAKY, slope=0.3)
 

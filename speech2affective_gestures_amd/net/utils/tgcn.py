@@ -186,12 +186,12 @@ class STGraphConv(nn.Module):
         """x (N, T, V*Cin) with column order ``in_col`` -> (N, T, V*Cout) in column order ``out_col``."""
         grp, cmap = self._fold_group(A, in_col, out_col, x.device)
         f = grp.tensors()
-        g = ops.conv1d_nlc(x, f[0], f[1], pad=self.gcn.pad, w_tap_major=True)                  # graph conv + einsum
+        g = ops.conv1d_nlc(x, f[0], f[1], pad=self.gcn.pad, w_tap_major=True, bn_stats=True)                  # graph conv + einsum
         h = ops.batch_norm_act(g, self.tcn[0], slope=0.0, chan_map=cmap)                       # BN2d + ReLU
-        h = ops.conv1d_nlc(h, f[2], f[3], pad=self.kt // 2, w_tap_major=True)
+        h = ops.conv1d_nlc(h, f[2], f[3], pad=self.kt // 2, w_tap_major=True, bn_stats=True)
         h = ops.batch_norm_act(h, self.tcn[3], slope=1.0, chan_map=cmap)
         if isinstance(self.residual, nn.Module):
-            r = ops.conv1d_nlc(x, f[4], f[5], w_tap_major=True)
+            r = ops.conv1d_nlc(x, f[4], f[5], w_tap_major=True, bn_stats=True)
             r = ops.batch_norm_act(r, self.residual[1], slope=1.0, chan_map=cmap)
             return ops.add_act(h, r, self.slope)
         return ops.add_act(h, None, self.slope)

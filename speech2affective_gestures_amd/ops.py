@@ -81,7 +81,7 @@ def _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy, wtm=0):
 # raw (non-autograd) launch helpers
 # ----------------------------------------------------------------------------------------------------
 def conv_fwd_raw(x: Tensor, w: Tensor, bias: Optional[Tensor], y: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad,
-                 dil, act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0, wtm=0):
+                 dil, act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0, wtm=0, stats_out=None):
     x, xr, xc, ldx = as_rows(x)
     _, yr, yc, ldy = as_rows(y)
     assert xr == N * Lin and xc == Cin, (xr, xc, N, Lin, Cin)
@@ -89,7 +89,17 @@ def conv_fwd_raw(x: Tensor, w: Tensor, bias: Optional[Tensor], y: Tensor, N, Lin
     assert w.is_contiguous() and w.numel() == Cout * Cin * ks
     g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy, wtm)
     e = _epi(act, slope, drop_p, noise, site)
-    L.check(_lib().s2ag_conv1d_nlc_fwd(_p(x), _p(w), _p(bias), _p(y), C.byref(g), C.byref(e), _stream()), 'conv_fwd')
+    if stats_out is None:
+        L.check(_lib().s2ag_conv1d_nlc_fwd(_p(x), _p(w), _p(bias), _p(y), C.byref(g), C.byref(e), _stream()), 'conv_fwd')
+        return None
+    # the layer feeds a training-mode BatchNorm: let the kernel leave per-row-block column sums behind
+    lib = _lib()
+    rows = lib.s2ag_conv_stats_rows(C.byref(g))
+    part = torch.empty(2 * rows * Cout, dtype=torch.float64, device=y.device)
+    got = C.c_int(0)
+    L.check(lib.s2ag_conv1d_nlc_fwd_stats(_p(x), _p(w), _p(bias), _p(y), C.byref(g), C.byref(e), _p(part),
+                                          C.byref(got), _stream()), 'conv_fwd_stats')
+    return (part, got.value) if got.value > 0 else None
 
 
 def conv_bwd_data_raw(gy: Tensor, w: Tensor, dx: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, accumulate,
@@ -251,7 +261,9 @@ class _ConvNLC(torch.autograd.Function):
         ctx.w_leaf, ctx.b_leaf = w, bias                   # for direct accumulation into .grad (see _grad_slot)
         w = w.contiguous()
         y = torch.empty(N * Lout, Cout, dtype=torch.float32, device=x.device)
-        conv_fwd_raw(x, w, bias, y, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, act, slope, drop_p, noise, site, wtm)
+        st = conv_fwd_raw(x, w, bias, y, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, act, slope, drop_p, noise, site,
+                          wtm, stats_out=True if _WANT_STATS[0] else None)
+        _LAST_STATS[0] = st
         ctx.geom, ctx.epi = geom, (act, slope, drop_p, site)
         ctx.noise = noise
         ctx.has_bias = bias is not None
@@ -301,11 +313,17 @@ class _ConvNLC(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
+BN_STATS_EPILOGUE = __import__('os').environ.get('S2AG_BN_EPILOGUE', '1') != '0'
+_WANT_STATS = [False]
+_LAST_STATS = [None]
+
+
 def conv1d_nlc(x: Tensor, w: Tensor, bias: Optional[Tensor], stride=1, pad=0, dil=1, lout: Optional[int] = None,
-               act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0, w_tap_major=False) -> Tensor:
+               act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0, w_tap_major=False, bn_stats=False) -> Tensor:
     """x (N, Lin, Cin) channels-last, w (Cout, Cin, k) [or (Cout, k, Cin) if ``w_tap_major``] -> (N, Lout, Cout).
     ``lout`` overrides the usual output length (the TCN's causal conv + chomp is pad = (k-1)*dil on the left with
-    lout = Lin)."""
+    lout = Lin).  ``bn_stats``: the output goes straight into a training-mode ``batch_norm_act``; where the kernel has a
+    statistics epilogue the column sums ride along (attribute on the returned tensor) and BatchNorm skips its own pass."""
     N, Lin, Cin = x.shape
     if w_tap_major:
         Cout, ks, Cin_w = w.shape
@@ -314,9 +332,17 @@ def conv1d_nlc(x: Tensor, w: Tensor, bias: Optional[Tensor], stride=1, pad=0, di
     assert Cin_w == Cin, (w.shape, x.shape)
     if lout is None:
         lout = (Lin + 2 * pad - dil * (ks - 1) - 1) // stride + 1
-    out = _ConvNLC.apply(x, w, bias, (N, Lin, lout, Cin, Cout, ks, stride, pad, dil, int(w_tap_major)), act,
-                         float(slope), float(drop_p), noise, site)
-    return out.view(N, lout, Cout)
+    _WANT_STATS[0] = bool(bn_stats) and BN_STATS_EPILOGUE
+    try:
+        out = _ConvNLC.apply(x, w, bias, (N, Lin, lout, Cin, Cout, ks, stride, pad, dil, int(w_tap_major)), act,
+                             float(slope), float(drop_p), noise, site)
+    finally:
+        _WANT_STATS[0] = False
+    out = out.view(N, lout, Cout)
+    if _LAST_STATS[0] is not None:
+        out._s2ag_stats = _LAST_STATS[0]        # (partials, rows): consumed by batch_norm_act on this very tensor
+    _LAST_STATS[0] = None
+    return out
 
 
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor], act=L.ACT_NONE, slope=1.0) -> Tensor:
@@ -332,6 +358,7 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor], act=L.ACT_NONE, slope=1
 # batch norm (+ leaky activation)
 # ----------------------------------------------------------------------------------------------------
 _BN_REPEAT = [1]
+_BN_PRE = [None]
 
 
 class bn_repeat:
@@ -364,7 +391,14 @@ class _BNAct(torch.autograd.Function):
         nchan = gamma.numel()
         dev = x.device
         coef = torch.empty(4, cols, dtype=torch.float32, device=dev)
-        if training:
+        pre = _BN_PRE[0]
+        _BN_PRE[0] = None
+        if training and pre is not None:
+            part, prow = pre        # column sums left behind by the producing layer: only the fold remains
+            L.check(lib.s2ag_bn_fold(_p(part), int(prow), rows, cols, _p(chan_map), nchan, _p(gamma), _p(beta), _p(rmean),
+                                     _p(rvar), _p(nbt), float(eps), float(momentum), int(_BN_REPEAT[0]), _p(coef[0]),
+                                     _p(coef[1]), _p(coef[2]), _p(coef[3]), _stream()), 'bn_fold')
+        elif training:
             # one launch: fp64 partial column sums per row block, folded into coefficients by the last block
             nrb = lib.s2ag_bn_partial_rows(rows, cols, ldx)
             part = torch.empty(2 * nrb * cols, dtype=torch.float64, device=dev)
@@ -422,6 +456,7 @@ def batch_norm_act(x: Tensor, bn: torch.nn.Module, slope: float = 1.0, chan_map:
     torch BatchNorm module used purely as the parameter/buffer container (state_dict compatibility)."""
     tr = bn.training if training is None else training
     shp = x.shape
+    _BN_PRE[0] = getattr(x, '_s2ag_stats', None) if tr else None
     y = _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                      bn.num_batches_tracked if tr else None, chan_map, float(slope), bool(tr), float(bn.eps),
                      float(bn.momentum))
