@@ -127,7 +127,7 @@ def gru_roofline(B, iters=20):
                 achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3, traffic=traffic,
                 traffic_source='profiles/r01_e_pmc_FETCH_SIZE.txt + r01_e_pmc_WRITE_SIZE.txt', ms_per_launch=ms,
                 algorithmic_flops_per_launch=flops,
-                note='sequential recurrence: per time step (tools/diag_coop_trace.py, profiles/r01_f_coop_gru_phase_trace.txt) '
+                note='sequential recurrence: per time step (tools/diag_coop_trace.py, profiles/r01_h_coop_gru_phase_trace.txt) '
                      '~1.0 us tagged-cell gather of h, 1.9 us for 12 waves x 38 fp32 MFMAs on one CU (the pipe itself: '
                      '3 waves/SIMD x 38 x 32 cycles), 0.4 us gate math, 0.3 us stores; 160 of 256 CUs hold W_hh in registers')
 
