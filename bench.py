@@ -119,13 +119,13 @@ def gru_roofline(B, iters=20):
     ms = sum(a.elapsed_time(b) for a, b in evs) / iters
     flops = 2.0 * B * T * 2 * H * 3 * H           # recurrent mat-vec MACs x2, both directions
     achieved = flops / (ms * 1e-3) / 1e12
-    # HBM/fabric bytes per launch from the PMC passes committed under profiles/r01_e_pmc_* (rocprofv3 --pmc FETCH_SIZE
-    # and WRITE_SIZE in separate runs, KB units, FETCH doubled as the gfx950 guide prescribes): gi + exchange reads,
-    # y / ydrop / saved-gate writes.  Only meaningful at the profiled shape (B = 128).
-    traffic = (2 * 77094.1 + 51872.2) * 1024 if (coop and B == 128) else None
-    return dict(bound='mfma', kernel=('gru_coop_fwd_k<300,32,1>' if coop else 'gru_seq_fwd_k<8>') + ' (H=300, T=34, 2 directions)',
+    # HBM/fabric bytes per launch from the PMC passes committed under profiles/r01_h_pmc_* (rocprofv3 --pmc FETCH_SIZE
+    # and WRITE_SIZE in separate runs, KB units, FETCH doubled as the gfx950 guide prescribes): gi + exchange-cell
+    # reads, y / ydrop / saved-gate / exchange-cell writes.  Only meaningful at the profiled shape (B = 128).
+    traffic = (2 * 118122.0 + 61589.0) * 1024 if (coop and B == 128) else None
+    return dict(bound='mfma', kernel=('gru_coop_fwd_k<300,32>' if coop else 'gru_seq_fwd_k<8>') + ' (H=300, T=34, 2 directions)',
                 achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3, traffic=traffic,
-                traffic_source='profiles/r01_e_pmc_FETCH_SIZE.txt + r01_e_pmc_WRITE_SIZE.txt', ms_per_launch=ms,
+                traffic_source='profiles/r01_h_pmc_FETCH_SIZE.txt + r01_h_pmc_WRITE_SIZE.txt', ms_per_launch=ms,
                 algorithmic_flops_per_launch=flops,
                 note='sequential recurrence: per time step (tools/diag_coop_trace.py, profiles/r01_h_coop_gru_phase_trace.txt) '
                      '~1.0 us tagged-cell gather of h, 1.9 us for 12 waves x 38 fp32 MFMAs on one CU (the pipe itself: '
