@@ -95,6 +95,88 @@ def test_conv1d_nlc_forward_backward(S, case):
     assert rel(bg.grad, br.grad) < TOL
 
 
+# (N, L, Cin, Cout, k, pad, dil, causal): stride-1 layers with TAP-MAJOR weights -> the straight-line kernels of gemm_lin.hip
+# (forward, data gradient and weight gradient), with K / row / column tails and every padding style on the path
+TM_CASES = [
+    (128, 34, 300, 300, 2, 4, 4, True),       # TCN level 2 at full batch (64-row tiles, K = 600 = 18.75 tiles)
+    (3, 34, 300, 300, 2, 8, 8, True),         # few rows: 32-row tiles, ragged last row block
+    (5, 34, 144, 48, 3, 1, 1, False),         # folded ST-GCN conv: "same" padding, Cout < 64
+    (2, 40, 36, 100, 9, 4, 1, False),         # 9 taps, channel count not a multiple of 32 (chunks straddle taps)
+    (7, 33, 64, 64, 1, 0, 1, False),          # 1 tap through the tap-major entry (ks == 1)
+    (1, 32, 32, 17, 3, 1, 1, False),          # smallest supported clip length / channel count, odd Cout
+]
+
+
+@pytest.mark.parametrize('case', TM_CASES)
+def test_tap_major_conv_straight_line_kernels(S, case):
+    ops = S['ops']
+    N, Ln, Cin, Cout, k, pad, dil, causal = case
+    g = torch.Generator().manual_seed(sum(case[:7]))
+    x = torch.randn(N, Ln, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    if causal:
+        yr = F.conv1d(xr.transpose(1, 2), wr, br, padding=pad, dilation=dil)[:, :, :-pad].transpose(1, 2)
+    else:
+        yr = F.conv1d(xr.transpose(1, 2), wr, br, padding=pad, dilation=dil).transpose(1, 2)
+    xg, bg = x.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    wtm = w.permute(0, 2, 1).contiguous().cuda().requires_grad_(True)            # (Cout, k, Cin)
+    yg = ops.conv1d_nlc(xg, wtm, bg, pad=pad, dil=dil, lout=Ln, w_tap_major=True, bn_stats=True)
+    assert rel(yg, yr) < TOL
+    st = getattr(yg, '_s2ag_stats', None)       # column sums left by the epilogue (absent where the general kernel ran)
+    if st is not None:
+        part, rows = st
+        part = part.view(2, rows, Cout).sum(1).cpu()
+        flat = yr.detach().reshape(-1, Cout).double()
+        assert rel(part[0], flat.sum(0)) < 1e-6 and rel(part[1], (flat * flat).sum(0)) < 1e-6
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.cuda())
+    assert rel(xg.grad, xr.grad) < TOL
+    assert rel(wtm.grad.permute(0, 2, 1), wr.grad) < TOL
+    assert rel(bg.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize('M,K,N', [(4352, 600, 1800), (70, 36, 5), (33, 100, 64), (257, 88, 900), (64, 4, 16)])
+def test_linear_straight_line_kernels_with_tails(S, M, K, N):
+    """Linear forward / data gradient / weight gradient (+ bias gradient in the same launch) at shapes whose row, column
+    and K extents are not multiples of the 64 x 64 x 32 tile; the GRU projection shape at full size."""
+    ops = S['ops']
+    g = torch.Generator().manual_seed(M + K + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.linear(xr, wr, br)
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    yg = ops.linear(xg, wg, bg)
+    assert rel(yg, yr) < TOL
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.cuda())
+    assert rel(xg.grad, xr.grad) < TOL and rel(wg.grad, wr.grad) < TOL and rel(bg.grad, br.grad) < TOL
+
+
+def test_shifted_frame_weight_gradient(S):
+    """dW_hh of the GRU is a 1-tap weight gradient against the state shifted by one frame inside each clip (pad = +-1):
+    the straight-line kernel's frame-boundary test."""
+    ops = S['ops']
+    g = torch.Generator().manual_seed(77)
+    B, T, H, H3 = 9, 34, 40, 120
+    gy, h = torch.randn(B * T, H3, generator=g), torch.randn(B * T, H, generator=g)
+    for pad in (1, -1):
+        dw = torch.zeros(H3, H, device='cuda')
+        db = torch.zeros(H3, device='cuda')
+        ops.conv_bwd_weight_raw(gy.cuda(), h.cuda(), dw, B, T, T, H, H3, 1, 1, pad, 1, True, dbias=db)
+        hp = torch.zeros(B, T, H)
+        hv = h.view(B, T, H)
+        if pad == 1:
+            hp[:, 1:] = hv[:, :-1]
+        else:
+            hp[:, :-1] = hv[:, 1:]
+        ref = gy.t() @ hp.reshape(B * T, H)
+        assert rel(dw, ref) < TOL and rel(db, gy.sum(0)) < TOL
+
+
 def test_conv_reads_and_writes_column_slices(S):
     ops = S['ops']
     g = torch.Generator().manual_seed(3)
