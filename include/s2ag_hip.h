@@ -255,7 +255,9 @@ int s2ag_reparam_fwd(const float* mu, const float* log_var, int n, const unsigne
 int s2ag_reparam_bwd(const float* dz, const float* log_var, int n, const unsigned long long* rng, unsigned site,
                      float* dmu, float* dlog_var, void* stream);
 
-/* Discriminator loss -mean(log(d_real+1e-8) + log(1-d_fake+1e-8)) and its gradient; processor_v2.py:811. */
+/* Discriminator loss -mean(log(d_real+1e-8) + log(1-d_fake+1e-8)) and its gradient; processor_v2.py:811.
+ * Either of d_real / d_fake (with its gradient output) may be NULL: the loss is the sum of the two separable terms, so
+ * the real half can be back-propagated while the generator pass that produces the fake half is still running. */
 int s2ag_dis_loss(const float* d_real, const float* d_fake, int B, float* loss /*1*/, float* g_real, float* g_fake,
                   void* stream);
 /* Generator losses of processor_v2.py:893-937 (+ the L1 metric of :956) fused in two launches.

@@ -257,11 +257,17 @@ __global__ __launch_bounds__(256) void dis_loss_k(const float* dr, const float* 
     __shared__ float sm[4];
     float s = 0.f;
     const float invB = 1.f / (float)B;
-    for (int i = threadIdx.x; i < B; i += blockDim.x) {
-        const float a = dr[i] + 1e-8f, b = 1.f - df[i] + 1e-8f;
-        s += logf(a) + logf(b);
-        gr[i] = -invB / a;
-        gf[i] = invB / b;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {      // either half may be absent (the two terms are separable)
+        if (dr) {
+            const float a = dr[i] + 1e-8f;
+            s += logf(a);
+            gr[i] = -invB / a;
+        }
+        if (df) {
+            const float b = 1.f - df[i] + 1e-8f;
+            s += logf(b);
+            gf[i] = invB / b;
+        }
     }
     s = block_sum(s, sm);
     if (threadIdx.x == 0) loss[0] = -s * invB;
@@ -563,7 +569,7 @@ extern "C" int s2ag_reparam_bwd(const float* dz, const float* log_var, int n, co
 
 extern "C" int s2ag_dis_loss(const float* d_real, const float* d_fake, int B, float* loss, float* g_real,
                              float* g_fake, void* stream) {
-    if (!d_real || !d_fake || !loss || !g_real || !g_fake || B <= 0) return S2AG_E_BADARG;
+    if ((!d_real && !d_fake) || (d_real && !g_real) || (d_fake && !g_fake) || !loss || B <= 0) return S2AG_E_BADARG;
     hipLaunchKernelGGL(dis_loss_k, dim3(1), dim3(256), 0, (hipStream_t)stream, d_real, d_fake, B, loss, g_real, g_fake);
     S2AG_LAUNCH_CHECK();
     return 0;

@@ -622,6 +622,22 @@ def fold(w: Tensor, csr: CSR) -> Tensor:
 # derived parameters: folded / weight-normed tensors cached per optimizer step, gradients staged and flushed
 # ----------------------------------------------------------------------------------------------------
 _PENDING_FLUSH = []
+_LOCAL_BACKWARD = [False]
+
+
+class local_backward:
+    """Context for a ``backward()`` whose kernels all run on the CURRENT stream (a pass that lives entirely on one forked
+    stream): the end-of-backward flush of derived-parameter gradients then must not join the trainer's other side
+    streams (that would tie two forked streams together inside a capture and take them off the trainer's join list)."""
+
+    def __enter__(self):
+        self.prev = _LOCAL_BACKWARD[0]
+        _LOCAL_BACKWARD[0] = True
+
+    def __exit__(self, *a):
+        _LOCAL_BACKWARD[0] = self.prev
+
+
 _GENERATION = [0]
 
 
@@ -656,7 +672,8 @@ def flush_derived() -> None:
     """Route every staged gradient to its trainable sources (and leave the stages zeroed)."""
     if not _PENDING_FLUSH:
         return
-    join_side_streams()          # weight-gradient kernels that fill the stages may still run on forked streams
+    if not _LOCAL_BACKWARD[0]:
+        join_side_streams()      # weight-gradient kernels that fill the stages may still run on forked streams
     while _PENDING_FLUSH:
         _PENDING_FLUSH.pop().flush()
 
@@ -1030,6 +1047,30 @@ class _DisLoss(torch.autograd.Function):
 
 def dis_loss(d_real: Tensor, d_fake: Tensor) -> Tensor:
     return _DisLoss.apply(d_real, d_fake)
+
+
+class _DisLossHalf(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d, real):
+        _need_cuda(d)
+        d = d.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=d.device)
+        g = torch.empty_like(d)
+        a = (_p(d), None) if real else (None, _p(d))
+        b = (_p(g), None) if real else (None, _p(g))
+        L.check(_lib().s2ag_dis_loss(a[0], a[1], d.numel(), _p(loss), b[0], b[1], _stream()), 'dis_loss')
+        ctx.save_for_backward(g)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        (g,) = ctx.saved_tensors
+        return g * dl, None
+
+
+def dis_loss_half(d: Tensor, real: bool) -> Tensor:
+    """-mean(log(d + 1e-8)) for the real half, -mean(log(1 - d + 1e-8)) for the fake half: their sum is ``dis_loss``."""
+    return _DisLossHalf.apply(d, bool(real))
 
 
 class _GenLoss(torch.autograd.Function):

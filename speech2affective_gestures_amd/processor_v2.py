@@ -204,6 +204,8 @@ class Processor(object):
         # the generator's dropout-free encoders run once per step instead of once per pass (see PoseGenerator)
         self.share_encoders = bool(getattr(args, 'share_encoders', os.environ.get('S2AG_SHARE_ENCODERS', '1') != '0'))
         self.encoders_aside = bool(getattr(args, 'encoders_aside', os.environ.get('S2AG_ENCODERS_ASIDE', '1') != '0'))
+        self.early_real_backward = bool(getattr(args, 'early_real_backward',
+                                                os.environ.get('S2AG_EARLY_REAL_BWD', '1') != '0'))
         self.early_rand = bool(getattr(args, 'early_rand', os.environ.get('S2AG_EARLY_RAND', '1') != '0'))
         self._side = [torch.cuda.Stream(device=self.device) for _ in range(2)]
         self._graphed = None
@@ -301,11 +303,22 @@ class Processor(object):
             with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
                 out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
             ops.stamp('D:G(dis) end [main]')
+            l_real = None
+            real_fwd_done = torch.cuda.Event()
             with torch.cuda.stream(side), noise.use_pass(nz_real), ops.sequential_branches():
                 ops.stamp('D:D(real) begin [side]')
                 dis_real = self.s2ag_discriminator(target_poses, in_text)
                 ops.stamp('D:D(real) end [side]')
-            cur.wait_stream(side)
+                real_fwd_done.record(side)
+                if train and self.early_real_backward:
+                    # The D loss is the sum of a real and a fake term (processor_v2.py:811): the real half is
+                    # back-propagated HERE, on the forked stream, while the generator pass that produces the fake half
+                    # is still running -- only the fake half is left for the critical path behind D(fake).
+                    l_real = ops.dis_loss_half(dis_real, True)
+                    with ops.local_backward():
+                        l_real.backward()
+                    ops.stamp('D:D(real) backward end [side]')
+            cur.wait_event(real_fwd_done)       # D(fake) follows D(real)'s FORWARD (BatchNorm running statistics order)
             if self.s2ag_generator.share_passes and self.early_rand:
                 # The generator's third forward (shuffled speakers, no_grad) depends on nothing the D step changes, and
                 # with the pose/audio encoders shared it contains no BatchNorm (no ordering of running statistics): it
@@ -323,17 +336,26 @@ class Processor(object):
                 z_rand.record_stream(cur)
                 self._early_rand = (out_rand, z_rand)
         else:
+            l_real = None
             with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
                 out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
             with noise.use_pass(nz_real):
                 dis_real = self.s2ag_discriminator(target_poses, in_text)
         with noise.use_pass(nz_fake):
             dis_fake = self.s2ag_discriminator(out_dir_vec.detach(), in_text)
-        dis_error = ops.dis_loss(dis_real, dis_fake)
-        ops.stamp('D:D(fake) end, backward begins')
-        if train:
-            dis_error.backward()
-        ops.join_side_streams()      # backward kernels ran on the forked streams too
+        if self.overlap_passes and l_real is not None:
+            l_fake = ops.dis_loss_half(dis_fake, False)
+            ops.stamp('D:D(fake) end, backward begins')
+            l_fake.backward()
+            dis_error = l_fake.detach()
+            ops.join_side_streams()
+            dis_error = dis_error + l_real.detach()
+        else:
+            dis_error = ops.dis_loss(dis_real, dis_fake)
+            ops.stamp('D:D(fake) end, backward begins')
+            if train:
+                dis_error.backward()
+            ops.join_side_streams()      # backward kernels ran on the forked streams too
         ops.stamp('D:end')
         return dis_error.detach()
 
