@@ -13,6 +13,14 @@
 namespace {
 using namespace s2ag;
 
+#ifdef S2AG_COOP_TRACE
+__device__ unsigned long long g_small_trace[64 * 8];
+#define SM_TR(slot)                                                                   \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && step < 64) g_small_trace[step * 8 + (slot)] = wall_clock64()
+#else
+#define SM_TR(slot)
+#endif
+
 constexpr int SNT = 512;  // threads per workgroup = 8 waves.  TWO threads share one (clip, unit): each holds half of the
 constexpr int KSPLIT = 2; // unit's W_hh rows (96 registers at H = 64) and half of every dot product; the halves meet in
                           // one DPP exchange.  One thread per unit (192 serial FMAs per step, one wave per SIMD) left
@@ -77,7 +85,9 @@ __global__ __launch_bounds__(SNT) void gru_small_fwd_k(const float* __restrict__
         const int t = dir ? (T - 1 - step) : step;
         const int cur = step & 1;
         const long long row = (long long)(b0 + b) * T + t;
+        SM_TR(0);
         load_gi(step + 1, gir_n, giz_n, gin_n);
+        SM_TR(1);
         float ar = 0.f, az = 0.f, an = 0.f;
 #pragma unroll
         for (int k = 0; k < HK; k += 4) {
@@ -87,6 +97,7 @@ __global__ __launch_bounds__(SNT) void gru_small_fwd_k(const float* __restrict__
             ar = fmaf(hv.z, wr[k + 2], ar); az = fmaf(hv.z, wz[k + 2], az); an = fmaf(hv.z, wn[k + 2], an);
             ar = fmaf(hv.w, wr[k + 3], ar); az = fmaf(hv.w, wz[k + 3], az); an = fmaf(hv.w, wn[k + 3], an);
         }
+        SM_TR(2);
         ar += __shfl_xor(ar, 1, 64);                     // the pair's two halves (both lanes end up with the full sums)
         az += __shfl_xor(az, 1, 64);
         an += __shfl_xor(an, 1, 64);
@@ -96,6 +107,7 @@ __global__ __launch_bounds__(SNT) void gru_small_fwd_k(const float* __restrict__
         const float n = tanhf(gin + r * an);
         const float hn = (1.f - z) * n + z * hp;
         hp = hn;
+        SM_TR(3);
         if (half == 0) hs[cur ^ 1][b][i] = hn;
         if (valid) {
             const long long yi = row * (2 * H) + dir * H + i;
@@ -110,10 +122,12 @@ __global__ __launch_bounds__(SNT) void gru_small_fwd_k(const float* __restrict__
                 gs[3 * H + i] = an;
             }
         }
+        SM_TR(4);
         gir = gir_n;
         giz = giz_n;
         gin = gin_n;
         lds_barrier();
+        SM_TR(5);
     }
 }
 
@@ -244,3 +258,9 @@ int s2ag_gru_small_bwd(const float* dy, int lddy, int dy_dir_stride, const float
     S2AG_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef S2AG_COOP_TRACE
+extern "C" int s2ag_gru_small_trace_read(unsigned long long* host64x8) {
+    return (int)hipMemcpyFromSymbol(host64x8, HIP_SYMBOL(g_small_trace), sizeof(unsigned long long) * 64 * 8);
+}
+#endif

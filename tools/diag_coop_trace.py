@@ -89,3 +89,26 @@ tb = timed(lambda: lib.s2ag_gru_coop_bwd(vp(dyt.data_ptr()), 2 * H, H, vp(whh.da
                                          vp(gates.data_ptr()), vp(dgi.data_ptr()), vp(dgh.data_ptr()), B, T, H,
                                          C.byref(e), vp(ws2.data_ptr()), sp))
 print(f'launch (incl. the clear kernel): forward {tf:.1f} us, backward {tb:.1f} us   [S2AG_COOP_L2={os.environ.get("S2AG_COOP_L2", "1")}]')
+
+
+# ---- small-H GRU (H = 64) forward
+Hs = 64
+gis = torch.randn(B * T, 6 * Hs, device=dev) * 0.5
+whs = torch.randn(2, 3 * Hs, Hs, device=dev) * 0.1
+bhs = torch.randn(2, 3 * Hs, device=dev) * 0.1
+ys = torch.empty(B * T, 2 * Hs, device=dev)
+yds = torch.empty_like(ys)
+gs = torch.empty(2, B * T, 4 * Hs, device=dev)
+for _ in range(3):
+    rc = lib.s2ag_gru_seq_fwd(vp(gis.data_ptr()), vp(whs.data_ptr()), None, vp(bhs.data_ptr()), vp(ys.data_ptr()),
+                              vp(yds.data_ptr()), vp(gs.data_ptr()), B, T, Hs, C.byref(e), vp(0))
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+tr = np.zeros(64 * 8, dtype=np.uint64)
+assert lib.s2ag_gru_small_trace_read(tr.ctypes.data_as(C.c_void_p)) == 0
+tr = tr.reshape(64, 8)[:T].astype(np.int64)
+names = ['gi prefetch issue', 'lds + fma', 'merge + gates', 'lds write + stores', 'barrier']
+print('SMALL-H FORWARD\nstep ' + ' '.join(f'{n:>18s}' for n in names) + '   step total (us)')
+for s_ in range(1, T - 1, 4):
+    d = [(tr[s_, i + 1] - tr[s_, i]) / 100.0 for i in range(5)]
+    print(f'{s_:4d} ' + ' '.join(f'{v:18.2f}' for v in d) + f'   {(tr[s_ + 1, 0] - tr[s_, 0]) / 100.0:8.2f}')
