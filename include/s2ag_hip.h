@@ -124,7 +124,7 @@ int s2ag_conv_stats_rows(const s2ag_conv_geom* g /*host*/);
 int s2ag_conv1d_nlc_fwd_stats(const float* x, const float* w, const float* bias, float* y, const s2ag_conv_geom* g,
                               const s2ag_epilogue* e /*host, nullable*/, double* partials, int* stat_rows /*host*/,
                               void* stream);
-int s2ag_bn_fold(const double* partials, int partial_rows, int rows, int cols, const int* chan_of_col /*nullable*/,
+int s2ag_bn_fold(double* partials /*consumed: large sets are pre-folded in place*/, int partial_rows, int rows, int cols, const int* chan_of_col /*nullable*/,
                  int nchan, const float* gamma, const float* beta, float* running_mean, float* running_var,
                  long long* num_batches_tracked /*nullable*/, float eps, float momentum, int repeat, float* scale_col,
                  float* shift_col, float* mean_col, float* invstd_col, void* stream);

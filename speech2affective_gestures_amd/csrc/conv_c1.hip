@@ -1,0 +1,218 @@
+// Direct (vector-ALU) kernels for the ONE-input-channel convolution at the head of the wave encoder
+// (net/multimodal_context_net_v2.py:18, nn.Conv1d(1, 16, 15, stride=5, padding=1600)):
+//   fwd    y[(n,l), co]  = b[co] + sum_t x[n, l*stride - pad + t] * w[co, t]
+//   wgrad  dw[co, t]    += sum_{n,l} gy[(n,l), co] * x[n, l*stride - pad + t],      db[co] += sum_{n,l} gy[(n,l), co]
+// As an implicit GEMM this layer has K = 15 and N = 16: a 64 x 64 x 32 MFMA tile is 6 % occupied and the kernel spends its
+// time gathering a (row, tap) operand matrix that is just the waveform read 15 times.  It is a memory-bound layer -- it
+// writes (fwd) or reads (wgrad) 16 floats per output frame and needs 240 FMAs for them -- so:
+//   * a block owns a run of output frames of ONE clip; the waveform segment under that run is staged in LDS once
+//     (coalesced, zero where the padding is), so the taps cost LDS reads, not global gathers;
+//   * a thread owns (frame, quad of output channels): its 4 x KS weights (fwd) or weight-gradient accumulators (wgrad)
+//     stay in registers for all its frames, and the float4 it stores / loads per frame is contiguous with its
+//     neighbours' -- every wave-level access of y / gy is one contiguous 1 KB run;
+//   * fwd: the fp64 column sums the following BatchNorm needs ride along (same (2, R, Cout) partial layout as the GEMM
+//     epilogues, one partial row per wave);
+//   * wgrad: per-thread accumulators are folded across the wave by shuffles, across waves in LDS, and one wave adds the
+//     block's 16 x KS (+16) sums to dw / db with contiguous atomics; blocks loop over several runs to keep that count low.
+// With Cin == 1 the reference (Cout, 1, k) and tap-major (Cout, k, 1) weight layouts coincide.
+#include "s2ag_common.h"
+
+namespace {
+using namespace s2ag;
+
+constexpr int C1_NT = 256;        // threads per block
+constexpr int C1_RUN = 512;       // output frames per run (a block-iteration): 64 frames x 8 per thread
+
+struct C1P {
+    const float* x;               // (N, Lin) waveform
+    const float* w;               // (CO, KS)
+    const float* bias;            // fwd, nullable
+    float* y;                     // fwd: (N*Lout, ldy) out;  wgrad: gy (read)
+    float* dw;                    // wgrad
+    float* db;                    // wgrad, nullable
+    double* stats;                // fwd, nullable: (2, R, CO), R = blocks * 4
+    int N, Lin, Lout, stride, pad, ldx, ldy;
+    int runs_per_clip;            // cdiv(Lout, C1_RUN)
+    int total_runs;               // N * runs_per_clip
+};
+
+// stage the waveform under output frames [l0, l0 + C1_RUN) of clip n: seg[i] = x[n, l0*stride - pad + i]
+template <int KS>
+__device__ __forceinline__ void stage_segment(const C1P& p, float* seg, int n, int l0, int seg_len) {
+    const long long base = (long long)l0 * p.stride - p.pad;
+    const float* xc = p.x + (long long)n * p.Lin * p.ldx;
+    for (int i = threadIdx.x; i < seg_len; i += C1_NT) {
+        const long long pos = base + i;
+        seg[i] = (pos >= 0 && pos < p.Lin) ? xc[pos * p.ldx] : 0.f;
+    }
+}
+
+template <int CO, int KS>
+__global__ __launch_bounds__(C1_NT) void conv_c1_fwd_k(const C1P p) {
+    static_assert(CO == 16, "thread mapping: 4 channel quads");
+    extern __shared__ float seg[];
+    const int tid = threadIdx.x, q = tid & 3, fr = tid >> 2;          // channel quad, frame within a 64-frame group
+    const int lane = tid & 63, wave = tid >> 6;
+    float wr[4][KS], br[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        br[c] = p.bias ? p.bias[q * 4 + c] : 0.f;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) wr[c][t] = p.w[(q * 4 + c) * KS + t];
+    }
+    const int seg_len = (C1_RUN - 1) * p.stride + KS;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int run = blockIdx.x; run < p.total_runs; run += gridDim.x) {
+        const int n = run / p.runs_per_clip, l0 = (run - n * p.runs_per_clip) * C1_RUN;
+        __syncthreads();                                              // the previous run's readers are done
+        stage_segment<KS>(p, seg, n, l0, seg_len);
+        __syncthreads();
+#pragma unroll 2
+        for (int i = 0; i < C1_RUN / 64; ++i) {
+            const int f = i * 64 + fr, l = l0 + f;
+            if (l < p.Lout) {
+                const float* sx = seg + f * p.stride;
+                float xv[KS];
+#pragma unroll
+                for (int t = 0; t < KS; ++t) xv[t] = sx[t];
+                float4 o;
+                float* op = &o.x;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float a = br[c];
+#pragma unroll
+                    for (int t = 0; t < KS; ++t) a = fmaf(xv[t], wr[c][t], a);
+                    op[c] = a;
+                    if (p.stats) {
+                        s1[c] += (double)a;
+                        s2[c] += (double)a * (double)a;
+                    }
+                }
+                *reinterpret_cast<float4*>(p.y + ((long long)n * p.Lout + l) * p.ldy + q * 4) = o;
+            }
+        }
+    }
+    if (p.stats) {
+        // one partial row per wave for all the block's runs; lanes that share a channel quad differ in lane bits 2..5
+        const size_t R = (size_t)gridDim.x * 4, r = (size_t)blockIdx.x * 4 + wave;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int m = 4; m < 64; m <<= 1) {
+                s1[c] += __shfl_xor(s1[c], m, 64);
+                s2[c] += __shfl_xor(s2[c], m, 64);
+            }
+            if (lane < 4) {
+                p.stats[r * CO + q * 4 + c] = s1[c];
+                p.stats[(R + r) * CO + q * 4 + c] = s2[c];
+            }
+        }
+    }
+}
+
+template <int CO, int KS>
+__global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
+    static_assert(CO == 16, "thread mapping: 4 channel quads");
+    extern __shared__ float seg[];
+    __shared__ float red[4][CO * KS + CO];                           // per-wave sums: dw (CO x KS) then db (CO)
+    const int tid = threadIdx.x, q = tid & 3, fr = tid >> 2;
+    const int lane = tid & 63, wave = tid >> 6;
+    float acc[4][KS], bsum[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bsum[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) acc[c][t] = 0.f;
+    }
+    const int seg_len = (C1_RUN - 1) * p.stride + KS;
+    for (int run = blockIdx.x; run < p.total_runs; run += gridDim.x) {
+        const int n = run / p.runs_per_clip, l0 = (run - n * p.runs_per_clip) * C1_RUN;
+        __syncthreads();
+        stage_segment<KS>(p, seg, n, l0, seg_len);
+        __syncthreads();
+#pragma unroll 2
+        for (int i = 0; i < C1_RUN / 64; ++i) {
+            const int f = i * 64 + fr, l = l0 + f;
+            if (l < p.Lout) {
+                const float4 g4 = *reinterpret_cast<const float4*>(p.y + ((long long)n * p.Lout + l) * p.ldy + q * 4);
+                const float* gp = &g4.x;
+                const float* sx = seg + f * p.stride;
+                float xv[KS];
+#pragma unroll
+                for (int t = 0; t < KS; ++t) xv[t] = sx[t];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bsum[c] += gp[c];
+#pragma unroll
+                    for (int t = 0; t < KS; ++t) acc[c][t] = fmaf(gp[c], xv[t], acc[c][t]);
+                }
+            }
+        }
+    }
+    // fold: across the 16 lanes of each channel quad (lane bits 2..5), then across the 4 waves through LDS
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) bsum[c] += __shfl_xor(bsum[c], m, 64);
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            float v = acc[c][t];
+#pragma unroll
+            for (int m = 4; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+            acc[c][t] = v;
+        }
+    }
+    if (lane < 4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            red[wave][CO * KS + q * 4 + c] = bsum[c];
+#pragma unroll
+            for (int t = 0; t < KS; ++t) red[wave][(q * 4 + c) * KS + t] = acc[c][t];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < CO * KS + CO; i += C1_NT) {
+        const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        if (i < CO * KS)
+            atomicAdd(p.dw + i, v);
+        else if (p.db)
+            atomicAdd(p.db + (i - CO * KS), v);
+    }
+}
+
+inline bool c1_shape_ok(int Cin, int Cout, int ks, int dil, int ldx, int ldy, int stride) {
+    return Cin == 1 && Cout == 16 && ks == 15 && dil == 1 && ldx == 1 && (ldy & 3) == 0 && stride >= 1 && stride <= 8;
+}
+inline size_t c1_seg_bytes(int stride) { return sizeof(float) * ((size_t)(C1_RUN - 1) * stride + 15); }
+}  // namespace
+
+// Returns the number of statistics partial rows written (> 0) if the launch was taken, 0 if the geometry is not this
+// kernel's (the caller falls back to the implicit-GEMM path).
+int s2ag_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Lin, int Lout, int Cin, int Cout,
+                int ks, int stride, int pad, int dil, int ldx, int ldy, double* stats, int stats_cap_rows,
+                hipStream_t stream) {
+    if (!c1_shape_ok(Cin, Cout, ks, dil, ldx, ldy, stride) || (reinterpret_cast<uintptr_t>(y) & 15)) return 0;
+    C1P p{};
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.stats = stats;
+    p.N = N; p.Lin = Lin; p.Lout = Lout; p.stride = stride; p.pad = pad; p.ldx = ldx; p.ldy = ldy;
+    p.runs_per_clip = cdiv(Lout, C1_RUN);
+    p.total_runs = N * p.runs_per_clip;
+    // persistent blocks (4 per CU): a thread's 60 weights are loaded once and serve all its runs
+    const int blocks = p.total_runs < 1024 ? p.total_runs : 1024;
+    if (stats && blocks * 4 > stats_cap_rows) return 0;
+    hipLaunchKernelGGL((conv_c1_fwd_k<16, 15>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(stride), stream, p);
+    return blocks * 4;
+}
+
+int s2ag_conv_c1_wgrad(const float* gy, const float* x, float* dw, float* db, int N, int Lin, int Lout, int Cin, int Cout,
+                  int ks, int stride, int pad, int dil, int ldx, int ldg, hipStream_t stream) {
+    if (!c1_shape_ok(Cin, Cout, ks, dil, ldx, ldg, stride) || (reinterpret_cast<uintptr_t>(gy) & 15)) return 0;
+    C1P p{};
+    p.x = x; p.y = const_cast<float*>(gy); p.dw = dw; p.db = db;
+    p.N = N; p.Lin = Lin; p.Lout = Lout; p.stride = stride; p.pad = pad; p.ldx = ldx; p.ldy = ldg;
+    p.runs_per_clip = cdiv(Lout, C1_RUN);
+    p.total_runs = N * p.runs_per_clip;
+    const int blocks = p.total_runs < 1024 ? p.total_runs : 1024;    // 4 blocks per CU; each adds 256 sums at the end
+    hipLaunchKernelGGL((conv_c1_wgrad_k<16, 15>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(stride), stream, p);
+    return 1;
+}

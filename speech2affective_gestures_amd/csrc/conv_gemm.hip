@@ -925,17 +925,24 @@ static bool use_gemm_lin() {
     return v;
 }
 
+// conv_c1.hip
+int s2ag_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Lin, int Lout, int Cin,
+                     int Cout, int ks, int stride, int pad, int dil, int ldx, int ldy, double* stats, int stats_cap_rows,
+                     hipStream_t stream);
+int s2ag_conv_c1_wgrad(const float* gy, const float* x, float* dw, float* db, int N, int Lin, int Lout, int Cin, int Cout,
+                       int ks, int stride, int pad, int dil, int ldx, int ldg, hipStream_t stream);
 // gemm_lin.hip
 int s2ag_gemm_lin_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int ldx, int ldy,
                       int act, float slope, float drop_p, const unsigned long long* rng, unsigned site, double* stats,
                       hipStream_t stream);
 int s2ag_gemm_lin_bwd_data(const float* gy, const float* w, float* dx, int M, int Cout, int Cin, int ldg, int ldx,
                            int accumulate, hipStream_t stream);
-int s2ag_wgrad_lin(const float* gy, const float* x, float* dw, float* db, int nclips, int L, int Cin, int Cout, int ks,
-                   int pad, int dil, int ldx, int ldg, int wtm, int chunk, int nsplit, hipStream_t stream);
-int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, float* y, int nclips, int L, int Cin,
-                          int Cout, int ks, int pad, int dil, int ldx, int ldy, int act, float slope, float drop_p,
-                          const unsigned long long* rng, unsigned site, double* stats, hipStream_t stream);
+int s2ag_wgrad_lin(const float* gy, const float* x, float* dw, float* db, int nclips, int Lin, int Lout, int Cin,
+                   int Cout, int ks, int stride, int pad, int dil, int ldx, int ldg, int wtm, int chunk, int nsplit,
+                   hipStream_t stream);
+int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, float* y, int nclips, int Lin, int Lout,
+                          int Cin, int Cout, int ks, int stride, int pad, int dil, int ldx, int ldy, int act, float slope,
+                          float drop_p, const unsigned long long* rng, unsigned site, double* stats, hipStream_t stream);
 int s2ag_gemm_conv_tm_bwd_data(const float* gy, const float* w, float* dx, int nclips, int L, int Cin, int Cout, int ks,
                                int pad, int dil, int ldg, int ldx, int accumulate, hipStream_t stream);
 
@@ -970,9 +977,19 @@ static int conv1d_nlc_fwd_impl(const float* x, const float* w, const float* bias
         return 0;
     }
     // stride-1 convs with tap-major weights (TCN, folded ST-GCN): the same straight-line kernel with (tap, channel) tracking
-    if (use_gemm_lin() && g->ksize > 1 && g->w_tap_major && g->stride == 1 && g->Lin == g->Lout &&
-        (rows_ = s2ag_gemm_conv_tm_fwd(x, w, bias, y, g->N, g->Lin, g->Cin, g->Cout, g->ksize, g->pad, g->dil, g->ldx,
-                                       g->ldy, p.act, p.slope, p.drop_p, p.rng, p.site, stats, (hipStream_t)stream))) {
+    if (use_gemm_lin() && g->ksize > 1 && g->w_tap_major &&
+        (rows_ = s2ag_gemm_conv_tm_fwd(x, w, bias, y, g->N, g->Lin, g->Lout, g->Cin, g->Cout, g->ksize, g->stride, g->pad,
+                                       g->dil, g->ldx, g->ldy, p.act, p.slope, p.drop_p, p.rng, p.site, stats,
+                                       (hipStream_t)stream))) {
+        S2AG_LAUNCH_CHECK();
+        if (stat_rows && stats) *stat_rows = rows_;
+        return 0;
+    }
+    // the one-channel waveform conv: direct vector-ALU kernel (conv_c1.hip)
+    if (use_gemm_lin() && g->Cin == 1 && p.act == S2AG_ACT_NONE && p.drop_p == 0.f &&
+        (rows_ = s2ag_conv_c1_fwd(x, w, bias, y, g->N, g->Lin, g->Lout, g->Cin, g->Cout, g->ksize, g->stride, g->pad,
+                                  g->dil, g->ldx, g->ldy, stats, 2 * cdiv((long long)g->N * g->Lout, 32),
+                                  (hipStream_t)stream))) {
         S2AG_LAUNCH_CHECK();
         if (stat_rows && stats) *stat_rows = rows_;
         return 0;
@@ -1050,8 +1067,8 @@ extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float
     const int tiles = cdiv(g->Cout, BM) * cdiv(g->ksize * g->Cin, BN);
     // split of the clips*frames axis: the straight-line kernel (stride-1 layers) likes ~384 blocks -- longer K loops, a
     // third of the merge atomics (sweep 256...1024 in the full step); the general kernels keep ~1024
-    const bool lin_ok = use_gemm_lin() && g->stride == 1 && g->Lin == g->Lout &&
-                        ((g->Lin == 1 && g->pad == 0 && g->ksize == 1) || g->Lin >= BK2);
+    const bool lin_ok = use_gemm_lin() && ((g->Lin == 1 && g->Lout == 1 && g->pad == 0 && g->ksize == 1 && g->stride == 1) ||
+                                           g->Lout >= BK2);
     int nsplit = cdiv(lin_ok ? 384 : 1024, tiles);
     const int max_split = cdiv(p.Mtot, 4 * BK);
     if (nsplit > max_split) nsplit = max_split;
@@ -1069,9 +1086,15 @@ extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float
             if (me != hipSuccess) return (int)me;
         }
     }
-    if (use_gemm_lin() && g->stride == 1 && g->Lin == g->Lout && p.chunk % BK2 == 0 &&
-        s2ag_wgrad_lin(gy, x, dw, dbias, g->N, g->Lin, g->Cin, g->Cout, g->ksize, g->pad, g->dil, g->ldx, g->ldy,
-                       g->w_tap_major, p.chunk, nsplit, (hipStream_t)stream)) {
+    if (use_gemm_lin() && g->Cin == 1 &&
+        s2ag_conv_c1_wgrad(gy, x, dw, dbias, g->N, g->Lin, g->Lout, g->Cin, g->Cout, g->ksize, g->stride, g->pad, g->dil,
+                           g->ldx, g->ldy, (hipStream_t)stream)) {
+        S2AG_LAUNCH_CHECK();
+        return 0;
+    }
+    if (lin_ok && p.chunk % BK2 == 0 &&
+        s2ag_wgrad_lin(gy, x, dw, dbias, g->N, g->Lin, g->Lout, g->Cin, g->Cout, g->ksize, g->stride, g->pad, g->dil,
+                       g->ldx, g->ldy, g->w_tap_major, p.chunk, nsplit, (hipStream_t)stream)) {
         S2AG_LAUNCH_CHECK();
         return 0;
     }

@@ -32,7 +32,9 @@ struct LinP {
     // CONV (tap-major weights (Cout, ks, Cin), stride 1): K = ks * CK, the contraction index is (tap, channel)
     int CK;                      // channels per tap of the contraction (Cin fwd, Cout bwd), >= 32, % 4 == 0
     int ks, dil;
-    int L;                       // frames per clip (Lin == Lout)
+    int L;                       // output frames per clip
+    int Ls;                      // source frames per clip (== L unless the forward conv is strided)
+    int stride;                  // forward only (the data gradient of a strided conv stays with the general kernel)
     int off;                     // source frame of tap 0 for output frame 0: fwd -pad, bwd +pad (bwd steps by -dil)
     double* stats;               // fwd, nullable: per-row-block column sums of the output and of its square,
                                  // layout (2, gridDim.x, N) -- the BatchNorm that follows folds them (s2ag_bn_fold)
@@ -66,12 +68,13 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
     // CONV: the A row of tap t is the clip's frame (l + off +- t*dil); (a_tap, a_c) = (tap, channel) of this thread's
     // chunk, advanced by LBK per tile (CK >= 32: at most one wrap per tile)
     int a_tap = 0, a_c = a_kq * 4, a_l = 0;
+    if (CONV) while (a_c >= p.CK) { a_c -= p.CK; ++a_tap; }        // fewer than 32 channels per tap
     const float* a_clip = nullptr;              // row 0 of the clip
     if (CONV && has_a && m0 + a_r < p.M) {
         const int m = m0 + a_r;
         const int nclip = m / p.L;
-        a_l = m - nclip * p.L + p.off;
-        a_clip = p.a + (long long)nclip * p.L * p.lda;
+        a_l = (m - nclip * p.L) * (BWD ? 1 : p.stride) + p.off;
+        a_clip = p.a + (long long)nclip * p.Ls * p.lda;
     }
     // B chunk: fwd = (col b_c, k quad b_kq) one float4 along k;  bwd = (col b_c, k quad b_kq) four k rows of W
     int b_c, b_kq;
@@ -89,6 +92,7 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
     const long long b_step = BWD ? (long long)LBK * p.ldw : LBK;
     // CONV bwd: k = (tap, co) lives in W row co*ks + tap, i.e. rows of one tap are ks*Cin floats apart
     int b_tap = 0, b_co = b_kq * 4;
+    if (CONV && BWD) while (b_co >= p.CK) { b_co -= p.CK; ++b_tap; }
     const long long b_row = (long long)p.ks * p.ldw;     // bwd CONV: distance of consecutive co at a fixed tap
 
     float4 ra0, rb0, ra1, rb1;
@@ -99,11 +103,11 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
         if (CONV) {
             if (a_clip && ka < p.K) {
                 const int pos = BWD ? a_l - a_tap * p.dil : a_l + a_tap * p.dil;
-                if ((unsigned)pos < (unsigned)p.L)
+                if ((unsigned)pos < (unsigned)p.Ls)
                     ra = *reinterpret_cast<const float4*>(a_clip + (long long)pos * p.lda + a_c);
             }
             a_c += LBK;
-            if (a_c >= p.CK) { a_c -= p.CK; ++a_tap; }
+            while (a_c >= p.CK) { a_c -= p.CK; ++a_tap; }
         } else {
             if (a_ptr && ka < p.K) ra = *reinterpret_cast<const float4*>(a_ptr + k0);
         }
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
                     rb.w = q[3 * b_row];
                 }
                 b_co += LBK;
-                if (b_co >= p.CK) { b_co -= p.CK; ++b_tap; }
+                while (b_co >= p.CK) { b_co -= p.CK; ++b_tap; }
             } else if (b_ptr) {
                 const float* q = b_ptr + (long long)(k0 / LBK) * b_step;
                 if (kb < p.K) rb.x = q[0];
@@ -313,18 +317,18 @@ int s2ag_gemm_lin_bwd_data(const float* gy, const float* w, float* dx, int M, in
     return 1;
 }
 
-// Stride-1 convolutions with TAP-MAJOR weights (Cout, ks, Cin) -- the weight-normed TCN convs and the folded ST-GCN convs
-// (both produced in that layout by their derived-parameter kernels) -- with at least 32 channels per tap:
-//   fwd  y[(n,l), co]   = epi( sum_{t,ci} x[(n, l - pad + t*dil), ci] w[co, t, ci] + b[co] )
+// Convolutions with TAP-MAJOR weights (Cout, ks, Cin) -- the weight-normed TCN convs, the folded ST-GCN convs and the
+// tap-major copies of the wave / MFCC encoder weights (all produced by derived-parameter kernels), Cin % 4 == 0:
+//   fwd  y[(n,l), co]   = epi( sum_{t,ci} x[(n, l*stride - pad + t*dil), ci] w[co, t, ci] + b[co] )      (any stride)
 //   bwd  dx[(n,p), ci] (+)= sum_{t,co} gy[(n, p + pad - t*dil), co] w[co, t, ci]
-int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, float* y, int nclips, int L, int Cin,
-                          int Cout, int ks, int pad, int dil, int ldx, int ldy, int act, float slope, float drop_p,
-                          const unsigned long long* rng, unsigned site, double* stats, hipStream_t stream) {
-    if ((Cin & 3) || Cin < LBK || (ldx & 3) || !al16(x) || !al16(w)) return 0;
+int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, float* y, int nclips, int Lin, int Lout,
+                          int Cin, int Cout, int ks, int stride, int pad, int dil, int ldx, int ldy, int act, float slope,
+                          float drop_p, const unsigned long long* rng, unsigned site, double* stats, hipStream_t stream) {
+    if ((Cin & 3) || (ldx & 3) || !al16(x) || !al16(w)) return 0;
     LinP p{};
-    p.a = x; p.w = w; p.bias = bias; p.out = y; p.M = nclips * L; p.K = ks * Cin; p.N = Cout;
+    p.a = x; p.w = w; p.bias = bias; p.out = y; p.M = nclips * Lout; p.K = ks * Cin; p.N = Cout;
     p.lda = ldx; p.ldo = ldy; p.ldw = ks * Cin;
-    p.CK = Cin; p.ks = ks; p.dil = dil; p.L = L; p.off = -pad;
+    p.CK = Cin; p.ks = ks; p.dil = dil; p.L = Lout; p.Ls = Lin; p.stride = stride; p.off = -pad;
     p.act = act; p.slope = slope; p.drop_p = drop_p; p.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     p.rng = rng; p.site = site; p.accumulate = 0; p.stats = stats;
     const int colb = cdiv(Cout, 64);
@@ -338,11 +342,11 @@ int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, flo
 
 int s2ag_gemm_conv_tm_bwd_data(const float* gy, const float* w, float* dx, int nclips, int L, int Cin, int Cout, int ks,
                                int pad, int dil, int ldg, int ldx, int accumulate, hipStream_t stream) {
-    if ((Cout & 3) || Cout < LBK || (ldg & 3) || !al16(gy)) return 0;
+    if ((Cout & 3) || (ldg & 3) || !al16(gy)) return 0;
     LinP p{};
     p.a = gy; p.w = w; p.bias = nullptr; p.out = dx; p.M = nclips * L; p.K = ks * Cout; p.N = Cin;
     p.lda = ldg; p.ldo = ldx; p.ldw = Cin;
-    p.CK = Cout; p.ks = ks; p.dil = dil; p.L = L; p.off = pad;
+    p.CK = Cout; p.ks = ks; p.dil = dil; p.L = L; p.Ls = L; p.stride = 1; p.off = pad;
     p.act = 0; p.slope = 1.f; p.drop_p = 0.f; p.inv_keep = 1.f; p.rng = nullptr; p.site = 0; p.accumulate = accumulate;
     const int colb = cdiv(Cin, 64);
     if ((long long)cdiv(p.M, 64) * colb >= bm64_min_blocks())
@@ -353,8 +357,8 @@ int s2ag_gemm_conv_tm_bwd_data(const float* gy, const float* w, float* dx, int n
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Straight-line weight gradient for stride-1 layers:  dw[co, (tap, ci)] += sum_m gy[m, co] * x[m + tap*dil - pad, ci]
-// (rows of one clip only), db[co] += sum_m gy[m, co].  Same tiling as conv_wgrad2_k (64 x 64 output tile, 32 contraction
+// Straight-line weight gradient:  dw[co, (tap, ci)] += sum_{n,l} gy[(n,l), co] * x[(n, l*stride + tap*dil - pad), ci]
+// (frames of one clip only), db[co] += sum_m gy[m, co].  Same tiling as conv_wgrad2_k (64 x 64 output tile, 32 contraction
 // rows per K tile, double-buffered k-major LDS, 8 waves with a 2-way in-block split, clips*frames split over grid.z and
 // merged with fp32 atomics) without the per-row clip/position arithmetic of the general kernel (10-15 vector-ALU
 // instructions per MFMA there): a thread owns one output column for the whole launch, so its operand rows are two
@@ -365,7 +369,7 @@ struct WgP {
     const float* x;
     float* dw;
     float* db;
-    int M, L, Cin, Cout, ks, pad, dil, ldx, ldg, wtm;
+    int M, L, Ls, stride, Cin, Cout, ks, pad, dil, ldx, ldg, wtm;     // L: output frames per clip, Ls: source frames
     int chunk;
 };
 
@@ -392,8 +396,11 @@ __global__ __launch_bounds__(512) void wgrad_lin_k(WgP p) {
     const int tapoff = tap * p.dil - p.pad;
     const long long r0 = mbeg + mq * 4;
     const float* g_ptr = co < p.Cout ? p.gy + r0 * p.ldg + co : nullptr;
-    const float* x_ptr = jcol < NCW ? p.x + (r0 + tapoff) * p.ldx + ci : nullptr;   // dereferenced only at valid frames
+    // linear mode: the x row of output row m is m itself.  SHIFT mode: row m = (clip n, frame l) reads source frame
+    // l*stride + tapoff of clip n (zero outside the clip): x_ptr is the clip's frame 0, advanced at clip boundaries
     int l = SHIFT ? (int)(r0 % p.L) : 0;              // frame of this thread's first row inside its clip
+    const float* x_ptr = jcol < NCW ? (SHIFT ? p.x + (r0 / p.L) * (long long)p.Ls * p.ldx + ci : p.x + r0 * p.ldx + ci)
+                                    : nullptr;
     const bool want_db = p.db != nullptr && blockIdx.y == 0;
     float bsum = 0.f;
 
@@ -403,21 +410,30 @@ __global__ __launch_bounds__(512) void wgrad_lin_k(WgP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool okrow = full || (mb + mq * 4 + j < mend);
-            bool okx = okrow;
+            ra[j] = (g_ptr && okrow) ? g_ptr[(long long)j * p.ldg] : 0.f;
             if (SHIFT) {
                 int lj = l + j;
-                lj -= (lj >= p.L) ? p.L : 0;
-                okx = okrow && (unsigned)(lj + tapoff) < (unsigned)p.L;
+                const float* xc = x_ptr;
+                if (lj >= p.L) {                      // this row already belongs to the next clip
+                    lj -= p.L;
+                    xc += (long long)p.Ls * p.ldx;
+                }
+                const int pos = lj * p.stride + tapoff;
+                rb[j] = (x_ptr && okrow && (unsigned)pos < (unsigned)p.Ls) ? xc[(long long)pos * p.ldx] : 0.f;
+            } else {
+                rb[j] = (x_ptr && okrow) ? x_ptr[(long long)j * p.ldx] : 0.f;
             }
-            ra[j] = (g_ptr && okrow) ? g_ptr[(long long)j * p.ldg] : 0.f;
-            rb[j] = (x_ptr && okx) ? x_ptr[(long long)j * p.ldx] : 0.f;
             bsum += ra[j];
         }
         if (g_ptr) g_ptr += (long long)LBK * p.ldg;
-        if (x_ptr) x_ptr += (long long)LBK * p.ldx;
         if (SHIFT) {
             l += LBK;
-            if (l >= p.L) l -= p.L;                   // host guarantees L >= 32
+            if (l >= p.L) {                           // host guarantees L >= 32: at most one clip boundary per tile
+                l -= p.L;
+                if (x_ptr) x_ptr += (long long)p.Ls * p.ldx;
+            }
+        } else if (x_ptr) {
+            x_ptr += (long long)LBK * p.ldx;
         }
     };
     float* const a_dst = &As[0][mq * 4][cidx];
@@ -519,14 +535,16 @@ __global__ __launch_bounds__(512) void wgrad_lin_k(WgP p) {
 }
 }  // namespace
 
-// Returns 1 if the launch was taken (stride 1, Lin == Lout, and either one frame per clip without padding -- Linear --
-// or at least 32 frames per clip); dw / db must already hold the values to accumulate into.
-int s2ag_wgrad_lin(const float* gy, const float* x, float* dw, float* db, int nclips, int L, int Cin, int Cout, int ks,
-                   int pad, int dil, int ldx, int ldg, int wtm, int chunk, int nsplit, hipStream_t stream) {
-    const bool linear = (L == 1 && pad == 0 && ks == 1);
-    if (!linear && L < LBK) return 0;
+// Returns 1 if the launch was taken (one frame per clip without padding -- Linear -- or at least 32 output frames per
+// clip, any stride / padding / dilation); dw / db must already hold the values to accumulate into.
+int s2ag_wgrad_lin(const float* gy, const float* x, float* dw, float* db, int nclips, int Lin, int Lout, int Cin,
+                   int Cout, int ks, int stride, int pad, int dil, int ldx, int ldg, int wtm, int chunk, int nsplit,
+                   hipStream_t stream) {
+    const bool linear = (Lin == 1 && Lout == 1 && pad == 0 && ks == 1 && stride == 1);
+    if (!linear && Lout < LBK) return 0;
     WgP p{};
-    p.gy = gy; p.x = x; p.dw = dw; p.db = db; p.M = nclips * L; p.L = L; p.Cin = Cin; p.Cout = Cout; p.ks = ks;
+    p.gy = gy; p.x = x; p.dw = dw; p.db = db; p.M = nclips * Lout; p.L = Lout; p.Ls = Lin; p.stride = stride;
+    p.Cin = Cin; p.Cout = Cout; p.ks = ks;
     p.pad = pad; p.dil = dil; p.ldx = ldx; p.ldg = ldg; p.wtm = wtm; p.chunk = chunk;
     dim3 grid(cdiv(Cout, 64), cdiv(ks * Cin, 64), nsplit);
     if (linear)

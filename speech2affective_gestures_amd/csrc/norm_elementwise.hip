@@ -352,18 +352,63 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_k(const float* s1, const fl
 // BatchNorm backward statistics in ONE launch (see bn_fwd_stats_k): partial column sums of dpre and dpre*xhat per row
 // block, folded by the last block into dgamma / dbeta (+=) and the per-column c1, c2 of the dx formula.
 // The producing layer already left per-row-block column sums (conv_gemm / gemm_lin epilogue): only the fold is left.
+// A big layer leaves thousands of partial rows (one per 32 output rows): one block folding them alone is a 60 us serial
+// tail.  This pre-pass folds slices of FOLD_SLICE rows in place -- block g leaves the sums of rows [g*S, (g+1)*S) in row
+// g*S of either half -- and bn_fold_k then reads every S-th row.  Fixed order: bit-reproducible.
+constexpr int FOLD_SLICE = 64;
+__global__ __launch_bounds__(256) void bn_fold_pre_k(double* part, int prow, int cols) {
+    __shared__ double red[2][256];
+    const int beg = blockIdx.x * FOLD_SLICE, end = min(prow, beg + FOLD_SLICE);
+    const int nsub = 256 / cols;                                     // host: cols <= 256
+    const int c = threadIdx.x % cols, sub = threadIdx.x / cols;
+    double a = 0.0, b = 0.0;
+    if (sub < nsub)
+        for (int r = beg + sub; r < end; r += nsub) {
+            a += part[(size_t)r * cols + c];
+            b += part[(size_t)(prow + r) * cols + c];
+        }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    if ((int)threadIdx.x < cols) {
+        for (int j = 1; j < nsub; ++j) {
+            a += red[0][j * cols + c];
+            b += red[1][j * cols + c];
+        }
+        part[(size_t)beg * cols + c] = a;
+        part[(size_t)(prow + beg) * cols + c] = b;
+    }
+}
+
 __global__ __launch_bounds__(1024) void bn_fold_k(const double* part, int prow, int rows, int cols, const int* chan_of_col,
                                                   int nchan, const float* gamma, const float* beta, float* rmean,
                                                   float* rvar, long long* nbt, float eps, float momentum, int repeat,
                                                   float* scale_col, float* shift_col, float* mean_col,
-                                                  float* invstd_col) {
+                                                  float* invstd_col, int pstep) {
     extern __shared__ double smd[];
     double* cs = smd;
     double* cq = smd + nchan;
     double* cn = smd + 2 * nchan;
     for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) smd[i] = 0.0;
     __syncthreads();
-    fold_partials<double, double, 1024>(part, prow, cols, chan_of_col, cs, cq, cn);
+    if (pstep == 1) {
+        fold_partials<double, double, 1024>(part, prow, cols, chan_of_col, cs, cq, cn);
+    } else {
+        // rows 0, pstep, 2*pstep, ... of either half (left by bn_fold_pre_k)
+        const int nsub = 1024 / cols;                              // host: cols <= 256 on this path
+        const int c = threadIdx.x % cols, sub = threadIdx.x / cols;
+        if (sub < nsub) {
+            double a = 0.0, b = 0.0;
+            for (int r = sub * pstep; r < prow; r += nsub * pstep) {
+                a += part[(size_t)r * cols + c];
+                b += part[(size_t)(prow + r) * cols + c];
+            }
+            const int ch = chan_of_col ? chan_of_col[c] : c;
+            atomicAdd(&cs[ch], a);
+            atomicAdd(&cq[ch], b);
+            if (sub == 0) atomicAdd(&cn[ch], 1.0);
+        }
+    }
     __syncthreads();
     bn_finish_coeffs(cs, cq, cn, chan_of_col, cols, nchan, rows, gamma, beta, rmean, rvar, nbt, eps, momentum, 1,
                      scale_col, shift_col, mean_col, invstd_col, repeat);
@@ -586,16 +631,22 @@ extern "C" int s2ag_bn_fwd_stats(const float* x, int rows, int cols, int ldx, co
     return 0;
 }
 
-extern "C" int s2ag_bn_fold(const double* partials, int partial_rows, int rows, int cols, const int* chan_of_col,
+extern "C" int s2ag_bn_fold(double* partials, int partial_rows, int rows, int cols, const int* chan_of_col,
                             int nchan, const float* gamma, const float* beta, float* running_mean, float* running_var,
                             long long* nbt, float eps, float momentum, int repeat, float* scale_col, float* shift_col,
                             float* mean_col, float* invstd_col, void* stream) {
     if (!partials || partial_rows <= 0 || rows <= 0 || cols <= 0 || nchan <= 0 || repeat < 1 || !gamma || !beta ||
         !running_mean || !running_var || !scale_col || !shift_col || !mean_col || !invstd_col)
         return S2AG_E_BADARG;
+    int pstep = 1;
+    if (partial_rows >= 1024 && cols <= 256) {
+        pstep = FOLD_SLICE;
+        hipLaunchKernelGGL(bn_fold_pre_k, dim3(cdiv(partial_rows, FOLD_SLICE)), dim3(256), 0, (hipStream_t)stream,
+                           partials, partial_rows, cols);
+    }
     hipLaunchKernelGGL(bn_fold_k, dim3(1), dim3(1024), sizeof(double) * 3 * nchan, (hipStream_t)stream, partials,
                        partial_rows, rows, cols, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt, eps,
-                       momentum, repeat, scale_col, shift_col, mean_col, invstd_col);
+                       momentum, repeat, scale_col, shift_col, mean_col, invstd_col, pstep);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -112,13 +112,13 @@ class WavEncoder(nn.Module):
     def forward(self, wav_data):
         fe = self.feat_extractor
         x = wav_data.unsqueeze(2)                                     # (B, L, 1) channels-last
-        x = ops.conv1d_nlc(x, fe[0].weight, fe[0].bias, stride=5, pad=1600)
+        x = ops.conv1d_nlc(x, fe[0].weight, fe[0].bias, stride=5, pad=1600, bn_stats=fe[1].training)
         x = ops.batch_norm_act(x, fe[1], slope=0.3)
-        x = ops.conv1d_nlc(x, fe[3].weight, fe[3].bias, stride=6)
+        x = ops.conv1d_nlc(x, fe[3].weight, fe[3].bias, stride=6, tm_copy=True, bn_stats=fe[4].training)
         x = ops.batch_norm_act(x, fe[4], slope=0.3)
-        x = ops.conv1d_nlc(x, fe[6].weight, fe[6].bias, stride=6)
+        x = ops.conv1d_nlc(x, fe[6].weight, fe[6].bias, stride=6, tm_copy=True, bn_stats=fe[7].training)
         x = ops.batch_norm_act(x, fe[7], slope=0.3)
-        return ops.conv1d_nlc(x, fe[9].weight, fe[9].bias, stride=6)  # already (batch x seq x dim)
+        return ops.conv1d_nlc(x, fe[9].weight, fe[9].bias, stride=6, tm_copy=True)  # already (batch x seq x dim)
 
 
 class MFCCEncoder(nn.Module):
@@ -142,7 +142,8 @@ class MFCCEncoder(nn.Module):
         x = mfcc_data
         for conv, bn, pad in ((self.conv1, self.batch_norm1, 2), (self.conv2, self.batch_norm2, 2),
                               (self.conv3, self.batch_norm3, 1), (self.conv4, self.batch_norm4, 1)):
-            x = ops.batch_norm_act(ops.conv1d_nlc(x, conv.weight, conv.bias, pad=pad, bn_stats=True), bn, slope=0.3)
+            x = ops.batch_norm_act(ops.conv1d_nlc(x, conv.weight, conv.bias, pad=pad, bn_stats=bn.training, tm_copy=True), bn,
+                                   slope=0.3)
         x = x.transpose(1, 2).contiguous()                            # (B, time_steps, num_mfcc): layout glue only
         return ops.linear(x, self.linear1.weight, self.linear1.bias, act=ACT_LEAKY, slope=0.3)
 

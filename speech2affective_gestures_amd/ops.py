@@ -99,7 +99,7 @@ def conv_fwd_raw(x: Tensor, w: Tensor, bias: Optional[Tensor], y: Tensor, N, Lin
     got = C.c_int(0)
     L.check(lib.s2ag_conv1d_nlc_fwd_stats(_p(x), _p(w), _p(bias), _p(y), C.byref(g), C.byref(e), _p(part),
                                           C.byref(got), _stream()), 'conv_fwd_stats')
-    return (part, got.value) if got.value > 0 else None
+    return (part[:2 * got.value * Cout], got.value) if got.value > 0 else None
 
 
 def conv_bwd_data_raw(gy: Tensor, w: Tensor, dx: Tensor, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, accumulate,
@@ -254,15 +254,19 @@ def _grad_slot(p: Optional[Tensor]):
 # ----------------------------------------------------------------------------------------------------
 class _ConvNLC(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, geom, act, slope, drop_p, noise, site):
+    def forward(ctx, x, w, bias, geom, act, slope, drop_p, noise, site, w_tm=None):
         _need_cuda(x, w, bias)
         N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, wtm = geom
         x, _, _, _ = as_rows(x)
         ctx.w_leaf, ctx.b_leaf = w, bias                   # for direct accumulation into .grad (see _grad_slot)
-        w = w.contiguous()
+        ctx.w_shape = w.shape
+        # w_tm: tap-major copy of a reference-layout weight (see tap_major): the forward / data-gradient kernels read
+        # the copy, the weight gradient is written in the leaf's own layout -- no staging, nothing to flush
+        ctx.wtm_k = 1 if w_tm is not None else wtm
+        w = w_tm if w_tm is not None else w.contiguous()
         y = torch.empty(N * Lout, Cout, dtype=torch.float32, device=x.device)
         st = conv_fwd_raw(x, w, bias, y, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, act, slope, drop_p, noise, site,
-                          wtm, stats_out=True if _WANT_STATS[0] else None)
+                          ctx.wtm_k, stats_out=True if _WANT_STATS[0] else None)
         _LAST_STATS[0] = st
         ctx.geom, ctx.epi = geom, (act, slope, drop_p, site)
         ctx.noise = noise
@@ -285,7 +289,7 @@ class _ConvNLC(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(N * Lin, Cin, dtype=torch.float32, device=dy.device)
-            conv_bwd_data_raw(g, w, dx, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False, wtm)
+            conv_bwd_data_raw(g, w, dx, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False, ctx.wtm_k)
             dx = dx.view(x.shape)
         wslot = _grad_slot(ctx.w_leaf) if ctx.needs_input_grad[1] else None
         bslot = _grad_slot(ctx.b_leaf) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
@@ -293,7 +297,7 @@ class _ConvNLC(torch.autograd.Function):
         if need_db:
             db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
         if ctx.needs_input_grad[1] and wslot is None:
-            dw = torch.empty_like(w)
+            dw = torch.empty(ctx.w_shape, dtype=torch.float32, device=dy.device)
             conv_bwd_weight_raw(g, x, dw, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False, wtm,
                                 dbias=db if need_db else None)
         elif need_db:
@@ -310,20 +314,36 @@ class _ConvNLC(torch.autograd.Function):
                 _note_staged(ctx.w_leaf)        # derived tensors (folded / weight-normed): flush when backward ends
             if bslot is not None:
                 _note_staged(ctx.b_leaf)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
+def tap_major(w: Tensor) -> Tensor:
+    """Cached (Cout, k, Cin) copy of a reference-layout (Cout, Cin, k) conv weight, refreshed when the weight changes
+    (optimizer step, load_state_dict) and, for trainable weights, at every step boundary (see begin_step).  Frozen
+    weights keep one copy for good."""
+    key = _source_key(w) + ((_GENERATION[0],) if w.requires_grad else ())
+    ent = getattr(w, '_s2ag_tm', None)
+    if ent is None or ent[0] != key:
+        with torch.no_grad():
+            ent = (key, w.detach().permute(0, 2, 1).contiguous())
+        w._s2ag_tm = ent
+    return ent[1]
+
+
+TM_COPIES = __import__('os').environ.get('S2AG_TM_COPIES', '1') != '0'
 BN_STATS_EPILOGUE = __import__('os').environ.get('S2AG_BN_EPILOGUE', '1') != '0'
 _WANT_STATS = [False]
 _LAST_STATS = [None]
 
 
 def conv1d_nlc(x: Tensor, w: Tensor, bias: Optional[Tensor], stride=1, pad=0, dil=1, lout: Optional[int] = None,
-               act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0, w_tap_major=False, bn_stats=False) -> Tensor:
+               act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0, w_tap_major=False, bn_stats=False,
+               tm_copy=False) -> Tensor:
     """x (N, Lin, Cin) channels-last, w (Cout, Cin, k) [or (Cout, k, Cin) if ``w_tap_major``] -> (N, Lout, Cout).
     ``lout`` overrides the usual output length (the TCN's causal conv + chomp is pad = (k-1)*dil on the left with
     lout = Lin).  ``bn_stats``: the output goes straight into a training-mode ``batch_norm_act``; where the kernel has a
-    statistics epilogue the column sums ride along (attribute on the returned tensor) and BatchNorm skips its own pass."""
+    statistics epilogue the column sums ride along (attribute on the returned tensor) and BatchNorm skips its own pass.
+    ``tm_copy``: run the forward / data gradient from a cached tap-major copy of ``w`` (straight-line kernels)."""
     N, Lin, Cin = x.shape
     if w_tap_major:
         Cout, ks, Cin_w = w.shape
@@ -334,8 +354,9 @@ def conv1d_nlc(x: Tensor, w: Tensor, bias: Optional[Tensor], stride=1, pad=0, di
         lout = (Lin + 2 * pad - dil * (ks - 1) - 1) // stride + 1
     _WANT_STATS[0] = bool(bn_stats) and BN_STATS_EPILOGUE
     try:
+        w_tm = tap_major(w) if (tm_copy and TM_COPIES and not w_tap_major and ks > 1 and Cin % 4 == 0) else None
         out = _ConvNLC.apply(x, w, bias, (N, Lin, lout, Cin, Cout, ks, stride, pad, dil, int(w_tap_major)), act,
-                             float(slope), float(drop_p), noise, site)
+                             float(slope), float(drop_p), noise, site, w_tm)
     finally:
         _WANT_STATS[0] = False
     out = out.view(N, lout, Cout)

@@ -138,6 +138,70 @@ def test_tap_major_conv_straight_line_kernels(S, case):
     assert rel(bg.grad, br.grad) < TOL
 
 
+@pytest.mark.parametrize('N,Lin,stride,pad', [(3, 4000, 5, 100), (2, 700, 5, 1600), (5, 333, 1, 0), (1, 5000, 8, 7)])
+def test_one_channel_wave_conv_direct_kernels(S, N, Lin, stride, pad):
+    """nn.Conv1d(1, 16, 15, ...) -- the head of the wave encoder -- runs on direct kernels (conv_c1.hip): forward with
+    the BatchNorm column sums riding along, weight + bias gradient; several runs per clip, ragged last run, padding
+    larger than a run."""
+    ops = S['ops']
+    g = torch.Generator().manual_seed(N + Lin + stride + pad)
+    x = torch.randn(N, Lin, 1, generator=g)
+    w = torch.randn(16, 1, 15, generator=g) / 4
+    b = torch.randn(16, generator=g)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv1d(x.transpose(1, 2), wr, br, stride=stride, padding=pad).transpose(1, 2)
+    wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yg = ops.conv1d_nlc(x.cuda(), wg, bg, stride=stride, pad=pad, bn_stats=True)
+    assert yg.shape == yr.shape and rel(yg, yr) < TOL
+    part, rows = yg._s2ag_stats                  # this geometry always has the statistics epilogue
+    part = part.view(2, rows, 16).sum(1).cpu()
+    flat = yr.detach().reshape(-1, 16).double()
+    assert rel(part[0], flat.sum(0)) < 1e-6 and rel(part[1], (flat * flat).sum(0)) < 1e-6
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.cuda())
+    assert rel(wg.grad, wr.grad) < TOL and rel(bg.grad, br.grad) < TOL
+
+
+# (N, Lin, Cin, Cout, k, stride, pad): STRIDED convs with tap-major weights (the wave / MFCC encoders' derived copies):
+# forward + weight gradient on the straight-line kernels, data gradient on the general residue kernel
+TM_STRIDED = [
+    (3, 300, 16, 32, 15, 6, 0),               # WavEncoder conv2 (Cin < 32: several taps per 32-wide K tile)
+    (2, 260, 32, 64, 15, 6, 0),               # WavEncoder conv3
+    (5, 250, 64, 32, 15, 6, 0),               # WavEncoder conv4: Lout = 40
+    (4, 77, 20, 24, 5, 2, 3),                 # padding + stride, K = 100 (tail), Lout = 40
+    (2, 40, 8, 9, 3, 3, 1),                   # Lout = 14 < 32: the weight gradient falls back to the general kernel
+]
+
+
+@pytest.mark.parametrize('case', TM_STRIDED)
+def test_tap_major_strided_conv(S, case):
+    ops = S['ops']
+    N, Lin, Cin, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Lin, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv1d(xr.transpose(1, 2), wr, br, stride=stride, padding=pad).transpose(1, 2)
+    xg, bg = x.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    wtm = w.permute(0, 2, 1).contiguous().cuda().requires_grad_(True)
+    yg = ops.conv1d_nlc(xg, wtm, bg, stride=stride, pad=pad, w_tap_major=True, bn_stats=True)
+    assert yg.shape == yr.shape and rel(yg, yr) < TOL
+    st = getattr(yg, '_s2ag_stats', None)
+    if st is not None:
+        part, rows = st
+        part = part.view(2, rows, Cout).sum(1).cpu()
+        flat = yr.detach().reshape(-1, Cout).double()
+        assert rel(part[0], flat.sum(0)) < 1e-6 and rel(part[1], (flat * flat).sum(0)) < 1e-6
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.cuda())
+    assert rel(xg.grad, xr.grad) < TOL
+    assert rel(wtm.grad.permute(0, 2, 1), wr.grad) < TOL
+    assert rel(bg.grad, br.grad) < TOL
+
+
 @pytest.mark.parametrize('M,K,N', [(4352, 600, 1800), (70, 36, 5), (33, 100, 64), (257, 88, 900), (64, 4, 16)])
 def test_linear_straight_line_kernels_with_tails(S, M, K, N):
     """Linear forward / data gradient / weight gradient (+ bias gradient in the same launch) at shapes whose row, column
