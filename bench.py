@@ -123,13 +123,23 @@ def gru_roofline(B, iters=20):
     # and WRITE_SIZE in separate runs, KB units, FETCH doubled as the gfx950 guide prescribes): gi + exchange-cell
     # reads, y / ydrop / saved-gate / exchange-cell writes.  Only meaningful at the profiled shape (B = 128).
     traffic = (2 * 118122.0 + 61589.0) * 1024 if (coop and B == 128) else None
-    return dict(bound='mfma', kernel=('gru_coop_fwd_k<300,32>' if coop else 'gru_seq_fwd_k<8>') + ' (H=300, T=34, 2 directions)',
+    np_ = int(lib.s2ag_gru_coop_split_pieces()) if coop else 0
+    name = (f'gru_coop_fwd_sp_k<300,32,{np_}>' if np_ else 'gru_coop_fwd_k<300,32>') if coop else 'gru_seq_fwd_k<8>'
+    pipe = {0: '12 waves x 38 f32 MFMAs (16x16x4) per CU and step',
+            2: '12 waves x 15 bf16 MFMAs (16x16x32; 3 piece products of 2-piece operand splits) per CU and step',
+            3: '12 waves x 30 bf16 MFMAs (16x16x32; the 6 leading piece products of exact 3-piece splits of the fp32 '
+               'operands: fp32-equivalent, error vs fp64 equal to the f32-MFMA kernel, tools/diag_gru_split.py) per CU '
+               'and step'}[np_]
+    return dict(bound='mfma', kernel=name + ' (H=300, T=34, 2 directions)',
                 achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3, traffic=traffic,
                 traffic_source='profiles/r01_h_pmc_FETCH_SIZE.txt + r01_h_pmc_WRITE_SIZE.txt', ms_per_launch=ms,
                 algorithmic_flops_per_launch=flops,
-                note='sequential recurrence: per time step (tools/diag_coop_trace.py, profiles/r01_h_coop_gru_phase_trace.txt) '
-                     '~1.0 us tagged-cell gather of h, 1.9 us for 12 waves x 38 fp32 MFMAs on one CU (the pipe itself: '
-                     '3 waves/SIMD x 38 x 32 cycles), 0.4 us gate math, 0.3 us stores; 160 of 256 CUs hold W_hh in registers')
+                note='peak = dense f32 MFMA peak (the arithmetic is fp32); algorithmic FLOPs = 2 x 3H x H per clip, frame '
+                     'and direction.  Sequential recurrence, bound by the per-step exchange latency, not by the pipe: per '
+                     'time step (tools/diag_coop_trace.py, profiles/r01_i_coop_gru_phase_trace.txt) ~1.3 us for the new '
+                     'state to reach the peers (write-through tagged cells, polling loads), ' + pipe +
+                     ', 0.4 us gate math, 0.5 us stores; 160 of 256 CUs hold W_hh in registers; ms_per_launch includes the '
+                     '~5 us exchange-buffer clear')
 
 
 def _graph_timer(fn, iters, warm=3):

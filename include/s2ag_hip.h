@@ -218,7 +218,8 @@ int s2ag_transpose(const float* src, int rows, int cols, float* dst, void* strea
  *        the register-resident small-H kernels read `whh` directly), else NULL
  *  y     (B*T, 2H): raw hidden states [forward | reverse]
  *  ydrop (B*T, 2H): nullable; y * keep-mask(site)/(1-p) -- the next layer's input in train mode
- *  gates (2, B*T, 4H): nullable; saved (r, z, n, W_hn h + b_hn) for the backward pass */
+ *  gates (2, B*T, H, 4): nullable; per unit the saved (r, z, n, W_hn h + b_hn) for the backward pass (opaque to the
+ *        caller: written by the forward kernels, read by the backward kernels, one 16-byte access per unit) */
 int s2ag_gru_seq_needs_transposed(int H);
 int s2ag_gru_seq_fwd(const float* gi, const float* whh, const float* whhT /*nullable*/, const float* bhh, float* y,
                      float* ydrop, float* gates, int B, int T, int H,
@@ -236,9 +237,16 @@ int s2ag_gru_seq_bwd(const float* dy, int lddy, int dy_dir_stride, const float* 
 /* Cooperative variant of the two calls above for large H (s2ag_gru_coop_supported(H) != 0; H = 300 on this path):
  * W_hh stays on chip (MFMA B-operands in registers); a group of ceil(H/32) workgroups shares one (direction,
  * 16-clip slice) and exchanges h_t (forward) / d(gh)_t (backward) once per step through `workspace` with
- * write-through stores + a per-step arrival counter (agent scope).  Same arguments and results as the
- * streaming kernels; `workspace` needs s2ag_gru_coop_workspace_bytes() bytes and may be uninitialised. */
+ * write-through stores of self-validating (value, step tag) cells (agent scope).  Same arguments and results as the
+ * streaming kernels; `workspace` needs s2ag_gru_coop_workspace_bytes() bytes and may be uninitialised.
+ * The per-step matrix products are fp32 products realised on the bf16 matrix pipe: every fp32 operand is split exactly
+ * into 3 bf16 pieces (24 mantissa bits) and the 6 leading piece products are accumulated in fp32 -- error against an
+ * fp64 reference equals the f32-MFMA kernels' (tools/diag_gru_split.py), 2.4x less time on the matrix pipe.
+ * s2ag_gru_coop_split_pieces(): pieces per operand in use (3 default; env S2AG_GRU_SPLIT=2: 16-bit mantissa, 3 products;
+ * S2AG_GRU_SPLIT=0: v_mfma_f32_16x16x4_f32). */
 int s2ag_gru_coop_supported(int H);
+int s2ag_gru_coop_split_pieces(void);
+int s2ag_gru_coop_set_split_pieces(int pieces /*0, 2, 3; anything else: back to the environment's choice*/);  /* returns the previous value */
 long long s2ag_gru_coop_workspace_bytes(int B, int T, int H, int backward);
 int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* ydrop, float* gates,
                       int B, int T, int H, const s2ag_epilogue* e /*host, nullable*/, void* workspace, void* stream);

@@ -97,10 +97,7 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_k(const float* __restrict__ gi
             if (ydrop) ydrop[yi] = drop ? hn * keep_scale(key, (unsigned long long)yi, drop_p, inv_keep) : hn;
             if (gates) {
                 float* gs = gates + ((long long)dir * B * T + row) * (4 * H);
-                gs[i] = r;
-                gs[H + i] = z;
-                gs[2 * H + i] = n;
-                gs[3 * H + i] = ghn;
+                *reinterpret_cast<float4*>(gs + 4 * i) = make_float4(r, z, n, ghn);
             }
         }
         __syncthreads();
@@ -147,7 +144,8 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_k(const float* __restrict__ dy
             if (drop) g *= keep_scale(key, (unsigned long long)(row * (2 * H) + dir * H + i), drop_p, inv_keep);
             const float dht = dh[b * H + i] + g;
             const float* gp = gates + ((long long)dir * B * T + row) * (4 * H);
-            const float r = gp[i], z = gp[H + i], n = gp[2 * H + i], hn = gp[3 * H + i];
+            const float4 sv = *reinterpret_cast<const float4*>(gp + 4 * i);
+            const float r = sv.x, z = sv.y, n = sv.z, hn = sv.w;
             float hp = 0.f;
             if (tprev >= 0 && tprev < T) hp = y[((long long)(b0 + b) * T + tprev) * (2 * H) + dir * H + i];
             const float dn = dht * (1.f - z) * (1.f - n * n);

@@ -26,6 +26,12 @@
 //
 // The backward kernel has the same structure with W_hh[:, slice] (3H x 32) in registers and the group
 // exchanging d(gh) (16 x 3H) cells per step; the running dL/dh of a (clip, unit) lives in its thread's register.
+//
+// Default build: the products run on the bf16 matrix pipe as exact 3-piece splits of the fp32 operands
+// (gru_coop_fwd_sp_k / gru_coop_bwd_k<.., 3>, see "fp32 products on the bf16 matrix pipe" below); the f32-MFMA kernels
+// described above remain selectable (S2AG_GRU_SPLIT=0) and are what the split kernels are validated against.
+#include <stdlib.h>
+
 #include "s2ag_common.h"
 
 namespace {
@@ -249,10 +255,247 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
                 if (ydrop) ydrop[yi] = drop ? hnew * keep_scale(key, (unsigned long long)yi, drop_p, inv_keep) : hnew;
                 if (gates) {
                     float* gs = gates + ((long long)dir * B * T + row) * (4 * H);
-                    gs[u] = r;
-                    gs[H + u] = z;
-                    gs[2 * H + u] = n;
-                    gs[3 * H + u] = ghn;
+                    *reinterpret_cast<float4*>(gs + 4 * u) = make_float4(r, z, n, ghn);
+                }
+            }
+        }
+        COOP_TR(5);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix pipe
+// ---------------------------------------------------------------------------------------------------------
+// The step's matrix product runs on the f32 MFMA (v_mfma_f32_16x16x4_f32: 32 cycles per SIMD for 1024 MACs) in the
+// kernels above -- 3 waves x 38 of them per SIMD are 1.5 us of the ~4.8 us step.  The bf16 pipe does 8192 MACs in ~17
+// cycles.  An fp32 value splits EXACTLY into bf16 pieces v = p0 + p1 (+ p2) + residual, |residual| <= 2^-17 |v| with two
+// pieces, 2^-25 |v| with three (each piece is the bf16 rounding of what the previous ones left; the differences are exact
+// in fp32).  The product a*b is then the sum of the piece products, accumulated in fp32 inside the MFMA:
+//   NP = 2:  a0b0 + a0b1 + a1b0                          (3 MFMAs, dropped terms <= 2^-16 |ab|: 16-bit mantissa)
+//   NP = 3:  ... + a1b1 + a0b2 + a2b0                    (6 MFMAs, dropped terms <= 2^-24 |ab|: fp32-equivalent)
+// W_hh is split once per launch into registers; a new state value is split once by the thread that produces it and
+// travels through the exchange already split: a cell is (p0, p1, p2, 16-bit step tag) in one 8-byte word.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+__device__ __forceinline__ unsigned bf16_rn(float v) {            // bf16 bits of v, round to nearest even (finite v)
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+template <int NP>
+__device__ __forceinline__ void split_bf16(float v, unsigned (&pc)[3]) {
+    pc[0] = bf16_rn(v);
+    float r = v - __uint_as_float(pc[0] << 16);
+    pc[1] = bf16_rn(r);
+    pc[2] = 0u;
+    if (NP == 3) {
+        r -= __uint_as_float(pc[1] << 16);
+        pc[2] = bf16_rn(r);
+    }
+}
+__device__ __forceinline__ void st_cell_sp(u64* p, const unsigned (&pc)[3], unsigned tag) {
+    const u64 w = (u64)(pc[0] | (pc[1] << 16)) | ((u64)(pc[2] | (tag << 16)) << 32);
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// gather_cells for split cells: piece p of (clip c, index k) goes to dst[p * PLANE + c * PITCH + k] (bf16 elements)
+template <int NL, int ROW, int PITCH, int PLANE, int NP>
+__device__ __forceinline__ bool gather_cells_sp(const u64* X, unsigned tag, unsigned short* dst, int* err,
+                                                unsigned* rounds) {
+    constexpr int n = CBS * ROW;
+    const int tid = threadIdx.x;
+    u64 v[NL];
+    unsigned spins = 0;
+    for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int i = tid + j * CNT;
+            v[j] = ld_cell(X + (i < n ? i : n - 1));
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) all = all && ((unsigned)(v[j] >> 48) == tag);
+        if (all) break;
+        if (++spins > SPIN_LIMIT) {
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int i = tid + j * CNT;
+        if (i < n) {
+            const int c = i / ROW, k = i - c * ROW;
+            unsigned short* d = dst + c * PITCH + k;
+            d[0] = (unsigned short)v[j];
+            d[PLANE] = (unsigned short)(v[j] >> 16);
+            if (NP == 3) d[2 * PLANE] = (unsigned short)(v[j] >> 32);
+        }
+    }
+    *rounds = spins;
+    return true;
+}
+
+// forward recurrence, products on the bf16 pipe (structure, mappings and exchange protocol of gru_coop_fwd_k)
+template <int H, int HW_, int NP>
+__global__ __launch_bounds__(CNT) void gru_coop_fwd_sp_k(const float* __restrict__ gi, const float* __restrict__ whh,
+                                                         const float* __restrict__ bhh, float* __restrict__ y,
+                                                         float* __restrict__ ydrop, float* __restrict__ gates,
+                                                         u64* xbuf, int* err, int B, int T, float drop_p,
+                                                         float inv_keep, const unsigned long long* rng, unsigned site) {
+    constexpr int H3 = 3 * H;
+    constexpr int NW_ = 3 * HW_;
+    constexpr int NTILES = NW_ / 16;
+    constexpr int KSPLIT = 12 / NTILES;
+    constexpr int KSTEPS = (H + 31) / 32;          // MFMA k-steps (K = 32 each) over the whole K = H
+    constexpr int KPW = (KSTEPS + KSPLIT - 1) / KSPLIT;
+    constexpr int GT = CBS * HW_;
+    constexpr int HPB = KSPLIT * KPW * 32 + 8;     // LDS row pitch in bf16 elements: 656 B = 164 words, rows 4 banks
+                                                   // apart (a lane's 16-byte operand chunk covers 4 banks)
+    constexpr int PLANE = CBS * HPB;               // one piece of the whole state
+    constexpr int RP = NW_ + 4;
+    constexpr int NLF = (H * CBS + CNT - 1) / CNT;
+    static_assert(NTILES * KSPLIT == 12 && GT <= CNT && HW_ == 32, "12 waves must tile (column tiles x K groups)");
+    static_assert((HPB * 2) % 16 == 0 && (HPB / 2) % 32 == 4, "operand chunks 16-byte aligned, rows 4 banks apart");
+    __shared__ __attribute__((aligned(16))) unsigned short hsb[NP * PLANE];   // h_{t-1} pieces, [piece][clip][k]
+    __shared__ float red[KSPLIT][CBS][RP];
+
+    const int s = blockIdx.x, bsl = blockIdx.y, dir = blockIdx.z;
+    const int nbs = gridDim.y;
+    const int group = dir * nbs + bsl;
+    const int u0 = s * HW_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave % NTILES, kh = wave / NTILES;
+    const float* W = whh + (size_t)dir * H3 * H;
+    const float* bh = bhh + dir * H3;
+
+    // B operands: lane = (gate column nt*16 + (lane & 15), k chunk (lane >> 4) * 8 ... + 7 of every 32-wide k-step)
+    const int kbeg = kh * KPW;
+    u32x4 breg[KPW][NP];
+    {
+        const int cl = nt * 16 + (lane & 15);
+        const int g = cl / HW_, cu = cl - g * HW_;
+        const int wu = u0 + cu;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            const int k0 = (kbeg + i) * 32 + (lane >> 4) * 8;
+            unsigned pk[8][3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                const float w = (k < H && wu < H) ? W[(size_t)(g * H + wu) * H + k] : 0.f;
+                split_bf16<NP>(w, pk[j]);
+            }
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) breg[i][pc][d] = pk[2 * d][pc] | (pk[2 * d + 1][pc] << 16);
+        }
+    }
+    for (int i = tid; i < NP * PLANE / 2; i += CNT) reinterpret_cast<unsigned*>(hsb)[i] = 0u;
+    SiteKey key{0, 0};
+    const bool drop = ydrop != nullptr && drop_p > 0.f;
+    if (drop) key = site_key(rng, site);
+    bool ok = true;
+
+    const int gc = tid >> 5, ul = tid & 31;
+    const int u = u0 + ul;
+    const int b0 = bsl * CBS;
+    const int nb = min(CBS, B - b0);
+    const bool gate_lane = tid < GT && u < H;
+    const bool gate_thread = gate_lane && gc < nb;
+    const float bias_r = gate_lane ? bh[u] : 0.f, bias_z = gate_lane ? bh[H + u] : 0.f,
+                bias_n = gate_lane ? bh[2 * H + u] : 0.f;
+    u64* X = xbuf + (size_t)group * 2 * H * CBS;
+    float hp = 0.f;
+    const unsigned short* a_base = hsb + (lane & 15) * HPB + kbeg * 32 + (lane >> 4) * 8;
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        const long long row = (long long)(b0 + gc) * T + t;
+        float gir = 0.f, giz = 0.f, gin = 0.f;
+        if (gate_thread) {
+            const float* gp = gi + row * (2 * H3) + dir * H3 + u;
+            gir = gp[0];
+            giz = gp[H];
+            gin = gp[2 * H];
+        }
+        COOP_TR(0);
+        if (step > 0) {
+            unsigned rounds = 0;
+            if (ok)
+                ok = gather_cells_sp<NLF, H, HPB, PLANE, NP>(X + (size_t)((step - 1) & 1) * H * CBS, (unsigned)step, hsb,
+                                                             err, &rounds);
+            COOP_TR(1);
+            COOP_TRV(7, rounds);
+            __syncthreads();
+        }
+        COOP_TR(2);
+#ifdef S2AG_COOP_TRACE
+        const u64 cyc0 = clock64();
+#endif
+        // ---- 16 x H times H x 16 per wave: KPW k-steps x (3 or 6) piece products, independent accumulation chains
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            bf16x8 a[NP], b[NP];
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+                a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a_base + pc * PLANE + i * 32));
+                b[pc] = __builtin_bit_cast(bf16x8, breg[i][pc]);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc2, 0, 0, 0);
+            if (NP == 3) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc2, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc1, 0, 0, 0);
+            }
+        }
+        const f32x4 acc = (acc1 + acc2) + acc0;     // small terms first
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[kh][(lane >> 4) * 4 + q][nt * 16 + (lane & 15)] = acc[q];
+#ifdef S2AG_COOP_TRACE
+        const u64 cyc1 = clock64();
+#endif
+        __syncthreads();
+        COOP_TR(3);
+        COOP_TRV(6, cyc1 - cyc0);
+        if (gate_lane) {
+            float hnew = 0.f, r = 0.f, z = 0.f, n = 0.f, ghn = bias_n;
+            if (gate_thread) {
+                float ghr = bias_r, ghz = bias_z;
+#pragma unroll
+                for (int q = 0; q < KSPLIT; ++q) {
+                    ghr += red[q][gc][ul];
+                    ghz += red[q][gc][HW_ + ul];
+                    ghn += red[q][gc][2 * HW_ + ul];
+                }
+                r = sigmoidf_(gir + ghr);
+                z = sigmoidf_(giz + ghz);
+                n = tanhf(gin + r * ghn);
+                hnew = (1.f - z) * n + z * hp;
+                hp = hnew;
+            }
+            COOP_TR(4);
+            if (step + 1 < T) {
+                unsigned pc[3];
+                split_bf16<NP>(hnew, pc);
+                st_cell_sp(X + (size_t)(step & 1) * H * CBS + (size_t)gc * H + u, pc, (unsigned)(step + 1));
+            }
+            if (gate_thread) {
+                const long long yi = row * (2 * H) + dir * H + u;
+                y[yi] = hnew;
+                if (ydrop) ydrop[yi] = drop ? hnew * keep_scale(key, (unsigned long long)yi, drop_p, inv_keep) : hnew;
+                if (gates) {
+                    float* gs = gates + ((long long)dir * B * T + row) * (4 * H);
+                    *reinterpret_cast<float4*>(gs + 4 * u) = make_float4(r, z, n, ghn);
                 }
             }
         }
@@ -270,7 +513,7 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_k(const float* __restrict__ 
 // (41 KB per workgroup and step).  The output-partitioned first version had every workgroup read the whole group's
 // d(gh) -- 14 400 cells, 115 KB, 18 MB per step over all groups: the gather ran at the memory-side fabric's ~4 TB/s and
 // was 4 of the step's 8.8 us.
-template <int H, int HW_>
+template <int H, int HW_, int NP>
 __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ dy, int lddy, int dy_dir_stride,
                                                       const float* __restrict__ whh, const float* __restrict__ y,
                                                       const float* __restrict__ gates, float* __restrict__ dgi,
@@ -286,10 +529,16 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
     constexpr int GT = CBS * HW_;
     constexpr int GOP = lds_pitch(3 * HW_);        // LDS pitch of the own d(gh) rows (132)
     constexpr int RP = NTL * 16 + 4;               // pitch of the per-gate partial products (308)
+    // NP > 0: products on the bf16 pipe from NP pieces per fp32 value (see gru_coop_fwd_sp_k); own d(gh) then sits in
+    // LDS as bf16 pieces [piece][clip][k'], pitch 104 elements = 52 words: 8 rows' 16-byte operand chunks tile the banks
+    constexpr int GOPB = 3 * HW_ + 8;
+    constexpr int GO_FLOATS = NP ? (NP * CBS * GOPB) / 2 : CBS * GOP;
     static_assert(HW_ == 32 && GT <= CNT, "one (clip, unit) per gate thread");
+    static_assert((GOPB * 2) % 16 == 0 && GO_FLOATS % 4 == 0, "16-byte operand chunks");
     extern __shared__ __attribute__((aligned(16))) float smem_bwd[];
     float* gO = smem_bwd;                                       // [CBS][GOP]: own d(gh), k' = gate*32 + unit
-    float (*red)[CBS][RP] = reinterpret_cast<float (*)[CBS][RP]>(gO + CBS * GOP);   // [3][CBS][RP]
+    unsigned short* gOb = reinterpret_cast<unsigned short*>(smem_bwd);
+    float (*red)[CBS][RP] = reinterpret_cast<float (*)[CBS][RP]>(smem_bwd + GO_FLOATS);   // [3][CBS][RP]
 
     const int s = blockIdx.x, bsl = blockIdx.y, dir = blockIdx.z;
     const int nbs = gridDim.y;
@@ -304,20 +553,35 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
     const float* W = whh + (size_t)dir * H3 * H;      // (3H, H) row-major
 
     // B operands: item it = wave + 12*i -> (column tile nt = it / 3, gate g = it % 3); B[k][j] = W[g*H + u0 + k][nt*16 + j]
-    float breg[IPW][KS];
+    float breg[NP ? 1 : IPW][NP ? 1 : KS];
+    u32x4 bsp[NP ? IPW : 1][NP ? NP : 1];          // split: one K = 32 step per item, lane = (column, units (lane>>4)*8..+7)
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
         const int it = wave + 12 * i;
         const int nt = it / 3, g = it - nt * 3;
         const int col = nt * 16 + (lane & 15);
+        if constexpr (NP == 0) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int ul = ks * 4 + (lane >> 4);
-            const int u = u0 + ul;
-            breg[i][ks] = (it < NITEM && u < H && col < H) ? W[(size_t)(g * H + u) * H + col] : 0.f;
+            for (int ks = 0; ks < KS; ++ks) {
+                const int ul = ks * 4 + (lane >> 4);
+                const int u = u0 + ul;
+                breg[i][ks] = (it < NITEM && u < H && col < H) ? W[(size_t)(g * H + u) * H + col] : 0.f;
+            }
+        } else {
+            unsigned pk[8][3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int u = u0 + (lane >> 4) * 8 + j;
+                const float w = (it < NITEM && u < H && col < H) ? W[(size_t)(g * H + u) * H + col] : 0.f;
+                split_bf16<(NP ? NP : 2)>(w, pk[j]);
+            }
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) bsp[i][pc][d] = pk[2 * d][pc] | (pk[2 * d + 1][pc] << 16);
         }
     }
-    for (int i = tid; i < CBS * GOP; i += CNT) gO[i] = 0.f;    // pad columns / clips beyond B stay zero
+    for (int i = tid; i < GO_FLOATS; i += CNT) gO[i] = 0.f;    // pad columns / clips beyond B stay zero
     SiteKey key{0, 0};
     const bool drop = drop_p > 0.f;
     if (drop) key = site_key(rng, site);
@@ -342,10 +606,11 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
             const long long row = (long long)(b0 + gc) * T + t;
             const float* gp = gates + ((long long)dir * B * T + row) * (4 * H);
             p.g = dy[row * lddy + dir * dy_dir_stride + u];
-            p.r = gp[u];
-            p.z = gp[H + u];
-            p.n = gp[2 * H + u];
-            p.hn = gp[3 * H + u];
+            const float4 sv = *reinterpret_cast<const float4*>(gp + 4 * u);
+            p.r = sv.x;
+            p.z = sv.y;
+            p.n = sv.z;
+            p.hn = sv.w;
             if (tprev >= 0 && tprev < T) p.hp = y[((long long)(b0 + gc) * T + tprev) * (2 * H) + dir * H + u];
         }
         return p;
@@ -380,9 +645,23 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
                 gh_o[H + u] = dz;
                 gh_o[2 * H + u] = dnr;
             }
-            gO[gc * GOP + ul] = dr;
-            gO[gc * GOP + HW_ + ul] = dz;
-            gO[gc * GOP + 2 * HW_ + ul] = dnr;
+            if constexpr (NP == 0) {
+                gO[gc * GOP + ul] = dr;
+                gO[gc * GOP + HW_ + ul] = dz;
+                gO[gc * GOP + 2 * HW_ + ul] = dnr;
+            } else {
+                unsigned pr[3], pz[3], pn[3];
+                split_bf16<(NP ? NP : 2)>(dr, pr);
+                split_bf16<(NP ? NP : 2)>(dz, pz);
+                split_bf16<(NP ? NP : 2)>(dnr, pn);
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) {
+                    unsigned short* d = gOb + pc * (CBS * GOPB) + gc * GOPB + ul;
+                    d[0] = (unsigned short)pr[pc];
+                    d[HW_] = (unsigned short)pz[pc];
+                    d[2 * HW_] = (unsigned short)pn[pc];
+                }
+            }
         }
         if (step + 1 == T) break;                   // the last step's dh is never consumed
         COOP_TR(1);
@@ -396,10 +675,33 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
             if (it >= NITEM) break;                 // wave-uniform
             const int nt = it / 3, g = it - nt * 3;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (NP == 0) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const float a = gO[(lane & 15) * GOP + g * HW_ + ks * 4 + (lane >> 4)];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[i][ks], acc, 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const float a = gO[(lane & 15) * GOP + g * HW_ + ks * 4 + (lane >> 4)];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[i][ks], acc, 0, 0, 0);
+                }
+            } else {
+                bf16x8 a[NP ? NP : 1], b[NP ? NP : 1];
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) {
+                    a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                                                           gOb + pc * (CBS * GOPB) + (lane & 15) * GOPB + g * HW_ +
+                                                           (lane >> 4) * 8));
+                    b[pc] = __builtin_bit_cast(bf16x8, bsp[i][pc]);
+                }
+                f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc1, 0, 0, 0);
+                if constexpr (NP == 3) {
+                    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc2, 0, 0, 0);
+                    acc1 += acc2;
+                }
+                acc += acc1;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) red[g][(lane >> 4) * 4 + q][nt * 16 + (lane & 15)] = acc[q];
@@ -457,6 +759,17 @@ inline size_t coop_payload_bytes(int B, int H, int backward) {
     return align_up(groups * producers * 2 * (size_t)H * CBS * sizeof(u64), 256);   // [group][parity][...] cells
 }
 
+// S2AG_GRU_SPLIT = 0: f32 MFMA; 2 / 3: fp32 products from 2 / 3 bf16 pieces on the bf16 pipe (see above)
+int g_split_override = -1;          // s2ag_gru_coop_set_split_pieces (tests / diagnostics)
+inline int coop_split_pieces() {
+    static const int v = [] {
+        const char* e = getenv("S2AG_GRU_SPLIT");
+        const int n = e ? atoi(e) : 3;
+        return (n == 2 || n == 3) ? n : 0;
+    }();
+    return g_split_override >= 0 ? g_split_override : v;
+}
+
 struct Ws {
     u64* x;
     int* err;
@@ -478,6 +791,12 @@ Ws carve(void* ws, int B, int H, int backward) {
 // H = 300: groups of 10 workgroups (32 units each) exchanging h per step.  (Small hidden sizes -- the
 // discriminators' H = 64 -- live entirely in registers: gru_small.hip.)
 extern "C" int s2ag_gru_coop_supported(int H) { return H == 300 ? 1 : 0; }
+extern "C" int s2ag_gru_coop_split_pieces(void) { return coop_split_pieces(); }
+extern "C" int s2ag_gru_coop_set_split_pieces(int pieces) {
+    const int prev = coop_split_pieces();
+    g_split_override = (pieces == 2 || pieces == 3) ? pieces : (pieces == 0 ? 0 : -1);
+    return prev;
+}
 
 extern "C" long long s2ag_gru_coop_workspace_bytes(int B, int T, int H, int backward) {
     if (B <= 0 || T <= 0 || !s2ag_gru_coop_supported(H)) return 0;
@@ -497,8 +816,20 @@ extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float*
     const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
     const unsigned long long* rg = e ? e->rng : nullptr;
     const unsigned site = e ? e->site : 0u;
-    hipLaunchKernelGGL((gru_coop_fwd_k<300, 32>), dim3(10, cdiv(B, CBS), 2), dim3(CNT), 0, (hipStream_t)stream, gi,
-                       whh, bhh, y, ydrop, gates, w.x, w.err, B, T, p, ik, rg, site);
+    const dim3 grid(10, cdiv(B, CBS), 2);
+    switch (coop_split_pieces()) {
+        case 2:
+            hipLaunchKernelGGL((gru_coop_fwd_sp_k<300, 32, 2>), grid, dim3(CNT), 0, (hipStream_t)stream, gi, whh, bhh, y,
+                               ydrop, gates, w.x, w.err, B, T, p, ik, rg, site);
+            break;
+        case 3:
+            hipLaunchKernelGGL((gru_coop_fwd_sp_k<300, 32, 3>), grid, dim3(CNT), 0, (hipStream_t)stream, gi, whh, bhh, y,
+                               ydrop, gates, w.x, w.err, B, T, p, ik, rg, site);
+            break;
+        default:
+            hipLaunchKernelGGL((gru_coop_fwd_k<300, 32>), grid, dim3(CNT), 0, (hipStream_t)stream, gi, whh, bhh, y, ydrop,
+                               gates, w.x, w.err, B, T, p, ik, rg, site);
+    }
     S2AG_LAUNCH_CHECK();
     return 0;
 }
@@ -516,16 +847,28 @@ extern "C" int s2ag_gru_coop_bwd(const float* dy, int lddy, int dy_dir_stride, c
     const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
     const unsigned long long* rg = e ? e->rng : nullptr;
     const unsigned site = e ? e->site : 0u;
-    constexpr size_t smem = sizeof(float) * (CBS * lds_pitch(96) + 3 * CBS * (19 * 16 + 4));   // gO + red
-    static bool granted = false;
-    if (!granted) {
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const int np = coop_split_pieces();
+    const size_t red_bytes = sizeof(float) * 3 * CBS * (19 * 16 + 4);
+    const size_t smem = red_bytes + (np ? (size_t)np * CBS * (96 + 8) * 2 : sizeof(float) * CBS * lds_pitch(96));   // gO + red
+    const void* fn = np == 3   ? reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 3>)
+                     : np == 2 ? reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 2>)
+                               : reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 0>);
+    static bool granted[4] = {false, false, false, false};
+    if (!granted[np]) {
+        hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (ae != hipSuccess) return (int)ae;
-        granted = true;
+        granted[np] = true;
     }
-    hipLaunchKernelGGL((gru_coop_bwd_k<300, 32>), dim3(10, cdiv(B, CBS), 2), dim3(CNT), smem, (hipStream_t)stream, dy,
-                       lddy, dy_dir_stride, whh, y, gates, dgi, dgh, w.x, w.err, B, T, p, ik, rg, site);
+    const dim3 grid(10, cdiv(B, CBS), 2);
+    if (np == 3)
+        hipLaunchKernelGGL((gru_coop_bwd_k<300, 32, 3>), grid, dim3(CNT), smem, (hipStream_t)stream, dy, lddy,
+                           dy_dir_stride, whh, y, gates, dgi, dgh, w.x, w.err, B, T, p, ik, rg, site);
+    else if (np == 2)
+        hipLaunchKernelGGL((gru_coop_bwd_k<300, 32, 2>), grid, dim3(CNT), smem, (hipStream_t)stream, dy, lddy,
+                           dy_dir_stride, whh, y, gates, dgi, dgh, w.x, w.err, B, T, p, ik, rg, site);
+    else
+        hipLaunchKernelGGL((gru_coop_bwd_k<300, 32, 0>), grid, dim3(CNT), smem, (hipStream_t)stream, dy, lddy,
+                           dy_dir_stride, whh, y, gates, dgi, dgh, w.x, w.err, B, T, p, ik, rg, site);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

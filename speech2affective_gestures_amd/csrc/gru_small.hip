@@ -116,10 +116,7 @@ __global__ __launch_bounds__(SNT) void gru_small_fwd_k(const float* __restrict__
                 if (ydrop) ydrop[yi] = drop ? hn * keep_scale(key, (unsigned long long)yi, drop_p, inv_keep) : hn;
             } else if (gates) {
                 float* gs = gates + ((long long)dir * B * T + row) * (4 * H);
-                gs[i] = r;
-                gs[H + i] = z;
-                gs[2 * H + i] = n;
-                gs[3 * H + i] = an;
+                *reinterpret_cast<float4*>(gs + 4 * i) = make_float4(r, z, n, an);
             }
         }
         SM_TR(4);
@@ -168,10 +165,11 @@ __global__ __launch_bounds__(SNT) void gru_small_bwd_k(const float* __restrict__
             const long long row = (long long)(b0 + b) * T + t;
             const float* gp = gates + ((long long)dir * B * T + row) * (4 * H);
             p.g = dy[row * lddy + dir * dy_dir_stride + i];
-            p.r = gp[i];
-            p.z = gp[H + i];
-            p.n = gp[2 * H + i];
-            p.hn = gp[3 * H + i];
+            const float4 sv = *reinterpret_cast<const float4*>(gp + 4 * i);
+            p.r = sv.x;
+            p.z = sv.y;
+            p.n = sv.z;
+            p.hn = sv.w;
             if (tprev >= 0 && tprev < T) p.hp = y[((long long)(b0 + b) * T + tprev) * (2 * H) + dir * H + i];
         }
         return p;

@@ -442,6 +442,41 @@ def test_gru_forward_backward(S, B, T, I, H, L, sum_dirs, p):
     assert ops.coop_gru_timeouts() == 0          # cooperative (H = 300) launches never timed out on a peer
 
 
+@pytest.mark.parametrize('pieces,tol', [(0, 3e-6), (3, 3e-6), (2, 2e-5)])
+def test_coop_gru_products_on_the_bf16_pipe(S, pieces, tol):
+    """H = 300 recurrence: the per-step products as exact bf16-piece splits of the fp32 operands (3 pieces = default,
+    2 pieces) against the f32-MFMA kernels (0) -- all three checked against an fp64 torch GRU.  Three pieces must be as
+    accurate as the f32 MFMA; two pieces carry 16 mantissa bits."""
+    ops, noise, lib = S['ops'], S['noise'], S['ops']._lib()
+    B, T, I, H, L_ = 21, 34, 88, 300, 2
+    sd = _gru_sd(I, H, L_, 4242)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, T, I, generator=g)
+    ref = torch.nn.GRU(I, H, L_, batch_first=True, bidirectional=True).double()
+    with torch.no_grad():
+        for k, v in sd.items():
+            getattr(ref, k[len('gru.'):]).copy_(v.double())
+    xr = x.double().requires_grad_(True)
+    yr, _ = ref(xr)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    prev = lib.s2ag_gru_coop_set_split_pieces(pieces)
+    try:
+        assert lib.s2ag_gru_coop_split_pieces() == pieces
+        wg = [w.cuda().requires_grad_(True) for w in _flat(sd, L_)]
+        xg = x.cuda().requires_grad_(True)
+        yg = ops.gru(xg, wg, H, L_, True, 0.0, noise.begin_pass('cuda'), 300, False)
+        yg.backward(dy.cuda())
+        torch.cuda.synchronize()
+    finally:
+        lib.s2ag_gru_coop_set_split_pieces(-1)
+    assert lib.s2ag_gru_coop_split_pieces() == prev
+    err = lambda a, b: float((a.detach().double().cpu() - b.detach()).abs().max() / b.detach().abs().max())
+    assert err(yg, yr) < tol and err(xg.grad, xr.grad) < tol
+    assert err(wg[1].grad, ref.weight_hh_l0.grad) < tol and err(wg[0].grad, ref.weight_ih_l0.grad) < tol
+    assert ops.coop_gru_timeouts() == 0
+
+
 def test_embedding_dropout_and_dense_gradient(S):
     ops, noise = S['ops'], S['noise']
     g = torch.Generator().manual_seed(12)

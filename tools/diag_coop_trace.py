@@ -14,7 +14,7 @@ from speech2affective_gestures_amd import _lib as L  # noqa: E402
 
 src = os.path.join(ROOT, 'speech2affective_gestures_amd', 'csrc')
 out = '/tmp/libs2ag_trace.so'
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-DS2AG_COOP_TRACE',
+cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-DS2AG_COOP_TRACE', *os.environ.get('EXTRA_DEFS', '').split(),
        '-I' + os.path.join(ROOT, 'include'), '-I' + src] + [os.path.join(src, f) for f in sorted(os.listdir(src))
                                                             if f.endswith('.hip')] + ['-o', out]
 subprocess.check_call(cmd)
