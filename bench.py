@@ -119,10 +119,10 @@ def gru_roofline(B, iters=20):
     ms = sum(a.elapsed_time(b) for a, b in evs) / iters
     flops = 2.0 * B * T * 2 * H * 3 * H           # recurrent mat-vec MACs x2, both directions
     achieved = flops / (ms * 1e-3) / 1e12
-    # HBM/fabric bytes per launch from the PMC passes committed under profiles/r01_h_pmc_* (rocprofv3 --pmc FETCH_SIZE
+    # HBM/fabric bytes per launch from the PMC passes committed under profiles/r01_i_pmc_* (rocprofv3 --pmc FETCH_SIZE
     # and WRITE_SIZE in separate runs, KB units, FETCH doubled as the gfx950 guide prescribes): gi + exchange-cell
     # reads, y / ydrop / saved-gate / exchange-cell writes.  Only meaningful at the profiled shape (B = 128).
-    traffic = (2 * 118122.0 + 61589.0) * 1024 if (coop and B == 128) else None
+    traffic = (2 * 118252.0 + 59134.6) * 1024 if (coop and B == 128) else None
     np_ = int(lib.s2ag_gru_coop_split_pieces()) if coop else 0
     name = (f'gru_coop_fwd_sp_k<300,32,{np_}>' if np_ else 'gru_coop_fwd_k<300,32>') if coop else 'gru_seq_fwd_k<8>'
     pipe = {0: '12 waves x 38 f32 MFMAs (16x16x4) per CU and step',
@@ -132,7 +132,7 @@ def gru_roofline(B, iters=20):
                'and step'}[np_]
     return dict(bound='mfma', kernel=name + ' (H=300, T=34, 2 directions)',
                 achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3, traffic=traffic,
-                traffic_source='profiles/r01_h_pmc_FETCH_SIZE.txt + r01_h_pmc_WRITE_SIZE.txt', ms_per_launch=ms,
+                traffic_source='profiles/r01_i_pmc_FETCH_SIZE.txt + r01_i_pmc_WRITE_SIZE.txt', ms_per_launch=ms,
                 algorithmic_flops_per_launch=flops,
                 note='peak = dense f32 MFMA peak (the arithmetic is fp32); algorithmic FLOPs = 2 x 3H x H per clip, frame '
                      'and direction.  Sequential recurrence, bound by the per-step exchange latency, not by the pipe: per '
