@@ -79,6 +79,14 @@ int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw,
                                float* dbias /*nullable: dbias[co] (+)= sum_m gy[m, co], folded into the same launch*/,
                                const s2ag_conv_geom* g /*host*/, int accumulate, void* stream);
 
+/* Both backward GEMMs of one stride-1 layer in ONE launch (they share gy): dx = (as s2ag_conv1d_nlc_bwd_data, not
+ * accumulating), dw / dbias += (as s2ag_conv1d_nlc_bwd_weight with accumulate = 1).  Returns S2AG_E_UNSUPPORTED (nothing
+ * launched) for geometries outside the straight-line kernels (strided, reference-layout multi-tap weights, clips shorter
+ * than 32 frames): the caller then issues the two separate calls.
+ * replaces: ConvolutionBackward / AddmmBackward of net/tcn.py:19,25, net/utils/tgcn.py:56,181,200 and the Linear layers. */
+int s2ag_conv1d_nlc_bwd_pair(const float* gy, const float* w, const float* x, float* dx, float* dw,
+                             float* dbias /*nullable*/, const s2ag_conv_geom* g /*host*/, void* stream);
+
 /* out[c] (+)= sum_r x[r*ld + c]; if sq != NULL also sq[c] (+)= sum_r x^2.   (bias grads, BN batch statistics) */
 int s2ag_colsum(const float* x, int rows, int cols, int ld, float* out, float* sq /*nullable*/, int accumulate,
                 void* stream);

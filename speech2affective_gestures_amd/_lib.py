@@ -39,6 +39,7 @@ SIGNATURES = {
     's2ag_conv1d_nlc_fwd': [vp, vp, vp, vp, PG, PE, vp],
     's2ag_conv1d_nlc_bwd_data': [vp, vp, vp, PG, ci, vp],
     's2ag_conv1d_nlc_bwd_weight': [vp, vp, vp, vp, PG, ci, vp],
+    's2ag_conv1d_nlc_bwd_pair': [vp, vp, vp, vp, vp, vp, PG, vp],
     's2ag_colsum': [vp, ci, ci, ci, vp, vp, ci, vp],
     's2ag_colstats_f64': [vp, ci, ci, ci, vp, vp, vp],
     's2ag_bn_coeffs': [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp],
@@ -112,6 +113,9 @@ def load():
         raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
     _lib = lib
     return lib
+
+
+E_UNSUPPORTED = -2          # S2AG_E_UNSUPPORTED (include/s2ag_hip.h)
 
 
 def check(rc: int, what: str):

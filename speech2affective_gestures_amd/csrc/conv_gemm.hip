@@ -925,6 +925,9 @@ static bool use_gemm_lin() {
     return v;
 }
 
+int s2ag_bwd_pair(const float* gy, const float* w, const float* x, float* dx, float* dw, float* db, int nclips, int L,
+                  int Cin, int Cout, int ks, int pad, int dil, int ldx, int ldg, int wtm, int chunk, int nsplit,
+                  hipStream_t stream);
 // conv_c1.hip
 int s2ag_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Lin, int Lout, int Cin,
                      int Cout, int ks, int stride, int pad, int dil, int ldx, int ldy, double* stats, int stats_cap_rows,
@@ -1103,6 +1106,25 @@ extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float
         hipLaunchKernelGGL(conv_wgrad2_k, grid, dim3(512), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(conv_wgrad_k, grid, dim3(256), 0, (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_conv1d_nlc_bwd_pair(const float* gy, const float* w, const float* x, float* dx, float* dw,
+                                        float* dbias, const s2ag_conv_geom* g, void* stream) {
+    if (bad_geom(g) || !gy || !w || !x || !dx || !dw) return S2AG_E_BADARG;
+    if (!use_gemm_lin() || g->stride != 1 || g->Lin != g->Lout) return S2AG_E_UNSUPPORTED;
+    const int Mtot = g->N * g->Lout;
+    const int tiles = cdiv(g->Cout, BM) * cdiv(g->ksize * g->Cin, BN);
+    int nsplit = cdiv(384, tiles);                       // as s2ag_conv1d_nlc_bwd_weight on the straight-line path
+    const int max_split = cdiv(Mtot, 4 * BK);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    const int chunk = cdiv(cdiv(Mtot, nsplit), BK2) * BK2;
+    nsplit = cdiv(Mtot, chunk);
+    if (!s2ag_bwd_pair(gy, w, x, dx, dw, dbias, g->N, g->Lin, g->Cin, g->Cout, g->ksize, g->pad, g->dil, g->ldx, g->ldy,
+                       g->w_tap_major, chunk, nsplit, (hipStream_t)stream))
+        return S2AG_E_UNSUPPORTED;
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -46,20 +46,20 @@ struct LinP {
 };
 
 template <bool BWD, int BM_, bool CONV>
-__global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
+__device__ __forceinline__ void gemm_lin_body(const LinP& p, float* smem, const int bx, const int by, const int gdx) {
     constexpr int NT = 512;
     constexpr int WM = 2, WN = 2, KG = 2;
     constexpr int TM = BM_ / (16 * WM), TN = 64 / (16 * WN);
     constexpr int CA = (BM_ * (LBK / 4)) / NT;                    // float4 chunks of A per thread (1 at BM=64)
     constexpr int KSG = (LBK / 4) / KG;
     static_assert(BM_ == 64 || BM_ == 32, "row tile");
-    __shared__ __attribute__((aligned(16))) float As[2][BM_][LPK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][64][LPK];
+    float (*As)[BM_][LPK] = reinterpret_cast<float (*)[BM_][LPK]>(smem);                       // [2][BM_][LPK]
+    float (*Bs)[64][LPK] = reinterpret_cast<float (*)[64][LPK]>(smem + 2 * BM_ * LPK);          // [2][64][LPK]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wave / (WM * WN), wr = (wave % (WM * WN)) / WN, wc = wave % WN;
-    const int m0 = blockIdx.x * BM_, n0 = blockIdx.y * 64;
+    const int m0 = bx * BM_, n0 = by * 64;
 
     // ---- loader coordinates: A chunk = (row a_r, k quad a_kq); at BM = 32 only the first 256 threads carry one
     const bool has_a = CA > 0 || tid < BM_ * (LBK / 4);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
         // Column sums of this wave's output rows (fp64 from the first add: E[x^2] - E[x]^2 cancels in fp32) for the
         // BatchNorm that follows the layer -- saves it a pass over the matrix.  One partial row per (row block, row
         // wave); lanes that share a column (lane >> 4 = 0..3) meet in two DPP steps.
-        const size_t R = (size_t)gridDim.x * WM, r = (size_t)blockIdx.x * WM + wr;
+        const size_t R = (size_t)gdx * WM, r = (size_t)bx * WM + wr;
 #pragma unroll
         for (int tj = 0; tj < TN; ++tj) {
             double s1 = 0.0, s2 = 0.0;
@@ -273,6 +273,14 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
             }
         }
     }
+}
+
+constexpr int gemm_lin_smem_floats(int bm) { return 2 * LPK * (bm + 64); }
+
+template <bool BWD, int BM_, bool CONV>
+__global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
+    __shared__ __attribute__((aligned(16))) float smem[gemm_lin_smem_floats(BM_)];
+    gemm_lin_body<BWD, BM_, CONV>(p, smem, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -375,15 +383,17 @@ struct WgP {
 
 constexpr int WPW = 64 + 16;          // k-major LDS pitch (fragment reads of 4 k-rows hit disjoint banks)
 
+constexpr int WG_SMEM_FLOATS = 4 * LBK * WPW;
+
 template <bool SHIFT>
-__global__ __launch_bounds__(512) void wgrad_lin_k(WgP p) {
-    __shared__ float As[2][LBK][WPW];                 // [m][co]
-    __shared__ float Bs[2][LBK][WPW];                 // [m][j = tap*Cin + ci]
+__device__ __forceinline__ void wgrad_lin_body(const WgP& p, float* smem, const int bx, const int by, const int bz) {
+    float (*As)[LBK][WPW] = reinterpret_cast<float (*)[LBK][WPW]>(smem);                        // [2][m][co]
+    float (*Bs)[LBK][WPW] = reinterpret_cast<float (*)[LBK][WPW]>(smem + 2 * LBK * WPW);        // [2][m][j = tap*Cin + ci]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
-    const int co0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
-    const int mbeg = blockIdx.z * p.chunk;
+    const int co0 = bx * 64, j0 = by * 64;
+    const int mbeg = bz * p.chunk;
     const int mend = min(p.M, mbeg + p.chunk);
     const int cidx = tid & 63, mq = tid >> 6;         // rows mq*4 .. mq*4+3 of the 32-row tile
     const int NCW = p.ks * p.Cin;
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(512) void wgrad_lin_k(WgP p) {
     int l = SHIFT ? (int)(r0 % p.L) : 0;              // frame of this thread's first row inside its clip
     const float* x_ptr = jcol < NCW ? (SHIFT ? p.x + (r0 / p.L) * (long long)p.Ls * p.ldx + ci : p.x + r0 * p.ldx + ci)
                                     : nullptr;
-    const bool want_db = p.db != nullptr && blockIdx.y == 0;
+    const bool want_db = p.db != nullptr && by == 0;
     float bsum = 0.f;
 
     float ra0[4], rb0[4], ra1[4], rb1[4];
@@ -533,6 +543,40 @@ __global__ __launch_bounds__(512) void wgrad_lin_k(WgP p) {
             }
         }
 }
+
+template <bool SHIFT>
+__global__ __launch_bounds__(512) void wgrad_lin_k(WgP p) {
+    __shared__ __attribute__((aligned(16))) float smem[WG_SMEM_FLOATS];
+    wgrad_lin_body<SHIFT>(p, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// One launch for a layer's two backward GEMMs (both read gy): blocks [0, n2) run the weight-gradient tiles, the rest the
+// data-gradient tiles.  At M = clips*frames = 4 352 either kernel alone leaves CUs idle (400 / 680 blocks of uneven
+// length over 256 CUs) and the backward pass of the TCN / ST-GCN stacks is a serial chain of such 25-40 us launches.
+template <int BM_, bool CONV, bool SHIFT>
+__global__ __launch_bounds__(512) void bwd_pair_k(LinP p1, WgP p2, int n2, int g2x, int g2y, int g1x) {
+    constexpr int SM = gemm_lin_smem_floats(BM_) > WG_SMEM_FLOATS ? gemm_lin_smem_floats(BM_) : WG_SMEM_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SM];
+    const int b = blockIdx.x;
+    if (b < n2) {
+        const int x = b % g2x, r = b / g2x;
+        wgrad_lin_body<SHIFT>(p2, smem, x, r % g2y, r / g2y);
+    } else {
+        const int b1 = b - n2;
+        gemm_lin_body<true, BM_, CONV>(p1, smem, b1 % g1x, b1 / g1x, g1x);
+    }
+}
+
+template <int BM_, bool CONV>
+void launch_pair(const LinP& p1, const WgP& p2, bool shift, dim3 g1, dim3 g2, hipStream_t stream) {
+    const int n2 = g2.x * g2.y * g2.z, n1 = g1.x * g1.y;
+    if (shift)
+        hipLaunchKernelGGL((bwd_pair_k<BM_, CONV, true>), dim3(n1 + n2), dim3(512), 0, stream, p1, p2, n2, (int)g2.x,
+                           (int)g2.y, (int)g1.x);
+    else
+        hipLaunchKernelGGL((bwd_pair_k<BM_, CONV, false>), dim3(n1 + n2), dim3(512), 0, stream, p1, p2, n2, (int)g2.x,
+                           (int)g2.y, (int)g1.x);
+}
 }  // namespace
 
 // Returns 1 if the launch was taken (one frame per clip without padding -- Linear -- or at least 32 output frames per
@@ -551,5 +595,38 @@ int s2ag_wgrad_lin(const float* gy, const float* x, float* dw, float* db, int nc
         hipLaunchKernelGGL(wgrad_lin_k<false>, grid, dim3(512), 0, stream, p);
     else
         hipLaunchKernelGGL(wgrad_lin_k<true>, grid, dim3(512), 0, stream, p);
+    return 1;
+}
+
+// Data gradient + weight (+ bias) gradient of one stride-1 layer in ONE launch (bwd_pair_k).  Returns 1 if taken: the
+// geometry must be covered by both straight-line kernels (1-tap layer, or tap-major weights with Lin == Lout).
+int s2ag_bwd_pair(const float* gy, const float* w, const float* x, float* dx, float* dw, float* db, int nclips, int L,
+                  int Cin, int Cout, int ks, int pad, int dil, int ldx, int ldg, int wtm, int chunk, int nsplit,
+                  hipStream_t stream) {
+    if ((Cout & 3) || (ldg & 3) || !al16(gy)) return 0;
+    const bool one_tap = (ks == 1 && pad == 0);
+    if (!one_tap && !wtm) return 0;
+    const bool linear = (L == 1 && one_tap);
+    if (!linear && L < LBK) return 0;
+    LinP p1{};
+    p1.a = gy; p1.w = w; p1.bias = nullptr; p1.out = dx; p1.M = nclips * L; p1.K = ks * Cout; p1.N = Cin;
+    p1.lda = ldg; p1.ldo = ldx; p1.ldw = Cin;
+    p1.CK = Cout; p1.ks = ks; p1.dil = dil; p1.L = L; p1.Ls = L; p1.stride = 1; p1.off = pad;
+    p1.act = 0; p1.slope = 1.f; p1.drop_p = 0.f; p1.inv_keep = 1.f; p1.rng = nullptr; p1.site = 0; p1.accumulate = 0;
+    WgP p2{};
+    p2.gy = gy; p2.x = x; p2.dw = dw; p2.db = db; p2.M = nclips * L; p2.L = L; p2.Ls = L; p2.stride = 1;
+    p2.Cin = Cin; p2.Cout = Cout; p2.ks = ks;
+    p2.pad = pad; p2.dil = dil; p2.ldx = ldx; p2.ldg = ldg; p2.wtm = wtm; p2.chunk = chunk;
+    const dim3 g2(cdiv(Cout, 64), cdiv(ks * Cin, 64), nsplit);
+    const int colb = cdiv(Cin, 64);
+    const bool bm64 = (long long)cdiv(p1.M, 64) * colb >= bm64_min_blocks();
+    const dim3 g1(cdiv(p1.M, bm64 ? 64 : 32), colb);
+    if (one_tap) {
+        if (bm64) launch_pair<64, false>(p1, p2, !linear, g1, g2, stream);
+        else launch_pair<32, false>(p1, p2, !linear, g1, g2, stream);
+    } else {
+        if (bm64) launch_pair<64, true>(p1, p2, true, g1, g2, stream);
+        else launch_pair<32, true>(p1, p2, true, g1, g2, stream);
+    }
     return 1;
 }

@@ -126,6 +126,28 @@ def conv_bwd_weight_raw(gy: Tensor, x: Tensor, dw: Tensor, N, Lin, Lout, Cin, Co
                                               _stream()), 'conv_bwd_weight')
 
 
+FUSE_BWD_PAIR = __import__('os').environ.get('S2AG_FUSE_BWD', '1') != '0'
+
+
+def conv_bwd_pair_raw(gy: Tensor, w: Tensor, x: Tensor, dx: Tensor, dw: Tensor, dbias: Optional[Tensor], N, Lin, Lout,
+                      Cin, Cout, ks, stride, pad, dil, wtm) -> bool:
+    """dx = data gradient, dw / dbias += weight / bias gradient of one stride-1 layer in ONE launch.  False (nothing
+    launched) where the geometry is outside the straight-line kernels: the caller issues the two separate calls."""
+    if stride != 1 or Lin != Lout:
+        return False
+    gy, gr, gc, ldg = as_rows(gy)
+    x, xr, xc, ldx = as_rows(x)
+    _, dr, dc, lddx = as_rows(dx)
+    assert gr == N * Lout and gc == Cout and xr == N * Lin and xc == Cin and dr == xr and dc == Cin and lddx == ldx
+    assert dw.is_contiguous() and dw.numel() == Cout * Cin * ks and w.is_contiguous()
+    g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg, wtm)
+    rc = _lib().s2ag_conv1d_nlc_bwd_pair(_p(gy), _p(w), _p(x), _p(dx), _p(dw), _p(dbias), C.byref(g), _stream())
+    if rc == L.E_UNSUPPORTED:
+        return False
+    L.check(rc, 'conv_bwd_pair')
+    return True
+
+
 def colsum_raw(x: Tensor, out: Tensor, sq: Optional[Tensor] = None, accumulate=False):
     x, r, c, ld = as_rows(x)
     L.check(_lib().s2ag_colsum(_p(x), r, c, ld, _p(out), _p(sq), int(accumulate), _stream()), 'colsum')
@@ -287,12 +309,24 @@ class _ConvNLC(torch.autograd.Function):
         else:
             g, _, _, _ = as_rows(dy)
         dx = dw = db = None
+        wslot = _grad_slot(ctx.w_leaf) if ctx.needs_input_grad[1] else None
+        bslot = _grad_slot(ctx.b_leaf) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        flops = 2.0 * N * Lout * Cout * Cin * ks
+        if (FUSE_BWD_PAIR and ctx.needs_input_grad[0] and wslot is not None and ctx.wtm_k == wtm
+                and flops < ASYNC_WGRAD_MIN_FLOPS and (bslot is not None or not (ctx.has_bias and ctx.needs_input_grad[2]))):
+            # both backward GEMMs of the layer in one launch (inline weight gradients only: the big GRU ones run
+            # beside the next layer's recurrence on a forked stream instead)
+            dx = torch.empty(N * Lin, Cin, dtype=torch.float32, device=dy.device)
+            if conv_bwd_pair_raw(g, w, x, dx, wslot, bslot, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, wtm):
+                _note_staged(ctx.w_leaf)
+                if bslot is not None:
+                    _note_staged(ctx.b_leaf)
+                return dx.view(x.shape), None, None, None, None, None, None, None, None, None
+            dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(N * Lin, Cin, dtype=torch.float32, device=dy.device)
             conv_bwd_data_raw(g, w, dx, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, False, ctx.wtm_k)
             dx = dx.view(x.shape)
-        wslot = _grad_slot(ctx.w_leaf) if ctx.needs_input_grad[1] else None
-        bslot = _grad_slot(ctx.b_leaf) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         need_db = ctx.has_bias and ctx.needs_input_grad[2] and bslot is None
         if need_db:
             db = torch.empty(Cout, dtype=torch.float32, device=dy.device)

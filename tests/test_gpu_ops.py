@@ -138,6 +138,38 @@ def test_tap_major_conv_straight_line_kernels(S, case):
     assert rel(bg.grad, br.grad) < TOL
 
 
+@pytest.mark.parametrize('case', TM_CASES + [(70, 1, 36, 20, 1, 0, 1, False), (9, 34, 64, 48, 1, 0, 1, False)])
+def test_fused_data_and_weight_gradient_launch(S, case, monkeypatch):
+    """With gradient slots in place (the trainer's arena / staging buffers) a stride-1 layer's data gradient and weight +
+    bias gradient are ONE launch (bwd_pair_k); results as the separate kernels', accumulated onto what the slots held."""
+    ops = S['ops']
+    N, Ln, Cin, Cout, k, pad, dil, causal = case
+    g = torch.Generator().manual_seed(sum(case[:7]) + 1)
+    x = torch.randn(N, Ln, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    if causal:
+        yr = F.conv1d(xr.transpose(1, 2), wr, br, padding=pad, dilation=dil)[:, :, :-pad].transpose(1, 2)
+    else:
+        yr = F.conv1d(xr.transpose(1, 2), wr, br, padding=pad, dilation=dil).transpose(1, 2)
+    xg, bg = x.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    wtm = w.permute(0, 2, 1).contiguous().cuda().requires_grad_(True)            # (Cout, k, Cin)
+    w0, b0 = torch.randn(wtm.shape, generator=g).cuda(), torch.randn(Cout, generator=g).cuda()
+    wtm.grad, bg.grad = w0.clone(), b0.clone()
+    taken = []
+    real = ops.conv_bwd_pair_raw
+    monkeypatch.setattr(ops, 'conv_bwd_pair_raw', lambda *a: (taken.append(real(*a)), taken[-1])[1])
+    yg = ops.conv1d_nlc(xg, wtm, bg, pad=pad, dil=dil, lout=yr.shape[1], w_tap_major=True)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    yg.backward(dy.cuda())
+    assert taken == [(Ln == 1 or Ln >= 32) and Cout % 4 == 0]      # else: the two separate launches
+    assert rel(xg.grad, xr.grad) < TOL
+    assert rel((wtm.grad - w0).permute(0, 2, 1), wr.grad) < TOL
+    assert rel(bg.grad - b0, br.grad) < TOL
+
+
 @pytest.mark.parametrize('N,Lin,stride,pad', [(3, 4000, 5, 100), (2, 700, 5, 1600), (5, 333, 1, 0), (1, 5000, 8, 7)])
 def test_one_channel_wave_conv_direct_kernels(S, N, Lin, stride, pad):
     """nn.Conv1d(1, 16, 15, ...) -- the head of the wave encoder -- runs on direct kernels (conv_c1.hip): forward with
