@@ -124,7 +124,9 @@ def gru_roofline(B, iters=20):
     # reads, y / ydrop / saved-gate / exchange-cell writes.  Only meaningful at the profiled shape (B = 128).
     traffic = (2 * 118252.0 + 59134.6) * 1024 if (coop and B == 128) else None
     np_ = int(lib.s2ag_gru_coop_split_pieces()) if coop else 0
-    name = (f'gru_coop_fwd_sp_k<300,32,{np_}>' if np_ else 'gru_coop_fwd_k<300,32>') if coop else 'gru_seq_fwd_k<8>'
+    ns_ = int(lib.s2ag_gru_coop_fwd_slices(B)) if coop else 1
+    name = ((f'gru_coop_fwd_sp2_k<300,32,{np_},2>' if ns_ == 2 else f'gru_coop_fwd_sp_k<300,32,{np_}>') if np_
+            else 'gru_coop_fwd_k<300,32>') if coop else 'gru_seq_fwd_k<8>'
     pipe = {0: '12 waves x 38 f32 MFMAs (16x16x4) per CU and step',
             2: '12 waves x 15 bf16 MFMAs (16x16x32; 3 piece products of 2-piece operand splits) per CU and step',
             3: '12 waves x 30 bf16 MFMAs (16x16x32; the 6 leading piece products of exact 3-piece splits of the fp32 '
@@ -138,7 +140,7 @@ def gru_roofline(B, iters=20):
                      'and direction.  Sequential recurrence, bound by the per-step exchange latency, not by the pipe: per '
                      'time step (tools/diag_coop_trace.py, profiles/r01_i_coop_gru_phase_trace.txt) ~1.3 us for the new '
                      'state to reach the peers (write-through tagged cells, polling loads), ' + pipe +
-                     ', 0.4 us gate math, 0.5 us stores; 160 of 256 CUs hold W_hh in registers; ms_per_launch includes the '
+                     ', 0.4 us gate math, 0.5 us stores; ' + ('a workgroup alternates between two 16-clip slices (one travels while the other is computed): 80 of 256 CUs per launch' if ns_ == 2 else '160 of 256 CUs hold W_hh in registers') + '; ms_per_launch includes the '
                      '~5 us exchange-buffer clear')
 
 

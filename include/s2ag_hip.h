@@ -254,6 +254,9 @@ int s2ag_gru_seq_bwd(const float* dy, int lddy, int dy_dir_stride, const float* 
  * S2AG_GRU_SPLIT=0: v_mfma_f32_16x16x4_f32). */
 int s2ag_gru_coop_supported(int H);
 int s2ag_gru_coop_split_pieces(void);
+/* 16-clip slices one forward workgroup alternates between (2 when B > 16 with the 3-piece products: while one slice's
+ * new state travels to the peers the other slice is computed; a launch then occupies 10 * ceil(B/32) * 2 CUs) */
+int s2ag_gru_coop_fwd_slices(int B);
 int s2ag_gru_coop_set_split_pieces(int pieces /*0, 2, 3; anything else: back to the environment's choice*/);  /* returns the previous value */
 long long s2ag_gru_coop_workspace_bytes(int B, int T, int H, int backward);
 int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* ydrop, float* gates,

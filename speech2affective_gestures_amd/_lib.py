@@ -69,6 +69,7 @@ SIGNATURES = {
     's2ag_gru_seq_bwd': [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],
     's2ag_gru_coop_supported': [ci],
     's2ag_gru_coop_split_pieces': [],
+    's2ag_gru_coop_fwd_slices': [ci],
     's2ag_gru_coop_set_split_pieces': [ci],
     's2ag_gru_coop_workspace_bytes': [ci, ci, ci, ci],
     's2ag_gru_coop_fwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp, vp],

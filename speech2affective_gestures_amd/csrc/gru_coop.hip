@@ -503,6 +503,227 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_sp_k(const float* __restrict
     }
 }
 
+
+// Two 16-clip slices per workgroup (B > 16): with the product on the bf16 pipe a step is ~1.3 us of waiting for the
+// peers' cells against ~1.8 us of work, so a workgroup alternates between two independent slices -- while slice A's new
+// state travels, slice B (whose cells arrived during A's work) is multiplied, gated and published.  Same W_hh registers
+// serve both.  A launch then needs 10 x ceil(B/32) x 2 = 80 workgroups at B = 128 instead of 160: two generator passes
+// (or a pass and the weight-gradient GEMMs of the previous layer) fit on the chip side by side.
+// Roles: waves 0..3 do the gate math, two (clip, unit) pairs per thread, and all the stores; waves 4..11 gather -- a
+// wave's loads cannot be consumed before its earlier stores are acknowledged (one in-order counter), and the gate waves
+// have just published the other slice.  Ten cells per gathering thread, all in flight at once.
+template <int H, int HW_, int NP, int NS>
+__global__ __launch_bounds__(CNT) void gru_coop_fwd_sp2_k(const float* __restrict__ gi, const float* __restrict__ whh,
+                                                          const float* __restrict__ bhh, float* __restrict__ y,
+                                                          float* __restrict__ ydrop, float* __restrict__ gates,
+                                                          u64* xbuf, int* err, int B, int T, float drop_p,
+                                                          float inv_keep, const unsigned long long* rng, unsigned site) {
+    constexpr int H3 = 3 * H;
+    constexpr int NW_ = 3 * HW_;
+    constexpr int NTILES = NW_ / 16;
+    constexpr int KSPLIT = 12 / NTILES;
+    constexpr int KSTEPS = (H + 31) / 32;
+    constexpr int KPW = (KSTEPS + KSPLIT - 1) / KSPLIT;
+    constexpr int CPT = 2;                         // (clip, unit) pairs per gate thread
+    constexpr int GT = CBS * HW_ / CPT;            // gate threads (waves 0..3)
+    constexpr int NGA = CNT - GT;                  // gathering threads (waves 4..11)
+    constexpr int HPB = KSPLIT * KPW * 32 + 8;
+    constexpr int PLANE = CBS * HPB;
+    constexpr int RP = NW_ + 4;
+    constexpr int NLG = (H * CBS + NGA - 1) / NGA; // exchange cells per gathering thread (10)
+    static_assert(NTILES * KSPLIT == 12 && GT < CNT && HW_ == 32, "12 waves must tile (column tiles x K groups)");
+    static_assert((HPB * 2) % 16 == 0 && (HPB / 2) % 32 == 4, "operand chunks 16-byte aligned, rows 4 banks apart");
+    extern __shared__ __attribute__((aligned(16))) unsigned short hsb2[];          // [slice][piece][clip][k]
+    __shared__ float red[KSPLIT][CBS][RP];
+
+    const int s = blockIdx.x, bpair = blockIdx.y, dir = blockIdx.z;
+    const int nbs = (B + CBS - 1) / CBS;           // 16-clip slices in the batch
+    const int u0 = s * HW_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave % NTILES, kh = wave / NTILES;
+    const float* W = whh + (size_t)dir * H3 * H;
+    const float* bh = bhh + dir * H3;
+
+    const int kbeg = kh * KPW;
+    u32x4 breg[KPW][NP];
+    {
+        const int cl = nt * 16 + (lane & 15);
+        const int g = cl / HW_, cu = cl - g * HW_;
+        const int wu = u0 + cu;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            const int k0 = (kbeg + i) * 32 + (lane >> 4) * 8;
+            unsigned pk[8][3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                const float w = (k < H && wu < H) ? W[(size_t)(g * H + wu) * H + k] : 0.f;
+                split_bf16<NP>(w, pk[j]);
+            }
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) breg[i][pc][d] = pk[2 * d][pc] | (pk[2 * d + 1][pc] << 16);
+        }
+    }
+    for (int i = tid; i < NS * NP * PLANE / 2; i += CNT) reinterpret_cast<unsigned*>(hsb2)[i] = 0u;
+    SiteKey key{0, 0};
+    const bool drop = ydrop != nullptr && drop_p > 0.f;
+    if (drop) key = site_key(rng, site);
+    bool ok = true;
+
+    const int gc = tid >> 5, ul = tid & 31;        // gate threads: clips gc and gc + 8 of a slice
+    const int u = u0 + ul;
+    const bool gate_lane = tid < GT && u < H;
+    const float bias_r = gate_lane ? bh[u] : 0.f, bias_z = gate_lane ? bh[H + u] : 0.f,
+                bias_n = gate_lane ? bh[2 * H + u] : 0.f;
+    int b0[NS];
+    bool live[NS];
+    u64* X[NS];
+    float hp[NS][CPT];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+        const int bsl = bpair * NS + sl;
+        live[sl] = bsl < nbs;                      // block-uniform: a trailing half-empty pair skips its second slice
+        b0[sl] = bsl * CBS;
+        X[sl] = xbuf + (size_t)(dir * nbs + (live[sl] ? bsl : 0)) * 2 * H * CBS;
+#pragma unroll
+        for (int c2 = 0; c2 < CPT; ++c2) hp[sl][c2] = 0.f;
+    }
+    const int a_off = (lane & 15) * HPB + kbeg * 32 + (lane >> 4) * 8;
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            if (!live[sl]) continue;
+            unsigned short* hs = hsb2 + sl * (NP * PLANE);
+            const int nb = min(CBS, B - b0[sl]);
+            float gir[CPT], giz[CPT], gin[CPT];
+#pragma unroll
+            for (int c2 = 0; c2 < CPT; ++c2) {
+                gir[c2] = giz[c2] = gin[c2] = 0.f;
+                const int c = gc + c2 * (CBS / CPT);
+                if (gate_lane && c < nb) {
+                    const float* gp = gi + ((long long)(b0[sl] + c) * T + t) * (2 * H3) + dir * H3 + u;
+                    gir[c2] = gp[0];
+                    giz[c2] = gp[H];
+                    gin[c2] = gp[2 * H];
+                }
+            }
+            if (step > 0 && tid >= GT) {
+                // cells tagged `step` of this slice, fetched by the store-free waves
+                const u64* Xs = X[sl] + (size_t)((step - 1) & 1) * H * CBS;
+                constexpr int n = CBS * H;
+                const int gt = tid - GT;
+                u64 v[NLG];
+                unsigned spins = 0;
+                while (ok) {
+                    bool all = true;
+#pragma unroll
+                    for (int j = 0; j < NLG; ++j) {
+                        const int i = gt + j * NGA;
+                        v[j] = ld_cell(Xs + (i < n ? i : n - 1));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NLG; ++j) all = all && ((unsigned)(v[j] >> 48) == (unsigned)step);
+                    if (all) break;
+                    if (++spins > SPIN_LIMIT) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = false;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int j = 0; j < NLG; ++j) {
+                    const int i = gt + j * NGA;
+                    if (i < n) {
+                        const int c = i / H, k = i - c * H;
+                        unsigned short* d = hs + c * HPB + k;
+                        d[0] = (unsigned short)v[j];
+                        d[PLANE] = (unsigned short)(v[j] >> 16);
+                        if (NP == 3) d[2 * PLANE] = (unsigned short)(v[j] >> 32);
+                    }
+                }
+            }
+            __syncthreads();      // also at step 0: red[] may still be read by the other slice's gate phase
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+                bf16x8 a[NP], b[NP];
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) {
+                    a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(hs + a_off + pc * PLANE + i * 32));
+                    b[pc] = __builtin_bit_cast(bf16x8, breg[i][pc]);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc2, 0, 0, 0);
+                if (NP == 3) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc2, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc1, 0, 0, 0);
+                }
+            }
+            const f32x4 acc = (acc1 + acc2) + acc0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[kh][(lane >> 4) * 4 + q][nt * 16 + (lane & 15)] = acc[q];
+            __syncthreads();
+            // gates; red[] is next written behind the other slice's (or the next step's) pre-MFMA barrier
+            if (gate_lane) {
+                float hnew[CPT], r[CPT], z[CPT], n[CPT], ghn[CPT];
+#pragma unroll
+                for (int c2 = 0; c2 < CPT; ++c2) {
+                    const int c = gc + c2 * (CBS / CPT);
+                    hnew[c2] = r[c2] = z[c2] = n[c2] = 0.f;
+                    ghn[c2] = bias_n;
+                    if (c < nb) {
+                        float ghr = bias_r, ghz = bias_z;
+#pragma unroll
+                        for (int q = 0; q < KSPLIT; ++q) {
+                            ghr += red[q][c][ul];
+                            ghz += red[q][c][HW_ + ul];
+                            ghn[c2] += red[q][c][2 * HW_ + ul];
+                        }
+                        r[c2] = sigmoidf_(gir[c2] + ghr);
+                        z[c2] = sigmoidf_(giz[c2] + ghz);
+                        n[c2] = tanhf(gin[c2] + r[c2] * ghn[c2]);
+                        hnew[c2] = (1.f - z[c2]) * n[c2] + z[c2] * hp[sl][c2];
+                        hp[sl][c2] = hnew[c2];
+                    }
+                }
+                if (step + 1 < T) {
+#pragma unroll
+                    for (int c2 = 0; c2 < CPT; ++c2) {
+                        unsigned pc[3];
+                        split_bf16<NP>(hnew[c2], pc);
+                        st_cell_sp(X[sl] + (size_t)(step & 1) * H * CBS + (size_t)(gc + c2 * (CBS / CPT)) * H + u, pc,
+                                   (unsigned)(step + 1));
+                    }
+                }
+#pragma unroll
+                for (int c2 = 0; c2 < CPT; ++c2) {
+                    const int c = gc + c2 * (CBS / CPT);
+                    if (c < nb) {
+                        const long long row = (long long)(b0[sl] + c) * T + t;
+                        const long long yi = row * (2 * H) + dir * H + u;
+                        y[yi] = hnew[c2];
+                        if (ydrop)
+                            ydrop[yi] = drop ? hnew[c2] * keep_scale(key, (unsigned long long)yi, drop_p, inv_keep)
+                                             : hnew[c2];
+                        if (gates) {
+                            float* gs = gates + ((long long)dir * B * T + row) * (4 * H);
+                            *reinterpret_cast<float4*>(gs + 4 * u) = make_float4(r[c2], z[c2], n[c2], ghn[c2]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // backward through time
 // ---------------------------------------------------------------------------------------------------------
@@ -770,6 +991,15 @@ inline int coop_split_pieces() {
     return g_split_override >= 0 ? g_split_override : v;
 }
 
+// S2AG_GRU_SLICES=1: one 16-clip slice per workgroup (160 workgroups at B = 128); default 2 (see gru_coop_fwd_sp2_k)
+inline bool coop_two_slices() {
+    static const bool v = [] {
+        const char* e = getenv("S2AG_GRU_SLICES");
+        return !(e && atoi(e) == 1);
+    }();
+    return v;
+}
+
 struct Ws {
     u64* x;
     int* err;
@@ -792,6 +1022,7 @@ Ws carve(void* ws, int B, int H, int backward) {
 // discriminators' H = 64 -- live entirely in registers: gru_small.hip.)
 extern "C" int s2ag_gru_coop_supported(int H) { return H == 300 ? 1 : 0; }
 extern "C" int s2ag_gru_coop_split_pieces(void) { return coop_split_pieces(); }
+extern "C" int s2ag_gru_coop_fwd_slices(int B) { return (coop_split_pieces() == 3 && B > CBS && coop_two_slices()) ? 2 : 1; }
 extern "C" int s2ag_gru_coop_set_split_pieces(int pieces) {
     const int prev = coop_split_pieces();
     g_split_override = (pieces == 2 || pieces == 3) ? pieces : (pieces == 0 ? 0 : -1);
@@ -817,6 +1048,20 @@ extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float*
     const unsigned long long* rg = e ? e->rng : nullptr;
     const unsigned site = e ? e->site : 0u;
     const dim3 grid(10, cdiv(B, CBS), 2);
+    if (coop_split_pieces() == 3 && B > CBS && coop_two_slices()) {
+        constexpr int smem2 = 2 * 3 * CBS * (5 * 2 * 32 + 8) * 2;          // [slice][piece][clip][k] bf16
+        static bool granted2 = false;
+        if (!granted2) {
+            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 3, 2>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+            if (ae != hipSuccess) return (int)ae;
+            granted2 = true;
+        }
+        hipLaunchKernelGGL((gru_coop_fwd_sp2_k<300, 32, 3, 2>), dim3(10, cdiv(B, 2 * CBS), 2), dim3(CNT), smem2,
+                           (hipStream_t)stream, gi, whh, bhh, y, ydrop, gates, w.x, w.err, B, T, p, ik, rg, site);
+        S2AG_LAUNCH_CHECK();
+        return 0;
+    }
     switch (coop_split_pieces()) {
         case 2:
             hipLaunchKernelGGL((gru_coop_fwd_sp_k<300, 32, 2>), grid, dim3(CNT), 0, (hipStream_t)stream, gi, whh, bhh, y,
