@@ -184,6 +184,13 @@ int s2ag_weight_norm_bwd(const float* dw, const float* v, const float* g, const 
  *   tensor, y = staged gradient of the derived tensor);  dv += ..., dg += ..., dw = 0 for weight norm.
  * The stage is a persistent buffer that the weight-gradient kernels accumulate into (accumulate = 1): it is zero
  * before the first use and every flush leaves it zero, so no clearing launch is ever needed. */
+/* Batch decode on the device.  replaces: processor_v2.py:603-606 / :614-617 (`audio * audio_max / 32767` in float64 on the
+ * host, `.float()`, then the copy): the raw int16 waveform (rows, cols) and the per-clip float64 peak cross PCIe instead,
+ * out = float(double(a) * peak[row] / 32767) -- bit-identical to the host path. */
+int s2ag_audio_decode(const short* audio_i16, const double* peak, float* out, int rows, int cols, void* stream);
+/* replaces the `.float()` of vec_seq (float64, processor_v2.py:602) and mfcc_features (float16, :607) */
+int s2ag_to_f32(const void* x, int src_is_f16 /*else float64*/, float* out, long long n, void* stream);
+
 /* diagnostics: *out = device wall clock (100 MHz ticks) when the stream reaches this point (capturable) */
 int s2ag_timestamp(unsigned long long* out, void* stream);
 

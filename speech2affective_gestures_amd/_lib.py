@@ -67,6 +67,8 @@ SIGNATURES = {
     's2ag_gru_seq_needs_transposed': [ci],
     's2ag_gru_seq_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],
     's2ag_gru_seq_bwd': [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp],
+    's2ag_audio_decode': [vp, vp, vp, ci, ci, vp],
+    's2ag_to_f32': [vp, ci, vp, cll, vp],
     's2ag_gru_coop_supported': [ci],
     's2ag_gru_coop_split_pieces': [],
     's2ag_gru_coop_fwd_slices': [ci],

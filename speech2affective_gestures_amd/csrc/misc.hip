@@ -531,8 +531,50 @@ extern "C" int s2ag_weight_norm_multi(const s2ag_wn_job* jobs, int njobs, int fl
 
 // ---- device-side wall clock (100 MHz) for scheduling diagnostics inside captured graphs ------------------------
 namespace {
+// Batch decode on the device (processor_v2.py:603-614 do it on the host before the copy): the raw int16 waveform and
+// its per-clip peak cross PCIe (half the bytes of the decoded fp32), out = float(double(a) * peak / 32767) -- the
+// reference's float64 arithmetic, so the result is bit-identical to its host path.
+__global__ __launch_bounds__(256) void audio_decode_k(const short* __restrict__ a, const double* __restrict__ peak,
+                                                      float* __restrict__ out, int rows, int cols) {
+    const long long total = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / cols);
+        out[i] = (float)((double)a[i] * peak[r] / 32767.0);
+    }
+}
+// vec_seq float64 -> float32 (.float()), mfcc float16 -> float32
+__global__ __launch_bounds__(256) void f64_to_f32_k(const double* __restrict__ x, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (float)x[i];
+}
+__global__ __launch_bounds__(256) void f16_to_f32_k(const _Float16* __restrict__ x, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (float)x[i];
+}
+
 __global__ void timestamp_k(unsigned long long* out) { *out = wall_clock64(); }
 }  // namespace
+
+extern "C" int s2ag_audio_decode(const short* audio_i16, const double* peak, float* out, int rows, int cols,
+                                 void* stream) {
+    if (!audio_i16 || !peak || !out || rows <= 0 || cols <= 0) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(audio_decode_k, dim3(ew_grid((long long)rows * cols)), dim3(256), 0, (hipStream_t)stream, audio_i16,
+                       peak, out, rows, cols);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_to_f32(const void* x, int src_is_f16, float* out, long long n, void* stream) {
+    if (!x || !out || n <= 0) return S2AG_E_BADARG;
+    if (src_is_f16)
+        hipLaunchKernelGGL(f16_to_f32_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const _Float16*>(x), out, n);
+    else
+        hipLaunchKernelGGL(f64_to_f32_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const double*>(x), out, n);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int s2ag_timestamp(unsigned long long* out, void* stream) {
     if (!out) return S2AG_E_BADARG;

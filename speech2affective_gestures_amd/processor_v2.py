@@ -245,6 +245,15 @@ class Processor(object):
         num_data = self.num_train_samples if train else self.num_val_samples
         spk = self.train_speaker_model if train else self.val_speaker_model
         B = self.args.batch_size
+        if torch.device(self.device).type == 'cuda' and getattr(
+                self.args, 'prefetch_batches', os.environ.get('S2AG_PREFETCH', '1') != '0'):
+            # pinned staging + background gather + device-side decode, two batches ahead (data.BatchFeeder)
+            from .data import BatchFeeder
+            feeders = self.__dict__.setdefault('_feeders', {})
+            if train not in feeders:
+                feeders[train] = BatchFeeder(samples, num_data, B, self.device, spk)
+            yield from feeders[train].batches((num_data + B - 1) // B)
+            return
         for _ in range((num_data + B - 1) // B):
             keys = np.random.choice(num_data, size=B, replace=True)
             text = torch.from_numpy(samples['extended_word_seq'][keys]).to(self.device, non_blocking=True)

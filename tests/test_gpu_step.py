@@ -239,3 +239,37 @@ def test_shared_encoder_pass_equals_three_separate_passes(monkeypatch):
             elif not is_noise_driven_after_adam(k):
                 ok, info = adam_close(sd1[k], sd0[k], 5e-4, step + 1)
                 assert ok, (step, k, info)
+
+
+@pytest.mark.gpu
+def test_prefetching_batch_feeder_matches_the_host_path():
+    """Processor.yield_batch through data.BatchFeeder (pinned staging, background gather, device-side decode) yields
+    bit-identical batches to the reference-shaped host path (processor_v2.py:589-638) for the same numpy RNG state."""
+    import types
+    import numpy as np
+    from speech2affective_gestures_amd import processor_v2 as P
+
+    class Vocab:
+        word2index = {'v%d' % i: i for i in range(12)}
+    rs = np.random.RandomState(5)
+    n, B = 70, 16
+    samples = dict(extended_word_seq=rs.randint(0, 9, (n, 34)).astype(np.int64), vec_seq=rs.randn(n, 34, 27),
+                   audio=rs.randint(-30000, 30000, (n, 3001)).astype(np.int16), audio_max=rs.rand(n) + 0.5,
+                   mfcc_features=rs.randn(n, 37, 7).astype(np.float16), vid_indices=rs.randint(0, 5, n))
+
+    def run(prefetch):
+        pr = object.__new__(P.Processor)
+        pr.train_samples, pr.val_samples, pr.num_train_samples, pr.num_val_samples = samples, None, n, 0
+        pr.train_speaker_model = pr.val_speaker_model = Vocab()
+        pr.args = types.SimpleNamespace(batch_size=B, prefetch_batches=prefetch)
+        pr.device = torch.device('cuda', 0)
+        np.random.seed(11)
+        out = [[None if t is None else t.cpu() for t in b] for b in pr.yield_batch(train=True)]
+        torch.cuda.synchronize()
+        return out
+    host, fed = run(False), run(True)
+    assert len(host) == len(fed) == 5
+    for hb, fb in zip(host, fed):
+        for h, f in zip(hb, fb):
+            assert h.dtype == f.dtype and h.shape == f.shape and torch.equal(h, f)
+    assert fed[0][2].dtype == torch.float32 and float(fed[0][2].abs().max()) <= 1.5 * 30000 / 32767 + 1e-6

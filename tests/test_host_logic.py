@@ -145,6 +145,18 @@ def test_yield_batch_semantics_on_host():
     assert vids.dtype == torch.int64 and 3 not in vids.tolist() and set(vids.tolist()) <= set(range(12))
 
 
+def test_other_speaker_sampler_excludes_the_batch():
+    """processor_v2.py:622-635: speaker ids for the generator are drawn from the speakers NOT present in the batch."""
+    from speech2affective_gestures_amd.data import other_speakers
+    spk = types.SimpleNamespace(word2index={'v%d' % i: i for i in range(20)})
+    np.random.seed(3)
+    present = np.array([1, 1, 7, 19, 4])
+    out = other_speakers(spk, present, 500)
+    assert out.shape == (500,) and out.dtype == np.int64
+    assert not set(out.tolist()) & set(present.tolist()) and set(out.tolist()) <= set(range(20))
+    assert len(set(out.tolist())) == 16           # every other speaker is reachable
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
