@@ -440,7 +440,9 @@ def _flat(sd, L):
 
 @pytest.mark.parametrize('B,T,I,H,L,sum_dirs,p', [(5, 7, 11, 32, 3, False, 0.0), (9, 6, 88, 300, 2, True, 0.0),
                                                    (10, 34, 8, 64, 4, True, 0.3), (3, 5, 20, 32, 2, False, 0.3),
-                                                   (37, 34, 88, 300, 3, True, 0.3), (128, 34, 108, 300, 2, False, 0.3)])
+                                                   (37, 34, 88, 300, 3, True, 0.3), (128, 34, 108, 300, 2, False, 0.3),
+                                                   (17, 1, 88, 300, 2, False, 0.3), (33, 2, 20, 300, 1, True, 0.0),
+                                                   (16, 3, 20, 300, 1, False, 0.0), (1, 34, 88, 300, 2, True, 0.3)])
 def test_gru_forward_backward(S, B, T, I, H, L, sum_dirs, p):
     ops, noise = S['ops'], S['noise']
     sd = _gru_sd(I, H, L, B * 100 + H)
