@@ -79,6 +79,19 @@ int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw,
                                float* dbias /*nullable: dbias[co] (+)= sum_m gy[m, co], folded into the same launch*/,
                                const s2ag_conv_geom* g /*host*/, int accumulate, void* stream);
 
+/* Up to S2AG_MAX_WGRAD_JOBS ACCUMULATING weight (+ bias) gradients in one launch (a GRU layer's dW_ih and both directions'
+ * dW_hh: each alone fills less than half of the chip's block slots).  Every job as s2ag_conv1d_nlc_bwd_weight with
+ * accumulate = 1; S2AG_E_UNSUPPORTED (nothing launched) if a job is outside the straight-line kernel. */
+#define S2AG_MAX_WGRAD_JOBS 4
+typedef struct s2ag_wgrad_job {
+    const float* gy;
+    const float* x;
+    float* dw;
+    float* dbias; /* nullable */
+    s2ag_conv_geom geom;
+} s2ag_wgrad_job;
+int s2ag_conv1d_nlc_bwd_weight_multi(const s2ag_wgrad_job* jobs /*host*/, int njobs, void* stream);
+
 /* Both backward GEMMs of one stride-1 layer in ONE launch (they share gy): dx = (as s2ag_conv1d_nlc_bwd_data, not
  * accumulating), dw / dbias += (as s2ag_conv1d_nlc_bwd_weight with accumulate = 1).  Returns S2AG_E_UNSUPPORTED (nothing
  * launched) for geometries outside the straight-line kernels (strided, reference-layout multi-tap weights, clips shorter

@@ -32,7 +32,12 @@ class WnJob(C.Structure):
                 ('dv', C.c_void_p), ('dg', C.c_void_p), ('rows', C.c_int), ('cols', C.c_int), ('ksize', C.c_int)]
 
 
+class WgradJob(C.Structure):     # s2ag_wgrad_job
+    _fields_ = [('gy', C.c_void_p), ('x', C.c_void_p), ('dw', C.c_void_p), ('dbias', C.c_void_p), ('geom', ConvGeom)]
+
+
 MAX_JOBS = 8
+MAX_WGRAD_JOBS = 4
 
 SIGNATURES = {
     's2ag_abi_version': [],
@@ -40,6 +45,7 @@ SIGNATURES = {
     's2ag_conv1d_nlc_bwd_data': [vp, vp, vp, PG, ci, vp],
     's2ag_conv1d_nlc_bwd_weight': [vp, vp, vp, vp, PG, ci, vp],
     's2ag_conv1d_nlc_bwd_pair': [vp, vp, vp, vp, vp, vp, PG, vp],
+    's2ag_conv1d_nlc_bwd_weight_multi': [vp, ci, vp],
     's2ag_colsum': [vp, ci, ci, ci, vp, vp, ci, vp],
     's2ag_colstats_f64': [vp, ci, ci, ci, vp, vp, vp],
     's2ag_bn_coeffs': [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp],

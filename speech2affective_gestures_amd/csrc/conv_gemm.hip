@@ -928,6 +928,14 @@ static bool use_gemm_lin() {
 int s2ag_bwd_pair(const float* gy, const float* w, const float* x, float* dx, float* dw, float* db, int nclips, int L,
                   int Cin, int Cout, int ks, int pad, int dil, int ldx, int ldg, int wtm, int chunk, int nsplit,
                   hipStream_t stream);
+struct s2ag_wg_job_i {
+    const float* gy;
+    const float* x;
+    float* dw;
+    float* db;
+    int nclips, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg, wtm, chunk, nsplit;
+};
+int s2ag_wgrad_multi(const s2ag_wg_job_i* jb, int n, hipStream_t stream);
 // conv_c1.hip
 int s2ag_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Lin, int Lout, int Cin,
                      int Cout, int ks, int stride, int pad, int dil, int ldx, int ldy, double* stats, int stats_cap_rows,
@@ -1106,6 +1114,30 @@ extern "C" int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float
         hipLaunchKernelGGL(conv_wgrad2_k, grid, dim3(512), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(conv_wgrad_k, grid, dim3(256), 0, (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_conv1d_nlc_bwd_weight_multi(const s2ag_wgrad_job* jobs, int njobs, void* stream) {
+    if (!jobs || njobs < 1 || njobs > S2AG_MAX_WGRAD_JOBS) return S2AG_E_BADARG;
+    if (!use_gemm_lin()) return S2AG_E_UNSUPPORTED;
+    s2ag_wg_job_i jb[S2AG_MAX_WGRAD_JOBS];
+    for (int i = 0; i < njobs; ++i) {
+        const s2ag_conv_geom* g = &jobs[i].geom;
+        if (bad_geom(g) || !jobs[i].gy || !jobs[i].x || !jobs[i].dw) return S2AG_E_BADARG;
+        if (g->Cin == 1) return S2AG_E_UNSUPPORTED;
+        const int Mtot = g->N * g->Lout;
+        const int tiles = cdiv(g->Cout, BM) * cdiv(g->ksize * g->Cin, BN);
+        int nsplit = cdiv(384, tiles);
+        const int max_split = cdiv(Mtot, 4 * BK);
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit < 1) nsplit = 1;
+        const int chunk = cdiv(cdiv(Mtot, nsplit), BK2) * BK2;
+        nsplit = cdiv(Mtot, chunk);
+        jb[i] = s2ag_wg_job_i{jobs[i].gy, jobs[i].x, jobs[i].dw, jobs[i].dbias, g->N, g->Lin, g->Lout, g->Cin, g->Cout,
+                              g->ksize, g->stride, g->pad, g->dil, g->ldx, g->ldy, g->w_tap_major, chunk, nsplit};
+    }
+    if (!s2ag_wgrad_multi(jb, njobs, (hipStream_t)stream)) return S2AG_E_UNSUPPORTED;
     S2AG_LAUNCH_CHECK();
     return 0;
 }

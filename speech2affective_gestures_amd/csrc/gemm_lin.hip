@@ -567,6 +567,29 @@ __global__ __launch_bounds__(512) void bwd_pair_k(LinP p1, WgP p2, int n2, int g
     }
 }
 
+// Several weight gradients in ONE launch (a GRU layer's dW_ih and the two directions' dW_hh: 450-580 blocks each, every
+// one of them alone leaves most of the 1 024 block slots of the chip empty)
+constexpr int WG_MAX_JOBS = 4;
+struct WgJobs {
+    WgP p[WG_MAX_JOBS];
+    int end[WG_MAX_JOBS];            // exclusive prefix sums of the jobs' block counts
+    int gx[WG_MAX_JOBS], gy[WG_MAX_JOBS];
+    int shift[WG_MAX_JOBS];
+    int n;
+};
+__global__ __launch_bounds__(512) void wgrad_multi_k(WgJobs jobs) {
+    __shared__ __attribute__((aligned(16))) float smem[WG_SMEM_FLOATS];
+    const int b = blockIdx.x;
+    int j = 0;
+    while (j + 1 < jobs.n && b >= jobs.end[j]) ++j;
+    const int b0 = b - (j ? jobs.end[j - 1] : 0);
+    const int x = b0 % jobs.gx[j], r = b0 / jobs.gx[j];
+    if (jobs.shift[j])
+        wgrad_lin_body<true>(jobs.p[j], smem, x, r % jobs.gy[j], r / jobs.gy[j]);
+    else
+        wgrad_lin_body<false>(jobs.p[j], smem, x, r % jobs.gy[j], r / jobs.gy[j]);
+}
+
 template <int BM_, bool CONV>
 void launch_pair(const LinP& p1, const WgP& p2, bool shift, dim3 g1, dim3 g2, hipStream_t stream) {
     const int n2 = g2.x * g2.y * g2.z, n1 = g1.x * g1.y;
@@ -628,5 +651,37 @@ int s2ag_bwd_pair(const float* gy, const float* w, const float* x, float* dx, fl
         if (bm64) launch_pair<64, true>(p1, p2, true, g1, g2, stream);
         else launch_pair<32, true>(p1, p2, true, g1, g2, stream);
     }
+    return 1;
+}
+
+// Up to 4 accumulating weight (+ bias) gradients in one launch; every job must be covered by the straight-line kernel
+// (see s2ag_wgrad_lin).  Returns 1 if launched.
+struct s2ag_wg_job_i {
+    const float* gy;
+    const float* x;
+    float* dw;
+    float* db;
+    int nclips, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg, wtm, chunk, nsplit;
+};
+int s2ag_wgrad_multi(const s2ag_wg_job_i* jb, int n, hipStream_t stream) {
+    if (n < 1 || n > WG_MAX_JOBS) return 0;
+    WgJobs J{};
+    J.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const s2ag_wg_job_i& q = jb[i];
+        const bool linear = (q.Lin == 1 && q.Lout == 1 && q.pad == 0 && q.ks == 1 && q.stride == 1);
+        if (!linear && q.Lout < LBK) return 0;
+        WgP& p = J.p[i];
+        p.gy = q.gy; p.x = q.x; p.dw = q.dw; p.db = q.db; p.M = q.nclips * q.Lout; p.L = q.Lout; p.Ls = q.Lin;
+        p.stride = q.stride; p.Cin = q.Cin; p.Cout = q.Cout; p.ks = q.ks; p.pad = q.pad; p.dil = q.dil; p.ldx = q.ldx;
+        p.ldg = q.ldg; p.wtm = q.wtm; p.chunk = q.chunk;
+        J.gx[i] = cdiv(q.Cout, 64);
+        J.gy[i] = cdiv(q.ks * q.Cin, 64);
+        J.shift[i] = linear ? 0 : 1;
+        total += J.gx[i] * J.gy[i] * q.nsplit;
+        J.end[i] = total;
+    }
+    hipLaunchKernelGGL(wgrad_multi_k, dim3(total), dim3(512), 0, stream, J);
     return 1;
 }

@@ -126,6 +126,28 @@ def conv_bwd_weight_raw(gy: Tensor, x: Tensor, dw: Tensor, N, Lin, Lout, Cin, Co
                                               _stream()), 'conv_bwd_weight')
 
 
+def conv_bwd_weight_multi_raw(jobs) -> bool:
+    """jobs: list of (gy, x, dw, dbias, (N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, wtm)) -- accumulating weight
+    (+ bias) gradients, all in ONE launch.  False (nothing launched) if a job is outside the straight-line kernel."""
+    arr = (L.WgradJob * len(jobs))()
+    keep = []
+    for k, (gy, x, dw, dbias, (N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, wtm)) in enumerate(jobs):
+        gy, gr, gc, ldg = as_rows(gy)
+        x, xr, xc, ldx = as_rows(x)
+        assert gr == N * Lout and gc == Cout and xr == N * Lin and xc == Cin, (gr, gc, xr, xc)
+        assert dw.is_contiguous() and dw.numel() == Cout * Cin * ks
+        assert dbias is None or (dbias.is_contiguous() and dbias.numel() == Cout)
+        keep += [gy, x]
+        arr[k] = L.WgradJob(gy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbias.data_ptr() if dbias is not None else None,
+                            _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldg, wtm))
+    rc = _lib().s2ag_conv1d_nlc_bwd_weight_multi(arr, len(jobs), _stream())
+    if rc == L.E_UNSUPPORTED:
+        return False
+    L.check(rc, 'conv_bwd_weight_multi')
+    return True
+
+
+FUSE_WGRADS = __import__('os').environ.get('S2AG_FUSE_WGRADS', '1') != '0'
 FUSE_BWD_PAIR = __import__('os').environ.get('S2AG_FUSE_BWD', '1') != '0'
 
 
@@ -1009,6 +1031,11 @@ class _GRU(torch.autograd.Function):
             if all(sl is not None for sl in slots) and pair_ih is not None and pair_bi is not None:
                 # arena layout: the two directions are adjacent, so dW_ih / db_ih of both are one launch each
                 def leaves(dgi=dgi, dgh=dgh, y=y, inp=inp, In=In, pair_ih=pair_ih, pair_bi=pair_bi, slots=slots):
+                    if FUSE_WGRADS and conv_bwd_weight_multi_raw(
+                            [(dgi, inp, pair_ih, pair_bi.view(-1), (B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1, 0))] +
+                            [(dgh[d], y[:, d * H:(d + 1) * H], slots[4 * d + 1], slots[4 * d + 3],
+                              (B, T, T, H, H3, 1, 1, 1 if d == 0 else -1, 1, 0)) for d in range(2)]):
+                        return                     # dW_ih (both directions) and the two dW_hh in one launch
                     conv_bwd_weight_raw(dgi, inp, pair_ih, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1, True,
                                         dbias=pair_bi.view(-1))
                     for d in range(2):
