@@ -389,6 +389,99 @@ def pose_generator_trimodal(sd: SD, cfg: ModelCfg, pre_seq, in_text, in_audio, v
     return out, z, mu, log_var
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# sliding-window synthesis (Processor.render_clip, processor_v2.py:1173-1330, without rendering / fade-out)
+# ---------------------------------------------------------------------------------------------------------------------
+def words_in_time_range(word_list, start_time: float, end_time: float):
+    """DataPreprocessor.get_words_in_time_range (utils/data_preprocessor.py): words overlapping [start, end)."""
+    words = []
+    for word in word_list:
+        _, word_s, word_e = word[0], word[1], word[2]
+        if word_s >= end_time:
+            break
+        if word_e <= start_time:
+            continue
+        words.append(word)
+    return words
+
+
+def synthesis_windows(n_samples: int, sample_rate: int, n_poses: int, n_pre: int, fps: float, unit_time=None):
+    """The window plan of render_clip (:1199-1216, :1233-1246): [(start_time, end_time, audio_start)], audio window length."""
+    clip_length = n_samples / sample_rate
+    if unit_time is None:
+        unit_time = n_poses / fps
+    stride_time = (n_poses - n_pre) / fps
+    num = 1 if clip_length < unit_time else math.ceil((clip_length - unit_time) / stride_time) + 1
+    audio_sample_length = int(unit_time * sample_rate)
+    plan = []
+    for k in range(num):
+        t0 = min(k * stride_time, clip_length)
+        t1 = min(t0 + unit_time, clip_length)
+        if t0 >= t1:
+            continue
+        plan.append((t0, t1, math.floor(t0 / clip_length * n_samples)))
+    return plan, audio_sample_length
+
+
+def window_text(clip_words, t0: float, t1: float, n_frames: int, word_index) -> Tensor:
+    """:1255-1271: every word of the window lands on the frame its start time falls into (PAD = 0 elsewhere)."""
+    ext = np.zeros(n_frames)
+    frame_duration = (t1 - t0) / n_frames
+    for word in words_in_time_range(clip_words, t0, t1):
+        ext[max(0, int(np.floor((word[1] - t0) / frame_duration)))] = word_index(word[0])
+    return torch.LongTensor(ext).unsqueeze(0)
+
+
+def crossfade_append(out_list: list, out_seq: np.ndarray, n_pre: int) -> None:
+    """:1296-1322: the previous window gives up its last n_pre frames, which are blended into the first n_pre of the new
+    one with weights (n - j) / (n + 1) and (j + 1) / (n + 1)."""
+    if len(out_list) > 0:
+        last_poses = out_list[-1][-n_pre:]
+        out_list[-1] = out_list[-1][:-n_pre]
+        n = len(last_poses)
+        for j in range(n):
+            out_seq[j] = last_poses[j] * (n - j) / (n + 1) + out_seq[j] * (j + 1) / (n + 1)
+    out_list.append(out_seq)
+
+
+def synthesize_clip(sdG: SD, sdT: SD, cfg: ModelCfg, seed_seq, clip_audio: np.ndarray, sample_rate: int, clip_words,
+                    mfcc_windows, vid: int, eps, word_index, fps: float = 15.0, pose_dim: int = 27):
+    """render_clip's synthesis loop: per window the tri-modal baseline and the s2ag generator run at batch 1, the last
+    n_pre output frames seed the next window, consecutive windows are cross-faded.  ``eps``: z noise per forward in
+    call order (tri-modal, s2ag per window); ``mfcc_windows[k]``: the MFCC image of window k (librosa is outside the
+    path).  Returns (out_dir_vec_trimodal, out_dir_vec), each (W * (n_poses - n_pre) + n_pre, pose_dim)."""
+    n_frames, n_pre = cfg.n_poses, cfg.n_pre_poses
+    plan, alen = synthesis_windows(len(clip_audio), sample_rate, n_frames, n_pre, fps)
+    pre_t = torch.zeros(1, n_frames, pose_dim + 1)
+    pre_g = torch.zeros(1, n_frames, pose_dim + 1)
+    seed = torch.as_tensor(np.asarray(seed_seq)[:n_pre], dtype=torch.float32)
+    for pre in (pre_t, pre_g):
+        pre[0, :n_pre, :-1] = seed
+        pre[0, :n_pre, -1] = 1
+    vid_t = torch.LongTensor([vid])
+    out_t = out_g = None
+    list_t, list_g = [], []
+    for k, (t0, t1, a0) in enumerate(plan):
+        win = np.asarray(clip_audio[a0:a0 + alen], dtype=np.float32)
+        if len(win) < alen:
+            win = np.pad(win, (0, alen - len(win)), 'constant')
+        in_audio = torch.from_numpy(win).unsqueeze(0)
+        in_mfcc = torch.as_tensor(np.asarray(mfcc_windows[k]), dtype=torch.float32).unsqueeze(0)
+        in_text = window_text(clip_words, t0, t1, n_frames, word_index)
+        if k > 0:
+            pre_t[0, :n_pre, :-1] = out_t[0, -n_pre:]
+            pre_t[0, :n_pre, -1] = 1
+            pre_g[0, :n_pre, :-1] = out_g[0, -n_pre:]
+            pre_g[0, :n_pre, -1] = 1
+        out_t = pose_generator_trimodal(sdT, cfg, pre_t, in_text, in_audio, vid_t, False,
+                                        Noise({'eps': torch.as_tensor(eps[2 * k])}))[0]
+        out_g = pose_generator(sdG, cfg, pre_g, in_text, in_mfcc, vid_t, False,
+                               Noise({'eps': torch.as_tensor(eps[2 * k + 1])}))[0]
+        crossfade_append(list_t, out_t[0].detach().numpy().copy(), n_pre)
+        crossfade_append(list_g, out_g[0].detach().numpy().copy(), n_pre)
+    return np.vstack(list_t), np.vstack(list_g)
+
+
 def aff_discriminator(sd: SD, poses: Tensor, training: bool, noise: Noise, fast: bool = False) -> Tensor:
     """AffDiscriminator.forward (:568-585): GRU dropout is hard-wired to 0.3 (:558)."""
     feat = aff_encoder(sd, 'aff_encoder.', poses, training)

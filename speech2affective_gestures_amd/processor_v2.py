@@ -12,6 +12,7 @@ What is MI355X-first here (DESIGN.md has the full story):
   * losses stay on the device; one 32-byte read-back per step replaces the reference's 5-7 ``.item()`` syncs.
 Rendering, FGD evaluation and the LMDB/npz data pipeline of the reference are outside this path.
 """
+import math
 import os
 import time
 from os.path import join as jn
@@ -266,6 +267,136 @@ class Processor(object):
                 others = np.setdiff1d(np.fromiter(spk.word2index.values(), dtype=np.int64), samples['vid_indices'][keys])
                 vids = torch.from_numpy(np.random.choice(others, size=B)).long().to(self.device, non_blocking=True)
             yield text, vec, audio, mfcc, vids
+
+    # ------------------------------------------------------------------------------------------------
+    def synthesize_clip(self, seed_seq, clip_audio, sample_rate, clip_words, mfcc_windows=None, mfcc_fn=None,
+                        speaker_vid_idx=0, unit_time=None):
+        """The synthesis loop of ``render_clip`` (processor_v2.py:1173-1330; rendering, pkl export and the optional
+        fade-out are outside the path): the clip is cut into windows of ``n_poses`` frames with a stride of
+        ``n_poses - n_pre_poses``; per window the tri-modal baseline and the s2ag generator run at batch 1, the last
+        ``n_pre_poses`` output frames seed the next window, and consecutive windows are cross-faded over those frames.
+
+        ``clip_words``: [[word, start_s, end_s], ...] relative to the clip start; ``mfcc_windows[k]`` (or
+        ``mfcc_fn(audio_window)``): the (num_mfcc, mfcc_length) image of window k -- MFCC extraction (librosa) is data
+        preparation.  Everything between the one upload of the window inputs and the one download of the result stays
+        on the device: seed hand-off and cross-fade included.  Returns ``(out_dir_vec_trimodal, out_dir_vec)`` as
+        float32 numpy arrays of shape (W * (n_poses - n_pre_poses) + n_pre_poses, pose_dim)."""
+        cfg = self.s2ag_config_args
+        T, n_pre, dev = cfg.n_poses, cfg.n_pre_poses, self.device
+        fps = cfg.motion_resampling_framerate
+        clip_audio = np.asarray(clip_audio, dtype=np.float32)
+        clip_length = len(clip_audio) / sample_rate
+        if unit_time is None:
+            unit_time = T / fps
+        stride_time = (T - n_pre) / fps
+        num = 1 if clip_length < unit_time else math.ceil((clip_length - unit_time) / stride_time) + 1
+        alen = int(unit_time * sample_rate)
+        texts, audios, mfccs = [], [], []
+        for k in range(num):
+            t0 = min(k * stride_time, clip_length)
+            t1 = min(t0 + unit_time, clip_length)
+            if t0 >= t1:
+                continue
+            a0 = math.floor(t0 / clip_length * len(clip_audio))
+            win = clip_audio[a0:a0 + alen]
+            if len(win) < alen:
+                win = np.pad(win, (0, alen - len(win)), 'constant')
+            ext = np.zeros(T, dtype=np.int64)              # PAD = 0 (utils/vocab.py:9)
+            frame_duration = (t1 - t0) / T
+            for word, w_s, w_e in clip_words:              # DataPreprocessor.get_words_in_time_range
+                if w_s >= t1:
+                    break
+                if w_e <= t0:
+                    continue
+                ext[max(0, int(np.floor((w_s - t0) / frame_duration)))] = self.lang_model.get_word_index(word)
+            texts.append(ext)
+            audios.append(win)
+            mfccs.append(np.asarray(mfcc_windows[len(mfccs)] if mfcc_windows is not None else mfcc_fn(win),
+                                    dtype=np.float32))
+        W = len(texts)
+        text_d = torch.from_numpy(np.stack(texts)).to(dev)
+        audio_d = torch.from_numpy(np.stack(audios)).to(dev)
+        mfcc_d = torch.from_numpy(np.stack(mfccs)).to(dev)
+        if cfg.z_type == 'speaker' and speaker_vid_idx is None:
+            speaker_vid_idx = np.random.randint(0, self.s2ag_generator.z_obj.n_words)
+        was_training = (self.trimodal_generator.training, self.s2ag_generator.training)
+        self.trimodal_generator.eval()
+        self.s2ag_generator.eval()
+        # One window = ~400 small launches at batch 1: the step runs on static buffers (inputs of the window, seed
+        # poses, outputs) so that from the second window on it is ONE hipGraph replay.  The graph bakes in derived
+        # weight tensors, so it is re-captured whenever a weight tensor changed (optimizer step, load_state_dict).
+        params = list(self.trimodal_generator.parameters()) + list(self.s2ag_generator.parameters())
+        key = (T, alen, tuple(mfcc_d.shape[1:]), cfg.z_type == 'speaker', sum(p._version for p in params),
+               getattr(getattr(self, 'gen_arena', None), 'epoch', -1))
+        st = self.__dict__.get('_synth')
+        if st is None or st['key'] != key:
+            st = dict(key=key, graph=None,
+                      pre_t=torch.zeros(1, T, self.pose_dim + 1, device=dev),
+                      pre_g=torch.zeros(1, T, self.pose_dim + 1, device=dev),
+                      text=torch.zeros(1, T, dtype=torch.int64, device=dev),
+                      audio=torch.zeros(1, alen, device=dev), mfcc=torch.zeros((1,) + tuple(mfcc_d.shape[1:]), device=dev),
+                      vid=torch.zeros(1, dtype=torch.int64, device=dev) if cfg.z_type == 'speaker' else None,
+                      out_t=torch.zeros(T, self.pose_dim, device=dev), out_g=torch.zeros(T, self.pose_dim, device=dev))
+            self._synth = st
+        pre_t, pre_g = st['pre_t'], st['pre_g']
+        pre_t.zero_()
+        pre_t[0, :n_pre, :-1] = torch.as_tensor(np.asarray(seed_seq)[:n_pre], dtype=torch.float32, device=dev)
+        pre_t[0, :n_pre, -1] = 1                            # indicating bit for seed poses
+        pre_g.copy_(pre_t)
+        if st['vid'] is not None:
+            st['vid'].fill_(int(speaker_vid_idx))
+
+        if 'side' not in st:
+            st['side'] = torch.cuda.Stream(device=dev)
+
+        def window_step():
+            # the two generators of a window are independent: the baseline runs on a forked stream; their noise
+            # snapshots are drawn first, in the reference's call order (tri-modal, then s2ag), on this stream
+            nz_t, nz_g = noise.begin_pass(dev), noise.begin_pass(dev)
+            cur, side = torch.cuda.current_stream(), st['side']
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), noise.use_pass(nz_t), ops.sequential_branches():
+                out_t = self.trimodal_generator(pre_t, st['text'], st['audio'], st['vid'])[0]
+                st['out_t'].copy_(out_t[0])
+                pre_t[0, :n_pre, :-1] = out_t[0, -n_pre:]   # the seed poses of the next window
+            with noise.use_pass(nz_g):
+                out_g = self.s2ag_generator(pre_g, st['text'], st['mfcc'], st['vid'])[0]
+            st['out_g'].copy_(out_g[0])
+            pre_g[0, :n_pre, :-1] = out_g[0, -n_pre:]
+            cur.wait_stream(side)
+
+        use_graph = getattr(self, 'use_hip_graph', True) and os.environ.get('S2AG_SYNTH_GRAPH', '1') != '0'
+        outs_t = torch.empty(W, T, self.pose_dim, device=dev)
+        outs_g = torch.empty(W, T, self.pose_dim, device=dev)
+        with torch.no_grad():
+            for k in range(W):
+                st['text'].copy_(text_d[k:k + 1])
+                st['audio'].copy_(audio_d[k:k + 1])
+                st['mfcc'].copy_(mfcc_d[k:k + 1])
+                if k == 0 or not use_graph:
+                    window_step()                           # eager: also warms up everything the capture needs
+                else:
+                    if st['graph'] is None:
+                        torch.cuda.synchronize()
+                        gr = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gr):          # nothing executes during capture
+                            window_step()
+                        st['graph'] = gr
+                    st['graph'].replay()
+                outs_t[k].copy_(st['out_t'])
+                outs_g[k].copy_(st['out_g'])
+            res = []
+            # smoothing motion transition (:1296-1322): window k-1 gives up its last n_pre frames, blended into the
+            # first n_pre of window k with weights (n - j) / (n + 1) and (j + 1) / (n + 1)
+            j = torch.arange(n_pre, device=dev, dtype=torch.float32).unsqueeze(1)
+            w_prev, w_next = (n_pre - j) / (n_pre + 1), (j + 1) / (n_pre + 1)
+            for o in (outs_t, outs_g):                      # (W, T, pose_dim)
+                if W > 1:
+                    o[1:, :n_pre] = o[:-1, -n_pre:] * w_prev + o[1:, :n_pre] * w_next
+                res.append(torch.cat([o[:-1, :T - n_pre].reshape(-1, o.shape[-1]), o[-1]]).cpu().numpy())
+        self.trimodal_generator.train(was_training[0])
+        self.s2ag_generator.train(was_training[1])
+        return res[0], res[1]
 
     # ------------------------------------------------------------------------------------------------
     def _use_gan(self):

@@ -206,3 +206,52 @@ def test_long_clip_136_frames_matches_oracle():
         assert ot.shape == (B, T, 27)
         assert rel(ot, O.pose_generator_trimodal(sdT, oc, pre, inp['in_text'], inp['in_audio'], inp['vid'], False,
                                                  O.Noise({'eps': eps}))[0]) < TOL
+
+
+@pytest.mark.gpu
+def test_sliding_window_synthesis_matches_oracle(golden_dir):
+    """Processor.synthesize_clip (render_clip's loop, processor_v2.py:1173-1330: window plan, word -> frame mapping,
+    seed hand-off and cross-fade on the device) against the oracle loop, which tests/test_oracle_golden.py pins to a
+    run of the reference's own render_clip.  The oracle is fed the eps the kernels draw (one noise pass per forward)."""
+    import sys
+    import types
+    from speech2affective_gestures_amd import noise, ops
+    from speech2affective_gestures_amd import processor_v2 as P
+    from speech2affective_gestures_amd.net import multimodal_context_net_v2 as m2
+    from s2ag_testing import Vocab, make_cfg
+    sys.path.insert(0, golden_dir)
+    import synth_recipe as R
+    g = dict(np.load(os.path.join(golden_dir, 'synth_small.npz')))
+    audio, words, mfcc, poses, _ = R.clip_fixture()
+    cfg = make_cfg(R.HIDDEN, 0.0)
+    cfg.motion_resampling_framerate, cfg.z_type = R.FPS, 'speaker'
+    oc = O.ModelCfg(hidden_size=R.HIDDEN, hidden_size_s2eg=R.HIDDEN, dropout_prob=0.0)
+    sdG = O.recipe_state_dict(O.generator_shapes(oc, R.N_WORDS, R.N_SPK), R.SEED0 + 1)
+    sdT = O.recipe_state_dict(O.trimodal_shapes(oc, R.N_WORDS, R.N_SPK), R.SEED0 + 4)
+    spk = Vocab(R.N_SPK)
+    G = m2.PoseGenerator(cfg, 27, R.N_WORDS, 300, None, 71, 37, 34, z_obj=spk)
+    T3 = m2.PoseGeneratorTriModal(cfg, 27, R.N_WORDS, 300, None, z_obj=spk)
+    for m, sd in ((G, sdG), (T3, sdT)):
+        m.load_state_dict(sd, strict=True)
+        m.cuda().eval()
+    G.z_site, T3.z_site = 4242, 4343
+    index = {w: 4 + i for i, w in enumerate(R.VOCAB)}
+    pr = object.__new__(P.Processor)
+    pr.s2ag_config_args, pr.device, pr.pose_dim = cfg, torch.device('cuda', 0), 27
+    pr.lang_model = types.SimpleNamespace(get_word_index=lambda w: index.get(w, 3))
+    pr.s2ag_generator, pr.trimodal_generator = G, T3
+    noise.manual_seed(21)
+    out_t, out_g = pr.synthesize_clip(g['seed_seq'], audio, R.SR, words, mfcc_windows=mfcc, speaker_vid_idx=R.SPEAKER)
+    assert out_t.shape == out_g.shape == (94, 27) and out_t.dtype == np.float32
+    eps = [ops.normal_noise(torch.tensor([21, k], dtype=torch.int64, device='cuda'), T3.z_site if k % 2 == 0 else G.z_site,
+                            (1, 16)).cpu() for k in range(6)]
+    with torch.no_grad():
+        ref_t, ref_g = O.synthesize_clip(sdG, sdT, oc, g['seed_seq'], audio, R.SR, words, mfcc, R.SPEAKER, eps,
+                                         lambda w: index.get(w, 3), fps=R.FPS)
+    assert rel(torch.from_numpy(out_t), torch.from_numpy(ref_t)) < TOL
+    assert rel(torch.from_numpy(out_g), torch.from_numpy(ref_g)) < TOL
+    # a clip shorter than one window is a single zero-padded window (processor_v2.py:1208-1209)
+    noise.manual_seed(21)
+    s_t, s_g = pr.synthesize_clip(g['seed_seq'], audio[:20000], R.SR, words[:2], mfcc_windows=mfcc[:1],
+                                  speaker_vid_idx=R.SPEAKER)
+    assert s_t.shape == s_g.shape == (34, 27)

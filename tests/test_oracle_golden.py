@@ -164,3 +164,25 @@ def test_checkpoint_name_protocol(golden_dir):
     g = _load(golden_dir, 'misc.npz')
     assert str(g['best'][0]) == 'epoch_000020_loss_0.2500_model.pth.tar'     # 2nd smallest, argpartition(…,2)[1]
     assert str(g['at20'][1]) == '20' and str(g['missing'][0]) == ''
+
+
+def test_synthesis_loop_matches_reference_render_clip(golden_dir):
+    """The oracle's sliding-window synthesis against a run of the reference's own ``Processor.render_clip`` (3 windows,
+    seed hand-off, cross-fade, zero-padded last window, word -> frame mapping): tests/golden/gen_golden_synth.py."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import synth_recipe as R
+    g = _load(golden_dir, 'synth_small.npz')
+    audio, words, mfcc, poses, eps = R.clip_fixture()
+    oc = O.ModelCfg(hidden_size=R.HIDDEN, hidden_size_s2eg=R.HIDDEN, dropout_prob=0.0)
+    sdG = O.recipe_state_dict(O.generator_shapes(oc, R.N_WORDS, R.N_SPK), R.SEED0 + 1)
+    sdT = O.recipe_state_dict(O.trimodal_shapes(oc, R.N_WORDS, R.N_SPK), R.SEED0 + 4)
+    index = {w: 4 + i for i, w in enumerate(R.VOCAB)}
+    with torch.no_grad():
+        out_t, out_g = O.synthesize_clip(sdG, sdT, oc, g['seed_seq'], audio, R.SR, words, mfcc, R.SPEAKER, eps,
+                                         lambda w: index.get(w, 3), fps=R.FPS)
+    assert out_t.shape == out_g.shape == (94, 27)
+    _close(g['out_trimodal'], out_t)
+    _close(g['out_s2ag'], out_g)
+    plan, alen = O.synthesis_windows(len(audio), R.SR, 34, 4, R.FPS)
+    assert alen == 36266 and [p[2] for p in plan] == [0, 32000, 64000]
