@@ -314,6 +314,9 @@ def main():
             line['gpu_over_cpu'] = value / line['cpu_baseline']['value']
         print(json.dumps(line), flush=True)
     dp.barrier()
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -26,7 +26,8 @@ class DataParallelContext:
         world = int(os.environ.get('WORLD_SIZE', '1'))
         rank = int(os.environ.get('RANK', '0'))
         local = int(os.environ.get('LOCAL_RANK', '0'))
-        if world > 1 and not dist.is_initialized():
+        force = os.environ.get('S2AG_FORCE_DIST', '0') == '1'     # world-size-1 process group: exercises the RCCL calls
+        if (world > 1 or force) and not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             if backend is None:
@@ -34,7 +35,15 @@ class DataParallelContext:
             if backend == 'nccl':
                 torch.cuda.set_device(local)
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-        return DataParallelContext(rank, world, local)
+        ctx = DataParallelContext(rank, world, local)
+        ctx.forced = force and world == 1
+        return ctx
+
+    forced: bool = False
+
+    @property
+    def active(self) -> bool:
+        return self.world_size > 1 or self.forced
 
     @property
     def grad_scale(self) -> float:
@@ -42,12 +51,12 @@ class DataParallelContext:
 
     def all_reduce_grads(self, arena) -> None:
         """SUM over ranks into ``arena.grad`` (scaled by 1/world inside the fused Adam)."""
-        if self.world_size > 1:
+        if self.active:
             dist.all_reduce(arena.grad, op=dist.ReduceOp.SUM)
 
     def broadcast_module(self, module, arena=None) -> None:
         """Rank 0's parameters (one flat broadcast when an arena exists) and buffers to everyone."""
-        if self.world_size == 1:
+        if not self.active:
             return
         if arena is not None:
             dist.broadcast(arena.data, src=0)
@@ -58,11 +67,11 @@ class DataParallelContext:
             dist.broadcast(b, src=0)
 
     def barrier(self) -> None:
-        if self.world_size > 1:
+        if self.active:
             dist.barrier()
 
     def max_over_ranks(self, value: float, device) -> float:
-        if self.world_size == 1:
+        if not self.active:
             return value
         t = torch.tensor([value], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
