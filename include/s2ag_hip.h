@@ -79,6 +79,16 @@ int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw,
                                float* dbias /*nullable: dbias[co] (+)= sum_m gy[m, co], folded into the same launch*/,
                                const s2ag_conv_geom* g /*host*/, int accumulate, void* stream);
 
+/* fp32 GEMM y = a w^T + bias on the bf16 matrix pipe from PRE-SPLIT operands (the GRU input projections -- W_ih x of
+ * nn.GRU, net/multimodal_context_net_v2.py:281,406 -- the one GEMM shape of the step bound by the f32 matrix pipe).
+ * s2ag_split_bf16x3: planes (3, rows, Kp) bf16, Kp = s2ag_split_k_padded(K): every value = piece0 + piece1 + piece2 exactly
+ * to 2^-25 (each piece the bf16 rounding of what the previous ones left), zero padded along K.  s2ag_gemm_split_fwd
+ * accumulates the six leading piece products in fp32: as accurate as the f32-MFMA GEMM, 2.5x less matrix-pipe time. */
+int s2ag_split_k_padded(int K);
+int s2ag_split_bf16x3(const float* x, int rows, int K, int ldx, void* planes, void* stream);
+int s2ag_gemm_split_fwd(const void* a_planes /*(3, M, Kp)*/, const void* w_planes /*(3, N, Kp)*/,
+                        const float* bias /*nullable*/, float* y, int M, int N, int K, int ldy, void* stream);
+
 /* Up to S2AG_MAX_WGRAD_JOBS ACCUMULATING weight (+ bias) gradients in one launch (a GRU layer's dW_ih and both directions'
  * dW_hh: each alone fills less than half of the chip's block slots).  Every job as s2ag_conv1d_nlc_bwd_weight with
  * accumulate = 1; S2AG_E_UNSUPPORTED (nothing launched) if a job is outside the straight-line kernel. */

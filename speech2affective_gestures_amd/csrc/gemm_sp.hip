@@ -1,0 +1,220 @@
+// fp32 GEMM on the bf16 matrix pipe from PRE-SPLIT operands (the GRU input projections: M = clips*frames = 4 352,
+// N = 2*3H = 1 800, K = 2H = 600 -- the one GEMM shape of the step that runs at 57 % of the f32 MFMA peak, i.e. that is
+// bound by the f32 matrix pipe itself).
+//
+//   y[m, n] = sum_k a[m, k] * w[n, k] + bias[n]
+//
+// Every fp32 operand value is split EXACTLY into three bf16 pieces v = p0 + p1 + p2 (+ <= 2^-25 |v|; each piece is the
+// bf16 rounding of what the previous ones left) and the six leading piece products a0w0 + a0w1 + a1w0 + a1w1 + a0w2 +
+// a2w0 are accumulated in fp32 inside v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-24 |a w|: the result is as accurate
+// as the f32 MFMA's, see gru_coop.hip and tools/diag_gru_split.py).  Six bf16 MFMAs (8 192 MACs each) do the work of
+// eight f32 MFMAs (1 024 MACs in 32 cycles each).  Measured here (tools/bench_gemm_split.py): a bf16 16x16x32 MFMA
+// issues every ~35-40 cycles per SIMD in this kernel whatever the accumulator order, register form (AGPR / VGPR) or
+// waves per SIMD -- not the ~17 of a lone dependent chain -- so the gain on the matrix pipe is 8 x 32 / (6 x ~38) = 1.1-1.3x
+// plus what the larger tile saves: 72-76 us against 113 us for the f32-MFMA kernel at M, N, K = 4 352, 1 800, 600.
+//
+// Splitting on the fly would cost as many vector-ALU cycles per K tile as it saves on the matrix pipe, so both operands
+// arrive split: s2ag_split_bf16x3 writes the three planes [piece][rows][Kp] (Kp = K rounded up to 32, zero padded) --
+// once per optimizer step for a weight, once per layer and pass for the activations (one streaming pass: 10 MB in, 16 MB
+// out at M = 4 352, K = 600).
+//
+// Kernel: 128 x 128 output tile (the operand planes are 6 bytes per element: a 64 x 64 tile moved 880 MB through L2 at
+// M, N, K = 4 352, 1 800, 600 and ran no faster than the f32 kernel), 4 waves of 64 x 64 (4 x 4 MFMA tiles, 64
+// accumulator registers), K tile = 32 = one MFMA K; per K tile a thread moves two 16-byte chunks (8 bf16 along k) per
+// operand plane through registers into LDS (row pitch 80 B: the 16-byte operand chunks of 16 consecutive rows tile the
+// 64 banks), a wave issues 96 MFMAs (6 products x 16 tiles, consecutive MFMAs on different accumulators) against
+// 24 ds_read_b128.
+#include "s2ag_common.h"
+
+namespace {
+using namespace s2ag;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int SPK = 32;                 // K tile
+constexpr int SPT = 128;                // tile rows / columns
+constexpr int SP_PITCH = 40;            // LDS row pitch in bf16 elements (80 B)
+constexpr int SP_PLANE = SPT * SP_PITCH;
+constexpr int WT = 4;                   // 16 x 16 MFMA tiles per wave along either axis (64 x 64 per wave)
+
+__device__ __forceinline__ unsigned bf16_rn(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+// planes[p][r][Kp]: piece p of x[r][k] (k < K), zero for K <= k < Kp
+__global__ __launch_bounds__(256) void split_bf16x3_k(const float* __restrict__ x, int rows, int K, int ldx, int Kp,
+                                                      unsigned short* __restrict__ planes) {
+    const long long total = (long long)rows * (Kp / 2);               // two consecutive k per thread: one 4-byte store
+    const size_t plane = (size_t)rows * Kp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / (Kp / 2)), k = (int)(i - (long long)r * (Kp / 2)) * 2;
+        unsigned pc[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float v = (k + e < K) ? x[(long long)r * ldx + k + e] : 0.f;
+            const unsigned p0 = bf16_rn(v);
+            const float r1 = v - __uint_as_float(p0 << 16);
+            const unsigned p1 = bf16_rn(r1);
+            const float r2 = r1 - __uint_as_float(p1 << 16);
+            const unsigned p2 = bf16_rn(r2);
+            pc[0] |= p0 << (16 * e);
+            pc[1] |= p1 << (16 * e);
+            pc[2] |= p2 << (16 * e);
+        }
+        const size_t o = (size_t)r * Kp + k;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(planes + p * plane + o) = pc[p];
+    }
+}
+
+struct SpP {
+    const unsigned short* a;            // [3][M][Kp]
+    const unsigned short* w;            // [3][N][Kp]
+    const float* bias;                  // nullable
+    float* y;
+    int M, N, Kp, ldy;
+};
+
+__global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
+    // single-buffered LDS (61 KB: two blocks per CU), the next K tile travels through registers meanwhile
+    __shared__ __attribute__((aligned(16))) unsigned short As[3][SP_PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][SP_PLANE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * SPT, n0 = blockIdx.y * SPT;
+    const size_t aplane = (size_t)p.M * p.Kp, wplane = (size_t)p.N * p.Kp;
+
+    // loader: rows lr and lr + 64, k chunk lk (16 bytes = 8 bf16) of every plane of both operands per K tile
+    const int lr = tid >> 2, lk = tid & 3;
+    bool a_ok[2], b_ok[2];
+    const unsigned short* a_src[2];
+    const unsigned short* b_src[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        a_ok[h] = m0 + lr + 64 * h < p.M;
+        b_ok[h] = n0 + lr + 64 * h < p.N;
+        a_src[h] = p.a + (size_t)(a_ok[h] ? m0 + lr + 64 * h : 0) * p.Kp + lk * 8;
+        b_src[h] = p.w + (size_t)(b_ok[h] ? n0 + lr + 64 * h : 0) * p.Kp + lk * 8;
+    }
+    const int l_off = lr * SP_PITCH + lk * 8;
+    u32x4 ra[2][3], rb[2][3];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                ra[h][pc] = a_ok[h] ? *reinterpret_cast<const u32x4*>(a_src[h] + pc * aplane + k0) : u32x4{0u, 0u, 0u, 0u};
+                rb[h][pc] = b_ok[h] ? *reinterpret_cast<const u32x4*>(b_src[h] + pc * wplane + k0) : u32x4{0u, 0u, 0u, 0u};
+            }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                *reinterpret_cast<u32x4*>(&As[pc][l_off + h * 64 * SP_PITCH]) = ra[h][pc];
+                *reinterpret_cast<u32x4*>(&Bs[pc][l_off + h * 64 * SP_PITCH]) = rb[h][pc];
+            }
+    };
+
+    f32x4 acc[WT][WT];
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int f_off = (lane & 15) * SP_PITCH + (lane >> 4) * 8;       // fragment chunk of this lane inside a 16-row tile
+    bf16x8 a[WT][3], b[WT][3];
+    auto load_frags = [&]() {
+#pragma unroll
+        for (int t = 0; t < WT; ++t)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a[t][pc] = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const u32x4*>(&As[pc][(wr * 64 + t * 16) * SP_PITCH + f_off]));
+                b[t][pc] = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const u32x4*>(&Bs[pc][(wc * 64 + t * 16) * SP_PITCH + f_off]));
+            }
+    };
+    auto mma = [&]() {
+        // every operand fragment is read from LDS once per K tile (24 ds_read_b128 for 96 MFMAs)
+        load_frags();
+        // all 24 reads in flight before the first MFMA: left to itself the scheduler sinks each read next to its first
+        // use to save registers, and a wave then sits out one LDS latency per product group (measured 2.2 us per K tile
+        // for a lone block instead of ~0.9)
+        __builtin_amdgcn_sched_barrier(0);
+        // the six products of a tile go back to back onto ITS accumulator (small terms first): a chain on one accumulator
+        // runs at the pipe's full rate, while MFMAs that each read a different accumulator issued only every ~35-40 cycles
+#pragma unroll
+        for (int ti = 0; ti < WT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < WT; ++tj) {
+                f32x4 c = acc[ti][tj];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][2], b[tj][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][1], b[tj][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][1], b[tj][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][0], c, 0, 0, 0);
+                acc[ti][tj] = c;
+            }
+    };
+
+    const int nkt = p.Kp / SPK;
+    fetch(0);
+    stash();
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) fetch((kt + 1) * SPK);
+        mma();
+        __syncthreads();                   // everyone is done reading this K tile
+        if (kt + 1 < nkt) {
+            stash();
+            __syncthreads();
+        }
+    }
+    // epilogue: C layout col = lane & 15, row = (lane >> 4) * 4 + q
+#pragma unroll
+    for (int ti = 0; ti < WT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < WT; ++tj) {
+            const int col = n0 + wc * 64 + tj * 16 + (lane & 15);
+            if (col >= p.N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = m0 + wr * 64 + ti * 16 + (lane >> 4) * 4 + q;
+                if (row < p.M) p.y[(long long)row * p.ldy + col] = acc[ti][tj][q] + bv;
+            }
+        }
+}
+}  // namespace
+
+/* planes (3, rows, Kp) bf16, Kp = s2ag_split_k_padded(K): the exact 3-piece split of x (rows, K) with row pitch ldx */
+extern "C" int s2ag_split_k_padded(int K) { return (K + SPK - 1) / SPK * SPK; }
+
+extern "C" int s2ag_split_bf16x3(const float* x, int rows, int K, int ldx, void* planes, void* stream) {
+    if (!x || !planes || rows <= 0 || K <= 0 || ldx < K) return S2AG_E_BADARG;
+    const int Kp = s2ag_split_k_padded(K);
+    const long long total = (long long)rows * (Kp / 2);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_bf16x3_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, rows, K, ldx, Kp,
+                       static_cast<unsigned short*>(planes));
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_gemm_split_fwd(const void* a_planes, const void* w_planes, const float* bias, float* y, int M, int N,
+                                   int K, int ldy, void* stream) {
+    if (!a_planes || !w_planes || !y || M <= 0 || N <= 0 || K <= 0 || ldy < N) return S2AG_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(a_planes) | reinterpret_cast<uintptr_t>(w_planes)) & 15) return S2AG_E_BADARG;
+    SpP p{static_cast<const unsigned short*>(a_planes), static_cast<const unsigned short*>(w_planes), bias, y, M, N,
+          s2ag_split_k_padded(K), ldy};
+    hipLaunchKernelGGL(gemm_sp_k, dim3(cdiv(M, SPT), cdiv(N, SPT)), dim3(256), 0, (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}

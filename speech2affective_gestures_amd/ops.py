@@ -373,6 +373,37 @@ class _ConvNLC(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, None
 
 
+SPLIT_GEMM = __import__('os').environ.get('S2AG_GEMM_SPLIT', '1') != '0'
+SPLIT_GEMM_MIN_FLOPS = float(__import__('os').environ.get('S2AG_GEMM_SPLIT_MIN_FLOPS', '4e9'))
+
+
+def split_planes_raw(x: Tensor) -> Tensor:
+    """(rows, K) fp32 -> (3, rows, Kp) bf16 planes: the exact 3-piece split consumed by gemm_split_raw."""
+    x, rows, K, ldx = as_rows(x)
+    Kp = _lib().s2ag_split_k_padded(K)
+    planes = torch.empty(3, rows, Kp, dtype=torch.bfloat16, device=x.device)
+    L.check(_lib().s2ag_split_bf16x3(_p(x), rows, K, ldx, _p(planes), _stream()), 'split_bf16x3')
+    return planes
+
+
+def split_planes_cached(w: Tensor) -> Tensor:
+    """Planes of a weight matrix (N, K), refreshed when the weight changes (same keying as tap_major)."""
+    key = _source_key(w) + ((_GENERATION[0],) if w.requires_grad else ())
+    ent = getattr(w, '_s2ag_sp', None)
+    if ent is None or ent[0] != key:
+        with torch.no_grad():
+            ent = (key, split_planes_raw(w.detach()))
+        w._s2ag_sp = ent
+    return ent[1]
+
+
+def gemm_split_raw(a_planes: Tensor, w_planes: Tensor, bias: Optional[Tensor], y: Tensor, K: int):
+    _, M, Kp = a_planes.shape
+    N = w_planes.shape[1]
+    assert w_planes.shape[2] == Kp and y.shape == (M, N) and y.is_contiguous()
+    L.check(_lib().s2ag_gemm_split_fwd(_p(a_planes), _p(w_planes), _p(bias), _p(y), M, N, K, N, _stream()), 'gemm_split')
+
+
 def tap_major(w: Tensor) -> Tensor:
     """Cached (Cout, k, Cin) copy of a reference-layout (Cout, Cin, k) conv weight, refreshed when the weight changes
     (optimizer step, load_state_dict) and, for trainable weights, at every step boundary (see begin_step).  Frozen
@@ -915,6 +946,18 @@ def _pair(a: Optional[Tensor], b: Optional[Tensor]) -> Optional[Tensor]:
         return torch.as_strided(a.detach(), (2,) + tuple(a.shape), (a.numel(),) + tuple(a.stride()))
 
 
+def _gru_proj_split(inp, wih, wih_r, wih2, bih2, gi, In):
+    """gi = inp [W_ih; W_ih_reverse]^T + [b_ih; b_ih_reverse] through the split-operand GEMM.  The planes of the weight
+    pair are cached on the forward-direction leaf (the two leaves are adjacent in the arena: one (2*3H, In) matrix)."""
+    key = _source_key(wih) + _source_key(wih_r) + ((_GENERATION[0],) if wih.requires_grad else ())
+    ent = getattr(wih, '_s2ag_sp2', None)
+    if ent is None or ent[0] != key:
+        with torch.no_grad():
+            ent = (key, split_planes_raw(wih2.reshape(-1, In)))
+        wih._s2ag_sp2 = ent
+    gemm_split_raw(split_planes_raw(inp), ent[1], bih2.reshape(-1), gi, In)
+
+
 class _GRU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, H, Lyr, training, drop_p, noise, site0, sum_dirs, need_grad, *weights):
@@ -931,7 +974,12 @@ class _GRU(torch.autograd.Function):
             In = wih.shape[1]
             gi = torch.empty(B * T, 2 * H3, dtype=torch.float32, device=dev)
             wih2, bih2 = _pair(wih, wih_r), _pair(bih, bih_r)
-            if wih2 is not None and bih2 is not None:            # both directions' input projections: one GEMM
+            if (wih2 is not None and bih2 is not None and SPLIT_GEMM
+                    and 2.0 * B * T * In * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
+                # the big projections are bound by the f32 matrix pipe: same fp32 products on the bf16 pipe from
+                # operands split once (the weight: once per optimizer step), see gemm_sp.hip
+                _gru_proj_split(inp, wih, wih_r, wih2, bih2, gi, In)
+            elif wih2 is not None and bih2 is not None:          # both directions' input projections: one GEMM
                 conv_fwd_raw(inp, wih2, bih2, gi, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1)
             else:
                 conv_fwd_raw(inp, wih, bih, gi[:, :H3], B * T, 1, 1, In, H3, 1, 1, 0, 1)

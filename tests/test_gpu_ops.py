@@ -511,6 +511,27 @@ def test_coop_gru_products_on_the_bf16_pipe(S, pieces, tol):
     assert ops.coop_gru_timeouts() == 0
 
 
+@pytest.mark.parametrize('M,K,N', [(4352, 600, 1800), (70, 36, 5), (33, 100, 64), (257, 88, 900), (64, 32, 64)])
+def test_split_operand_gemm_is_fp32_accurate(S, M, K, N):
+    """y = a w^T + b on the bf16 matrix pipe from exact 3-piece splits of the fp32 operands: the planes reproduce the
+    operands to 2^-24, the GEMM is as accurate as an fp32 one (checked against fp64), tails in M, N and K."""
+    ops = S['ops']
+    g = torch.Generator().manual_seed(M + K + N)
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    ap, wp = ops.split_planes_raw(a.cuda()), ops.split_planes_raw(w.cuda())
+    Kp = ap.shape[2]
+    assert ap.shape == (3, M, Kp) and Kp % 32 == 0 and Kp - K < 32 and ap.dtype == torch.bfloat16
+    rec = ap.float().sum(0)[:, :K].cpu()
+    assert float((rec - a).abs().max()) <= 2.0 ** -23 * float(a.abs().max())
+    assert float(ap.float()[:, :, K:].abs().max() if Kp > K else 0.0) == 0.0
+    y = torch.empty(M, N, device='cuda')
+    ops.gemm_split_raw(ap, wp, b.cuda(), y, K)
+    ref = a.double() @ w.double().t() + b.double()
+    err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+    err32 = float(((a @ w.t() + b).double() - ref).abs().max() / ref.abs().max())
+    assert err < max(2e-6, 4 * err32), (err, err32)
+
+
 def test_embedding_dropout_and_dense_gradient(S):
     ops, noise = S['ops'], S['noise']
     g = torch.Generator().manual_seed(12)
