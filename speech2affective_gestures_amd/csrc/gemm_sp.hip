@@ -9,9 +9,11 @@
 // a2w0 are accumulated in fp32 inside v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-24 |a w|: the result is as accurate
 // as the f32 MFMA's, see gru_coop.hip and tools/diag_gru_split.py).  Six bf16 MFMAs (8 192 MACs each) do the work of
 // eight f32 MFMAs (1 024 MACs in 32 cycles each).  Measured here (tools/bench_gemm_split.py): a bf16 16x16x32 MFMA
-// issues every ~35-40 cycles per SIMD in this kernel whatever the accumulator order, register form (AGPR / VGPR) or
-// waves per SIMD -- not the ~17 of a lone dependent chain -- so the gain on the matrix pipe is 8 x 32 / (6 x ~38) = 1.1-1.3x
-// plus what the larger tile saves: 72-76 us against 113 us for the f32-MFMA kernel at M, N, K = 4 352, 1 800, 600.
+// issues every ~35-40 cycles per SIMD in this kernel whatever the accumulator order (rotating or pinned chains), register
+// form (AGPR / VGPR), waves per SIMD or MFMA shape (a v_mfma_f32_32x32x16_bf16 variant with half as many instructions ran
+// at the same speed: the time follows the MAC count at ~45 % of the nominal bf16 rate) -- so the gain on the matrix pipe
+// is 8 x 32 / (6 x ~38) = 1.1-1.3x plus what the larger tile saves: 71-76 us against 113 us for the f32-MFMA kernel at
+// M, N, K = 4 352, 1 800, 600.
 //
 // Splitting on the fly would cost as many vector-ALU cycles per K tile as it saves on the matrix pipe, so both operands
 // arrive split: s2ag_split_bf16x3 writes the three planes [piece][rows][Kp] (Kp = K rounded up to 32, zero padded) --
@@ -24,6 +26,8 @@
 // operand plane through registers into LDS (row pitch 80 B: the 16-byte operand chunks of 16 consecutive rows tile the
 // 64 banks), a wave issues 96 MFMAs (6 products x 16 tiles, consecutive MFMAs on different accumulators) against
 // 24 ds_read_b128.
+#include <stdlib.h>
+
 #include "s2ag_common.h"
 
 namespace {
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
             }
         }
 }
+
 }  // namespace
 
 /* planes (3, rows, Kp) bf16, Kp = s2ag_split_k_padded(K): the exact 3-piece split of x (rows, K) with row pitch ldx */
