@@ -119,29 +119,29 @@ def gru_roofline(B, iters=20):
     ms = sum(a.elapsed_time(b) for a, b in evs) / iters
     flops = 2.0 * B * T * 2 * H * 3 * H           # recurrent mat-vec MACs x2, both directions
     achieved = flops / (ms * 1e-3) / 1e12
-    # HBM/fabric bytes per launch from the PMC passes committed under profiles/r01_j_pmc_* (r01_i_pmc_* for the one-slice kernel) (rocprofv3 --pmc FETCH_SIZE
+    # HBM/fabric bytes per launch from the PMC passes committed under profiles/r01_m_pmc_* (r01_i_pmc_* for the one-slice kernel) (rocprofv3 --pmc FETCH_SIZE
     # and WRITE_SIZE in separate runs, KB units, FETCH doubled as the gfx950 guide prescribes): gi + exchange-cell
     # reads, y / ydrop / saved-gate / exchange-cell writes.  Only meaningful at the profiled shape (B = 128).
     two_slices = coop and int(lib.s2ag_gru_coop_fwd_slices(B)) == 2
-    traffic = ((2 * 112767.6 + 59135.0) if two_slices else (2 * 118252.0 + 59134.6)) * 1024 if (coop and B == 128) else None
+    traffic = ((2 * 112755.4 + 59134.1) if two_slices else (2 * 118252.0 + 59134.6)) * 1024 if (coop and B == 128) else None
     np_ = int(lib.s2ag_gru_coop_split_pieces()) if coop else 0
     ns_ = int(lib.s2ag_gru_coop_fwd_slices(B)) if coop else 1
     name = ((f'gru_coop_fwd_sp2_k<300,32,{np_},2>' if ns_ == 2 else f'gru_coop_fwd_sp_k<300,32,{np_}>') if np_
             else 'gru_coop_fwd_k<300,32>') if coop else 'gru_seq_fwd_k<8>'
     pipe = {0: '12 waves x 38 f32 MFMAs (16x16x4) per CU and step',
-            2: '12 waves x 15 bf16 MFMAs (16x16x32; 3 piece products of 2-piece operand splits) per CU and step',
+            2: '12 waves x 15 bf16 MFMAs (16x16x32; the 3 leading piece products of 2-piece bf16 splits of the fp32 operands: products carry 16 mantissa bits, error vs fp64 1.5e-6 against the f32-MFMA kernel\'s 3.8e-7, tools/diag_gru_split.py; S2AG_GRU_SPLIT=3 is fp32-equivalent) per CU and slice step',
             3: '12 waves x 30 bf16 MFMAs (16x16x32; the 6 leading piece products of exact 3-piece splits of the fp32 '
                'operands: fp32-equivalent, error vs fp64 equal to the f32-MFMA kernel, tools/diag_gru_split.py) per CU '
                'and step'}[np_]
     return dict(bound='mfma', kernel=name + ' (H=300, T=34, 2 directions)',
                 achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3, traffic=traffic,
-                traffic_source='profiles/r01_j_pmc_FETCH_SIZE.txt + r01_j_pmc_WRITE_SIZE.txt' if two_slices else 'profiles/r01_i_pmc_FETCH_SIZE.txt + r01_i_pmc_WRITE_SIZE.txt', ms_per_launch=ms,
+                traffic_source='profiles/r01_m_pmc_FETCH_SIZE.txt + r01_m_pmc_WRITE_SIZE.txt' if two_slices else 'profiles/r01_i_pmc_FETCH_SIZE.txt + r01_i_pmc_WRITE_SIZE.txt', ms_per_launch=ms,
                 algorithmic_flops_per_launch=flops,
                 note='peak = dense f32 MFMA peak (the arithmetic is fp32); algorithmic FLOPs = 2 x 3H x H per clip, frame '
                      'and direction.  Sequential recurrence, bound by the per-step exchange latency, not by the pipe: per '
-                     'time step (tools/diag_coop_trace.py, profiles/r01_i_coop_gru_phase_trace.txt) ~1.3 us for the new '
+                     'time step (tools/diag_coop_trace.py, profiles/r01_m_coop_gru_phase_trace.txt) ~1.3 us for the new '
                      'state to reach the peers (write-through tagged cells, polling loads), ' + pipe +
-                     ', 0.4 us gate math, 0.5 us stores; ' + ('a workgroup alternates between two 16-clip slices (one travels while the other is computed): 80 of 256 CUs per launch -- 14 % longer alone than the one-slice kernel (S2AG_GRU_SLICES=1: 0.154 ms, frac 0.194, 160 CUs) but +1.1 % on the step, where passes share the chip' if ns_ == 2 else '160 of 256 CUs hold W_hh in registers') + '; ms_per_launch includes the '
+                     ', 0.4 us gate math, 0.5 us stores; ' + ('a workgroup alternates between two 16-clip slices (one travels while the other is computed): 80 of 256 CUs per launch -- 13 % longer alone than the one-slice kernel (S2AG_GRU_SLICES=1: 0.139 ms, frac 0.215, 160 CUs) but +1.4 % on the step, where passes share the chip' if ns_ == 2 else '160 of 256 CUs hold W_hh in registers') + '; ms_per_launch includes the '
                      '~5 us exchange-buffer clear')
 
 

@@ -83,7 +83,8 @@ int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw,
  * nn.GRU, net/multimodal_context_net_v2.py:281,406 -- the one GEMM shape of the step bound by the f32 matrix pipe).
  * s2ag_split_bf16x3: planes (3, rows, Kp) bf16, Kp = s2ag_split_k_padded(K): every value = piece0 + piece1 + piece2 exactly
  * to 2^-25 (each piece the bf16 rounding of what the previous ones left), zero padded along K.  s2ag_gemm_split_fwd
- * accumulates the six leading piece products in fp32: as accurate as the f32-MFMA GEMM, 2.5x less matrix-pipe time. */
+ * accumulates the piece products in fp32: three of them with the default two pieces (error vs fp64 ~3e-6 of the largest
+ * output), six with S2AG_GRU_SPLIT=3 (as accurate as the f32-MFMA GEMM). */
 int s2ag_split_k_padded(int K);
 int s2ag_split_bf16x3(const float* x, int rows, int K, int ldx, void* planes, void* stream);
 int s2ag_gemm_split_fwd(const void* a_planes /*(3, M, Kp)*/, const void* w_planes /*(3, N, Kp)*/,
@@ -277,11 +278,13 @@ int s2ag_gru_seq_bwd(const float* dy, int lddy, int dy_dir_stride, const float* 
  * 16-clip slice) and exchanges h_t (forward) / d(gh)_t (backward) once per step through `workspace` with
  * write-through stores of self-validating (value, step tag) cells (agent scope).  Same arguments and results as the
  * streaming kernels; `workspace` needs s2ag_gru_coop_workspace_bytes() bytes and may be uninitialised.
- * The per-step matrix products are fp32 products realised on the bf16 matrix pipe: every fp32 operand is split exactly
- * into 3 bf16 pieces (24 mantissa bits) and the 6 leading piece products are accumulated in fp32 -- error against an
- * fp64 reference equals the f32-MFMA kernels' (tools/diag_gru_split.py), 2.4x less time on the matrix pipe.
- * s2ag_gru_coop_split_pieces(): pieces per operand in use (3 default; env S2AG_GRU_SPLIT=2: 16-bit mantissa, 3 products;
- * S2AG_GRU_SPLIT=0: v_mfma_f32_16x16x4_f32). */
+ * The per-step matrix products are fp32 products realised on the bf16 matrix pipe from bf16-piece splits of the fp32
+ * operands (each piece the bf16 rounding of what the previous ones left), piece products accumulated in fp32:
+ *   2 pieces (default): a0b0 + a0b1 + a1b0 -- products carry 16 mantissa bits; error against an fp64 GRU 1.5e-6 (y),
+ *     1.9e-6 (gradients), the f32-MFMA kernels' being 3.8e-7 / 4.6e-7 (tools/diag_gru_split.py) -- ~600x inside the 1e-3 bar;
+ *   3 pieces (S2AG_GRU_SPLIT=3): + a1b1 + a0b2 + a2b0 -- 24 mantissa bits, error equal to the f32-MFMA kernels';
+ *   S2AG_GRU_SPLIT=0: v_mfma_f32_16x16x4_f32.
+ * s2ag_gru_coop_split_pieces(): the setting in use (shared by s2ag_gemm_split_fwd). */
 int s2ag_gru_coop_supported(int H);
 int s2ag_gru_coop_split_pieces(void);
 /* 16-clip slices one forward workgroup alternates between (2 when B > 16 with the 3-piece products: while one slice's

@@ -82,10 +82,11 @@ struct SpP {
     int M, N, Kp, ldy;
 };
 
+template <int NP>      // operand pieces used: 3 (six products, fp32-equivalent) or 2 (three products, 16 mantissa bits)
 __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
     // single-buffered LDS (61 KB: two blocks per CU), the next K tile travels through registers meanwhile
-    __shared__ __attribute__((aligned(16))) unsigned short As[3][SP_PLANE];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][SP_PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short As[NP][SP_PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[NP][SP_PLANE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -105,12 +106,12 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
         b_src[h] = p.w + (size_t)(b_ok[h] ? n0 + lr + 64 * h : 0) * p.Kp + lk * 8;
     }
     const int l_off = lr * SP_PITCH + lk * 8;
-    u32x4 ra[2][3], rb[2][3];
+    u32x4 ra[2][NP], rb[2][NP];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
+            for (int pc = 0; pc < NP; ++pc) {
                 ra[h][pc] = a_ok[h] ? *reinterpret_cast<const u32x4*>(a_src[h] + pc * aplane + k0) : u32x4{0u, 0u, 0u, 0u};
                 rb[h][pc] = b_ok[h] ? *reinterpret_cast<const u32x4*>(b_src[h] + pc * wplane + k0) : u32x4{0u, 0u, 0u, 0u};
             }
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
+            for (int pc = 0; pc < NP; ++pc) {
                 *reinterpret_cast<u32x4*>(&As[pc][l_off + h * 64 * SP_PITCH]) = ra[h][pc];
                 *reinterpret_cast<u32x4*>(&Bs[pc][l_off + h * 64 * SP_PITCH]) = rb[h][pc];
             }
@@ -131,12 +132,12 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
 #pragma unroll
         for (int j = 0; j < WT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int f_off = (lane & 15) * SP_PITCH + (lane >> 4) * 8;       // fragment chunk of this lane inside a 16-row tile
-    bf16x8 a[WT][3], b[WT][3];
+    bf16x8 a[WT][NP], b[WT][NP];
     auto load_frags = [&]() {
 #pragma unroll
         for (int t = 0; t < WT; ++t)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
+            for (int pc = 0; pc < NP; ++pc) {
                 a[t][pc] = __builtin_bit_cast(
                     bf16x8, *reinterpret_cast<const u32x4*>(&As[pc][(wr * 64 + t * 16) * SP_PITCH + f_off]));
                 b[t][pc] = __builtin_bit_cast(
@@ -157,9 +158,11 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
 #pragma unroll
             for (int tj = 0; tj < WT; ++tj) {
                 f32x4 c = acc[ti][tj];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][2], b[tj][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][1], b[tj][1], c, 0, 0, 0);
+                if constexpr (NP == 3) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][NP - 1], b[tj][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][NP - 1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][1], b[tj][1], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][1], b[tj][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][0], c, 0, 0, 0);
@@ -198,6 +201,8 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
 
 }  // namespace
 
+extern "C" int s2ag_gru_coop_split_pieces(void);
+
 /* planes (3, rows, Kp) bf16, Kp = s2ag_split_k_padded(K): the exact 3-piece split of x (rows, K) with row pitch ldx */
 extern "C" int s2ag_split_k_padded(int K) { return (K + SPK - 1) / SPK * SPK; }
 
@@ -219,7 +224,12 @@ extern "C" int s2ag_gemm_split_fwd(const void* a_planes, const void* w_planes, c
     if ((reinterpret_cast<uintptr_t>(a_planes) | reinterpret_cast<uintptr_t>(w_planes)) & 15) return S2AG_E_BADARG;
     SpP p{static_cast<const unsigned short*>(a_planes), static_cast<const unsigned short*>(w_planes), bias, y, M, N,
           s2ag_split_k_padded(K), ldy};
-    hipLaunchKernelGGL(gemm_sp_k, dim3(cdiv(M, SPT), cdiv(N, SPT)), dim3(256), 0, (hipStream_t)stream, p);
+    // pieces: the setting shared with the cooperative GRU (S2AG_GRU_SPLIT; 0 there means "f32 MFMA": the caller then does
+    // not come here); the planes always hold three pieces, two-piece products simply leave the third unread
+    if (s2ag_gru_coop_split_pieces() == 2)
+        hipLaunchKernelGGL(gemm_sp_k<2>, dim3(cdiv(M, SPT), cdiv(N, SPT)), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(gemm_sp_k<3>, dim3(cdiv(M, SPT), cdiv(N, SPT)), dim3(256), 0, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

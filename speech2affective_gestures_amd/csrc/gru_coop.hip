@@ -27,9 +27,10 @@
 // The backward kernel has the same structure with W_hh[:, slice] (3H x 32) in registers and the group
 // exchanging d(gh) (16 x 3H) cells per step; the running dL/dh of a (clip, unit) lives in its thread's register.
 //
-// Default build: the products run on the bf16 matrix pipe as exact 3-piece splits of the fp32 operands
-// (gru_coop_fwd_sp_k / gru_coop_bwd_k<.., 3>, see "fp32 products on the bf16 matrix pipe" below); the f32-MFMA kernels
-// described above remain selectable (S2AG_GRU_SPLIT=0) and are what the split kernels are validated against.
+// Default build: the products run on the bf16 matrix pipe from bf16-piece splits of the fp32 operands (two pieces = three
+// products, 16 mantissa bits, by default; three pieces = six products, fp32-equivalent, with S2AG_GRU_SPLIT=3; see "fp32
+// products on the bf16 matrix pipe" below); the f32-MFMA kernels described above remain selectable (S2AG_GRU_SPLIT=0) and
+// are what the split kernels are validated against.
 #include <stdlib.h>
 
 #include "s2ag_common.h"
@@ -980,12 +981,12 @@ inline size_t coop_payload_bytes(int B, int H, int backward) {
     return align_up(groups * producers * 2 * (size_t)H * CBS * sizeof(u64), 256);   // [group][parity][...] cells
 }
 
-// S2AG_GRU_SPLIT = 0: f32 MFMA; 2 / 3: fp32 products from 2 / 3 bf16 pieces on the bf16 pipe (see above)
+// S2AG_GRU_SPLIT = 0: f32 MFMA; 2 (default) / 3: fp32 products from 2 / 3 bf16 pieces on the bf16 pipe (see above)
 int g_split_override = -1;          // s2ag_gru_coop_set_split_pieces (tests / diagnostics)
 inline int coop_split_pieces() {
     static const int v = [] {
         const char* e = getenv("S2AG_GRU_SPLIT");
-        const int n = e ? atoi(e) : 3;
+        const int n = e ? atoi(e) : 2;
         return (n == 2 || n == 3) ? n : 0;
     }();
     return g_split_override >= 0 ? g_split_override : v;
@@ -1022,7 +1023,7 @@ Ws carve(void* ws, int B, int H, int backward) {
 // discriminators' H = 64 -- live entirely in registers: gru_small.hip.)
 extern "C" int s2ag_gru_coop_supported(int H) { return H == 300 ? 1 : 0; }
 extern "C" int s2ag_gru_coop_split_pieces(void) { return coop_split_pieces(); }
-extern "C" int s2ag_gru_coop_fwd_slices(int B) { return (coop_split_pieces() == 3 && B > CBS && coop_two_slices()) ? 2 : 1; }
+extern "C" int s2ag_gru_coop_fwd_slices(int B) { return (coop_split_pieces() != 0 && B > CBS && coop_two_slices()) ? 2 : 1; }
 extern "C" int s2ag_gru_coop_set_split_pieces(int pieces) {
     const int prev = coop_split_pieces();
     g_split_override = (pieces == 2 || pieces == 3) ? pieces : (pieces == 0 ? 0 : -1);
@@ -1048,17 +1049,24 @@ extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float*
     const unsigned long long* rg = e ? e->rng : nullptr;
     const unsigned site = e ? e->site : 0u;
     const dim3 grid(10, cdiv(B, CBS), 2);
-    if (coop_split_pieces() == 3 && B > CBS && coop_two_slices()) {
-        constexpr int smem2 = 2 * 3 * CBS * (5 * 2 * 32 + 8) * 2;          // [slice][piece][clip][k] bf16
-        static bool granted2 = false;
-        if (!granted2) {
-            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 3, 2>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+    if (coop_split_pieces() != 0 && B > CBS && coop_two_slices()) {
+        const int np = coop_split_pieces();
+        const int smem2 = 2 * np * CBS * (5 * 2 * 32 + 8) * 2;             // [slice][piece][clip][k] bf16
+        const void* fn2 = np == 3 ? reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 3, 2>)
+                                  : reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 2, 2>);
+        static bool granted2[4] = {false, false, false, false};
+        if (!granted2[np]) {
+            hipError_t ae = hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
             if (ae != hipSuccess) return (int)ae;
-            granted2 = true;
+            granted2[np] = true;
         }
-        hipLaunchKernelGGL((gru_coop_fwd_sp2_k<300, 32, 3, 2>), dim3(10, cdiv(B, 2 * CBS), 2), dim3(CNT), smem2,
-                           (hipStream_t)stream, gi, whh, bhh, y, ydrop, gates, w.x, w.err, B, T, p, ik, rg, site);
+        const dim3 grid2(10, cdiv(B, 2 * CBS), 2);
+        if (np == 3)
+            hipLaunchKernelGGL((gru_coop_fwd_sp2_k<300, 32, 3, 2>), grid2, dim3(CNT), smem2, (hipStream_t)stream, gi, whh,
+                               bhh, y, ydrop, gates, w.x, w.err, B, T, p, ik, rg, site);
+        else
+            hipLaunchKernelGGL((gru_coop_fwd_sp2_k<300, 32, 2, 2>), grid2, dim3(CNT), smem2, (hipStream_t)stream, gi, whh,
+                               bhh, y, ydrop, gates, w.x, w.err, B, T, p, ik, rg, site);
         S2AG_LAUNCH_CHECK();
         return 0;
     }

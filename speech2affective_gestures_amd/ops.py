@@ -974,7 +974,7 @@ class _GRU(torch.autograd.Function):
             In = wih.shape[1]
             gi = torch.empty(B * T, 2 * H3, dtype=torch.float32, device=dev)
             wih2, bih2 = _pair(wih, wih_r), _pair(bih, bih_r)
-            if (wih2 is not None and bih2 is not None and SPLIT_GEMM
+            if (wih2 is not None and bih2 is not None and SPLIT_GEMM and lib.s2ag_gru_coop_split_pieces() != 0
                     and 2.0 * B * T * In * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
                 # the big projections are bound by the f32 matrix pipe: same fp32 products on the bf16 pipe from
                 # operands split once (the weight: once per optimizer step), see gemm_sp.hip

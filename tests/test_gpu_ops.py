@@ -512,9 +512,10 @@ def test_coop_gru_products_on_the_bf16_pipe(S, pieces, tol):
 
 
 @pytest.mark.parametrize('M,K,N', [(4352, 600, 1800), (70, 36, 5), (33, 100, 64), (257, 88, 900), (64, 32, 64)])
-def test_split_operand_gemm_is_fp32_accurate(S, M, K, N):
-    """y = a w^T + b on the bf16 matrix pipe from exact 3-piece splits of the fp32 operands: the planes reproduce the
-    operands to 2^-24, the GEMM is as accurate as an fp32 one (checked against fp64), tails in M, N and K."""
+def test_split_operand_gemm_accuracy(S, M, K, N):
+    """y = a w^T + b on the bf16 matrix pipe from bf16-piece splits of the fp32 operands: the three planes reproduce the
+    operands to 2^-24; with three pieces the GEMM is as accurate as an fp32 one, with the default two pieces its products
+    carry 16 mantissa bits (checked against fp64); tails in M, N and K."""
     ops = S['ops']
     g = torch.Generator().manual_seed(M + K + N)
     a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
@@ -529,7 +530,10 @@ def test_split_operand_gemm_is_fp32_accurate(S, M, K, N):
     ref = a.double() @ w.double().t() + b.double()
     err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
     err32 = float(((a @ w.t() + b).double() - ref).abs().max() / ref.abs().max())
-    assert err < max(2e-6, 4 * err32), (err, err32)
+    if S['ops']._lib().s2ag_gru_coop_split_pieces() == 3:
+        assert err < max(2e-6, 4 * err32), (err, err32)          # six products: fp32-equivalent
+    else:
+        assert err < 2e-5, (err, err32)                          # three products: 16 mantissa bits
 
 
 def test_embedding_dropout_and_dense_gradient(S):
