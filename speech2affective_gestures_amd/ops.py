@@ -374,6 +374,7 @@ class _ConvNLC(torch.autograd.Function):
 
 
 SPLIT_GEMM = __import__('os').environ.get('S2AG_GEMM_SPLIT', '1') != '0'
+SPLIT_GEMM_DX = __import__('os').environ.get('S2AG_DX_SPLIT', '1') != '0'
 SPLIT_GEMM_MIN_FLOPS = float(__import__('os').environ.get('S2AG_GEMM_SPLIT_MIN_FLOPS', '4e9'))
 
 
@@ -1065,7 +1066,22 @@ class _GRU(torch.autograd.Function):
             if l > 0 or ctx.needs_input_grad[0]:
                 dx = torch.empty(B * T, In, dtype=torch.float32, device=dev)
                 wih2 = _pair(wih, wih_r)
-                if wih2 is not None:
+                if (wih2 is not None and SPLIT_GEMM and SPLIT_GEMM_DX and lib.s2ag_gru_coop_split_pieces() != 0
+                        and 2.0 * B * T * In * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
+                    # dx = dgi [W_ih; W_ih_reverse]: the same split-operand GEMM with the transposed weight pair's planes
+                    # (refreshed once per optimizer step) and a split pass over dgi
+                    wih_leaf, wih_r_leaf = ctx.w_leaves[8 * l], ctx.w_leaves[8 * l + 4]
+                    key = _source_key(wih_leaf) + _source_key(wih_r_leaf) + ((_GENERATION[0],) if wih_leaf.requires_grad
+                                                                             else ())
+                    ent = getattr(wih_leaf, '_s2ag_spT', None)
+                    if ent is None or ent[0] != key:
+                        with torch.no_grad():
+                            wt = torch.empty(In, 2 * H3, dtype=torch.float32, device=dev)
+                            transpose_raw(wih2.reshape(-1, In), wt)
+                            ent = (key, split_planes_raw(wt))
+                        wih_leaf._s2ag_spT = ent
+                    gemm_split_raw(split_planes_raw(dgi), ent[1], None, dx, 2 * H3)
+                elif wih2 is not None:
                     conv_bwd_data_raw(dgi, wih2, dx, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1, False)
                 else:
                     conv_bwd_data_raw(dgi[:, :H3], wih, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, False)
