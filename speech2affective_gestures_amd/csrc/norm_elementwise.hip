@@ -1,6 +1,8 @@
 // BatchNorm (training + eval), residual/activation glue and their backward passes on channels-last
 // fp32 matrices.  All of these are HBM/latency-bound streaming kernels: consecutive lanes walk
 // consecutive columns of a row (coalesced), grid-stride over rows.
+#include <stdlib.h>
+
 #include "s2ag_common.h"
 
 namespace {
@@ -357,10 +359,13 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_k(const float* s1, const fl
 // g*S of either half -- and bn_fold_k then reads every S-th row.  Fixed order: bit-reproducible.
 constexpr int FOLD_SLICE = 64;
 __global__ __launch_bounds__(256) void bn_fold_pre_k(double* part, int prow, int cols) {
+    // block (slice of FOLD_SLICE rows, block of up to 256 columns)
     __shared__ double red[2][256];
     const int beg = blockIdx.x * FOLD_SLICE, end = min(prow, beg + FOLD_SLICE);
-    const int nsub = 256 / cols;                                     // host: cols <= 256
-    const int c = threadIdx.x % cols, sub = threadIdx.x / cols;
+    const int c0 = blockIdx.y * 256, cw = min(256, cols - c0);       // this block's columns
+    const int nsub = 256 / cw;
+    const int cl = threadIdx.x % cw, sub = threadIdx.x / cw;
+    const int c = c0 + cl;
     double a = 0.0, b = 0.0;
     if (sub < nsub)
         for (int r = beg + sub; r < end; r += nsub) {
@@ -370,10 +375,10 @@ __global__ __launch_bounds__(256) void bn_fold_pre_k(double* part, int prow, int
     red[0][threadIdx.x] = a;
     red[1][threadIdx.x] = b;
     __syncthreads();
-    if ((int)threadIdx.x < cols) {
+    if ((int)threadIdx.x < cw) {
         for (int j = 1; j < nsub; ++j) {
-            a += red[0][j * cols + c];
-            b += red[1][j * cols + c];
+            a += red[0][j * cw + cl];
+            b += red[1][j * cw + cl];
         }
         part[(size_t)beg * cols + c] = a;
         part[(size_t)(prow + beg) * cols + c] = b;
@@ -395,9 +400,9 @@ __global__ __launch_bounds__(1024) void bn_fold_k(const double* part, int prow, 
         fold_partials<double, double, 1024>(part, prow, cols, chan_of_col, cs, cq, cn);
     } else {
         // rows 0, pstep, 2*pstep, ... of either half (left by bn_fold_pre_k)
-        const int nsub = 1024 / cols;                              // host: cols <= 256 on this path
-        const int c = threadIdx.x % cols, sub = threadIdx.x / cols;
-        if (sub < nsub) {
+        const int nsub = cols >= 1024 ? 1 : 1024 / cols;
+        const int sub = cols >= 1024 ? 0 : (int)threadIdx.x / cols;
+        for (int c = cols >= 1024 ? (int)threadIdx.x : (int)threadIdx.x % cols; c < cols && sub < nsub; c += 1024) {
             double a = 0.0, b = 0.0;
             for (int r = sub * pstep; r < prow; r += nsub * pstep) {
                 a += part[(size_t)r * cols + c];
@@ -407,6 +412,7 @@ __global__ __launch_bounds__(1024) void bn_fold_k(const double* part, int prow, 
             atomicAdd(&cs[ch], a);
             atomicAdd(&cq[ch], b);
             if (sub == 0) atomicAdd(&cn[ch], 1.0);
+            if (cols < 1024) break;
         }
     }
     __syncthreads();
@@ -639,10 +645,11 @@ extern "C" int s2ag_bn_fold(double* partials, int partial_rows, int rows, int co
         !running_mean || !running_var || !scale_col || !shift_col || !mean_col || !invstd_col)
         return S2AG_E_BADARG;
     int pstep = 1;
-    if (partial_rows >= 1024 && cols <= 256) {
+    static const int pre_min = [] { const char* e = getenv("S2AG_BN_PREFOLD_MIN"); return e ? atoi(e) : 1024; }();
+    if (partial_rows >= pre_min) {
         pstep = FOLD_SLICE;
-        hipLaunchKernelGGL(bn_fold_pre_k, dim3(cdiv(partial_rows, FOLD_SLICE)), dim3(256), 0, (hipStream_t)stream,
-                           partials, partial_rows, cols);
+        hipLaunchKernelGGL(bn_fold_pre_k, dim3(cdiv(partial_rows, FOLD_SLICE), cdiv(cols, 256)), dim3(256), 0,
+                           (hipStream_t)stream, partials, partial_rows, cols);
     }
     hipLaunchKernelGGL(bn_fold_k, dim3(1), dim3(1024), sizeof(double) * 3 * nchan, (hipStream_t)stream, partials,
                        partial_rows, rows, cols, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt, eps,
