@@ -37,10 +37,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int SPK = 32;                 // K tile
-constexpr int SPT = 128;                // tile rows / columns
 constexpr int SP_PITCH = 40;            // LDS row pitch in bf16 elements (80 B)
-constexpr int SP_PLANE = SPT * SP_PITCH;
-constexpr int WT = 4;                   // 16 x 16 MFMA tiles per wave along either axis (64 x 64 per wave)
 
 __device__ __forceinline__ unsigned bf16_rn(float v) {
     unsigned u = __float_as_uint(v);
@@ -82,9 +79,15 @@ struct SpP {
     int M, N, Kp, ldy;
 };
 
-template <int NP>      // operand pieces used: 3 (six products, fp32-equivalent) or 2 (three products, 16 mantissa bits)
+// NP: operand pieces used: 3 (six products, fp32-equivalent) or 2 (three products, 16 mantissa bits).
+// SPT: tile rows = columns: 128 (4 waves of 64 x 64) where the grid still fills the chip, else 64 (4 waves of 32 x 32).
+template <int NP, int SPT>
 __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
-    // single-buffered LDS (61 KB: two blocks per CU), the next K tile travels through registers meanwhile
+    constexpr int SP_PLANE = SPT * SP_PITCH;
+    constexpr int WT = SPT / 32;           // 16 x 16 MFMA tiles per wave along either axis
+    constexpr int WS = SPT / 2;            // rows / columns per wave
+    constexpr int NH = SPT / 64;           // loader passes of 64 rows
+    // single-buffered LDS (61 KB at 128: two blocks per CU), the next K tile travels through registers meanwhile
     __shared__ __attribute__((aligned(16))) unsigned short As[NP][SP_PLANE];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[NP][SP_PLANE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -95,21 +98,21 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
 
     // loader: rows lr and lr + 64, k chunk lk (16 bytes = 8 bf16) of every plane of both operands per K tile
     const int lr = tid >> 2, lk = tid & 3;
-    bool a_ok[2], b_ok[2];
-    const unsigned short* a_src[2];
-    const unsigned short* b_src[2];
+    bool a_ok[NH], b_ok[NH];
+    const unsigned short* a_src[NH];
+    const unsigned short* b_src[NH];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
         a_ok[h] = m0 + lr + 64 * h < p.M;
         b_ok[h] = n0 + lr + 64 * h < p.N;
         a_src[h] = p.a + (size_t)(a_ok[h] ? m0 + lr + 64 * h : 0) * p.Kp + lk * 8;
         b_src[h] = p.w + (size_t)(b_ok[h] ? n0 + lr + 64 * h : 0) * p.Kp + lk * 8;
     }
     const int l_off = lr * SP_PITCH + lk * 8;
-    u32x4 ra[2][NP], rb[2][NP];
+    u32x4 ra[NH][NP], rb[NH][NP];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
                 ra[h][pc] = a_ok[h] ? *reinterpret_cast<const u32x4*>(a_src[h] + pc * aplane + k0) : u32x4{0u, 0u, 0u, 0u};
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
                 *reinterpret_cast<u32x4*>(&As[pc][l_off + h * 64 * SP_PITCH]) = ra[h][pc];
@@ -139,9 +142,9 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
                 a[t][pc] = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const u32x4*>(&As[pc][(wr * 64 + t * 16) * SP_PITCH + f_off]));
+                    bf16x8, *reinterpret_cast<const u32x4*>(&As[pc][(wr * WS + t * 16) * SP_PITCH + f_off]));
                 b[t][pc] = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const u32x4*>(&Bs[pc][(wc * 64 + t * 16) * SP_PITCH + f_off]));
+                    bf16x8, *reinterpret_cast<const u32x4*>(&Bs[pc][(wc * WS + t * 16) * SP_PITCH + f_off]));
             }
     };
     auto mma = [&]() {
@@ -188,12 +191,12 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
     for (int ti = 0; ti < WT; ++ti)
 #pragma unroll
         for (int tj = 0; tj < WT; ++tj) {
-            const int col = n0 + wc * 64 + tj * 16 + (lane & 15);
+            const int col = n0 + wc * WS + tj * 16 + (lane & 15);
             if (col >= p.N) continue;
             const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int row = m0 + wr * 64 + ti * 16 + (lane >> 4) * 4 + q;
+                const int row = m0 + wr * WS + ti * 16 + (lane >> 4) * 4 + q;
                 if (row < p.M) p.y[(long long)row * p.ldy + col] = acc[ti][tj][q] + bv;
             }
         }
@@ -225,11 +228,18 @@ extern "C" int s2ag_gemm_split_fwd(const void* a_planes, const void* w_planes, c
     SpP p{static_cast<const unsigned short*>(a_planes), static_cast<const unsigned short*>(w_planes), bias, y, M, N,
           s2ag_split_k_padded(K), ldy};
     // pieces: the setting shared with the cooperative GRU (S2AG_GRU_SPLIT; 0 there means "f32 MFMA": the caller then does
-    // not come here); the planes always hold three pieces, two-piece products simply leave the third unread
-    if (s2ag_gru_coop_split_pieces() == 2)
-        hipLaunchKernelGGL(gemm_sp_k<2>, dim3(cdiv(M, SPT), cdiv(N, SPT)), dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(gemm_sp_k<3>, dim3(cdiv(M, SPT), cdiv(N, SPT)), dim3(256), 0, (hipStream_t)stream, p);
+    // not come here); the planes always hold three pieces, two-piece products simply leave the third unread.
+    // Tile: 128 x 128 halves the operand traffic but needs >= ~1.5 blocks per CU to fill the chip; else 64 x 64.
+    const bool big = (long long)cdiv(M, 128) * cdiv(N, 128) >= 384;
+    const bool two = s2ag_gru_coop_split_pieces() == 2;
+    const dim3 grid(cdiv(M, big ? 128 : 64), cdiv(N, big ? 128 : 64));
+    if (big) {
+        if (two) hipLaunchKernelGGL((gemm_sp_k<2, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((gemm_sp_k<3, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (two) hipLaunchKernelGGL((gemm_sp_k<2, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((gemm_sp_k<3, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     S2AG_LAUNCH_CHECK();
     return 0;
 }
