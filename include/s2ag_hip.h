@@ -87,6 +87,15 @@ int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw,
  * output), six with S2AG_GRU_SPLIT=3 (as accurate as the f32-MFMA GEMM). */
 int s2ag_split_k_padded(int K);
 int s2ag_split_bf16x3(const float* x, int rows, int K, int ldx, void* planes, void* stream);
+/* Weight gradients on the same pipe: dW (M, N) += gy^T x contracts over the rows, so both operands are split TRANSPOSED
+ * (planes (3, cols, Rp), Rp = s2ag_split_k_padded(rows); `shift`: the operand row of frame t is frame t + shift of the same
+ * clip of L frames, zero outside it -- dW_hh of nn.GRU pairs d(gh)_t with h_{t-1}; `colsum` (nullable, shift == 0): += the
+ * column sums, i.e. the bias gradient) and s2ag_gemm_split_acc accumulates a w^T into y with the contraction split over
+ * blocks (fp32 atomics). */
+int s2ag_split_bf16x3_t(const float* x, int rows, int cols, int ldx, int shift, int L, void* planes, float* colsum,
+                        void* stream);
+int s2ag_gemm_split_acc(const void* a_planes /*(3, M, Kp)*/, const void* w_planes /*(3, N, Kp)*/, float* y, int M, int N,
+                        int K, int ldy, void* stream);
 int s2ag_gemm_split_fwd(const void* a_planes /*(3, M, Kp)*/, const void* w_planes /*(3, N, Kp)*/,
                         const float* bias /*nullable*/, float* y, int M, int N, int K, int ldy, void* stream);
 

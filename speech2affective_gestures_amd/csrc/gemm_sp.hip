@@ -71,12 +71,73 @@ __global__ __launch_bounds__(256) void split_bf16x3_k(const float* __restrict__ 
     }
 }
 
+// Transposed planes for the weight gradients (contraction over the rows): planes[p][c][r] = piece p of x[src(r)][c],
+// r < rows (zero for rows <= r < Rp), where src(r) = r + shift inside the clip of L frames the row belongs to (zero outside
+// it: the GRU's dW_hh contracts d(gh)_t with h_{t-1}).  32 x 32 tiles through LDS: coalesced reads along the columns,
+// coalesced 2-byte writes along the rows.  colsum (nullable): += column sums of x (the bias gradient rides along).
+__global__ __launch_bounds__(256) void split_bf16x3_t_k(const float* __restrict__ x, int rows, int cols, int ldx, int Rp,
+                                                        int shift, int L, unsigned short* __restrict__ planes,
+                                                        float* __restrict__ colsum) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        float v = 0.f;
+        if (r < rows && c < cols) {
+            int src = r;
+            bool ok = true;
+            if (shift != 0) {
+                const int l = r % L + shift;
+                ok = l >= 0 && l < L;
+                src = r + shift;
+            }
+            if (ok) v = x[(long long)src * ldx + c];
+        }
+        tile[ty + 8 * j][tx] = v;
+        part += v;
+    }
+    if (colsum) {                                                    // (only used with shift == 0)
+        __shared__ float cs[8][32];
+        cs[ty][tx] = part;
+        __syncthreads();
+        if (ty == 0 && c0 + tx < cols) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += cs[j][tx];
+            atomicAdd(colsum + c0 + tx, t);
+        }
+    }
+    __syncthreads();
+    const size_t plane = (size_t)cols * Rp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, r = r0 + tx;
+        if (c < cols && r < Rp) {
+            const float v = tile[tx][ty + 8 * j];
+            const unsigned p0 = bf16_rn(v);
+            const float r1 = v - __uint_as_float(p0 << 16);
+            const unsigned p1 = bf16_rn(r1);
+            const float r2 = r1 - __uint_as_float(p1 << 16);
+            const unsigned p2 = bf16_rn(r2);
+            const size_t o = (size_t)c * Rp + r;
+            planes[o] = (unsigned short)p0;
+            planes[plane + o] = (unsigned short)p1;
+            planes[2 * plane + o] = (unsigned short)p2;
+        }
+    }
+}
+
 struct SpP {
     const unsigned short* a;            // [3][M][Kp]
     const unsigned short* w;            // [3][N][Kp]
     const float* bias;                  // nullable
     float* y;
     int M, N, Kp, ldy;
+    int kchunk;                         // K range per blockIdx.z (multiple of 32); == Kp without a K split
+    int atomic_acc;                     // 1: y += (atomicAdd; weight gradients, K split over blockIdx.z), bias ignored
 };
 
 // NP: operand pieces used: 3 (six products, fp32-equivalent) or 2 (three products, 16 mantissa bits).
@@ -173,12 +234,13 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
             }
     };
 
-    const int nkt = p.Kp / SPK;
-    fetch(0);
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int nkt = (min(p.Kp, kbeg + p.kchunk) - kbeg) / SPK;
+    fetch(kbeg);
     stash();
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) fetch((kt + 1) * SPK);
+        if (kt + 1 < nkt) fetch(kbeg + (kt + 1) * SPK);
         mma();
         __syncthreads();                   // everyone is done reading this K tile
         if (kt + 1 < nkt) {
@@ -193,11 +255,15 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
         for (int tj = 0; tj < WT; ++tj) {
             const int col = n0 + wc * WS + tj * 16 + (lane & 15);
             if (col >= p.N) continue;
-            const float bv = p.bias ? p.bias[col] : 0.f;
+            const float bv = (p.bias && !p.atomic_acc) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = m0 + wr * WS + ti * 16 + (lane >> 4) * 4 + q;
-                if (row < p.M) p.y[(long long)row * p.ldy + col] = acc[ti][tj][q] + bv;
+                if (row >= p.M) continue;
+                if (p.atomic_acc)
+                    atomicAdd(p.y + (long long)row * p.ldy + col, acc[ti][tj][q]);
+                else
+                    p.y[(long long)row * p.ldy + col] = acc[ti][tj][q] + bv;
             }
         }
 }
@@ -226,7 +292,7 @@ extern "C" int s2ag_gemm_split_fwd(const void* a_planes, const void* w_planes, c
     if (!a_planes || !w_planes || !y || M <= 0 || N <= 0 || K <= 0 || ldy < N) return S2AG_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(a_planes) | reinterpret_cast<uintptr_t>(w_planes)) & 15) return S2AG_E_BADARG;
     SpP p{static_cast<const unsigned short*>(a_planes), static_cast<const unsigned short*>(w_planes), bias, y, M, N,
-          s2ag_split_k_padded(K), ldy};
+          s2ag_split_k_padded(K), ldy, s2ag_split_k_padded(K), 0};
     // pieces: the setting shared with the cooperative GRU (S2AG_GRU_SPLIT; 0 there means "f32 MFMA": the caller then does
     // not come here); the planes always hold three pieces, two-piece products simply leave the third unread.
     // Tile: 128 x 128 halves the operand traffic but needs >= ~1.5 blocks per CU to fill the chip; else 64 x 64.
@@ -240,6 +306,41 @@ extern "C" int s2ag_gemm_split_fwd(const void* a_planes, const void* w_planes, c
         if (two) hipLaunchKernelGGL((gemm_sp_k<2, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((gemm_sp_k<3, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* planes (3, cols, Rp) bf16, Rp = s2ag_split_k_padded(rows): the TRANSPOSED split of x (rows, cols), optionally shifted by
+ * `shift` frames inside clips of L frames (zero outside the clip); colsum (nullable) += column sums of x. */
+extern "C" int s2ag_split_bf16x3_t(const float* x, int rows, int cols, int ldx, int shift, int L, void* planes,
+                                   float* colsum, void* stream) {
+    if (!x || !planes || rows <= 0 || cols <= 0 || ldx < cols || L <= 0 || (shift != 0 && colsum)) return S2AG_E_BADARG;
+    const int Rp = s2ag_split_k_padded(rows);
+    hipLaunchKernelGGL(split_bf16x3_t_k, dim3(cdiv(cols, 32), cdiv(Rp, 32)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       cols, ldx, Rp, shift, L, static_cast<unsigned short*>(planes), colsum);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* y (M, N) += a w^T with a = planes (3, M, Kp), w = planes (3, N, Kp): the contraction is split over blocks and merged with
+ * fp32 atomics (weight gradients: M, N = the weight's shape, K = clips * frames). */
+extern "C" int s2ag_gemm_split_acc(const void* a_planes, const void* w_planes, float* y, int M, int N, int K, int ldy,
+                                   void* stream) {
+    if (!a_planes || !w_planes || !y || M <= 0 || N <= 0 || K <= 0 || ldy < N) return S2AG_E_BADARG;
+    const int Kp = s2ag_split_k_padded(K);
+    const int tiles = cdiv(M, 64) * cdiv(N, 64);
+    int nsplit = cdiv(512, tiles);
+    if (nsplit > Kp / (4 * SPK)) nsplit = Kp / (4 * SPK);
+    if (nsplit < 1) nsplit = 1;
+    const int kchunk = cdiv(cdiv(Kp, nsplit), SPK) * SPK;
+    nsplit = cdiv(Kp, kchunk);
+    SpP p{static_cast<const unsigned short*>(a_planes), static_cast<const unsigned short*>(w_planes), nullptr, y, M, N, Kp,
+          ldy, kchunk, 1};
+    const dim3 grid(cdiv(M, 64), cdiv(N, 64), nsplit);
+    if (s2ag_gru_coop_split_pieces() == 2)
+        hipLaunchKernelGGL((gemm_sp_k<2, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((gemm_sp_k<3, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -405,6 +405,30 @@ def gemm_split_raw(a_planes: Tensor, w_planes: Tensor, bias: Optional[Tensor], y
     L.check(_lib().s2ag_gemm_split_fwd(_p(a_planes), _p(w_planes), _p(bias), _p(y), M, N, K, N, _stream()), 'gemm_split')
 
 
+# off by default: one GRU layer's three weight gradients take 197 us this way (6 transposed splits + 3 split-K GEMMs)
+# against 206 us for the single f32-MFMA wgrad_multi_k launch -- nine launches for nothing (tools/bench history)
+SPLIT_WGRAD = __import__('os').environ.get('S2AG_WGRAD_SPLIT', '0') != '0'
+
+
+def split_planes_t_raw(x: Tensor, shift: int = 0, L_: int = 1, colsum: Optional[Tensor] = None) -> Tensor:
+    """(rows, cols) fp32 -> (3, cols, Rp) bf16: the transposed split (contraction axis = rows), optionally frame-shifted
+    inside clips of ``L_`` frames; ``colsum`` += column sums of x (bias gradient)."""
+    x, rows, cols, ldx = as_rows(x)
+    Rp = _lib().s2ag_split_k_padded(rows)
+    planes = torch.empty(3, cols, Rp, dtype=torch.bfloat16, device=x.device)
+    L.check(_lib().s2ag_split_bf16x3_t(_p(x), rows, cols, ldx, int(shift), int(L_), _p(planes), _p(colsum), _stream()),
+            'split_bf16x3_t')
+    return planes
+
+
+def gemm_split_acc_raw(a_planes: Tensor, w_planes: Tensor, y: Tensor, K: int):
+    """y (M, N) += a w^T from transposed planes a (3, M, Kp), w (3, N, Kp)."""
+    _, M, Kp = a_planes.shape
+    N = w_planes.shape[1]
+    assert w_planes.shape[2] == Kp and y.is_contiguous() and y.numel() == M * N
+    L.check(_lib().s2ag_gemm_split_acc(_p(a_planes), _p(w_planes), _p(y), M, N, K, N, _stream()), 'gemm_split_acc')
+
+
 def tap_major(w: Tensor) -> Tensor:
     """Cached (Cout, k, Cin) copy of a reference-layout (Cout, Cin, k) conv weight, refreshed when the weight changes
     (optimizer step, load_state_dict) and, for trainable weights, at every step boundary (see begin_step).  Frozen
@@ -1095,6 +1119,17 @@ class _GRU(torch.autograd.Function):
             if all(sl is not None for sl in slots) and pair_ih is not None and pair_bi is not None:
                 # arena layout: the two directions are adjacent, so dW_ih / db_ih of both are one launch each
                 def leaves(dgi=dgi, dgh=dgh, y=y, inp=inp, In=In, pair_ih=pair_ih, pair_bi=pair_bi, slots=slots):
+                    if (SPLIT_WGRAD and SPLIT_GEMM and lib.s2ag_gru_coop_split_pieces() != 0
+                            and 2.0 * B * T * In * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
+                        # weight gradients on the bf16 pipe: transposed splits (contraction over clips * frames; the bias
+                        # gradients are the column sums of the same pass), split-K GEMMs accumulating into the arena
+                        gT = split_planes_t_raw(dgi, colsum=pair_bi.view(-1))
+                        gemm_split_acc_raw(gT, split_planes_t_raw(inp), pair_ih.view(-1, In), B * T)
+                        for d in range(2):
+                            ghT = split_planes_t_raw(dgh[d], colsum=slots[4 * d + 3])
+                            hT = split_planes_t_raw(y[:, d * H:(d + 1) * H], shift=-1 if d == 0 else 1, L_=T)
+                            gemm_split_acc_raw(ghT, hT, slots[4 * d + 1], B * T)
+                        return
                     if FUSE_WGRADS and conv_bwd_weight_multi_raw(
                             [(dgi, inp, pair_ih, pair_bi.view(-1), (B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1, 0))] +
                             [(dgh[d], y[:, d * H:(d + 1) * H], slots[4 * d + 1], slots[4 * d + 3],

@@ -536,6 +536,35 @@ def test_split_operand_gemm_accuracy(S, M, K, N):
         assert err < 2e-5, (err, err32)                          # three products: 16 mantissa bits
 
 
+@pytest.mark.parametrize('rows,L_,cn,ck,shift', [(4352, 34, 1800, 600, 0), (340, 34, 96, 40, -1), (340, 34, 96, 40, 1),
+                                                    (77, 7, 33, 20, 0)])
+def test_split_operand_weight_gradient(S, rows, L_, cn, ck, shift):
+    """dW += gy^T x (and db += column sums of gy) through transposed bf16-piece planes and the split-K GEMM; with a frame
+    shift inside the clips (the GRU's dW_hh pairs d(gh)_t with h_{t-1}); row counts that are not multiples of 32."""
+    ops = S['ops']
+    g = torch.Generator().manual_seed(rows + cn + ck + shift)
+    gy, x = torch.randn(rows, cn, generator=g), torch.randn(rows, ck, generator=g)
+    dw0, db0 = torch.randn(cn, ck, generator=g), torch.randn(cn, generator=g)
+    dw, db = dw0.cuda(), db0.cuda()
+    gT = ops.split_planes_t_raw(gy.cuda(), colsum=db)
+    xT = ops.split_planes_t_raw(x.cuda(), shift=shift, L_=L_)
+    assert gT.shape[1] == cn and gT.shape[2] % 32 == 0 and gT.shape[2] - rows < 32
+    assert float(gT.float().sum(0)[:, rows:].abs().max() if gT.shape[2] > rows else 0.0) == 0.0
+    ops.gemm_split_acc_raw(gT, xT, dw, rows)
+    xs = torch.zeros_like(x).view(-1, L_, ck)
+    xv = x.view(-1, L_, ck)
+    if shift == 0:
+        xs = xv.clone()
+    elif shift < 0:
+        xs[:, -shift:] = xv[:, :shift]           # row of frame t pairs with frame t + shift
+    else:
+        xs[:, :-shift] = xv[:, shift:]
+    ref = dw0.double() + gy.double().t() @ xs.reshape(rows, ck).double()
+    err = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < (3e-6 if ops._lib().s2ag_gru_coop_split_pieces() == 3 else 3e-5), err
+    assert rel(db, db0 + gy.sum(0)) < 1e-5
+
+
 def test_embedding_dropout_and_dense_gradient(S):
     ops, noise = S['ops'], S['noise']
     g = torch.Generator().manual_seed(12)
