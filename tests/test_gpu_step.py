@@ -159,6 +159,42 @@ def test_two_steps_with_dropout_match_the_oracle(monkeypatch):
     assert int(pr.s2ag_generator.state_dict()['aff_encoder.batch_norm1.num_batches_tracked']) == 6
 
 
+def test_validation_branch_matches_the_oracle(monkeypatch):
+    """per_val_epoch's call: forward_pass_s2ag(train=False) with G and D in eval mode (processor_v2.py:1010-1011) -- the
+    tri-modal baseline stays in train mode as upstream never switches it -- leaves every weight and running statistic of
+    G and D untouched and returns the metric / loss components of the oracle's train=False branch."""
+    from speech2affective_gestures_amd import noise
+    from speech2affective_gestures_amd import processor_v2 as P
+    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 5, 8300
+    pr, sds = make_processor(hidden, n_words, n_spk, B, s0, 0.3)
+    pr.s2ag_generator.eval()
+    pr.s2ag_discriminator.eval()
+    G, D, T3 = ({k: v.clone() for k, v in sds[n].items()} for n in ('G', 'D', 'T3'))
+    oc, scfg = oracle_cfg(hidden, 0.3), O.StepCfg()
+    noise.manual_seed(STEP_SEED)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3))
+    monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm.cuda())
+    inp = O.recipe_inputs(B, 34, s0 + 100, n_words, n_spk)
+    gi = to_cuda(inp)
+    nz = _materialise_step_noise(pr, 0, B, 34, hidden)
+    nz.perm = perm
+    before = {k: v.clone() for k, v in pr.s2ag_generator.state_dict().items()}
+    before_d = {k: v.clone() for k, v in pr.s2ag_discriminator.state_dict().items()}
+    with torch.no_grad():
+        ret = pr.forward_pass_s2ag(gi['in_text'], gi['in_audio'], gi['in_mfcc'], gi['target'], gi['vid'], False)
+    monkeypatch.undo()
+    metric, losses, grads = O.gan_step(G, D, T3, O.AdamState(), O.AdamState(), oc, scfg, inp['in_text'], inp['in_audio'],
+                                       inp['in_mfcc'], inp['target'], inp['vid'], epoch=1, noise=nz, train=False)
+    assert not grads
+    for k in ('dis', 'total', 'loss', 'KLD', 'DIV_REG', 'gen'):
+        assert pr.last_losses[k] == pytest.approx(losses[k], rel=TOL, abs=1e-6), k
+    assert ret[0] == pytest.approx(metric, rel=5e-3, abs=2e-6) and ret[1:] == (None,) * 6
+    for k, v in pr.s2ag_generator.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    for k, v in pr.s2ag_discriminator.state_dict().items():
+        assert torch.equal(v, before_d[k]), k
+
+
 @pytest.mark.parametrize('gan', [True, False])
 def test_hip_graph_replay_equals_eager(monkeypatch, gan):
     from speech2affective_gestures_amd import noise
