@@ -309,3 +309,33 @@ def test_prefetching_batch_feeder_matches_the_host_path():
         for h, f in zip(hb, fb):
             assert h.dtype == f.dtype and h.shape == f.shape and torch.equal(h, f)
     assert fed[0][2].dtype == torch.float32 and float(fed[0][2].abs().max()) <= 1.5 * 30000 / 32767 + 1e-6
+
+
+@pytest.mark.gpu
+def test_train_and_val_epoch_loops_over_a_host_dataset():
+    """per_train_epoch / per_val_epoch (processor_v2.py:959-1030) end to end on a small host-resident dataset: batches come
+    through yield_batch (feeder, device-side decode), the step is replayed from hipGraphs, weights move in training and
+    stay put in validation, the epoch statistics are finite."""
+    hidden, n_words, n_spk, B, n = 32, 64, 12, 8, 40
+    pr, _ = make_processor(hidden, n_words, n_spk, B, 8500, 0.3, hip_graph=True)
+    rs = np.random.RandomState(1)
+    text = np.zeros((n, 34), dtype=np.int64)
+    for i in range(n):
+        text[i, rs.permutation(34)[:4]] = rs.randint(4, n_words, 4)
+    samples = dict(extended_word_seq=text, vec_seq=rs.randn(n, 34, 27) * 0.2,
+                   audio=np.clip(rs.randn(n, 36267) * 0.05 * 32767, -32767, 32767).astype(np.int16),
+                   audio_max=np.ones(n), mfcc_features=(rs.randn(n, 37, 71) * 0.1).astype(np.float16),
+                   vid_indices=rs.randint(0, n_spk, n))
+    pr.train_samples = pr.val_samples = samples
+    pr.num_train_samples = pr.num_val_samples = n
+    pr.min_train_epochs = 0
+    w0 = pr.s2ag_generator.out[0].weight.detach().clone()
+    np.random.seed(0)
+    pr.per_train_epoch()
+    assert np.isfinite(pr.epoch_info['mean_s2ag_loss']) and pr.meta_info['iter'] == 5
+    w1 = pr.s2ag_generator.out[0].weight.detach().clone()
+    assert not torch.equal(w0, w1)
+    pr.per_val_epoch()
+    assert np.isfinite(pr.epoch_info['mean_s2ag_loss'])
+    assert torch.equal(pr.s2ag_generator.out[0].weight.detach(), w1)
+    assert not pr.s2ag_generator.training and not pr.s2ag_discriminator.training
