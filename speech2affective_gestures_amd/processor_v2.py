@@ -239,6 +239,35 @@ class Processor(object):
         return path
 
     # ------------------------------------------------------------------------------------------------
+    def load_cache(self, part, dir_name, load_full=True):
+        """processor_v2.py:222-271: the cached TED arrays of ``part`` ('train' / 'val' / 'test') in the reference's npz
+        layout -- ``<dir_name>/../full/<part>.npz`` with keys extended_word_seq (N, T) int64, vec_seq (N, T, pose_dim),
+        audio (N, L) int16, audio_max (N,), mfcc_features (N, num_mfcc, mfcc_length) [kept as float16], vid_indices (N,),
+        or one ``<dir_name>/<k:06d>.npz`` per clip when ``load_full`` is False.  (Writing the cache reads the LMDB
+        data set and is data preparation: not on this path.)"""
+        keys = ('extended_word_seq', 'vec_seq', 'audio', 'audio_max', 'mfcc_features', 'vid_indices')
+        if load_full:
+            with np.load(jn(dir_name, '../full', part + '.npz'), allow_pickle=True) as npz:
+                samples = {k: npz[k] for k in keys}
+        else:
+            num = getattr(self, {'train': 'num_train_samples', 'val': 'num_val_samples'}.get(part, 'num_test_samples'), 0)
+            rows = {k: [] for k in keys}
+            for i in range(num):
+                with np.load(jn(dir_name, str(i).zfill(self.zfill) + '.npz'), allow_pickle=True) as npz:
+                    for k in keys:
+                        rows[k].append(npz[k])
+            samples = {k: np.stack(v) for k, v in rows.items()}
+        samples['mfcc_features'] = samples['mfcc_features'].astype(np.float16)
+        n = int(samples['audio'].shape[0])
+        if part == 'train':
+            self.train_samples, self.num_train_samples = samples, n
+        elif part == 'val':
+            self.val_samples, self.num_val_samples = samples, n
+        else:
+            self.test_samples, self.num_test_samples = samples, n
+        self.__dict__.get('_feeders', {}).clear()         # feeders hold the previous arrays
+        return samples
+
     def yield_batch(self, train):
         """processor_v2.py:589-638: B indices drawn WITH replacement per pseudo pass; audio int16 * max / 32767;
         mfcc fp16 -> fp32; speaker ids drawn from the speakers NOT present in the batch (vectorised)."""

@@ -145,6 +145,34 @@ def test_yield_batch_semantics_on_host():
     assert vids.dtype == torch.int64 and 3 not in vids.tolist() and set(vids.tolist()) <= set(range(12))
 
 
+def test_load_cache_reads_the_reference_npz_layout(tmp_path):
+    """processor_v2.py:222-271: <dir>/../full/<part>.npz and the per-clip <k:06d>.npz variant; mfcc kept as float16."""
+    from speech2affective_gestures_amd import processor_v2 as P
+    rs = np.random.RandomState(2)
+    n = 5
+    full = dict(extended_word_seq=rs.randint(0, 9, (n, 34)).astype(np.int64), vec_seq=rs.randn(n, 34, 27),
+                audio=rs.randint(-3000, 3000, (n, 100)).astype(np.int16), audio_max=rs.rand(n) + 0.5,
+                mfcc_features=rs.randn(n, 37, 7), vid_indices=rs.randint(0, 4, n).astype(np.int64))
+    (tmp_path / 'full').mkdir()
+    (tmp_path / 'train').mkdir()
+    np.savez_compressed(tmp_path / 'full' / 'train.npz', **full)
+    for k in range(n):
+        np.savez_compressed(tmp_path / 'train' / ('%06d.npz' % k), **{key: v[k] for key, v in full.items()})
+    pr = object.__new__(P.Processor)
+    pr.zfill = 6
+    got = pr.load_cache('train', str(tmp_path / 'train'))
+    assert pr.num_train_samples == n and got is pr.train_samples
+    assert got['mfcc_features'].dtype == np.float16 and got['audio'].dtype == np.int16
+    for key in full:
+        np.testing.assert_allclose(got[key].astype(np.float64), full[key].astype(np.float64), atol=2e-3)
+    pr2 = object.__new__(P.Processor)
+    pr2.zfill, pr2.num_train_samples = 6, n
+    got2 = pr2.load_cache('train', str(tmp_path / 'train'), load_full=False)
+    for key in full:
+        assert got2[key].shape == full[key].shape
+        np.testing.assert_allclose(got2[key].astype(np.float64), full[key].astype(np.float64), atol=2e-3)
+
+
 def test_other_speaker_sampler_excludes_the_batch():
     """processor_v2.py:622-635: speaker ids for the generator are drawn from the speakers NOT present in the batch."""
     from speech2affective_gestures_amd.data import other_speakers
