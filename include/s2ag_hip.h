@@ -87,6 +87,13 @@ int s2ag_conv1d_nlc_bwd_weight(const float* gy, const float* x, float* dw,
  * output), six with S2AG_GRU_SPLIT=3 (as accurate as the f32-MFMA GEMM). */
 int s2ag_split_k_padded(int K);
 int s2ag_split_bf16x3(const float* x, int rows, int K, int ldx, void* planes, void* stream);
+/* Forward of a stride-1 conv with tap-major weights on the same pipe: the weight arrives as planes (s2ag_split_bf16x3 of
+ * the weight viewed as (Cout*ks, Cin)), the activations are split by the kernel's loader.  Epilogue and dropout-mask
+ * indexing as s2ag_conv1d_nlc_fwd.  replaces: the dilated causal convs of net/tcn.py:19,25 (and any other stride-1
+ * tap-major conv).  S2AG_E_UNSUPPORTED (nothing launched) outside stride 1 / Lin == Lout / Cin % 4 == 0. */
+int s2ag_conv1d_nlc_fwd_split(const float* x, const void* w_planes, const float* bias /*nullable*/, float* y,
+                              const s2ag_conv_geom* g /*host*/, const s2ag_epilogue* e /*host, nullable*/, void* stream);
+
 /* Weight gradients on the same pipe: dW (M, N) += gy^T x contracts over the rows, so both operands are split TRANSPOSED
  * (planes (3, cols, Rp), Rp = s2ag_split_k_padded(rows); `shift`: the operand row of frame t is frame t + shift of the same
  * clip of L frames, zero outside it -- dW_hh of nn.GRU pairs d(gh)_t with h_{t-1}; `colsum` (nullable, shift == 0): += the

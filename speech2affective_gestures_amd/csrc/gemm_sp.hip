@@ -268,6 +268,156 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-1 convolution forward with tap-major weights on the same pipe:
+//   y[(n,l), co] = epi( sum_{t,ci} x[(n, l - pad + t*dil), ci] * w[co, t, ci] + b[co] )
+// The weight planes are split ahead of time ((3, Cout*ks, Kp) with Kp = Cin rounded up to 32: every tap padded on its own);
+// the ACTIVATIONS are split on the fly by the loader (fp32 global -> registers -> bf16 pieces -> LDS): with two pieces that
+// is ~8 vector-ALU operations per element against a third of the matrix-pipe time of the f32 kernel, and -- unlike the f32
+// kernels, which read one k per ds_read_b32 -- a fragment read brings 8 k per lane, so the loop is no longer bound by LDS
+// instruction issue.  64 x 64 tile, 4 waves of 32 x 32, K tile = 32 channels of one tap.
+struct SpcP {
+    const float* x;
+    const unsigned short* w;            // [3][Cout*ks][Kp]
+    const float* bias;
+    float* y;
+    int M, L, Cin, Cout, ks, pad, dil, ldx, ldy, Kp;
+    int act;
+    float slope, drop_p, inv_keep;
+    const unsigned long long* rng;
+    unsigned site;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void conv_sp_k(const SpcP p) {
+    constexpr int SPT = 64;
+    constexpr int SP_PLANE = SPT * SP_PITCH;
+    __shared__ __attribute__((aligned(16))) unsigned short As[NP][SP_PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[NP][SP_PLANE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * SPT, n0 = blockIdx.y * SPT;
+    const size_t wplane = (size_t)p.Cout * p.ks * p.Kp;
+
+    const int lr = tid >> 2, lk = tid & 3;                 // row of the tile, 8-wide k chunk of the K tile
+    const int m = m0 + lr;
+    const bool a_row = m < p.M;
+    const int nclip = a_row ? m / p.L : 0;
+    const int l = a_row ? m - nclip * p.L : 0;
+    const float* a_clip = p.x + (long long)nclip * p.L * p.ldx;
+    const bool b_ok = n0 + lr < p.Cout;
+    const unsigned short* b_src = p.w + (size_t)(b_ok ? n0 + lr : 0) * p.ks * p.Kp + lk * 8;
+    const int l_off = lr * SP_PITCH + lk * 8;
+    const int kpt = p.Kp / SPK;                            // K tiles per tap
+
+    float4 xa0, xa1;                                       // the thread's 8 activations of the next K tile
+    u32x4 rb[NP];
+    auto fetch = [&](int kt) {
+        const int tap = kt / kpt, k0 = (kt - tap * kpt) * SPK + lk * 8;
+        const int pos = l - p.pad + tap * p.dil;
+        const bool ok = a_row && (unsigned)pos < (unsigned)p.L;
+        const float* src = a_clip + (long long)pos * p.ldx + k0;
+        xa0 = (ok && k0 < p.Cin) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xa1 = (ok && k0 + 4 < p.Cin) ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc)
+            rb[pc] = b_ok ? *reinterpret_cast<const u32x4*>(b_src + pc * wplane + (size_t)tap * p.Kp + (k0 - lk * 8))
+                          : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto stash = [&]() {
+        const float v[8] = {xa0.x, xa0.y, xa0.z, xa0.w, xa1.x, xa1.y, xa1.z, xa1.w};
+        u32x4 pa[NP];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned q[2][3];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float f = v[2 * d + e];
+                q[e][0] = bf16_rn(f);
+                const float r1 = f - __uint_as_float(q[e][0] << 16);
+                q[e][1] = bf16_rn(r1);
+                q[e][2] = NP == 3 ? bf16_rn(r1 - __uint_as_float(q[e][1] << 16)) : 0u;
+            }
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) pa[pc][d] = q[0][pc] | (q[1][pc] << 16);
+        }
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) {
+            *reinterpret_cast<u32x4*>(&As[pc][l_off]) = pa[pc];
+            *reinterpret_cast<u32x4*>(&Bs[pc][l_off]) = rb[pc];
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int f_off = (lane & 15) * SP_PITCH + (lane >> 4) * 8;
+    auto mma = [&]() {
+        bf16x8 a[2][NP], b[2][NP];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+                a[t][pc] = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const u32x4*>(&As[pc][(wr * 32 + t * 16) * SP_PITCH + f_off]));
+                b[t][pc] = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const u32x4*>(&Bs[pc][(wc * 32 + t * 16) * SP_PITCH + f_off]));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                f32x4 c = acc[ti][tj];
+                if constexpr (NP == 3) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][NP - 1], b[tj][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][NP - 1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][1], b[tj][1], c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][1], b[tj][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][0], c, 0, 0, 0);
+                acc[ti][tj] = c;
+            }
+    };
+
+    const int nkt = p.ks * kpt;
+    fetch(0);
+    stash();
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) fetch(kt + 1);
+        mma();
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            stash();
+            __syncthreads();
+        }
+    }
+    SiteKey key{0, 0};
+    const bool drop = p.drop_p > 0.f;
+    if (drop) key = site_key(p.rng, p.site);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int col = n0 + wc * 32 + tj * 16 + (lane & 15);
+            if (col >= p.Cout) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = m0 + wr * 32 + ti * 16 + (lane >> 4) * 4 + q;
+                if (row >= p.M) continue;
+                float v = apply_act(acc[ti][tj][q] + bv, p.act, p.slope);
+                if (drop) v *= keep_scale(key, (unsigned long long)row * p.Cout + col, p.drop_p, p.inv_keep);
+                p.y[(long long)row * p.ldy + col] = v;
+            }
+        }
+}
 }  // namespace
 
 extern "C" int s2ag_gru_coop_split_pieces(void);
@@ -341,6 +491,34 @@ extern "C" int s2ag_gemm_split_acc(const void* a_planes, const void* w_planes, f
         hipLaunchKernelGGL((gemm_sp_k<2, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL((gemm_sp_k<3, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* Forward of a stride-1 conv with tap-major weights (Cout, ks, Cin) from the weight's planes (3, Cout*ks, Kp), Kp =
+ * s2ag_split_k_padded(Cin) (= s2ag_split_bf16x3 of the weight viewed as (Cout*ks, Cin)): the activations are split by the
+ * loader.  Same epilogue as s2ag_conv1d_nlc_fwd (bias, activation, counter dropout with the same mask indexing).
+ * S2AG_E_UNSUPPORTED (nothing launched) unless stride == 1, Lin == Lout, Cin % 4 == 0, ldx % 4 == 0 and x 16-byte aligned. */
+extern "C" int s2ag_conv1d_nlc_fwd_split(const float* x, const void* w_planes, const float* bias, float* y,
+                                         const s2ag_conv_geom* g, const s2ag_epilogue* e, void* stream) {
+    if (!x || !w_planes || !y || !g || g->N <= 0 || g->Lin <= 0 || g->Cin <= 0 || g->Cout <= 0 || g->ksize <= 0)
+        return S2AG_E_BADARG;
+    if (e && e->drop_p > 0.f && !e->rng) return S2AG_E_BADARG;
+    if (g->stride != 1 || g->Lin != g->Lout || (g->Cin & 3) || (g->ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+        (reinterpret_cast<uintptr_t>(w_planes) & 15))
+        return S2AG_E_UNSUPPORTED;
+    SpcP p{};
+    p.x = x; p.w = static_cast<const unsigned short*>(w_planes); p.bias = bias; p.y = y;
+    p.M = g->N * g->Lout; p.L = g->Lin; p.Cin = g->Cin; p.Cout = g->Cout; p.ks = g->ksize; p.pad = g->pad; p.dil = g->dil;
+    p.ldx = g->ldx; p.ldy = g->ldy; p.Kp = s2ag_split_k_padded(g->Cin);
+    p.act = e ? e->act : S2AG_ACT_NONE; p.slope = e ? e->slope : 1.f; p.drop_p = e ? e->drop_p : 0.f;
+    p.inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+    p.rng = e ? e->rng : nullptr; p.site = e ? e->site : 0u;
+    const dim3 grid(cdiv(p.M, 64), cdiv(p.Cout, 64));
+    if (s2ag_gru_coop_split_pieces() == 2)
+        hipLaunchKernelGGL(conv_sp_k<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv_sp_k<3>, grid, dim3(256), 0, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -90,6 +90,17 @@ def conv_fwd_raw(x: Tensor, w: Tensor, bias: Optional[Tensor], y: Tensor, N, Lin
     g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy, wtm)
     e = _epi(act, slope, drop_p, noise, site)
     if stats_out is None:
+        if (SPLIT_CONV and wtm and ks > 1 and stride == 1 and Lin == Lout and Cin % 4 == 0
+                and 2.0 * N * Lout * Cout * Cin * ks >= SPLIT_CONV_MIN_FLOPS and _lib().s2ag_gru_coop_split_pieces() != 0):
+            # big stride-1 tap-major convs (the TCN): bf16-pipe kernel, weight planes cached on the (derived) weight tensor
+            wp = getattr(w, '_s2ag_wp', None)
+            if wp is None or wp[0] != w._version:
+                wp = (w._version, split_planes_raw(w.detach().view(Cout * ks, Cin)))
+                w._s2ag_wp = wp
+            rc = _lib().s2ag_conv1d_nlc_fwd_split(_p(x), _p(wp[1]), _p(bias), _p(y), C.byref(g), C.byref(e), _stream())
+            if rc != L.E_UNSUPPORTED:
+                L.check(rc, 'conv_fwd_split')
+                return None
         L.check(_lib().s2ag_conv1d_nlc_fwd(_p(x), _p(w), _p(bias), _p(y), C.byref(g), C.byref(e), _stream()), 'conv_fwd')
         return None
     # the layer feeds a training-mode BatchNorm: let the kernel leave per-row-block column sums behind
@@ -373,6 +384,10 @@ class _ConvNLC(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, None
 
 
+# off by default: at the TCN's shape (M = 4 352, 300 -> 300, 2 taps) the split kernel takes 27 us, the f32 straight-line
+# kernel 27 us -- 340 blocks of 4 waves with two barriers per K tile are latency bound, not pipe bound
+SPLIT_CONV = __import__('os').environ.get('S2AG_CONV_SPLIT', '0') != '0'
+SPLIT_CONV_MIN_FLOPS = float(__import__('os').environ.get('S2AG_CONV_SPLIT_MIN_FLOPS', '1e9'))
 SPLIT_GEMM = __import__('os').environ.get('S2AG_GEMM_SPLIT', '1') != '0'
 SPLIT_GEMM_DX = __import__('os').environ.get('S2AG_DX_SPLIT', '1') != '0'
 SPLIT_GEMM_MIN_FLOPS = float(__import__('os').environ.get('S2AG_GEMM_SPLIT_MIN_FLOPS', '4e9'))
