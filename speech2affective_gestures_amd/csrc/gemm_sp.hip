@@ -276,7 +276,10 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
 // the ACTIVATIONS are split on the fly by the loader (fp32 global -> registers -> bf16 pieces -> LDS): with two pieces that
 // is ~8 vector-ALU operations per element against a third of the matrix-pipe time of the f32 kernel, and -- unlike the f32
 // kernels, which read one k per ds_read_b32 -- a fragment read brings 8 k per lane, so the loop is no longer bound by LDS
-// instruction issue.  64 x 64 tile, 4 waves of 32 x 32, K tile = 32 channels of one tap.
+// instruction issue.  32 x 64 tile (64 x 64 once that still gives >= 1 024 blocks), 4 waves, K tile = 32 channels of one
+// tap, double-buffered LDS (one barrier per K tile), three K tiles in flight in registers.  At the TCN's shape (M = 4 352,
+// 300 -> 300, 2 taps): 21.6 us against 27.5 us for the f32 straight-line kernel (the first version -- 64 x 64, single
+// buffer, one tile in flight -- took 27 us: the block's dependent chain, not the matrix pipe, set the time).
 struct SpcP {
     const float* x;
     const unsigned short* w;            // [3][Cout*ks][Kp]
@@ -289,52 +292,61 @@ struct SpcP {
     unsigned site;
 };
 
-template <int NP>
+template <int NP, int BM>      // BM: tile rows, 64 (4 waves of 32 x 32) or 32 (4 waves of 16 x 32: twice the blocks)
 __global__ __launch_bounds__(256) void conv_sp_k(const SpcP p) {
-    constexpr int SPT = 64;
-    constexpr int SP_PLANE = SPT * SP_PITCH;
-    __shared__ __attribute__((aligned(16))) unsigned short As[NP][SP_PLANE];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[NP][SP_PLANE];
+    constexpr int TM = BM / 32;                            // 16-row MFMA tiles per wave along M
+    constexpr int AF = BM / 8;                             // activations per thread and K tile (8 or 4)
+    constexpr int A_PLANE = BM * SP_PITCH, B_PLANE = 64 * SP_PITCH;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][NP][A_PLANE];       // double buffered: one barrier per K tile
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][NP][B_PLANE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * SPT, n0 = blockIdx.y * SPT;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * 64;
     const size_t wplane = (size_t)p.Cout * p.ks * p.Kp;
 
-    const int lr = tid >> 2, lk = tid & 3;                 // row of the tile, 8-wide k chunk of the K tile
-    const int m = m0 + lr;
+    // A loader: row ar, AF consecutive channels starting at ak of the K tile;  B loader: column br, 8-wide k chunk bk
+    const int ar = tid / (32 / AF), ak = (tid % (32 / AF)) * AF;
+    const int m = m0 + ar;
     const bool a_row = m < p.M;
     const int nclip = a_row ? m / p.L : 0;
     const int l = a_row ? m - nclip * p.L : 0;
     const float* a_clip = p.x + (long long)nclip * p.L * p.ldx;
-    const bool b_ok = n0 + lr < p.Cout;
-    const unsigned short* b_src = p.w + (size_t)(b_ok ? n0 + lr : 0) * p.ks * p.Kp + lk * 8;
-    const int l_off = lr * SP_PITCH + lk * 8;
+    const int br = tid >> 2, bk = (tid & 3) * 8;
+    const bool b_ok = n0 + br < p.Cout;
+    const unsigned short* b_src = p.w + (size_t)(b_ok ? n0 + br : 0) * p.ks * p.Kp + bk;
+    const int a_off = ar * SP_PITCH + ak, b_off = br * SP_PITCH + bk;
     const int kpt = p.Kp / SPK;                            // K tiles per tap
 
-    float4 xa0, xa1;                                       // the thread's 8 activations of the next K tile
-    u32x4 rb[NP];
-    auto fetch = [&](int kt) {
-        const int tap = kt / kpt, k0 = (kt - tap * kpt) * SPK + lk * 8;
+    constexpr int PD = 3;                                  // K tiles in flight in registers: a tile's operands are
+                                                           // requested three tiles before they are needed (a global round
+                                                           // trip is ~1 us, a K tile of MFMAs ~0.2 us)
+    float4 xq[PD][AF / 4];
+    u32x4 rbq[PD][NP];
+    auto fetch_to = [&](int kt, int set) {
+        const int tap = kt / kpt, kb = (kt - tap * kpt) * SPK;
         const int pos = l - p.pad + tap * p.dil;
         const bool ok = a_row && (unsigned)pos < (unsigned)p.L;
-        const float* src = a_clip + (long long)pos * p.ldx + k0;
-        xa0 = (ok && k0 < p.Cin) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-        xa1 = (ok && k0 + 4 < p.Cin) ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* src = a_clip + (long long)pos * p.ldx + kb + ak;
+#pragma unroll
+        for (int h = 0; h < AF / 4; ++h)
+            xq[set][h] = (ok && kb + ak + 4 * h < p.Cin) ? *reinterpret_cast<const float4*>(src + 4 * h)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc)
-            rb[pc] = b_ok ? *reinterpret_cast<const u32x4*>(b_src + pc * wplane + (size_t)tap * p.Kp + (k0 - lk * 8))
-                          : u32x4{0u, 0u, 0u, 0u};
+            rbq[set][pc] = b_ok ? *reinterpret_cast<const u32x4*>(b_src + pc * wplane + (size_t)tap * p.Kp + kb)
+                                : u32x4{0u, 0u, 0u, 0u};
     };
-    auto stash = [&]() {
-        const float v[8] = {xa0.x, xa0.y, xa0.z, xa0.w, xa1.x, xa1.y, xa1.z, xa1.w};
-        u32x4 pa[NP];
+    auto stash_from = [&](int set, int buf) {
+        unsigned pa[NP][AF / 2];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < AF / 2; ++d) {
             unsigned q[2][3];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const float f = v[2 * d + e];
+                const float4 x4 = xq[set][(2 * d + e) / 4];
+                const int c = (2 * d + e) & 3;
+                const float f = c == 0 ? x4.x : c == 1 ? x4.y : c == 2 ? x4.z : x4.w;
                 q[e][0] = bf16_rn(f);
                 const float r1 = f - __uint_as_float(q[e][0] << 16);
                 q[e][1] = bf16_rn(r1);
@@ -345,31 +357,36 @@ __global__ __launch_bounds__(256) void conv_sp_k(const SpcP p) {
         }
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc) {
-            *reinterpret_cast<u32x4*>(&As[pc][l_off]) = pa[pc];
-            *reinterpret_cast<u32x4*>(&Bs[pc][l_off]) = rb[pc];
+            if constexpr (AF == 8)
+                *reinterpret_cast<u32x4*>(&As[buf][pc][a_off]) = u32x4{pa[pc][0], pa[pc][1], pa[pc][2], pa[pc][3]};
+            else
+                *reinterpret_cast<uint2*>(&As[buf][pc][a_off]) = make_uint2(pa[pc][0], pa[pc][1]);
+            *reinterpret_cast<u32x4*>(&Bs[buf][pc][b_off]) = rbq[set][pc];
         }
     };
 
-    f32x4 acc[2][2];
+    f32x4 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int f_off = (lane & 15) * SP_PITCH + (lane >> 4) * 8;
-    auto mma = [&]() {
-        bf16x8 a[2][NP], b[2][NP];
+    auto mma = [&](int buf) {
+        bf16x8 a[TM][NP], b[2][NP];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int pc = 0; pc < NP; ++pc) {
 #pragma unroll
-            for (int pc = 0; pc < NP; ++pc) {
+            for (int t = 0; t < TM; ++t)
                 a[t][pc] = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const u32x4*>(&As[pc][(wr * 32 + t * 16) * SP_PITCH + f_off]));
+                    bf16x8, *reinterpret_cast<const u32x4*>(&As[buf][pc][(wr * (BM / 2) + t * 16) * SP_PITCH + f_off]));
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
                 b[t][pc] = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const u32x4*>(&Bs[pc][(wc * 32 + t * 16) * SP_PITCH + f_off]));
-            }
+                    bf16x8, *reinterpret_cast<const u32x4*>(&Bs[buf][pc][(wc * 32 + t * 16) * SP_PITCH + f_off]));
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj) {
                 f32x4 c = acc[ti][tj];
@@ -386,15 +403,19 @@ __global__ __launch_bounds__(256) void conv_sp_k(const SpcP p) {
     };
 
     const int nkt = p.ks * kpt;
-    fetch(0);
-    stash();
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+        if (d < nkt) fetch_to(d, d);
+    stash_from(0, 0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) fetch(kt + 1);
-        mma();
-        __syncthreads();
-        if (kt + 1 < nkt) {
-            stash();
+    for (int base = 0; base < nkt; base += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int kt = base + d;
+            if (kt >= nkt) break;
+            mma(kt & 1);
+            if (kt + 1 < nkt) stash_from((d + 1) % PD, (kt + 1) & 1);
+            if (kt + PD < nkt) fetch_to(kt + PD, d);
             __syncthreads();
         }
     }
@@ -402,7 +423,7 @@ __global__ __launch_bounds__(256) void conv_sp_k(const SpcP p) {
     const bool drop = p.drop_p > 0.f;
     if (drop) key = site_key(p.rng, p.site);
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
             const int col = n0 + wc * 32 + tj * 16 + (lane & 15);
@@ -410,7 +431,7 @@ __global__ __launch_bounds__(256) void conv_sp_k(const SpcP p) {
             const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int row = m0 + wr * 32 + ti * 16 + (lane >> 4) * 4 + q;
+                const int row = m0 + wr * (BM / 2) + ti * 16 + (lane >> 4) * 4 + q;
                 if (row >= p.M) continue;
                 float v = apply_act(acc[ti][tj][q] + bv, p.act, p.slope);
                 if (drop) v *= keep_scale(key, (unsigned long long)row * p.Cout + col, p.drop_p, p.inv_keep);
@@ -514,11 +535,17 @@ extern "C" int s2ag_conv1d_nlc_fwd_split(const float* x, const void* w_planes, c
     p.act = e ? e->act : S2AG_ACT_NONE; p.slope = e ? e->slope : 1.f; p.drop_p = e ? e->drop_p : 0.f;
     p.inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
     p.rng = e ? e->rng : nullptr; p.site = e ? e->site : 0u;
-    const dim3 grid(cdiv(p.M, 64), cdiv(p.Cout, 64));
-    if (s2ag_gru_coop_split_pieces() == 2)
-        hipLaunchKernelGGL(conv_sp_k<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(conv_sp_k<3>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    static const int bm_env = [] { const char* e = getenv("S2AG_CONV_SPLIT_BM"); return e ? atoi(e) : 0; }();
+    const bool bm64 = bm_env ? bm_env == 64 : (long long)cdiv(p.M, 64) * cdiv(p.Cout, 64) >= 1024;
+    const dim3 grid(cdiv(p.M, bm64 ? 64 : 32), cdiv(p.Cout, 64));
+    const bool two = s2ag_gru_coop_split_pieces() == 2;
+    if (bm64) {
+        if (two) hipLaunchKernelGGL((conv_sp_k<2, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv_sp_k<3, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (two) hipLaunchKernelGGL((conv_sp_k<2, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv_sp_k<3, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -111,9 +111,9 @@ TM_CASES = [
 @pytest.mark.parametrize('case', TM_CASES)
 def test_tap_major_conv_straight_line_kernels(S, case, split, monkeypatch):
     ops = S['ops']
-    if split:        # the bf16-pipe forward kernel (conv_sp_k: activations split by the loader), off by default
-        monkeypatch.setattr(ops, 'SPLIT_CONV', True)
-        monkeypatch.setattr(ops, 'SPLIT_CONV_MIN_FLOPS', 0.0)
+    # split: the bf16-pipe forward kernel (conv_sp_k: activations split by the loader) at every size; else the f32 kernels
+    monkeypatch.setattr(ops, 'SPLIT_CONV', bool(split))
+    monkeypatch.setattr(ops, 'SPLIT_CONV_MIN_FLOPS', 0.0)
     N, Ln, Cin, Cout, k, pad, dil, causal = case
     g = torch.Generator().manual_seed(sum(case[:7]))
     x = torch.randn(N, Ln, Cin, generator=g)
