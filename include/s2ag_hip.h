@@ -92,7 +92,9 @@ int s2ag_split_bf16x3(const float* x, int rows, int K, int ldx, void* planes, vo
  * indexing as s2ag_conv1d_nlc_fwd.  replaces: the dilated causal convs of net/tcn.py:19,25 (and any other stride-1
  * tap-major conv).  S2AG_E_UNSUPPORTED (nothing launched) outside stride 1 / Lin == Lout / Cin % 4 == 0. */
 int s2ag_conv1d_nlc_fwd_split(const float* x, const void* w_planes, const float* bias /*nullable*/, float* y,
-                              const s2ag_conv_geom* g /*host*/, const s2ag_epilogue* e /*host, nullable*/, void* stream);
+                              const s2ag_conv_geom* g /*host*/, const s2ag_epilogue* e /*host, nullable*/,
+                              double* partials /*nullable: BatchNorm column-sum partials, sized by s2ag_conv_stats_rows*/,
+                              int* stat_rows /*host; nullable together with partials*/, void* stream);
 
 /* Weight gradients on the same pipe: dW (M, N) += gy^T x contracts over the rows, so both operands are split TRANSPOSED
  * (planes (3, cols, Rp), Rp = s2ag_split_k_padded(rows); `shift`: the operand row of frame t is frame t + shift of the same

@@ -76,7 +76,7 @@ SIGNATURES = {
     's2ag_split_k_padded': [ci],
     's2ag_split_bf16x3': [vp, ci, ci, ci, vp, vp],
     's2ag_gemm_split_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, vp],
-    's2ag_conv1d_nlc_fwd_split': [vp, vp, vp, vp, PG, PE, vp],
+    's2ag_conv1d_nlc_fwd_split': [vp, vp, vp, vp, PG, PE, vp, vp, vp],
     's2ag_split_bf16x3_t': [vp, ci, ci, ci, ci, ci, vp, vp, vp],
     's2ag_gemm_split_acc': [vp, vp, vp, ci, ci, ci, ci, vp],
     's2ag_audio_decode': [vp, vp, vp, ci, ci, vp],

@@ -290,6 +290,7 @@ struct SpcP {
     float slope, drop_p, inv_keep;
     const unsigned long long* rng;
     unsigned site;
+    double* stats;                      // nullable: (2, R, Cout) per-wave column sums of y and y^2, R = gridDim.x * 2
 };
 
 template <int NP, int BM>      // BM: tile rows, 64 (4 waves of 32 x 32) or 32 (4 waves of 16 x 32: twice the blocks)
@@ -436,8 +437,38 @@ __global__ __launch_bounds__(256) void conv_sp_k(const SpcP p) {
                 float v = apply_act(acc[ti][tj][q] + bv, p.act, p.slope);
                 if (drop) v *= keep_scale(key, (unsigned long long)row * p.Cout + col, p.drop_p, p.inv_keep);
                 p.y[(long long)row * p.ldy + col] = v;
+                acc[ti][tj][q] = v;                        // what the statistics are taken of
             }
         }
+    if (p.stats) {
+        // fp64 column sums of this wave's rows for the BatchNorm behind the layer (as gemm_lin_k's epilogue): one partial row
+        // per (row block, row wave); lanes that share a column (lane >> 4) meet in two shuffles
+        const size_t R = (size_t)gridDim.x * 2, r = (size_t)blockIdx.x * 2 + wr;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = m0 + wr * (BM / 2) + ti * 16 + (lane >> 4) * 4 + q;
+                    if (row < p.M) {
+                        const double v = (double)acc[ti][tj][q];
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                }
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const int col = n0 + wc * 32 + tj * 16 + (lane & 15);
+            if (lane < 16 && col < p.Cout) {
+                p.stats[r * p.Cout + col] = s1;
+                p.stats[(R + r) * p.Cout + col] = s2;
+            }
+        }
+    }
 }
 }  // namespace
 
@@ -518,10 +549,14 @@ extern "C" int s2ag_gemm_split_acc(const void* a_planes, const void* w_planes, f
 
 /* Forward of a stride-1 conv with tap-major weights (Cout, ks, Cin) from the weight's planes (3, Cout*ks, Kp), Kp =
  * s2ag_split_k_padded(Cin) (= s2ag_split_bf16x3 of the weight viewed as (Cout*ks, Cin)): the activations are split by the
- * loader.  Same epilogue as s2ag_conv1d_nlc_fwd (bias, activation, counter dropout with the same mask indexing).
+ * loader.  Same epilogue as s2ag_conv1d_nlc_fwd (bias, activation, counter dropout with the same mask indexing);
+ * partials / stat_rows (both or neither): BatchNorm column-sum partials as s2ag_conv1d_nlc_fwd_stats (same sizing).
  * S2AG_E_UNSUPPORTED (nothing launched) unless stride == 1, Lin == Lout, Cin % 4 == 0, ldx % 4 == 0 and x 16-byte aligned. */
 extern "C" int s2ag_conv1d_nlc_fwd_split(const float* x, const void* w_planes, const float* bias, float* y,
-                                         const s2ag_conv_geom* g, const s2ag_epilogue* e, void* stream) {
+                                         const s2ag_conv_geom* g, const s2ag_epilogue* e, double* partials,
+                                         int* stat_rows, void* stream) {
+    if (stat_rows) *stat_rows = 0;
+    if ((partials == nullptr) != (stat_rows == nullptr)) return S2AG_E_BADARG;
     if (!x || !w_planes || !y || !g || g->N <= 0 || g->Lin <= 0 || g->Cin <= 0 || g->Cout <= 0 || g->ksize <= 0)
         return S2AG_E_BADARG;
     if (e && e->drop_p > 0.f && !e->rng) return S2AG_E_BADARG;
@@ -535,6 +570,7 @@ extern "C" int s2ag_conv1d_nlc_fwd_split(const float* x, const void* w_planes, c
     p.act = e ? e->act : S2AG_ACT_NONE; p.slope = e ? e->slope : 1.f; p.drop_p = e ? e->drop_p : 0.f;
     p.inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
     p.rng = e ? e->rng : nullptr; p.site = e ? e->site : 0u;
+    p.stats = partials;
     static const int bm_env = [] { const char* e = getenv("S2AG_CONV_SPLIT_BM"); return e ? atoi(e) : 0; }();
     const bool bm64 = bm_env ? bm_env == 64 : (long long)cdiv(p.M, 64) * cdiv(p.Cout, 64) >= 1024;
     const dim3 grid(cdiv(p.M, bm64 ? 64 : 32), cdiv(p.Cout, 64));
@@ -546,6 +582,7 @@ extern "C" int s2ag_conv1d_nlc_fwd_split(const float* x, const void* w_planes, c
         if (two) hipLaunchKernelGGL((conv_sp_k<2, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((conv_sp_k<3, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
+    if (stat_rows) *stat_rows = (int)grid.x * 2;
     S2AG_LAUNCH_CHECK();
     return 0;
 }

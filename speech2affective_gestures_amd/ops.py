@@ -89,25 +89,36 @@ def conv_fwd_raw(x: Tensor, w: Tensor, bias: Optional[Tensor], y: Tensor, N, Lin
     assert w.is_contiguous() and w.numel() == Cout * Cin * ks
     g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy, wtm)
     e = _epi(act, slope, drop_p, noise, site)
+    lib = _lib()
+    split = (SPLIT_CONV and wtm and ks > 1 and stride == 1 and Lin == Lout and Cin % 4 == 0
+             and 2.0 * N * Lout * Cout * Cin * ks >= SPLIT_CONV_MIN_FLOPS and lib.s2ag_gru_coop_split_pieces() != 0)
+    wp = None
+    if split:
+        # big stride-1 tap-major convs (the TCN, the folded ST-GCN convs): bf16-pipe kernel, weight planes cached on the
+        # (derived) weight tensor
+        wp = getattr(w, '_s2ag_wp', None)
+        if wp is None or wp[0] != w._version:
+            wp = (w._version, split_planes_raw(w.detach().view(Cout * ks, Cin)))
+            w._s2ag_wp = wp
     if stats_out is None:
-        if (SPLIT_CONV and wtm and ks > 1 and stride == 1 and Lin == Lout and Cin % 4 == 0
-                and 2.0 * N * Lout * Cout * Cin * ks >= SPLIT_CONV_MIN_FLOPS and _lib().s2ag_gru_coop_split_pieces() != 0):
-            # big stride-1 tap-major convs (the TCN): bf16-pipe kernel, weight planes cached on the (derived) weight tensor
-            wp = getattr(w, '_s2ag_wp', None)
-            if wp is None or wp[0] != w._version:
-                wp = (w._version, split_planes_raw(w.detach().view(Cout * ks, Cin)))
-                w._s2ag_wp = wp
-            rc = _lib().s2ag_conv1d_nlc_fwd_split(_p(x), _p(wp[1]), _p(bias), _p(y), C.byref(g), C.byref(e), _stream())
+        if split:
+            rc = lib.s2ag_conv1d_nlc_fwd_split(_p(x), _p(wp[1]), _p(bias), _p(y), C.byref(g), C.byref(e), None, None,
+                                               _stream())
             if rc != L.E_UNSUPPORTED:
                 L.check(rc, 'conv_fwd_split')
                 return None
-        L.check(_lib().s2ag_conv1d_nlc_fwd(_p(x), _p(w), _p(bias), _p(y), C.byref(g), C.byref(e), _stream()), 'conv_fwd')
+        L.check(lib.s2ag_conv1d_nlc_fwd(_p(x), _p(w), _p(bias), _p(y), C.byref(g), C.byref(e), _stream()), 'conv_fwd')
         return None
     # the layer feeds a training-mode BatchNorm: let the kernel leave per-row-block column sums behind
-    lib = _lib()
     rows = lib.s2ag_conv_stats_rows(C.byref(g))
     part = torch.empty(2 * rows * Cout, dtype=torch.float64, device=y.device)
     got = C.c_int(0)
+    if split:
+        rc = lib.s2ag_conv1d_nlc_fwd_split(_p(x), _p(wp[1]), _p(bias), _p(y), C.byref(g), C.byref(e), _p(part),
+                                           C.byref(got), _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, 'conv_fwd_split')
+            return (part[:2 * got.value * Cout], got.value) if got.value > 0 else None
     L.check(lib.s2ag_conv1d_nlc_fwd_stats(_p(x), _p(w), _p(bias), _p(y), C.byref(g), C.byref(e), _p(part),
                                           C.byref(got), _stream()), 'conv_fwd_stats')
     return (part[:2 * got.value * Cout], got.value) if got.value > 0 else None
