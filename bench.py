@@ -6,8 +6,12 @@
 
 One step = Processor.train_step: 3 generator + 3 discriminator + 1 tri-modal forward, 2 backward, 2 Adam
 (processor_v2.py:776-957 of the reference), on configs[1] of BASELINE.json: batch 128 per GPU, T = 34,
-n_words 20000, 1371 speakers, synthetic TED-shaped inputs resident in HBM.  Arithmetic is fp32
-end to end (fp32 MFMA / FMA), i.e. at least the precision BASELINE names.  N > 1: one process per GPU, weak
+n_words 20000, 1371 speakers, synthetic TED-shaped inputs resident in HBM.  Storage, accumulation and
+all element-wise arithmetic are fp32; the large matrix products (GRU recurrence and its input projections / input
+gradients, the big convs' forward) multiply fp32 operands as bf16 pieces on the bf16 matrix pipe with fp32 accumulation:
+2 pieces (16 mantissa bits per product, error vs fp64 ~1.5e-6) by default, 3 pieces (fp32-equivalent) with
+S2AG_GRU_SPLIT=3, the f32 MFMA with S2AG_GRU_SPLIT=0 -- in every mode well above the bf16 BASELINE names, and inside
+the 1e-3 parity bar by > 2 orders of magnitude (the line's config.matrix_products says which mode ran).  N > 1: one process per GPU, weak
 scaling, RCCL all-reduce of the flat gradient arenas.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
@@ -75,6 +79,18 @@ def build_processor(B, hip_graph):
     for m in (pr.s2ag_generator, pr.s2ag_discriminator, pr.trimodal_generator):
         m.train()
     return pr
+
+
+def matrix_products_mode():
+    """How the large matrix products are formed in this run (see the module docstring)."""
+    from speech2affective_gestures_amd import _lib as L
+    np_ = int(L.load().s2ag_gru_coop_split_pieces())
+    return {0: 'f32 MFMA (v_mfma_f32_16x16x4_f32) everywhere',
+            2: 'fp32 operands as 2 bf16 pieces (3 products, 16 mantissa bits, fp32 accumulation) on the bf16 matrix pipe for '
+               'the GRU recurrence, its input projections / input gradients and the big convs forward; f32 MFMA elsewhere',
+            3: 'fp32 operands as 3 bf16 pieces (6 products, fp32-equivalent, fp32 accumulation) on the bf16 matrix pipe for '
+               'the GRU recurrence, its input projections / input gradients and the big convs forward; f32 MFMA elsewhere'
+            }[np_]
 
 
 def gru_roofline(B, iters=20):
@@ -303,6 +319,7 @@ def main():
                                    '2 Adam), 34-frame TED-shaped clips', 'batch_per_gpu': a.batch,
                        'global_batch': a.batch * dp.world_size, 'frames': T, 'n_words': N_WORDS, 'n_speakers': N_SPK,
                        'parallelism': f'dp{dp.world_size}', 'hip_graph': not a.no_graph,
+                       'matrix_products': matrix_products_mode(),
                        'last_step_losses': pr.last_losses if metric is not None else None},
         }
         line['roofline'] = gru_roofline(a.batch)
