@@ -90,7 +90,7 @@ def conv_fwd_raw(x: Tensor, w: Tensor, bias: Optional[Tensor], y: Tensor, N, Lin
     g = _geom(N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, ldx, ldy, wtm)
     e = _epi(act, slope, drop_p, noise, site)
     lib = _lib()
-    split = (SPLIT_CONV and wtm and ks > 1 and stride == 1 and Lin == Lout and Cin % 4 == 0
+    split = (SPLIT_CONV and (wtm or ks == 1) and (ks > 1 or SPLIT_LINEAR) and stride == 1 and Lin == Lout and Cin % 4 == 0
              and 2.0 * N * Lout * Cout * Cin * ks >= SPLIT_CONV_MIN_FLOPS and lib.s2ag_gru_coop_split_pieces() != 0)
     wp = None
     if split:
@@ -398,6 +398,7 @@ class _ConvNLC(torch.autograd.Function):
 # big stride-1 tap-major convs without a BatchNorm behind them (the TCN): 21.6 us against 27.5 us for the f32 straight-line
 # kernel at M = 4 352, 300 -> 300, 2 taps; +2.1 % on the step
 SPLIT_CONV = __import__('os').environ.get('S2AG_CONV_SPLIT', '1') != '0'
+SPLIT_LINEAR = __import__('os').environ.get('S2AG_LINEAR_SPLIT', '1') != '0'   # 1-tap layers >= 1 GFLOP (GRU layer-0 projections): 22 vs 33 us
 SPLIT_CONV_MIN_FLOPS = float(__import__('os').environ.get('S2AG_CONV_SPLIT_MIN_FLOPS', '1e9'))
 SPLIT_GEMM = __import__('os').environ.get('S2AG_GEMM_SPLIT', '1') != '0'
 SPLIT_GEMM_DX = __import__('os').environ.get('S2AG_DX_SPLIT', '1') != '0'
