@@ -4,8 +4,10 @@ The reference draws B clip indices with replacement, fancy-indexes five numpy ar
 the host (``int16 * audio_max / 32767``), converts to float32 and copies each tensor synchronously -- ~10 ms of host
 work and 20 MB of PCIe per batch of 128, i.e. as long as a whole training step takes on the MI355X.  Here
 
-* a background thread draws the indices (same ``np.random`` calls in the same order as the reference: batch keys, then
-  the "other speaker" ids), gathers the RAW rows (int16 audio, float64 peaks / poses, float16 MFCCs, int64 words)
+* a background thread draws the indices (the reference's ``np.random`` stream: batch keys through
+  ``choice(n, B, True, p=uniform)``, then the "other speaker" ids -- one vectorised draw that consumes the stream exactly
+  as the reference's B scalar draws do; pinned by tests/golden/batch_small.npz, recorded from the reference's own
+  ``yield_batch``), gathers the RAW rows (int16 audio, float64 peaks / poses, float16 MFCCs, int64 words)
   straight into pinned staging buffers (``np.take(..., out=pinned)``),
 * copies them on its own HIP stream and decodes on the device (``s2ag_audio_decode`` / ``s2ag_to_f32``: the reference's
   float64 arithmetic, bit-identical results, half the PCIe bytes for the audio),
@@ -22,6 +24,30 @@ import torch
 from . import _lib as L
 
 _FIELDS = ('extended_word_seq', 'vec_seq', 'audio', 'audio_max', 'mfcc_features')
+
+
+def draw_keys(num_data: int, size: int) -> np.ndarray:
+    """The clip indices of one batch, drawn exactly as the reference does (processor_v2.py:598-601): WITH replacement and
+    with an explicit uniform ``p`` -- passing ``p`` makes numpy take its cdf / searchsorted path (one uniform double per
+    index), a different consumption of the RandomState stream than the ``p=None`` integer path, so under the same
+    ``np.random.seed`` only this call reproduces the reference's batches."""
+    prob_dist = np.ones(num_data) / float(num_data)
+    return np.random.choice(num_data, size=size, replace=True, p=prob_dist)
+
+
+def host_batch(samples, num_data: int, size: int, speaker_model=None):
+    """One batch on the host, decoded with the reference's arithmetic (float64 ``int16 * max / 32767``, then float32):
+    numpy arrays (text i64, vec f32, audio f32, mfcc f32, vids i64 | None).  The reference-shaped path of
+    ``Processor.yield_batch`` (prefetch off) and the checker of the feeder's device-side decode."""
+    keys = draw_keys(num_data, size)
+    text = samples['extended_word_seq'][keys]
+    vec = samples['vec_seq'][keys].astype(np.float32)
+    audio = (samples['audio'][keys] * samples['audio_max'][keys, None] / 32767).astype(np.float32)
+    mfcc = samples['mfcc_features'][keys].astype(np.float32)
+    vids = None
+    if speaker_model is not None and speaker_model.__class__.__name__ == 'Vocab':
+        vids = other_speakers(speaker_model, samples['vid_indices'][keys], size).astype(np.int64)
+    return text, vec, audio, mfcc, vids
 
 
 def other_speakers(speaker_model, present: np.ndarray, size: int):
@@ -67,7 +93,7 @@ class BatchFeeder:
     # ------------------------------------------------------------------------------------------------
     def _stage(self, slot):
         """Host part of one batch (runs on the feeder thread): index draw + row gather into pinned memory."""
-        keys = np.random.choice(self.num_data, size=self.B, replace=True)
+        keys = draw_keys(self.num_data, self.B)
         for k in _FIELDS:
             np.take(self.src[k], keys, axis=0, out=slot[k][1], mode='clip')
         has_vids = self.spk is not None

@@ -14,12 +14,12 @@ Rendering, FGD evaluation and the LMDB/npz data pipeline of the reference are ou
 """
 import math
 import os
+import re
 import time
 from os.path import join as jn
 
 import numpy as np
 import torch
-import torch.nn.functional as F  # noqa: F401  (kept for API familiarity; no functional op is used on the path)
 
 from . import noise, ops
 from .net.multimodal_context_net_v2 import (AffDiscriminator, ConvDiscriminatorTriModal as CDT, PoseGenerator,
@@ -29,13 +29,8 @@ from .parallel import DataParallelContext
 
 
 def find_all_substr(a_str, sub):
-    start = 0
-    while True:
-        start = a_str.find(sub, start)
-        if start == -1:
-            return
-        yield start
-        start += len(sub)
+    """Start offsets of the non-overlapping occurrences of ``sub`` (processor_v2.py:43-50 of the reference)."""
+    return (m.start() for m in re.finditer(re.escape(sub), a_str))
 
 
 def get_epoch_and_loss(path_to_model_files, epoch='best'):
@@ -284,18 +279,11 @@ class Processor(object):
                 feeders[train] = BatchFeeder(samples, num_data, B, self.device, spk)
             yield from feeders[train].batches((num_data + B - 1) // B)
             return
+        from .data import host_batch
         for _ in range((num_data + B - 1) // B):
-            keys = np.random.choice(num_data, size=B, replace=True)
-            text = torch.from_numpy(samples['extended_word_seq'][keys]).to(self.device, non_blocking=True)
-            vec = torch.from_numpy(samples['vec_seq'][keys]).float().to(self.device, non_blocking=True)
-            audio = torch.from_numpy(samples['audio'][keys] * samples['audio_max'][keys, None] / 32767).float() \
-                .to(self.device, non_blocking=True)
-            mfcc = torch.from_numpy(samples['mfcc_features'][keys]).float().to(self.device, non_blocking=True)
-            vids = None
-            if spk is not None and spk.__class__.__name__ == 'Vocab':
-                others = np.setdiff1d(np.fromiter(spk.word2index.values(), dtype=np.int64), samples['vid_indices'][keys])
-                vids = torch.from_numpy(np.random.choice(others, size=B)).long().to(self.device, non_blocking=True)
-            yield text, vec, audio, mfcc, vids
+            text, vec, audio, mfcc, vids = host_batch(samples, num_data, B, spk)
+            yield tuple(None if a is None else torch.from_numpy(a).to(self.device, non_blocking=True)
+                        for a in (text, vec, audio, mfcc, vids))
 
     # ------------------------------------------------------------------------------------------------
     def synthesize_clip(self, seed_seq, clip_audio, sample_rate, clip_words, mfcc_windows=None, mfcc_fn=None,

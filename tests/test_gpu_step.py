@@ -312,6 +312,33 @@ def test_prefetching_batch_feeder_matches_the_host_path():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('train', [True, False])
+def test_batch_feeder_reproduces_the_reference_yield_batch(golden_dir, train):
+    """The feeder (background index draw, pinned gather, device-side decode) against tests/golden/batch_small.npz, which
+    was recorded from the REFERENCE's own Processor.yield_batch under the same np.random.seed: torch.equal per tensor."""
+    import sys
+    import types
+    sys.path.insert(0, golden_dir)
+    import batch_recipe as R
+    from speech2affective_gestures_amd import processor_v2 as P
+    g = np.load(os.path.join(golden_dir, 'batch_small.npz'))
+    tag = 'train' if train else 'val'
+    pr = object.__new__(P.Processor)
+    pr.train_samples = pr.val_samples = R.samples()
+    pr.num_train_samples = pr.num_val_samples = R.N_DATA
+    pr.train_speaker_model = pr.val_speaker_model = R.Vocab(R.N_SPK)
+    pr.args = types.SimpleNamespace(batch_size=R.BATCH, prefetch_batches=True)
+    pr.device = torch.device('cuda', 0)
+    np.random.seed(R.SEED + int(train))
+    batches = [[t.cpu() for t in b] for b in pr.yield_batch(train)]
+    assert len(batches) == int(g[tag + '.n'])
+    for i, b in enumerate(batches):
+        for name, t in zip(('text', 'vec', 'audio', 'mfcc', 'vids'), b):
+            want = torch.from_numpy(g[f'{tag}.{name}'][i])
+            assert t.dtype == want.dtype and torch.equal(t, want), (tag, i, name)
+
+
+@pytest.mark.gpu
 def test_train_and_val_epoch_loops_over_a_host_dataset():
     """per_train_epoch / per_val_epoch (processor_v2.py:959-1030) end to end on a small host-resident dataset: batches come
     through yield_batch (feeder, device-side decode), the step is replayed from hipGraphs, weights move in training and

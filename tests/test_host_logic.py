@@ -145,6 +145,32 @@ def test_yield_batch_semantics_on_host():
     assert vids.dtype == torch.int64 and 3 not in vids.tolist() and set(vids.tolist()) <= set(range(12))
 
 
+@pytest.mark.parametrize('train', [True, False])
+def test_host_batch_reproduces_the_reference_yield_batch(golden_dir, train):
+    """tests/golden/batch_small.npz was recorded from the reference's own Processor.yield_batch (processor_v2.py:589-638,
+    tests/golden/gen_golden_batch.py): same np.random.seed => the same clips (``p=prob_dist`` index draw), the same
+    decoded tensors bit for bit, the same "other speaker" ids (one vectorised draw == the reference's B scalar draws)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import batch_recipe as R
+    from speech2affective_gestures_amd import processor_v2 as P
+    g = np.load(os.path.join(golden_dir, 'batch_small.npz'))
+    tag = 'train' if train else 'val'
+    pr = object.__new__(P.Processor)
+    pr.train_samples = pr.val_samples = R.samples()
+    pr.num_train_samples = pr.num_val_samples = R.N_DATA
+    pr.train_speaker_model = pr.val_speaker_model = R.Vocab(R.N_SPK)
+    pr.args = types.SimpleNamespace(batch_size=R.BATCH)
+    pr.device = torch.device('cpu')
+    np.random.seed(R.SEED + int(train))
+    batches = list(pr.yield_batch(train))
+    assert len(batches) == int(g[tag + '.n'])
+    for i, b in enumerate(batches):
+        for name, t in zip(('text', 'vec', 'audio', 'mfcc', 'vids'), b):
+            want = g[f'{tag}.{name}'][i]
+            assert t.numpy().dtype == want.dtype and np.array_equal(t.numpy(), want), (tag, i, name)
+
+
 def test_load_cache_reads_the_reference_npz_layout(tmp_path):
     """processor_v2.py:222-271: <dir>/../full/<part>.npz and the per-clip <k:06d>.npz variant; mfcc kept as float16."""
     from speech2affective_gestures_amd import processor_v2 as P
