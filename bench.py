@@ -34,6 +34,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_WORDS, N_SPK, T, POSE_DIM, AUDIO_LEN, MFCC_LEN, NUM_MFCC = 20000, 1371, 34, 27, 36267, 71, 37
+MAX_WORDS_PER_CLIP = 8            # synthetic_batch draws k ~ U{2..8} words per clip
+
+# BASELINE.json configs the bench can run as the timed workload (--config)
+CONFIGS = {
+    'step': dict(name='BASELINE configs[1]: full G+D GAN step (3 G fwd, 3 D fwd, 1 tri-modal fwd, 2 bwd, 2 Adam), '
+                      '34-frame TED-shaped clips', batch=128, frames=34, audio_len=36267),
+    # 146 000 samples -> exactly 136 wave-encoder frames; mfcc_length = ceil(146000 / 512) = 286 (processor_v2.py:124)
+    'long': dict(name='BASELINE configs[4]: long-context full G+D GAN step, 136-frame clips (audio 146 000 samples, '
+                      'mfcc_length 286), fp32', batch=64, frames=136, audio_len=146000),
+}
 
 
 class Vocab:                       # duck-typed speaker model (utils/vocab.py): class name must be 'Vocab'
@@ -42,38 +52,38 @@ class Vocab:                       # duck-typed speaker model (utils/vocab.py): 
         self.word2index = {'v%d' % i: i for i in range(n)}
 
 
-def synthetic_batch(B, seed, device):
+def synthetic_batch(B, seed, device, frames=T, audio_len=AUDIO_LEN):
     """CPU generator seeded per rank, then copied."""
     g = torch.Generator().manual_seed(seed)
-    text = torch.zeros(B, T, dtype=torch.int64)
+    text = torch.zeros(B, frames, dtype=torch.int64)
     for b in range(B):
-        k = int(torch.randint(2, 9, (1,), generator=g))
-        pos = torch.randperm(T, generator=g)[:k]
+        k = int(torch.randint(2, MAX_WORDS_PER_CLIP + 1, (1,), generator=g))
+        pos = torch.randperm(frames, generator=g)[:k]
         text[b, pos] = torch.randint(4, N_WORDS, (k,), generator=g)
-    audio = (torch.randn(B, AUDIO_LEN, generator=g) * 0.05).clamp_(-1, 1)
-    mfcc = torch.randn(B, NUM_MFCC, MFCC_LEN, generator=g) * 0.1
-    target = torch.randn(B, T, POSE_DIM, generator=g) * 0.2
+    audio = (torch.randn(B, audio_len, generator=g) * 0.05).clamp_(-1, 1)
+    mfcc = torch.randn(B, NUM_MFCC, -(-audio_len // 512), generator=g) * 0.1
+    target = torch.randn(B, frames, POSE_DIM, generator=g) * 0.2
     vid = torch.randint(0, N_SPK, (B,), generator=g)
     return [t.to(device) for t in (text, audio, mfcc, target, vid)]
 
 
-def make_cfg():
-    return types.SimpleNamespace(n_pre_poses=4, n_poses=T, input_context='both', hidden_size=300,
+def make_cfg(frames=T):
+    return types.SimpleNamespace(n_pre_poses=4, n_poses=frames, input_context='both', hidden_size=300,
                                  hidden_size_s2eg=300, n_layers=4, dropout_prob=0.3, freeze_wordembed=False,
                                  loss_warmup=0, loss_gan_weight=5.0, z_type='speaker', loss_reg_weight=0.05,
                                  loss_regression_weight=500, loss_kld_weight=0.1, wordembed_dim=300,
                                  learning_rate=5e-4, discriminator_lr_weight=0.2)
 
 
-def build_processor(B, hip_graph):
+def build_processor(B, hip_graph, frames=T, audio_len=AUDIO_LEN):
     from speech2affective_gestures_amd import processor_v2 as P
     lang = types.SimpleNamespace(n_words=N_WORDS, word_embedding_weights=None)
-    meta = types.SimpleNamespace(n_poses=T, expected_audio_length=AUDIO_LEN, num_mfcc_combined=NUM_MFCC,
+    meta = types.SimpleNamespace(n_poses=frames, expected_audio_length=audio_len, num_mfcc_combined=NUM_MFCC,
                                  lang_model=lang, speaker_model=Vocab(N_SPK), n_samples=0)
     args = types.SimpleNamespace(batch_size=B, train_s2ag=True, work_dir_s2ag=None, save_log=False, print_log=False,
-                                 hip_graph=hip_graph,
+                                 hip_graph=hip_graph, max_words_per_clip=MAX_WORDS_PER_CLIP,
                                  overlap_passes=os.environ.get('S2AG_OVERLAP_PASSES', '1') != '0')
-    pr = P.Processor(ROOT, args, make_cfg(), {'train_data_s2ag': meta, 'val_data_s2ag': meta, 'test_data_s2ag': meta},
+    pr = P.Processor(ROOT, args, make_cfg(frames), {'train_data_s2ag': meta, 'val_data_s2ag': meta, 'test_data_s2ag': meta},
                      POSE_DIM, 3, 16000)
     pr.meta_info['epoch'] = 1            # discriminator branch active (epoch > loss_warmup)
     for m in (pr.s2ag_generator, pr.s2ag_discriminator, pr.trimodal_generator):
@@ -93,8 +103,26 @@ def matrix_products_mode():
             }[np_]
 
 
-def gru_roofline(B, iters=20):
-    """Time the dominant kernel (gru_seq_fwd, H=300, both directions, T=34) with HIP events on its stream."""
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the kernel whose name starts with ``kernel_prefix``, from the tracked summary of the two
+    separate rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, written by tools/pmc_traffic.py from
+    FETCH_SIZE / WRITE_SIZE with the gfx950 corrections of the micro-architecture guide).  None when the file or the
+    kernel is absent: the line then says traffic = null instead of quoting a stale constant."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    for name, ent in table.get('kernels', {}).items():
+        if name.startswith(kernel_prefix):
+            return float(ent['bytes_per_launch']), 'profiles/r02_pmc_traffic.json (' + table.get('source', '?') + ')'
+    return None, None
+
+
+def gru_roofline(B, iters=20, T=T):
+    """Time the dominant kernel (the H=300 GRU forward recurrence, both directions, T frames) with HIP events on the
+    stream it is launched on."""
     import ctypes as C
     from speech2affective_gestures_amd import _lib as L
     lib = L.load()
@@ -135,30 +163,29 @@ def gru_roofline(B, iters=20):
     ms = sum(a.elapsed_time(b) for a, b in evs) / iters
     flops = 2.0 * B * T * 2 * H * 3 * H           # recurrent mat-vec MACs x2, both directions
     achieved = flops / (ms * 1e-3) / 1e12
-    # HBM/fabric bytes per launch from the PMC passes committed under profiles/r01_m_pmc_* (r01_i_pmc_* for the one-slice kernel) (rocprofv3 --pmc FETCH_SIZE
-    # and WRITE_SIZE in separate runs, KB units, FETCH doubled as the gfx950 guide prescribes): gi + exchange-cell
-    # reads, y / ydrop / saved-gate / exchange-cell writes.  Only meaningful at the profiled shape (B = 128).
-    two_slices = coop and int(lib.s2ag_gru_coop_fwd_slices(B)) == 2
-    traffic = ((2 * 112755.4 + 59134.1) if two_slices else (2 * 118252.0 + 59134.6)) * 1024 if (coop and B == 128) else None
     np_ = int(lib.s2ag_gru_coop_split_pieces()) if coop else 0
     ns_ = int(lib.s2ag_gru_coop_fwd_slices(B)) if coop else 1
     name = ((f'gru_coop_fwd_sp2_k<300,32,{np_},2>' if ns_ == 2 else f'gru_coop_fwd_sp_k<300,32,{np_}>') if np_
             else 'gru_coop_fwd_k<300,32>') if coop else 'gru_seq_fwd_k<8>'
+    # HBM / fabric bytes per launch: measured, from the tracked PMC summary -- only at the profiled shape
+    traffic, source = pmc_traffic(name.split('<')[0]) if (coop and (B, T) == (128, 34)) else (None, None)
     pipe = {0: '12 waves x 38 f32 MFMAs (16x16x4) per CU and step',
-            2: '12 waves x 15 bf16 MFMAs (16x16x32; the 3 leading piece products of 2-piece bf16 splits of the fp32 operands: products carry 16 mantissa bits, error vs fp64 1.5e-6 against the f32-MFMA kernel\'s 3.8e-7, tools/diag_gru_split.py; S2AG_GRU_SPLIT=3 is fp32-equivalent) per CU and slice step',
-            3: '12 waves x 30 bf16 MFMAs (16x16x32; the 6 leading piece products of exact 3-piece splits of the fp32 '
-               'operands: fp32-equivalent, error vs fp64 equal to the f32-MFMA kernel, tools/diag_gru_split.py) per CU '
-               'and step'}[np_]
-    return dict(bound='mfma', kernel=name + ' (H=300, T=34, 2 directions)',
+            2: '12 waves x 15 bf16 MFMAs (16x16x32; the 3 leading piece products of 2-piece bf16 splits of the fp32 '
+               'operands: 16 mantissa bits per product) per CU and slice step',
+            3: '12 waves x 30 bf16 MFMAs (16x16x32; the 6 leading piece products of exact 3-piece splits: '
+               'fp32-equivalent) per CU and step'}[np_]
+    algo_bytes = 4.0 * B * T * (6 * H + 2 * 2 * H + 2 * 4 * H) + 4.0 * 2 * 3 * H * H
+    return dict(bound='mfma', kernel=name + f' (H=300, T={T}, 2 directions)',
                 achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3, traffic=traffic,
-                traffic_source='profiles/r01_m_pmc_FETCH_SIZE.txt + r01_m_pmc_WRITE_SIZE.txt' if two_slices else 'profiles/r01_i_pmc_FETCH_SIZE.txt + r01_i_pmc_WRITE_SIZE.txt', ms_per_launch=ms,
+                traffic_source=source, algorithmic_bytes_per_launch=algo_bytes, ms_per_launch=ms,
                 algorithmic_flops_per_launch=flops,
                 note='peak = dense f32 MFMA peak (the arithmetic is fp32); algorithmic FLOPs = 2 x 3H x H per clip, frame '
-                     'and direction.  Sequential recurrence, bound by the per-step exchange latency, not by the pipe: per '
-                     'time step (tools/diag_coop_trace.py, profiles/r01_m_coop_gru_phase_trace.txt) ~1.3 us for the new '
-                     'state to reach the peers (write-through tagged cells, polling loads), ' + pipe +
-                     ', 0.4 us gate math, 0.5 us stores; ' + ('a workgroup alternates between two 16-clip slices (one travels while the other is computed): 80 of 256 CUs per launch -- 13 % longer alone than the one-slice kernel (S2AG_GRU_SLICES=1: 0.139 ms, frac 0.215, 160 CUs) but +1.4 % on the step, where passes share the chip' if ns_ == 2 else '160 of 256 CUs hold W_hh in registers') + '; ms_per_launch includes the '
-                     '~5 us exchange-buffer clear')
+                     'and direction; algorithmic bytes = gi in, y / dropped y / saved gates out, W_hh once.  Sequential '
+                     'recurrence, bound by the per-step exchange latency, not by a pipe: per time step ~1.3 us for the new '
+                     'state to reach the peers (write-through tagged cells, polling loads), ' + pipe + ', 0.4 us gate '
+                     'math, 0.5 us stores' + ('; a workgroup alternates between two 16-clip slices, 80 of 256 CUs per '
+                     'launch' if ns_ == 2 else '; 160 of 256 CUs hold W_hh in registers') + '; ms_per_launch includes '
+                     'the ~5 us exchange-buffer clear')
 
 
 def _graph_timer(fn, iters, warm=3):
@@ -187,8 +214,42 @@ def _graph_timer(fn, iters, warm=3):
     return ts[len(ts) // 2]
 
 
-def gen_forward_ms(pr, device):
-    """BASELINE metric tail 'gen fwd ms': PoseGenerator forward, eval mode, B = 4 and B = 128, median of 100 replays."""
+def _cpu_threads():
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        phys = os.cpu_count()
+    return phys, sorted({c for c in (8, 16, 32, 64, phys) if c <= phys})
+
+
+def _cpu_time(fn, warm, timed, cand):
+    """Median wall time of ``fn`` on the host at the fastest of a few thread counts (these are chains of small ops:
+    oversubscribing a many-core host makes them slower)."""
+    best, cores = None, cand[0]
+    torch.set_num_threads(cand[0])
+    for _ in range(warm):
+        fn()
+    for c in cand:
+        torch.set_num_threads(c)
+        t0 = time.perf_counter()
+        fn()
+        d = time.perf_counter() - t0
+        if best is None or d < best:
+            best, cores = d, c
+    torch.set_num_threads(cores)
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], cores
+
+
+def gen_forward_ms(pr, device, cpu=True):
+    """BASELINE metric tail 'gen fwd ms': PoseGenerator forward, eval mode, B = 4 and B = 128, median of 100 replays;
+    beside it the CPU oracle's forward on the host cores (3 warm-up + 10 timed, median)."""
     out = {}
     G = pr.s2ag_generator
     was = G.training
@@ -204,13 +265,32 @@ def gen_forward_ms(pr, device):
             out[f'b{B}'] = _graph_timer(fn, 100)
     finally:
         G.train(was)
+    if cpu:
+        from oracle import s2ag_oracle as O
+        phys, cand = _cpu_threads()
+        oc = O.ModelCfg()
+        sd = O.recipe_state_dict(O.generator_shapes(oc, N_WORDS, N_SPK), 1)
+        base = {}
+        for B in (4, 128):
+            inp = O.recipe_inputs(B, T, 7, N_WORDS, N_SPK)
+            pre = O.make_pre_seq(inp['target'], 4)
+
+            def one():
+                with torch.no_grad():
+                    O.pose_generator(sd, oc, pre, inp['in_text'], inp['in_mfcc'], inp['vid'], False, O.Noise(None), True)
+            dt, cores = _cpu_time(one, 3, 10, cand)
+            base[f'b{B}'] = dt * 1e3
+            base[f'b{B}_cores'] = cores
+        out['cpu_baseline'] = dict(value=base, unit='ms', kind='port', physical_cores=phys,
+                                   sample='CPU oracle PoseGenerator forward (eval), 3 warm-up + 10 timed, median, fastest '
+                                          f'of {cand} threads')
     return out
 
 
-def conv1d_roofline_run(device, B=256, iters=30):
+def conv1d_roofline_run(device, B=256, iters=30, cpu=True):
     """BASELINE configs[3] (the 'Conv1d roofline run'): WavEncoder + TextEncoderTCN forward + backward, train mode,
-    dropout on, isolated, B = 256, fp32.  HBM-bound by design: algorithmic traffic 5.75 MB/clip (SURVEY.md 8d:
-    every layer reads its input and writes its output once forward; backward re-reads x, reads dy, writes dx)."""
+    dropout on, isolated, B = 256.  HBM-bound by design: algorithmic traffic 5.75 MB/clip in fp32 (every
+    layer reads its input and writes its output once forward; backward re-reads x, reads dy, writes dx)."""
     from speech2affective_gestures_amd.net.multimodal_context_net_v2 import TextEncoderTCN, WavEncoder
     from speech2affective_gestures_amd.optim import ParamArena
     cfg = make_cfg()
@@ -224,31 +304,48 @@ def conv1d_roofline_run(device, B=256, iters=30):
     ms = _graph_timer(fn, iters)
     clips = B / (ms * 1e-3)
     bytes_per_clip, flops_per_clip = 5.75e6, 413.8e6
-    return dict(workload='BASELINE configs[3]: WavEncoder + TextEncoderTCN fwd+bwd, B=256, T=34, fp32, dropout on',
-                ms_per_iter=ms, clips_per_s=clips,
-                roofline=dict(bound='hbm', achieved=clips * bytes_per_clip / 1e9, peak=8000.0, unit='GB/s',
-                              frac=clips * bytes_per_clip / 8e12, traffic=None,
-                              note='fp32 MFMA (157.3 TF) caps this path at ~27% of the HBM roofline: '
-                                   f'{clips * flops_per_clip / 1e12:.1f} TFLOP/s achieved of 157.3'))
+    out = dict(workload='BASELINE configs[3]: WavEncoder + TextEncoderTCN fwd+bwd, B=256, T=34, fp32, dropout on',
+               ms_per_iter=ms, clips_per_s=clips, dtype='f32',
+               roofline=dict(bound='hbm', achieved=clips * bytes_per_clip / 1e9, peak=8000.0, unit='GB/s',
+                             frac=clips * bytes_per_clip / 8e12, traffic=None,
+                             algorithmic_bytes_per_clip=bytes_per_clip,
+                             note=f'{clips * flops_per_clip / 1e12:.1f} TFLOP/s of matrix work at this rate '
+                                  '(413.8 MFLOP/clip); kernel-level trace: profiles/r02_cfg3_kernel_stats.txt'))
+    if cpu:
+        from oracle import s2ag_oracle as O
+        phys, cand = _cpu_threads()
+        oc = O.ModelCfg()
+        sd = O.recipe_state_dict({**O._wav_encoder_shapes('wav.'),
+                                  **O._text_encoder_shapes('txt.', N_WORDS, 300, oc.hidden_size, oc.n_layers)}, 11)
+        inp = O.recipe_inputs(B, T, 5, N_WORDS, N_SPK)
+
+        def one():
+            leaf = {k: (v.detach().requires_grad_(True) if O.is_param(k) and '.net.' not in k else v)
+                    for k, v in sd.items()}
+            for k in list(leaf):
+                if '.net.0.' in k or '.net.4.' in k:
+                    leaf[k] = leaf[k.replace('.net.0.', '.conv1.').replace('.net.4.', '.conv2.')]
+            y = O.wav_encoder(leaf, 'wav.', inp['in_audio'], True).sum() + \
+                O.text_encoder_tcn(leaf, 'txt.', inp['in_text'], True, oc.dropout_prob, O.Noise(None)).sum()
+            y.backward()
+        dt, cores = _cpu_time(one, 3, 10, cand)
+        out['cpu_baseline'] = dict(value=B / dt, unit='clips/s', cores=cores, kind='port', physical_cores=phys,
+                                   sample=f'CPU oracle WavEncoder + TextEncoderTCN fwd+bwd at B={B}, 3 warm-up + 10 timed, '
+                                          f'median, fastest of {cand} threads; {dt * 1e3:.0f} ms/iter')
+    return out
 
 
-def cpu_baseline(B, steps=2):
+def cpu_baseline(B, steps=2, frames=T, audio_len=AUDIO_LEN):
     """The oracle's gan_step (ATen fused GRU, drawn dropout) on the host cores -- bounded sample."""
     from oracle import s2ag_oracle as O
-    try:
-        import psutil
-        phys = psutil.cpu_count(logical=False) or os.cpu_count()
-    except Exception:
-        phys = os.cpu_count()
-    # the step is a chain of small ops: oversubscribing a many-core host makes it SLOWER, so the baseline uses the
-    # fastest of a few thread counts (1 probe step each) -- the number reported is the best the host can do
-    cand = sorted({c for c in (8, 16, 32, 64, phys) if c <= phys})
-    oc = O.ModelCfg()
-    G = O.recipe_state_dict(O.generator_shapes(oc, N_WORDS, N_SPK), 1)
-    D = O.recipe_state_dict(O.aff_discriminator_shapes(), 2)
+    phys, cand = _cpu_threads()
+    oc = O.ModelCfg(n_poses=frames)
+    mfcc_len = -(-audio_len // 512)
+    G = O.recipe_state_dict(O.generator_shapes(oc, N_WORDS, N_SPK, mfcc_length=mfcc_len), 1)
+    D = O.recipe_state_dict(O.aff_discriminator_shapes(frames), 2)
     T3 = O.recipe_state_dict(O.trimodal_shapes(oc, N_WORDS, N_SPK), 3)
     gopt, dopt, scfg = O.AdamState(), O.AdamState(), O.StepCfg()
-    inp = O.recipe_inputs(B, T, 7, N_WORDS, N_SPK)
+    inp = O.recipe_inputs(B, frames, 7, N_WORDS, N_SPK, audio_len=audio_len, mfcc_len=mfcc_len)
 
     def one():
         O.gan_step(G, D, T3, gopt, dopt, oc, scfg, inp['in_text'], inp['in_audio'], inp['in_mfcc'], inp['target'],
@@ -269,8 +366,45 @@ def cpu_baseline(B, steps=2):
         one()
     dt = (time.perf_counter() - t0) / steps
     return dict(value=B / dt, unit='clips/s', cores=cores, kind='port', physical_cores=phys,
-                sample=f'{steps} timed GAN steps (+1 warm-up) of the CPU oracle at batch {B}, T=34, fp32, '
-                       f'torch {torch.__version__}, {cores} threads (fastest of {cand}); {dt * 1e3:.0f} ms/step')
+                sample=f'{steps} timed GAN steps (+1 warm-up, +1 probe per thread count) of the CPU oracle at batch {B}, '
+                       f'T={frames}, fp32, torch {torch.__version__}, {cores} threads (fastest of {cand}: the step is a '
+                       f'chain of small ops, more threads are slower); {dt * 1e3:.0f} ms/step')
+
+
+def timed_steps(pr, dp, batch, steps, warmup, sync):
+    """W untimed + exactly K timed steps between barrier + synchronize on both sides; max over ranks."""
+    text, audio, mfcc, target, vid = batch
+    for _ in range(max(1, warmup)):       # also triggers graph capture (3 internal warm-up steps) on the 1st call
+        pr.train_step(text, audio, mfcc, target, vid, sync=sync)
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pr.train_step(text, audio, mfcc, target, vid, sync=sync)
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    return dp.max_over_ranks(time.perf_counter() - t0, pr.device)
+
+
+def alt_modes(pr, dp, batch, B, steps=10):
+    """The same step with the large matrix products formed differently (same process, graphs re-captured): 3 bf16
+    pieces = fp32-equivalent products, 0 = the f32 MFMA everywhere.  The headline `value` is the default (2 pieces)."""
+    from speech2affective_gestures_amd import _lib as L
+    lib = L.load()
+    out = {}
+    prev = int(lib.s2ag_gru_coop_split_pieces())
+    try:
+        for pieces, tag in ((3, 'fp32_equivalent_3_bf16_pieces'), (0, 'f32_mfma_everywhere')):
+            lib.s2ag_gru_coop_set_split_pieces(pieces)
+            pr._graphed = None
+            el = timed_steps(pr, dp, batch, steps, 2, False)
+            out[tag] = dict(clips_per_s=B * dp.world_size * steps / el, ms_per_step=el / steps * 1e3, steps=steps)
+    finally:
+        lib.s2ag_gru_coop_set_split_pieces(prev if prev in (0, 2, 3) else -1)
+        pr._graphed = None
+    return out
 
 
 def main():
@@ -278,57 +412,68 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=128, help='clips per GPU')
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='step',
+                    help="'step' = BASELINE configs[1] (the metric's configuration); 'long' = configs[4] (T=136, B=64)")
+    ap.add_argument('--batch', type=int, default=None, help='clips per GPU (default: the config\'s)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extras', action='store_true', help='skip gen-forward latency and the Conv1d roofline run')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip gen-forward latency, the Conv1d roofline run, alternative product modes, the long config')
     a = ap.parse_args()
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; the product has no CPU path')
-    pr = build_processor(a.batch, not a.no_graph)
+    wl = CONFIGS[a.config]
+    B, frames, audio_len = a.batch or wl['batch'], wl['frames'], wl['audio_len']
+    pr = build_processor(B, not a.no_graph, frames, audio_len)
     dp = pr.dp
     assert dp.world_size == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={dp.world_size}'
     from speech2affective_gestures_amd import noise
     noise.manual_seed(1234 + dp.rank)
-    batch = synthetic_batch(a.batch, dp.rank, pr.device)
-    text, audio, mfcc, target, vid = batch
+    batch = synthetic_batch(B, dp.rank, pr.device, frames, audio_len)
 
-    for _ in range(max(1, a.warmup)):       # also triggers graph capture (3 internal warm-up steps) on the 1st call
-        pr.train_step(text, audio, mfcc, target, vid, sync=False)
-    torch.cuda.synchronize()
-    dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        pr.train_step(text, audio, mfcc, target, vid, sync=False)
-    torch.cuda.synchronize()
-    dp.barrier()
-    torch.cuda.synchronize()
-    elapsed = dp.max_over_ranks(time.perf_counter() - t0, pr.device)
+    elapsed = timed_steps(pr, dp, batch, a.steps, a.warmup, sync=False)
     metric = pr._finish(pr._graphed['out']['comps'], pr._graphed['out']['dis']) if pr._graphed else None
     ms = elapsed / a.steps * 1e3
-    value = a.batch * dp.world_size * a.steps / elapsed
+    value = B * dp.world_size * a.steps / elapsed
+    # the epoch loop's call (per_train_epoch: one 40-byte loss read-back per step) -- the API path beside the async one
+    el_sync = timed_steps(pr, dp, batch, max(5, a.steps // 2), 1, sync=True)
+    sync_value = B * dp.world_size * max(5, a.steps // 2) / el_sync
 
     if dp.rank == 0:
+        ex = pr._exchange()
         line = {
             'metric': 'gan_train_step_clips_per_sec', 'value': value, 'unit': 'clips/s', 'n_gpus': dp.world_size,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: full G+D GAN step (3 G fwd, 3 D fwd, 1 tri-modal fwd, 2 bwd, '
-                                   '2 Adam), 34-frame TED-shaped clips', 'batch_per_gpu': a.batch,
-                       'global_batch': a.batch * dp.world_size, 'frames': T, 'n_words': N_WORDS, 'n_speakers': N_SPK,
+            'config': {'workload': wl['name'], 'batch_per_gpu': B, 'global_batch': B * dp.world_size, 'frames': frames,
+                       'audio_samples': audio_len, 'n_words': N_WORDS, 'n_speakers': N_SPK,
                        'parallelism': f'dp{dp.world_size}', 'hip_graph': not a.no_graph,
                        'matrix_products': matrix_products_mode(),
+                       'gradient_exchange_bytes_per_rank': ex.bytes_per_step() if ex is not None else None,
                        'last_step_losses': pr.last_losses if metric is not None else None},
+            'value_with_per_step_loss_readback': sync_value,
         }
-        line['roofline'] = gru_roofline(a.batch)
+        line['roofline'] = gru_roofline(B, T=frames)
         if dp.world_size == 1 and not a.no_extras:
-            line['gen_fwd_ms'] = gen_forward_ms(pr, pr.device)
-            line['conv1d_roofline_run'] = conv1d_roofline_run(pr.device)
+            line['alt_modes'] = alt_modes(pr, dp, batch, B)
+            line['gen_fwd_ms'] = gen_forward_ms(pr, pr.device, cpu=not a.no_cpu_baseline)
+            line['conv1d_roofline_run'] = conv1d_roofline_run(pr.device, cpu=not a.no_cpu_baseline)
         if dp.world_size == 1 and not a.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(a.batch)
+            line['cpu_baseline'] = cpu_baseline(B, frames=frames, audio_len=audio_len)
             line['gpu_over_cpu'] = value / line['cpu_baseline']['value']
+        if dp.world_size == 1 and not a.no_extras and a.config == 'step':
+            # BASELINE configs[4] beside the headline configuration (its own processor; parity: tests/test_gpu_step.py
+            # ::test_long_clip_steps_136_frames_match_the_oracle and tests/test_gpu_fullsize.py)
+            del pr
+            torch.cuda.empty_cache()
+            lw = CONFIGS['long']
+            pl = build_processor(lw['batch'], not a.no_graph, lw['frames'], lw['audio_len'])
+            lb = synthetic_batch(lw['batch'], 0, pl.device, lw['frames'], lw['audio_len'])
+            el = timed_steps(pl, pl.dp, lb, 10, 3, sync=False)
+            line['long_context_run'] = dict(workload=lw['name'], batch_per_gpu=lw['batch'], frames=lw['frames'],
+                                            clips_per_s=lw['batch'] * 10 / el, ms_per_step=el / 10 * 1e3, steps=10,
+                                            dtype='f32')
         print(json.dumps(line), flush=True)
     dp.barrier()
     import torch.distributed as dist

@@ -317,6 +317,25 @@ int s2ag_gru_coop_bwd(const float* dy, int lddy, int dy_dir_stride, const float*
                       const s2ag_epilogue* e /*host, nullable*/, void* workspace, void* stream);
 /* byte offset inside `workspace` of the int32 word a launch sets to 1 if it timed out waiting for a peer */
 int s2ag_gru_coop_error_word_offset(int B, int T, int H, int backward, long long* offset /*host*/);
+/* Production error reporting: after this call every cooperative launch of the process reports a peer time-out by
+ * storing 1 to `*device_word` (sticky: the library never clears it; NULL = back to the per-workspace words).  The
+ * trainer appends the word to its one read-back per step and raises -- nn.GRU of the reference
+ * (net/multimodal_context_net_v2.py:480-486) cannot fail silently, so neither may its replacement. */
+int s2ag_gru_coop_set_error_flag(int* device_word);
+
+/* ---- touched-row exchange of the embedding gradient between data-parallel replicas (csrc/rows.hip) ----------------
+ * Replaces, for text_encoder.embedding.weight (nn.Embedding(n_words, 300), net/multimodal_context_net_v2.py:70-73), the
+ * gradient reduction nn.DataParallel performs onto GPU 0 (processor_v2.py:167-172): only the rows a batch touches travel.
+ * s2ag_rows_unique: sorted unique ids of ids[0:n_tokens) into uids[0:cap) (padded with the sentinel n_entries), their
+ *   number into *count; `mark` is an n_entries-int workspace that must be zero on entry and is zero again on exit;
+ *   more than `cap` distinct ids ORs 2 into *overflow_flag (nullable).
+ * s2ag_rows_pack: records[s] = [int bits of uids[s] | dense[uids[s], 0:dim)] (cap x (dim + 1) floats; zeros behind a sentinel).
+ * s2ag_rows_merge: `gathered` = the records of all replicas, rank-major (world x cap x (dim + 1)); for every listed row
+ *   dense[row] = sum over the replicas that list it, added in rank order (identical bits on every replica). */
+int s2ag_rows_unique(const long long* ids, int n_tokens, int n_entries, int cap, int* mark, int* uids, int* count,
+                     int* overflow_flag, void* stream);
+int s2ag_rows_pack(const float* dense, const int* uids, int cap, int dim, int n_entries, float* records, void* stream);
+int s2ag_rows_merge(const float* gathered, int world, int cap, int dim, int n_entries, float* dense, void* stream);
 
 /* z = mu + eps*exp(0.5*log_var), eps ~ N(0,1) from (rng, site);  net/embedding_net.py:10-13. */
 int s2ag_reparam_fwd(const float* mu, const float* log_var, int n, const unsigned long long* rng, unsigned site,

@@ -89,6 +89,10 @@ SIGNATURES = {
     's2ag_gru_coop_fwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp, vp],
     's2ag_gru_coop_bwd': [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp, vp],
     's2ag_gru_coop_error_word_offset': [ci, ci, ci, ci, C.POINTER(cll)],
+    's2ag_gru_coop_set_error_flag': [vp],
+    's2ag_rows_unique': [vp, ci, ci, ci, vp, vp, vp, vp, vp],
+    's2ag_rows_pack': [vp, vp, ci, ci, ci, vp, vp],
+    's2ag_rows_merge': [vp, ci, ci, ci, ci, vp, vp],
     's2ag_reparam_fwd': [vp, vp, ci, vp, cu, vp, vp],
     's2ag_reparam_bwd': [vp, vp, ci, vp, cu, vp, vp, vp],
     's2ag_dis_loss': [vp, vp, ci, vp, vp, vp, vp],

@@ -1001,6 +1001,10 @@ inline bool coop_two_slices() {
     return v;
 }
 
+// sticky time-out flag of the process (s2ag_gru_coop_set_error_flag): when set, every launch reports a peer time-out
+// THERE (never cleared by the library) instead of in its own workspace word, so a trainer reads one word per step
+int* g_sticky_err = nullptr;
+
 struct Ws {
     u64* x;
     int* err;
@@ -1010,7 +1014,7 @@ Ws carve(void* ws, int B, int H, int backward) {
     char* p = static_cast<char*>(ws);
     Ws w;
     w.x = reinterpret_cast<u64*>(p);
-    w.err = reinterpret_cast<int*>(p + coop_payload_bytes(B, H, backward));
+    w.err = g_sticky_err ? g_sticky_err : reinterpret_cast<int*>(p + coop_payload_bytes(B, H, backward));
     w.zero_bytes = coop_payload_bytes(B, H, backward) + 256;     // cells (tag 0 = never valid) and the error word
     return w;
 }
@@ -1028,6 +1032,11 @@ extern "C" int s2ag_gru_coop_set_split_pieces(int pieces) {
     const int prev = coop_split_pieces();
     g_split_override = (pieces == 2 || pieces == 3) ? pieces : (pieces == 0 ? 0 : -1);
     return prev;
+}
+
+extern "C" int s2ag_gru_coop_set_error_flag(int* device_word) {
+    g_sticky_err = device_word;
+    return 0;
 }
 
 extern "C" long long s2ag_gru_coop_workspace_bytes(int B, int T, int H, int backward) {

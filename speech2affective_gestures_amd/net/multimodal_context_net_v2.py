@@ -264,9 +264,20 @@ class _SpeakerZ:
         z = ops.normal_noise(nz, self.z_site, (in_text.shape[0], self.z_size))
         return z, None, None
 
+    # Data-parallel trainers cut the autograd graph at the decoder's input: everything behind the cut (GRU, out) is
+    # back-propagated first and its gradient bucket goes on the wire while the encoders' backward still runs
+    # (parallel.GradExchange).  ``cut_backward = True`` makes a grad-enabled forward leave ``(full, leaf)`` in ``_cut``:
+    # ``loss.backward()`` then stops at ``leaf``; ``torch.autograd.backward(full, leaf.grad)`` runs the rest.
+    cut_backward = False
+    _cut = None
+
     def _decode(self, in_data, z_context, nz, out_slope):
         if z_context is not None:
             in_data = torch.cat((in_data, z_context.unsqueeze(1).expand(-1, in_data.shape[1], -1)), dim=2)
+        if self.cut_backward and torch.is_grad_enabled() and in_data.requires_grad:
+            leaf = in_data.detach().requires_grad_(True)
+            self._cut = (in_data, leaf)
+            in_data = leaf
         h = self.gru.run(in_data, nz, sum_dirs=True)                                     # (B, T, H), halves summed
         h = ops.linear(h, self.out[0].weight, self.out[0].bias, act=ACT_LEAKY, slope=out_slope)
         return ops.linear(h, self.out[2].weight, self.out[2].bias)

@@ -274,6 +274,34 @@ def normal_noise(noise: Tensor, site: int, shape: Sequence[int]) -> Tensor:
 # ----------------------------------------------------------------------------------------------------
 _TICKETS = {}
 _TICKET_POOL = 1 << 15
+_COOP_FLAG = {}
+
+
+class CoopGruTimeout(RuntimeError):
+    """A cooperative GRU launch gave up waiting for a peer workgroup: its outputs (and everything computed from them
+    since) are invalid."""
+
+
+def coop_error_flag(device=None) -> Optional[Tensor]:
+    """The device's sticky time-out word as a (1,) float32 VIEW of the int32 (non-zero bits <=> timed out), ready to be
+    concatenated into the trainer's per-step read-back; None before init_tickets()."""
+    key = torch.cuda.current_device() if device is None or torch.device(device).index is None \
+        else torch.device(device).index
+    f = _COOP_FLAG.get(key)
+    return None if f is None else f.view(torch.float32)
+
+
+def check_coop_flag(host_value) -> None:
+    """Raise if a read-back of coop_error_flag() is non-zero (any bit pattern but +0.0)."""
+    import struct
+    bits = struct.unpack('<I', struct.pack('<f', float(host_value)))[0]
+    if bits & 2:
+        raise RuntimeError('touched-row exchange: a batch held more distinct word ids than the row capacity the trainer '
+                           'was built with (args.max_words_per_clip too small): the embedding gradient was truncated')
+    if bits:
+        raise CoopGruTimeout('a cooperative GRU recurrence timed out waiting for a peer workgroup (the 10 workgroups '
+                             'of a group were not co-resident): results since the last check are invalid. Re-run with '
+                             'fewer concurrent passes (S2AG_OVERLAP_PASSES=0) or set ops.USE_COOP_GRU = False')
 
 
 def init_tickets(device) -> None:
@@ -286,6 +314,10 @@ def init_tickets(device) -> None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError('ops.init_tickets(device) must run before hipGraph capture (run one eager step first)')
         _TICKETS[key] = [torch.zeros(_TICKET_POOL, dtype=torch.int32, device=dev), 0]
+        # sticky time-out flag of the cooperative GRU launches (one word; the trainer reads it with its per-step
+        # read-back and raises: a recurrence that lost a peer continues with wrong values)
+        _COOP_FLAG[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(_lib().s2ag_gru_coop_set_error_flag(_p(_COOP_FLAG[key])), 'gru_coop_set_error_flag')
 
 
 def _ticket(dev):
@@ -696,6 +728,45 @@ def embedding(ids: Tensor, table: Tensor, drop_p: float = 0.0, noise=None, site=
 
 
 # ----------------------------------------------------------------------------------------------------
+# touched-row exchange of the embedding gradient (data parallel; csrc/rows.hip, parallel.GradExchange)
+# ----------------------------------------------------------------------------------------------------
+_ROW_MARKS = {}
+
+
+def rows_unique_raw(ids: Tensor, n_entries: int, uids_out: Tensor) -> None:
+    """Sorted unique ids of ``ids`` into ``uids_out`` (int32, padded with ``n_entries``).  More distinct ids than
+    ``uids_out`` holds sets bit 1 of the sticky error word (the trainer raises at its next read-back)."""
+    _need_cuda(ids, uids_out)
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and uids_out.dtype == torch.int32
+    key = (ids.device.index, int(n_entries))
+    if key not in _ROW_MARKS:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('rows_unique_raw: first use must happen before hipGraph capture (one eager step)')
+        _ROW_MARKS[key] = (torch.zeros(n_entries, dtype=torch.int32, device=ids.device),
+                           torch.zeros(1, dtype=torch.int32, device=ids.device))
+    mark, count = _ROW_MARKS[key]
+    flag = _COOP_FLAG.get(ids.device.index if ids.device.index is not None else torch.cuda.current_device())
+    L.check(_lib().s2ag_rows_unique(_p(ids), ids.numel(), int(n_entries), uids_out.numel(), _p(mark), _p(uids_out),
+                                    _p(count), _p(flag), _stream()), 'rows_unique')
+
+
+def rows_pack_raw(dense: Tensor, uids: Tensor, records_out: Tensor) -> None:
+    _need_cuda(dense, uids, records_out)
+    n_entries, dim = dense.shape
+    assert dense.is_contiguous() and records_out.is_contiguous() and records_out.shape == (uids.numel(), dim + 1)
+    L.check(_lib().s2ag_rows_pack(_p(dense), _p(uids), uids.numel(), dim, n_entries, _p(records_out), _stream()),
+            'rows_pack')
+
+
+def rows_merge_raw(gathered: Tensor, dense: Tensor) -> None:
+    _need_cuda(gathered, dense)
+    world, cap, rec = gathered.shape
+    n_entries, dim = dense.shape
+    assert rec == dim + 1 and gathered.is_contiguous() and dense.is_contiguous()
+    L.check(_lib().s2ag_rows_merge(_p(gathered), world, cap, dim, n_entries, _p(dense), _stream()), 'rows_merge')
+
+
+# ----------------------------------------------------------------------------------------------------
 # weight norm
 # ----------------------------------------------------------------------------------------------------
 class _WeightNorm(torch.autograd.Function):
@@ -975,9 +1046,12 @@ _COOP_WS = __import__('collections').deque(maxlen=64)   # recent cooperative wor
 
 
 def coop_gru_timeouts() -> int:
-    """Number of recent cooperative GRU launches whose peer wait timed out (synchronises; tests/debug only)."""
+    """Number of recent cooperative GRU launches whose peer wait timed out (synchronises).  With the sticky flag armed
+    (init_tickets; always in a Processor) this is the flag itself: 0 or 1."""
     lib, bad = _lib(), 0
     torch.cuda.synchronize()
+    if _COOP_FLAG:
+        return sum(int(f.item() != 0) for f in _COOP_FLAG.values())
     for ws, B, T, H, bwd in list(_COOP_WS):
         off = C.c_longlong(0)
         L.check(lib.s2ag_gru_coop_error_word_offset(B, T, H, bwd, C.byref(off)), 'error_word_offset')

@@ -14,9 +14,13 @@ from . import _lib as L
 
 
 class ParamArena:
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], first: Iterable[torch.nn.Parameter] = ()):
+        """``first``: parameters placed at the front of the arena (the rest keep their order) -- the data-parallel
+        exchange wants the row-sparse word embedding in front of the dense buckets (parallel.GradExchange)."""
         seen, uniq = set(), []
-        for p in params:
+        params = list(params)
+        front = [p for p in first if any(p is q for q in params)]
+        for p in front + params:
             if id(p) not in seen and p.requires_grad:
                 seen.add(id(p))
                 uniq.append(p)
@@ -41,6 +45,13 @@ class ParamArena:
             p._s2ag_arena = self
             self.offsets.append(off)
             off += n
+
+    def offset_of(self, p: torch.nn.Parameter) -> int:
+        """Element offset of ``p``'s view inside ``data`` / ``grad``."""
+        for q, off in zip(self.params, self.offsets):
+            if q is p:
+                return off
+        raise KeyError('parameter is not in this arena')
 
     def zero_grad(self):
         self.grad.zero_()

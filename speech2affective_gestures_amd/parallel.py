@@ -2,14 +2,28 @@
 
 The reference's only parallelism is ``nn.DataParallel`` (processor_v2.py:167-172): single process, per-step
 parameter broadcast, input scatter, output gather, gradients reduced onto GPU 0.  Here every rank owns a full
-replica and its own B clips (weak scaling, per-replica BatchNorm statistics exactly as under DataParallel);
-the only exchange is one SUM all-reduce per optimizer over the flat gradient arena (D: 313 k floats,
-G: 13.2 M floats), after which Adam consumes grad/world_size.  With the gradient already contiguous there
-is nothing to bucket: one collective moves the whole arena and RCCL pipelines it across the 7 xGMI links.
-The frozen tri-modal baseline needs no communication.
+replica and its own B clips (weak scaling, per-replica BatchNorm statistics exactly as under DataParallel); the
+exchange per optimizer is a SUM over ranks of the flat gradient arena, after which Adam consumes grad/world_size.
+
+``GradExchange`` is the schedule of the generator's exchange (the discriminator's 1.25 MB arena is one all-reduce):
+
+  * the arena is laid out [word embedding | encoders | GRU decoder + out], i.e. in REVERSE order of the backward pass;
+  * bucket A (GRU + out, 22.9 MB at the default config) is complete when the backward pass leaves the recurrent
+    decoder: its all-reduce is launched right there, asynchronously on RCCL's stream, and runs beside the rest of the
+    backward pass (encoders, TCN, embedding: ~0.7 ms of kernels against ~0.2-0.3 ms of collective);
+  * bucket B (encoders, 6 MB) follows when backward ends;
+  * the word embedding (24 MB dense at n_words = 20 000) never travels as a dense tensor: only the rows some replica's
+    batch touched do (csrc/rows.hip: sorted unique ids, [id | row] records, ONE all-gather, merge in rank order --
+    bit-identical on all ranks like an all-reduce).  The optimizer stays the reference's dense Adam.
+
+xGMI is point to point (7 links per GPU), so a ring collective is bound per link: three mid-sized collectives per step
+(22.9 MB hidden, 6 MB + ~1.4 MB x world exposed) instead of one exposed 53 MB all-reduce.  The frozen tri-modal
+baseline needs no communication.  All collectives are issued from the host between / beside hipGraph segments
+(processor_v2._GraphSegments); nothing here is captured into a graph.
 """
 import os
-from dataclasses import dataclass
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -20,6 +34,8 @@ class DataParallelContext:
     rank: int = 0
     world_size: int = 1
     local_rank: int = 0
+    forced: bool = False
+    n_collectives: int = 0          # issued so far (tests)
 
     @staticmethod
     def from_env(backend=None) -> 'DataParallelContext':
@@ -35,11 +51,7 @@ class DataParallelContext:
             if backend == 'nccl':
                 torch.cuda.set_device(local)
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-        ctx = DataParallelContext(rank, world, local)
-        ctx.forced = force and world == 1
-        return ctx
-
-    forced: bool = False
+        return DataParallelContext(rank, world, local, force and world == 1)
 
     @property
     def active(self) -> bool:
@@ -49,10 +61,26 @@ class DataParallelContext:
     def grad_scale(self) -> float:
         return 1.0 / self.world_size
 
+    # ---- collectives --------------------------------------------------------------------------------
+    def all_reduce(self, t: torch.Tensor, async_op: bool = False):
+        """SUM over ranks, in place.  ``async_op``: returns the work handle; the caller's stream does not wait for the
+        collective until ``handle.wait()`` (RCCL runs it on its own stream, ordered after what the caller has queued)."""
+        if not self.active:
+            return None
+        self.n_collectives += 1
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        """out (world * n,) <- inp (n,) of every rank, rank-major."""
+        if not self.active:
+            out.copy_(inp)
+            return
+        self.n_collectives += 1
+        dist.all_gather_into_tensor(out, inp)
+
     def all_reduce_grads(self, arena) -> None:
         """SUM over ranks into ``arena.grad`` (scaled by 1/world inside the fused Adam)."""
-        if self.active:
-            dist.all_reduce(arena.grad, op=dist.ReduceOp.SUM)
+        self.all_reduce(arena.grad)
 
     def broadcast_module(self, module, arena=None) -> None:
         """Rank 0's parameters (one flat broadcast when an arena exists) and buffers to everyone."""
@@ -76,3 +104,87 @@ class DataParallelContext:
         t = torch.tensor([value], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+
+@dataclass
+class RowKernels:
+    """The three device kernels of the touched-row exchange (csrc/rows.hip through ops.py in the product; the CPU tests
+    of the schedule pass torch doubles).  All write into caller-owned static buffers (hipGraph friendly)."""
+    unique: Callable      # (ids (n,) i64, n_entries, uids_out (cap,) i32): sorted unique ids, padded with n_entries
+    pack: Callable        # (dense (n_entries, dim), uids, records_out (cap, dim + 1) f32)
+    merge: Callable       # (gathered (world, cap, dim + 1), dense): dense rows overwritten with the rank-ordered sums
+
+
+@dataclass
+class GradExchange:
+    """Exchange schedule of one flat gradient arena.  ``split`` = element offset where bucket A begins (everything the
+    backward pass finishes FIRST lives behind it); ``rows`` = (lo, hi, n_entries, dim) of a row-sparse tensor at the
+    front of the arena, or None.  Per step, in this order:
+
+        launch_a()        host, when bucket A is complete on the current stream (async all-reduce, nobody waits yet)
+        pack_rows(ids)    device kernels (capturable), when the whole gradient is complete
+        exchange_rest()   host: all-reduce of bucket B, all-gather of the row records, then wait for bucket A
+        merge_rows()      device kernel (capturable): touched rows <- sum over ranks, in rank order
+
+    afterwards ``grad`` holds the SUM over ranks everywhere."""
+    dp: DataParallelContext
+    grad: torch.Tensor
+    split: int
+    rows: Optional[Tuple[int, int, int, int]] = None
+    row_cap: int = 0
+    kernels: Optional[RowKernels] = None
+    _work: list = field(default_factory=list)
+
+    def __post_init__(self):
+        n = self.grad.numel()
+        lo = self.rows[1] if self.rows else 0
+        assert 0 <= lo <= self.split <= n, (lo, self.split, n)
+        if self.rows:
+            assert self.rows[0] == 0 and self.kernels is not None and self.row_cap > 0
+            _, hi, n_entries, dim = self.rows
+            assert hi == n_entries * dim
+            dev = self.grad.device
+            self.uids = torch.full((self.row_cap,), n_entries, dtype=torch.int32, device=dev)
+            self.records = torch.zeros(self.row_cap, dim + 1, dtype=torch.float32, device=dev)
+            self.gathered = torch.zeros(self.dp.world_size, self.row_cap, dim + 1, dtype=torch.float32, device=dev)
+
+    @property
+    def buckets(self) -> List[Tuple[str, int, int]]:
+        lo = self.rows[1] if self.rows else 0
+        return [('A', self.split, self.grad.numel()), ('B', lo, self.split)]
+
+    def bytes_per_step(self) -> dict:
+        """Payload each rank contributes per step (fp32 bytes) -- what the schedule moves instead of the dense arena."""
+        out = {name: 4 * (hi - lo) for name, lo, hi in self.buckets}
+        out['rows'] = 4 * self.records.numel() if self.rows else 0
+        out['dense_arena'] = 4 * self.grad.numel()
+        return out
+
+    def launch_a(self) -> None:
+        if self.split < self.grad.numel():
+            w = self.dp.all_reduce(self.grad[self.split:], async_op=True)
+            if w is not None:
+                self._work.append(w)
+
+    def pack_rows(self, ids: torch.Tensor) -> None:
+        if self.rows is None:
+            return
+        _, hi, n_entries, dim = self.rows
+        self.kernels.unique(ids.reshape(-1), n_entries, self.uids)
+        self.kernels.pack(self.grad[:hi].view(n_entries, dim), self.uids, self.records)
+
+    def exchange_rest(self) -> None:
+        lo = self.rows[1] if self.rows else 0
+        if lo < self.split:
+            self.dp.all_reduce(self.grad[lo:self.split])
+        if self.rows is not None:
+            self.dp.all_gather(self.gathered.view(-1), self.records.view(-1))
+        for w in self._work:
+            w.wait()
+        self._work.clear()
+
+    def merge_rows(self) -> None:
+        if self.rows is None:
+            return
+        _, hi, n_entries, dim = self.rows
+        self.kernels.merge(self.gathered, self.grad[:hi].view(n_entries, dim))

@@ -105,7 +105,8 @@ class _GraphSegments:
         pool = torch.cuda.graph_pool_handle()
         for i, fn in enumerate(fns):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            # 'thread_local': the batch feeder's thread allocates / records events on its own stream meanwhile
+            with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
                 fn()
             self.graphs.append(g)      # nothing executes during capture, so no collective here
 
@@ -178,8 +179,12 @@ class Processor(object):
 
         ops.init_tickets(self.device)
         # flat arenas (must come after .to(device)); identical initial weights on every rank
-        self.gen_arena = ParamArena(self.s2ag_generator.parameters())
+        # generator arena = [word embedding | encoders | GRU decoder + out]: reverse order of the backward pass, so the
+        # data-parallel exchange works on contiguous buckets (parallel.GradExchange)
+        emb = self.s2ag_generator.text_encoder.embedding.weight
+        self.gen_arena = ParamArena(self.s2ag_generator.parameters(), first=[emb])
         self.dis_arena = ParamArena(self.s2ag_discriminator.parameters())
+        self.gen_exchange = None          # built at the first data-parallel step (see _exchange)
         self.dp.broadcast_module(self.s2ag_generator, self.gen_arena)
         self.dp.broadcast_module(self.s2ag_discriminator, self.dis_arena)
         self.dp.broadcast_module(self.trimodal_generator, None)
@@ -206,6 +211,41 @@ class Processor(object):
         self._side = [torch.cuda.Stream(device=self.device) for _ in range(2)]
         self._graphed = None
         self.last_losses = {}
+
+    def _exchange(self):
+        """The generator's gradient-exchange schedule, or None outside data-parallel runs."""
+        if not self.dp.active:
+            return None
+        if self.gen_exchange is None:
+            self.gen_exchange = self._make_gen_exchange(self.s2ag_generator.text_encoder.embedding.weight)
+        return self.gen_exchange
+
+    def _make_gen_exchange(self, emb):
+        """Buckets of the generator's gradient exchange (see parallel.GradExchange): A = GRU decoder + out (behind the
+        backward cut), B = the encoders, touched rows for the word embedding.  Row capacity: a batch of B clips touches
+        at most B * K distinct rows, K = the largest number of distinct ids in one clip (PAD included) -- from
+        ``args.max_words_per_clip`` (+1 for PAD) or the training set itself; without either, B * T (always safe)."""
+        from .parallel import GradExchange, RowKernels
+        G, ar = self.s2ag_generator, self.gen_arena
+        split = min(ar.offset_of(p) for p in list(G.gru.parameters()) + list(G.out.parameters()))
+        assert all(ar.offset_of(p) >= split for p in list(G.gru.parameters()) + list(G.out.parameters()))
+        rows, cap, kern = None, 0, None
+        if emb.requires_grad and os.environ.get('S2AG_SPARSE_EMBEDDING', '1') != '0':
+            assert ar.offset_of(emb) == 0
+            n_entries, dim = emb.shape
+            B, T = int(self.args.batch_size), int(self.time_steps)
+            k = getattr(self.args, 'max_words_per_clip', None)
+            if k is not None:
+                k = int(k) + 1
+            else:
+                seqs = (self.train_samples or {}).get('extended_word_seq') if isinstance(self.train_samples, dict) else None
+                if seqs is not None and len(seqs):
+                    srt = np.sort(np.asarray(seqs), axis=1)
+                    k = int((np.diff(srt, axis=1) != 0).sum(axis=1).max()) + 1
+            cap = min(n_entries, B * min(T, k if k is not None else T))
+            rows = (0, n_entries * dim, n_entries, dim)
+            kern = RowKernels(unique=ops.rows_unique_raw, pack=ops.rows_pack_raw, merge=ops.rows_merge_raw)
+        return GradExchange(self.dp, ar.grad, split, rows=rows, row_cap=cap, kernels=kern)
 
     # ------------------------------------------------------------------------------------------------
     def count_parameters(self):
@@ -261,6 +301,8 @@ class Processor(object):
         else:
             self.test_samples, self.num_test_samples = samples, n
         self.__dict__.get('_feeders', {}).clear()         # feeders hold the previous arrays
+        if part == 'train':                               # the touched-row capacity is derived from the training set
+            self.gen_exchange, self._graphed = None, None
         return samples
 
     def yield_batch(self, train):
@@ -339,6 +381,13 @@ class Processor(object):
         was_training = (self.trimodal_generator.training, self.s2ag_generator.training)
         self.trimodal_generator.eval()
         self.s2ag_generator.eval()
+        # A training step leaves the generator in "share the pose/audio encoders across the passes of this step" mode,
+        # keyed on buffer addresses: here every window reuses the same static buffers, so it must be off (each window
+        # encodes its own seed poses and audio), and derived weight tensors of a step in flight are not to be reused.
+        was_sharing = self.s2ag_generator.share_passes
+        self.s2ag_generator.share_passes = None
+        self.s2ag_generator._shared = None
+        ops.begin_step()
         # One window = ~400 small launches at batch 1: the step runs on static buffers (inputs of the window, seed
         # poses, outputs) so that from the second window on it is ONE hipGraph replay.  The graph bakes in derived
         # weight tensors, so it is re-captured whenever a weight tensor changed (optimizer step, load_state_dict).
@@ -396,7 +445,7 @@ class Processor(object):
                     if st['graph'] is None:
                         torch.cuda.synchronize()
                         gr = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(gr):          # nothing executes during capture
+                        with torch.cuda.graph(gr, capture_error_mode='thread_local'):     # nothing executes during capture
                             window_step()
                         st['graph'] = gr
                     st['graph'].replay()
@@ -413,6 +462,7 @@ class Processor(object):
                 res.append(torch.cat([o[:-1, :T - n_pre].reshape(-1, o.shape[-1]), o[-1]]).cpu().numpy())
         self.trimodal_generator.train(was_training[0])
         self.s2ag_generator.train(was_training[1])
+        self.s2ag_generator.share_passes = was_sharing
         return res[0], res[1]
 
     # ------------------------------------------------------------------------------------------------
@@ -460,7 +510,7 @@ class Processor(object):
             with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
                 out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
             ops.stamp('D:G(dis) end [main]')
-            l_real = None
+            l_real = real_bwd_done = None
             real_fwd_done = torch.cuda.Event()
             with torch.cuda.stream(side), noise.use_pass(nz_real), ops.sequential_branches():
                 ops.stamp('D:D(real) begin [side]')
@@ -475,6 +525,8 @@ class Processor(object):
                     with ops.local_backward():
                         l_real.backward()
                     ops.stamp('D:D(real) backward end [side]')
+                    real_bwd_done = torch.cuda.Event()
+                    real_bwd_done.record(side)
             cur.wait_event(real_fwd_done)       # D(fake) follows D(real)'s FORWARD (BatchNorm running statistics order)
             if self.s2ag_generator.share_passes and self.early_rand:
                 # The generator's third forward (shuffled speakers, no_grad) depends on nothing the D step changes, and
@@ -503,6 +555,10 @@ class Processor(object):
         if self.overlap_passes and l_real is not None:
             l_fake = ops.dis_loss_half(dis_fake, False)
             ops.stamp('D:D(fake) end, backward begins')
+            # D(real)'s backward ends with the flush of D's derived-parameter stages (read-then-clear, not atomic):
+            # the fake half accumulates into the same stages, so it must start after that flush.  D(real)'s backward
+            # (~1 ms) began while the generator pass was still running: the wait is normally already satisfied.
+            cur.wait_event(real_bwd_done)
             l_fake.backward()
             dis_error = l_fake.detach()
             ops.join_side_streams()
@@ -516,9 +572,12 @@ class Processor(object):
         ops.stamp('D:end')
         return dis_error.detach()
 
-    def _gen_phase(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, pre_seq, train):
-        """processor_v2.py:816-941 up to (and including) loss.backward()."""
+    def _gen_phase(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, pre_seq, train, cut=False):
+        """processor_v2.py:816-941 up to (and including) loss.backward().  ``cut`` (data parallel): backward stops at the
+        recurrent decoder's input -- GRU and out gradients are complete, ``_gen_backward_rest`` does the encoders."""
         cfg = self.s2ag_config_args
+        self.s2ag_generator.cut_backward = bool(cut and train)
+        self.s2ag_generator._cut = None
         ops.set_main_stream()
         ops.stamp('G:start')
         self.s2ag_gen_optimizer.zero_grad()
@@ -579,14 +638,30 @@ class Processor(object):
         if train:
             total.backward()
         ops.join_side_streams()
-        ops.stamp('G:end')
+        ops.stamp('G:end' if not self.s2ag_generator.cut_backward else 'G:decoder backward done (bucket A complete)')
         return comps
+
+    def _gen_backward_rest(self, in_text, ex):
+        """Second half of the generator's backward pass in data-parallel runs: from the decoder's input through the
+        encoders (bucket A is already on the wire), then the touched-row records of the embedding gradient."""
+        G = self.s2ag_generator
+        full, leaf = G._cut
+        G._cut, G.cut_backward = None, False
+        ops.set_main_stream()
+        if self.overlap_passes and self.encoders_aside and G.share_passes and self._use_gan():
+            ops.mark_side_stream(self._side[1])
+        torch.autograd.backward([full], [leaf.grad])
+        ops.join_side_streams()
+        ex.pack_rows(in_text)
+        ops.stamp('G:end')
 
     def _finish(self, comps, dis_error):
         """ONE device->host read per step (upstream: 5-7 .item() syncs, processor_v2.py:943-956)."""
         cfg = self.s2ag_config_args
-        host = torch.cat((comps, dis_error.reshape(1) if dis_error is not None else comps.new_zeros(1))).tolist()
-        total, huber, gen_error, div_reg, kld, l1, l1_tri, _, dis = host
+        flag = ops.coop_error_flag(comps.device)
+        host = torch.cat((comps, dis_error.reshape(1) if dis_error is not None else comps.new_zeros(1), flag)).tolist()
+        total, huber, gen_error, div_reg, kld, l1, l1_tri, _, dis, timed_out = host
+        ops.check_coop_flag(timed_out)       # a cooperative recurrence that lost a peer continued with wrong values
         d = {'loss': cfg.loss_regression_weight * huber, 'KLD': cfg.loss_kld_weight * kld,
              'DIV_REG': cfg.loss_reg_weight * div_reg, 'total': total}
         if self._use_gan():
@@ -613,9 +688,14 @@ class Processor(object):
             if train:
                 self.dp.all_reduce_grads(self.dis_arena)
                 self.s2ag_dis_optimizer.step(self.dp.grad_scale)
-        comps = self._gen_phase(in_text, in_audio, in_mfcc, target_poses, vid_indices, pre_seq, train)
+        ex = self._exchange() if train else None
+        comps = self._gen_phase(in_text, in_audio, in_mfcc, target_poses, vid_indices, pre_seq, train, cut=ex is not None)
         if train:
-            self.dp.all_reduce_grads(self.gen_arena)
+            if ex is not None:
+                ex.launch_a()                              # GRU + out gradients travel ...
+                self._gen_backward_rest(in_text, ex)       # ... while the encoders are back-propagated
+                ex.exchange_rest()
+                ex.merge_rows()
             self.s2ag_gen_optimizer.step(self.dp.grad_scale)
         metric = self._finish(comps, dis_error)
         return metric, losses_all_trimodal, joint_mae_trimodal, accel_trimodal, losses_all, joint_mae, accel
@@ -634,20 +714,33 @@ class Processor(object):
             out['dis'] = self._dis_phase(st['text'], st['mfcc'], st['target'], st['vid'], out['pre'], True) \
                 if use_gan else None
 
+        ex = self._exchange()
+
         def seg_gen():
             if use_gan:
                 self.s2ag_dis_optimizer.step(self.dp.grad_scale)
             out['comps'] = self._gen_phase(st['text'], st['audio'], st['mfcc'], st['target'], st['vid'], out['pre'],
-                                           True)
+                                           True, cut=ex is not None)
+
+        def seg_gen_rest():
+            self._gen_backward_rest(st['text'], ex)
 
         def seg_opt():
+            if ex is not None:
+                ex.merge_rows()
             self.s2ag_gen_optimizer.step(self.dp.grad_scale)
             ops.stamp('step end (G-Adam done)')
 
-        between = [(lambda: self.dp.all_reduce_grads(self.dis_arena)) if (use_gan and self.dp.world_size > 1) else None,
-                   (lambda: self.dp.all_reduce_grads(self.gen_arena)) if self.dp.world_size > 1 else None,
-                   None]
-        segs = _GraphSegments([seg_dis, seg_gen, seg_opt], between)
+        # Single process: three segments, nothing between them.  Data parallel: the collectives run from the host
+        # between the segments -- the graphs never contain RCCL nodes -- and bucket A's all-reduce runs BESIDE the
+        # segment that back-propagates the encoders.
+        if ex is None:
+            fns, between = [seg_dis, seg_gen, seg_opt], [None, None, None]
+        else:
+            fns = [seg_dis, seg_gen, seg_gen_rest, seg_opt]
+            between = [(lambda: self.dp.all_reduce_grads(self.dis_arena)) if use_gan else None,
+                       ex.launch_a, ex.exchange_rest, None]
+        segs = _GraphSegments(fns, between)
         self._graphed = dict(st=st, out=out, segs=segs, key=self._graph_key(in_text, in_audio, in_mfcc, target_poses))
 
     def _graph_key(self, in_text, in_audio, in_mfcc, target_poses):
@@ -667,9 +760,31 @@ class Processor(object):
                         ('vid', vid_indices)):
             g['st'][name].copy_(t, non_blocking=True)
         g['segs'].replay()
+        # the Python side effects of a step do not replay with the graph: the arenas changed (tensors derived from the
+        # weights -- weight-normed / folded / tap-major / split planes, the synthesis graph -- are stale) and a new
+        # step generation begins
+        self.gen_arena.epoch += 1
+        self.dis_arena.epoch += 1
+        ops.begin_step()
         if not sync:
+            self._async_flag_check()
             return None
         return self._finish(g['out']['comps'], g['out']['dis'])
+
+    def _async_flag_check(self, every=16):
+        """sync=False steps never read anything back: every ``every`` steps the sticky cooperative-GRU time-out word is
+        copied to pinned host memory WITHOUT waiting, and the copy issued ``every`` steps earlier is inspected."""
+        st = self.__dict__.setdefault('_flag_poll', dict(n=0, host=None, ev=None))
+        st['n'] += 1
+        if st['n'] % every:
+            return
+        if st['host'] is None:
+            st['host'] = torch.zeros(1, dtype=torch.float32).pin_memory()
+        elif st['ev'].query():
+            ops.check_coop_flag(st['host'][0].item())
+        st['host'].copy_(ops.coop_error_flag(self.device), non_blocking=True)
+        st['ev'] = torch.cuda.Event()
+        st['ev'].record()
 
     # ------------------------------------------------------------------------------------------------
     def per_train_epoch(self):

@@ -15,23 +15,23 @@ class Vocab:                       # duck-typed like utils/vocab.py: class name 
         self.word_embedding_weights = None
 
 
-def make_cfg(hidden, drop):
-    return types.SimpleNamespace(n_pre_poses=4, n_poses=34, input_context='both', hidden_size=hidden,
+def make_cfg(hidden, drop, n_poses=34):
+    return types.SimpleNamespace(n_pre_poses=4, n_poses=n_poses, input_context='both', hidden_size=hidden,
                                  hidden_size_s2eg=hidden, n_layers=4, dropout_prob=drop, freeze_wordembed=False,
                                  loss_warmup=0, loss_gan_weight=5.0, z_type='speaker', loss_reg_weight=0.05,
                                  loss_regression_weight=500, loss_kld_weight=0.1, wordembed_dim=300,
                                  learning_rate=5e-4, discriminator_lr_weight=0.2)
 
 
-def oracle_cfg(hidden, drop):
-    return O.ModelCfg(hidden_size=hidden, hidden_size_s2eg=hidden, dropout_prob=drop)
+def oracle_cfg(hidden, drop, n_poses=34):
+    return O.ModelCfg(n_poses=n_poses, hidden_size=hidden, hidden_size_s2eg=hidden, dropout_prob=drop)
 
 
-def recipe_sds(hidden, n_words, n_spk, seed0):
-    oc = oracle_cfg(hidden, 0.0)
-    return dict(G=O.recipe_state_dict(O.generator_shapes(oc, n_words, n_spk), seed0 + 1),
-                D=O.recipe_state_dict(O.aff_discriminator_shapes(), seed0 + 2),
-                CD=O.recipe_state_dict(O.conv_discriminator_shapes(), seed0 + 3),
+def recipe_sds(hidden, n_words, n_spk, seed0, n_poses=34, mfcc_length=71):
+    oc = oracle_cfg(hidden, 0.0, n_poses)
+    return dict(G=O.recipe_state_dict(O.generator_shapes(oc, n_words, n_spk, mfcc_length=mfcc_length), seed0 + 1),
+                D=O.recipe_state_dict(O.aff_discriminator_shapes(n_poses), seed0 + 2),
+                CD=O.recipe_state_dict(O.conv_discriminator_shapes(n_poses=n_poses), seed0 + 3),
                 T3=O.recipe_state_dict(O.trimodal_shapes(oc, n_words, n_spk), seed0 + 4),
                 GA=O.recipe_state_dict(O.generator_shapes(oc, n_words, n_spk, audio='wav'), seed0 + 5))
 

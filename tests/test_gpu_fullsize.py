@@ -128,3 +128,49 @@ def test_checkpoint_round_trip(pr):
             assert torch.equal(G(pre, text, mfcc, vid)[0], ref)
         G.train()
         pr.args.work_dir_s2ag = None
+
+
+def test_long_context_full_size_steps():
+    """BASELINE configs[4] at full size (B = 64, T = 136, H = 300, audio 146 000, n_words 20 000) through the
+    size-independent checks: the cooperative GRU at T = 136 loses no peer (error word), graph-replayed steps stay finite
+    and keep drawing fresh noise, the D phase leaves G untouched, and an eval forward of 64 clips equals two forwards of 32
+    (clip independence).  Oracle parity of the same step at hidden 32: test_gpu_step.py::test_long_clip_steps_136_frames_...."""
+    from speech2affective_gestures_amd import noise, ops
+    cfgl = bench.CONFIGS['long']
+    B, T, AL = cfgl['batch'], cfgl['frames'], cfgl['audio_len']
+    p = bench.build_processor(B, True, T, AL)
+    noise.manual_seed(17)
+    text, audio, mfcc, target, vid = bench.synthetic_batch(B, 6, p.device, T, AL)
+    assert mfcc.shape == (B, 37, 286) and p.s2ag_discriminator.out2.weight.shape == (1, T)
+    before_g = p.gen_arena.data.clone()
+    pre = p._make_pre_seq(target)
+    p._dis_phase(text, mfcc, target, vid, pre, True)
+    p.s2ag_dis_optimizer.step()
+    assert torch.equal(p.gen_arena.data, before_g)
+    losses = []
+    for _ in range(3):
+        p.train_step(text, audio, mfcc, target, vid)
+        L = dict(p.last_losses)
+        assert all(torch.isfinite(torch.tensor(v)) for v in L.values()), L
+        losses.append(L)
+    assert not torch.equal(p.gen_arena.data, before_g)
+    assert ops.coop_gru_timeouts() == 0
+    assert losses[0]['total'] != losses[1]['total'] != losses[2]['total']
+    assert 0.0 < losses[-1]['dis'] < 5.0 and losses[-1]['loss'] > 0.0
+    G, T3 = p.s2ag_generator, p.trimodal_generator
+    G.eval()
+    T3.eval()
+    try:
+        with torch.no_grad():
+            outs = []
+            for sl in (slice(0, B), slice(0, B // 2), slice(B // 2, B)):
+                noise.manual_seed(11)
+                outs.append((G(pre[sl], text[sl], mfcc[sl], vid[sl])[2], T3.audio_encoder(audio[sl]),
+                             G.text_encoder(text[sl])[0]))
+            for i in range(3):
+                assert rel(torch.cat((outs[1][i], outs[2][i])), outs[0][i]) < 1e-5, i
+            assert outs[0][1].shape == (B, T, 32)
+    finally:
+        G.train()
+        T3.train()
+    assert ops.coop_gru_timeouts() == 0

@@ -109,10 +109,14 @@ def _g_noise(G, nz, B, T, hidden, p, p_emb):
     return pin
 
 
-@pytest.mark.parametrize('which', ['G', 'GA'])
-def test_generator_train_mode_with_dropout_forward_and_all_gradients(which):
-    from speech2affective_gestures_amd import noise
-    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 3, 5000
+@pytest.mark.parametrize('which,hidden,n_words,B', [('G', 32, 64, 3), ('GA', 32, 64, 3), ('G', 300, 2000, 88)])
+def test_generator_train_mode_with_dropout_forward_and_all_gradients(which, hidden, n_words, B):
+    """Forward and every parameter gradient against the oracle fed the product's materialised masks.  The H = 300,
+    B = 88 case runs the kernels the bench runs: the two-slice cooperative GRU (B > 16: one workgroup alternates between
+    two 16-clip slices; here 5 full slices + a ragged one of 8 clips), its cooperative BPTT, the split-operand
+    projection GEMMs (>= 4 GFLOP) and the bf16-pipe TCN convs (>= 1 GFLOP)."""
+    from speech2affective_gestures_amd import noise, ops
+    n_spk, s0 = 12, 5000
     cfg, mods, sds = build_product(hidden, n_words, n_spk, 0.3, s0, which=(which,))
     G = mods[which].train()
     inp = O.recipe_inputs(B, 34, s0 + 10, n_words, n_spk)
@@ -144,6 +148,7 @@ def test_generator_train_mode_with_dropout_forward_and_all_gradients(which):
     # BN running statistics were updated identically
     for k in ('aff_encoder.batch_norm1.running_mean', 'aff_encoder.st_gcn2.tcn.3.running_var'):
         assert rel(G.state_dict()[k], sd[k]) < TOL
+    assert ops.coop_gru_timeouts() == 0
 
 
 def test_discriminators_train_mode_with_dropout_gradients():

@@ -769,3 +769,51 @@ def test_fused_adam_matches_torch_adam(S):
         opt_g.step()
     for p, q in zip(ref, gp):
         assert rel(q, p) < 1e-5
+
+
+@pytest.mark.parametrize('n_entries,dim,world,cap,n_tok', [(20000, 300, 8, 1152, 4352), (64, 5, 3, 40, 70), (1030, 300, 1, 64, 60)])
+def test_touched_row_exchange_kernels(S, n_entries, dim, world, cap, n_tok):
+    """csrc/rows.hip: sorted-unique row list (bit-exact vs torch.unique), [id | row] records, and the rank-ordered merge of
+    `world` replicas' records (bit-exact vs a sequential sum in rank order; every replica touches the PAD row 0)."""
+    ops = S['ops']
+    ops.init_tickets(torch.device('cuda', 0))
+    g = torch.Generator().manual_seed(n_entries + world)
+    gathered = torch.zeros(world, cap, dim + 1, device='cuda')
+    want = {}
+    dense_r = []
+    for r in range(world):
+        ids = torch.randint(0, n_entries, (n_tok,), generator=g)
+        ids[::3] = 0
+        ids[1::7] = ids[2]                                           # repeats
+        ids = ids[:max(1, n_tok // 12)].repeat(12)[:n_tok] if n_tok > cap else ids      # keep the unique count <= cap
+        dense = torch.zeros(n_entries, dim)
+        dense.index_add_(0, ids, torch.randn(ids.numel(), dim, generator=g))
+        u = torch.unique(ids)
+        assert u.numel() <= cap
+        uids = torch.empty(cap, dtype=torch.int32, device='cuda')
+        ops.rows_unique_raw(ids.cuda(), n_entries, uids)
+        assert torch.equal(uids[:u.numel()].cpu().long(), u) and bool((uids[u.numel():] == n_entries).all())
+        rec = torch.empty(cap, dim + 1, device='cuda')
+        ops.rows_pack_raw(dense.cuda(), uids, rec)
+        assert torch.equal(rec[:, 0].contiguous().view(torch.int32), uids)
+        assert torch.equal(rec[:u.numel(), 1:].cpu(), dense[u]) and float(rec[u.numel():, 1:].abs().max() if u.numel() < cap else 0) == 0
+        gathered[r] = rec
+        for i in u.tolist():
+            want[i] = dense[i].clone() if i not in want else want[i] + dense[i]
+        dense_r.append(dense)
+    out = dense_r[0].cuda().clone()                                   # replica 0's view: its own dense gradient
+    ops.rows_merge_raw(gathered, out)
+    out = out.cpu()
+    touched = torch.zeros(n_entries, dtype=torch.bool)
+    for i, v in want.items():
+        assert torch.equal(out[i], v), i
+        touched[i] = True
+    assert torch.equal(out[~touched], dense_r[0][~touched])           # rows nobody listed are left alone
+    assert ops.coop_gru_timeouts() == 0
+    # capacity overflow is reported through the sticky error word (bit 1), loudly at the trainer's next read-back
+    small = torch.empty(2, dtype=torch.int32, device='cuda')
+    ops.rows_unique_raw(torch.arange(5, device='cuda'), n_entries, small)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='row capacity'):
+        ops.check_coop_flag(ops.coop_error_flag().cpu()[0].item())
+    ops._COOP_FLAG[0].zero_()

@@ -26,17 +26,17 @@ def rel(a, b):
     return float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
 
 
-def make_processor(hidden, n_words, n_spk, B, seed0, drop, hip_graph=False, **extra):
+def make_processor(hidden, n_words, n_spk, B, seed0, drop, hip_graph=False, T=34, audio_len=36267, **extra):
     from speech2affective_gestures_amd import processor_v2 as P
-    cfg = make_cfg(hidden, drop)
+    cfg = make_cfg(hidden, drop, T)
     lang = types.SimpleNamespace(n_words=n_words, word_embedding_weights=None)
-    meta = types.SimpleNamespace(n_poses=34, expected_audio_length=36267, num_mfcc_combined=37, lang_model=lang,
+    meta = types.SimpleNamespace(n_poses=T, expected_audio_length=audio_len, num_mfcc_combined=37, lang_model=lang,
                                  speaker_model=Vocab(n_spk), n_samples=0)
     args = types.SimpleNamespace(batch_size=B, train_s2ag=True, work_dir_s2ag=None, save_log=False, print_log=False,
                                  hip_graph=hip_graph, **extra)
     pr = P.Processor('.', args, cfg, {'train_data_s2ag': meta, 'val_data_s2ag': meta, 'test_data_s2ag': meta}, 27, 3,
                      16000)
-    sds = recipe_sds(hidden, n_words, n_spk, seed0)
+    sds = recipe_sds(hidden, n_words, n_spk, seed0, n_poses=T, mfcc_length=pr.mfcc_length)
     pr.s2ag_generator.load_state_dict(sds['G'], strict=True)
     pr.s2ag_discriminator.load_state_dict(sds['D'], strict=True)
     pr.trimodal_generator.load_state_dict(sds['T3'], strict=True)
@@ -157,6 +157,39 @@ def test_two_steps_with_dropout_match_the_oracle(monkeypatch):
             ok, info = adam_close(v, D[k], 1e-4, 2) if 'running' not in k else (rel(v, D[k]) < TOL, None)
             assert ok, (k, info)
     assert int(pr.s2ag_generator.state_dict()['aff_encoder.batch_norm1.num_batches_tracked']) == 6
+
+
+def test_long_clip_steps_136_frames_match_the_oracle(monkeypatch):
+    """BASELINE configs[4] as a STEP (not only a forward): T = 136 frames, 146 000 audio samples (the wave encoder then
+    yields exactly 136 frames), mfcc_length = ceil(146000 / 512) = 286 as the reference derives it (processor_v2.py:124),
+    D.out2 sized from n_poses (net/multimodal_context_net_v2.py:562 hard-codes 34).  Two training steps with dropout on
+    against the oracle's gan_step fed the product's materialised masks: losses, metric, every generator gradient."""
+    from speech2affective_gestures_amd import noise, ops
+    from speech2affective_gestures_amd import processor_v2 as P
+    hidden, n_words, n_spk, B, s0, T, AL = 32, 64, 12, 3, 8600, 136, 146000
+    pr, sds = make_processor(hidden, n_words, n_spk, B, s0, 0.3, T=T, audio_len=AL)
+    assert pr.mfcc_length == 286 and pr.s2ag_discriminator.out2.weight.shape == (1, T)
+    G, D, T3 = ({k: v.clone() for k, v in sds[n].items()} for n in ('G', 'D', 'T3'))
+    gopt, dopt, scfg, oc = O.AdamState(), O.AdamState(), O.StepCfg(), oracle_cfg(hidden, 0.3, T)
+    noise.manual_seed(STEP_SEED)
+    for s in range(2):
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(s))
+        monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm.cuda())
+        inp = O.recipe_inputs(B, T, s0 + 100 + s, n_words, n_spk, audio_len=AL, mfcc_len=286)
+        gi = to_cuda(inp)
+        nz = _materialise_step_noise(pr, PASSES_PER_STEP * s, B, T, hidden)
+        nz.perm = perm
+        ret = pr.forward_pass_s2ag(gi['in_text'], gi['in_audio'], gi['in_mfcc'], gi['target'], gi['vid'], True)
+        monkeypatch.undo()
+        metric, losses, grads = O.gan_step(G, D, T3, gopt, dopt, oc, scfg, inp['in_text'], inp['in_audio'],
+                                           inp['in_mfcc'], inp['target'], inp['vid'], epoch=1, noise=nz)
+        for k in ('dis', 'total', 'loss', 'KLD', 'DIV_REG', 'gen'):
+            assert pr.last_losses[k] == pytest.approx(losses[k], rel=TOL, abs=1e-6), (s, k)
+        assert ret[0] == pytest.approx(metric, rel=5e-3, abs=2e-6)
+        for k, p in pr.s2ag_generator.named_parameters():
+            if '.net.' not in k:
+                assert grad_err(p.grad, grads['G'][k], k) < 10 * TOL, (s, k)
+    assert ops.coop_gru_timeouts() == 0
 
 
 def test_validation_branch_matches_the_oracle(monkeypatch):
@@ -309,6 +342,79 @@ def test_prefetching_batch_feeder_matches_the_host_path():
         for h, f in zip(hb, fb):
             assert h.dtype == f.dtype and h.shape == f.shape and torch.equal(h, f)
     assert fed[0][2].dtype == torch.float32 and float(fed[0][2].abs().max()) <= 1.5 * 30000 / 32767 + 1e-6
+
+
+@pytest.mark.gpu
+def test_world_size_1_rccl_between_graph_segments():
+    """The data-parallel step (graph segments with RCCL collectives between and beside them, gradient buckets in
+    reverse-autograd order, touched-row exchange of the embedding gradient) executed for real on ONE GPU: a
+    world-size-1 RCCL group (S2AG_FORCE_DIST=1) must leave six graph-replayed steps unchanged against the plain
+    single-process step -- it proves the stream ordering around the eager collectives, and that RCCL runs at all."""
+    import json
+    import subprocess
+    import sys
+
+    def probe(force):
+        env = dict(os.environ, S2AG_FORCE_DIST='1' if force else '0', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(29700 + os.getpid() % 200), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 's2ag_dist_probe.py')],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('PROBE ')][-1]
+        return json.loads(line[6:])
+    plain, forced = probe(False), probe(True)
+    assert not plain['dist'] and forced['dist'] and forced['active'] and forced['timeouts'] == 0
+    assert forced['segments'] > plain['segments'] and forced['collectives'] >= 6 * 4
+    for a, b in zip(plain['steps'], forced['steps']):
+        for k in a:      # atomically merged gradients: summation order differs between runs (cf. graph replay == eager)
+            assert b[k] == pytest.approx(a[k], rel=1e-3, abs=1e-6), k
+    for k in plain['sums']:
+        assert forced['sums'][k] == pytest.approx(plain['sums'][k], rel=2e-4), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hip_graph', [False, True])
+def test_synthesis_after_training_steps_uses_the_current_weights(golden_dir, hip_graph):
+    """synthesize_clip in a process that has trained: (1) the generator's per-step encoder sharing (keyed on buffer
+    addresses) must be off, or every window reuses window 0's pose/audio features; (2) tensors derived from the weights
+    (weight-normed / folded / tap-major / split planes) and the synthesis graph must follow the weights the replayed
+    training graphs left behind.  Checked against the oracle loop run from the trained state_dicts, twice (the second
+    call after one more step: the synthesis graph is re-captured)."""
+    import sys
+    from speech2affective_gestures_amd import noise, ops
+    sys.path.insert(0, golden_dir)
+    import synth_recipe as R
+    g = dict(np.load(os.path.join(golden_dir, 'synth_small.npz')))
+    audio, words, mfcc, _, _ = R.clip_fixture()
+    B = 4
+    pr, _ = make_processor(R.HIDDEN, R.N_WORDS, R.N_SPK, B, R.SEED0, 0.3, hip_graph=hip_graph)
+    pr.s2ag_config_args.motion_resampling_framerate = R.FPS
+    index = {w: 4 + i for i, w in enumerate(R.VOCAB)}
+    pr.lang_model = types.SimpleNamespace(get_word_index=lambda w: index.get(w, 3), n_words=R.N_WORDS,
+                                          word_embedding_weights=None)
+    inp = to_cuda(O.recipe_inputs(B, 34, R.SEED0 + 10, R.N_WORDS, R.N_SPK))
+    oc = O.ModelCfg(hidden_size=R.HIDDEN, hidden_size_s2eg=R.HIDDEN, dropout_prob=0.0)
+    noise.manual_seed(5)
+    for rounds in (2, 1):
+        for _ in range(rounds):
+            pr.train_step(inp['in_text'], inp['in_audio'], inp['in_mfcc'], inp['target'], inp['vid'])
+        assert pr.s2ag_generator.share_passes
+        sdG = {k: v.detach().cpu().clone() for k, v in pr.s2ag_generator.state_dict().items()}
+        sdT = {k: v.detach().cpu().clone() for k, v in pr.trimodal_generator.state_dict().items()}
+        noise.manual_seed(21)
+        out_t, out_g = pr.synthesize_clip(g['seed_seq'], audio, R.SR, words, mfcc_windows=mfcc,
+                                          speaker_vid_idx=R.SPEAKER)
+        G, T3 = pr.s2ag_generator, pr.trimodal_generator
+        assert G.training and G.share_passes            # restored for the next training step
+        eps = [ops.normal_noise(torch.tensor([21, k], dtype=torch.int64, device='cuda'),
+                                T3.z_site if k % 2 == 0 else G.z_site, (1, 16)).cpu() for k in range(6)]
+        with torch.no_grad():
+            ref_t, ref_g = O.synthesize_clip(sdG, sdT, oc, g['seed_seq'], audio, R.SR, words, mfcc, R.SPEAKER, eps,
+                                             lambda w: index.get(w, 3), fps=R.FPS)
+        assert rel(torch.from_numpy(out_t), torch.from_numpy(ref_t)) < TOL
+        assert rel(torch.from_numpy(out_g), torch.from_numpy(ref_g)) < TOL
+        noise.manual_seed(5 + rounds)
+    assert ops.coop_gru_timeouts() == 0
 
 
 @pytest.mark.gpu

@@ -211,6 +211,104 @@ def test_other_speaker_sampler_excludes_the_batch():
     assert len(set(out.tolist())) == 16           # every other speaker is reachable
 
 
+def _cpu_row_kernels():
+    """torch-CPU doubles of csrc/rows.hip (test infrastructure: the product binds the HIP kernels, ops.rows_*_raw)."""
+    from speech2affective_gestures_amd.parallel import RowKernels
+
+    def unique(ids, n_entries, uids_out):
+        u = torch.unique(ids)
+        assert u.numel() <= uids_out.numel()
+        uids_out.fill_(n_entries)
+        uids_out[:u.numel()] = u.to(torch.int32)
+
+    def pack(dense, uids, records_out):
+        n_entries = dense.shape[0]
+        live = uids < n_entries
+        records_out.zero_()
+        records_out[:, 0] = uids.view(torch.float32)
+        records_out[live, 1:] = dense[uids[live].long()]
+
+    def merge(gathered, dense):
+        n_entries = dense.shape[0]
+        ids = gathered[:, :, 0].contiguous().view(torch.int32)
+        acc = {}
+        for r in range(gathered.shape[0]):                      # rank order
+            for s in range(gathered.shape[1]):
+                i = int(ids[r, s])
+                if i < n_entries:
+                    acc[i] = gathered[r, s, 1:].clone() if i not in acc else acc[i] + gathered[r, s, 1:]
+        for i, v in acc.items():
+            dense[i] = v
+    return RowKernels(unique=unique, pack=pack, merge=merge)
+
+
+def _guarded(fn, rank, world, port, q):
+    try:
+        fn(rank, world, port, q)
+    except BaseException:
+        import traceback
+        q.put('rank %d: %s' % (rank, traceback.format_exc()))
+        q.put('rank %d failed' % rank)          # unblock the parent's second get
+
+
+def _exchange_worker(rank, world, port, q):
+    """One replica of the generator's gradient exchange (parallel.GradExchange) over gloo: arena laid out
+    [embedding rows | bucket B | bucket A]; every rank fills its own gradient, the schedule must leave the SUM."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from speech2affective_gestures_amd.parallel import DataParallelContext, GradExchange
+    dp = DataParallelContext.from_env(backend='gloo')
+    n_entries, dim, nb, na, cap = 50, 6, 37, 64, 16
+    out = []
+    for step in range(2):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        ids = torch.randint(0, n_entries, (3, 5), generator=g)
+        ids[:, 0] = 0                                           # the PAD row is touched by every rank
+        grad = torch.zeros(n_entries * dim + nb + na)
+        emb = grad[:n_entries * dim].view(n_entries, dim)
+        emb.index_add_(0, ids.reshape(-1), torch.randn(ids.numel(), dim, generator=g))
+        grad[n_entries * dim:] = torch.randn(nb + na, generator=g)
+        mine = grad.clone()
+        if step == 0:
+            ex = GradExchange(dp, grad, n_entries * dim + nb, rows=(0, n_entries * dim, n_entries, dim), row_cap=cap,
+                              kernels=_cpu_row_kernels())
+        else:
+            ex.grad.copy_(grad)
+            grad = ex.grad
+        assert [b[0] for b in ex.buckets] == ['A', 'B'] and ex.bytes_per_step()['rows'] == 4 * cap * (dim + 1)
+        ex.launch_a()
+        ex.pack_rows(ids)
+        ex.exchange_rest()
+        ex.merge_rows()
+        out.append((mine.tolist(), grad.tolist()))
+    dp.barrier()
+    q.put((rank, out, dp.n_collectives))
+
+
+def test_gradient_exchange_schedule_world_size_2_gloo():
+    """Bucketed all-reduce (A asynchronous, B at the end) + touched-row all-gather of the embedding gradient == the
+    plain sum of the two replicas' dense gradients, bit-identical on both ranks (rank-ordered merge)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29811 + os.getpid() % 150
+    procs = [ctx.Process(target=_guarded, args=(_exchange_worker, r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    assert not any(isinstance(r, str) for r in res), res
+    res = sorted(res)
+    for p in procs:
+        p.join(timeout=60)
+    (_, out0, c0), (_, out1, c1) = res
+    assert c0 == c1 == 2 * 3                      # per step: all-reduce A, all-reduce B, all-gather rows
+    for (m0, g0), (m1, g1) in zip(out0, out1):
+        assert g0 == g1                           # identical bits on both ranks
+        want = (torch.tensor(m0) + torch.tensor(m1))
+        assert torch.allclose(torch.tensor(g0), want, rtol=0, atol=1e-6)
+        assert torch.equal(torch.tensor(g0), want)      # two addends: the rank-ordered sum IS the plain sum
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
