@@ -680,7 +680,16 @@ class Processor(object):
         if make_video or calculate_metrics:
             raise NotImplementedError('rendering / FGD evaluation are outside the MI355X hot path')
         ops.begin_step()
+        # encoder sharing is scoped to THIS step (the cache is keyed on buffer addresses): off again when the step ends
         self.s2ag_generator.share_passes = (3 if self._use_gan() else 2) if self.share_encoders else None
+        try:
+            return self._step(in_text, in_audio, in_mfcc, target_poses, vid_indices, train) + \
+                (losses_all_trimodal, joint_mae_trimodal, accel_trimodal, losses_all, joint_mae, accel)
+        finally:
+            self.s2ag_generator.share_passes = None
+            self.s2ag_generator._shared = None
+
+    def _step(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, train):
         pre_seq = self._make_pre_seq(target_poses)
         dis_error = None
         if self._use_gan():
@@ -697,8 +706,7 @@ class Processor(object):
                 ex.exchange_rest()
                 ex.merge_rows()
             self.s2ag_gen_optimizer.step(self.dp.grad_scale)
-        metric = self._finish(comps, dis_error)
-        return metric, losses_all_trimodal, joint_mae_trimodal, accel_trimodal, losses_all, joint_mae, accel
+        return (self._finish(comps, dis_error),)
 
     # ---- hipGraph replay of the training step (static shapes) ---------------------------------------------
     def _build_graphed(self, in_text, in_audio, in_mfcc, target_poses, vid_indices):
@@ -730,6 +738,8 @@ class Processor(object):
                 ex.merge_rows()
             self.s2ag_gen_optimizer.step(self.dp.grad_scale)
             ops.stamp('step end (G-Adam done)')
+            self.s2ag_generator.share_passes = None        # sharing is scoped to the step (see forward_pass_s2ag)
+            self.s2ag_generator._shared = None
 
         # Single process: three segments, nothing between them.  Data parallel: the collectives run from the host
         # between the segments -- the graphs never contain RCCL nodes -- and bucket A's all-reduce runs BESIDE the
