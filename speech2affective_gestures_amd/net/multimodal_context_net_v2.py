@@ -267,17 +267,33 @@ class _SpeakerZ:
     # Data-parallel trainers cut the autograd graph at the decoder's input: everything behind the cut (GRU, out) is
     # back-propagated first and its gradient bucket goes on the wire while the encoders' backward still runs
     # (parallel.GradExchange).  ``cut_backward = True`` makes a grad-enabled forward leave ``(full, leaf)`` in ``_cut``:
-    # ``loss.backward()`` then stops at ``leaf``; ``torch.autograd.backward(full, leaf.grad)`` runs the rest.
+    # ``loss.backward()`` then stops at ``leaf``; ``torch.autograd.backward(full, leaf.grad)`` runs the rest.  The
+    # speaker statistics (z_mu, z_log_var feed the KLD term directly) are cut the same way, so that the first half
+    # never enters the encoder side of the graph: ``_cut`` = ([full tensors], [leaves]).
     cut_backward = False
     _cut = None
+
+    def _cut_here(self, *tensors):
+        """Detached leaves of ``tensors`` (recorded in ``_cut``) when the backward cut is armed, else ``tensors``."""
+        if not (self.cut_backward and torch.is_grad_enabled()):
+            return tensors
+        if self._cut is None:
+            self._cut = ([], [])
+        out = []
+        for t in tensors:
+            if t is None or not t.requires_grad:
+                out.append(t)
+                continue
+            leaf = t.detach().requires_grad_(True)
+            self._cut[0].append(t)
+            self._cut[1].append(leaf)
+            out.append(leaf)
+        return tuple(out)
 
     def _decode(self, in_data, z_context, nz, out_slope):
         if z_context is not None:
             in_data = torch.cat((in_data, z_context.unsqueeze(1).expand(-1, in_data.shape[1], -1)), dim=2)
-        if self.cut_backward and torch.is_grad_enabled() and in_data.requires_grad:
-            leaf = in_data.detach().requires_grad_(True)
-            self._cut = (in_data, leaf)
-            in_data = leaf
+        (in_data,) = self._cut_here(in_data)
         h = self.gru.run(in_data, nz, sum_dirs=True)                                     # (B, T, H), halves summed
         h = ops.linear(h, self.out[0].weight, self.out[0].bias, act=ACT_LEAKY, slope=out_slope)
         return ops.linear(h, self.out[2].weight, self.out[2].bias)
@@ -465,6 +481,7 @@ class PoseGenerator(nn.Module, _SpeakerZ):
                     'Audio and text features must have the same number of time steps. ' \
                     'Found time steps: audio features: {}, text features: {}.'.format(audio.shape[1], text.shape[1])
             out = self._decode(self._context(pre, audio, text), z_context, nz, out_slope=0.01)
+            z_mu, z_log_var = self._cut_here(z_mu, z_log_var)
         return out, z_context, z_mu, z_log_var
 
 

@@ -645,12 +645,13 @@ class Processor(object):
         """Second half of the generator's backward pass in data-parallel runs: from the decoder's input through the
         encoders (bucket A is already on the wire), then the touched-row records of the embedding gradient."""
         G = self.s2ag_generator
-        full, leaf = G._cut
+        fulls, leaves = G._cut
         G._cut, G.cut_backward = None, False
+        pairs = [(f, l.grad) for f, l in zip(fulls, leaves) if l.grad is not None]
         ops.set_main_stream()
         if self.overlap_passes and self.encoders_aside and G.share_passes and self._use_gan():
             ops.mark_side_stream(self._side[1])
-        torch.autograd.backward([full], [leaf.grad])
+        torch.autograd.backward([f for f, _ in pairs], [g for _, g in pairs])
         ops.join_side_streams()
         ex.pack_rows(in_text)
         ops.stamp('G:end')

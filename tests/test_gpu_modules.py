@@ -137,22 +137,35 @@ def test_generator_train_mode_with_dropout_forward_and_all_gradients(which, hidd
     d_out, d_mu = torch.randn(o_r.shape, generator=gen), torch.randn(mu_r.shape, generator=gen)
     (o_r * d_out).sum().add((mu_r * d_mu).sum()).add((lv_r * d_mu).sum()).backward()
     (out * d_out.cuda()).sum().add((mu * d_mu.cuda()).sum()).add((lv * d_mu.cuda()).sum()).backward()
-    errs = {}
+    errs, l2 = {}, {}
     for k, p in G.named_parameters():
         if '.net.' in k:
             continue
         assert p.grad is not None, k
         errs[k] = grad_err(p.grad, sd[k].grad, k)
+        a, b = p.grad.detach().cpu().double(), sd[k].grad.double()
+        l2[k] = 0.0 if errs[k] == 0.0 else float((a - b).norm() / max(1e-12, float(b.norm())))
     top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
-    print(f'[grad parity {which} H={hidden} B={B}] out {rel(out, o_r):.2e}; worst gradients: ' +
-          ', '.join(f'{k} {v:.2e}' for k, v in top))
-    # At H = 300 the default products carry 16 mantissa bits (two bf16 pieces per fp32 operand): through four BPTT layers
-    # and eight TCN convs the deepest gradient (the word embedding's) is off by ~1e-3 of its largest element; with
-    # S2AG_GRU_SPLIT=3 (fp32-equivalent products) or =0 (f32 MFMA) the fp32 tolerance below holds at every width.
-    two_piece = hidden >= 128 and ops._lib().s2ag_gru_coop_split_pieces() == 2
-    gtol = 3e-3 if two_piece else 5 * TOL
-    for k, e in errs.items():
-        assert e < gtol, (k, e)
+    print(f'[grad parity {which} H={hidden} B={B}] out {rel(out, o_r):.2e}; worst gradients (max-norm): ' +
+          ', '.join(f'{k} {v:.2e}' for k, v in top) + '; worst relative L2: ' +
+          ', '.join(f'{k} {v:.2e}' for k, v in sorted(l2.items(), key=lambda kv: -kv[1])[:3]))
+    if hidden < 128:
+        for k, e in errs.items():
+            assert e < 5 * TOL, (k, e)
+    else:
+        # At this width (0.9 M ReLU inputs per TCN conv) a handful of pre-activations lie within rounding distance of 0:
+        # product and oracle then take different sides of the ReLU for that ONE element (tools/diag_relu_flips.py: 0-1
+        # per layer, |pre| < 5e-7), which moves one row of that layer's weight gradient / one bias-gradient entry by
+        # up to ~1e-2 of the tensor's largest element -- in every product mode, the f32 MFMA included, and in the
+        # reference against itself on another BLAS.  So: max-norm within 2e-2 everywhere and within the fp32 tolerance
+        # for all but a few tensors; the relative L2 error (which one flipped element cannot move) within 1e-3 (two
+        # bf16 pieces: 16-bit products through 4 BPTT layers + 8 convs) / 3e-4 (fp32-equivalent products).
+        two_piece = ops._lib().s2ag_gru_coop_split_pieces() == 2
+        loose = [k for k, e in errs.items() if e >= (3e-3 if two_piece else 5 * TOL)]
+        assert len(loose) <= 6 and all('text_encoder' in k for k in loose), loose
+        assert max(errs.values()) < 2e-2, top
+        for k, e in l2.items():
+            assert e < (1e-3 if two_piece else 3e-4), (k, e)
     # BN running statistics were updated identically
     for k in ('aff_encoder.batch_norm1.running_mean', 'aff_encoder.st_gcn2.tcn.3.running_var'):
         assert rel(G.state_dict()[k], sd[k]) < TOL
