@@ -145,9 +145,10 @@ def test_two_steps_with_dropout_match_the_oracle(monkeypatch):
         for k in ('dis', 'total', 'loss', 'KLD', 'DIV_REG', 'gen'):
             assert pr.last_losses[k] == pytest.approx(losses[k], rel=TOL, abs=1e-6), (s, k)
         assert ret[0] == pytest.approx(metric, rel=5e-3, abs=2e-6)
-        for k, p in pr.s2ag_generator.named_parameters():
-            if '.net.' not in k:
-                assert grad_err(p.grad, grads['G'][k], k) < 10 * TOL, (s, k)
+        errs = {k: grad_err(p.grad, grads['G'][k], k) for k, p in pr.s2ag_generator.named_parameters()
+                if '.net.' not in k}
+        bad = sorted(((e, k) for k, e in errs.items() if e >= 10 * TOL), reverse=True)
+        assert not bad, (s, len(bad), len(errs), bad[:8])
     for k, v in pr.s2ag_generator.state_dict().items():
         if not k.endswith('num_batches_tracked') and not is_noise_driven_after_adam(k):
             ok, info = adam_close(v, G[k], 5e-4, 2) if 'running' not in k else (rel(v, G[k]) < TOL, None)
