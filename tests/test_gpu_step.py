@@ -32,6 +32,8 @@ def make_processor(hidden, n_words, n_spk, B, seed0, drop, hip_graph=False, T=34
     lang = types.SimpleNamespace(n_words=n_words, word_embedding_weights=None)
     meta = types.SimpleNamespace(n_poses=T, expected_audio_length=audio_len, num_mfcc_combined=37, lang_model=lang,
                                  speaker_model=Vocab(n_spk), n_samples=0)
+    if os.environ.get('S2AG_TEST_OVERLAP') == '0':       # debugging: every pass of the step on ONE stream
+        extra.setdefault('overlap_passes', False)
     args = types.SimpleNamespace(batch_size=B, train_s2ag=True, work_dir_s2ag=None, save_log=False, print_log=False,
                                  hip_graph=hip_graph, **extra)
     pr = P.Processor('.', args, cfg, {'train_data_s2ag': meta, 'val_data_s2ag': meta, 'test_data_s2ag': meta}, 27, 3,
