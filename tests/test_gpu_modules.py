@@ -158,12 +158,14 @@ def test_generator_train_mode_with_dropout_forward_and_all_gradients(which, hidd
         # per TCN conv with |pre| < 5e-7; tools/diag_gru_in_grad.py: one flip in `out` moves d(loss)/d(GRU input) by 5e-2
         # max-norm / 3e-3 L2 at B = 88 while the same kernels agree to 3.6e-6 at B = 128 where none occurs).  A flip is a
         # property of the example, not of a kernel -- the reference against itself on another BLAS does the same -- and
-        # its probability grows with the forward rounding difference (2-piece products: ~5e-6).  So here: forward
-        # strictly (above), every gradient within 5e-3 relative L2 and 0.1 max-norm of the oracle's; the kernels'
-        # own precision at these sizes is pinned by the kink-free tests in test_gpu_ops.py (GRU fwd/BPTT, split GEMMs,
-        # convs) at 2e-4 / 2e-5.
+        # its probability grows with the forward rounding difference (2-piece products: ~5e-6; with the f32 MFMA the
+        # same test sees flips for other mask draws).  So here: forward strictly (above), every gradient within 2e-2
+        # relative L2 (one flipped bias-gradient entry of 300 is ~5e-3) and 0.1 max-norm of the oracle's, all but a few
+        # tensors within 1e-3 L2; the kernels' own precision at these sizes is pinned by the kink-free tests in
+        # test_gpu_ops.py (GRU fwd/BPTT, split GEMMs, convs) at 2e-4 / 2e-5.
         for k in errs:
-            assert l2[k] < 5e-3 and errs[k] < 0.1, (k, errs[k], l2[k])
+            assert l2[k] < 2e-2 and errs[k] < 0.1, (k, errs[k], l2[k])
+        assert sum(v >= 1e-3 for v in l2.values()) <= len(l2) // 4, sorted(l2.items(), key=lambda kv: -kv[1])[:8]
     # BN running statistics were updated identically
     for k in ('aff_encoder.batch_norm1.running_mean', 'aff_encoder.st_gcn2.tcn.3.running_var'):
         assert rel(G.state_dict()[k], sd[k]) < TOL
