@@ -323,6 +323,12 @@ int s2ag_gru_coop_error_word_offset(int B, int T, int H, int backward, long long
  * (net/multimodal_context_net_v2.py:480-486) cannot fail silently, so neither may its replacement. */
 int s2ag_gru_coop_set_error_flag(int* device_word);
 
+/* Measurement aid (tools/pmc_traffic.py): touches `bytes` of `buf` with a known access pattern so the rocprofv3 counters
+ * FETCH_SIZE / WRITE_SIZE can be calibrated against a known byte count in OUR access shapes: 0 = 16 B/lane coalesced
+ * reads, 1 = 8 B/lane agent-scope reads (the cooperative GRU's exchange polling), 2 = 16 B/lane writes, 3 = 8 B/lane
+ * agent-scope writes.  Not on the training path. */
+int s2ag_calib_traffic(void* buf, long long bytes, int pattern, void* stream);
+
 /* ---- touched-row exchange of the embedding gradient between data-parallel replicas (csrc/rows.hip) ----------------
  * Replaces, for text_encoder.embedding.weight (nn.Embedding(n_words, 300), net/multimodal_context_net_v2.py:70-73), the
  * gradient reduction nn.DataParallel performs onto GPU 0 (processor_v2.py:167-172): only the rows a batch touches travel.

@@ -90,6 +90,7 @@ SIGNATURES = {
     's2ag_gru_coop_bwd': [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp, vp],
     's2ag_gru_coop_error_word_offset': [ci, ci, ci, ci, C.POINTER(cll)],
     's2ag_gru_coop_set_error_flag': [vp],
+    's2ag_calib_traffic': [vp, cll, ci, vp],
     's2ag_rows_unique': [vp, ci, ci, ci, vp, vp, vp, vp, vp],
     's2ag_rows_pack': [vp, vp, ci, ci, ci, vp, vp],
     's2ag_rows_merge': [vp, ci, ci, ci, ci, vp, vp],

@@ -576,6 +576,52 @@ extern "C" int s2ag_to_f32(const void* x, int src_is_f16, float* out, long long 
     return 0;
 }
 
+// ---- measurement aid: known-byte-count access patterns for calibrating the FETCH_SIZE / WRITE_SIZE counters -----------
+namespace {
+__global__ __launch_bounds__(256) void calib_read16_k(const uint4* __restrict__ p, size_t n, unsigned* sink) {
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint4 v = p[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u) *sink = acc;
+}
+// the cooperative GRU's polling load: 8 bytes per lane, agent scope (bypasses the non-coherent caches)
+__global__ __launch_bounds__(256) void calib_read8_agent_k(const unsigned long long* p, size_t n, unsigned* sink) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        acc ^= __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (acc == 0x9e3779b97f4a7c15ull) *sink = 1u;
+}
+__global__ __launch_bounds__(256) void calib_write16_k(uint4* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        p[i] = uint4{(unsigned)i, 1u, 2u, 3u};
+}
+__global__ __launch_bounds__(256) void calib_write8_agent_k(unsigned long long* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        __hip_atomic_store(p + i, (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+
+extern "C" int s2ag_calib_traffic(void* buf, long long bytes, int pattern, void* stream) {
+    if (!buf || bytes < 4096 || pattern < 0 || pattern > 3) return S2AG_E_BADARG;
+    unsigned* sink = static_cast<unsigned*>(buf);
+    const dim3 grid(2048), block(256);
+    if (pattern == 0)
+        hipLaunchKernelGGL(calib_read16_k, grid, block, 0, (hipStream_t)stream, static_cast<const uint4*>(buf) + 1,
+                           (size_t)(bytes - 16) / 16, sink);
+    else if (pattern == 1)
+        hipLaunchKernelGGL(calib_read8_agent_k, grid, block, 0, (hipStream_t)stream,
+                           static_cast<const unsigned long long*>(buf) + 1, (size_t)(bytes - 8) / 8, sink);
+    else if (pattern == 2)
+        hipLaunchKernelGGL(calib_write16_k, grid, block, 0, (hipStream_t)stream, static_cast<uint4*>(buf), (size_t)bytes / 16);
+    else
+        hipLaunchKernelGGL(calib_write8_agent_k, grid, block, 0, (hipStream_t)stream,
+                           static_cast<unsigned long long*>(buf), (size_t)bytes / 8);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int s2ag_timestamp(unsigned long long* out, void* stream) {
     if (!out) return S2AG_E_BADARG;
     hipLaunchKernelGGL(timestamp_k, dim3(1), dim3(1), 0, (hipStream_t)stream, out);
