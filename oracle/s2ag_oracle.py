@@ -376,6 +376,19 @@ def pose_generator_abl_audio(sd: SD, cfg: ModelCfg, pre_seq, in_text, in_audio, 
     return out, z, mu, log_var
 
 
+def pose_generator_abl_aff(sd: SD, cfg: ModelCfg, pre_seq, in_text, in_mfcc, vid, training: bool, noise: Noise,
+                           fast: bool = False):
+    """_abl_aff.PoseGenerator.forward (net/multimodal_context_net_v2_abl_aff.py:336-392): no affective encoder, the raw
+    (pose_dim + 1)-column seed sequence is the GRU's pose input."""
+    audio = mfcc_encoder(sd, 'audio_encoder.', in_mfcc, training)
+    text = text_encoder_tcn(sd, 'text_encoder.', in_text, training, cfg.dropout_prob, noise)
+    assert audio.shape[1] == text.shape[1], 'Audio and text features must have the same number of time steps.'
+    z, mu, log_var = _speaker_z(sd, vid, noise)
+    in_data = torch.cat((pre_seq, audio, text, z.unsqueeze(1).expand(-1, pre_seq.shape[1], -1)), dim=2)
+    out = _decode(sd, cfg.dropout_prob, in_data, training, noise, 0.01, fast)
+    return out, z, mu, log_var
+
+
 def pose_generator_trimodal(sd: SD, cfg: ModelCfg, pre_seq, in_text, in_audio, vid, training: bool, noise: Noise,
                             fast: bool = False):
     """PoseGeneratorTriModal.forward (:287-343): raw pre_seq into the GRU; ``nn.LeakyReLU(True)`` in
@@ -765,8 +778,9 @@ def _speaker_shapes(n_spk: int):
 
 
 def generator_shapes(cfg: ModelCfg, n_words: int, n_spk: int, mfcc_length: int = 71, num_mfcc: int = 37,
-                     pose_dim: int = 27, embed: int = 300, audio: str = 'mfcc'):
-    """state_dict layout of PoseGenerator ('mfcc') / _abl_audio.PoseGenerator ('wav')."""
+                     pose_dim: int = 27, embed: int = 300, audio: str = 'mfcc', aff: bool = True):
+    """state_dict layout of PoseGenerator ('mfcc') / _abl_audio.PoseGenerator ('wav') / _abl_aff.PoseGenerator
+    (``aff=False``: no aff_encoder entries, the GRU reads the raw pose_dim + 1 columns)."""
     s: Dict[str, Tuple[int, ...]] = {}
     if audio == 'mfcc':
         chans = [mfcc_length, 64, 64, 48, cfg.n_poses]
@@ -779,10 +793,11 @@ def generator_shapes(cfg: ModelCfg, n_words: int, n_spk: int, mfcc_length: int =
     else:
         s.update(_wav_encoder_shapes('audio_encoder.'))
     s.update(_text_encoder_shapes('text_encoder.', n_words, embed, cfg.hidden_size, cfg.n_layers))
-    s.update(_aff_encoder_shapes('aff_encoder.'))
+    if aff:
+        s.update(_aff_encoder_shapes('aff_encoder.'))
     s.update(_speaker_shapes(n_spk))
     H = cfg.hidden_size_s2eg
-    s.update(_gru_shapes('gru.', 8 + 32 + 32 + 16, H, cfg.n_layers))
+    s.update(_gru_shapes('gru.', (8 if aff else pose_dim + 1) + 32 + 32 + 16, H, cfg.n_layers))
     s['out.0.weight'] = (H // 2, H)
     s['out.0.bias'] = (H // 2,)
     s['out.2.weight'] = (pose_dim, H // 2)
