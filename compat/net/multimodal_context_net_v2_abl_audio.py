@@ -1,0 +1,4 @@
+"""Reference import name -> MI355X implementation (see compat/README.md)."""
+from speech2affective_gestures_amd.net.multimodal_context_net_v2_abl_audio import *  # noqa: F401,F403
+import speech2affective_gestures_amd.net.multimodal_context_net_v2_abl_audio as _impl
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})

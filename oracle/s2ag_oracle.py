@@ -528,6 +528,98 @@ def conv_discriminator(sd: SD, poses: Tensor, training: bool, noise: Noise, fast
 
 
 # ----------------------------------------------------------------------------------------------
+# evaluation metrics: pose auto-encoder (net/embedding_net.py) + Frechet gesture distance
+# ----------------------------------------------------------------------------------------------
+def _bn1(sd: SD, p: str, x: Tensor, training: bool) -> Tensor:
+    """BatchNorm1d over (B, C) or (B, C, L) with the running estimates living in ``sd`` (updated in place)."""
+    return F.batch_norm(x, sd[p + 'running_mean'], sd[p + 'running_var'], sd[p + 'weight'], sd[p + 'bias'], training,
+                        0.1, 1e-5)
+
+
+def pose_encoder_conv(sd: SD, p: str, poses: Tensor, training: bool) -> Tuple[Tensor, Tensor]:
+    """PoseEncoderConv.forward (net/embedding_net.py:42-83) without the re-parametrisation: (mu, log_var)."""
+    x = poses.transpose(1, 2)
+    for i, stride in ((0, 1), (1, 1), (2, 2)):
+        x = F.conv1d(x, sd[f'{p}net.{i}.0.weight'], sd[f'{p}net.{i}.0.bias'], stride=stride)
+        x = F.leaky_relu(_bn1(sd, f'{p}net.{i}.1.', x, training), 0.2)
+    x = F.conv1d(x, sd[p + 'net.3.weight'], sd[p + 'net.3.bias']).flatten(1)
+    x = _bn1(sd, p + 'out_net.1.', F.linear(x, sd[p + 'out_net.0.weight'], sd[p + 'out_net.0.bias']), training)
+    x = _bn1(sd, p + 'out_net.4.', F.linear(x, sd[p + 'out_net.3.weight'], sd[p + 'out_net.3.bias']), training)
+    x = F.linear(x, sd[p + 'out_net.6.weight'], sd[p + 'out_net.6.bias'])      # nn.LeakyReLU(True) = slope 1 = identity
+    return (F.linear(x, sd[p + 'fc_mu.weight'], sd[p + 'fc_mu.bias']),
+            F.linear(x, sd[p + 'fc_log_var.weight'], sd[p + 'fc_log_var.bias']))
+
+
+def pose_decoder_conv(sd: SD, p: str, feat: Tensor, training: bool) -> Tensor:
+    """PoseDecoderConv.forward (:165-217), length 34, no pre-pose branch."""
+    x = _bn1(sd, p + 'pre_net.1.', F.linear(feat, sd[p + 'pre_net.0.weight'], sd[p + 'pre_net.0.bias']), training)
+    x = F.linear(x, sd[p + 'pre_net.3.weight'], sd[p + 'pre_net.3.bias']).view(feat.shape[0], 4, -1)
+    for i in (0, 3):
+        x = F.conv_transpose1d(x, sd[f'{p}net.{i}.weight'], sd[f'{p}net.{i}.bias'])
+        x = F.leaky_relu(_bn1(sd, f'{p}net.{i + 1}.', x, training), 0.2)
+    x = F.conv1d(x, sd[p + 'net.6.weight'], sd[p + 'net.6.bias'])
+    return F.conv1d(x, sd[p + 'net.7.weight'], sd[p + 'net.7.bias']).transpose(1, 2)
+
+
+def embedding_net_pose(sd: SD, poses: Tensor, training: bool, eps: Optional[Tensor] = None):
+    """EmbeddingNet.forward in 'pose' mode (:277-301): (poses_feat, mu, log_var, out_poses); ``eps`` = variational."""
+    mu, log_var = pose_encoder_conv(sd, 'pose_encoder.', poses, training)
+    z = mu if eps is None else mu + eps * torch.exp(0.5 * log_var)
+    return z, mu, log_var, pose_decoder_conv(sd, 'decoder.', z, training)
+
+
+def embedding_net_shapes(pose_dim: int = 27, n_frames: int = 34) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    e, d = 'pose_encoder.', 'decoder.'
+    for i, (ci, co, k) in enumerate(((pose_dim, 32, 3), (32, 64, 3), (64, 64, 4))):
+        s[f'{e}net.{i}.0.weight'], s[f'{e}net.{i}.0.bias'] = (co, ci, k), (co,)
+        s.update(_bn_entries(f'{e}net.{i}.1.', co))
+    s[e + 'net.3.weight'], s[e + 'net.3.bias'] = (32, 64, 3), (32,)
+    flat = 32 * ((((n_frames - 2) - 2) - 4) // 2 + 1 - 2)
+    for i, (ci, co) in zip((0, 3, 6), ((flat, 256), (256, 128), (128, 32))):
+        s[f'{e}out_net.{i}.weight'], s[f'{e}out_net.{i}.bias'] = (co, ci), (co,)
+    s.update(_bn_entries(e + 'out_net.1.', 256))
+    s.update(_bn_entries(e + 'out_net.4.', 128))
+    for n in ('fc_mu', 'fc_log_var'):
+        s[f'{e}{n}.weight'], s[f'{e}{n}.bias'] = (32, 32), (32,)
+    s[d + 'pre_net.0.weight'], s[d + 'pre_net.0.bias'] = (64, 32), (64,)
+    s.update(_bn_entries(d + 'pre_net.1.', 64))
+    s[d + 'pre_net.3.weight'], s[d + 'pre_net.3.bias'] = (4 * n_frames, 64), (4 * n_frames,)
+    s[d + 'net.0.weight'], s[d + 'net.0.bias'] = (4, 32, 3), (32,)
+    s[d + 'net.3.weight'], s[d + 'net.3.bias'] = (32, 32, 3), (32,)
+    s.update(_bn_entries(d + 'net.1.', 32))
+    s.update(_bn_entries(d + 'net.4.', 32))
+    s[d + 'net.6.weight'], s[d + 'net.6.bias'] = (32, 32, 3), (32,)
+    s[d + 'net.7.weight'], s[d + 'net.7.bias'] = (pose_dim, 32, 3), (pose_dim,)
+    return s
+
+
+def frechet_distance(mu1, sigma1, mu2, sigma2, eps: float = 1e-6) -> float:
+    """EmbeddingSpaceEvaluator.calculate_frechet_distance (net/embedding_space_evaluator.py:105-156)."""
+    from scipy import linalg
+    diff = np.asarray(mu1) - np.asarray(mu2)
+    root, _ = linalg.sqrtm(np.asarray(sigma1).dot(np.asarray(sigma2)), disp=False)
+    if not np.isfinite(root).all():
+        off = np.eye(len(diff)) * eps
+        root = linalg.sqrtm((sigma1 + off).dot(sigma2 + off))
+    if np.iscomplexobj(root):
+        if not np.allclose(np.diagonal(root).imag, 0, atol=1e-3):
+            raise ValueError('Imaginary component')
+        root = root.real
+    return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(root))
+
+
+def fgd_scores(generated_feats: np.ndarray, real_feats: np.ndarray) -> Tuple[float, float]:
+    """EmbeddingSpaceEvaluator.get_scores (:74-103): (frechet_dist, mean L1 feature distance)."""
+    try:
+        fd = frechet_distance(generated_feats.mean(0), np.cov(generated_feats, rowvar=False), real_feats.mean(0),
+                              np.cov(real_feats, rowvar=False))
+    except ValueError:
+        fd = 1e+10
+    return fd, float(np.abs(real_feats - generated_feats).sum(1).mean())
+
+
+# ----------------------------------------------------------------------------------------------
 # the GAN step  (processor_v2.py:776-957) and Adam (processor_v2.py:215-220)
 # ----------------------------------------------------------------------------------------------
 @dataclass
@@ -647,13 +739,23 @@ class StepNoise:
 
 def gan_step(G: SD, D: SD, PGT: SD, g_opt: AdamState, d_opt: AdamState, mcfg: ModelCfg, scfg: StepCfg,
              in_text, in_audio, in_mfcc, target, vid, epoch: int, noise: StepNoise, train: bool = True,
-             fast: bool = False, d_drop_noise_off: bool = False):
+             fast: bool = False, d_drop_noise_off: bool = False, ablation: str = 'none'):
     """Processor.forward_pass_s2ag (processor_v2.py:776-957), train branch, use_mfcc = True.
 
     G and D run in train mode (per_train_epoch :961-962); the frozen tri-modal baseline PGT is never
     put in eval mode by the reference either, so it also runs in train mode (BN batch stats, dropout).
     Returns (metric, loss_dict, grads) where metric is the 7-tuple's first element.
     """
+    # ``ablation``: 'none' = PoseGenerator + AffDiscriminator (net/multimodal_context_net_v2.py); 'aff' = the
+    # _abl_aff pairing (generator without the affective encoder + ConvDiscriminator); 'audio' = the _abl_audio generator
+    # (raw waveform, use_mfcc False at processor_v2.py:794-797) + AffDiscriminator.
+    if ablation == 'aff':
+        pose_generator, aff_discriminator = pose_generator_abl_aff, conv_discriminator
+    elif ablation == 'audio':
+        pose_generator, aff_discriminator = pose_generator_abl_audio, globals()['aff_discriminator']
+        in_mfcc = in_audio
+    else:
+        pose_generator, aff_discriminator = globals()['pose_generator'], globals()['aff_discriminator']
     pre_seq = make_pre_seq(target, scfg.n_pre_poses)
     use_gan = epoch > scfg.loss_warmup and scfg.loss_gan_weight > 0.0
     losses: Dict[str, float] = {}
@@ -837,7 +939,7 @@ def conv_discriminator_shapes(pose_dim: int = 27, n_poses: int = 34):
     return s
 
 
-def recipe_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, scale: float = 1.0) -> SD:
+def recipe_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, scale: float = 1.0, tcn_aliases: bool = True) -> SD:
     """Frozen weight recipe shared by the golden generator and the tests: one legacy
     ``np.random.RandomState(seed)`` stream (version-stable), consumed in sorted-key order.
     Fan-in scaled uniform weights; BN gamma in [0.5,1.5], running_var in [0.5,1.5];
@@ -846,7 +948,7 @@ def recipe_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, scale: floa
     sd: SD = {}
     for k in sorted(shapes):
         shp = shapes[k]
-        if '.net.0.' in k or '.net.4.' in k:
+        if tcn_aliases and ('.net.0.' in k or '.net.4.' in k):
             continue
         if k.endswith('num_batches_tracked'):
             sd[k] = torch.zeros((), dtype=torch.int64)
@@ -864,7 +966,7 @@ def recipe_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, scale: floa
             t = u * (scale / math.sqrt(fan_in))
         sd[k] = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
     for k in shapes:
-        if '.net.0.' in k or '.net.4.' in k:
+        if tcn_aliases and ('.net.0.' in k or '.net.4.' in k):
             sd[k] = sd[k.replace('.net.0.', '.conv1.').replace('.net.4.', '.conv2.')]
     return sd
 

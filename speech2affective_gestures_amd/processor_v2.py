@@ -165,12 +165,25 @@ class Processor(object):
                                       word_embed_size=cfg.wordembed_dim, word_embeddings=wemb,
                                       z_obj=self.train_speaker_model)
         self.trimodal_discriminator = CDT(pose_dim, n_poses=self.time_steps)
-        self.use_mfcc = True
-        self.s2ag_generator = PoseGenerator(cfg, pose_dim=pose_dim, n_words=self.lang_model.n_words,
-                                            word_embed_size=cfg.wordembed_dim, word_embeddings=wemb,
-                                            mfcc_length=self.mfcc_length, num_mfcc=self.num_mfcc,
-                                            time_steps=self.time_steps, z_obj=self.train_speaker_model)
-        self.s2ag_discriminator = AffDiscriminator(pose_dim, n_poses=self.time_steps)
+        # The reference selects its ablations by importing PoseGenerator / the discriminator from another net module
+        # (net/multimodal_context_net_v2_abl_aff.py, ..._abl_audio.py); here ``args.ablation`` names the pairing:
+        # 'none' (default) | 'aff' (no affective encoder, ConvDiscriminator) | 'audio' (raw-waveform encoder, use_mfcc False)
+        self.ablation = getattr(args, 'ablation', 'none') or 'none'
+        self.use_mfcc = self.ablation != 'audio'
+        if self.ablation == 'aff':
+            from .net.multimodal_context_net_v2_abl_aff import ConvDiscriminator as Dis, PoseGenerator as Gen
+        elif self.ablation == 'audio':
+            from .net.multimodal_context_net_v2_abl_audio import PoseGenerator as Gen
+            Dis = AffDiscriminator
+        elif self.ablation == 'none':
+            Gen, Dis = PoseGenerator, AffDiscriminator
+        else:
+            raise ValueError("args.ablation must be 'none', 'aff' or 'audio'")
+        self.s2ag_generator = Gen(cfg, pose_dim=pose_dim, n_words=self.lang_model.n_words,
+                                  word_embed_size=cfg.wordembed_dim, word_embeddings=wemb,
+                                  mfcc_length=self.mfcc_length, num_mfcc=self.num_mfcc,
+                                  time_steps=self.time_steps, z_obj=self.train_speaker_model)
+        self.s2ag_discriminator = Dis(pose_dim, n_poses=self.time_steps)
         for m in (self.trimodal_generator, self.trimodal_discriminator, self.s2ag_generator,
                   self.s2ag_discriminator):
             m.to(self.device)
@@ -203,7 +216,8 @@ class Processor(object):
         # independent forward passes of a step run on forked streams (every kernel here fills only part of the chip)
         self.overlap_passes = bool(getattr(args, 'overlap_passes', True))
         # the generator's dropout-free encoders run once per step instead of once per pass (see PoseGenerator)
-        self.share_encoders = bool(getattr(args, 'share_encoders', os.environ.get('S2AG_SHARE_ENCODERS', '1') != '0'))
+        self.share_encoders = bool(getattr(args, 'share_encoders', os.environ.get('S2AG_SHARE_ENCODERS', '1') != '0')) \
+            and hasattr(self.s2ag_generator, '_shared_encoders')
         self.encoders_aside = bool(getattr(args, 'encoders_aside', os.environ.get('S2AG_ENCODERS_ASIDE', '1') != '0'))
         self.early_real_backward = bool(getattr(args, 'early_real_backward',
                                                 os.environ.get('S2AG_EARLY_REAL_BWD', '1') != '0'))
@@ -576,6 +590,8 @@ class Processor(object):
         """processor_v2.py:816-941 up to (and including) loss.backward().  ``cut`` (data parallel): backward stops at the
         recurrent decoder's input -- GRU and out gradients are complete, ``_gen_backward_rest`` does the encoders."""
         cfg = self.s2ag_config_args
+        if not self.use_mfcc:                 # the audio-ablation generator reads the raw waveform (processor_v2.py:794-797)
+            in_mfcc = in_audio
         self.s2ag_generator.cut_backward = bool(cut and train)
         self.s2ag_generator._cut = None
         ops.set_main_stream()
@@ -694,7 +710,8 @@ class Processor(object):
         pre_seq = self._make_pre_seq(target_poses)
         dis_error = None
         if self._use_gan():
-            dis_error = self._dis_phase(in_text, in_mfcc, target_poses, vid_indices, pre_seq, train)
+            dis_error = self._dis_phase(in_text, in_mfcc if self.use_mfcc else in_audio, target_poses, vid_indices,
+                                        pre_seq, train)
             if train:
                 self.dp.all_reduce_grads(self.dis_arena)
                 self.s2ag_dis_optimizer.step(self.dp.grad_scale)
@@ -720,8 +737,8 @@ class Processor(object):
             ops.begin_step()
             self.s2ag_generator.share_passes = (3 if use_gan else 2) if self.share_encoders else None
             out['pre'] = self._make_pre_seq(st['target'])
-            out['dis'] = self._dis_phase(st['text'], st['mfcc'], st['target'], st['vid'], out['pre'], True) \
-                if use_gan else None
+            out['dis'] = self._dis_phase(st['text'], st['mfcc'] if self.use_mfcc else st['audio'], st['target'],
+                                         st['vid'], out['pre'], True) if use_gan else None
 
         ex = self._exchange()
 

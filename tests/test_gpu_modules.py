@@ -286,3 +286,100 @@ def test_sliding_window_synthesis_matches_oracle(golden_dir):
     s_t, s_g = pr.synthesize_clip(g['seed_seq'], audio[:20000], R.SR, words[:2], mfcc_windows=mfcc[:1],
                                   speaker_vid_idx=R.SPEAKER)
     assert s_t.shape == s_g.shape == (34, 27)
+
+
+@pytest.mark.parametrize('tag', ['small', 'full'])
+def test_abl_aff_pairing_matches_reference_goldens(golden_dir, tag):
+    """The second trainable configuration: net.multimodal_context_net_v2_abl_aff.PoseGenerator (no affective
+    encoder: the raw 28-column seed sequence feeds the GRU) with ConvDiscriminator, against tests/golden/abl_aff.npz --
+    recorded from the reference's own modules (gen_golden_abl_aff.py): forwards in eval and train mode and the gradients
+    of (out * d_out).sum() + log D(out).mean() for the recorded tensors.  state_dict keys == the reference's (strict)."""
+    from speech2affective_gestures_amd.net import multimodal_context_net_v2_abl_aff as m2f
+    from s2ag_testing import Vocab, make_cfg
+    c = CASES[tag]
+    g = dict(np.load(os.path.join(golden_dir, 'abl_aff.npz')))
+    oc = oracle_cfg(c['hidden'], 0.0)
+    inp = to_cuda(O.recipe_inputs(c['B'], 34, c['seed0'] + 10, c['n_words'], c['n_spk']))
+    pre_seq = O.make_pre_seq(inp['target'], 4)
+    for mode in ('eval', 'train'):
+        G = m2f.PoseGenerator(make_cfg(c['hidden'], 0.0), 27, c['n_words'], 300, None, 71, 37, 34, z_obj=Vocab(c['n_spk']))
+        D = m2f.ConvDiscriminator(27)
+        G.load_state_dict(O.recipe_state_dict(O.generator_shapes(oc, c['n_words'], c['n_spk'], aff=False), c['seed0'] + 6),
+                          strict=True)
+        D.load_state_dict(O.recipe_state_dict(O.conv_discriminator_shapes(), c['seed0'] + 3), strict=True)
+        assert not any(k.startswith('aff_encoder') for k in G.state_dict())
+        assert G.gru.weight_ih_l0.shape == (3 * c['hidden'], 28 + 32 + 32 + 16)
+        for m in (G, D):
+            m.cuda().train(mode == 'train')
+            set_dropout(m, 0.0, 0.0, 0.0)
+        G.z_site = G_Z_SITE
+        _reset_noise()
+        with torch.set_grad_enabled(mode == 'train'):
+            o, z, mu, lv = G(pre_seq, inp['in_text'], inp['in_mfcc'], inp['vid'])
+            d = D(o)
+        assert rel(o, g[f'{tag}.{mode}.out']) < TOL and rel(z, g[f'{tag}.{mode}.z']) < TOL
+        assert rel(mu, g[f'{tag}.{mode}.mu']) < TOL and rel(d, g[f'{tag}.{mode}.d']) < TOL
+        if mode == 'train':
+            ((o * torch.from_numpy(g[f'{tag}.d_out']).cuda()).sum() + d.log().mean()).backward()
+            named = dict(G.named_parameters())
+            for k in g:
+                if k.startswith(f'{tag}.grad.'):
+                    assert grad_err(named[k[len(tag) + 6:]].grad, g[k], k) < 5 * TOL, k
+            assert rel(G.state_dict()['audio_encoder.batch_norm2.running_var'], g[f'{tag}.train.bn_rv']) < TOL
+
+
+def test_embedding_net_and_fgd_evaluator_match_reference_golden(golden_dir):
+    """the pose auto-encoder (EmbeddingNet, 'pose' mode) and the Frechet Gesture Distance evaluator on the
+    GPU against tests/golden/fgd.npz, recorded from the reference's own net/embedding_net.py and
+    net/embedding_space_evaluator.py (gen_golden_fgd.py): forwards in eval and train mode (BatchNorm running statistics
+    included), then push_samples x 3 / get_scores; plus forward + every gradient in train mode against the oracle."""
+    import types
+    from speech2affective_gestures_amd.net.embedding_net import EmbeddingNet
+    from speech2affective_gestures_amd.net.embedding_space_evaluator import EmbeddingSpaceEvaluator
+    g = dict(np.load(os.path.join(golden_dir, 'fgd.npz')))
+    SEED, B, NB = 6100, 24, 3
+
+    def poses(seed, n):
+        return torch.from_numpy((np.random.RandomState(seed).standard_normal((n, 34, 27)) * 0.2).astype(np.float32))
+    recipe = lambda: O.recipe_state_dict(O.embedding_net_shapes(), SEED, scale=3.0, tcn_aliases=False)
+    for mode in ('eval', 'train'):
+        net = EmbeddingNet(None, 27, 34, 10, 300, None, 'pose')
+        net.load_state_dict(recipe(), strict=True)               # same keys / shapes as the reference
+        net.cuda().train(mode == 'train')
+        with torch.no_grad():
+            ctx, _, _, feat, mu, lv, rec = net(None, None, None, poses(SEED + 1, B).cuda(), 'pose', variational_encoding=False)
+        assert ctx is None and feat is mu
+        assert rel(feat, g[f'{mode}.feat']) < TOL and rel(lv, g[f'{mode}.log_var']) < TOL
+        assert rel(rec, g[f'{mode}.recon']) < TOL and rec.shape == (B, 34, 27)
+        if mode == 'train':
+            assert rel(net.state_dict()['pose_encoder.out_net.1.running_var'], g['train.rv']) < TOL
+    args = types.SimpleNamespace(n_pre_poses=4, n_poses=34, wordembed_dim=300)
+    ev = EmbeddingSpaceEvaluator('.', args, 27, types.SimpleNamespace(n_words=10, word_embedding_weights=None), 'cuda',
+                                 checkpoint=None)
+    ev.net.load_state_dict(recipe(), strict=True)
+    for b in range(NB):
+        real = poses(SEED + 10 + b, B)
+        gen = real * 0.5 + poses(SEED + 20 + b, B) * 1.5 + 0.2
+        ev.push_samples(None, None, gen.cuda(), real.cuda())
+    assert ev.get_no_of_samples() == NB
+    fd, dist = ev.get_scores()
+    assert fd == pytest.approx(float(g['scores'][0]), rel=1e-3) and dist == pytest.approx(float(g['scores'][1]), rel=1e-4)
+    np.testing.assert_allclose(ev.reconstruction_error_differences(), g['recon_err_diff'], rtol=1e-3)
+    # train mode with the variational branch: forward + all gradients vs the oracle fed the eps the kernel draws
+    from speech2affective_gestures_amd import noise, ops
+    net = EmbeddingNet(None, 27, 34, 10, 300, None, 'pose')
+    net.load_state_dict(recipe(), strict=True)
+    net.cuda().train()
+    x = poses(SEED + 3, B)
+    noise.manual_seed(31)
+    eps = ops.normal_noise(torch.tensor([31, 0], dtype=torch.int64, device='cuda'), net.pose_encoder.site, (B, 32)).cpu()
+    _, _, _, z, mu, lv, rec = net(None, None, None, x.cuda(), 'pose', variational_encoding=True)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
+          for k, v in recipe().items()}
+    z_r, mu_r, lv_r, rec_r = O.embedding_net_pose(sd, x, True, eps=eps)
+    assert rel(z, z_r) < TOL and rel(rec, rec_r) < TOL
+    d = torch.randn(rec_r.shape, generator=torch.Generator().manual_seed(2))
+    ((rec_r * d).sum() + lv_r.sum() + mu_r.square().sum()).backward()
+    ((rec * d.cuda()).sum() + lv.sum() + mu.square().sum()).backward()
+    for k, p in net.named_parameters():
+        assert grad_err(p.grad, sd[k].grad, k) < 5 * TOL, k

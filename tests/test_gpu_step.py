@@ -39,8 +39,9 @@ def make_processor(hidden, n_words, n_spk, B, seed0, drop, hip_graph=False, T=34
     pr = P.Processor('.', args, cfg, {'train_data_s2ag': meta, 'val_data_s2ag': meta, 'test_data_s2ag': meta}, 27, 3,
                      16000)
     sds = recipe_sds(hidden, n_words, n_spk, seed0, n_poses=T, mfcc_length=pr.mfcc_length)
-    pr.s2ag_generator.load_state_dict(sds['G'], strict=True)
-    pr.s2ag_discriminator.load_state_dict(sds['D'], strict=True)
+    if extra.get('ablation', 'none') == 'none':          # (the ablation tests load their own pairing's recipe weights)
+        pr.s2ag_generator.load_state_dict(sds['G'], strict=True)
+        pr.s2ag_discriminator.load_state_dict(sds['D'], strict=True)
     pr.trimodal_generator.load_state_dict(sds['T3'], strict=True)
     pr.s2ag_generator.z_site, pr.trimodal_generator.z_site = G_Z_SITE, PGT_Z_SITE
     pr.meta_info['epoch'] = 1
@@ -193,6 +194,48 @@ def test_long_clip_steps_136_frames_match_the_oracle(monkeypatch):
             if '.net.' not in k:
                 assert grad_err(p.grad, grads['G'][k], k) < 10 * TOL, (s, k)
     assert ops.coop_gru_timeouts() == 0
+
+
+@pytest.mark.parametrize('ablation', ['aff', 'audio'])
+def test_ablation_pairings_train_like_the_oracle(monkeypatch, ablation):
+    """The reference's two ablation configurations as full training steps: 'aff' = _abl_aff.PoseGenerator (no affective
+    encoder) against ConvDiscriminator (net/multimodal_context_net_v2_abl_aff.py:285-439), 'audio' = _abl_audio.PoseGenerator
+    on the raw waveform (use_mfcc False, processor_v2.py:794-797).  Two steps with dropout on against the oracle's gan_step
+    in the same pairing, fed the product's materialised masks: losses, metric and every generator gradient."""
+    from speech2affective_gestures_amd import noise
+    from speech2affective_gestures_amd import processor_v2 as P
+    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 5, 8700
+    pr, _ = make_processor(hidden, n_words, n_spk, B, s0, 0.3, ablation=ablation)
+    oc, scfg = oracle_cfg(hidden, 0.3), O.StepCfg()
+    G = O.recipe_state_dict(O.generator_shapes(oc, n_words, n_spk, aff=ablation != 'aff',
+                                               audio='wav' if ablation == 'audio' else 'mfcc'), s0 + 21)
+    D = O.recipe_state_dict(O.conv_discriminator_shapes() if ablation == 'aff' else O.aff_discriminator_shapes(), s0 + 22)
+    T3 = {k: v.clone() for k, v in pr.trimodal_generator.state_dict().items()}
+    T3 = {k: v.cpu() for k, v in T3.items()}
+    pr.s2ag_generator.load_state_dict(G, strict=True)
+    pr.s2ag_discriminator.load_state_dict(D, strict=True)
+    G, D = ({k: v.clone() for k, v in sd.items()} for sd in (G, D))
+    assert type(pr.s2ag_discriminator).__name__ == ('ConvDiscriminatorTriModal' if ablation == 'aff' else 'AffDiscriminator')
+    gopt, dopt = O.AdamState(), O.AdamState()
+    noise.manual_seed(STEP_SEED)
+    for s in range(2):
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(s))
+        monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm.cuda())
+        inp = O.recipe_inputs(B, 34, s0 + 100 + s, n_words, n_spk)
+        gi = to_cuda(inp)
+        nz = _materialise_step_noise(pr, PASSES_PER_STEP * s, B, 34, hidden)
+        nz.perm = perm
+        ret = pr.forward_pass_s2ag(gi['in_text'], gi['in_audio'], gi['in_mfcc'], gi['target'], gi['vid'], True)
+        monkeypatch.undo()
+        metric, losses, grads = O.gan_step(G, D, T3, gopt, dopt, oc, scfg, inp['in_text'], inp['in_audio'],
+                                           inp['in_mfcc'], inp['target'], inp['vid'], epoch=1, noise=nz, ablation=ablation)
+        for k in ('dis', 'total', 'loss', 'KLD', 'DIV_REG', 'gen'):
+            assert pr.last_losses[k] == pytest.approx(losses[k], rel=TOL, abs=1e-6), (s, k)
+        assert ret[0] == pytest.approx(metric, rel=5e-3, abs=2e-6)
+        errs = {k: grad_err(p.grad, grads['G'][k], k) for k, p in pr.s2ag_generator.named_parameters()
+                if '.net.' not in k}
+        bad = sorted(((e, k) for k, e in errs.items() if e >= 10 * TOL), reverse=True)
+        assert not bad, (s, len(bad), len(errs), bad[:8])
 
 
 def test_validation_branch_matches_the_oracle(monkeypatch):

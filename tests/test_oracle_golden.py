@@ -186,3 +186,76 @@ def test_synthesis_loop_matches_reference_render_clip(golden_dir):
     _close(g['out_s2ag'], out_g)
     plan, alen = O.synthesis_windows(len(audio), R.SR, 34, 4, R.FPS)
     assert alen == 36266 and [p[2] for p in plan] == [0, 32000, 64000]
+
+
+@pytest.mark.parametrize('tag', ['small', 'full'])
+def test_abl_aff_generator_and_conv_discriminator_match_reference(golden_dir, tag):
+    """tests/golden/abl_aff.npz was recorded from the reference's net.multimodal_context_net_v2_abl_aff (PoseGenerator
+    without the affective encoder, trained against ConvDiscriminator): forwards in both modes and parameter gradients."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import s2ag_rng
+    c = CASES[tag]
+    g = _load(golden_dir, 'abl_aff.npz')
+    oc = O.ModelCfg(hidden_size=c['hidden'], hidden_size_s2eg=c['hidden'], dropout_prob=0.0)
+    inp = O.recipe_inputs(c['B'], 34, c['seed0'] + 10, c['n_words'], c['n_spk'])
+    pre_seq = O.make_pre_seq(inp['target'], 4)
+    eps = torch.from_numpy(s2ag_rng.normal(1234, 0, 9001, c['B'] * 16).reshape(c['B'], 16))
+    for mode in ('eval', 'train'):
+        sdG = O.recipe_state_dict(O.generator_shapes(oc, c['n_words'], c['n_spk'], aff=False), c['seed0'] + 6)
+        sdD = O.recipe_state_dict(O.conv_discriminator_shapes(), c['seed0'] + 3)
+        tr = mode == 'train'
+        if tr:
+            sdG = {k: (v.clone().requires_grad_(True) if O.is_param(k) and '.net.' not in k else v) for k, v in sdG.items()}
+            for k in list(sdG):
+                if '.net.0.' in k or '.net.4.' in k:
+                    sdG[k] = sdG[k.replace('.net.0.', '.conv1.').replace('.net.4.', '.conv2.')]
+        with torch.set_grad_enabled(tr):
+            class PinnedEpsNoDropout(O.Noise):            # the fixture was recorded with every dropout at p = 0
+                def dropout(self, name, x, p):
+                    return x
+            o, z, mu, lv = O.pose_generator_abl_aff(sdG, oc, pre_seq, inp['in_text'], inp['in_mfcc'], inp['vid'], tr,
+                                                    PinnedEpsNoDropout({'eps': eps}))
+            d = O.conv_discriminator(sdD, o, tr, O.Noise('off'))
+        _close(g[f'{tag}.{mode}.out'], o)
+        _close(g[f'{tag}.{mode}.z'], z)
+        _close(g[f'{tag}.{mode}.mu'], mu)
+        _close(g[f'{tag}.{mode}.d'], d)
+        if tr:
+            ((o * torch.from_numpy(g[f'{tag}.d_out'])).sum() + d.log().mean()).backward()
+            for k in g:
+                if k.startswith(f'{tag}.grad.'):
+                    _close(g[k], sdG[k[len(tag) + 6:]].grad, tol=1e-4)
+            _close(g[f'{tag}.train.bn_rv'], sdG['audio_encoder.batch_norm2.running_var'])
+
+
+def test_embedding_net_and_fgd_match_reference(golden_dir):
+    """tests/golden/fgd.npz: the reference's EmbeddingNet ('pose' mode) forwards in eval / train mode and its
+    EmbeddingSpaceEvaluator scores (Frechet distance, feature L1 distance, reconstruction-error differences)."""
+    g = _load(golden_dir, 'fgd.npz')
+    SEED, B, NB = 6100, 24, 3
+
+    def poses(seed, n):
+        return torch.from_numpy((np.random.RandomState(seed).standard_normal((n, 34, 27)) * 0.2).astype(np.float32))
+    for mode in ('eval', 'train'):
+        sd = O.recipe_state_dict(O.embedding_net_shapes(), SEED, scale=3.0, tcn_aliases=False)
+        with torch.no_grad():
+            feat, mu, lv, rec = O.embedding_net_pose(sd, poses(SEED + 1, B), mode == 'train')
+        _close(g[f'{mode}.feat'], feat)
+        _close(g[f'{mode}.log_var'], lv)
+        _close(g[f'{mode}.recon'], rec)
+        if mode == 'train':
+            _close(g['train.rv'], sd['pose_encoder.out_net.1.running_var'])
+    sd = O.recipe_state_dict(O.embedding_net_shapes(), SEED, scale=3.0, tcn_aliases=False)
+    reals, gens, diffs = [], [], []
+    with torch.no_grad():
+        for b in range(NB):
+            real = poses(SEED + 10 + b, B)
+            gen = real * 0.5 + poses(SEED + 20 + b, B) * 1.5 + 0.2
+            fr, _, _, rr = O.embedding_net_pose(sd, real, False)
+            fg, _, _, rg = O.embedding_net_pose(sd, gen, False)
+            reals.append(fr.numpy()), gens.append(fg.numpy())
+            diffs.append(float((gen - rg).abs().mean()) - float((real - rr).abs().mean()))
+    fd, dist = O.fgd_scores(np.vstack(gens), np.vstack(reals))
+    assert fd == pytest.approx(float(g['scores'][0]), rel=1e-4) and dist == pytest.approx(float(g['scores'][1]), rel=1e-5)
+    np.testing.assert_allclose(diffs, g['recon_err_diff'], rtol=1e-4, atol=1e-7)
