@@ -97,8 +97,10 @@ def test_three_steps_match_the_reference_trace(golden_dir, monkeypatch):
             assert rel(sdD[k[8:]], g[k]) < TOL, k
 
 
-def _materialise_step_noise(pr, counter0, B, T, hidden):
-    """Pinned noise of the 7 passes of one product step, named for the oracle."""
+def _materialise_step_noise(pr, counter0, B, T, hidden, T_dis=None):
+    """Pinned noise of the 7 passes of one product step, named for the oracle.  ``T_dis``: frames the discriminator's GRU
+    sees (the convolutional discriminator's three valid k = 3 convs leave T - 6)."""
+    T_dis = T if T_dis is None else T_dis
     from speech2affective_gestures_amd import ops
 
     def snap(k):
@@ -118,7 +120,7 @@ def _materialise_step_noise(pr, counter0, B, T, hidden):
         return O.Noise(pin)
 
     def dis_noise(D, nz):
-        return O.Noise({f'gru.drop{l}': ops.dropout_mask(nz, D.gru.site0 + l, 0.3, (B, T, 128)).cpu()
+        return O.Noise({f'gru.drop{l}': ops.dropout_mask(nz, D.gru.site0 + l, 0.3, (B, T_dis, 128)).cpu()
                         for l in range(3)})
     G, D, T3 = pr.s2ag_generator, pr.s2ag_discriminator, pr.trimodal_generator
     return O.StepNoise(g_dis=gen_noise(G, snap(0), True), d_real=dis_noise(D, snap(1)), d_fake=dis_noise(D, snap(2)),
@@ -196,15 +198,16 @@ def test_long_clip_steps_136_frames_match_the_oracle(monkeypatch):
     assert ops.coop_gru_timeouts() == 0
 
 
+@pytest.mark.parametrize('s0', [8700, 8710, 8720, 8730])
 @pytest.mark.parametrize('ablation', ['aff', 'audio'])
-def test_ablation_pairings_train_like_the_oracle(monkeypatch, ablation):
+def test_ablation_pairings_train_like_the_oracle(monkeypatch, ablation, s0):
     """The reference's two ablation configurations as full training steps: 'aff' = _abl_aff.PoseGenerator (no affective
     encoder) against ConvDiscriminator (net/multimodal_context_net_v2_abl_aff.py:285-439), 'audio' = _abl_audio.PoseGenerator
     on the raw waveform (use_mfcc False, processor_v2.py:794-797).  Two steps with dropout on against the oracle's gan_step
     in the same pairing, fed the product's materialised masks: losses, metric and every generator gradient."""
     from speech2affective_gestures_amd import noise
     from speech2affective_gestures_amd import processor_v2 as P
-    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 5, 8700
+    hidden, n_words, n_spk, B = 32, 64, 12, 5
     pr, _ = make_processor(hidden, n_words, n_spk, B, s0, 0.3, ablation=ablation)
     oc, scfg = oracle_cfg(hidden, 0.3), O.StepCfg()
     G = O.recipe_state_dict(O.generator_shapes(oc, n_words, n_spk, aff=ablation != 'aff',
@@ -223,7 +226,7 @@ def test_ablation_pairings_train_like_the_oracle(monkeypatch, ablation):
         monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm.cuda())
         inp = O.recipe_inputs(B, 34, s0 + 100 + s, n_words, n_spk)
         gi = to_cuda(inp)
-        nz = _materialise_step_noise(pr, PASSES_PER_STEP * s, B, 34, hidden)
+        nz = _materialise_step_noise(pr, PASSES_PER_STEP * s, B, 34, hidden, T_dis=28 if ablation == 'aff' else 34)
         nz.perm = perm
         ret = pr.forward_pass_s2ag(gi['in_text'], gi['in_audio'], gi['in_mfcc'], gi['target'], gi['vid'], True)
         monkeypatch.undo()
