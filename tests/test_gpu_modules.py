@@ -381,12 +381,15 @@ def test_embedding_net_and_fgd_evaluator_match_reference_golden(golden_dir):
     d = torch.randn(rec_r.shape, generator=torch.Generator().manual_seed(2))
     ((rec_r * d).sum() + lv_r.sum() + mu_r.square().sum()).backward()
     ((rec * d.cuda()).sum() + lv.sum() + mu.square().sum()).backward()
-    dead = ('pose_encoder.net.0.0.bias', 'pose_encoder.net.1.0.bias', 'pose_encoder.net.2.0.bias', 'pose_encoder.net.3.bias',
-            'pose_encoder.out_net.0.bias', 'pose_encoder.out_net.3.bias', 'decoder.pre_net.0.bias', 'decoder.net.0.bias',
-            'decoder.net.3.bias')          # biases a BatchNorm removes (net.3.bias: through the Linear in front of it): true gradient exactly zero
+    # parameters a BatchNorm downstream cancels exactly (conv / linear biases in front of one -- net.3.bias through the
+    # Linear behind the flatten -- and out_net.1's beta through the Linear in front of out_net.4) have a true gradient of
+    # zero: both sides hold rounding noise there
     scale = float(net.pose_encoder.fc_mu.weight.grad.abs().max())
+    n_dead = 0
     for k, p in net.named_parameters():
-        if k in dead:
-            assert float(p.grad.abs().max()) < 2e-3 * scale and float(sd[k].grad.abs().max()) < 2e-3 * scale, k
+        if float(sd[k].grad.abs().max()) < 1e-3 * scale:
+            assert float(p.grad.abs().max()) < 2e-3 * scale, k
+            n_dead += 1
         else:
             assert grad_err(p.grad, sd[k].grad, k) < 5 * TOL, k
+    assert n_dead <= 10
