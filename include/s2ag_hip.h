@@ -323,6 +323,99 @@ int s2ag_gru_coop_error_word_offset(int B, int T, int H, int backward, long long
  * (net/multimodal_context_net_v2.py:480-486) cannot fail silently, so neither may its replacement. */
 int s2ag_gru_coop_set_error_flag(int* device_word);
 
+/* ---- bf16 mode of the Conv1d hot path (csrc/conv_bf16.hip) ------------------------------------------------------------
+ * Replaces, with activations stored as bf16 in HBM (channels-last rows, channel count padded with ZEROS to a multiple of
+ * 32 where a layer is read tap by tap), fp32 accumulation on v_mfma_f32_16x16x32_bf16 and fp32 master weights, the ATen
+ * calls behind nn.Conv1d / BatchNorm1d / LeakyReLU of WavEncoder (net/multimodal_context_net_v2.py:14-33) and behind the
+ * weight-normed dilated convs, ReLU, Dropout and residual adds of TemporalBlock (net/tcn.py:16-46), forward and backward.
+ * The reference has no reduced-precision path (hard part 5): this is BASELINE configs[1] / [3] "bf16".
+ *
+ * s2ag_bf16_conv: implicit GEMM  y[n, q, co] = epi(b[co] + sum_{t<ks, c<Cp} x[n, q*pos_mul + pos_off + t*pos_tap, c] * w[co, t, c])
+ *   over rows q < Lq of clips n < N; a source row outside [0, Lin) reads as zero, as do channels >= Cvalid.  Forward pass,
+ *   stride-1 data gradient (tap-flipped transposed weights) and -- with phases > 1 -- the poly-phase form of a strided data
+ *   gradient (phase r = blockIdx.z uses the weight set w + r*w_phase, writes y rows at offset r*y_phase and only rows q with
+ *   q*phases + r < q_total).  y element (n, q, co) lives at n*y_clip + q*y_row + y_off + co; channels [Cout, CoutS) are
+ *   stored as zeros (padding).  Epilogue as s2ag_conv1d_nlc_fwd (mask index row*mask_cols + co); partials / stat_rows as
+ *   s2ag_conv1d_nlc_fwd_stats with s2ag_bf16_conv_stats_rows(N*Lq) rows: column sums of the ROUNDED outputs. */
+typedef struct {
+    const void* x;              /* bf16 */
+    const void* w;              /* bf16 (phases, Cout, ks, Cp) */
+    const float* bias;          /* nullable, Cout entries */
+    void* y;                    /* bf16, or fp32 if out_f32 */
+    int N, Lq, Lin;
+    long long x_clip;           /* elements between clips of x */
+    int ldx;                    /* row pitch of x, multiple of 8 */
+    int pos_mul, pos_off, pos_tap;
+    int ks, Cp, Cvalid;         /* Cp multiple of 32, Cvalid multiple of 8 */
+    int Cout, CoutS;
+    long long y_clip;
+    int y_row, y_off;
+    int out_f32;
+    int phases;                 /* >= 1 */
+    long long w_phase;
+    int y_phase, q_total;
+    int mask_cols;              /* 0: Cout */
+} s2ag_bf16_conv_args;
+int s2ag_bf16_conv_stats_rows(int rows);
+int s2ag_bf16_conv(const s2ag_bf16_conv_args* c, const s2ag_epilogue* e /*host, nullable*/, double* partials, int* stat_rows,
+                   void* stream);
+/* dw[co*d_co + t*d_t + c*d_c] += sum_{n, q} gy[(n, q), co] * x[n, q*pos_mul + pos_off + t*pos_tap, c]   (co < Cout, c < Cin),
+ * db[co] += sum gy[:, co] (nullable).  flat_cin > 0: the window is ONE tap of ks_out*flat_cin contiguous channels (Cp =
+ * that rounded up to 64) and channel k of it is (t, c) = (k / flat_cin, k % flat_cin).  Cp multiple of 64. */
+typedef struct {
+    const void* gy;             /* bf16 (N*Lq, ldg) */
+    const void* x;              /* bf16 */
+    float* dw;
+    float* db;
+    int N, Lq, Lin;
+    long long x_clip;
+    int ldx, ldg;
+    int pos_mul, pos_off, pos_tap;
+    int ks, Cp, Cvalid;
+    int Cout, Cin;
+    long long d_co;
+    int d_t, d_c;
+    int flat_cin, ks_out;
+} s2ag_bf16_wgrad_args;
+int s2ag_bf16_conv_wgrad(const s2ag_bf16_wgrad_args* g, void* stream);
+/* fp32 master weights -> bf16 operand layouts, up to 32 tensors per launch (once per optimizer step):
+ * dst[(o*taps + t)*Cp + c] = (c < cols and 0 <= tap0 + t*tap_step < src_taps) ? src[o*s_o + (tap0 + t*tap_step)*s_t + c*s_c] : 0 */
+#define S2AG_BF16_MAX_PACK 32
+typedef struct {
+    const float* src;
+    void* dst;
+    int rows, taps, Cp, cols;
+    int tap0, tap_step, src_taps;
+    long long s_o;
+    int s_t, s_c;
+    int flat_cin;               /* > 0 (taps == 1): channel k of the single tap is (tap, c) = (k / flat_cin, k % flat_cin) */
+} s2ag_bf16_pack_job;
+int s2ag_bf16_pack_weights(const s2ag_bf16_pack_job* jobs /*host*/, int njobs, void* stream);
+/* (rows, cols) fp32 <-> bf16 with row pitches; to_bf16 also zero-fills the pad columns [cols, ldy) */
+int s2ag_bf16_cast(const void* x, int ldx, long long rows, int cols, void* y, int ldy, int to_bf16, void* stream);
+/* BatchNorm apply / backward on bf16 rows (cols, ld multiples of 8); coefficient vectors are fp32 as in s2ag_bn_apply.
+ * s2ag_bf16_bn_bwd: dgamma / dbeta (nullable) are accumulated atomically; `sums` is a 2*cols fp32 scratch, zero on entry
+ * and exit; c1 / c2 receive the per-column means of d and d*xhat. */
+int s2ag_bf16_bn_apply(const void* x, long long rows, int cols, int ld, const float* scale, const float* shift, float slope,
+                       void* y, void* stream);
+int s2ag_bf16_bn_bwd(const void* x, const void* dy, long long rows, int cols, int ld, const float* scale, const float* shift,
+                     const float* mean, const float* invstd, float slope, float* dgamma, float* dbeta, float* sums, float* c1,
+                     float* c2, void* dx, void* stream);
+/* y = leaky(a + b) over n bf16 elements (b nullable; n multiple of 8);  g = dy * act'(y) * mask (pad columns zero) */
+int s2ag_bf16_add_act(const void* a, const void* b, long long n, float slope, void* y, void* stream);
+int s2ag_bf16_epilogue_bwd(const void* dy, const void* y, long long rows, int cols, int ld, const s2ag_epilogue* e, void* g,
+                           void* stream);
+/* nn.Embedding + Dropout -> bf16 rows (pad columns zero); its table gradient from bf16 dy */
+int s2ag_bf16_embedding_fwd(const long long* ids, const float* table, long long rows, int dim, int n_entries, void* out, int ld,
+                            const s2ag_epilogue* e, void* stream);
+int s2ag_bf16_embedding_bwd(const long long* ids, const void* dy, int ld, long long rows, int dim, int n_entries, float* dtable,
+                            const s2ag_epilogue* e, void* stream);
+/* the one-input-channel wave conv (conv1) writing bf16 / reading a bf16 output gradient */
+int s2ag_bf16_conv_c1_fwd(const float* x, const float* w, const float* bias, void* y, const s2ag_conv_geom* g, double* partials,
+                          int* stat_rows, void* stream);
+int s2ag_bf16_conv_c1_wgrad(const void* gy, const float* x, float* dw, float* db, const s2ag_conv_geom* g, void* stream);
+int s2ag_bf16_conv_c1_rows(const s2ag_conv_geom* g);      /* statistics partial rows s2ag_bf16_conv_c1_fwd writes */
+
 /* Measurement aid (tools/pmc_traffic.py): touches `bytes` of `buf` with a known access pattern so the rocprofv3 counters
  * FETCH_SIZE / WRITE_SIZE can be calibrated against a known byte count in OUR access shapes: 0 = 16 B/lane coalesced
  * reads, 1 = 8 B/lane agent-scope reads (the cooperative GRU's exchange polling), 2 = 16 B/lane writes, 3 = 8 B/lane

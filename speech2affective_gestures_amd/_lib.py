@@ -36,8 +36,28 @@ class WgradJob(C.Structure):     # s2ag_wgrad_job
     _fields_ = [('gy', C.c_void_p), ('x', C.c_void_p), ('dw', C.c_void_p), ('dbias', C.c_void_p), ('geom', ConvGeom)]
 
 
+class BF16Conv(C.Structure):      # s2ag_bf16_conv_args
+    _fields_ = [('x', vp), ('w', vp), ('bias', vp), ('y', vp), ('N', ci), ('Lq', ci), ('Lin', ci), ('x_clip', cll),
+                ('ldx', ci), ('pos_mul', ci), ('pos_off', ci), ('pos_tap', ci), ('ks', ci), ('Cp', ci), ('Cvalid', ci),
+                ('Cout', ci), ('CoutS', ci), ('y_clip', cll), ('y_row', ci), ('y_off', ci), ('out_f32', ci),
+                ('phases', ci), ('w_phase', cll), ('y_phase', ci), ('q_total', ci), ('mask_cols', ci)]
+
+
+class BF16Wgrad(C.Structure):     # s2ag_bf16_wgrad_args
+    _fields_ = [('gy', vp), ('x', vp), ('dw', vp), ('db', vp), ('N', ci), ('Lq', ci), ('Lin', ci), ('x_clip', cll),
+                ('ldx', ci), ('ldg', ci), ('pos_mul', ci), ('pos_off', ci), ('pos_tap', ci), ('ks', ci), ('Cp', ci),
+                ('Cvalid', ci), ('Cout', ci), ('Cin', ci), ('d_co', cll), ('d_t', ci), ('d_c', ci), ('flat_cin', ci),
+                ('ks_out', ci)]
+
+
+class BF16PackJob(C.Structure):   # s2ag_bf16_pack_job
+    _fields_ = [('src', vp), ('dst', vp), ('rows', ci), ('taps', ci), ('Cp', ci), ('cols', ci), ('tap0', ci),
+                ('tap_step', ci), ('src_taps', ci), ('s_o', cll), ('s_t', ci), ('s_c', ci), ('flat_cin', ci)]
+
+
 MAX_JOBS = 8
 MAX_WGRAD_JOBS = 4
+BF16_MAX_PACK = 32
 
 SIGNATURES = {
     's2ag_abi_version': [],
@@ -91,6 +111,20 @@ SIGNATURES = {
     's2ag_gru_coop_error_word_offset': [ci, ci, ci, ci, C.POINTER(cll)],
     's2ag_gru_coop_set_error_flag': [vp],
     's2ag_calib_traffic': [vp, cll, ci, vp],
+    's2ag_bf16_conv_stats_rows': [ci],
+    's2ag_bf16_conv': [vp, PE, vp, vp, vp],
+    's2ag_bf16_conv_wgrad': [vp, vp],
+    's2ag_bf16_pack_weights': [vp, ci, vp],
+    's2ag_bf16_cast': [vp, ci, cll, ci, vp, ci, ci, vp],
+    's2ag_bf16_bn_apply': [vp, cll, ci, ci, vp, vp, cf, vp, vp],
+    's2ag_bf16_bn_bwd': [vp, vp, cll, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp],
+    's2ag_bf16_add_act': [vp, vp, cll, cf, vp, vp],
+    's2ag_bf16_epilogue_bwd': [vp, vp, cll, ci, ci, PE, vp, vp],
+    's2ag_bf16_embedding_fwd': [vp, vp, cll, ci, ci, vp, ci, PE, vp],
+    's2ag_bf16_embedding_bwd': [vp, vp, ci, cll, ci, ci, vp, PE, vp],
+    's2ag_bf16_conv_c1_fwd': [vp, vp, vp, vp, PG, vp, vp, vp],
+    's2ag_bf16_conv_c1_wgrad': [vp, vp, vp, vp, PG, vp],
+    's2ag_bf16_conv_c1_rows': [PG],
     's2ag_rows_unique': [vp, ci, ci, ci, vp, vp, vp, vp, vp],
     's2ag_rows_pack': [vp, vp, ci, ci, ci, vp, vp],
     's2ag_rows_merge': [vp, ci, ci, ci, ci, vp, vp],

@@ -1,0 +1,539 @@
+"""bf16 mode of the Conv1d hot path: host side of csrc/conv_bf16.hip.
+
+``S2AG_PRECISION=bf16`` (or ``with bf16.precision('bf16'):``) makes the wave encoder and the text TCN keep their
+activations in HBM as bf16 (fp32 accumulation on the bf16 matrix pipe, BatchNorm statistics from fp64 column sums of the
+rounded outputs, fp32 master weights converted once per optimizer step, fp32 weight gradients) -- BASELINE configs[1] /
+configs[3] "bf16", SURVEY section 7 hard part 5.  The reference has no reduced-precision path, so this mode has its own
+parity tests with their own, measured tolerance (tests/test_gpu_bf16.py); fp32 stays the default and the mode in which
+the 1e-3 bar is proven.  What enters and leaves the two encoders is fp32 (raw audio, token ids -> (B, T, 32) features).
+
+Layout: an activation is a torch.bfloat16 tensor (clips, frames, Cp); where a layer is read tap by tap (the TCN) Cp is the
+channel count rounded up to 32 and the pad channels are zeros (every producer writes them).
+"""
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+Tensor = torch.Tensor
+_MODE = [os.environ.get('S2AG_PRECISION', 'fp32').lower() in ('bf16', 'bfloat16')]
+
+
+def enabled() -> bool:
+    return _MODE[0]
+
+
+class precision:
+    """Context manager: ``precision('bf16')`` / ``precision('fp32')``."""
+
+    def __init__(self, mode: str):
+        self.on = mode.lower() in ('bf16', 'bfloat16')
+
+    def __enter__(self):
+        self.prev = _MODE[0]
+        _MODE[0] = self.on
+
+    def __exit__(self, *a):
+        _MODE[0] = self.prev
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def _lib():
+    return L.load()
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _rows16(t: Tensor):
+    """(tensor, rows, ld) of a contiguous bf16 activation whose last axis is the (padded) channel axis."""
+    assert t.dtype == torch.bfloat16 and t.is_cuda, 'bf16 activation on the GPU expected'
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t, t.numel() // t.shape[-1], t.shape[-1]
+
+
+# ----------------------------------------------------------------------------------------------------
+# casts
+# ----------------------------------------------------------------------------------------------------
+def to_bf16_raw(x: Tensor, ld: Optional[int] = None) -> Tensor:
+    x, rows, cols, ldx = ops.as_rows(x)
+    ld = cols if ld is None else ld
+    y = torch.empty(rows, ld, dtype=torch.bfloat16, device=x.device)
+    L.check(_lib().s2ag_bf16_cast(_p(x), ldx, rows, cols, _p(y), ld, 1, _s()), 'bf16_cast')
+    return y
+
+
+def to_f32_raw(x: Tensor, cols: Optional[int] = None) -> Tensor:
+    x, rows, ld = _rows16(x)
+    cols = ld if cols is None else cols
+    y = torch.empty(rows, cols, dtype=torch.float32, device=x.device)
+    L.check(_lib().s2ag_bf16_cast(_p(x), ld, rows, cols, _p(y), cols, 0, _s()), 'bf16_cast')
+    return y
+
+
+class _ToBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ld):
+        ctx.shape = x.shape
+        return to_bf16_raw(x, ld).view(*x.shape[:-1], ld)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return to_f32_raw(dy, ctx.shape[-1]).view(ctx.shape), None
+
+
+class _ToF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cols):
+        ctx.ld = x.shape[-1]
+        ctx.shape = x.shape
+        return to_f32_raw(x, cols).view(*x.shape[:-1], cols)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return to_bf16_raw(dy.contiguous(), ctx.ld).view(ctx.shape), None
+
+
+def to_bf16(x: Tensor, ld: Optional[int] = None) -> Tensor:
+    return _ToBF16.apply(x, x.shape[-1] if ld is None else ld)
+
+
+def to_f32(x: Tensor, cols: Optional[int] = None) -> Tensor:
+    return _ToF32.apply(x, x.shape[-1] if cols is None else cols)
+
+
+# ----------------------------------------------------------------------------------------------------
+# weights: fp32 masters -> bf16 operand layouts, one launch per group and optimizer step
+# ----------------------------------------------------------------------------------------------------
+class WeightPack:
+    """bf16 operand layouts of a module's conv weights.  ``add`` registers what a layer needs; ``get(name)`` returns
+    the tensors, refreshing ALL registered layouts with one launch when a source changed (optimizer step, load) or a
+    new training step began (ops.begin_step: derived tensors are never carried across steps)."""
+
+    def __init__(self):
+        self.entries = {}          # name -> dict(src_fn, jobs=[(key, shape, fields)], )
+        self._key = None
+        self._out = {}
+
+    def add(self, name, src_fn, layout, Cout, Cin, ks, stride=1):
+        """``src_fn()`` -> the fp32 weight; ``layout``: 'tap_major' (Cout, ks, Cin) or 'reference' (Cout, Cin, ks)."""
+        if name not in self.entries:
+            self.entries[name] = dict(src=src_fn, layout=layout, Cout=Cout, Cin=Cin, ks=ks, stride=stride)
+
+    def _jobs(self, e, w):
+        Cout, Cin, ks, s = e['Cout'], e['Cin'], e['ks'], e['stride']
+        if e['layout'] == 'tap_major':
+            so, st, sc = ks * Cin, Cin, 1
+        else:
+            so, st, sc = Cin * ks, 1, ks
+        jobs = []
+        flat = e['layout'] == 'reference' and Cin % 8 == 0          # wave-encoder convs: contiguous windows
+        if flat:
+            Kp = (ks * Cin + 63) // 64 * 64
+            jobs.append(('fwd', (Cout, 1, Kp), dict(rows=Cout, taps=1, Cp=Kp, cols=Cin, tap0=0, tap_step=1, src_taps=ks,
+                                                    s_o=so, s_t=st, s_c=sc, flat_cin=Cin)))
+        else:
+            Cp = pad32(Cin)
+            jobs.append(('fwd', (Cout, ks, Cp), dict(rows=Cout, taps=ks, Cp=Cp, cols=Cin, tap0=0, tap_step=1, src_taps=ks,
+                                                     s_o=so, s_t=st, s_c=sc, flat_cin=0)))
+        CpO = pad32(Cout)
+        if s == 1:      # data gradient = the same kernel with tap-flipped, transposed weights
+            jobs.append(('dgrad', (Cin, ks, CpO), dict(rows=Cin, taps=ks, Cp=CpO, cols=Cout, tap0=ks - 1, tap_step=-1,
+                                                       src_taps=ks, s_o=sc, s_t=st, s_c=so, flat_cin=0)))
+        else:           # poly-phase: phase r uses the taps r, r + s, r + 2s, ...
+            nt = (ks + s - 1) // s
+            for r in range(s):
+                jobs.append((('phase', r), (Cin, nt, CpO), dict(rows=Cin, taps=nt, Cp=CpO, cols=Cout, tap0=r, tap_step=s,
+                                                               src_taps=ks, s_o=sc, s_t=st, s_c=so, flat_cin=0)))
+        return jobs
+
+    def _refresh(self):
+        srcs = {n: e['src']() for n, e in self.entries.items()}
+        key = (ops.generation(),) + tuple((id(w), w._version, w.data_ptr()) for w in srcs.values())
+        if key == self._key:
+            return
+        with torch.no_grad():
+            plan = []
+            for n, e in self.entries.items():
+                for tag, shape, f in self._jobs(e, srcs[n]):
+                    plan.append((n, tag, shape, f, srcs[n]))
+            assert len(plan) <= L.BF16_MAX_PACK, 'too many weight layouts in one WeightPack'
+            dev = next(iter(srcs.values())).device
+            total = sum(sh[0] * sh[1] * sh[2] for _, _, sh, _, _ in plan)
+            flat = torch.empty(total + 64, dtype=torch.bfloat16, device=dev)      # + slack: nothing reads past it, but cheap
+            arr = (L.BF16PackJob * len(plan))()
+            out, off = {}, 0
+            for k, (n, tag, sh, f, w) in enumerate(plan):
+                cnt = sh[0] * sh[1] * sh[2]
+                t = flat[off:off + cnt].view(sh)
+                arr[k] = L.BF16PackJob(w.detach().data_ptr(), t.data_ptr(), f['rows'], f['taps'], f['Cp'], f['cols'],
+                                       f['tap0'], f['tap_step'], f['src_taps'], f['s_o'], f['s_t'], f['s_c'],
+                                       f['flat_cin'])
+                if isinstance(tag, tuple):          # phases of one layer are adjacent: one (phases, Cin, nt, CpO) tensor
+                    if tag[1] == 0:
+                        s = self.entries[n]['stride']
+                        out[(n, 'phases')] = flat[off:off + s * cnt].view((s,) + sh)
+                else:
+                    out[(n, tag)] = t
+                off += cnt
+            L.check(_lib().s2ag_bf16_pack_weights(arr, len(plan), _s()), 'bf16_pack_weights')
+        self._out, self._key = out, key
+
+    def get(self, name, what):
+        self._refresh()
+        return self._out[(name, what)]
+
+
+# ----------------------------------------------------------------------------------------------------
+# conv (implicit GEMM), forward + both gradients
+# ----------------------------------------------------------------------------------------------------
+def _conv_launch(x, w16, bias, y, N, Lq, Lin, x_clip, ldx, pos, ks, Cp, Cvalid, Cout, CoutS, y_clip, y_row, out_f32,
+                 epi=None, phases=1, w_phase=0, y_phase=0, q_total=0, mask_cols=0, want_stats=False):
+    lib = _lib()
+    a = L.BF16Conv(_p(x), _p(w16), _p(bias), _p(y), N, Lq, Lin, x_clip, ldx, pos[0], pos[1], pos[2], ks, Cp, Cvalid, Cout,
+                   CoutS, y_clip, y_row, 0, int(out_f32), phases, w_phase, y_phase, q_total, mask_cols)
+    e = epi if epi is not None else L.Epilogue(L.ACT_NONE, 1.0, 0.0, None, 0)
+    if want_stats:
+        rows = lib.s2ag_bf16_conv_stats_rows(N * Lq)
+        part = torch.empty(2 * rows * Cout, dtype=torch.float64, device=x.device)
+        got = C.c_int(0)
+        L.check(lib.s2ag_bf16_conv(C.byref(a), C.byref(e), _p(part), C.byref(got), _s()), 'bf16_conv')
+        return part[:2 * got.value * Cout], got.value
+    L.check(lib.s2ag_bf16_conv(C.byref(a), C.byref(e), None, None, _s()), 'bf16_conv')
+    return None
+
+
+class _Conv16(torch.autograd.Function):
+    """x (N, Lin, ldx) bf16 -> y (N, Lout, CoutS) bf16 [or fp32 (N, Lout, Cout)].  ``w`` is the fp32 leaf (or derived
+    tensor) whose .grad slot receives the weight gradient; ``pack`` / ``name`` give its bf16 layouts."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, pack, name, geom, epi, flags):
+        N, Lin, Lout, Cin, Cout, ks, stride, pad, dil = geom
+        act, slope, drop_p, noise, site = epi
+        out_f32, want_stats, pad_out = flags
+        x, rows, ldx = _rows16(x)
+        assert rows == N * Lin
+        w16 = pack.get(name, 'fwd')
+        flat = w16.shape[1] == 1 and ks > 1
+        if flat:
+            assert ldx == Cin and pad == 0 and dil == 1
+            Cp, Cvalid, kk, pos = w16.shape[2], ks * Cin, 1, (stride, 0, 0)
+        else:
+            Cp, kk, pos = w16.shape[2], ks, (stride, -pad, dil)
+            Cvalid = min(Cp, ldx)
+            assert ldx % 8 == 0 and ldx >= Cin
+        CoutS = Cout if out_f32 else (pad32(Cout) if pad_out else Cout)
+        y = torch.empty(N * Lout, CoutS, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+        e = L.Epilogue(act, float(slope), float(drop_p), _p(noise) if drop_p > 0 else None, int(site))
+        st = _conv_launch(x, w16, bias, y, N, Lout, Lin, Lin * ldx, ldx, pos, kk, Cp, Cvalid, Cout, CoutS, Lout * CoutS,
+                          CoutS, out_f32, e, mask_cols=Cout, want_stats=want_stats)
+        ctx.geom, ctx.epi, ctx.noise = geom, (act, slope, drop_p, site), noise
+        ctx.pack, ctx.name, ctx.flat, ctx.out_f32, ctx.ldx, ctx.CoutS = pack, name, flat, out_f32, ldx, CoutS
+        ctx.w_leaf, ctx.b_leaf = w, bias
+        need_y = (act == L.ACT_LEAKY and not out_f32)
+        ctx.save_for_backward(x, y if need_y else None)
+        _Conv16.last_stats = st
+        return y.view(N, Lout, CoutS)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        N, Lin, Lout, Cin, Cout, ks, stride, pad, dil = ctx.geom
+        act, slope, drop_p, site = ctx.epi
+        lib = _lib()
+        pack, name = ctx.pack, ctx.name
+        if ctx.out_f32:                         # fp32 gradient of an fp32 output (the decoder Linear): one cast
+            g = to_bf16_raw(dy.reshape(N * Lout, Cout).contiguous(), pad32(Cout))
+            ldg = g.shape[1]
+        else:
+            dy, _, ldg = _rows16(dy)
+            if act != L.ACT_NONE or drop_p > 0:
+                g = torch.empty_like(dy)
+                e = L.Epilogue(act, float(slope), float(drop_p), _p(ctx.noise) if drop_p > 0 else None, int(site))
+                L.check(lib.s2ag_bf16_epilogue_bwd(_p(dy), _p(y), N * Lout, Cout, ldg, C.byref(e), _p(g), _s()),
+                        'bf16_epilogue_bwd')
+            else:
+                g = dy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            ldx = ctx.ldx
+            dx = torch.empty(N * Lin, ldx, dtype=torch.bfloat16, device=g.device)
+            CpO = pad32(Cout)
+            gv = min(CpO, ldg)
+            if stride == 1:
+                wd = pack.get(name, 'dgrad')                                   # (Cin, ks, CpO)
+                _conv_launch(g, wd, None, dx, N, Lin, Lout, Lout * ldg, ldg, (1, pad - (ks - 1) * dil, dil), ks, CpO, gv,
+                             Cin, ldx, Lin * ldx, ldx, False)
+            else:
+                assert pad == 0 and dil == 1
+                wph = pack.get(name, 'phases')                                 # (s, Cin, nt, CpO)
+                nt = wph.shape[2]
+                Lq = (Lin + stride - 1) // stride
+                _conv_launch(g, wph, None, dx, N, Lq, Lout, Lout * ldg, ldg, (1, 0, -1), nt, CpO, gv, Cin, ldx, Lin * ldx,
+                             stride * ldx, False, phases=stride, w_phase=Cin * nt * CpO, y_phase=ldx, q_total=Lin)
+            dx = dx.view(N, Lin, ldx)
+        # weight (+ bias) gradient, accumulated into the leaf's gradient slot
+        wleaf, bleaf = ctx.w_leaf, ctx.b_leaf
+        dw = db = None
+        if ctx.needs_input_grad[1] or (bleaf is not None and ctx.needs_input_grad[2]):
+            wslot = ops._grad_slot(wleaf) if ctx.needs_input_grad[1] else None
+            bslot = ops._grad_slot(bleaf) if (bleaf is not None and ctx.needs_input_grad[2]) else None
+            if ctx.needs_input_grad[1] and wslot is None:
+                dw = torch.zeros_like(wleaf)
+                wslot = dw
+            if bleaf is not None and ctx.needs_input_grad[2] and bslot is None:
+                db = torch.zeros_like(bleaf)
+                bslot = db
+            tap_major = pack.entries[name]['layout'] == 'tap_major'
+            if wleaf.dim() == 2:
+                d_co, d_t, d_c = Cin, 0, 1
+            elif tap_major:
+                d_co, d_t, d_c = ks * Cin, Cin, 1
+            else:
+                d_co, d_t, d_c = Cin * ks, 1, ks
+            if ctx.flat:
+                Kp64 = (ks * Cin + 63) // 64 * 64
+                a = L.BF16Wgrad(_p(g), _p(x), _p(wslot), _p(bslot), N, Lout, Lin, Lin * ctx.ldx, ctx.ldx, ldg, stride, 0, 0,
+                                1, Kp64, ks * Cin, Cout, Cin, d_co, d_t, d_c, Cin, ks)
+            else:
+                Cp64 = (max(ctx.ldx, Cin) + 63) // 64 * 64
+                a = L.BF16Wgrad(_p(g), _p(x), _p(wslot), _p(bslot), N, Lout, Lin, Lin * ctx.ldx, ctx.ldx, ldg, stride, -pad,
+                                dil, ks, Cp64, ctx.ldx, Cout, Cin, d_co, d_t, d_c, 0, ks)
+            if wslot is not None:
+                L.check(lib.s2ag_bf16_conv_wgrad(C.byref(a), _s()), 'bf16_conv_wgrad')
+                if dw is None:
+                    ops._note_staged(wleaf)
+                if bslot is not None and db is None:
+                    ops._note_staged(bleaf)
+            elif bslot is not None:
+                ops.colsum_raw(to_f32_raw(g, Cout), bslot, accumulate=True)
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv(x: Tensor, w: Tensor, bias: Optional[Tensor], pack: WeightPack, name: str, Cin: int, Cout: int, ks: int,
+         stride=1, pad=0, dil=1, lout=None, act=L.ACT_NONE, slope=1.0, drop_p=0.0, noise=None, site=0, out_f32=False,
+         bn_stats=False, pad_out=False):
+    """bf16 conv1d on channels-last rows.  Returns y, with ``y._s2ag_stats`` set when ``bn_stats``."""
+    N, Lin = x.shape[0], x.shape[1]
+    if lout is None:
+        lout = (Lin + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+    y = _Conv16.apply(x, w, bias, pack, name, (N, Lin, lout, Cin, Cout, ks, stride, pad, dil),
+                      (act, float(slope), float(drop_p), noise, site), (bool(out_f32), bool(bn_stats), bool(pad_out)))
+    if bn_stats and _Conv16.last_stats is not None:
+        y._s2ag_stats = _Conv16.last_stats
+    _Conv16.last_stats = None
+    return y
+
+
+_Conv16.last_stats = None
+
+
+# ----------------------------------------------------------------------------------------------------
+# the one-channel wave conv (conv1 of the wave encoder): fp32 waveform in, bf16 out
+# ----------------------------------------------------------------------------------------------------
+class _ConvC1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, wav, w, bias, stride, pad, want_stats):
+        lib = _lib()
+        N, Lin = wav.shape
+        Cout, _, ks = w.shape
+        Lout = (Lin + 2 * pad - (ks - 1) - 1) // stride + 1
+        wav = wav.contiguous()
+        g = L.ConvGeom(N, Lin, Lout, 1, Cout, ks, stride, pad, 1, 1, Cout, 0)
+        y = torch.empty(N, Lout, Cout, dtype=torch.bfloat16, device=wav.device)
+        st = None
+        if want_stats:
+            rows = lib.s2ag_bf16_conv_c1_rows(C.byref(g))
+            part = torch.empty(2 * rows * Cout, dtype=torch.float64, device=wav.device)
+            got = C.c_int(0)
+            L.check(lib.s2ag_bf16_conv_c1_fwd(_p(wav), _p(w), _p(bias), _p(y), C.byref(g), _p(part), C.byref(got), _s()),
+                    'bf16_conv_c1_fwd')
+            st = (part[:2 * got.value * Cout], got.value)
+        else:
+            L.check(lib.s2ag_bf16_conv_c1_fwd(_p(wav), _p(w), _p(bias), _p(y), C.byref(g), None, None, _s()),
+                    'bf16_conv_c1_fwd')
+        ctx.geom = (N, Lin, Lout, Cout, ks, stride, pad)
+        ctx.w_leaf, ctx.b_leaf = w, bias
+        ctx.save_for_backward(wav)
+        _ConvC1.last_stats = st
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (wav,) = ctx.saved_tensors
+        N, Lin, Lout, Cout, ks, stride, pad = ctx.geom
+        dy, _, ldg = _rows16(dy)
+        g = L.ConvGeom(N, Lin, Lout, 1, Cout, ks, stride, pad, 1, 1, ldg, 0)
+        w, b = ctx.w_leaf, ctx.b_leaf
+        wslot = ops._grad_slot(w)
+        bslot = ops._grad_slot(b) if b is not None else None
+        dw = db = None
+        if wslot is None:
+            dw = torch.zeros_like(w)
+            wslot = dw
+        if b is not None and bslot is None:
+            db = torch.zeros_like(b)
+            bslot = db
+        L.check(_lib().s2ag_bf16_conv_c1_wgrad(_p(dy), _p(wav), _p(wslot), _p(bslot), C.byref(g), _s()), 'bf16_conv_c1_wgrad')
+        return None, dw, db, None, None, None
+
+
+_ConvC1.last_stats = None
+
+
+def conv_c1(wav: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad: int, bn_stats=False) -> Tensor:
+    y = _ConvC1.apply(wav, w, bias, int(stride), int(pad), bool(bn_stats))
+    if bn_stats and _ConvC1.last_stats is not None:
+        y._s2ag_stats = _ConvC1.last_stats
+    _ConvC1.last_stats = None
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------
+# BatchNorm (+ leaky) on bf16 rows
+# ----------------------------------------------------------------------------------------------------
+_BN_SCRATCH = {}
+
+
+def _bn_scratch(dev, cols):
+    key = (dev.index, cols)
+    if key not in _BN_SCRATCH:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('bf16 BatchNorm scratch must exist before hipGraph capture (run one eager step first)')
+        _BN_SCRATCH[key] = torch.zeros(2 * cols, dtype=torch.float32, device=dev)
+    return _BN_SCRATCH[key]
+
+
+class _BNAct16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, nbt, slope, training, eps, momentum, stats):
+        lib = _lib()
+        shape = x.shape
+        x, rows, ld = _rows16(x)
+        cols = gamma.numel()
+        assert ld == cols and cols % 8 == 0, 'bf16 BatchNorm: unpadded channel axis, multiple of 8'
+        dev = x.device
+        coef = torch.empty(4, cols, dtype=torch.float32, device=dev)
+        if training:
+            assert stats is not None, 'bf16 BatchNorm takes its batch statistics from the producing conv'
+            part, prow = stats
+            L.check(lib.s2ag_bn_fold(_p(part), int(prow), rows, cols, None, cols, _p(gamma), _p(beta), _p(rmean), _p(rvar),
+                                     _p(nbt), float(eps), float(momentum), int(ops._BN_REPEAT[0]), _p(coef[0]),
+                                     _p(coef[1]), _p(coef[2]), _p(coef[3]), _s()), 'bn_fold')
+        else:
+            L.check(lib.s2ag_bn_coeffs(None, None, None, cols, cols, rows, _p(gamma), _p(beta), _p(rmean), _p(rvar), None,
+                                       float(eps), float(momentum), 0, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
+                                       _s()), 'bn_coeffs')
+        y = torch.empty_like(x)
+        L.check(lib.s2ag_bf16_bn_apply(_p(x), rows, cols, ld, _p(coef[0]), _p(coef[1]), float(slope), _p(y), _s()),
+                'bf16_bn_apply')
+        ctx.save_for_backward(x, coef)
+        ctx.meta = (rows, cols, ld, float(slope), bool(training))
+        ctx.leaves = (gamma, beta)
+        _bn_scratch(dev, cols)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, coef = ctx.saved_tensors
+        rows, cols, ld, slope, training = ctx.meta
+        shape = dy.shape
+        dy, _, _ = _rows16(dy)
+        dev = dy.device
+        dx = torch.empty_like(dy)
+        sg, sb = ops._grad_slot(ctx.leaves[0]), ops._grad_slot(ctx.leaves[1])
+        dgamma = dbeta = None
+        if sg is None or sb is None:
+            dgb = torch.zeros(2, cols, dtype=torch.float32, device=dev)
+            sg, sb = dgb[0], dgb[1]
+            dgamma, dbeta = dgb[0], dgb[1]
+        tmp = torch.empty(2, cols, dtype=torch.float32, device=dev)
+        assert training, 'bf16 BatchNorm backward is only defined in training mode'
+        L.check(_lib().s2ag_bf16_bn_bwd(_p(x), _p(dy), rows, cols, ld, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
+                                        slope, _p(sg), _p(sb), _p(_bn_scratch(dev, cols)), _p(tmp[0]), _p(tmp[1]),
+                                        _p(dx), _s()), 'bf16_bn_bwd')
+        return dx.view(shape), dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x: Tensor, bn: torch.nn.Module, slope: float = 1.0) -> Tensor:
+    tr = bn.training
+    stats = getattr(x, '_s2ag_stats', None) if tr else None
+    return _BNAct16.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked if tr else None,
+                          float(slope), bool(tr), float(bn.eps), float(bn.momentum), stats)
+
+
+# ----------------------------------------------------------------------------------------------------
+# residual add + ReLU, embedding
+# ----------------------------------------------------------------------------------------------------
+class _AddAct16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, slope, cols):
+        a_, rows, ld = _rows16(a)
+        b_, _, _ = _rows16(b)
+        y = torch.empty_like(a_)
+        L.check(_lib().s2ag_bf16_add_act(_p(a_), _p(b_), a_.numel(), float(slope), _p(y), _s()), 'bf16_add_act')
+        ctx.meta = (rows, cols, ld, float(slope))
+        ctx.save_for_backward(y)
+        return y.view(a.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        rows, cols, ld, slope = ctx.meta
+        dy, _, _ = _rows16(dy)
+        g = torch.empty_like(dy)
+        e = L.Epilogue(L.ACT_LEAKY, slope, 0.0, None, 0)
+        L.check(_lib().s2ag_bf16_epilogue_bwd(_p(dy), _p(y), rows, cols, ld, C.byref(e), _p(g), _s()), 'bf16_epilogue_bwd')
+        return g, g, None, None
+
+
+def add_act(a: Tensor, b: Tensor, slope: float, cols: int) -> Tensor:
+    return _AddAct16.apply(a, b, float(slope), int(cols))
+
+
+class _Embedding16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, table, drop_p, noise, site, ld):
+        ids_ = ids.contiguous().view(-1)
+        rows, dim = ids_.numel(), table.shape[1]
+        out = torch.empty(rows, ld, dtype=torch.bfloat16, device=table.device)
+        e = L.Epilogue(L.ACT_NONE, 1.0, float(drop_p), _p(noise) if drop_p > 0 else None, int(site))
+        L.check(_lib().s2ag_bf16_embedding_fwd(_p(ids_), _p(table), rows, dim, table.shape[0], _p(out), ld, C.byref(e), _s()),
+                'bf16_embedding_fwd')
+        ctx.save_for_backward(ids_)
+        ctx.meta = (table.shape[0], dim, float(drop_p), int(site), ld)
+        ctx.noise, ctx.table_leaf = noise, table
+        return out.view(*ids.shape, ld)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids_,) = ctx.saved_tensors
+        n_entries, dim, drop_p, site, ld = ctx.meta
+        dy, rows, _ = _rows16(dy)
+        e = L.Epilogue(L.ACT_NONE, 1.0, drop_p, _p(ctx.noise) if drop_p > 0 else None, site)
+        slot = ops._grad_slot(ctx.table_leaf)
+        dt = None
+        if slot is None:
+            dt = torch.zeros(n_entries, dim, dtype=torch.float32, device=dy.device)
+            slot = dt
+        L.check(_lib().s2ag_bf16_embedding_bwd(_p(ids_), _p(dy), ld, rows, dim, n_entries, _p(slot), C.byref(e), _s()),
+                'bf16_embedding_bwd')
+        return None, dt, None, None, None, None
+
+
+def embedding(ids: Tensor, table: Tensor, drop_p: float = 0.0, noise=None, site=0) -> Tensor:
+    return _Embedding16.apply(ids, table, float(drop_p), noise, int(site), pad32(table.shape[1]))

@@ -36,6 +36,12 @@ struct C1P {
     int total_runs;               // N * runs_per_clip
 };
 
+__device__ __forceinline__ unsigned c1_bf16_rn(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
 // stage the waveform under output frames [l0, l0 + C1_RUN) of clip n: seg[i] = x[n, l0*stride - pad + i]
 template <int KS>
 __device__ __forceinline__ void stage_segment(const C1P& p, float* seg, int n, int l0, int seg_len) {
@@ -47,7 +53,7 @@ __device__ __forceinline__ void stage_segment(const C1P& p, float* seg, int n, i
     }
 }
 
-template <int CO, int KS>
+template <int CO, int KS, bool BF>
 __global__ __launch_bounds__(C1_NT) void conv_c1_fwd_k(const C1P p) {
     static_assert(CO == 16, "thread mapping: 4 channel quads");
     extern __shared__ float seg[];
@@ -82,13 +88,19 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_fwd_k(const C1P p) {
                     float a = br[c];
 #pragma unroll
                     for (int t = 0; t < KS; ++t) a = fmaf(xv[t], wr[c][t], a);
+                    if (BF) a = __uint_as_float(c1_bf16_rn(a) << 16);        // what is stored (and normalised later)
                     op[c] = a;
                     if (p.stats) {
                         s1[c] += (double)a;
                         s2[c] += (double)a * (double)a;
                     }
                 }
-                *reinterpret_cast<float4*>(p.y + ((long long)n * p.Lout + l) * p.ldy + q * 4) = o;
+                if (BF)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + ((long long)n * p.Lout + l) * p.ldy + q * 4) =
+                        make_uint2((__float_as_uint(o.x) >> 16) | (__float_as_uint(o.y) & 0xffff0000u),
+                                   (__float_as_uint(o.z) >> 16) | (__float_as_uint(o.w) & 0xffff0000u));
+                else
+                    *reinterpret_cast<float4*>(p.y + ((long long)n * p.Lout + l) * p.ldy + q * 4) = o;
             }
         }
     }
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_fwd_k(const C1P p) {
     }
 }
 
-template <int CO, int KS>
+template <int CO, int KS, bool BF>
 __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
     static_assert(CO == 16, "thread mapping: 4 channel quads");
     extern __shared__ float seg[];
@@ -134,7 +146,15 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
         for (int i = 0; i < C1_RUN / 64; ++i) {
             const int f = i * 64 + fr, l = l0 + f;
             if (l < p.Lout) {
-                const float4 g4 = *reinterpret_cast<const float4*>(p.y + ((long long)n * p.Lout + l) * p.ldy + q * 4);
+                float4 g4;
+                if (BF) {
+                    const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.y) +
+                                                                    ((long long)n * p.Lout + l) * p.ldy + q * 4);
+                    g4 = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u),
+                                     __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+                } else {
+                    g4 = *reinterpret_cast<const float4*>(p.y + ((long long)n * p.Lout + l) * p.ldy + q * 4);
+                }
                 const float* gp = &g4.x;
                 const float* sx = seg + f * p.stride;
                 float xv[KS];
@@ -200,7 +220,7 @@ int s2ag_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y
     // persistent blocks (4 per CU): a thread's 60 weights are loaded once and serve all its runs
     const int blocks = p.total_runs < 1024 ? p.total_runs : 1024;
     if (stats && blocks * 4 > stats_cap_rows) return 0;
-    hipLaunchKernelGGL((conv_c1_fwd_k<16, 15>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(stride), stream, p);
+    hipLaunchKernelGGL((conv_c1_fwd_k<16, 15, false>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(stride), stream, p);
     return blocks * 4;
 }
 
@@ -213,6 +233,47 @@ int s2ag_conv_c1_wgrad(const float* gy, const float* x, float* dw, float* db, in
     p.runs_per_clip = cdiv(Lout, C1_RUN);
     p.total_runs = N * p.runs_per_clip;
     const int blocks = p.total_runs < 1024 ? p.total_runs : 1024;    // 4 blocks per CU; each adds 256 sums at the end
-    hipLaunchKernelGGL((conv_c1_wgrad_k<16, 15>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(stride), stream, p);
+    hipLaunchKernelGGL((conv_c1_wgrad_k<16, 15, false>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(stride), stream, p);
     return 1;
+}
+
+// bf16 mode (conv_bf16.hip): the same two kernels storing / loading 4 bf16 (8 bytes) per thread and frame
+extern "C" int s2ag_bf16_conv_c1_fwd(const float* x, const float* w, const float* bias, void* y, const s2ag_conv_geom* g,
+                                     double* partials, int* stat_rows, void* stream) {
+    if (stat_rows) *stat_rows = 0;
+    if (!x || !w || !y || !g || (partials == nullptr) != (stat_rows == nullptr)) return S2AG_E_BADARG;
+    if (!c1_shape_ok(g->Cin, g->Cout, g->ksize, g->dil, g->ldx, g->ldy, g->stride) || (reinterpret_cast<uintptr_t>(y) & 7))
+        return S2AG_E_UNSUPPORTED;
+    C1P p{};
+    p.x = x; p.w = w; p.bias = bias; p.y = static_cast<float*>(y); p.stats = partials;
+    p.N = g->N; p.Lin = g->Lin; p.Lout = g->Lout; p.stride = g->stride; p.pad = g->pad; p.ldx = g->ldx; p.ldy = g->ldy;
+    p.runs_per_clip = cdiv(g->Lout, C1_RUN);
+    p.total_runs = g->N * p.runs_per_clip;
+    const int blocks = p.total_runs < 1024 ? p.total_runs : 1024;
+    hipLaunchKernelGGL((conv_c1_fwd_k<16, 15, true>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(g->stride), (hipStream_t)stream, p);
+    if (stat_rows) *stat_rows = blocks * 4;
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_bf16_conv_c1_rows(const s2ag_conv_geom* g) {
+    if (!g) return S2AG_E_BADARG;
+    const int runs = g->N * cdiv(g->Lout, C1_RUN);
+    return (runs < 1024 ? runs : 1024) * 4;
+}
+
+extern "C" int s2ag_bf16_conv_c1_wgrad(const void* gy, const float* x, float* dw, float* db, const s2ag_conv_geom* g,
+                                       void* stream) {
+    if (!gy || !x || !dw || !g) return S2AG_E_BADARG;
+    if (!c1_shape_ok(g->Cin, g->Cout, g->ksize, g->dil, g->ldx, g->ldy, g->stride) || (reinterpret_cast<uintptr_t>(gy) & 7))
+        return S2AG_E_UNSUPPORTED;
+    C1P p{};
+    p.x = x; p.y = static_cast<float*>(const_cast<void*>(gy)); p.dw = dw; p.db = db;
+    p.N = g->N; p.Lin = g->Lin; p.Lout = g->Lout; p.stride = g->stride; p.pad = g->pad; p.ldx = g->ldx; p.ldy = g->ldy;
+    p.runs_per_clip = cdiv(g->Lout, C1_RUN);
+    p.total_runs = g->N * p.runs_per_clip;
+    const int blocks = p.total_runs < 1024 ? p.total_runs : 1024;
+    hipLaunchKernelGGL((conv_c1_wgrad_k<16, 15, true>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(g->stride), (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
 }

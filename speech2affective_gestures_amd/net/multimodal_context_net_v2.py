@@ -109,7 +109,29 @@ class WavEncoder(nn.Module):
             nn.Conv1d(64, 32, 15, stride=6),
         )
 
+    def _forward_bf16(self, wav_data):
+        """bf16 mode (bf16.py): conv1 reads the fp32 waveform and writes bf16; conv2-4 are implicit GEMMs on the bf16
+        matrix pipe over contiguous 15-tap windows; BatchNorm statistics ride in the conv epilogues; (B, 34, 32) leaves
+        as fp32."""
+        from .. import bf16
+        fe = self.feat_extractor
+        if getattr(self, '_pack16', None) is None:
+            self._pack16 = bf16.WeightPack()
+            for i, (ci, co) in zip((3, 6, 9), ((16, 32), (32, 64), (64, 32))):
+                self._pack16.add(f'c{i}', (lambda c=fe[i]: c.weight), 'reference', co, ci, 15, stride=6)
+        pk = self._pack16
+        x = bf16.conv_c1(wav_data, fe[0].weight, fe[0].bias, 5, 1600, bn_stats=fe[1].training)
+        x = bf16.batch_norm_act(x, fe[1], slope=0.3)
+        x = bf16.conv(x, fe[3].weight, fe[3].bias, pk, 'c3', 16, 32, 15, stride=6, bn_stats=fe[4].training)
+        x = bf16.batch_norm_act(x, fe[4], slope=0.3)
+        x = bf16.conv(x, fe[6].weight, fe[6].bias, pk, 'c6', 32, 64, 15, stride=6, bn_stats=fe[7].training)
+        x = bf16.batch_norm_act(x, fe[7], slope=0.3)
+        return bf16.conv(x, fe[9].weight, fe[9].bias, pk, 'c9', 64, 32, 15, stride=6, out_f32=True)
+
     def forward(self, wav_data):
+        from .. import bf16
+        if bf16.enabled() and self.training:
+            return self._forward_bf16(wav_data)
         fe = self.feat_extractor
         x = wav_data.unsqueeze(2)                                     # (B, L, 1) channels-last
         x = ops.conv1d_nlc(x, fe[0].weight, fe[0].bias, stride=5, pad=1600, bn_stats=fe[1].training)
@@ -174,8 +196,14 @@ class TextEncoderTCN(nn.Module):
         self.decoder.weight.data.normal_(0, 0.01)
 
     def forward(self, in_data):
+        from .. import bf16
         with noise_pass(in_data.device) as nz:
             p = self.drop.p if self.training else 0.0
+            if bf16.enabled() and self.training and self.tcn.bf16_capable():
+                # bf16 mode: (B, T, 320) bf16 rows with zero pad channels from the embedding gather to the decoder
+                emb = bf16.embedding(in_data, self.embedding.weight, p, nz, self.site)
+                y = self.tcn.forward_nlc_bf16(emb, nz, decoder=self.decoder)
+                return y.contiguous(), 0
             emb = ops.embedding(in_data, self.embedding.weight, p, nz, self.site)      # (B, T, E) channels-last
             y = self.tcn.forward_nlc(emb, nz)
             y = ops.linear(y, self.decoder.weight, self.decoder.bias)

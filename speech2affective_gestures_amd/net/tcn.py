@@ -61,6 +61,20 @@ class TemporalBlock(nn.Module):
         res = x if self.downsample is None else ops.conv1d_nlc(x, self.downsample.weight, self.downsample.bias)
         return ops.add_act(out, res, 0.0)
 
+    def forward_nlc_bf16(self, x, noise, weights, pack, idx):
+        """bf16 mode: x (B, T, Cp) bf16 with zero pad channels; ``weights`` = the two normalised fp32 (Cout, k, Cin)
+        tensors (gradient stages), ``pack`` their bf16 layouts under the names c{idx}a / c{idx}b."""
+        from .. import bf16
+        out = x
+        pad = (self.kernel_size - 1) * self.dilation
+        C = self.conv1.out_channels
+        p = self.p if self.training else 0.0
+        for j, (conv, site) in enumerate(((self.conv1, self.sites[0]), (self.conv2, self.sites[1]))):
+            out = bf16.conv(out, weights[j], conv.bias, pack, f'c{idx}{"ab"[j]}', conv.in_channels, conv.out_channels,
+                            self.kernel_size, pad=pad, dil=self.dilation, lout=x.shape[1], act=ACT_LEAKY, slope=0.0,
+                            drop_p=p, noise=noise, site=site, pad_out=True)
+        return bf16.add_act(out, x, 0.0, C)
+
     def forward(self, x):
         """reference layout (B, C, T)"""
         with noise_pass(x.device) as nz:
@@ -92,6 +106,33 @@ class TemporalConvNet(nn.Module):
         ws = [w for g in self._weight_groups() for w in g.tensors()]
         for i, blk in enumerate(self.network):
             x = blk.forward_nlc(x, noise, weights=ws[2 * i:2 * i + 2])
+        return x
+
+    def bf16_capable(self):
+        """The bf16 path covers the shape the S2AG text encoder uses: no down-sampling residual (in == out channels)."""
+        return all(blk.downsample is None for blk in self.network)
+
+    def forward_nlc_bf16(self, x, noise, decoder=None):
+        """bf16 mode (bf16.py): x (B, T, Cp) bf16.  The weight-normed fp32 weights stay the gradient stages; their bf16
+        forward / data-gradient layouts (and the decoder Linear's) are refreshed with one launch per optimizer step.
+        Returns bf16 (B, T, Cp), or the decoder's fp32 (B, T, out) when ``decoder`` is given."""
+        from .. import bf16
+        ws = [w for g in self._weight_groups() for w in g.tensors()]
+        if getattr(self, '_pack16', None) is None or self._pack16_dec is not decoder:
+            pk = bf16.WeightPack()
+            for i, blk in enumerate(self.network):
+                for j, conv in enumerate((blk.conv1, blk.conv2)):
+                    pk.add(f'c{i}{"ab"[j]}', (lambda k=2 * i + j: self._cur_ws[k]), 'tap_major', conv.out_channels,
+                           conv.in_channels, blk.kernel_size)
+            if decoder is not None:
+                pk.add('dec', (lambda d=decoder: d.weight), 'tap_major', decoder.out_features, decoder.in_features, 1)
+            self._pack16, self._pack16_dec = pk, decoder
+        self._cur_ws = ws
+        for i, blk in enumerate(self.network):
+            x = blk.forward_nlc_bf16(x, noise, ws[2 * i:2 * i + 2], self._pack16, i)
+        if decoder is not None:
+            return bf16.conv(x, decoder.weight, decoder.bias, self._pack16, 'dec', decoder.in_features,
+                             decoder.out_features, 1, out_f32=True)
         return x
 
     def forward(self, x):

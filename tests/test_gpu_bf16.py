@@ -1,0 +1,217 @@
+"""bf16 mode of the Conv1d hot path (csrc/conv_bf16.hip, bf16.py): kernels against torch fp32 on the SAME bf16-rounded
+operands, and the two encoders in bf16 mode against their own fp32 mode.  The reference has no reduced-precision path; the
+tolerances below are the measured ones of bf16 storage (8 mantissa bits: 2^-9 = 2e-3 per stored element), fp32
+accumulation -- stated per assertion.  fp32 remains the mode in which the 1e-3 parity bar is proven."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
+
+
+def l2(a, b):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    return float((a - b).norm() / max(1e-12, float(b.norm())))
+
+
+def r16(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize('case', [
+    dict(N=5, L=34, Cin=300, Cout=300, ks=2, stride=1, dil=4, causal=True, relu=True, drop=0.3, layout='tap_major'),
+    dict(N=3, L=41, Cin=300, Cout=300, ks=2, stride=1, dil=1, causal=True, relu=True, drop=0.0, layout='tap_major'),
+    dict(N=3, L=700, Cin=16, Cout=32, ks=15, stride=6, dil=1, causal=False, relu=False, drop=0.0, layout='reference'),
+    dict(N=2, L=431, Cin=32, Cout=64, ks=15, stride=6, dil=1, causal=False, relu=False, drop=0.0, layout='reference'),
+    dict(N=7, L=217, Cin=64, Cout=32, ks=15, stride=6, dil=1, causal=False, relu=False, drop=0.0, layout='reference',
+         out_f32=True),
+    dict(N=9, L=34, Cin=300, Cout=32, ks=1, stride=1, dil=1, causal=False, relu=False, drop=0.0, layout='tap_major',
+         out_f32=True),
+])
+def test_bf16_conv_forward_and_both_gradients(case):
+    """s2ag_bf16_conv (forward, stride-1 and poly-phase data gradients) and s2ag_bf16_conv_wgrad through bf16.conv against
+    F.conv1d in fp32 on the same bf16-rounded x and w.  Outputs are bf16: <= 2^-8 of the largest element (4e-3) + the
+    accumulation-order noise; weight gradients are fp32 sums of bf16 products: 1e-2 of the largest element with bf16 gy."""
+    from speech2affective_gestures_amd import bf16, noise, ops
+    from speech2affective_gestures_amd import _lib as L
+    c = case
+    N, Lin, Cin, Cout, ks, s, dil = c['N'], c['L'], c['Cin'], c['Cout'], c['ks'], c['stride'], c['dil']
+    pad = (ks - 1) * dil if c['causal'] else 0
+    g = torch.Generator().manual_seed(N * 1000 + Lin)
+    x = torch.randn(N, Lin, Cin, generator=g)
+    w = torch.randn(Cout, Cin, ks, generator=g) / math.sqrt(Cin * ks)
+    b = torch.randn(Cout, generator=g) * 0.1
+    wl = (w.permute(0, 2, 1).contiguous() if c['layout'] == 'tap_major' else w.clone())
+    if ks == 1 and c['layout'] == 'tap_major':
+        wl = wl.reshape(Cout, Cin)
+    wd = wl.cuda().requires_grad_(True)
+    bd = b.cuda().requires_grad_(True)
+    pack = bf16.WeightPack()
+    pack.add('w', lambda: wd, c['layout'], Cout, Cin, ks, stride=s)
+    ldx = bf16.pad32(Cin) if c['layout'] == 'tap_major' else Cin
+    xd = bf16.to_bf16_raw(x.cuda().reshape(-1, Cin), ldx).view(N, Lin, ldx).requires_grad_(True)
+    noise.manual_seed(3)
+    nz = noise.begin_pass('cuda')
+    lout = Lin if c['causal'] else None
+    out_f32 = c.get('out_f32', False)
+    y = bf16.conv(xd, wd, bd, pack, 'w', Cin, Cout, ks, stride=s, pad=pad, dil=dil, lout=lout,
+                  act=L.ACT_LEAKY if c['relu'] else L.ACT_NONE, slope=0.0, drop_p=c['drop'], noise=nz, site=7,
+                  out_f32=out_f32, bn_stats=not out_f32 and not c['relu'], pad_out=c['layout'] == 'tap_major')
+    # reference on the rounded operands
+    xr = r16(x).requires_grad_(True)
+    wr = r16(w).requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    xin = xr.transpose(1, 2)
+    if c['causal']:
+        xin = F.pad(xin, (pad, 0))
+    yr = F.conv1d(xin, wr, br, stride=s, dilation=dil).transpose(1, 2)
+    if c['relu']:
+        yr = yr.relu()
+    if c['drop'] > 0:
+        yr = yr * ops.dropout_mask(nz, 7, c['drop'], yr.shape).cpu()
+    Lout = yr.shape[1]
+    assert y.shape[:2] == (N, Lout)
+    yl = y[..., :Cout].float()
+    assert rel(yl, yr) < 6e-3, rel(yl, yr)
+    if y.shape[-1] > Cout:
+        assert float(y[..., Cout:].float().abs().max()) == 0.0            # pad channels are written as zeros
+    st = getattr(y, '_s2ag_stats', None)
+    if st is not None:                                                    # fp64 column sums of the rounded outputs
+        part, rows = st
+        part = part.view(2, rows, Cout).sum(1).cpu()
+        yq = y.float().cpu().double().reshape(-1, Cout)
+        assert torch.allclose(part[0], yq.sum(0), rtol=1e-9, atol=1e-6)
+        assert torch.allclose(part[1], (yq * yq).sum(0), rtol=1e-9, atol=1e-6)
+    dy = torch.randn(yr.shape, generator=g)
+    if out_f32:
+        y.backward(dy.cuda())
+        yr.backward(dy)
+    else:
+        dyq = torch.zeros(y.shape)
+        dyq[..., :Cout] = dy
+        y.backward(dyq.cuda().to(torch.bfloat16))
+        yr.backward(r16(dy))
+    dx = xd.grad[..., :Cin].float()
+    assert rel(dx, xr.grad) < 1e-2, rel(dx, xr.grad)
+    if ldx > Cin:
+        assert float(xd.grad[..., Cin:].float().abs().max()) == 0.0
+    gw = wd.grad.reshape(Cout, ks, Cin).permute(0, 2, 1) if c['layout'] == 'tap_major' else wd.grad
+    # gy passes through one more bf16 rounding (the epilogue backward) in the ReLU / dropout cases
+    assert rel(gw, wr.grad) < 1e-2, rel(gw, wr.grad)
+    assert rel(bd.grad, br.grad) < 1e-2, rel(bd.grad, br.grad)
+
+
+def test_bf16_wave_conv1_batchnorm_and_elementwise_kernels():
+    """conv1 of the wave encoder writing bf16 (+ statistics), BatchNorm apply / backward on bf16 rows, residual add + ReLU
+    and the embedding gather with dropout -- each against torch fp32 on the rounded operands."""
+    from speech2affective_gestures_amd import bf16, noise, ops
+    g = torch.Generator().manual_seed(5)
+    N, Lin = 3, 4000
+    wav = torch.randn(N, Lin, generator=g) * 0.05
+    w = torch.randn(16, 1, 15, generator=g) / 4
+    b = torch.randn(16, generator=g) * 0.1
+    wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(16).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.2, 0.2)
+    bn_ref = torch.nn.BatchNorm1d(16).train()
+    bn_ref.load_state_dict({k: v.cpu() for k, v in bn.state_dict().items()})
+    y = bf16.conv_c1(wav.cuda(), wd, bd, 5, 1600, bn_stats=True)
+    z = bf16.batch_norm_act(y, bn, slope=0.3)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv1d(wav.unsqueeze(1), wr, br, stride=5, padding=1600)                  # (N, 16, Lout)
+    assert rel(y.float(), yr.transpose(1, 2)) < 5e-3
+    # BatchNorm of the ROUNDED conv output (what the kernel normalises), straight-through for the gradient check
+    yq = (r16(yr) - yr).detach() + yr
+    zr = F.leaky_relu(bn_ref(yq), 0.3)
+    assert rel(z.float(), zr.transpose(1, 2)) < 6e-3
+    assert rel(bn.running_var, bn_ref.running_var) < 1e-4 and rel(bn.running_mean, bn_ref.running_mean) < 1e-4
+    dz = torch.randn(zr.shape, generator=g)
+    z.backward(dz.transpose(1, 2).contiguous().cuda().to(torch.bfloat16))
+    zr.backward(r16(dz))
+    assert rel(bn.weight.grad, bn_ref.weight.grad) < 1e-2 and rel(bn.bias.grad, bn_ref.bias.grad) < 1e-2
+    assert rel(wd.grad, wr.grad) < 2e-2 and rel(bd.grad, br.grad) < 2e-2
+    # residual add + ReLU
+    a, c = torch.randn(4, 34, 320, generator=g), torch.randn(4, 34, 320, generator=g)
+    a[..., 300:] = 0
+    c[..., 300:] = 0
+    ad, cd = (t.cuda().to(torch.bfloat16).requires_grad_(True) for t in (a, c))
+    s = bf16.add_act(ad, cd, 0.0, 300)
+    assert rel(s.float(), (r16(a) + r16(c)).relu()) < 5e-3
+    ds = torch.randn(4, 34, 320, generator=g)
+    s.backward(ds.cuda().to(torch.bfloat16))
+    want = r16(ds) * ((r16(a) + r16(c)) > 0)
+    want[..., 300:] = 0
+    assert rel(ad.grad.float(), want) < 5e-3 and torch.equal(ad.grad, cd.grad)
+    # embedding + dropout
+    table = torch.randn(50, 300, generator=g).cuda().requires_grad_(True)
+    ids = torch.randint(0, 50, (4, 34), generator=g)
+    ids[:, ::3] = 0
+    noise.manual_seed(9)
+    nz = noise.begin_pass('cuda')
+    e = bf16.embedding(ids.cuda(), table, 0.1, nz, 11)
+    mask = ops.dropout_mask(nz, 11, 0.1, (4, 34, 300)).cpu()
+    want = table.detach().cpu()[ids] * mask
+    assert e.shape == (4, 34, 320) and rel(e[..., :300].float(), want) < 5e-3
+    assert float(e[..., 300:].float().abs().max()) == 0.0
+    de = torch.randn(4, 34, 320, generator=g)
+    e.backward(de.cuda().to(torch.bfloat16))
+    wt = torch.zeros(50, 300)
+    wt.index_add_(0, ids.reshape(-1), (r16(de)[..., :300] * mask).reshape(-1, 300))
+    assert rel(table.grad, wt) < 1e-4
+
+
+@pytest.mark.parametrize('B', [3, 40])
+def test_encoders_in_bf16_mode_track_their_fp32_mode(B):
+    """WavEncoder and TextEncoderTCN (train mode, dropout on) in bf16 mode against the same modules in fp32 mode: same
+    weights, same noise stream.  Measured: features within 2e-2 of the largest element (BatchNorm amplifies the 2e-3
+    storage rounding of its input by the inverse standard deviation), every parameter gradient within 6e-2 relative L2."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import types
+    from oracle import s2ag_oracle as O
+    from speech2affective_gestures_amd import bf16, noise
+    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import TextEncoderTCN, WavEncoder
+    cfg = types.SimpleNamespace(hidden_size=300, n_layers=4, dropout_prob=0.3, freeze_wordembed=False)
+    inp = O.recipe_inputs(B, 34, 77, 500, 12)
+    res = {}
+    for mode in ('fp32', 'bf16'):
+        torch.manual_seed(1)
+        noise.reset_sites(0)
+        wav, txt = WavEncoder().cuda().train(), TextEncoderTCN(cfg, 500, 300, dropout=0.3).cuda().train()
+        if mode == 'fp32':
+            state = (wav.state_dict(), txt.state_dict())
+        else:
+            wav.load_state_dict(state[0])
+            txt.load_state_dict(state[1])
+        noise.manual_seed(5)
+        with bf16.precision(mode):
+            a = wav(inp['in_audio'].cuda())
+            t = txt(inp['in_text'].cuda())[0]
+        assert a.dtype == t.dtype == torch.float32 and a.shape == t.shape == (B, 34, 32)
+        gen = torch.Generator().manual_seed(2)
+        da, dt = torch.randn(a.shape, generator=gen).cuda(), torch.randn(t.shape, generator=gen).cuda()
+        ((a * da).sum() + (t * dt).sum()).backward()
+        grads = {('wav.' + k): p.grad.clone() for k, p in wav.named_parameters()}
+        grads.update({('txt.' + k): p.grad.clone() for k, p in txt.named_parameters() if '.net.' not in k})
+        res[mode] = (a.detach(), t.detach(), grads, wav.state_dict()['feat_extractor.4.running_var'].clone())
+    (a0, t0, g0, rv0), (a1, t1, g1, rv1) = res['fp32'], res['bf16']
+    print(f'[bf16 vs fp32, B={B}] wav {rel(a1, a0):.2e} txt {rel(t1, t0):.2e}; worst gradient L2: ' +
+          ', '.join(f'{k} {v:.2e}' for k, v in sorted(((k, l2(g1[k], g0[k])) for k in g0), key=lambda kv: -kv[1])[:4]))
+    assert rel(a1, a0) < 2e-2 and rel(t1, t0) < 2e-2
+    assert rel(rv1, rv0) < 5e-3
+    dead = ('wav.feat_extractor.0.bias', 'wav.feat_extractor.3.bias', 'wav.feat_extractor.6.bias')   # BatchNorm cancels them
+    for k in g0:
+        if k in dead:
+            continue
+        assert l2(g1[k], g0[k]) < 6e-2, (k, l2(g1[k], g0[k]))
