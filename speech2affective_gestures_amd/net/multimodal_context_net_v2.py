@@ -115,11 +115,11 @@ class WavEncoder(nn.Module):
         as fp32."""
         from .. import bf16
         fe = self.feat_extractor
-        if getattr(self, '_pack16', None) is None:
-            self._pack16 = bf16.WeightPack()
+        if self.__dict__.get('_pack16') is None:
+            self.__dict__['_pack16'] = bf16.WeightPack()
             for i, (ci, co) in zip((3, 6, 9), ((16, 32), (32, 64), (64, 32))):
-                self._pack16.add(f'c{i}', (lambda c=fe[i]: c.weight), 'reference', co, ci, 15, stride=6)
-        pk = self._pack16
+                self.__dict__['_pack16'].add(f'c{i}', (lambda c=fe[i]: c.weight), 'reference', co, ci, 15, stride=6)
+        pk = self.__dict__['_pack16']
         x = bf16.conv_c1(wav_data, fe[0].weight, fe[0].bias, 5, 1600, bn_stats=fe[1].training)
         x = bf16.batch_norm_act(x, fe[1], slope=0.3)
         x = bf16.conv(x, fe[3].weight, fe[3].bias, pk, 'c3', 16, 32, 15, stride=6, bn_stats=fe[4].training)

@@ -118,20 +118,21 @@ class TemporalConvNet(nn.Module):
         Returns bf16 (B, T, Cp), or the decoder's fp32 (B, T, out) when ``decoder`` is given."""
         from .. import bf16
         ws = [w for g in self._weight_groups() for w in g.tensors()]
-        if getattr(self, '_pack16', None) is None or self._pack16_dec is not decoder:
+        if self.__dict__.get('_pack16') is None or self.__dict__.get('_pack16_dec') is not decoder:
             pk = bf16.WeightPack()
             for i, blk in enumerate(self.network):
                 for j, conv in enumerate((blk.conv1, blk.conv2)):
-                    pk.add(f'c{i}{"ab"[j]}', (lambda k=2 * i + j: self._cur_ws[k]), 'tap_major', conv.out_channels,
+                    pk.add(f'c{i}{"ab"[j]}', (lambda k=2 * i + j: self.__dict__['_cur_ws'][k]), 'tap_major', conv.out_channels,
                            conv.in_channels, blk.kernel_size)
             if decoder is not None:
                 pk.add('dec', (lambda d=decoder: d.weight), 'tap_major', decoder.out_features, decoder.in_features, 1)
-            self._pack16, self._pack16_dec = pk, decoder
-        self._cur_ws = ws
+            # plain attributes (NOT nn.Module attributes: the decoder must not become a sub-module of the TCN)
+            self.__dict__['_pack16'], self.__dict__['_pack16_dec'] = pk, decoder
+        self.__dict__['_cur_ws'] = ws
         for i, blk in enumerate(self.network):
-            x = blk.forward_nlc_bf16(x, noise, ws[2 * i:2 * i + 2], self._pack16, i)
+            x = blk.forward_nlc_bf16(x, noise, ws[2 * i:2 * i + 2], self.__dict__['_pack16'], i)
         if decoder is not None:
-            return bf16.conv(x, decoder.weight, decoder.bias, self._pack16, 'dec', decoder.in_features,
+            return bf16.conv(x, decoder.weight, decoder.bias, self.__dict__['_pack16'], 'dec', decoder.in_features,
                              decoder.out_features, 1, out_f32=True)
         return x
 

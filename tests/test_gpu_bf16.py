@@ -141,7 +141,7 @@ def test_bf16_wave_conv1_batchnorm_and_elementwise_kernels():
     z.backward(dz.transpose(1, 2).contiguous().cuda().to(torch.bfloat16))
     zr.backward(r16(dz))
     assert rel(bn.weight.grad, bn_ref.weight.grad) < 1e-2 and rel(bn.bias.grad, bn_ref.bias.grad) < 1e-2
-    assert rel(wd.grad, wr.grad) < 2e-2 and rel(bd.grad, br.grad) < 2e-2
+    assert rel(wd.grad, wr.grad) < 2e-2          # (conv1's bias is cancelled by the BatchNorm: its gradient is rounding noise)
     # residual add + ReLU
     a, c = torch.randn(4, 34, 320, generator=g), torch.randn(4, 34, 320, generator=g)
     a[..., 300:] = 0
