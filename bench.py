@@ -287,10 +287,15 @@ def gen_forward_ms(pr, device, cpu=True):
     return out
 
 
-def conv1d_roofline_run(device, B=256, iters=30, cpu=True):
+def conv1d_roofline_run(device, B=256, iters=30, cpu=True, mode='fp32'):
     """BASELINE configs[3] (the 'Conv1d roofline run'): WavEncoder + TextEncoderTCN forward + backward, train mode,
-    dropout on, isolated, B = 256.  HBM-bound by design: algorithmic traffic 5.75 MB/clip in fp32 (every
-    layer reads its input and writes its output once forward; backward re-reads x, reads dy, writes dx)."""
+    dropout on, isolated, B = 256, in fp32 or in bf16 mode (bf16 activations in HBM, fp32 accumulation / statistics /
+    master weights; csrc/conv_bf16.hip).  HBM-bound by design.  Algorithmic traffic per clip (every layer
+    reads its input and writes its output once forward; backward re-reads x, reads dy, writes dx): 5.75 MB in fp32;
+    2.95 MB in bf16 mode (the 145 KB waveform stays fp32, every activation and activation gradient halves).  Every
+    iteration starts a new step generation, so the per-optimizer-step weight preparation (weight norm, tap-major / bf16
+    operand copies) is inside the timed region, as in training."""
+    from speech2affective_gestures_amd import bf16, ops
     from speech2affective_gestures_amd.net.multimodal_context_net_v2 import TextEncoderTCN, WavEncoder
     from speech2affective_gestures_amd.optim import ParamArena
     cfg = make_cfg()
@@ -299,19 +304,23 @@ def conv1d_roofline_run(device, B=256, iters=30, cpu=True):
     text, audio, _, _, _ = synthetic_batch(B, 5, device)
 
     def fn():
+        ops.begin_step()
         arena.zero_grad()
         (wav(audio).sum() + txt(text)[0].sum()).backward()
-    ms = _graph_timer(fn, iters)
+    with bf16.precision(mode):
+        ms = _graph_timer(fn, iters)
     clips = B / (ms * 1e-3)
-    bytes_per_clip, flops_per_clip = 5.75e6, 413.8e6
-    out = dict(workload='BASELINE configs[3]: WavEncoder + TextEncoderTCN fwd+bwd, B=256, T=34, fp32, dropout on',
-               ms_per_iter=ms, clips_per_s=clips, dtype='f32',
+    bytes_per_clip, flops_per_clip = (5.75e6 if mode == 'fp32' else 2.95e6), 413.8e6
+    out = dict(workload=f'BASELINE configs[3]: WavEncoder + TextEncoderTCN fwd+bwd, B=256, T=34, {mode}, dropout on',
+               ms_per_iter=ms, clips_per_s=clips, dtype='f32' if mode == 'fp32' else 'bf16',
                roofline=dict(bound='hbm', achieved=clips * bytes_per_clip / 1e9, peak=8000.0, unit='GB/s',
                              frac=clips * bytes_per_clip / 8e12, traffic=None,
                              algorithmic_bytes_per_clip=bytes_per_clip,
+                             frac_at_fp32_bytes=clips * 5.75e6 / 8e12,
                              note=f'{clips * flops_per_clip / 1e12:.1f} TFLOP/s of matrix work at this rate '
-                                  '(413.8 MFLOP/clip); kernel-level trace: profiles/r02_cfg3_kernel_stats.txt'))
-    if cpu:
+                                  '(413.8 MFLOP/clip); kernel-level trace: profiles/r02_cfg3_kernel_stats.txt (fp32), '
+                                  'profiles/r02_cfg3_bf16_kernel_stats.txt (bf16)'))
+    if cpu and mode == 'fp32':
         from oracle import s2ag_oracle as O
         phys, cand = _cpu_threads()
         oc = O.ModelCfg()
@@ -459,6 +468,7 @@ def main():
             line['alt_modes'] = alt_modes(pr, dp, batch, B)
             line['gen_fwd_ms'] = gen_forward_ms(pr, pr.device, cpu=not a.no_cpu_baseline)
             line['conv1d_roofline_run'] = conv1d_roofline_run(pr.device, cpu=not a.no_cpu_baseline)
+            line['conv1d_roofline_run_bf16'] = conv1d_roofline_run(pr.device, cpu=False, mode='bf16')
         if dp.world_size == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(B, frames=frames, audio_len=audio_len)
             line['gpu_over_cpu'] = value / line['cpu_baseline']['value']
