@@ -355,6 +355,14 @@ typedef struct {
     long long w_phase;
     int y_phase, q_total;
     int mask_cols;              /* 0: Cout */
+    /* optional, data-gradient launches (bf16 output, phases == 1): the stored value is additionally multiplied by
+     * act'(post_y) * dropout mask of the layer that produced this launch's gradient target -- post_y is that layer's
+     * output, laid out exactly like y here; mask index row*post_cols + co; channels >= post_cols become zero */
+    const void* post_y;
+    int post_act, post_cols;
+    float post_slope, post_drop;
+    const void* post_rng;
+    unsigned post_site;
 } s2ag_bf16_conv_args;
 int s2ag_bf16_conv_stats_rows(int rows);
 int s2ag_bf16_conv(const s2ag_bf16_conv_args* c, const s2ag_epilogue* e /*host, nullable*/, double* partials, int* stat_rows,

@@ -40,7 +40,9 @@ class BF16Conv(C.Structure):      # s2ag_bf16_conv_args
     _fields_ = [('x', vp), ('w', vp), ('bias', vp), ('y', vp), ('N', ci), ('Lq', ci), ('Lin', ci), ('x_clip', cll),
                 ('ldx', ci), ('pos_mul', ci), ('pos_off', ci), ('pos_tap', ci), ('ks', ci), ('Cp', ci), ('Cvalid', ci),
                 ('Cout', ci), ('CoutS', ci), ('y_clip', cll), ('y_row', ci), ('y_off', ci), ('out_f32', ci),
-                ('phases', ci), ('w_phase', cll), ('y_phase', ci), ('q_total', ci), ('mask_cols', ci)]
+                ('phases', ci), ('w_phase', cll), ('y_phase', ci), ('q_total', ci), ('mask_cols', ci), ('post_y', vp),
+                ('post_act', ci), ('post_cols', ci), ('post_slope', cf), ('post_drop', cf), ('post_rng', vp),
+                ('post_site', cu)]
 
 
 class BF16Wgrad(C.Structure):     # s2ag_bf16_wgrad_args

@@ -201,10 +201,12 @@ class WeightPack:
 # conv (implicit GEMM), forward + both gradients
 # ----------------------------------------------------------------------------------------------------
 def _conv_launch(x, w16, bias, y, N, Lq, Lin, x_clip, ldx, pos, ks, Cp, Cvalid, Cout, CoutS, y_clip, y_row, out_f32,
-                 epi=None, phases=1, w_phase=0, y_phase=0, q_total=0, mask_cols=0, want_stats=False):
+                 epi=None, phases=1, w_phase=0, y_phase=0, q_total=0, mask_cols=0, want_stats=False, post=None):
     lib = _lib()
+    py, pact, pcols, pslope, pdrop, prng, psite = (None, 0, 0, 1.0, 0.0, None, 0) if post is None else post
     a = L.BF16Conv(_p(x), _p(w16), _p(bias), _p(y), N, Lq, Lin, x_clip, ldx, pos[0], pos[1], pos[2], ks, Cp, Cvalid, Cout,
-                   CoutS, y_clip, y_row, 0, int(out_f32), phases, w_phase, y_phase, q_total, mask_cols)
+                   CoutS, y_clip, y_row, 0, int(out_f32), phases, w_phase, y_phase, q_total, mask_cols, _p(py), int(pact),
+                   int(pcols), float(pslope), float(pdrop), _p(prng) if pdrop > 0 else None, int(psite))
     e = epi if epi is not None else L.Epilogue(L.ACT_NONE, 1.0, 0.0, None, 0)
     if want_stats:
         rows = lib.s2ag_bf16_conv_stats_rows(N * Lq)
@@ -246,6 +248,14 @@ class _Conv16(torch.autograd.Function):
         ctx.w_leaf, ctx.b_leaf = w, bias
         need_y = (act == L.ACT_LEAKY and not out_f32)
         ctx.save_for_backward(x, y if need_y else None)
+        # epilogue-backward fusion: if x is the output of a _Conv16 with an activation / dropout epilogue (it told us
+        # through _PRODUCER), this layer's data gradient applies that epilogue's derivative itself
+        ctx.prev = _PRODUCER.pop(x.data_ptr(), None) if (stride == 1 and FUSE_EPILOGUE_BWD) else None
+        ctx.token = None
+        if (need_y or drop_p > 0) and not out_f32:
+            ctx.token = object()
+            _PRODUCER.clear() if len(_PRODUCER) > 64 else None
+            _PRODUCER[y.data_ptr()] = (y, act, Cout, float(slope), float(drop_p), noise, int(site), ctx.token)
         _Conv16.last_stats = st
         return y.view(N, Lout, CoutS)
 
@@ -261,7 +271,9 @@ class _Conv16(torch.autograd.Function):
             ldg = g.shape[1]
         else:
             dy, _, ldg = _rows16(dy)
-            if act != L.ACT_NONE or drop_p > 0:
+            if ctx.token is not None and _FUSED.pop(ctx.token, None) == dy.data_ptr():
+                g = dy                          # the consumer's data gradient already applied this layer's epilogue
+            elif act != L.ACT_NONE or drop_p > 0:
                 g = torch.empty_like(dy)
                 e = L.Epilogue(act, float(slope), float(drop_p), _p(ctx.noise) if drop_p > 0 else None, int(site))
                 L.check(lib.s2ag_bf16_epilogue_bwd(_p(dy), _p(y), N * Lout, Cout, ldg, C.byref(e), _p(g), _s()),
@@ -276,8 +288,14 @@ class _Conv16(torch.autograd.Function):
             gv = min(CpO, ldg)
             if stride == 1:
                 wd = pack.get(name, 'dgrad')                                   # (Cin, ks, CpO)
+                post = None
+                if ctx.prev is not None and ctx.prev[0].shape[-1] == ldx:
+                    post = ctx.prev[:7]
+                    if len(_FUSED) > 64:
+                        _FUSED.clear()
+                    _FUSED[ctx.prev[7]] = dx.data_ptr()
                 _conv_launch(g, wd, None, dx, N, Lin, Lout, Lout * ldg, ldg, (1, pad - (ks - 1) * dil, dil), ks, CpO, gv,
-                             Cin, ldx, Lin * ldx, ldx, False)
+                             Cin, ldx, Lin * ldx, ldx, False, post=post)
             else:
                 assert pad == 0 and dil == 1
                 wph = pack.get(name, 'phases')                                 # (s, Cin, nt, CpO)
@@ -340,6 +358,9 @@ def conv(x: Tensor, w: Tensor, bias: Optional[Tensor], pack: WeightPack, name: s
 
 
 _Conv16.last_stats = None
+FUSE_EPILOGUE_BWD = os.environ.get('S2AG_BF16_FUSE_EPI', '1') != '0'
+_PRODUCER = {}      # data_ptr of a conv output -> (y, act, cols, slope, drop_p, noise, site, token) of its epilogue
+_FUSED = {}         # token -> data_ptr of the gradient tensor that already carries that epilogue's derivative
 
 
 # ----------------------------------------------------------------------------------------------------

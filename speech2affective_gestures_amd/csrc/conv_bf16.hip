@@ -70,6 +70,13 @@ struct CvP {
     unsigned site;
     int mask_cols;              // logical channel count of the dropout mask index (row * mask_cols + co)
     double* stats;              // nullable: (2, R, Cout), R = gridDim.x * 4
+    // data-gradient launches: the result is the gradient w.r.t. the OUTPUT of the producing layer; multiplying it here by
+    // that layer's act'(y) * dropout mask saves the separate epilogue-backward pass (y laid out like this launch's output)
+    const bf16_t* post_y;       // nullable
+    int post_act, post_cols;
+    float post_slope, post_drop, post_inv;
+    const unsigned long long* post_rng;
+    unsigned post_site;
 };
 
 template <int BN, bool OUT_F32>
@@ -153,6 +160,8 @@ __global__ __launch_bounds__(256) void conv_bf16_k(const CvP p) {
     SiteKey key{0, 0};
     const bool drop = p.drop_p > 0.f;
     if (drop) key = site_key(p.rng, p.site);
+    SiteKey pkey{0, 0};
+    if (p.post_y && p.post_drop > 0.f) pkey = site_key(p.post_rng, p.post_site);
     const int q_lim = (p.q_total - phase + p.q_step - 1) / p.q_step;
     double s1[TN][4], s2[TN][4];
 #pragma unroll
@@ -180,6 +189,21 @@ __global__ __launch_bounds__(256) void conv_bf16_k(const CvP p) {
                 v[c] = t;
             }
             if (!rok) continue;
+            if (p.post_y) {
+                const uint2 yp2 = *reinterpret_cast<const uint2*>(p.post_y + yb + co);
+                const unsigned yw[4] = {yp2.x & 0xffffu, yp2.x >> 16, yp2.y & 0xffffu, yp2.y >> 16};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float f = 1.f;
+                    if (co + c >= p.post_cols) f = 0.f;
+                    else {
+                        if (p.post_drop > 0.f)
+                            f = keep_scale(pkey, (unsigned long long)m * p.post_cols + co + c, p.post_drop, p.post_inv);
+                        if (p.post_act == S2AG_ACT_LEAKY) f *= (bf16_f((bf16_t)yw[c]) > 0.f ? 1.f : p.post_slope);
+                    }
+                    v[c] *= f;
+                }
+            }
             if constexpr (OUT_F32) {
                 float* yp = static_cast<float*>(p.y) + yb + co;
 #pragma unroll
@@ -258,10 +282,13 @@ struct WgP {
     int m_chunk;                // rows per blockIdx.y (multiple of 32)
 };
 
+constexpr int WG_ROWS = 64;     // rows of the contraction per step (two MFMA K steps)
+constexpr int WG_PITCH = 72;    // [column][row] image pitch in bf16 (144 B: 16 consecutive columns tile the 64 banks)
+
 __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
-    // [column][row] images of a 32-row step: 64 gy columns (channels co) and 64 x columns (channels c of tap t)
-    __shared__ __attribute__((aligned(16))) bf16_t Gt[64 * PITCH];
-    __shared__ __attribute__((aligned(16))) bf16_t Xt[64 * PITCH];
+    // [column][row] images of a 64-row step: 64 gy columns (channels co) and 64 x columns (channels c of tap t)
+    __shared__ __attribute__((aligned(16))) bf16_t Gt[64 * WG_PITCH];
+    __shared__ __attribute__((aligned(16))) bf16_t Xt[64 * WG_PITCH];
     __shared__ float bsum[64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,12 +300,11 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
     const bool do_bias = p.db != nullptr && kt == 0;
     if (tid < 64) bsum[tid] = 0.f;
 
-    // loader: threads 0..127 transpose gy, 128..255 transpose x; each handles the row pair (2*pr, 2*pr + 1) and the
-    // 8-column chunk ch of its operand
-    const bool is_x = tid >= 128;
-    const int t2 = tid & 127, pr = t2 & 15, ch = t2 >> 4;
+    // loader: every thread transposes the row pair (2*pr, 2*pr + 1) x the 8-column chunk ch of BOTH operands
+    const int pr = tid & 31, ch = tid >> 5;
     const int m_beg = blockIdx.y * p.m_chunk;
     const int m_end = min(p.M, m_beg + p.m_chunk);
+    const bool g_col = co0 + ch * 8 < p.ldg, x_col = c0 + ch * 8 < p.Cvalid;
     float bacc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bacc[j] = 0.f;
@@ -288,39 +314,37 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int wr = wave >> 1, wc = wave & 1;                    // wave's 32 x 32 quadrant: channels co, columns c
-    const int f_off = (lane & 15) * PITCH + (lane >> 4) * 8;
+    const int f_off = (lane & 15) * WG_PITCH + (lane >> 4) * 8;
 
-    u32x4 r0, r1;
+    u32x4 rg[2], rx[2];
     auto fetch = [&](int mb) {
-        r0 = r1 = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int m = mb + 2 * pr + e;
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            rg[e] = rx[e] = u32x4{0u, 0u, 0u, 0u};
             if (m < m_end) {
-                if (!is_x) {
-                    if (co0 + ch * 8 < p.ldg) v = *reinterpret_cast<const u32x4*>(p.gy + (long long)m * p.ldg + co0 + ch * 8);
-                } else {
-                    const int n = m / p.Lq, q = m - n * p.Lq;
-                    const int row = q * p.pos_mul + p.pos_off + tap * p.pos_tap;
-                    if ((unsigned)row < (unsigned)p.Lin && c0 + ch * 8 < p.Cvalid)
-                        v = *reinterpret_cast<const u32x4*>(p.x + (long long)n * p.x_clip + (long long)row * p.ldx + c0 + ch * 8);
-                }
+                if (g_col) rg[e] = *reinterpret_cast<const u32x4*>(p.gy + (long long)m * p.ldg + co0 + ch * 8);
+                const int n = m / p.Lq, q = m - n * p.Lq;
+                const int row = q * p.pos_mul + p.pos_off + tap * p.pos_tap;
+                if (x_col && (unsigned)row < (unsigned)p.Lin)
+                    rx[e] = *reinterpret_cast<const u32x4*>(p.x + (long long)n * p.x_clip + (long long)row * p.ldx + c0 + ch * 8);
             }
-            if (e == 0) r0 = v; else r1 = v;
+        }
+    };
+    auto transpose_store = [&](bf16_t* img, const u32x4& r0, const u32x4& r1) {
+        const unsigned a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned lo = (j & 1) ? (a[j >> 1] >> 16) : (a[j >> 1] & 0xffffu);
+            const unsigned hi = (j & 1) ? (b[j >> 1] >> 16) : (b[j >> 1] & 0xffffu);
+            *reinterpret_cast<unsigned*>(&img[(ch * 8 + j) * WG_PITCH + 2 * pr]) = lo | (hi << 16);
         }
     };
     auto stash = [&]() {
-        bf16_t* img = is_x ? Xt : Gt;
-        const unsigned a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int j = (jj + 2 * (ch & 3)) & 7;              // stagger the column order across chunks: spreads the banks
-            const unsigned lo = (j & 1) ? (a[j >> 1] >> 16) : (a[j >> 1] & 0xffffu);
-            const unsigned hi = (j & 1) ? (b[j >> 1] >> 16) : (b[j >> 1] & 0xffffu);
-            *reinterpret_cast<unsigned*>(&img[(ch * 8 + j) * PITCH + 2 * pr]) = lo | (hi << 16);
-        }
-        if (do_bias && !is_x) {
+        transpose_store(Gt, rg[0], rg[1]);
+        transpose_store(Xt, rx[0], rx[1]);
+        if (do_bias) {
+            const unsigned a[4] = {rg[0].x, rg[0].y, rg[0].z, rg[0].w}, b[4] = {rg[1].x, rg[1].y, rg[1].z, rg[1].w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const unsigned lo = (j & 1) ? (a[j >> 1] >> 16) : (a[j >> 1] & 0xffffu);
@@ -331,22 +355,27 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
     };
 
     if (m_beg < m_end) fetch(m_beg);
-    for (int mb = m_beg; mb < m_end; mb += 32) {
+    for (int mb = m_beg; mb < m_end; mb += WG_ROWS) {
         __syncthreads();                                        // the previous step's fragment reads are done
         stash();
         __syncthreads();
-        if (mb + 32 < m_end) fetch(mb + 32);
-        bf16x8 a[2], b[2];
+        if (mb + WG_ROWS < m_end) fetch(mb + WG_ROWS);          // in flight behind this step's MFMAs
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Gt[(wr * 32 + t * 16) * PITCH + f_off]));
-            b[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Xt[(wc * 32 + t * 16) * PITCH + f_off]));
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                                                      &Gt[(wr * 32 + t * 16) * WG_PITCH + kk * 32 + f_off]));
+                b[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                                                      &Xt[(wc * 32 + t * 16) * WG_PITCH + kk * 32 + f_off]));
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
         }
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
-                acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
     }
     // C layout: column (lane & 15) = x channel, rows (lane >> 4)*4 + {0..3} = output channel
 #pragma unroll
@@ -368,10 +397,9 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
             }
         }
     if (do_bias) {
-        if (!is_x) {
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(&bsum[ch * 8 + j], bacc[j]);
-        }
+        for (int j = 0; j < 8; ++j) atomicAdd(&bsum[ch * 8 + j], bacc[j]);
         __syncthreads();
         if (tid < 64 && co0 + tid < p.Cout) atomicAdd(p.db + co0 + tid, bsum[tid]);
     }
@@ -682,6 +710,11 @@ static int launch_conv(const s2ag_bf16_conv_args* c, const s2ag_epilogue* e, dou
     p.rng = e ? e->rng : nullptr; p.site = e ? e->site : 0u;
     p.mask_cols = c->mask_cols > 0 ? c->mask_cols : c->Cout;
     p.stats = partials;
+    p.post_y = static_cast<const bf16_t*>(c->post_y); p.post_act = c->post_act; p.post_cols = c->post_cols;
+    p.post_slope = c->post_slope; p.post_drop = c->post_drop;
+    p.post_inv = c->post_drop > 0.f ? 1.f / (1.f - c->post_drop) : 1.f;
+    p.post_rng = static_cast<const unsigned long long*>(c->post_rng); p.post_site = c->post_site;
+    if (p.post_y && (c->out_f32 || c->phases > 1 || (p.post_drop > 0.f && !p.post_rng))) return S2AG_E_BADARG;
     const int bn = p.CoutS <= 16 ? 16 : (p.CoutS <= 32 ? 32 : 64);
     const dim3 grid(cdiv(p.M, BM), cdiv(p.CoutS, bn), c->phases);
 #define S2AG_LAUNCH_CV(BN_)                                                                              \
@@ -718,10 +751,10 @@ extern "C" int s2ag_bf16_conv_wgrad(const s2ag_bf16_wgrad_args* g, void* stream)
     p.ks_out = g->flat_cin > 0 ? g->ks_out : g->ks;
     const int tiles = cdiv(g->Cout, 64) * g->ks * (g->Cp / 64);
     int splits = cdiv(768, tiles);
-    const int max_splits = cdiv(p.M, 256);                      // at least 8 steps of 32 rows per block
+    const int max_splits = cdiv(p.M, 512);                      // at least 8 steps of 64 rows per block
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    p.m_chunk = cdiv(cdiv(p.M, splits), 32) * 32;
+    p.m_chunk = cdiv(cdiv(p.M, splits), WG_ROWS) * WG_ROWS;
     splits = cdiv(p.M, p.m_chunk);
     hipLaunchKernelGGL(conv_bf16_wgrad_k, dim3(tiles, splits), dim3(256), 0, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
@@ -827,7 +860,7 @@ extern "C" int s2ag_bf16_embedding_bwd(const long long* ids, const void* dy, int
     if (!ids || !dy || !dtable || rows <= 0 || dim <= 0 || ld < dim) return S2AG_E_BADARG;
     const float p = e ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
-    const int rpb = 8;
+    const int rpb = 32;
     hipLaunchKernelGGL(embedding_bwd_bf16_k, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(128), 0, (hipStream_t)stream, ids,
                        static_cast<const bf16_t*>(dy), ld, dim, n_entries, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
                        e ? e->rng : nullptr, e ? e->site : 0u, dtable, rows, rpb);
