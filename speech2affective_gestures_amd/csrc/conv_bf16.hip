@@ -38,7 +38,6 @@ typedef unsigned short bf16_t;
 
 constexpr int KT = 32;          // K tile (channels)
 constexpr int PITCH = 40;       // LDS row pitch in bf16 (80 B)
-constexpr int BM = 128;         // output rows per block
 
 __device__ __forceinline__ unsigned bf16_rn(float v) {
     unsigned u = __float_as_uint(v);
@@ -79,23 +78,24 @@ struct CvP {
     unsigned post_site;
 };
 
-template <int BN, bool OUT_F32>
+template <int BMT, int BN, bool OUT_F32>
 __global__ __launch_bounds__(256) void conv_bf16_k(const CvP p) {
-    constexpr int TN = BN / 16;
-    __shared__ __attribute__((aligned(16))) bf16_t Xs[2][BM * PITCH];
+    constexpr int TN = BN / 16;             // weight (channel) tiles per wave
+    constexpr int RH = BMT / 64;            // activation rows per loader thread
+    __shared__ __attribute__((aligned(16))) bf16_t Xs[2][BMT * PITCH];
     __shared__ __attribute__((aligned(16))) bf16_t Ws[2][BN * PITCH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, phase = blockIdx.z;
+    const int m0 = blockIdx.x * BMT, n0 = blockIdx.y * BN, phase = blockIdx.z;
     const bf16_t* wbase = p.w + (long long)phase * p.w_phase;
 
-    // loader: rows lr and lr + 64 of the activation tile, 16-byte chunk lc; row lr (< BN) of the weight tile
+    // loader: rows lr (+ 64) of the activation tile, 16-byte chunk lc; row lr (< BN) of the weight tile
     const int lr = tid >> 2, lc = tid & 3;
-    long long xb[2];
-    int xq[2];
-    bool xok[2];
+    long long xb[RH];
+    int xq[RH];
+    bool xok[RH];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < RH; ++h) {
         const int m = m0 + lr + 64 * h;
         xok[h] = m < p.M;
         const int n = xok[h] ? m / p.Lq : 0;
@@ -105,58 +105,68 @@ __global__ __launch_bounds__(256) void conv_bf16_k(const CvP p) {
     const bool wok = lr < BN && n0 + lr < p.Cout;
     const bf16_t* wsrc = wbase + (long long)(wok ? n0 + lr : 0) * p.ks * p.Cp + lc * 8;
     const int ct = p.Cp / KT, nkt = p.ks * ct;
-    u32x4 rx[2], rw;
-    auto fetch = [&](int kt) {
+    // two K tiles in flight in registers: a tile's operands are requested two tiles before they are multiplied (one
+    // block per CU in the worst case: nothing else hides the global round trip)
+    u32x4 rx[2][RH], rw[2];
+    auto fetch = [&](int kt, int set) {
         const int tap = kt / ct, c0 = (kt - tap * ct) * KT;
         const bool cok = c0 + lc * 8 < p.Cvalid;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < RH; ++h) {
             const int row = xq[h] * p.pos_mul + p.pos_off + tap * p.pos_tap;
             const bool ok = xok[h] && cok && (unsigned)row < (unsigned)p.Lin;
-            rx[h] = ok ? *reinterpret_cast<const u32x4*>(p.x + xb[h] + (long long)row * p.ldx + c0) : u32x4{0u, 0u, 0u, 0u};
+            rx[set][h] = ok ? *reinterpret_cast<const u32x4*>(p.x + xb[h] + (long long)row * p.ldx + c0)
+                            : u32x4{0u, 0u, 0u, 0u};
         }
-        rw = wok ? *reinterpret_cast<const u32x4*>(wsrc + (long long)tap * p.Cp + c0) : u32x4{0u, 0u, 0u, 0u};
+        rw[set] = wok ? *reinterpret_cast<const u32x4*>(wsrc + (long long)tap * p.Cp + c0) : u32x4{0u, 0u, 0u, 0u};
     };
     const int l_off = lr * PITCH + lc * 8;
-    auto stash = [&](int buf) {
-        *reinterpret_cast<u32x4*>(&Xs[buf][l_off]) = rx[0];
-        *reinterpret_cast<u32x4*>(&Xs[buf][l_off + 64 * PITCH]) = rx[1];
-        if (lr < BN) *reinterpret_cast<u32x4*>(&Ws[buf][l_off]) = rw;
+    auto stash = [&](int set, int buf) {
+#pragma unroll
+        for (int h = 0; h < RH; ++h) *reinterpret_cast<u32x4*>(&Xs[buf][l_off + h * 64 * PITCH]) = rx[set][h];
+        if (lr < BN) *reinterpret_cast<u32x4*>(&Ws[buf][l_off]) = rw[set];
     };
 
-    f32x4 acc[TN][2];
+    constexpr int TMT = BMT / 64;           // 16-row tiles per wave (a wave owns BMT/4 rows)
+    f32x4 acc[TN][TMT];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TMT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int f_off = (lane & 15) * PITCH + (lane >> 4) * 8;
     auto mma = [&](int buf) {
-        bf16x8 a[TN], b[2];
+        bf16x8 a[TN], b[TMT];
 #pragma unroll
         for (int t = 0; t < TN; ++t)
             a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Ws[buf][t * 16 * PITCH + f_off]));
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-            b[t] = __builtin_bit_cast(bf16x8,
-                                      *reinterpret_cast<const u32x4*>(&Xs[buf][(wave * 32 + t * 16) * PITCH + f_off]));
+        for (int t = 0; t < TMT; ++t)
+            b[t] = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const u32x4*>(&Xs[buf][(wave * (BMT / 4) + t * 16) * PITCH + f_off]));
 #pragma unroll
         for (int ti = 0; ti < TN; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
+            for (int tj = 0; tj < TMT; ++tj)
                 acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
     };
 
-    fetch(0);
-    stash(0);
+    fetch(0, 0);
+    if (nkt > 1) fetch(1, 1);
+    stash(0, 0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) fetch(kt + 1);
-        mma(kt & 1);
-        if (kt + 1 < nkt) stash((kt + 1) & 1);
+    for (int kt = 0; kt < nkt; kt += 2) {
+        mma(0);
+        if (kt + 1 < nkt) stash(1, 1);
+        if (kt + 2 < nkt) fetch(kt + 2, 0);
+        __syncthreads();
+        if (kt + 1 >= nkt) break;
+        mma(1);
+        if (kt + 2 < nkt) stash(0, 0);
+        if (kt + 3 < nkt) fetch(kt + 3, 1);
         __syncthreads();
     }
 
-    // epilogue: lane holds channels co = n0 + ti*16 + (lane >> 4)*4 + {0..3} of row m = m0 + wave*32 + tj*16 + (lane & 15)
+    // epilogue: lane holds channels co = n0 + ti*16 + (lane >> 4)*4 + {0..3} of row m = m0 + wave*(BMT/4) + tj*16 + (lane & 15)
     SiteKey key{0, 0};
     const bool drop = p.drop_p > 0.f;
     if (drop) key = site_key(p.rng, p.site);
@@ -169,8 +179,8 @@ __global__ __launch_bounds__(256) void conv_bf16_k(const CvP p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) s1[ti][c] = s2[ti][c] = 0.0;
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        const int m = m0 + wave * 32 + tj * 16 + (lane & 15);
+    for (int tj = 0; tj < TMT; ++tj) {
+        const int m = m0 + wave * (BMT / 4) + tj * 16 + (lane & 15);
         const bool mok = m < p.M;
         const int n = mok ? m / p.Lq : 0, q = mok ? m - n * p.Lq : 0;
         const bool rok = mok && q < q_lim;
@@ -316,18 +326,19 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
     const int wr = wave >> 1, wc = wave & 1;                    // wave's 32 x 32 quadrant: channels co, columns c
     const int f_off = (lane & 15) * WG_PITCH + (lane >> 4) * 8;
 
-    u32x4 rg[2], rx[2];
-    auto fetch = [&](int mb) {
+    // two steps in flight in registers (3 blocks per CU at best: nothing else hides the global round trip)
+    u32x4 rg[2][2], rx[2][2];
+    auto fetch = [&](int mb, int set) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int m = mb + 2 * pr + e;
-            rg[e] = rx[e] = u32x4{0u, 0u, 0u, 0u};
+            rg[set][e] = rx[set][e] = u32x4{0u, 0u, 0u, 0u};
             if (m < m_end) {
-                if (g_col) rg[e] = *reinterpret_cast<const u32x4*>(p.gy + (long long)m * p.ldg + co0 + ch * 8);
+                if (g_col) rg[set][e] = *reinterpret_cast<const u32x4*>(p.gy + (long long)m * p.ldg + co0 + ch * 8);
                 const int n = m / p.Lq, q = m - n * p.Lq;
                 const int row = q * p.pos_mul + p.pos_off + tap * p.pos_tap;
                 if (x_col && (unsigned)row < (unsigned)p.Lin)
-                    rx[e] = *reinterpret_cast<const u32x4*>(p.x + (long long)n * p.x_clip + (long long)row * p.ldx + c0 + ch * 8);
+                    rx[set][e] = *reinterpret_cast<const u32x4*>(p.x + (long long)n * p.x_clip + (long long)row * p.ldx + c0 + ch * 8);
             }
         }
     };
@@ -340,11 +351,12 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
             *reinterpret_cast<unsigned*>(&img[(ch * 8 + j) * WG_PITCH + 2 * pr]) = lo | (hi << 16);
         }
     };
-    auto stash = [&]() {
-        transpose_store(Gt, rg[0], rg[1]);
-        transpose_store(Xt, rx[0], rx[1]);
+    auto stash = [&](int set) {
+        transpose_store(Gt, rg[set][0], rg[set][1]);
+        transpose_store(Xt, rx[set][0], rx[set][1]);
         if (do_bias) {
-            const unsigned a[4] = {rg[0].x, rg[0].y, rg[0].z, rg[0].w}, b[4] = {rg[1].x, rg[1].y, rg[1].z, rg[1].w};
+            const unsigned a[4] = {rg[set][0].x, rg[set][0].y, rg[set][0].z, rg[set][0].w};
+            const unsigned b[4] = {rg[set][1].x, rg[set][1].y, rg[set][1].z, rg[set][1].w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const unsigned lo = (j & 1) ? (a[j >> 1] >> 16) : (a[j >> 1] & 0xffffu);
@@ -353,13 +365,7 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
             }
         }
     };
-
-    if (m_beg < m_end) fetch(m_beg);
-    for (int mb = m_beg; mb < m_end; mb += WG_ROWS) {
-        __syncthreads();                                        // the previous step's fragment reads are done
-        stash();
-        __syncthreads();
-        if (mb + WG_ROWS < m_end) fetch(mb + WG_ROWS);          // in flight behind this step's MFMAs
+    auto mma = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 a[2], b[2];
@@ -376,6 +382,22 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
                 for (int tj = 0; tj < 2; ++tj)
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
         }
+    };
+
+    if (m_beg < m_end) fetch(m_beg, 0);
+    if (m_beg + WG_ROWS < m_end) fetch(m_beg + WG_ROWS, 1);
+    for (int mb = m_beg; mb < m_end; mb += 2 * WG_ROWS) {
+        __syncthreads();                                        // the previous step's fragment reads are done
+        stash(0);
+        __syncthreads();
+        if (mb + 2 * WG_ROWS < m_end) fetch(mb + 2 * WG_ROWS, 0);
+        mma();
+        if (mb + WG_ROWS >= m_end) break;
+        __syncthreads();
+        stash(1);
+        __syncthreads();
+        if (mb + 3 * WG_ROWS < m_end) fetch(mb + 3 * WG_ROWS, 1);
+        mma();
     }
     // C layout: column (lane & 15) = x channel, rows (lane >> 4)*4 + {0..3} = output channel
 #pragma unroll
@@ -650,32 +672,38 @@ __global__ __launch_bounds__(256) void embedding_fwd_bf16_k(const long long* __r
     }
 }
 
-// table gradient += dy (bf16) * mask, one block per token row; runs of equal ids are rare enough here to take atomics
-__global__ __launch_bounds__(128) void embedding_bwd_bf16_k(const long long* __restrict__ ids, const bf16_t* __restrict__ dy,
+// table gradient += dy (bf16) * mask.  A block owns 32 token rows, a thread one channel: the rows' loads are independent
+// (unrolled, many in flight); contributions to the PAD row (id 0: most frames of a clip) are summed in a register and leave
+// the block as ONE atomic per channel, the few word rows use direct atomics.
+__global__ __launch_bounds__(320) void embedding_bwd_bf16_k(const long long* __restrict__ ids, const bf16_t* __restrict__ dy,
                                                             int ld, int dim, int n_entries, float drop_p, float inv_keep,
                                                             const unsigned long long* rng, unsigned site,
                                                             float* __restrict__ dtable, long long rows, int rows_per_block) {
+    __shared__ long long sid[32];
     SiteKey key{0, 0};
     const bool drop = drop_p > 0.f;
     if (drop) key = site_key(rng, site);
     const long long r0 = (long long)blockIdx.x * rows_per_block;
-    for (int c = threadIdx.x; c < dim; c += 128) {
-        // merge runs of equal ids (the PAD token dominates) in a register before touching memory
-        long long cur = -1;
-        float accv = 0.f;
-        for (long long r = r0; r < r0 + rows_per_block && r < rows; ++r) {
-            long long id = ids[r];
-            if (id < 0 || id >= n_entries) id = 0;
+    const int nr = (int)min((long long)rows_per_block, rows - r0);
+    if (threadIdx.x < 32) {
+        long long id = threadIdx.x < nr ? ids[r0 + threadIdx.x] : -1;
+        if (threadIdx.x < nr && (id < 0 || id >= n_entries)) id = 0;
+        sid[threadIdx.x] = id;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        float pad_acc = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            if (i >= nr) break;
+            const long long r = r0 + i;
             float d = bf16_f(dy[r * ld + c]);
             if (drop) d *= keep_scale(key, (unsigned long long)r * dim + c, drop_p, inv_keep);
-            if (id != cur) {
-                if (cur >= 0) atomicAdd(dtable + cur * dim + c, accv);
-                cur = id;
-                accv = 0.f;
-            }
-            accv += d;
+            const long long id = sid[i];
+            if (id == 0) pad_acc += d;
+            else atomicAdd(dtable + id * dim + c, d);
         }
-        if (cur >= 0) atomicAdd(dtable + cur * dim + c, accv);
+        if (pad_acc != 0.f) atomicAdd(dtable + c, pad_acc);
     }
 }
 
@@ -716,11 +744,18 @@ static int launch_conv(const s2ag_bf16_conv_args* c, const s2ag_epilogue* e, dou
     p.post_rng = static_cast<const unsigned long long*>(c->post_rng); p.post_site = c->post_site;
     if (p.post_y && (c->out_f32 || c->phases > 1 || (p.post_drop > 0.f && !p.post_rng))) return S2AG_E_BADARG;
     const int bn = p.CoutS <= 16 ? 16 : (p.CoutS <= 32 ? 32 : 64);
-    const dim3 grid(cdiv(p.M, BM), cdiv(p.CoutS, bn), c->phases);
+    // 64-row tiles where 128-row ones would leave most CUs with a single block (the TCN: 68 x 5 blocks)
+    const int bm = (long long)cdiv(p.M, 128) * cdiv(p.CoutS, bn) * c->phases >= 1024 ? 128 : 64;
+    const dim3 grid(cdiv(p.M, bm), cdiv(p.CoutS, bn), c->phases);
 #define S2AG_LAUNCH_CV(BN_)                                                                              \
     do {                                                                                                 \
-        if (c->out_f32) hipLaunchKernelGGL((conv_bf16_k<BN_, true>), grid, dim3(256), 0, s, p);          \
-        else hipLaunchKernelGGL((conv_bf16_k<BN_, false>), grid, dim3(256), 0, s, p);                    \
+        if (bm == 128) {                                                                                 \
+            if (c->out_f32) hipLaunchKernelGGL((conv_bf16_k<128, BN_, true>), grid, dim3(256), 0, s, p); \
+            else hipLaunchKernelGGL((conv_bf16_k<128, BN_, false>), grid, dim3(256), 0, s, p);           \
+        } else {                                                                                         \
+            if (c->out_f32) hipLaunchKernelGGL((conv_bf16_k<64, BN_, true>), grid, dim3(256), 0, s, p);  \
+            else hipLaunchKernelGGL((conv_bf16_k<64, BN_, false>), grid, dim3(256), 0, s, p);            \
+        }                                                                                                \
     } while (0)
     if (bn == 16) S2AG_LAUNCH_CV(16);
     else if (bn == 32) S2AG_LAUNCH_CV(32);
@@ -731,7 +766,7 @@ static int launch_conv(const s2ag_bf16_conv_args* c, const s2ag_epilogue* e, dou
     return 0;
 }
 
-extern "C" int s2ag_bf16_conv_stats_rows(int rows) { return cdiv(rows, BM) * 4; }
+extern "C" int s2ag_bf16_conv_stats_rows(int rows) { return cdiv(rows, 64) * 4; }
 
 extern "C" int s2ag_bf16_conv(const s2ag_bf16_conv_args* c, const s2ag_epilogue* e, double* partials, int* stat_rows,
                               void* stream) {
@@ -861,7 +896,7 @@ extern "C" int s2ag_bf16_embedding_bwd(const long long* ids, const void* dy, int
     const float p = e ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
     const int rpb = 32;
-    hipLaunchKernelGGL(embedding_bwd_bf16_k, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(128), 0, (hipStream_t)stream, ids,
+    hipLaunchKernelGGL(embedding_bwd_bf16_k, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(320), 0, (hipStream_t)stream, ids,
                        static_cast<const bf16_t*>(dy), ld, dim, n_entries, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
                        e ? e->rng : nullptr, e ? e->site : 0u, dtable, rows, rpb);
     S2AG_LAUNCH_CHECK();
