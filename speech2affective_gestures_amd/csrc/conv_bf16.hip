@@ -27,6 +27,8 @@
 // the loader transposes through registers (two rows per thread, packed pairs, 4-byte LDS stores into [column][row] images)
 // so the fragments are again 16-byte reads; the contraction is split over blocks and merged with fp32 atomics, the bias
 // gradient rides along.
+#include <stdlib.h>
+
 #include "s2ag_common.h"
 
 namespace {
@@ -310,8 +312,12 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
     const bool do_bias = p.db != nullptr && kt == 0;
     if (tid < 64) bsum[tid] = 0.f;
 
-    // loader: every thread transposes the row pair (2*pr, 2*pr + 1) x the 8-column chunk ch of BOTH operands
-    const int pr = tid & 31, ch = tid >> 5;
+    // loader: every thread transposes the row pair (2*pr, 2*pr + 1) x the 8-column chunk ch of BOTH operands.  The chunk
+    // index runs fastest along the lanes: a wave-level load touches 8 rows x 128 contiguous bytes (with the row pair along
+    // the lanes it was 64 rows x 16 bytes: one cache line per lane, and the L1 line rate -- not LDS, MFMA or the atomics --
+    // set the kernel's time).  The [column][row] images are XOR-swizzled in units of 4 words (8 rows) by the chunk index so
+    // that the transposing 4-byte stores of a wave still spread over all 32 banks.
+    const int ch = tid & 7, pr = tid >> 3;
     const int m_beg = blockIdx.y * p.m_chunk;
     const int m_end = min(p.M, m_beg + p.m_chunk);
     const bool g_col = co0 + ch * 8 < p.ldg, x_col = c0 + ch * 8 < p.Cvalid;
@@ -324,8 +330,6 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int wr = wave >> 1, wc = wave & 1;                    // wave's 32 x 32 quadrant: channels co, columns c
-    const int f_off = (lane & 15) * WG_PITCH + (lane >> 4) * 8;
-
     // two steps in flight in registers (3 blocks per CU at best: nothing else hides the global round trip)
     u32x4 rg[2][2], rx[2][2];
     auto fetch = [&](int mb, int set) {
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
         for (int j = 0; j < 8; ++j) {
             const unsigned lo = (j & 1) ? (a[j >> 1] >> 16) : (a[j >> 1] & 0xffffu);
             const unsigned hi = (j & 1) ? (b[j >> 1] >> 16) : (b[j >> 1] & 0xffffu);
-            *reinterpret_cast<unsigned*>(&img[(ch * 8 + j) * WG_PITCH + 2 * pr]) = lo | (hi << 16);
+            *reinterpret_cast<unsigned*>(&img[(ch * 8 + j) * WG_PITCH + 2 * (pr ^ (ch << 2))]) = lo | (hi << 16);
         }
     };
     auto stash = [&](int set) {
@@ -371,10 +375,12 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
             bf16x8 a[2], b[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
+                const int ca = wr * 32 + t * 16 + (lane & 15), cb = wc * 32 + t * 16 + (lane & 15);
+                const int grp = kk * 4 + (lane >> 4);                   // 8-row group of this lane's K chunk
                 a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
-                                                      &Gt[(wr * 32 + t * 16) * WG_PITCH + kk * 32 + f_off]));
+                                                      &Gt[ca * WG_PITCH + ((grp ^ ((ca >> 3) & 7)) << 3)]));
                 b[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
-                                                      &Xt[(wc * 32 + t * 16) * WG_PITCH + kk * 32 + f_off]));
+                                                      &Xt[cb * WG_PITCH + ((grp ^ ((cb >> 3) & 7)) << 3)]));
             }
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti)
@@ -785,7 +791,10 @@ extern "C" int s2ag_bf16_conv_wgrad(const s2ag_bf16_wgrad_args* g, void* stream)
     p.d_co = g->d_co; p.d_t = g->d_t; p.d_c = g->d_c; p.flat_cin = g->flat_cin;
     p.ks_out = g->flat_cin > 0 ? g->ks_out : g->ks;
     const int tiles = cdiv(g->Cout, 64) * g->ks * (g->Cp / 64);
-    int splits = cdiv(768, tiles);
+    // every block ends with 4 096 fp32 atomics: the split count, not the loop, sets the time (768 blocks: 49 us per TCN
+    // layer, S2AG_BF16_WGRAD_BLOCKS to tune)
+    static const int target = [] { const char* e = getenv("S2AG_BF16_WGRAD_BLOCKS"); return e ? atoi(e) : 320; }();
+    int splits = cdiv(target, tiles);
     const int max_splits = cdiv(p.M, 512);                      // at least 8 steps of 64 rows per block
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
