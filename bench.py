@@ -303,10 +303,23 @@ def conv1d_roofline_run(device, B=256, iters=30, cpu=True, mode='fp32'):
     arena = ParamArena(list(wav.parameters()) + list(txt.parameters()))
     text, audio, _, _, _ = synthetic_batch(B, 5, device)
 
+    side = torch.cuda.Stream()
+    two_streams = os.environ.get('S2AG_CFG3_STREAMS', '2') != '1'
+
     def fn():
+        # the two encoders share nothing: as in the training step (where they are branches of one generator pass) they
+        # run on two streams, forward and backward each
         ops.begin_step()
         arena.zero_grad()
-        (wav(audio).sum() + txt(text)[0].sum()).backward()
+        if not two_streams:
+            (wav(audio).sum() + txt(text)[0].sum()).backward()
+            return
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            txt(text)[0].sum().backward()
+        wav(audio).sum().backward()
+        cur.wait_stream(side)
     with bf16.precision(mode):
         ms = _graph_timer(fn, iters)
     clips = B / (ms * 1e-3)

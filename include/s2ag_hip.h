@@ -424,6 +424,53 @@ int s2ag_bf16_conv_c1_fwd(const float* x, const float* w, const float* bias, voi
 int s2ag_bf16_conv_c1_wgrad(const void* gy, const float* x, float* dw, float* db, const s2ag_conv_geom* g, void* stream);
 int s2ag_bf16_conv_c1_rows(const s2ag_conv_geom* g);      /* statistics partial rows s2ag_bf16_conv_c1_fwd writes */
 
+/* ---- clip-resident TemporalConvNet in bf16 mode (csrc/tcn_fused.hip) ----------------------------------------------
+ * Replaces the whole stack of TemporalBlocks of net/tcn.py:16-64 (conv1 -> chomp -> ReLU -> dropout -> conv2 -> chomp ->
+ * ReLU -> dropout, + residual, ReLU; kernel size 2, dilations dil[b], in == out channels C <= 320) by ONE launch
+ * forward and ONE launch for the whole chain of data gradients: a workgroup owns the rows of whole clips (clips are
+ * independent along time: the dilated receptive-field window of every frame lies inside its clip), keeps the current
+ * activation of its clips in LDS (bf16, 320 padded channels) through all 2*n_blocks convs and streams the weights from
+ * L2 in MFMA-fragment order (s2ag_bf16_tcn_pack, once per optimizer step).  Every intermediate that the backward pass
+ * needs is written to HBM once (h1 = dropout(relu(conv1)) and y = relu(h2 + x) as (clips*T, 320) bf16 rows with zero
+ * pad channels, rounded exactly where the layer-by-layer bf16 kernels round; of h2 = dropout(relu(conv2)) only the sign
+ * bits); the backward launch reads the sign bits, carries the gradient through LDS and leaves, per conv, the gradient w.r.t.
+ * its pre-activation (gp1 / gp2, the `gy` operand of s2ag_bf16_conv_wgrad_multi) in HBM.  Dropout masks are the
+ * counter-based ones of s2ag_conv1d_nlc_fwd (index row*C + channel, site[2*b + j]).
+ * s2ag_bf16_tcn_clips_per_block: clips one workgroup holds (0: shape unsupported -- use the layer-by-layer kernels). */
+#define S2AG_TCN_MAX_BLOCKS 4
+typedef struct {
+    const void* x;                              /* bf16 (clips*T, 320): input of the first block */
+    void* h1[S2AG_TCN_MAX_BLOCKS];              /* bf16 (clips*T, 320) each: written forward; the weight gradients' operands */
+    void* sign[S2AG_TCN_MAX_BLOCKS];            /* s2ag_bf16_tcn_sign_bytes each: "h1 > 0", "h2 > 0", "y > 0" bits, written
+                                                   forward, read backward */
+    void* y[S2AG_TCN_MAX_BLOCKS];
+    const void* wfrag;                          /* s2ag_bf16_tcn_pack output */
+    const float* bias[2 * S2AG_TCN_MAX_BLOCKS]; /* conv1, conv2 of block 0, 1, ... (nullable entries) */
+    int dil[S2AG_TCN_MAX_BLOCKS];
+    int n_blocks, n_clips, T, C;
+    float drop_p;
+    const void* rng;                            /* noise snapshot (drop_p > 0) */
+    unsigned site[2 * S2AG_TCN_MAX_BLOCKS];
+    /* backward only */
+    const void* gy;                             /* bf16 (clips*T, 320): gradient w.r.t. the last block's output */
+    void* gx;                                   /* bf16 (clips*T, 320): gradient w.r.t. x */
+    void* gp1[S2AG_TCN_MAX_BLOCKS];             /* bf16 (clips*T, 320): gradient w.r.t. conv1's / conv2's pre-activation */
+    void* gp2[S2AG_TCN_MAX_BLOCKS];
+} s2ag_bf16_tcn_args;
+int s2ag_bf16_tcn_clips_per_block(int T, int C, int ksize);
+long long s2ag_bf16_tcn_sign_bytes(int n_clips, int T);  /* bytes of one block's sign buffer */
+long long s2ag_bf16_tcn_pack_elems(int n_convs);          /* bf16 elements of the fragment-ordered weight set */
+/* w[k]: fp32 (C, 2, C) tap-major normalised weights of conv k (k = 2*block + {0, 1}); host array of device pointers */
+int s2ag_bf16_tcn_pack(const float* const* w, int n_convs, int C, void* wfrag, void* stream);
+int s2ag_bf16_tcn_fwd(const s2ag_bf16_tcn_args* a, void* stream);
+/* diagnostics (tools/diag_tcn_trace.py): 256 x u64 device buffer that workgroup 0 fills with s_memtime stamps at its phase
+ * boundaries (forward from word 0, backward from word 128); NULL switches it off.  Not on the training path. */
+int s2ag_bf16_tcn_set_trace(void* buf);
+int s2ag_bf16_tcn_bwd(const s2ag_bf16_tcn_args* a, void* stream);
+/* up to 8 s2ag_bf16_conv_wgrad jobs in one launch (the TCN's eight weight gradients fill the chip together) */
+#define S2AG_BF16_MAX_WGRAD_JOBS 8
+int s2ag_bf16_conv_wgrad_multi(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs, void* stream);
+
 /* Measurement aid (tools/pmc_traffic.py): touches `bytes` of `buf` with a known access pattern so the rocprofv3 counters
  * FETCH_SIZE / WRITE_SIZE can be calibrated against a known byte count in OUR access shapes: 0 = 16 B/lane coalesced
  * reads, 1 = 8 B/lane agent-scope reads (the cooperative GRU's exchange polling), 2 = 16 B/lane writes, 3 = 8 B/lane

@@ -57,9 +57,17 @@ class BF16PackJob(C.Structure):   # s2ag_bf16_pack_job
                 ('tap_step', ci), ('src_taps', ci), ('s_o', cll), ('s_t', ci), ('s_c', ci), ('flat_cin', ci)]
 
 
+class BF16Tcn(C.Structure):       # s2ag_bf16_tcn_args
+    _fields_ = [('x', vp), ('h1', vp * 4), ('sign', vp * 4), ('y', vp * 4), ('wfrag', vp), ('bias', vp * 8), ('dil', ci * 4),
+                ('n_blocks', ci), ('n_clips', ci), ('T', ci), ('C', ci), ('drop_p', cf), ('rng', vp), ('site', cu * 8),
+                ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4)]
+
+
 MAX_JOBS = 8
 MAX_WGRAD_JOBS = 4
 BF16_MAX_PACK = 32
+BF16_MAX_WGRAD_JOBS = 8
+TCN_MAX_BLOCKS = 4
 
 SIGNATURES = {
     's2ag_abi_version': [],
@@ -127,6 +135,14 @@ SIGNATURES = {
     's2ag_bf16_conv_c1_fwd': [vp, vp, vp, vp, PG, vp, vp, vp],
     's2ag_bf16_conv_c1_wgrad': [vp, vp, vp, vp, PG, vp],
     's2ag_bf16_conv_c1_rows': [PG],
+    's2ag_bf16_tcn_clips_per_block': [ci, ci, ci],
+    's2ag_bf16_tcn_pack_elems': [ci],
+    's2ag_bf16_tcn_sign_bytes': [ci, ci],
+    's2ag_bf16_tcn_pack': [vp, ci, ci, vp, vp],
+    's2ag_bf16_tcn_fwd': [vp, vp],
+    's2ag_bf16_tcn_set_trace': [vp],
+    's2ag_bf16_tcn_bwd': [vp, vp],
+    's2ag_bf16_conv_wgrad_multi': [vp, ci, vp],
     's2ag_rows_unique': [vp, ci, ci, ci, vp, vp, vp, vp, vp],
     's2ag_rows_pack': [vp, vp, ci, ci, ci, vp, vp],
     's2ag_rows_merge': [vp, ci, ci, ci, ci, vp, vp],
@@ -164,7 +180,7 @@ def load():
         except AttributeError as e:
             raise S2AGLibraryError(f'{path} lacks symbol {name}; rebuild it') from e
         fn.argtypes = args
-        fn.restype = cll if name == 's2ag_gru_coop_workspace_bytes' else ci
+        fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes') else ci
     if lib.s2ag_abi_version() != 1:
         raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
     _lib = lib

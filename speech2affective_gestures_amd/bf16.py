@@ -364,6 +364,132 @@ _FUSED = {}         # token -> data_ptr of the gradient tensor that already carr
 
 
 # ----------------------------------------------------------------------------------------------------
+# clip-resident TemporalConvNet (csrc/tcn_fused.hip): all blocks in one launch forward, one for the data gradients
+# ----------------------------------------------------------------------------------------------------
+FUSE_TCN = os.environ.get('S2AG_BF16_FUSE_TCN', '1') != '0'
+
+
+def tcn_fused_supported(T: int, C: int, ks: int, n_blocks: int) -> bool:
+    return (FUSE_TCN and 256 < C <= 320 and 1 <= n_blocks <= L.TCN_MAX_BLOCKS
+            and _lib().s2ag_bf16_tcn_clips_per_block(int(T), int(C), int(ks)) > 0)
+
+
+class TcnFragments:
+    """The 2 * n_blocks normalised conv weights in MFMA-fragment order (forward and data-gradient operand of every conv),
+    refreshed with one launch when a weight changed or a new step began (like WeightPack)."""
+
+    def __init__(self):
+        self._key, self._frag = None, None
+
+    def get(self, ws):
+        key = (ops.generation(),) + tuple((id(w), w._version, w.data_ptr()) for w in ws)
+        if key != self._key:
+            lib = _lib()
+            C_ = ws[0].shape[0]
+            assert all(tuple(w.shape) == (C_, 2, C_) and w.is_contiguous() for w in ws), 'tap-major (C, 2, C) weights'
+            frag = torch.empty(int(lib.s2ag_bf16_tcn_pack_elems(len(ws))), dtype=torch.bfloat16, device=ws[0].device)
+            ptrs = (C.c_void_p * len(ws))(*[w.detach().data_ptr() for w in ws])
+            L.check(lib.s2ag_bf16_tcn_pack(ptrs, len(ws), C_, _p(frag), _s()), 'bf16_tcn_pack')
+            self._key, self._frag = key, frag
+        return self._frag
+
+
+class _TcnFused16(torch.autograd.Function):
+    """x (N, T, 320) bf16 -> y (N, T, 320) bf16 through all TemporalBlocks.  ``params`` = the 2*nb normalised weights
+    (fp32 (C, 2, C) gradient stages) followed by the 2*nb biases."""
+
+    @staticmethod
+    def forward(ctx, x, frags, meta, noise, *params):
+        dils, sites, drop_p = meta
+        nb = len(dils)
+        ws, bs = params[:2 * nb], params[2 * nb:]
+        x, rows, ld = _rows16(x)
+        N, T = ctx_shape = x.shape[0], x.shape[1]
+        assert ld == 320 and x.dim() == 3
+        C_ = ws[0].shape[0]
+        frag = frags.get(ws)
+        saved = torch.empty(2 * nb, rows, 320, dtype=torch.bfloat16, device=x.device)      # h1[b], y[b]
+        sb = int(_lib().s2ag_bf16_tcn_sign_bytes(N, T))
+        signs = torch.empty(nb, sb, dtype=torch.uint8, device=x.device)
+        a = L.BF16Tcn()
+        a.x, a.wfrag = x.data_ptr(), frag.data_ptr()
+        for b in range(nb):
+            a.h1[b], a.sign[b], a.y[b] = saved[2 * b].data_ptr(), signs[b].data_ptr(), saved[2 * b + 1].data_ptr()
+            a.dil[b] = int(dils[b])
+            for j in range(2):
+                a.bias[2 * b + j] = bs[2 * b + j].data_ptr() if bs[2 * b + j] is not None else None
+                a.site[2 * b + j] = int(sites[2 * b + j])
+        a.n_blocks, a.n_clips, a.T, a.C = nb, N, T, C_
+        a.drop_p = float(drop_p)
+        a.rng = noise.data_ptr() if drop_p > 0 else None
+        L.check(_lib().s2ag_bf16_tcn_fwd(C.byref(a), _s()), 'bf16_tcn_fwd')
+        ctx.meta, ctx.frags, ctx.noise, ctx.params, ctx.shape = meta, frags, noise, params, ctx_shape
+        ctx.save_for_backward(x, saved, signs)
+        return saved[2 * nb - 1].view(N, T, 320)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, saved, signs = ctx.saved_tensors
+        dils, sites, drop_p = ctx.meta
+        nb = len(dils)
+        params = ctx.params
+        ws, bs = params[:2 * nb], params[2 * nb:]
+        N, T = ctx.shape
+        rows = N * T
+        C_ = ws[0].shape[0]
+        lib = _lib()
+        gy, _, ldg = _rows16(gy)
+        assert ldg == 320
+        gx = torch.empty(rows, 320, dtype=torch.bfloat16, device=gy.device)
+        gp = torch.empty(2 * nb, rows, 320, dtype=torch.bfloat16, device=gy.device)
+        a = L.BF16Tcn()
+        a.x, a.wfrag = x.data_ptr(), ctx.frags.get(ws).data_ptr()
+        for b in range(nb):
+            a.h1[b], a.sign[b], a.y[b] = saved[2 * b].data_ptr(), signs[b].data_ptr(), saved[2 * b + 1].data_ptr()
+            a.gp1[b], a.gp2[b] = gp[2 * b].data_ptr(), gp[2 * b + 1].data_ptr()
+            a.dil[b] = int(dils[b])
+        a.n_blocks, a.n_clips, a.T, a.C = nb, N, T, C_
+        a.drop_p = float(drop_p)
+        a.rng = ctx.noise.data_ptr() if drop_p > 0 else None
+        a.gy, a.gx = gy.data_ptr(), gx.data_ptr()
+        L.check(lib.s2ag_bf16_tcn_bwd(C.byref(a), _s()), 'bf16_tcn_bwd')
+        # the 2*nb weight (+ bias) gradients: one launch, accumulated into the leaves' gradient slots
+        grads = [None] * (4 * nb)
+        jobs = (L.BF16Wgrad * (2 * nb))()
+        nj = 0
+        for b in range(nb):
+            for j in range(2):
+                k = 2 * b + j
+                need_w = ctx.needs_input_grad[4 + k]
+                need_b = bs[k] is not None and ctx.needs_input_grad[4 + 2 * nb + k]
+                if not (need_w or need_b):
+                    continue
+                wslot = ops._grad_slot(ws[k]) if need_w else None
+                bslot = ops._grad_slot(bs[k]) if need_b else None
+                if need_w and wslot is None:
+                    grads[k] = wslot = torch.zeros_like(ws[k])
+                if need_b and bslot is None:
+                    grads[2 * nb + k] = bslot = torch.zeros_like(bs[k])
+                if wslot is None:                                   # bias only: rare (frozen weights), plain column sum
+                    ops.colsum_raw(to_f32_raw(gp[k], C_), bslot, accumulate=True)
+                    continue
+                xin = (x.view(rows, 320) if b == 0 else saved[2 * b - 1]) if j == 0 else saved[2 * b]
+                d = int(dils[b])
+                jobs[nj] = L.BF16Wgrad(_p(gp[k]), _p(xin), _p(wslot), _p(bslot), N, T, T, T * 320, 320, 320, 1, -d, d, 2, 320,
+                                       320, C_, C_, 2 * C_, C_, 1, 0, 2)
+                nj += 1
+                if grads[k] is None:
+                    ops._note_staged(ws[k])
+        if nj:
+            L.check(lib.s2ag_bf16_conv_wgrad_multi(jobs, nj, _s()), 'bf16_conv_wgrad_multi')
+        return (gx.view(N, T, 320), None, None, None) + tuple(grads)
+
+
+def tcn_fused(x: Tensor, frags: TcnFragments, ws, biases, dils, sites, drop_p: float, noise) -> Tensor:
+    return _TcnFused16.apply(x, frags, (tuple(dils), tuple(sites), float(drop_p)), noise, *ws, *biases)
+
+
+# ----------------------------------------------------------------------------------------------------
 # the one-channel wave conv (conv1 of the wave encoder): fp32 waveform in, bf16 out
 # ----------------------------------------------------------------------------------------------------
 class _ConvC1(torch.autograd.Function):

@@ -297,7 +297,7 @@ struct WgP {
 constexpr int WG_ROWS = 64;     // rows of the contraction per step (two MFMA K steps)
 constexpr int WG_PITCH = 72;    // [column][row] image pitch in bf16 (144 B: 16 consecutive columns tile the 64 banks)
 
-__global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
+__device__ __forceinline__ void wgrad_body(const WgP& p, const int tile, const int split) {
     // [column][row] images of a 64-row step: 64 gy columns (channels co) and 64 x columns (channels c of tap t)
     __shared__ __attribute__((aligned(16))) bf16_t Gt[64 * WG_PITCH];
     __shared__ __attribute__((aligned(16))) bf16_t Xt[64 * WG_PITCH];
@@ -306,7 +306,6 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kct = p.Cp / 64;                                  // 64-channel tiles per tap
     const int nco = (p.Cout + 63) / 64;
-    const int tile = blockIdx.x;
     const int cot = tile % nco, kt = tile / nco;
     const int tap = kt / kct, c0 = (kt - tap * kct) * 64, co0 = cot * 64;
     const bool do_bias = p.db != nullptr && kt == 0;
@@ -318,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
     // set the kernel's time).  The [column][row] images are XOR-swizzled in units of 4 words (8 rows) by the chunk index so
     // that the transposing 4-byte stores of a wave still spread over all 32 banks.
     const int ch = tid & 7, pr = tid >> 3;
-    const int m_beg = blockIdx.y * p.m_chunk;
+    const int m_beg = split * p.m_chunk;
     const int m_end = min(p.M, m_beg + p.m_chunk);
     const bool g_col = co0 + ch * 8 < p.ldg, x_col = c0 + ch * 8 < p.Cvalid;
     float bacc[8];
@@ -431,6 +430,19 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) {
         __syncthreads();
         if (tid < 64 && co0 + tid < p.Cout) atomicAdd(p.db + co0 + tid, bsum[tid]);
     }
+}
+
+__global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) { wgrad_body(p, blockIdx.x, blockIdx.y); }
+
+// several layers' weight gradients in one launch: blockIdx.z = job; every job brings its own tile and split counts
+struct WgJobs {
+    WgP j[S2AG_BF16_MAX_WGRAD_JOBS];
+    int tiles[S2AG_BF16_MAX_WGRAD_JOBS], splits[S2AG_BF16_MAX_WGRAD_JOBS];
+};
+__global__ __launch_bounds__(256) void conv_bf16_wgrad_multi_k(const WgJobs js) {
+    const int job = blockIdx.z;
+    if ((int)blockIdx.x >= js.tiles[job] || (int)blockIdx.y >= js.splits[job]) return;
+    wgrad_body(js.j[job], blockIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -777,6 +789,44 @@ extern "C" int s2ag_bf16_conv_stats_rows(int rows) { return cdiv(rows, 64) * 4; 
 extern "C" int s2ag_bf16_conv(const s2ag_bf16_conv_args* c, const s2ag_epilogue* e, double* partials, int* stat_rows,
                               void* stream) {
     return launch_conv(c, e, partials, stat_rows, (hipStream_t)stream);
+}
+
+// fills p and returns the tile count; *splits_out = blocks along the contraction for a launch aiming at `target` blocks
+static int wgrad_plan(const s2ag_bf16_wgrad_args* g, WgP& p, int target, int* splits_out) {
+    if (!g || !g->gy || !g->x || !g->dw || g->N <= 0 || g->Lq <= 0 || g->ks <= 0) return S2AG_E_BADARG;
+    if ((g->Cp % 64) || (g->Cvalid & 7) || (g->ldx & 7) || (g->ldg & 7)) return S2AG_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(g->x) | reinterpret_cast<uintptr_t>(g->gy)) & 15) return S2AG_E_BADARG;
+    p.gy = static_cast<const bf16_t*>(g->gy); p.x = static_cast<const bf16_t*>(g->x); p.dw = g->dw; p.db = g->db;
+    p.M = g->N * g->Lq; p.Lq = g->Lq; p.Lin = g->Lin; p.x_clip = g->x_clip; p.ldx = g->ldx; p.ldg = g->ldg;
+    p.pos_mul = g->pos_mul; p.pos_off = g->pos_off; p.pos_tap = g->pos_tap;
+    p.ks = g->ks; p.Cp = g->Cp; p.Cvalid = g->Cvalid; p.Cout = g->Cout; p.Cin = g->Cin;
+    p.d_co = g->d_co; p.d_t = g->d_t; p.d_c = g->d_c; p.flat_cin = g->flat_cin;
+    p.ks_out = g->flat_cin > 0 ? g->ks_out : g->ks;
+    const int tiles = cdiv(g->Cout, 64) * g->ks * (g->Cp / 64);
+    int splits = cdiv(target, tiles);
+    const int max_splits = cdiv(p.M, 512);                      // at least 8 steps of 64 rows per block
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.m_chunk = cdiv(cdiv(p.M, splits), WG_ROWS) * WG_ROWS;
+    *splits_out = cdiv(p.M, p.m_chunk);
+    return tiles;
+}
+
+extern "C" int s2ag_bf16_conv_wgrad_multi(const s2ag_bf16_wgrad_args* jobs, int njobs, void* stream) {
+    if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS) return S2AG_E_BADARG;
+    static const int target = [] { const char* e = getenv("S2AG_BF16_WGRAD_MULTI_BLOCKS"); return e ? atoi(e) : 768; }();
+    WgJobs js{};
+    int mt = 0, ms = 0;
+    for (int k = 0; k < njobs; ++k) {
+        const int t = wgrad_plan(jobs + k, js.j[k], cdiv(target, njobs), &js.splits[k]);
+        if (t < 0) return t;
+        js.tiles[k] = t;
+        mt = t > mt ? t : mt;
+        ms = js.splits[k] > ms ? js.splits[k] : ms;
+    }
+    hipLaunchKernelGGL(conv_bf16_wgrad_multi_k, dim3(mt, ms, njobs), dim3(256), 0, (hipStream_t)stream, js);
+    S2AG_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int s2ag_bf16_conv_wgrad(const s2ag_bf16_wgrad_args* g, void* stream) {

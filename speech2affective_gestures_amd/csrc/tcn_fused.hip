@@ -1,0 +1,521 @@
+// Clip-resident TemporalConvNet for the bf16 mode (include/s2ag_hip.h, "clip-resident TemporalConvNet"): the text
+// encoder's stack of TemporalBlocks (net/tcn.py:16-64; kernel size 2, dilations 1, 2, 4, 8, 300 -> 300 channels) as ONE
+// launch forward and ONE launch for the chain of data gradients.
+//
+// Why: layer by layer the TCN is 16 implicit GEMMs of 3.1 GFLOP over 8 704 rows (B = 256) plus 20 element-wise passes --
+// ~45 dependent launches of 5-20 us, each a round trip of the 5.5 MB activation through HBM and each too small to fill the
+// chip.  But clips never mix along time: the receptive-field window of a frame (t, t - d) lies inside its own clip.  So a
+// workgroup takes the rows of whole clips (2 clips x 34 frames = 68 rows), keeps them in LDS as bf16 [row][320 channels]
+// through all eight convs, and only the weights move: they are streamed from L2 straight into MFMA A-operand registers,
+// pre-arranged in fragment order so that every wave-level load is 1 KB contiguous (no LDS staging: the four waves split
+// the output channels, so no two waves of a workgroup want the same weight fragment).
+//
+//   D[co][m] += sum_k W[co][k] * X[m + off(tap)][c]      v_mfma_f32_16x16x32_bf16, A = weights, B = activations:
+//   an accumulator register holds 4 consecutive output channels of one row, i.e. 8 contiguous bytes of the bf16 row.
+//
+// LDS: row buffers of R = clips_per_block * T rows with a 656-byte pitch + one zero row that stands in for every source
+// row outside the clip (causal left padding forward, the mirrored right padding backward) and for the tile rows >= R;
+// forward {X, H1}: conv1 X -> H1, conv2 H1 -> registers and, in the same epilogue and in place, X <- relu(h2 + X);
+// backward {G, P2, P1}: G <- G * [y > 0]; P2 <- G * drop'relu'(h2); P1 <- dgrad2(P2) * drop'relu'(h1); G <- dgrad1(P1) + G.
+// relu' * dropout mask needs no random numbers backward: h = mask * relu(pre) is positive exactly where the element was
+// kept and pre > 0 -- and of h2 and of y's sign that ONE BIT per element is all the backward pass needs, so the forward
+// pass leaves sign bytes (3 bits per element) instead of a third activation tensor, and the backward launch reads 8 KB of
+// them per workgroup and block (prefetched a block ahead) instead of 130 KB of activations it would wait for.
+#include "s2ag_common.h"
+
+namespace {
+using namespace s2ag;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+typedef unsigned short bf16_t;
+
+constexpr int CP = 320;                 // padded channels (LDS / HBM row of an activation)
+constexpr int NCT = CP / 16;            // 16-channel tiles of the output
+constexpr int KT_TAP = CP / 32;         // K tiles per tap
+constexpr int NKT = 2 * KT_TAP;         // K tiles per conv (2 taps)
+constexpr int PITCH = 328;              // LDS row pitch in bf16 (656 B)
+constexpr int MT = 5;                   // 16-row tiles per workgroup: up to 80 rows
+constexpr int CT_W = NCT / 4;           // channel tiles per wave (4 waves)
+constexpr long long FRAG = (long long)NCT * NKT * 64 * 8;      // bf16 elements of one conv's fragment-ordered weights
+
+__device__ __forceinline__ unsigned bf16_rn(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float lo_f(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_f(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+struct TcnP {
+    const bf16_t* x;
+    bf16_t* h1[S2AG_TCN_MAX_BLOCKS];
+    unsigned char* sign[S2AG_TCN_MAX_BLOCKS];
+    bf16_t* y[S2AG_TCN_MAX_BLOCKS];
+    const bf16_t* wfrag;
+    const float* bias[2 * S2AG_TCN_MAX_BLOCKS];
+    int dil[S2AG_TCN_MAX_BLOCKS];
+    int n_blocks, n_clips, T, C, cpb;
+    float drop_p, inv_keep;
+    const unsigned long long* rng;
+    unsigned site[2 * S2AG_TCN_MAX_BLOCKS];
+    const bf16_t* gy;
+    bf16_t* gx;
+    bf16_t* gp1[S2AG_TCN_MAX_BLOCKS];
+    bf16_t* gp2[S2AG_TCN_MAX_BLOCKS];
+    unsigned long long* trace;          // diagnostics (s2ag_bf16_tcn_set_trace): s_memtime stamps of workgroup 0, wave 0
+};
+
+#define TCN_STAMP()                                                                  \
+    do {                                                                             \
+        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[nst++] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+// acc[i][mt] (+)= conv over the LDS rows at src_off: K tile kt covers tap kt / KT_TAP (row offset -d forward / +d
+// backward for tap 0, 0 for tap 1) and channels (kt % KT_TAP)*32 .. +32.  wa points at this wave's first fragment of the
+// conv (+ lane).  One wave per SIMD, so nothing but the wave's own instruction order hides latency: the weight fragments
+// of K tile kt + 4 are requested right after the MFMAs of tile kt (a ring of four register sets: three tiles = ~1 200
+// matrix-pipe cycles for the L2 round trip), the activation fragments of tile kt + 1 are read from LDS before the MFMAs
+// of tile kt.  sched_barrier pins that order -- left alone the compiler sinks every load next to its first use
+// (s_waitcnt vmcnt(1) in front of each group of 5 MFMAs: 21 us per conv instead of 4).
+template <bool BWD>
+__device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_off, const u32x4* __restrict__ wa, int d, int T,
+                                          int R, int lane, f32x4 (&acc)[CT_W][MT]) {
+    int off0[MT], off1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + (lane & 15);
+        const bool ok = m < R;
+        const int n = m / T, q = m - n * T;
+        const bool ok0 = ok && (BWD ? (q + d < T) : (q >= d));
+        off1[mt] = (ok ? src_off + m * PITCH : z_off) + (lane >> 4) * 8;
+        off0[mt] = (ok0 ? src_off + (BWD ? m + d : m - d) * PITCH : z_off) + (lane >> 4) * 8;
+    }
+    static_assert(NKT % 4 == 0, "ring of four");
+    u32x4 a[4][CT_W];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < CT_W; ++i) a[s][i] = wa[(i * NKT + s) * 64];
+    bf16x8 b[2][MT];
+    auto load_b = [&](int kt, bf16x8 (&dst)[MT]) {
+        const bool t0 = kt < KT_TAP;
+        const int c0 = (t0 ? kt : kt - KT_TAP) * 32;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            dst[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sm + (t0 ? off0[mt] : off1[mt]) + c0));
+    };
+    load_b(0, b[0]);
+#pragma unroll
+    for (int kp = 0; kp < NKT / 4; ++kp) {       // fully unrolled: a rolled loop made the allocator rotate the accumulators
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kt = kp * 4 + s;
+            if (kt + 1 < NKT) load_b(kt + 1, b[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CT_W; ++i) {
+                const bf16x8 av = __builtin_bit_cast(bf16x8, a[s][i]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[s & 1][mt], acc[i][mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 4 < NKT) {
+#pragma unroll
+                for (int i = 0; i < CT_W; ++i) a[s][i] = wa[(i * NKT + kt + 4) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[CT_W][MT]) {
+#pragma unroll
+    for (int i = 0; i < CT_W; ++i)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// rows of an LDS buffer <-> the workgroup's contiguous rows in HBM, 16 bytes per thread and access
+__device__ __forceinline__ void rows_out(const bf16_t* lds, bf16_t* __restrict__ dst, int R, int tid) {
+    for (int idx = tid; idx < R * (CP / 8); idx += 256) {
+        const int m = idx / (CP / 8), kc = idx - m * (CP / 8);
+        *reinterpret_cast<u32x4*>(dst + (long long)m * CP + kc * 8) = *reinterpret_cast<const u32x4*>(lds + m * PITCH + kc * 8);
+    }
+}
+__device__ __forceinline__ void rows_in(bf16_t* lds, const bf16_t* __restrict__ src, int R, int tid) {
+    for (int idx = tid; idx < R * (CP / 8); idx += 256) {
+        const int m = idx / (CP / 8), kc = idx - m * (CP / 8);
+        *reinterpret_cast<u32x4*>(lds + m * PITCH + kc * 8) = *reinterpret_cast<const u32x4*>(src + (long long)m * CP + kc * 8);
+    }
+}
+
+// sign bytes: what the backward pass needs of h1, h2 and y besides their use as GEMM operands is one bit per element.
+// Per workgroup and TemporalBlock: [m][40] bytes "h1 > 0" (S1 = that rounded up to 16) followed by [m][80] bytes
+// "h2 > 0" (0..39) and "y > 0" (40..79); byte kc of a row covers channels 8*kc .. 8*kc + 7.
+__host__ __device__ inline int sign_s1(int rows) { return (rows * 40 + 15) / 16 * 16; }
+__host__ __device__ inline int sign_s2(int rows) { return (rows * 80 + 15) / 16 * 16; }
+
+// the 4 bits of a lane (channels co .. co + 3 of row m) -> one byte per 8-channel chunk: lanes l and l ^ 16 hold the two
+// halves of a chunk; the lane with the even (lane >> 4) stores it
+__device__ __forceinline__ void put_bits(unsigned char* dst, unsigned nib, int lane, bool ok) {
+    const unsigned other = __shfl_xor(nib, 16, 64);
+    if (ok && !((lane >> 4) & 1)) *dst = (unsigned char)(nib | (other << 4));
+}
+
+__global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sm = reinterpret_cast<bf16_t*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ra = p.cpb * p.T;                                  // rows per buffer
+    const int X = 0, H1 = Ra * PITCH, Z = 2 * Ra * PITCH;
+    unsigned char* M1 = smem_raw + (size_t)(2 * Ra + 1) * PITCH * sizeof(bf16_t);
+    const int S1 = sign_s1(Ra), S2 = sign_s2(Ra);
+    unsigned char* M2 = M1 + S1;
+    const int clip0 = blockIdx.x * p.cpb;
+    const int R = min(p.cpb, p.n_clips - clip0) * p.T;
+    const long long row0 = (long long)clip0 * p.T;
+
+    rows_in(sm + X, p.x + row0 * CP, R, tid);
+    for (int i = tid; i < PITCH / 2; i += 256) reinterpret_cast<unsigned*>(sm + Z)[i] = 0u;
+    const bool drop = p.drop_p > 0.f;
+    unsigned long long rng0 = 0, rng1 = 0;
+    if (drop) { rng0 = p.rng[0]; rng1 = p.rng[1]; }
+    const unsigned long long rngv[2] = {rng0, rng1};
+    __syncthreads();
+
+    f32x4 acc[CT_W][MT];
+    int nst = 0;
+    TCN_STAMP();
+    for (int blk = 0; blk < p.n_blocks; ++blk) {
+        const int d = p.dil[blk];
+        unsigned char* sg = p.sign[blk] + (size_t)blockIdx.x * (S1 + S2);
+#pragma unroll 1
+        for (int j = 0; j < 2; ++j) {
+            const int cv = 2 * blk + j;
+            const u32x4* wa = reinterpret_cast<const u32x4*>(p.wfrag + (long long)(2 * cv) * FRAG) + (wave * CT_W * NKT) * 64 + lane;
+            // bias values of this lane's channels: requested before the MFMA loop, consumed after it
+            const float* bias = p.bias[cv];
+            float bv[CT_W][4];
+#pragma unroll
+            for (int i = 0; i < CT_W; ++i) {
+                const int co = (wave * CT_W + i) * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bv[i][c] = (bias && co + c < p.C) ? bias[co + c] : 0.f;
+            }
+            zero_acc(acc);
+            conv_tile<false>(sm, j == 0 ? X : H1, Z, wa, d, p.T, R, lane, acc);
+            TCN_STAMP();
+            SiteKey key{0, 0};
+            if (drop) key = site_key(rngv, p.site[cv]);
+            // the mask index of an element does not depend on the conv: left visible, the compiler computes the first
+            // hash stage of all 100 elements ONCE, before the block loop, and keeps 200 registers alive across the kernel
+            // (512 VGPRs + 85 spilled).  An opaque copy of the row base per conv keeps the hashes inside the epilogue.
+            unsigned row0_lo = (unsigned)row0, row0_hi = (unsigned)(row0 >> 32);
+            asm volatile("" : "+s"(row0_lo), "+s"(row0_hi));
+            const long long row0v = (long long)(((unsigned long long)row0_hi << 32) | row0_lo);
+#pragma unroll
+            for (int i = 0; i < CT_W; ++i) {
+                const int co = (wave * CT_W + i) * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = mt * 16 + (lane & 15);
+                    const bool ok = m < R;
+                    const int mm = ok ? m : 0;
+                    unsigned h[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v = fmaxf(acc[i][mt][c] + bv[i][c], 0.f);
+                        if (drop && co + c < p.C)
+                            v *= keep_scale(key, (unsigned long long)(row0v + mm) * p.C + co + c, p.drop_p, p.inv_keep);
+                        h[c] = bf16_rn(v);
+                    }
+                    const unsigned hb = (h[0] ? 1u : 0u) | (h[1] ? 2u : 0u) | (h[2] ? 4u : 0u) | (h[3] ? 8u : 0u);   // h >= 0
+                    if (j == 0) {
+                        if (ok) *reinterpret_cast<uint2*>(sm + H1 + m * PITCH + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                        put_bits(M1 + mm * 40 + (co >> 3), hb, lane, ok);
+                    } else {                                     // residual + ReLU, in place over the block input
+                        uint2* xp = reinterpret_cast<uint2*>(sm + X + mm * PITCH + co);
+                        const uint2 xv = *xp;
+                        const unsigned y0 = bf16_rn(fmaxf(__uint_as_float(h[0] << 16) + lo_f(xv.x), 0.f));
+                        const unsigned y1 = bf16_rn(fmaxf(__uint_as_float(h[1] << 16) + hi_f(xv.x), 0.f));
+                        const unsigned y2 = bf16_rn(fmaxf(__uint_as_float(h[2] << 16) + lo_f(xv.y), 0.f));
+                        const unsigned y3 = bf16_rn(fmaxf(__uint_as_float(h[3] << 16) + hi_f(xv.y), 0.f));
+                        if (ok) *xp = make_uint2(y0 | (y1 << 16), y2 | (y3 << 16));
+                        const unsigned yb = (y0 ? 1u : 0u) | (y1 ? 2u : 0u) | (y2 ? 4u : 0u) | (y3 ? 8u : 0u);
+                        put_bits(M2 + mm * 80 + (co >> 3), hb, lane, ok);
+                        put_bits(M2 + mm * 80 + 40 + (co >> 3), yb, lane, ok);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // one (tile, row tile) at a time: interleaving all 25 spills
+                }
+            }
+            TCN_STAMP();
+            __syncthreads();
+            TCN_STAMP();
+            if (j == 0) {
+                rows_out(sm + H1, p.h1[blk] + row0 * CP, R, tid);
+                for (int i = tid; i < S1 / 16; i += 256) reinterpret_cast<u32x4*>(sg)[i] = reinterpret_cast<const u32x4*>(M1)[i];
+            } else {
+                rows_out(sm + X, p.y[blk] + row0 * CP, R, tid);
+                for (int i = tid; i < S2 / 16; i += 256)
+                    reinterpret_cast<u32x4*>(sg + S1)[i] = reinterpret_cast<const u32x4*>(M2)[i];
+            }
+            TCN_STAMP();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sm = reinterpret_cast<bf16_t*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ra = p.cpb * p.T;
+    const int G = 0, P2 = Ra * PITCH, P1 = 2 * Ra * PITCH, Z = 3 * Ra * PITCH;
+    unsigned char* M1 = smem_raw + (size_t)(3 * Ra + 1) * PITCH * sizeof(bf16_t);
+    const int S1 = sign_s1(Ra), S2 = sign_s2(Ra);
+    const unsigned char* M2 = M1 + S1;
+    const int clip0 = blockIdx.x * p.cpb;
+    const int R = min(p.cpb, p.n_clips - clip0) * p.T;
+    const long long row0 = (long long)clip0 * p.T;
+    const float ik = p.inv_keep;
+    const int nsg = (S1 + S2) / 16;                              // 16-byte words of a block's sign bytes (<= 2 per thread)
+
+    rows_in(sm + G, p.gy + row0 * CP, R, tid);
+    for (int i = tid; i < PITCH / 2; i += 256) reinterpret_cast<unsigned*>(sm + Z)[i] = 0u;
+    u32x4 sreg[3];
+    auto fetch_signs = [&](int blk) {
+        const u32x4* sg = reinterpret_cast<const u32x4*>(p.sign[blk] + (size_t)blockIdx.x * (S1 + S2));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sreg[k] = tid + 256 * k < nsg ? sg[tid + 256 * k] : u32x4{0u, 0u, 0u, 0u};
+    };
+    fetch_signs(p.n_blocks - 1);
+
+    f32x4 acc[CT_W][MT];
+    int nst = 128;
+    TCN_STAMP();
+    for (int blk = p.n_blocks - 1; blk >= 0; --blk) {
+        const int d = p.dil[blk];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (tid + 256 * k < nsg) reinterpret_cast<u32x4*>(M1)[tid + 256 * k] = sreg[k];
+        if (blk > 0) fetch_signs(blk - 1);                       // in flight during this block's two convs
+        __syncthreads();
+        TCN_STAMP();
+        // (a) G <- G * [y > 0];  P2 <- G * [h2 > 0] / keep (-> HBM too)
+        {
+            bf16_t* gp2 = p.gp2[blk] + row0 * CP;
+            for (int idx = tid; idx < R * (CP / 8); idx += 256) {
+                const int m = idx / (CP / 8), kc = idx - m * (CP / 8);
+                const int lo = m * PITCH + kc * 8;
+                const unsigned by = M2[m * 80 + 40 + kc], bh = M2[m * 80 + kc];
+                const u32x4 gv = *reinterpret_cast<const u32x4*>(sm + G + lo);
+                const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w};
+                unsigned gs[4], p2[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned g_lo = (by >> (2 * w)) & 1u ? (gw[w] & 0xffffu) : 0u;
+                    const unsigned g_hi = (by >> (2 * w + 1)) & 1u ? (gw[w] >> 16) : 0u;
+                    gs[w] = g_lo | (g_hi << 16);
+                    const unsigned q_lo = (bh >> (2 * w)) & 1u ? bf16_rn(__uint_as_float(g_lo << 16) * ik) : 0u;
+                    const unsigned q_hi = (bh >> (2 * w + 1)) & 1u ? bf16_rn(__uint_as_float(g_hi << 16) * ik) : 0u;
+                    p2[w] = q_lo | (q_hi << 16);
+                }
+                const u32x4 pv = u32x4{p2[0], p2[1], p2[2], p2[3]};
+                *reinterpret_cast<u32x4*>(sm + G + lo) = u32x4{gs[0], gs[1], gs[2], gs[3]};
+                *reinterpret_cast<u32x4*>(sm + P2 + lo) = pv;
+                *reinterpret_cast<u32x4*>(gp2 + (long long)m * CP + kc * 8) = pv;
+            }
+        }
+        TCN_STAMP();
+        __syncthreads();
+        TCN_STAMP();
+        // (b) P1 <- dgrad_conv2(P2) * [h1 > 0] / keep
+        {
+            const int cv = 2 * blk + 1;
+            const u32x4* wa = reinterpret_cast<const u32x4*>(p.wfrag + (long long)(2 * cv + 1) * FRAG) + (wave * CT_W * NKT) * 64 + lane;
+            zero_acc(acc);
+            conv_tile<true>(sm, P2, Z, wa, d, p.T, R, lane, acc);
+            TCN_STAMP();
+#pragma unroll
+            for (int i = 0; i < CT_W; ++i) {
+                const int co = (wave * CT_W + i) * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = mt * 16 + (lane & 15);
+                    if (m >= R) continue;
+                    const unsigned hb = (unsigned)M1[m * 40 + (co >> 3)] >> (co & 4);
+                    const unsigned q0 = hb & 1u ? bf16_rn(acc[i][mt][0] * ik) : 0u;
+                    const unsigned q1 = hb & 2u ? bf16_rn(acc[i][mt][1] * ik) : 0u;
+                    const unsigned q2 = hb & 4u ? bf16_rn(acc[i][mt][2] * ik) : 0u;
+                    const unsigned q3 = hb & 8u ? bf16_rn(acc[i][mt][3] * ik) : 0u;
+                    *reinterpret_cast<uint2*>(sm + P1 + m * PITCH + co) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
+                }
+            }
+        }
+        TCN_STAMP();
+        __syncthreads();
+        rows_out(sm + P1, p.gp1[blk] + row0 * CP, R, tid);
+        TCN_STAMP();
+        // (c) G <- dgrad_conv1(P1) + G
+        {
+            const int cv = 2 * blk;
+            const u32x4* wa = reinterpret_cast<const u32x4*>(p.wfrag + (long long)(2 * cv + 1) * FRAG) + (wave * CT_W * NKT) * 64 + lane;
+            zero_acc(acc);
+            conv_tile<true>(sm, P1, Z, wa, d, p.T, R, lane, acc);
+            TCN_STAMP();
+#pragma unroll
+            for (int i = 0; i < CT_W; ++i) {
+                const int co = (wave * CT_W + i) * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = mt * 16 + (lane & 15);
+                    if (m >= R) continue;
+                    uint2* gp = reinterpret_cast<uint2*>(sm + G + m * PITCH + co);
+                    const uint2 gv = *gp;
+                    const unsigned r0 = bf16_rn(acc[i][mt][0] + lo_f(gv.x)), r1 = bf16_rn(acc[i][mt][1] + hi_f(gv.x));
+                    const unsigned r2 = bf16_rn(acc[i][mt][2] + lo_f(gv.y)), r3 = bf16_rn(acc[i][mt][3] + hi_f(gv.y));
+                    *gp = make_uint2(r0 | (r1 << 16), r2 | (r3 << 16));
+                }
+            }
+        }
+        TCN_STAMP();
+        __syncthreads();
+    }
+    rows_out(sm + G, p.gx + row0 * CP, R, tid);
+}
+
+// fragment order: element e of conv cv, direction dir = ((((cv*2 + dir)*NCT + ct)*NKT + kt)*64 + lane)*8 + i holds
+// A[row = ct*16 + (lane & 15)][k = kt*32 + (lane >> 4)*8 + i], k = tap*320 + channel:
+//   forward   A[co][tap, ci] = w[co][tap][ci];   data gradient   A[ci][tap, co] = w[co][tap][ci]
+struct PackP {
+    const float* w[2 * S2AG_TCN_MAX_BLOCKS];
+    int n, C;
+    bf16_t* out;
+};
+__global__ __launch_bounds__(256) void tcn_pack_k(const PackP p) {
+    const long long total = (long long)p.n * 2 * FRAG;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        long long r = e >> 9;
+        const int kt = (int)(r % NKT);
+        r /= NKT;
+        const int ct = (int)(r % NCT);
+        r /= NCT;
+        const int dir = (int)(r & 1), cv = (int)(r >> 1);
+        const int row = ct * 16 + (lane & 15), k = kt * 32 + (lane >> 4) * 8 + i;
+        const int tap = k / CP, ch = k - tap * CP;
+        const int co = dir == 0 ? row : ch, ci = dir == 0 ? ch : row;
+        float v = 0.f;
+        if (co < p.C && ci < p.C) v = p.w[cv][((long long)co * 2 + tap) * p.C + ci];
+        p.out[e] = (bf16_t)bf16_rn(v);
+    }
+}
+
+unsigned long long* g_trace = nullptr;
+
+int fill(const s2ag_bf16_tcn_args* a, TcnP& p, bool bwd) {
+    if (!a || !a->x || !a->wfrag || a->n_blocks < 1 || a->n_blocks > S2AG_TCN_MAX_BLOCKS || a->n_clips <= 0) return S2AG_E_BADARG;
+    const int cpb = s2ag_bf16_tcn_clips_per_block(a->T, a->C, 2);
+    if (cpb <= 0) return S2AG_E_UNSUPPORTED;
+    if (a->drop_p < 0.f || a->drop_p >= 1.f || (a->drop_p > 0.f && !a->rng)) return S2AG_E_BADARG;
+    p.x = static_cast<const bf16_t*>(a->x);
+    p.wfrag = static_cast<const bf16_t*>(a->wfrag);
+    for (int b = 0; b < a->n_blocks; ++b) {
+        if (!a->h1[b] || !a->sign[b] || !a->y[b] || a->dil[b] < 1) return S2AG_E_BADARG;
+        p.h1[b] = static_cast<bf16_t*>(a->h1[b]);
+        p.sign[b] = static_cast<unsigned char*>(a->sign[b]);
+        p.y[b] = static_cast<bf16_t*>(a->y[b]);
+        p.dil[b] = a->dil[b];
+        p.bias[2 * b] = a->bias[2 * b];
+        p.bias[2 * b + 1] = a->bias[2 * b + 1];
+        p.site[2 * b] = a->site[2 * b];
+        p.site[2 * b + 1] = a->site[2 * b + 1];
+        if (bwd) {
+            if (!a->gp1[b] || !a->gp2[b]) return S2AG_E_BADARG;
+            p.gp1[b] = static_cast<bf16_t*>(a->gp1[b]);
+            p.gp2[b] = static_cast<bf16_t*>(a->gp2[b]);
+        }
+    }
+    if (bwd) {
+        if (!a->gy || !a->gx) return S2AG_E_BADARG;
+        p.gy = static_cast<const bf16_t*>(a->gy);
+        p.gx = static_cast<bf16_t*>(a->gx);
+    }
+    p.n_blocks = a->n_blocks; p.n_clips = a->n_clips; p.T = a->T; p.C = a->C; p.cpb = cpb;
+    p.drop_p = a->drop_p;
+    p.inv_keep = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
+    p.rng = static_cast<const unsigned long long*>(a->rng);
+    p.trace = g_trace;
+    return 0;
+}
+
+size_t lds_bytes(int cpb, int T, bool bwd) {
+    return (size_t)((bwd ? 3 : 2) * cpb * T + 1) * PITCH * sizeof(bf16_t) + sign_s1(cpb * T) + sign_s2(cpb * T);
+}
+}  // namespace
+
+extern "C" int s2ag_bf16_tcn_clips_per_block(int T, int C, int ksize) {
+    if (ksize != 2 || C < 1 || C > CP || T < 1 || T > MT * 16) return 0;
+    return (MT * 16) / T > 2 ? 2 : (MT * 16) / T;           // two clips: 128 workgroups at B = 256 beside the wave encoder
+}
+
+extern "C" int s2ag_bf16_tcn_set_trace(void* buf) {
+    g_trace = static_cast<unsigned long long*>(buf);
+    return 0;
+}
+
+extern "C" long long s2ag_bf16_tcn_sign_bytes(int n_clips, int T) {
+    const int cpb = s2ag_bf16_tcn_clips_per_block(T, CP, 2);
+    if (cpb <= 0 || n_clips <= 0) return 0;
+    return (long long)cdiv(n_clips, cpb) * (sign_s1(cpb * T) + sign_s2(cpb * T));
+}
+
+extern "C" long long s2ag_bf16_tcn_pack_elems(int n_convs) { return (long long)n_convs * 2 * FRAG; }
+
+extern "C" int s2ag_bf16_tcn_pack(const float* const* w, int n_convs, int C, void* wfrag, void* stream) {
+    if (!w || !wfrag || n_convs < 1 || n_convs > 2 * S2AG_TCN_MAX_BLOCKS || C < 1 || C > CP) return S2AG_E_BADARG;
+    PackP p{};
+    for (int k = 0; k < n_convs; ++k) {
+        if (!w[k]) return S2AG_E_BADARG;
+        p.w[k] = w[k];
+    }
+    p.n = n_convs; p.C = C; p.out = static_cast<bf16_t*>(wfrag);
+    hipLaunchKernelGGL(tcn_pack_k, dim3(2048), dim3(256), 0, (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_bf16_tcn_fwd(const s2ag_bf16_tcn_args* a, void* stream) {
+    TcnP p{};
+    const int rc = fill(a, p, false);
+    if (rc) return rc;
+    const size_t lds = lds_bytes(p.cpb, p.T, false);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)tcn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return S2AG_E_UNSUPPORTED;
+        attr = true;
+    }
+    hipLaunchKernelGGL(tcn_fwd_k, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_bf16_tcn_bwd(const s2ag_bf16_tcn_args* a, void* stream) {
+    TcnP p{};
+    const int rc = fill(a, p, true);
+    if (rc) return rc;
+    const size_t lds = lds_bytes(p.cpb, p.T, true);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)tcn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return S2AG_E_UNSUPPORTED;
+        attr = true;
+    }
+    hipLaunchKernelGGL(tcn_bwd_k, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}

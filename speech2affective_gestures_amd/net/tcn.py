@@ -129,8 +129,18 @@ class TemporalConvNet(nn.Module):
             # plain attributes (NOT nn.Module attributes: the decoder must not become a sub-module of the TCN)
             self.__dict__['_pack16'], self.__dict__['_pack16_dec'] = pk, decoder
         self.__dict__['_cur_ws'] = ws
-        for i, blk in enumerate(self.network):
-            x = blk.forward_nlc_bf16(x, noise, ws[2 * i:2 * i + 2], self.__dict__['_pack16'], i)
+        blks = list(self.network)
+        p = blks[0].p if self.training else 0.0
+        if (x.shape[-1] == 320 and all(b.kernel_size == 2 and b.p == blks[0].p for b in blks)
+                and bf16.tcn_fused_supported(x.shape[1], blks[0].conv1.out_channels, 2, len(blks))):
+            # clip-resident path (csrc/tcn_fused.hip): every block in one launch, forward and backward
+            if self.__dict__.get('_frag16') is None:
+                self.__dict__['_frag16'] = bf16.TcnFragments()
+            x = bf16.tcn_fused(x, self.__dict__['_frag16'], ws, [c.bias for b in blks for c in (b.conv1, b.conv2)],
+                               [b.dilation for b in blks], [s for b in blks for s in b.sites], p, noise)
+        else:
+            for i, blk in enumerate(blks):
+                x = blk.forward_nlc_bf16(x, noise, ws[2 * i:2 * i + 2], self.__dict__['_pack16'], i)
         if decoder is not None:
             return bf16.conv(x, decoder.weight, decoder.bias, self.__dict__['_pack16'], 'dec', decoder.in_features,
                              decoder.out_features, 1, out_f32=True)

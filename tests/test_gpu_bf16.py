@@ -223,3 +223,44 @@ def test_encoders_in_bf16_mode_track_their_fp32_mode(B):
         tol = 0.6 if k in ('wav.feat_extractor.1.weight', 'wav.feat_extractor.1.bias', 'wav.feat_extractor.4.weight',
                            'wav.feat_extractor.4.bias', 'wav.feat_extractor.7.weight', 'wav.feat_extractor.7.bias') else 0.15
         assert l2(g1[k], g0[k]) < tol, (k, l2(g1[k], g0[k]))
+
+
+@pytest.mark.parametrize('B', [5, 64])
+def test_clip_resident_tcn_equals_the_layer_by_layer_bf16_path(B):
+    """csrc/tcn_fused.hip (all TemporalBlocks in one launch, activations resident in LDS) against the layer-by-layer bf16
+    kernels on the same weights and the same noise stream.  Forward: the roundings sit at the same places and the K order
+    of the accumulation is the same -> identical up to a few bf16 ulps; backward: the data gradient sums its taps in the
+    other order and adds the residual branch before rounding (once instead of twice) -> 2^-8 per element."""
+    import types
+    from speech2affective_gestures_amd import bf16, noise, ops
+    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import TextEncoderTCN
+    cfg = types.SimpleNamespace(hidden_size=300, n_layers=4, dropout_prob=0.3, freeze_wordembed=False)
+    torch.manual_seed(3)
+    noise.reset_sites(0)
+    txt = TextEncoderTCN(cfg, 400, 300, dropout=0.3).cuda().train()
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(0, 400, (B, 34), generator=g)
+    ids[:, 20:] = 0
+    dt = torch.randn(B, 34, 32, generator=g).cuda()
+    res = {}
+    prev = bf16.FUSE_TCN
+    try:
+        for fused in (False, True):
+            bf16.FUSE_TCN = fused
+            for p in txt.parameters():
+                p.grad = None
+            ops.begin_step()
+            noise.manual_seed(5)
+            with bf16.precision('bf16'):
+                assert bf16.tcn_fused_supported(34, 300, 2, 4) == fused
+                t = txt(ids.cuda())[0]
+                (t * dt).sum().backward()
+            torch.cuda.synchronize()
+            res[fused] = (t.detach().clone(), {k: p.grad.clone() for k, p in txt.named_parameters() if '.net.' not in k})
+    finally:
+        bf16.FUSE_TCN = prev
+    (t0, g0), (t1, g1) = res[False], res[True]
+    print(f'[fused TCN, B={B}] out {rel(t1, t0):.2e}; gradients: ' + ', '.join(f'{k} {l2(g1[k], g0[k]):.2e}' for k in g0))
+    assert rel(t1, t0) < 2e-3
+    for k in g0:
+        assert l2(g1[k], g0[k]) < 2e-2, (k, l2(g1[k], g0[k]))
