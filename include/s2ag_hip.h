@@ -386,6 +386,11 @@ typedef struct {
     int flat_cin, ks_out;
 } s2ag_bf16_wgrad_args;
 int s2ag_bf16_conv_wgrad(const s2ag_bf16_wgrad_args* g, void* stream);
+/* The same gradient as two launches without atomics: the contraction is cut into many short pieces whose tiles are stored
+ * to `scratch` (s2ag_bf16_conv_wgrad_scratch_floats floats), then summed into dw / db by one thread per element -- for
+ * layers with a long contraction and a small, reference-layout (scattered) weight: the wave encoder's conv2-4. */
+long long s2ag_bf16_conv_wgrad_scratch_floats(const s2ag_bf16_wgrad_args* g);
+int s2ag_bf16_conv_wgrad_split(const s2ag_bf16_wgrad_args* g, float* scratch, long long scratch_floats, void* stream);
 /* fp32 master weights -> bf16 operand layouts, up to 32 tensors per launch (once per optimizer step):
  * dst[(o*taps + t)*Cp + c] = (c < cols and 0 <= tap0 + t*tap_step < src_taps) ? src[o*s_o + (tap0 + t*tap_step)*s_t + c*s_c] : 0 */
 #define S2AG_BF16_MAX_PACK 32

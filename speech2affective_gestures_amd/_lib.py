@@ -124,6 +124,8 @@ SIGNATURES = {
     's2ag_bf16_conv_stats_rows': [ci],
     's2ag_bf16_conv': [vp, PE, vp, vp, vp],
     's2ag_bf16_conv_wgrad': [vp, vp],
+    's2ag_bf16_conv_wgrad_scratch_floats': [vp],
+    's2ag_bf16_conv_wgrad_split': [vp, vp, cll, vp],
     's2ag_bf16_pack_weights': [vp, ci, vp],
     's2ag_bf16_cast': [vp, ci, cll, ci, vp, ci, ci, vp],
     's2ag_bf16_bn_apply': [vp, cll, ci, ci, vp, vp, cf, vp, vp],
@@ -180,7 +182,8 @@ def load():
         except AttributeError as e:
             raise S2AGLibraryError(f'{path} lacks symbol {name}; rebuild it') from e
         fn.argtypes = args
-        fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes') else ci
+        fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes',
+                              's2ag_bf16_conv_wgrad_scratch_floats') else ci
     if lib.s2ag_abi_version() != 1:
         raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
     _lib = lib

@@ -332,7 +332,12 @@ class _Conv16(torch.autograd.Function):
                 a = L.BF16Wgrad(_p(g), _p(x), _p(wslot), _p(bslot), N, Lout, Lin, Lin * ctx.ldx, ctx.ldx, ldg, stride, -pad,
                                 dil, ks, Cp64, ctx.ldx, Cout, Cin, d_co, d_t, d_c, 0, ks)
             if wslot is not None:
-                L.check(lib.s2ag_bf16_conv_wgrad(C.byref(a), _s()), 'bf16_conv_wgrad')
+                if ctx.flat and SPLIT_WGRAD:
+                    need = int(lib.s2ag_bf16_conv_wgrad_scratch_floats(C.byref(a)))
+                    sc = _wgrad_scratch(g.device, (id(pack), name), need)
+                    L.check(lib.s2ag_bf16_conv_wgrad_split(C.byref(a), _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_split')
+                else:
+                    L.check(lib.s2ag_bf16_conv_wgrad(C.byref(a), _s()), 'bf16_conv_wgrad')
                 if dw is None:
                     ops._note_staged(wleaf)
                 if bslot is not None and db is None:
@@ -358,6 +363,23 @@ def conv(x: Tensor, w: Tensor, bias: Optional[Tensor], pack: WeightPack, name: s
 
 
 _Conv16.last_stats = None
+SPLIT_WGRAD = os.environ.get('S2AG_BF16_SPLIT_WGRAD', '1') != '0'
+_WG_SCRATCH = {}
+
+
+def _wgrad_scratch(dev, owner, floats):
+    """Tile store of the split weight-gradient launches: one buffer per layer (passes of a step that run on forked streams
+    never share one), grown only outside hipGraph capture."""
+    key = (dev.index, owner)
+    t = _WG_SCRATCH.get(key)
+    if t is None or t.numel() < floats:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('bf16 weight-gradient scratch must exist before hipGraph capture (run one eager step first)')
+        t = torch.empty(floats, dtype=torch.float32, device=dev)
+        _WG_SCRATCH[key] = t
+    return t
+
+
 FUSE_EPILOGUE_BWD = os.environ.get('S2AG_BF16_FUSE_EPI', '1') != '0'
 _PRODUCER = {}      # data_ptr of a conv output -> (y, act, cols, slope, drop_p, noise, site, token) of its epilogue
 _FUSED = {}         # token -> data_ptr of the gradient tensor that already carries that epilogue's derivative

@@ -292,6 +292,10 @@ struct WgP {
     int flat_cin;               // > 0: "flat" windows -- channel index k of the single tap is (t, c) = (k / flat_cin, k % flat_cin)
     int ks_out;                 // taps of dw (== ks unless flat)
     int m_chunk;                // rows per blockIdx.y (multiple of 32)
+    // split launches (s2ag_bf16_conv_wgrad_split): every block stores its tile here instead of adding it to dw atomically
+    float* part;                // (splits, tiles, 64, 64) fp32;  nullable
+    float* part_b;              // (splits, co tiles, 64)
+    int ntiles;
 };
 
 constexpr int WG_ROWS = 64;     // rows of the contraction per step (two MFMA K steps)
@@ -418,9 +422,12 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int tile, const i
             if (c >= p.Cin || t >= p.ks_out) continue;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int co = co0 + wr * 32 + ti * 16 + (lane >> 4) * 4 + q;
-                if (co < p.Cout) atomicAdd(p.dw + (long long)co * p.d_co + (long long)t * p.d_t + (long long)c * p.d_c,
-                                           acc[ti][tj][q]);
+                const int col = wr * 32 + ti * 16 + (lane >> 4) * 4 + q, co = co0 + col;
+                if (co >= p.Cout) continue;
+                if (p.part)
+                    p.part[((long long)split * p.ntiles + tile) * 4096 + col * 64 + wc * 32 + tj * 16 + (lane & 15)] = acc[ti][tj][q];
+                else
+                    atomicAdd(p.dw + (long long)co * p.d_co + (long long)t * p.d_t + (long long)c * p.d_c, acc[ti][tj][q]);
             }
         }
     if (do_bias) {
@@ -428,8 +435,55 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int tile, const i
 #pragma unroll
         for (int j = 0; j < 8; ++j) atomicAdd(&bsum[ch * 8 + j], bacc[j]);
         __syncthreads();
-        if (tid < 64 && co0 + tid < p.Cout) atomicAdd(p.db + co0 + tid, bsum[tid]);
+        if (tid < 64 && co0 + tid < p.Cout) {
+            if (p.part) p.part_b[((long long)split * nco + cot) * 64 + tid] = bsum[tid];
+            else atomicAdd(p.db + co0 + tid, bsum[tid]);
+        }
     }
+}
+
+// second half of a split launch: dw (+ db) += the sum over the splits of the stored tiles -- one thread per element, no
+// atomics, and the scattered (Cout, Cin, ks) addresses of a reference-layout weight gradient are written once
+__global__ __launch_bounds__(256) void conv_bf16_wgrad_reduce_k(const WgP p, const int splits) {
+    // a block owns 32 consecutive elements; its 8 thread rows share the splits (many loads in flight, 128-byte segments)
+    __shared__ float red[8][33];
+    const int kct = p.Cp / 64, nco = (p.Cout + 63) / 64;
+    const long long total = (long long)p.ntiles * 4096;
+    const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + e;
+    const bool is_bias = i >= total;
+    const int j = (int)(i - total);
+    float sum = 0.f;
+    if (!is_bias) {
+        const float* src = p.part + i;
+        const int co_ = ((int)(i >> 12) % nco) * 64 + (((int)i & 4095) >> 6);
+        if (co_ < p.Cout) {                                      // rows of a tile beyond Cout were never stored
+#pragma unroll 8
+            for (int sp = grp; sp < splits; sp += 8) sum += src[(long long)sp * total];
+        }
+    } else if (j < nco * 64) {
+#pragma unroll 8
+        for (int sp = grp; sp < splits; sp += 8) sum += p.part_b[(long long)sp * nco * 64 + j];
+    }
+    red[grp][e] = sum;
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int g = 1; g < 8; ++g) sum += red[g][e];
+    if (is_bias) {
+        if (p.db && j < p.Cout) p.db[j] += sum;
+        return;
+    }
+    const int tile = (int)(i >> 12), r = (int)(i & 4095), col = r >> 6, kl = r & 63;
+    const int cot = tile % nco, kt = tile / nco;
+    const int tap = kt / kct, k = (kt - tap * kct) * 64 + kl, co = cot * 64 + col;
+    int t = tap, c = k;
+    if (p.flat_cin > 0) {
+        t = k / p.flat_cin;
+        c = k - t * p.flat_cin;
+    }
+    if (co >= p.Cout || c >= p.Cin || t >= p.ks_out) return;
+    p.dw[(long long)co * p.d_co + (long long)t * p.d_t + (long long)c * p.d_c] += sum;
 }
 
 __global__ __launch_bounds__(256) void conv_bf16_wgrad_k(const WgP p) { wgrad_body(p, blockIdx.x, blockIdx.y); }
@@ -812,6 +866,44 @@ static int wgrad_plan(const s2ag_bf16_wgrad_args* g, WgP& p, int target, int* sp
     return tiles;
 }
 
+// Split form: the contraction is cut into many short pieces (a block's loop is a chain of dependent global round trips:
+// 66 steps per block made conv2's gradient 106 us), each block stores its tile, a second launch sums them.
+static int split_count(const WgP& p, int tiles) {
+    int splits = cdiv(1280, tiles);
+    const int max_splits = cdiv(p.M, 4 * WG_ROWS);              // at least 4 steps of 64 rows per block
+    if (splits > max_splits) splits = max_splits;
+    return splits < 1 ? 1 : splits;
+}
+
+extern "C" long long s2ag_bf16_conv_wgrad_scratch_floats(const s2ag_bf16_wgrad_args* g) {
+    WgP p{};
+    int sp = 0;
+    const int tiles = wgrad_plan(g, p, 1, &sp);
+    if (tiles < 0) return tiles;
+    const int splits = split_count(p, tiles);
+    return (long long)splits * tiles * 4096 + (long long)splits * cdiv(p.Cout, 64) * 64;
+}
+
+extern "C" int s2ag_bf16_conv_wgrad_split(const s2ag_bf16_wgrad_args* g, float* scratch, long long scratch_floats, void* stream) {
+    WgP p{};
+    int sp = 0;
+    const int tiles = wgrad_plan(g, p, 1, &sp);
+    if (tiles < 0) return tiles;
+    int splits = split_count(p, tiles);
+    p.m_chunk = cdiv(cdiv(p.M, splits), WG_ROWS) * WG_ROWS;
+    splits = cdiv(p.M, p.m_chunk);
+    const long long need = (long long)splits * tiles * 4096 + (long long)splits * cdiv(p.Cout, 64) * 64;
+    if (!scratch || scratch_floats < need) return S2AG_E_BADARG;
+    p.part = scratch;
+    p.part_b = scratch + (long long)splits * tiles * 4096;
+    p.ntiles = tiles;
+    hipLaunchKernelGGL(conv_bf16_wgrad_k, dim3(tiles, splits), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv_bf16_wgrad_reduce_k, dim3(cdiv((long long)tiles * 4096 + cdiv(p.Cout, 64) * 64, 32)), dim3(256), 0,
+                       (hipStream_t)stream, p, splits);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int s2ag_bf16_conv_wgrad_multi(const s2ag_bf16_wgrad_args* jobs, int njobs, void* stream) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS) return S2AG_E_BADARG;
     static const int target = [] { const char* e = getenv("S2AG_BF16_WGRAD_MULTI_BLOCKS"); return e ? atoi(e) : 768; }();
@@ -901,8 +993,10 @@ extern "C" int s2ag_bf16_bn_bwd(const void* x, const void* dy, long long rows, i
         (cols & 7) || (ld & 7) || ld < cols)
         return S2AG_E_BADARG;
     const int cpr = cols / 8, lanes_c = cpr < 256 ? cpr : 256, rstep = 256 / lanes_c;
-    long long nb = (rows + (long long)rstep * 64 - 1) / ((long long)rstep * 64);       // ~64 rows per thread
-    if (nb > 1024) nb = 1024;
+    // ~16 rows per thread: with 64 the largest layer ran on 247 blocks -- one per CU, every thread a chain of 64 dependent
+    // load pairs (47 us for 129 MB)
+    long long nb = (rows + (long long)rstep * 16 - 1) / ((long long)rstep * 16);
+    if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(bn_bwd_sums_bf16_k, dim3((unsigned)nb), dim3(256), sizeof(float) * 2 * cols, (hipStream_t)stream,
                        static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dy), rows, cols, ld, scale, shift, mean,
