@@ -475,6 +475,12 @@ int s2ag_bf16_tcn_bwd(const s2ag_bf16_tcn_args* a, void* stream);
 /* up to 8 s2ag_bf16_conv_wgrad jobs in one launch (the TCN's eight weight gradients fill the chip together) */
 #define S2AG_BF16_MAX_WGRAD_JOBS 8
 int s2ag_bf16_conv_wgrad_multi(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs, void* stream);
+/* The same gradients through the LDS transpose read (csrc/wgrad_tr.hip): operand tiles go to LDS row-major as loaded and
+ * ds_read_b64_tr_b16 delivers the K-major MFMA operands -- no transposing loader, no atomics (tiles of the split
+ * contraction are stored to `scratch` and summed by a second launch).  Up to 8 jobs per call. */
+long long s2ag_bf16_conv_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs);
+int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs, float* scratch, long long scratch_floats,
+                            void* stream);
 
 /* Measurement aid (tools/pmc_traffic.py): touches `bytes` of `buf` with a known access pattern so the rocprofv3 counters
  * FETCH_SIZE / WRITE_SIZE can be calibrated against a known byte count in OUR access shapes: 0 = 16 B/lane coalesced

@@ -332,7 +332,11 @@ class _Conv16(torch.autograd.Function):
                 a = L.BF16Wgrad(_p(g), _p(x), _p(wslot), _p(bslot), N, Lout, Lin, Lin * ctx.ldx, ctx.ldx, ldg, stride, -pad,
                                 dil, ks, Cp64, ctx.ldx, Cout, Cin, d_co, d_t, d_c, 0, ks)
             if wslot is not None:
-                if ctx.flat and SPLIT_WGRAD:
+                if ctx.flat and WGRAD_TR:
+                    need = int(lib.s2ag_bf16_conv_wgrad_tr_scratch_floats(C.byref(a), 1))
+                    sc = _wgrad_scratch(g.device, (id(pack), name), need)
+                    L.check(lib.s2ag_bf16_conv_wgrad_tr(C.byref(a), 1, _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_tr')
+                elif ctx.flat and SPLIT_WGRAD:
                     need = int(lib.s2ag_bf16_conv_wgrad_scratch_floats(C.byref(a)))
                     sc = _wgrad_scratch(g.device, (id(pack), name), need)
                     L.check(lib.s2ag_bf16_conv_wgrad_split(C.byref(a), _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_split')
@@ -364,6 +368,7 @@ def conv(x: Tensor, w: Tensor, bias: Optional[Tensor], pack: WeightPack, name: s
 
 _Conv16.last_stats = None
 SPLIT_WGRAD = os.environ.get('S2AG_BF16_SPLIT_WGRAD', '1') != '0'
+WGRAD_TR = os.environ.get('S2AG_BF16_WGRAD_TR', '1') != '0'      # LDS transpose-read kernels (csrc/wgrad_tr.hip)
 _WG_SCRATCH = {}
 
 
@@ -502,7 +507,11 @@ class _TcnFused16(torch.autograd.Function):
                 nj += 1
                 if grads[k] is None:
                     ops._note_staged(ws[k])
-        if nj:
+        if nj and WGRAD_TR:
+            need = int(lib.s2ag_bf16_conv_wgrad_tr_scratch_floats(jobs, nj))
+            sc = _wgrad_scratch(gy.device, (id(ctx.frags), 'tcn'), need)
+            L.check(lib.s2ag_bf16_conv_wgrad_tr(jobs, nj, _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_tr')
+        elif nj:
             L.check(lib.s2ag_bf16_conv_wgrad_multi(jobs, nj, _s()), 'bf16_conv_wgrad_multi')
         return (gx.view(N, T, 320), None, None, None) + tuple(grads)
 
