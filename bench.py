@@ -426,6 +426,17 @@ def alt_modes(pr, dp, batch, B, steps=10):
     finally:
         lib.s2ag_gru_coop_set_split_pieces(prev if prev in (0, 2, 3) else -1)
         pr._graphed = None
+    # BASELINE configs[1] names bf16: the same step with the Conv1d path (wave encoder, text TCN) in bf16 mode -- bf16
+    # activations in HBM, fp32 accumulation / statistics / master weights (bf16.py; its own, looser parity tests)
+    from speech2affective_gestures_amd import bf16
+    try:
+        with bf16.precision('bf16'):
+            pr._graphed = None
+            el = timed_steps(pr, dp, batch, steps, 2, False)
+            out['bf16_conv_path'] = dict(clips_per_s=B * dp.world_size * steps / el, ms_per_step=el / steps * 1e3, steps=steps,
+                                         dtype='bf16 activations in the wave encoder and the text TCN, fp32 elsewhere')
+    finally:
+        pr._graphed = None
     return out
 
 

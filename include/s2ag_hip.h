@@ -461,9 +461,13 @@ typedef struct {
     void* gx;                                   /* bf16 (clips*T, 320): gradient w.r.t. x */
     void* gp1[S2AG_TCN_MAX_BLOCKS];             /* bf16 (clips*T, 320): gradient w.r.t. conv1's / conv2's pre-activation */
     void* gp2[S2AG_TCN_MAX_BLOCKS];
+    /* forward only, drop_p > 0: workspace of s2ag_bf16_tcn_keep_bytes bytes (the pass's dropout keep bits, generated by a
+     * launch of their own in front of the forward kernel) */
+    void* keep;
 } s2ag_bf16_tcn_args;
 int s2ag_bf16_tcn_clips_per_block(int T, int C, int ksize);
 long long s2ag_bf16_tcn_sign_bytes(int n_clips, int T);  /* bytes of one block's sign buffer */
+long long s2ag_bf16_tcn_keep_bytes(int n_clips, int T, int n_blocks);
 long long s2ag_bf16_tcn_pack_elems(int n_convs);          /* bf16 elements of the fragment-ordered weight set */
 /* w[k]: fp32 (C, 2, C) tap-major normalised weights of conv k (k = 2*block + {0, 1}); host array of device pointers */
 int s2ag_bf16_tcn_pack(const float* const* w, int n_convs, int C, void* wfrag, void* stream);

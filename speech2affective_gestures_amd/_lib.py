@@ -60,7 +60,7 @@ class BF16PackJob(C.Structure):   # s2ag_bf16_pack_job
 class BF16Tcn(C.Structure):       # s2ag_bf16_tcn_args
     _fields_ = [('x', vp), ('h1', vp * 4), ('sign', vp * 4), ('y', vp * 4), ('wfrag', vp), ('bias', vp * 8), ('dil', ci * 4),
                 ('n_blocks', ci), ('n_clips', ci), ('T', ci), ('C', ci), ('drop_p', cf), ('rng', vp), ('site', cu * 8),
-                ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4)]
+                ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4), ('keep', vp)]
 
 
 MAX_JOBS = 8
@@ -140,6 +140,7 @@ SIGNATURES = {
     's2ag_bf16_tcn_clips_per_block': [ci, ci, ci],
     's2ag_bf16_tcn_pack_elems': [ci],
     's2ag_bf16_tcn_sign_bytes': [ci, ci],
+    's2ag_bf16_tcn_keep_bytes': [ci, ci, ci],
     's2ag_bf16_tcn_pack': [vp, ci, ci, vp, vp],
     's2ag_bf16_tcn_fwd': [vp, vp],
     's2ag_bf16_tcn_set_trace': [vp],
@@ -184,7 +185,7 @@ def load():
         except AttributeError as e:
             raise S2AGLibraryError(f'{path} lacks symbol {name}; rebuild it') from e
         fn.argtypes = args
-        fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes',
+        fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes', 's2ag_bf16_tcn_keep_bytes',
                               's2ag_bf16_conv_wgrad_scratch_floats', 's2ag_bf16_conv_wgrad_tr_scratch_floats') else ci
     if lib.s2ag_abi_version() != 1:
         raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')

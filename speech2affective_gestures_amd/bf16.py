@@ -449,6 +449,9 @@ class _TcnFused16(torch.autograd.Function):
         a.n_blocks, a.n_clips, a.T, a.C = nb, N, T, C_
         a.drop_p = float(drop_p)
         a.rng = noise.data_ptr() if drop_p > 0 else None
+        if drop_p > 0:
+            keep = torch.empty(int(_lib().s2ag_bf16_tcn_keep_bytes(N, T, nb)), dtype=torch.uint8, device=x.device)
+            a.keep = keep.data_ptr()
         L.check(_lib().s2ag_bf16_tcn_fwd(C.byref(a), _s()), 'bf16_tcn_fwd')
         ctx.meta, ctx.frags, ctx.noise, ctx.params, ctx.shape = meta, frags, noise, params, ctx_shape
         ctx.save_for_backward(x, saved, signs)

@@ -44,6 +44,15 @@ __device__ __forceinline__ unsigned bf16_rn(float v) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+// two fp32 -> packed bf16 pair, round to nearest even: ONE v_cvt_pk_bf16_f32 (the integer form above is 5 instructions per
+// element, and with one wave per SIMD every vector instruction of an epilogue is 4 cycles of the workgroup's time)
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+// bits b0 b1 (bit 0, 1 of x) -> 0x0000ffff * b0 + 0xffff0000 * b1
+__device__ __forceinline__ unsigned pair_mask(unsigned x) { return (((x & 3u) * 0x8001u) & 0x10001u) * 0xffffu; }
 __device__ __forceinline__ float lo_f(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi_f(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -63,6 +72,7 @@ struct TcnP {
     bf16_t* gx;
     bf16_t* gp1[S2AG_TCN_MAX_BLOCKS];
     bf16_t* gp2[S2AG_TCN_MAX_BLOCKS];
+    u32x4* keep;                        // dropout keep bits of the forward pass (tcn_keep_k), one u32x4 per thread and conv
     unsigned long long* trace;          // diagnostics (s2ag_bf16_tcn_set_trace): s_memtime stamps of workgroup 0, wave 0
 };
 
@@ -151,18 +161,43 @@ __device__ __forceinline__ void rows_in(bf16_t* lds, const bf16_t* __restrict__ 
     }
 }
 
+// Dropout keep bits of all convs of a forward pass, in the layout the forward epilogue consumes: thread (workgroup wg,
+// conv cv, tid) owns the 100 elements (i, mt, c) of its MFMA accumulators; bit (i*MT + mt)*4 + c of its u32x4 says
+// "kept".  The hashes are the counter-based ones of every other kernel (index row*C + channel), but generated here they
+// run on all 256 CUs at full occupancy and off the forward kernel's dependent chain: inside its epilogue (one wave per
+// SIMD) they were 2/3 of its time -- 28 000 of 43 000 cycles per conv.
+__global__ __launch_bounds__(256) void tcn_keep_k(const TcnP p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x, cv = blockIdx.y;
+    const int clip0 = wg * p.cpb;
+    const int R = min(p.cpb, p.n_clips - clip0) * p.T;
+    const long long row0 = (long long)clip0 * p.T;
+    const SiteKey key = site_key(p.rng, p.site[cv]);
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < CT_W; ++i) {
+        const int co = (wave * CT_W + i) * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 16 + (lane & 15);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int b = (i * MT + mt) * 4 + c;
+                bool k = false;
+                if (m < R && co + c < p.C)
+                    k = keep_scale(key, (unsigned long long)(row0 + m) * p.C + co + c, p.drop_p, p.inv_keep) != 0.f;
+                w[b >> 5] |= k ? (1u << (b & 31)) : 0u;
+            }
+        }
+    }
+    p.keep[((size_t)cv * gridDim.x + wg) * 256 + tid] = u32x4{w[0], w[1], w[2], w[3]};
+}
+
 // sign bytes: what the backward pass needs of h1, h2 and y besides their use as GEMM operands is one bit per element.
 // Per workgroup and TemporalBlock: [m][40] bytes "h1 > 0" (S1 = that rounded up to 16) followed by [m][80] bytes
 // "h2 > 0" (0..39) and "y > 0" (40..79); byte kc of a row covers channels 8*kc .. 8*kc + 7.
 __host__ __device__ inline int sign_s1(int rows) { return (rows * 40 + 15) / 16 * 16; }
 __host__ __device__ inline int sign_s2(int rows) { return (rows * 80 + 15) / 16 * 16; }
-
-// the 4 bits of a lane (channels co .. co + 3 of row m) -> one byte per 8-channel chunk: lanes l and l ^ 16 hold the two
-// halves of a chunk; the lane with the even (lane >> 4) stores it
-__device__ __forceinline__ void put_bits(unsigned char* dst, unsigned nib, int lane, bool ok) {
-    const unsigned other = __shfl_xor(nib, 16, 64);
-    if (ok && !((lane >> 4) & 1)) *dst = (unsigned char)(nib | (other << 4));
-}
 
 __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -181,9 +216,6 @@ __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
     rows_in(sm + X, p.x + row0 * CP, R, tid);
     for (int i = tid; i < PITCH / 2; i += 256) reinterpret_cast<unsigned*>(sm + Z)[i] = 0u;
     const bool drop = p.drop_p > 0.f;
-    unsigned long long rng0 = 0, rng1 = 0;
-    if (drop) { rng0 = p.rng[0]; rng1 = p.rng[1]; }
-    const unsigned long long rngv[2] = {rng0, rng1};
     __syncthreads();
 
     f32x4 acc[CT_W][MT];
@@ -205,50 +237,59 @@ __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) bv[i][c] = (bias && co + c < p.C) ? bias[co + c] : 0.f;
             }
+            u32x4 kv = u32x4{0u, 0u, 0u, 0u};                    // this thread's keep bits: requested now, used after the K loop
+            if (drop) kv = p.keep[((size_t)cv * gridDim.x + blockIdx.x) * 256 + tid];
             zero_acc(acc);
             conv_tile<false>(sm, j == 0 ? X : H1, Z, wa, d, p.T, R, lane, acc);
             TCN_STAMP();
-            SiteKey key{0, 0};
-            if (drop) key = site_key(rngv, p.site[cv]);
-            // the mask index of an element does not depend on the conv: left visible, the compiler computes the first
-            // hash stage of all 100 elements ONCE, before the block loop, and keeps 200 registers alive across the kernel
-            // (512 VGPRs + 85 spilled).  An opaque copy of the row base per conv keeps the hashes inside the epilogue.
-            unsigned row0_lo = (unsigned)row0, row0_hi = (unsigned)(row0 >> 32);
-            asm volatile("" : "+s"(row0_lo), "+s"(row0_hi));
-            const long long row0v = (long long)(((unsigned long long)row0_hi << 32) | row0_lo);
+            const unsigned kw[4] = {kv.x, kv.y, kv.z, kv.w};
+            const float ik = p.inv_keep;
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
                 const int co = (wave * CT_W + i) * 16 + (lane >> 4) * 4;
+                unsigned hbits = 0u, ybits = 0u;                  // sign nibbles of this lane's five row tiles
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int m = mt * 16 + (lane & 15);
                     const bool ok = m < R;
                     const int mm = ok ? m : 0;
-                    unsigned h[4];
+                    float v[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        float v = fmaxf(acc[i][mt][c] + bv[i][c], 0.f);
-                        if (drop && co + c < p.C)
-                            v *= keep_scale(key, (unsigned long long)(row0v + mm) * p.C + co + c, p.drop_p, p.inv_keep);
-                        h[c] = bf16_rn(v);
+                        const int b = (i * MT + mt) * 4 + c;
+                        v[c] = fmaxf(acc[i][mt][c] + bv[i][c], 0.f);
+                        if (drop) v[c] = (kw[b >> 5] >> (b & 31)) & 1u ? v[c] * ik : 0.f;
                     }
-                    const unsigned hb = (h[0] ? 1u : 0u) | (h[1] ? 2u : 0u) | (h[2] ? 4u : 0u) | (h[3] ? 8u : 0u);   // h >= 0
+                    const unsigned h01 = pk_bf16(v[0], v[1]), h23 = pk_bf16(v[2], v[3]);
+                    hbits |= ((h01 & 0xffffu ? 1u : 0u) | (h01 >> 16 ? 2u : 0u) | (h23 & 0xffffu ? 4u : 0u) | (h23 >> 16 ? 8u : 0u))
+                             << (4 * mt);                      // h >= 0: nonzero = positive
                     if (j == 0) {
-                        if (ok) *reinterpret_cast<uint2*>(sm + H1 + m * PITCH + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                        put_bits(M1 + mm * 40 + (co >> 3), hb, lane, ok);
+                        if (ok) *reinterpret_cast<uint2*>(sm + H1 + m * PITCH + co) = make_uint2(h01, h23);
                     } else {                                     // residual + ReLU, in place over the block input
                         uint2* xp = reinterpret_cast<uint2*>(sm + X + mm * PITCH + co);
                         const uint2 xv = *xp;
-                        const unsigned y0 = bf16_rn(fmaxf(__uint_as_float(h[0] << 16) + lo_f(xv.x), 0.f));
-                        const unsigned y1 = bf16_rn(fmaxf(__uint_as_float(h[1] << 16) + hi_f(xv.x), 0.f));
-                        const unsigned y2 = bf16_rn(fmaxf(__uint_as_float(h[2] << 16) + lo_f(xv.y), 0.f));
-                        const unsigned y3 = bf16_rn(fmaxf(__uint_as_float(h[3] << 16) + hi_f(xv.y), 0.f));
-                        if (ok) *xp = make_uint2(y0 | (y1 << 16), y2 | (y3 << 16));
-                        const unsigned yb = (y0 ? 1u : 0u) | (y1 ? 2u : 0u) | (y2 ? 4u : 0u) | (y3 ? 8u : 0u);
-                        put_bits(M2 + mm * 80 + (co >> 3), hb, lane, ok);
-                        put_bits(M2 + mm * 80 + 40 + (co >> 3), yb, lane, ok);
+                        const unsigned y01 = pk_bf16(fmaxf(lo_f(h01) + lo_f(xv.x), 0.f), fmaxf(hi_f(h01) + hi_f(xv.x), 0.f));
+                        const unsigned y23 = pk_bf16(fmaxf(lo_f(h23) + lo_f(xv.y), 0.f), fmaxf(hi_f(h23) + hi_f(xv.y), 0.f));
+                        if (ok) *xp = make_uint2(y01, y23);
+                        ybits |= ((y01 & 0xffffu ? 1u : 0u) | (y01 >> 16 ? 2u : 0u) | (y23 & 0xffffu ? 4u : 0u) | (y23 >> 16 ? 8u : 0u))
+                                 << (4 * mt);
                     }
-                    __builtin_amdgcn_sched_barrier(0);          // one (tile, row tile) at a time: interleaving all 25 spills
+                }
+                // lanes l and l ^ 16 hold the two halves of every 8-channel chunk: one exchange per channel tile
+                const unsigned ho = __shfl_xor(hbits, 16, 64), yo = __shfl_xor(ybits, 16, 64);
+                if (!((lane >> 4) & 1)) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int m = mt * 16 + (lane & 15);
+                        if (m >= R) continue;
+                        const unsigned hb = ((hbits >> (4 * mt)) & 15u) | (((ho >> (4 * mt)) & 15u) << 4);
+                        if (j == 0) {
+                            M1[m * 40 + (co >> 3)] = (unsigned char)hb;
+                        } else {
+                            M2[m * 80 + (co >> 3)] = (unsigned char)hb;
+                            M2[m * 80 + 40 + (co >> 3)] = (unsigned char)(((ybits >> (4 * mt)) & 15u) | (((yo >> (4 * mt)) & 15u) << 4));
+                        }
+                    }
                 }
             }
             TCN_STAMP();
@@ -316,12 +357,8 @@ __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
                 unsigned gs[4], p2[4];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const unsigned g_lo = (by >> (2 * w)) & 1u ? (gw[w] & 0xffffu) : 0u;
-                    const unsigned g_hi = (by >> (2 * w + 1)) & 1u ? (gw[w] >> 16) : 0u;
-                    gs[w] = g_lo | (g_hi << 16);
-                    const unsigned q_lo = (bh >> (2 * w)) & 1u ? bf16_rn(__uint_as_float(g_lo << 16) * ik) : 0u;
-                    const unsigned q_hi = (bh >> (2 * w + 1)) & 1u ? bf16_rn(__uint_as_float(g_hi << 16) * ik) : 0u;
-                    p2[w] = q_lo | (q_hi << 16);
+                    gs[w] = gw[w] & pair_mask(by >> (2 * w));
+                    p2[w] = pk_bf16(lo_f(gs[w]) * ik, hi_f(gs[w]) * ik) & pair_mask(bh >> (2 * w));
                 }
                 const u32x4 pv = u32x4{p2[0], p2[1], p2[2], p2[3]};
                 *reinterpret_cast<u32x4*>(sm + G + lo) = u32x4{gs[0], gs[1], gs[2], gs[3]};
@@ -347,11 +384,9 @@ __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
                     const int m = mt * 16 + (lane & 15);
                     if (m >= R) continue;
                     const unsigned hb = (unsigned)M1[m * 40 + (co >> 3)] >> (co & 4);
-                    const unsigned q0 = hb & 1u ? bf16_rn(acc[i][mt][0] * ik) : 0u;
-                    const unsigned q1 = hb & 2u ? bf16_rn(acc[i][mt][1] * ik) : 0u;
-                    const unsigned q2 = hb & 4u ? bf16_rn(acc[i][mt][2] * ik) : 0u;
-                    const unsigned q3 = hb & 8u ? bf16_rn(acc[i][mt][3] * ik) : 0u;
-                    *reinterpret_cast<uint2*>(sm + P1 + m * PITCH + co) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
+                    const unsigned q01 = pk_bf16(acc[i][mt][0] * ik, acc[i][mt][1] * ik) & pair_mask(hb);
+                    const unsigned q23 = pk_bf16(acc[i][mt][2] * ik, acc[i][mt][3] * ik) & pair_mask(hb >> 2);
+                    *reinterpret_cast<uint2*>(sm + P1 + m * PITCH + co) = make_uint2(q01, q23);
                 }
             }
         }
@@ -375,9 +410,8 @@ __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
                     if (m >= R) continue;
                     uint2* gp = reinterpret_cast<uint2*>(sm + G + m * PITCH + co);
                     const uint2 gv = *gp;
-                    const unsigned r0 = bf16_rn(acc[i][mt][0] + lo_f(gv.x)), r1 = bf16_rn(acc[i][mt][1] + hi_f(gv.x));
-                    const unsigned r2 = bf16_rn(acc[i][mt][2] + lo_f(gv.y)), r3 = bf16_rn(acc[i][mt][3] + hi_f(gv.y));
-                    *gp = make_uint2(r0 | (r1 << 16), r2 | (r3 << 16));
+                    *gp = make_uint2(pk_bf16(acc[i][mt][0] + lo_f(gv.x), acc[i][mt][1] + hi_f(gv.x)),
+                                     pk_bf16(acc[i][mt][2] + lo_f(gv.y), acc[i][mt][3] + hi_f(gv.y)));
                 }
             }
         }
@@ -448,6 +482,8 @@ int fill(const s2ag_bf16_tcn_args* a, TcnP& p, bool bwd) {
     p.drop_p = a->drop_p;
     p.inv_keep = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
     p.rng = static_cast<const unsigned long long*>(a->rng);
+    p.keep = static_cast<u32x4*>(a->keep);
+    if (!bwd && a->drop_p > 0.f && !a->keep) return S2AG_E_BADARG;
     p.trace = g_trace;
     return 0;
 }
@@ -471,6 +507,12 @@ extern "C" long long s2ag_bf16_tcn_sign_bytes(int n_clips, int T) {
     const int cpb = s2ag_bf16_tcn_clips_per_block(T, CP, 2);
     if (cpb <= 0 || n_clips <= 0) return 0;
     return (long long)cdiv(n_clips, cpb) * (sign_s1(cpb * T) + sign_s2(cpb * T));
+}
+
+extern "C" long long s2ag_bf16_tcn_keep_bytes(int n_clips, int T, int n_blocks) {
+    const int cpb = s2ag_bf16_tcn_clips_per_block(T, CP, 2);
+    if (cpb <= 0 || n_clips <= 0 || n_blocks < 1) return 0;
+    return (long long)cdiv(n_clips, cpb) * 2 * n_blocks * 256 * 16;
 }
 
 extern "C" long long s2ag_bf16_tcn_pack_elems(int n_convs) { return (long long)n_convs * 2 * FRAG; }
@@ -499,6 +541,8 @@ extern "C" int s2ag_bf16_tcn_fwd(const s2ag_bf16_tcn_args* a, void* stream) {
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
+    if (p.drop_p > 0.f)
+        hipLaunchKernelGGL(tcn_keep_k, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(tcn_fwd_k, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
