@@ -42,14 +42,28 @@ __device__ __forceinline__ unsigned c1_bf16_rn(float v) {
     return u >> 16;
 }
 
-// stage the waveform under output frames [l0, l0 + C1_RUN) of clip n: seg[i] = x[n, l0*stride - pad + i]
-template <int KS>
-__device__ __forceinline__ void stage_segment(const C1P& p, float* seg, int n, int l0, int seg_len) {
+// The waveform under output frames [l0, l0 + C1_RUN) of clip n: seg[i] = x[n, l0*stride - pad + i].  Two halves so that
+// the NEXT run's segment is in flight (registers) while the current one is consumed from LDS: a block is a chain of runs,
+// and with the load, the barrier and the compute in sequence every run paid a full memory round trip (fwd 48 us, wgrad
+// 86 us at B = 256 against ~25 us of traffic).
+constexpr int C1_SEG_REGS = 17;   // ceil(((C1_RUN - 1) * stride + KS) / C1_NT) for stride <= 8, KS <= 15 -- checked by the host
+
+__device__ __forceinline__ void fetch_segment(const C1P& p, float (&r)[C1_SEG_REGS], int run, int seg_len) {
+    const int n = run / p.runs_per_clip, l0 = (run - n * p.runs_per_clip) * C1_RUN;
     const long long base = (long long)l0 * p.stride - p.pad;
     const float* xc = p.x + (long long)n * p.Lin * p.ldx;
-    for (int i = threadIdx.x; i < seg_len; i += C1_NT) {
+#pragma unroll
+    for (int k = 0; k < C1_SEG_REGS; ++k) {
+        const int i = threadIdx.x + k * C1_NT;
         const long long pos = base + i;
-        seg[i] = (pos >= 0 && pos < p.Lin) ? xc[pos * p.ldx] : 0.f;
+        r[k] = (i < seg_len && pos >= 0 && pos < p.Lin) ? xc[pos * p.ldx] : 0.f;
+    }
+}
+__device__ __forceinline__ void store_segment(float* seg, const float (&r)[C1_SEG_REGS], int seg_len) {
+#pragma unroll
+    for (int k = 0; k < C1_SEG_REGS; ++k) {
+        const int i = threadIdx.x + k * C1_NT;
+        if (i < seg_len) seg[i] = r[k];
     }
 }
 
@@ -68,11 +82,14 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_fwd_k(const C1P p) {
     }
     const int seg_len = (C1_RUN - 1) * p.stride + KS;
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    float sr[C1_SEG_REGS];
+    if ((int)blockIdx.x < p.total_runs) fetch_segment(p, sr, blockIdx.x, seg_len);
     for (int run = blockIdx.x; run < p.total_runs; run += gridDim.x) {
         const int n = run / p.runs_per_clip, l0 = (run - n * p.runs_per_clip) * C1_RUN;
         __syncthreads();                                              // the previous run's readers are done
-        stage_segment<KS>(p, seg, n, l0, seg_len);
+        store_segment(seg, sr, seg_len);
         __syncthreads();
+        if (run + (int)gridDim.x < p.total_runs) fetch_segment(p, sr, run + gridDim.x, seg_len);
 #pragma unroll 2
         for (int i = 0; i < C1_RUN / 64; ++i) {
             const int f = i * 64 + fr, l = l0 + f;
@@ -137,24 +154,36 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
         for (int t = 0; t < KS; ++t) acc[c][t] = 0.f;
     }
     const int seg_len = (C1_RUN - 1) * p.stride + KS;
+    float sr[C1_SEG_REGS];
+    if ((int)blockIdx.x < p.total_runs) fetch_segment(p, sr, blockIdx.x, seg_len);
     for (int run = blockIdx.x; run < p.total_runs; run += gridDim.x) {
         const int n = run / p.runs_per_clip, l0 = (run - n * p.runs_per_clip) * C1_RUN;
-        __syncthreads();
-        stage_segment<KS>(p, seg, n, l0, seg_len);
-        __syncthreads();
-#pragma unroll 2
+        // all of the run's output-gradient rows of this thread are requested up front (one round trip per run, not four)
+        float4 gq[C1_RUN / 64];
+#pragma unroll
         for (int i = 0; i < C1_RUN / 64; ++i) {
-            const int f = i * 64 + fr, l = l0 + f;
+            const int l = l0 + i * 64 + fr;
+            gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (l < p.Lout) {
-                float4 g4;
                 if (BF) {
                     const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.y) +
                                                                     ((long long)n * p.Lout + l) * p.ldy + q * 4);
-                    g4 = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u),
-                                     __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+                    gq[i] = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u),
+                                        __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
                 } else {
-                    g4 = *reinterpret_cast<const float4*>(p.y + ((long long)n * p.Lout + l) * p.ldy + q * 4);
+                    gq[i] = *reinterpret_cast<const float4*>(p.y + ((long long)n * p.Lout + l) * p.ldy + q * 4);
                 }
+            }
+        }
+        __syncthreads();
+        store_segment(seg, sr, seg_len);
+        __syncthreads();
+        if (run + (int)gridDim.x < p.total_runs) fetch_segment(p, sr, run + gridDim.x, seg_len);
+#pragma unroll
+        for (int i = 0; i < C1_RUN / 64; ++i) {
+            const int f = i * 64 + fr, l = l0 + f;
+            if (l < p.Lout) {
+                const float4 g4 = gq[i];
                 const float* gp = &g4.x;
                 const float* sx = seg + f * p.stride;
                 float xv[KS];
@@ -201,7 +230,8 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
 }
 
 inline bool c1_shape_ok(int Cin, int Cout, int ks, int dil, int ldx, int ldy, int stride) {
-    return Cin == 1 && Cout == 16 && ks == 15 && dil == 1 && ldx == 1 && (ldy & 3) == 0 && stride >= 1 && stride <= 8;
+    return Cin == 1 && Cout == 16 && ks == 15 && dil == 1 && ldx == 1 && (ldy & 3) == 0 && stride >= 1 &&
+           (C1_RUN - 1) * stride + 15 <= C1_SEG_REGS * C1_NT;      // the register-staged segment (stride <= 8)
 }
 inline size_t c1_seg_bytes(int stride) { return sizeof(float) * ((size_t)(C1_RUN - 1) * stride + 15); }
 }  // namespace

@@ -1060,7 +1060,9 @@ extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float*
     const dim3 grid(10, cdiv(B, CBS), 2);
     if (coop_split_pieces() != 0 && B > CBS && coop_two_slices()) {
         const int np = coop_split_pieces();
-        const int smem2 = 2 * np * CBS * (5 * 2 * 32 + 8) * 2;             // [slice][piece][clip][k] bf16
+        int smem2 = 2 * np * CBS * (5 * 2 * 32 + 8) * 2;                   // [slice][piece][clip][k] bf16
+        static const int reserve_f = [] { const char* e = getenv("S2AG_COOP_FWD_LDS_RESERVE"); return (e ? atoi(e) : 0) * 1024; }();
+        if (reserve_f > smem2) smem2 = reserve_f;                          // CU reservation, see s2ag_gru_coop_bwd
         const void* fn2 = np == 3 ? reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 3, 2>)
                                   : reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 2, 2>);
         static bool granted2[4] = {false, false, false, false};
@@ -1111,7 +1113,13 @@ extern "C" int s2ag_gru_coop_bwd(const float* dy, int lddy, int dy_dir_stride, c
     const unsigned site = e ? e->site : 0u;
     const int np = coop_split_pieces();
     const size_t red_bytes = sizeof(float) * 3 * CBS * (19 * 16 + 4);
-    const size_t smem = red_bytes + (np ? (size_t)np * CBS * (96 + 8) * 2 : sizeof(float) * CBS * lds_pitch(96));   // gO + red
+    size_t smem = red_bytes + (np ? (size_t)np * CBS * (96 + 8) * 2 : sizeof(float) * CBS * lds_pitch(96));   // gO + red
+    // CU reservation: a workgroup that asks for (almost) all of a CU's LDS keeps every other LDS-using workgroup -- the
+    // weight-gradient GEMMs that run beside the recurrence on a forked stream -- off its CU.  The recurrence is a chain of
+    // latency-bound steps: sharing the CU's issue slots and LDS pipe with a GEMM made a launch 299 us inside the step
+    // against 158 us alone, while 96 of the 256 CUs have no recurrence workgroup at all.
+    static const size_t reserve = [] { const char* e = getenv("S2AG_COOP_BWD_LDS_RESERVE"); return (size_t)(e ? atoi(e) : 0) * 1024; }();
+    if (reserve > smem) smem = reserve;
     const void* fn = np == 3   ? reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 3>)
                      : np == 2 ? reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 2>)
                                : reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 0>);
