@@ -532,6 +532,9 @@ int s2ag_gen_loss(const float* out, const float* target, const float* out_tri /*
 int s2ag_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                    float eps, const int* step, float grad_scale, void* stream);
 int s2ag_counter_inc(int* counter /*nullable*/, unsigned long long* rng /*nullable: rng[1] += 1*/, void* stream);
+/* noise state of one forward pass: snap[0:2] = rng[0:2], then rng[1] += 1 (the reference draws fresh torch RNG per
+ * F.dropout / randn call -- net/tcn.py:22,28, net/embedding_net.py:10-13; here a pass = one counter value) */
+int s2ag_rng_snapshot(unsigned long long* rng, unsigned long long* snap, void* stream);
 
 /* materialise the noise a kernel will use (parity tests / debugging only) */
 int s2ag_dropout_mask(const unsigned long long* rng, unsigned site, float p, long long n, float* mask, void* stream);

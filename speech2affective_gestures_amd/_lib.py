@@ -157,6 +157,7 @@ SIGNATURES = {
     's2ag_gen_loss': [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, C.POINTER(cf), vp, vp, vp, vp, vp, vp, vp],
     's2ag_adam_step': [vp, vp, vp, vp, cll, cf, cf, cf, cf, vp, cf, vp],
     's2ag_counter_inc': [vp, vp, vp],
+    's2ag_rng_snapshot': [vp, vp, vp],
     's2ag_dropout_mask': [vp, cu, cf, cll, vp, vp],
     's2ag_normal_noise': [vp, cu, cll, vp, vp],
 }

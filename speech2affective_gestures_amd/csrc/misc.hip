@@ -412,6 +412,17 @@ __global__ void counter_inc_k(int* counter, unsigned long long* rng) {
     }
 }
 
+// snapshot of the noise state for one forward pass + advance of the pass counter, in ONE one-thread launch (was: a
+// 16-byte ATen clone + counter_inc_k, ten times per step)
+__global__ void rng_snapshot_k(unsigned long long* rng, unsigned long long* snap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const unsigned long long s = rng[0], c = rng[1];
+        snap[0] = s;
+        snap[1] = c;
+        rng[1] = c + 1ULL;
+    }
+}
+
 __global__ __launch_bounds__(256) void dropout_mask_k(const unsigned long long* rng, unsigned site, float p,
                                                       float inv_keep, long long n, float* mask) {
     const SiteKey key = site_key(rng, site);
@@ -693,6 +704,13 @@ extern "C" int s2ag_adam_step(float* p, const float* g, float* m, float* v, long
 
 extern "C" int s2ag_counter_inc(int* counter, unsigned long long* rng, void* stream) {
     hipLaunchKernelGGL(counter_inc_k, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, rng);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_rng_snapshot(unsigned long long* rng, unsigned long long* snap, void* stream) {
+    if (!rng || !snap) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(rng_snapshot_k, dim3(1), dim3(64), 0, (hipStream_t)stream, rng, snap);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

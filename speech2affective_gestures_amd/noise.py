@@ -1,7 +1,7 @@
 """Device-resident random state.
 
 ``rng`` is a 2-word device array {seed, pass counter} (see include/s2ag_hip.h).  Every top-level forward
-pass takes a *snapshot* of it (a 16-byte device copy) and bumps the counter with a one-thread kernel, so
+pass takes a *snapshot* of it and bumps the counter (one one-thread kernel for both), so
   * consecutive passes (the three generator forwards of one GAN step) see different noise,
   * the backward pass of a forward regenerates exactly that forward's masks from its snapshot,
   * a captured hipGraph keeps advancing the noise on every replay (the counter lives on the device).
@@ -48,9 +48,9 @@ def manual_seed(seed: int, device='cuda') -> None:
 
 def begin_pass(device) -> torch.Tensor:
     st = _dev_state(device)
-    snap = st.clone()
-    L.check(L.load().s2ag_counter_inc(None, C.c_void_p(st.data_ptr()),
-                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'counter_inc')
+    snap = torch.empty_like(st)
+    L.check(L.load().s2ag_rng_snapshot(C.c_void_p(st.data_ptr()), C.c_void_p(snap.data_ptr()),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'rng_snapshot')
     return snap
 
 
