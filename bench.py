@@ -508,6 +508,13 @@ def main():
             line['long_context_run'] = dict(workload=lw['name'], batch_per_gpu=lw['batch'], frames=lw['frames'],
                                             clips_per_s=lw['batch'] * 10 / el, ms_per_step=el / 10 * 1e3, steps=10,
                                             dtype='f32')
+        # RCCL writes a version banner through C stdio, which is flushed at exit -- i.e. AFTER this line; push it out first
+        # so that the JSON line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     dp.barrier()
     import torch.distributed as dist
