@@ -332,7 +332,7 @@ class _Conv16(torch.autograd.Function):
                 a = L.BF16Wgrad(_p(g), _p(x), _p(wslot), _p(bslot), N, Lout, Lin, Lin * ctx.ldx, ctx.ldx, ldg, stride, -pad,
                                 dil, ks, Cp64, ctx.ldx, Cout, Cin, d_co, d_t, d_c, 0, ks)
             if wslot is not None:
-                if ctx.flat and WGRAD_TR:
+                if ctx.flat and WGRAD_TR and Lout >= 32:      # (the transpose-read loader steps 32 rows with one clip wrap)
                     need = int(lib.s2ag_bf16_conv_wgrad_tr_scratch_floats(C.byref(a), 1))
                     sc = _wgrad_scratch(g.device, (id(pack), name), need)
                     L.check(lib.s2ag_bf16_conv_wgrad_tr(C.byref(a), 1, _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_tr')
@@ -510,7 +510,7 @@ class _TcnFused16(torch.autograd.Function):
                 nj += 1
                 if grads[k] is None:
                     ops._note_staged(ws[k])
-        if nj and WGRAD_TR:
+        if nj and WGRAD_TR and T >= 32:
             need = int(lib.s2ag_bf16_conv_wgrad_tr_scratch_floats(jobs, nj))
             sc = _wgrad_scratch(gy.device, (id(ctx.frags), 'tcn'), need)
             L.check(lib.s2ag_bf16_conv_wgrad_tr(jobs, nj, _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_tr')

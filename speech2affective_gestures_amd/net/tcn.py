@@ -118,21 +118,25 @@ class TemporalConvNet(nn.Module):
         Returns bf16 (B, T, Cp), or the decoder's fp32 (B, T, out) when ``decoder`` is given."""
         from .. import bf16
         ws = [w for g in self._weight_groups() for w in g.tensors()]
-        if self.__dict__.get('_pack16') is None or self.__dict__.get('_pack16_dec') is not decoder:
+        blks = list(self.network)
+        fused = (x.shape[-1] == 320 and all(b.kernel_size == 2 and b.p == blks[0].p for b in blks)
+                 and bf16.tcn_fused_supported(x.shape[1], blks[0].conv1.out_channels, 2, len(blks)))
+        if (self.__dict__.get('_pack16') is None or self.__dict__.get('_pack16_dec') is not decoder
+                or self.__dict__.get('_pack16_fused') != fused):
             pk = bf16.WeightPack()
             for i, blk in enumerate(self.network):
+                if fused:
+                    break           # the clip-resident kernels take their weights in fragment order (bf16.TcnFragments)
                 for j, conv in enumerate((blk.conv1, blk.conv2)):
                     pk.add(f'c{i}{"ab"[j]}', (lambda k=2 * i + j: self.__dict__['_cur_ws'][k]), 'tap_major', conv.out_channels,
                            conv.in_channels, blk.kernel_size)
             if decoder is not None:
                 pk.add('dec', (lambda d=decoder: d.weight), 'tap_major', decoder.out_features, decoder.in_features, 1)
             # plain attributes (NOT nn.Module attributes: the decoder must not become a sub-module of the TCN)
-            self.__dict__['_pack16'], self.__dict__['_pack16_dec'] = pk, decoder
+            self.__dict__['_pack16'], self.__dict__['_pack16_dec'], self.__dict__['_pack16_fused'] = pk, decoder, fused
         self.__dict__['_cur_ws'] = ws
-        blks = list(self.network)
         p = blks[0].p if self.training else 0.0
-        if (x.shape[-1] == 320 and all(b.kernel_size == 2 and b.p == blks[0].p for b in blks)
-                and bf16.tcn_fused_supported(x.shape[1], blks[0].conv1.out_channels, 2, len(blks))):
+        if fused:
             # clip-resident path (csrc/tcn_fused.hip): every block in one launch, forward and backward
             if self.__dict__.get('_frag16') is None:
                 self.__dict__['_frag16'] = bf16.TcnFragments()
