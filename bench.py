@@ -321,7 +321,10 @@ def conv1d_roofline_run(device, B=256, iters=30, cpu=True, mode='fp32'):
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             txt(text)[0].backward(g_ones)
-        wav(audio).backward(g_ones)
+        y = wav(audio)
+        ops.set_main_stream()                # as the trainer does: big weight gradients (leaves of the backward graph) run
+        y.backward(g_ones)                   # beside the data-gradient chain on the weight-gradient stream
+        ops.join_side_streams()
         cur.wait_stream(side)
     with bf16.precision(mode):
         ms = _graph_timer(fn, iters)

@@ -332,16 +332,22 @@ class _Conv16(torch.autograd.Function):
                 a = L.BF16Wgrad(_p(g), _p(x), _p(wslot), _p(bslot), N, Lout, Lin, Lin * ctx.ldx, ctx.ldx, ldg, stride, -pad,
                                 dil, ks, Cp64, ctx.ldx, Cout, Cin, d_co, d_t, d_c, 0, ks)
             if wslot is not None:
+                sc = None
                 if ctx.flat and WGRAD_TR and Lout >= 32:      # (the transpose-read loader steps 32 rows with one clip wrap)
-                    need = int(lib.s2ag_bf16_conv_wgrad_tr_scratch_floats(C.byref(a), 1))
-                    sc = _wgrad_scratch(g.device, (id(pack), name), need)
-                    L.check(lib.s2ag_bf16_conv_wgrad_tr(C.byref(a), 1, _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_tr')
+                    sc = _wgrad_scratch(g.device, (id(pack), name), int(lib.s2ag_bf16_conv_wgrad_tr_scratch_floats(C.byref(a), 1)))
                 elif ctx.flat and SPLIT_WGRAD:
-                    need = int(lib.s2ag_bf16_conv_wgrad_scratch_floats(C.byref(a)))
-                    sc = _wgrad_scratch(g.device, (id(pack), name), need)
-                    L.check(lib.s2ag_bf16_conv_wgrad_split(C.byref(a), _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_split')
-                else:
-                    L.check(lib.s2ag_bf16_conv_wgrad(C.byref(a), _s()), 'bf16_conv_wgrad')
+                    sc = _wgrad_scratch(g.device, (id(pack), name), int(lib.s2ag_bf16_conv_wgrad_scratch_floats(C.byref(a))))
+
+                def launch(a=a, sc=sc):
+                    if sc is not None and WGRAD_TR and Lout >= 32:
+                        L.check(lib.s2ag_bf16_conv_wgrad_tr(C.byref(a), 1, _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_tr')
+                    elif sc is not None:
+                        L.check(lib.s2ag_bf16_conv_wgrad_split(C.byref(a), _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_split')
+                    else:
+                        L.check(lib.s2ag_bf16_conv_wgrad(C.byref(a), _s()), 'bf16_conv_wgrad')
+                # a leaf of the backward graph: big ones run beside the data-gradient chain (ops.run_wgrad forks them to
+                # the weight-gradient stream when the trainer armed it; the trainer joins before the optimizer)
+                ops.run_wgrad(launch, keep=(g, x), flops=2.0 * N * Lout * Cout * Cin * ks)
                 if dw is None:
                     ops._note_staged(wleaf)
                 if bslot is not None and db is None:
@@ -510,12 +516,17 @@ class _TcnFused16(torch.autograd.Function):
                 nj += 1
                 if grads[k] is None:
                     ops._note_staged(ws[k])
-        if nj and WGRAD_TR and T >= 32:
-            need = int(lib.s2ag_bf16_conv_wgrad_tr_scratch_floats(jobs, nj))
-            sc = _wgrad_scratch(gy.device, (id(ctx.frags), 'tcn'), need)
-            L.check(lib.s2ag_bf16_conv_wgrad_tr(jobs, nj, _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_tr')
-        elif nj:
-            L.check(lib.s2ag_bf16_conv_wgrad_multi(jobs, nj, _s()), 'bf16_conv_wgrad_multi')
+        if nj:
+            sc = None
+            if WGRAD_TR and T >= 32:
+                sc = _wgrad_scratch(gy.device, (id(ctx.frags), 'tcn'), int(lib.s2ag_bf16_conv_wgrad_tr_scratch_floats(jobs, nj)))
+
+            def launch(jobs=jobs, nj=nj, sc=sc):
+                if sc is not None:
+                    L.check(lib.s2ag_bf16_conv_wgrad_tr(jobs, nj, _p(sc), sc.numel(), _s()), 'bf16_conv_wgrad_tr')
+                else:
+                    L.check(lib.s2ag_bf16_conv_wgrad_multi(jobs, nj, _s()), 'bf16_conv_wgrad_multi')
+            ops.run_wgrad(launch, keep=(gp, saved, x), flops=2.0 * rows * C_ * C_ * 2 * nj)
         return (gx.view(N, T, 320), None, None, None) + tuple(grads)
 
 

@@ -59,8 +59,17 @@ __device__ __forceinline__ float bf16_f(unsigned short h) { return __uint_as_flo
 
 template <int TCO, int TK>
 __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
-    const TrP& p = js.j[blockIdx.z];
-    const int tile = blockIdx.x, split = blockIdx.y;
+    // XCD-aware block order: the dispatcher places hardware block b on XCD b % 8, each XCD has its own L2, and the tiles of
+    // one (layer, split) read the same operand rows (the k tiles share gy, the co tiles share x).  In hardware order
+    // (tile fastest) the 8 tiles of a group land on 8 different XCDs and every L2 fetches its own copy through the
+    // Infinity Cache (356 MB for 89 MB of operands: the TCN launch ran at that fabric's ~3.7 TB/s).  The bijective remap
+    // gives every XCD a contiguous range of virtual ids, so a group's tiles share one L2.
+    const int nwg = gridDim.x * gridDim.y * gridDim.z;
+    const int hw = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = hw & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (hw >> 3);
+    const int tile = v % gridDim.x, split = (v / gridDim.x) % gridDim.y;
+    const TrP& p = js.j[v / (gridDim.x * gridDim.y)];
     if (tile >= p.ntiles || split >= p.splits) return;
     constexpr int PA = TCO + 8, PB = TK + 8;                    // LDS row pitches (bf16): rows stay 16-byte aligned
     constexpr int CA = TCO / 8, CB = TK / 8;                    // 16-byte chunks per row
@@ -95,14 +104,24 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
         cb[i] = id - rb[i] * CB;
         okb[i] = id < 32 * CB && c0 + cb[i] * 8 < p.Cvalid;
     }
-    // (clip, frame) of every x chunk's row, advanced by 32 rows per step instead of divided out per load
-    int xn[NB], xq[NB];
+    // Running pointers: a chunk's source address advances by a constant per 32-row step (plus a constant at a clip
+    // boundary for x), so a fetch costs an add and a select per chunk -- recomputing clip, frame and the 64-bit products
+    // per load was ~100 of the ~360 instructions of a step, and with one wave per SIMD a step is its instruction count.
+    const bf16_t* gptr[NA];
+    const bf16_t* xptr[NB];
+    int xq[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) gptr[i] = p.gy + (long long)(m_beg + ra[i]) * p.ldg + co0 + ca[i] * 8;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int m = min(m_beg + rb[i], p.M - 1);
-        xn[i] = m / p.Lq;
-        xq[i] = m - xn[i] * p.Lq;
+        const int n = m / p.Lq;
+        xq[i] = m - n * p.Lq;
+        xptr[i] = p.x + (long long)n * p.x_clip + (long long)(xq[i] * p.pos_mul + p.pos_off + tap * p.pos_tap) * p.ldx + c0 + cb[i] * 8;
     }
+    const long long g_step = 32ll * p.ldg, x_step = 32ll * p.pos_mul * p.ldx;
+    const long long x_wrap = p.x_clip - (long long)p.Lq * p.pos_mul * p.ldx;      // extra advance across a clip boundary
+    const int row_off = p.pos_off + tap * p.pos_tap;
     int next_mb = m_beg;                                         // fetches are issued for consecutive steps
     constexpr int RING = 4;                                      // register sets = steps in flight (+ the one being stored)
     u32x4 rg[RING][NA], rx[RING][NB];
@@ -113,23 +132,21 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
         unsigned vm = 0u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int m = mb + ra[i];
-            const bool v = oka[i] && m < m_end;
+            const bool v = oka[i] && mb + ra[i] < m_end;
             vm |= v ? (1u << i) : 0u;
-            rg[set][i] = *reinterpret_cast<const u32x4*>(p.gy + (v ? (long long)m * p.ldg + co0 + ca[i] * 8 : 0ll));
+            rg[set][i] = *reinterpret_cast<const u32x4*>(v ? gptr[i] : p.gy);
+            gptr[i] += g_step;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int m = mb + rb[i];
-            const int row = xq[i] * p.pos_mul + p.pos_off + tap * p.pos_tap;
-            const bool v = okb[i] && m < m_end && (unsigned)row < (unsigned)p.Lin;
+            const int row = xq[i] * p.pos_mul + row_off;
+            const bool v = okb[i] && mb + rb[i] < m_end && (unsigned)row < (unsigned)p.Lin;
             vm |= v ? (1u << (8 + i)) : 0u;
-            rx[set][i] = *reinterpret_cast<const u32x4*>(
-                p.x + (v ? (long long)xn[i] * p.x_clip + (long long)row * p.ldx + c0 + cb[i] * 8 : 0ll));
+            rx[set][i] = *reinterpret_cast<const u32x4*>(v ? xptr[i] : p.x);
             // next step: 32 rows on (plan() guarantees Lq >= 32: at most one clip boundary per step)
             const bool wrap = xq[i] + 32 >= p.Lq;
             xq[i] += wrap ? 32 - p.Lq : 32;
-            xn[i] += wrap ? 1 : 0;
+            xptr[i] += wrap ? x_step + x_wrap : x_step;
         }
         vmask[set] = vm;
         next_mb = mb + 32;
