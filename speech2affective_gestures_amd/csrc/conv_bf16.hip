@@ -88,7 +88,22 @@ __global__ __launch_bounds__(256) void conv_bf16_k(const CvP p) {
     __shared__ __attribute__((aligned(16))) bf16_t Ws[2][BN * PITCH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * BMT, n0 = blockIdx.y * BN, phase = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y, phase = blockIdx.z;
+    if (gridDim.z > 1) {
+        // poly-phase launches: the phases of one row block read the same gy rows and write interleaved pieces (stride *
+        // channels apart) of the same output lines.  In hardware order they are gridDim.x*gridDim.y blocks apart and on
+        // different XCDs (block b runs on XCD b % 8); remapped, every XCD owns a contiguous range of virtual ids with the
+        // phase running fastest, so a row block's phases run back to back behind one L2
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int hw = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = hw & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (hw >> 3);
+        phase = v % gridDim.z;
+        const int t = v / gridDim.z;
+        by = t % gridDim.y;
+        bx = t / gridDim.y;
+    }
+    const int m0 = bx * BMT, n0 = by * BN;
     const bf16_t* wbase = p.w + (long long)phase * p.w_phase;
 
     // loader: rows lr (+ 64) of the activation tile, 16-byte chunk lc; row lr (< BN) of the weight tile
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_bf16_k(const CvP p) {
     }
     if (p.stats) {
         // one partial row per wave: the 16 lanes that share (lane >> 4) hold 16 different rows of the same 4 channels
-        const size_t R = (size_t)gridDim.x * 4, r = (size_t)blockIdx.x * 4 + wave;
+        const size_t R = (size_t)gridDim.x * 4, r = (size_t)bx * 4 + wave;
 #pragma unroll
         for (int ti = 0; ti < TN; ++ti)
 #pragma unroll
