@@ -416,7 +416,7 @@ def timed_steps(pr, dp, batch, steps, warmup, sync):
     return dp.max_over_ranks(time.perf_counter() - t0, pr.device)
 
 
-def alt_modes(pr, dp, batch, B, steps=10):
+def alt_modes(pr, dp, batch, B, steps=20):
     """The same step with the large matrix products formed differently (same process, graphs re-captured): 3 bf16
     pieces = fp32-equivalent products, 0 = the f32 MFMA everywhere.  The headline `value` is the default (2 pieces)."""
     from speech2affective_gestures_amd import _lib as L

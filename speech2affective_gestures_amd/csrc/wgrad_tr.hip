@@ -53,6 +53,7 @@ struct TrP {
 
 struct TrJobs {
     TrP j[S2AG_BF16_MAX_WGRAD_JOBS];
+    int xcd_remap;
 };
 
 __device__ __forceinline__ float bf16_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
     const int nwg = gridDim.x * gridDim.y * gridDim.z;
     const int hw = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const int xcd = hw & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (hw >> 3);
+    const int v = js.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (hw >> 3) : hw;
     const int tile = v % gridDim.x, split = (v / gridDim.x) % gridDim.y;
     const TrP& p = js.j[v / (gridDim.x * gridDim.y)];
     if (tile >= p.ntiles || split >= p.splits) return;
@@ -374,6 +375,8 @@ extern "C" int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njo
     const int TCO = big ? 160 : 64, TK = big ? 160 : 64;
     const int target = target_blocks() > 0 ? target_blocks() : (big ? 256 : 1024);
     TrJobs js{};
+    static const int remap = [] { const char* e = getenv("S2AG_WGRAD_TR_XCD"); return e ? atoi(e) : 1; }();
+    js.xcd_remap = remap;
     long long off = 0, max_red = 0;
     int mt = 0, ms = 0;
     for (int k = 0; k < njobs; ++k) {
