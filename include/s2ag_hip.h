@@ -178,6 +178,23 @@ int s2ag_bn_fold(double* partials /*consumed: large sets are pre-folded in place
                  int nchan, const float* gamma, const float* beta, float* running_mean, float* running_var,
                  long long* num_batches_tracked /*nullable*/, float eps, float momentum, int repeat, float* scale_col,
                  float* shift_col, float* mean_col, float* invstd_col, void* stream);
+/* ONE-launch BatchNorm (training): statistics, fold, coefficients AND the apply (forward: y = leaky(x*scale + shift);
+ * backward: dx) in the same kernel -- the workgroups wait for the one that folds and then process the rows they have
+ * just read.  replaces the same nn.BatchNorm1d/2d (+ LeakyReLU) call sites as s2ag_bn_fwd_stats + s2ag_bn_apply /
+ * s2ag_bn_bwd_stats + s2ag_bn_bwd_apply (net/multimodal_context_net_v2.py:20-26,41-47,103-148, net/utils/tgcn.py:185-204)
+ * for tensors of up to 4 Mi elements (s2ag_bn_fused_supported); `bar` = 3 ints, zero once, left zero; partials sized by
+ * s2ag_bn_fused_partial_rows.  A wait that times out ORs 4 into the word registered with s2ag_bn_set_error_flag. */
+int s2ag_bn_fused_supported(int rows, int cols);
+int s2ag_bn_fused_partial_rows(int rows, int cols, int ld);
+int s2ag_bn_set_error_flag(int* flag /*device, nullable*/);
+int s2ag_bn_fwd_fused(const float* x, int rows, int cols, int ldx, const int* chan_of_col, int nchan, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var, long long* nbt, float eps, float momentum,
+                      int repeat, double* partials, int* bar, float* scale_col, float* shift_col, float* mean_col,
+                      float* invstd_col, float slope, float* y, int ldy, void* stream);
+int s2ag_bn_bwd_fused(const float* x, const float* dy, int rows, int cols, int ldx, int lddy, const float* scale_col,
+                      const float* shift_col, const float* mean_col, const float* invstd_col, float slope,
+                      const int* chan_of_col, int nchan, float* dgamma, float* dbeta, int accumulate, float* partials,
+                      int* bar, float* c1_col, float* c2_col, float* dx, int lddx, void* stream);
 /* y = leaky(x*scale_col + shift_col, slope) */
 int s2ag_bn_apply(const float* x, int rows, int cols, int ldx, const float* scale_col, const float* shift_col,
                   float slope, float* y, int ldy, void* stream);

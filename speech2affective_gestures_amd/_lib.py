@@ -86,6 +86,11 @@ SIGNATURES = {
     's2ag_conv1d_nlc_fwd_stats': [vp, vp, vp, vp, PG, PE, vp, vp, vp],
     's2ag_bn_fold': [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp],
     's2ag_bn_apply': [vp, ci, ci, ci, vp, vp, cf, vp, ci, vp],
+    's2ag_bn_fused_supported': [ci, ci],
+    's2ag_bn_fused_partial_rows': [ci, ci, ci],
+    's2ag_bn_set_error_flag': [vp],
+    's2ag_bn_fwd_fused': [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp, vp, cf, vp, ci, vp],
+    's2ag_bn_bwd_fused': [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp],
     's2ag_bn_bwd_reduce': [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp],
     's2ag_bn_bwd_coeffs': [vp, vp, vp, ci, ci, ci, vp, vp, ci, vp, vp, vp],
     's2ag_bn_bwd_apply': [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, ci, vp],

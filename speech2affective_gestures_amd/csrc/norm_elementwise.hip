@@ -39,6 +39,59 @@ __device__ __forceinline__ bool last_block_done(int* ticket, int nblocks) {
     return is_last != 0;
 }
 
+// ---- grid-wide wait for the ONE-launch BatchNorm (statistics + apply in the same kernel) ----------------------------------
+// w[0] counts arrivals, w[1] is the "coefficients are published" flag, w[2] counts workgroups that have passed the wait.
+// The last arriver folds the partial sums, publishes the coefficients (write-through) and raises the flag; every other
+// workgroup polls the flag with agent-scope loads, then applies the coefficients to the rows it has just read (L2-hot).
+// The workgroup that passes last re-arms all three words, so the next launch on them (stream ordered) needs no clear.
+// Co-residency: the waiters occupy their CUs until the last workgroup has ARRIVED, so the launch must fit on the chip
+// beside whatever else runs -- the host caps these launches at 64 workgroups of 1 024 threads (1 024 of the chip's 8 192
+// wave slots; a few such launches on forked streams cannot starve each other) and takes the two-launch path for bigger
+// tensors.  The poll is bounded: on a time-out the kernel goes on (wrong values) and ORs 4 into the sticky error word the
+// trainer reads back every step (ops.check_coop_flag), exactly like the cooperative GRU's exchange.
+__device__ int* g_bn_err = nullptr;
+constexpr int BN_SPIN_LIMIT = 4000000;
+
+__device__ __forceinline__ bool bar_arrive(int* w, int nblocks) {
+    __shared__ int is_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == nblocks - 1);
+    }
+    __syncthreads();
+    return is_last != 0;
+}
+__device__ __forceinline__ void bar_release(int* w) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through coefficient stores are out
+    __syncthreads();                                             // ... and every other wave's
+    if (threadIdx.x == 0) __hip_atomic_store(w + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void bar_wait(int* w) {
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > BN_SPIN_LIMIT) {
+                if (g_bn_err) atomicOr(g_bn_err, 4);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void bar_leave(int* w, int nblocks) {
+    if (threadIdx.x == 0) {
+        const int e = __hip_atomic_fetch_add(w + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e == nblocks - 1) {
+            __hip_atomic_store(w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(w + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(w + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // Per-column totals from the (2, nrb, cols) partial sums, folded straight into per-channel LDS accumulators.
 // NT threads: G = NT/cols groups share the partial rows of a column, one thread per column if cols >= NT.
 template <typename T, typename A>
@@ -128,10 +181,10 @@ __device__ __forceinline__ void bn_finish_coeffs(double* cs, double* cq, const d
         const int ch = chan_of_col ? chan_of_col[c] : c;
         const float mean = (float)cs[ch], invstd = (float)cq[ch];
         const float sc = gamma[ch] * invstd;
-        scale_col[c] = sc;
-        shift_col[c] = beta[ch] - mean * sc;
-        mean_col[c] = mean;
-        invstd_col[c] = invstd;
+        st_agent(scale_col + c, sc);                            // write-through: the one-launch form reads them in this kernel
+        st_agent(shift_col + c, beta[ch] - mean * sc);
+        st_agent(mean_col + c, mean);
+        st_agent(invstd_col + c, invstd);
     }
 }
 
@@ -171,7 +224,8 @@ __global__ __launch_bounds__(NT) void bn_fwd_stats_k(const float* __restrict__ x
                                                       const float* gamma, const float* beta, float* rmean,
                                                       float* rvar, long long* nbt, float eps, float momentum,
                                                       float* scale_col, float* shift_col, float* mean_col,
-                                                      float* invstd_col, int repeat) {
+                                                      float* invstd_col, int repeat,
+                                                      float* __restrict__ y, int ldy, float act_slope, int* bar) {
     extern __shared__ double smd[];           // 3 * nchan doubles (finalising block)
     constexpr int RL = NT / 64;               // row lanes of the column-per-lane walk
     __shared__ double s1[RL][64], s2[RL][64];
@@ -206,7 +260,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_stats_k(const float* __restrict__ x
         const int rend = min(rows, rbeg + rpb);
         double a = 0.0, b = 0.0;
         if (c < cols) {
-#pragma unroll 4
+#pragma unroll 8
             for (int r = rbeg + ry; r < rend; r += RL) {
                 const double v = (double)x[(long long)r * ldx + c];
                 a += v;
@@ -228,16 +282,41 @@ __global__ __launch_bounds__(NT) void bn_fwd_stats_k(const float* __restrict__ x
             st_agent(part + (size_t)(nrb + blockIdx.y) * cols + c, q);
         }
     }
-    if (!last_block_done(ticket, gridDim.x * gridDim.y)) return;
-    double* cs = smd;
-    double* cq = smd + nchan;
-    double* cn = smd + 2 * nchan;
-    for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) smd[i] = 0.0;
-    __syncthreads();
-    fold_partials<double, double, NT>(part, nrb, cols, chan_of_col, cs, cq, cn);
-    __syncthreads();
-    bn_finish_coeffs(cs, cq, cn, chan_of_col, cols, nchan, rows, gamma, beta, rmean, rvar, nbt, eps, momentum, 1,
-                     scale_col, shift_col, mean_col, invstd_col, repeat);
+    const int nblocks = gridDim.x * gridDim.y;
+    const bool last = bar ? bar_arrive(bar, nblocks) : last_block_done(ticket, nblocks);
+    if (last) {
+        double* cs = smd;
+        double* cq = smd + nchan;
+        double* cn = smd + 2 * nchan;
+        for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) smd[i] = 0.0;
+        __syncthreads();
+        fold_partials<double, double, NT>(part, nrb, cols, chan_of_col, cs, cq, cn);
+        __syncthreads();
+        bn_finish_coeffs(cs, cq, cn, chan_of_col, cols, nchan, rows, gamma, beta, rmean, rvar, nbt, eps, momentum, 1,
+                         scale_col, shift_col, mean_col, invstd_col, repeat);
+        if (bar) bar_release(bar);
+    }
+    if (!bar) return;
+    if (!last) bar_wait(bar);
+    bar_leave(bar, nblocks);
+    // apply to the rows this workgroup has just read
+    if (FLAT) {
+        const long long total = (long long)rows * cols;
+        const int c = threadIdx.x % cols;
+        const float sc = ld_agent(scale_col + c), sh = ld_agent(shift_col + c);
+        for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long long)nrb * 256)
+            y[i] = leaky(x[i] * sc + sh, act_slope);
+    } else {
+        const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+        const int ry = threadIdx.x >> 6;
+        const int rbeg = blockIdx.y * rpb;
+        const int rend = min(rows, rbeg + rpb);
+        if (c < cols) {
+            const float sc = ld_agent(scale_col + c), sh = ld_agent(shift_col + c);
+#pragma unroll 8
+            for (int r = rbeg + ry; r < rend; r += RL) y[(long long)r * ldy + c] = leaky(x[(long long)r * ldx + c] * sc + sh, act_slope);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, int rows, int cols, int ldx,
@@ -327,8 +406,8 @@ __device__ __forceinline__ void bn_bwd_finish(const float* t1, const float* t2, 
     for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
         const int ch = chan_of_col ? chan_of_col[c] : c;
         const float n = cn[ch] * (float)rows;
-        c1[c] = t1[ch] / n;
-        c2[c] = t2[ch] / n;
+        st_agent(c1 + c, t1[ch] / n);
+        st_agent(c2 + c, t2[ch] / n);
     }
 }
 
@@ -426,7 +505,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_k(const float* __restrict__ x
                                                       const float* scale, const float* shift, const float* mean,
                                                       const float* invstd, float slope, float* part, int* ticket,
                                                       const int* chan_of_col, int nchan, float* dgamma, float* dbeta,
-                                                      int accumulate, float* c1, float* c2) {
+                                                      int accumulate, float* c1, float* c2, float* __restrict__ dx,
+                                                      int lddx, int* bar) {
     extern __shared__ float sm[];            // 3 * nchan floats (finalising block)
     constexpr int RL = NT / 64;
     __shared__ float a1[RL][64], a2[RL][64];
@@ -465,7 +545,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_k(const float* __restrict__ x
         float p = 0.f, q = 0.f;
         if (c < cols) {
             const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-#pragma unroll 4
+#pragma unroll 8
             for (int r = rbeg + ry; r < rend; r += RL) {
                 const float xv = x[(long long)r * ldx + c];
                 const float pre = xv * sc + sh;
@@ -489,15 +569,49 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_k(const float* __restrict__ x
             st_agent(part + (size_t)(nrb + blockIdx.y) * cols + c, v);
         }
     }
-    if (!last_block_done(ticket, gridDim.x * gridDim.y)) return;
-    float* t1 = sm;
-    float* t2 = sm + nchan;
-    float* cn = sm + 2 * nchan;
-    for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) sm[i] = 0.f;
-    __syncthreads();
-    fold_partials<float, float, NT>(part, nrb, cols, chan_of_col, t1, t2, cn);
-    __syncthreads();
-    bn_bwd_finish(t1, t2, cn, chan_of_col, cols, nchan, rows, dgamma, dbeta, accumulate, c1, c2);
+    const int nblocks = gridDim.x * gridDim.y;
+    const bool last = bar ? bar_arrive(bar, nblocks) : last_block_done(ticket, nblocks);
+    if (last) {
+        float* t1 = sm;
+        float* t2 = sm + nchan;
+        float* cn = sm + 2 * nchan;
+        for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) sm[i] = 0.f;
+        __syncthreads();
+        fold_partials<float, float, NT>(part, nrb, cols, chan_of_col, t1, t2, cn);
+        __syncthreads();
+        bn_bwd_finish(t1, t2, cn, chan_of_col, cols, nchan, rows, dgamma, dbeta, accumulate, c1, c2);
+        if (bar) bar_release(bar);
+    }
+    if (!bar) return;
+    if (!last) bar_wait(bar);
+    bar_leave(bar, nblocks);
+    // dx = scale * (d - c1 - xhat * c2) for the rows this workgroup has just read
+    if (FLAT) {
+        const long long total = (long long)rows * cols;
+        const int c = threadIdx.x % cols;
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        const float k1 = ld_agent(c1 + c), k2 = ld_agent(c2 + c);
+        for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long long)nrb * 256) {
+            const float xv = x[i];
+            const float d = dy[i] * (xv * sc + sh > 0.f ? 1.f : slope);
+            dx[i] = sc * (d - k1 - (xv - mu) * is * k2);
+        }
+    } else {
+        const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+        const int ry = threadIdx.x >> 6;
+        const int rbeg = blockIdx.y * rpb;
+        const int rend = min(rows, rbeg + rpb);
+        if (c < cols) {
+            const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+            const float k1 = ld_agent(c1 + c), k2 = ld_agent(c2 + c);
+#pragma unroll 8
+            for (int r = rbeg + ry; r < rend; r += RL) {
+                const float xv = x[(long long)r * ldx + c];
+                const float d = dy[(long long)r * lddy + c] * (xv * sc + sh > 0.f ? 1.f : slope);
+                dx[(long long)r * lddx + c] = sc * (d - k1 - (xv - mu) * is * k2);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ x, const float* __restrict__ dy,
@@ -585,7 +699,7 @@ extern "C" int s2ag_bn_coeffs(const double* colsum, const double* colsq, const i
 static inline bool bn_flat(int cols, int ldx, int lddy) {
     return ldx == cols && lddy == cols && cols <= 32 && (cols & (cols - 1)) == 0;
 }
-static inline void bn_plan(int rows, int cols, bool flat, int* colblocks, int* nrb, int* rpb) {
+static inline void bn_plan(int rows, int cols, bool flat, int* colblocks, int* nrb, int* rpb, int max_blocks = 0) {
     // The finalising block reads 2 * nrb * cols partial sums with 256 threads: cap that at ~128 loads per thread
     // (4 batches of 32 in flight), i.e. nrb <= 16384 / cols -- which still gives ~256 workgroups at every width.
     int cap = 16384 / cols;
@@ -593,6 +707,7 @@ static inline void bn_plan(int rows, int cols, bool flat, int* colblocks, int* n
     if (flat) {
         long long nb = ((long long)rows * cols + 256 * 16 - 1) / (256 * 16);
         *colblocks = 1;
+        if (max_blocks > 0 && cap > 4 * max_blocks) cap = 4 * max_blocks;      // 256-thread workgroups: 4 per 1024 threads
         *nrb = (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
         *rpb = 0;
         return;
@@ -600,6 +715,7 @@ static inline void bn_plan(int rows, int cols, bool flat, int* colblocks, int* n
     *colblocks = cdiv(cols, 64);
     int r = 64;      // 1024 threads = 16 row lanes per block: 4+ rows per lane, more while that still leaves ~256 blocks
     while (cdiv(rows, r) > cap || (long long)cdiv(rows, 2 * r) * *colblocks >= 256) r *= 2;
+    while (max_blocks > 0 && (long long)cdiv(rows, r) * *colblocks > max_blocks) r *= 2;
     *rpb = r;
     *nrb = cdiv(rows, r);
 }
@@ -628,11 +744,82 @@ extern "C" int s2ag_bn_fwd_stats(const float* x, int rows, int cols, int ldx, co
     if (flat)
         hipLaunchKernelGGL((bn_fwd_stats_k<true, 256>), dim3(cb, nrb), dim3(256), smem, (hipStream_t)stream, x, rows, cols, ldx,
                            rpb, partials, ticket, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt, eps,
-                           momentum, scale_col, shift_col, mean_col, invstd_col, repeat);
+                           momentum, scale_col, shift_col, mean_col, invstd_col, repeat, nullptr, 0, 1.f, nullptr);
     else
         hipLaunchKernelGGL((bn_fwd_stats_k<false, 1024>), dim3(cb, nrb), dim3(1024), smem, (hipStream_t)stream, x, rows, cols,
                            ldx, rpb, partials, ticket, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt,
-                           eps, momentum, scale_col, shift_col, mean_col, invstd_col, repeat);
+                           eps, momentum, scale_col, shift_col, mean_col, invstd_col, repeat, nullptr, 0, 1.f, nullptr);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- one-launch forms (statistics + apply; see bar_arrive) ---------------------------------------------------------------
+constexpr int BN_FUSED_MAX_BLOCKS = 64;                 // workgroups of 1024 threads (4x as many of 256 in the flat form)
+constexpr long long BN_FUSED_MAX_ELEMS = 4ll << 20;     // bigger tensors keep the two-launch path (full grids)
+
+extern "C" int s2ag_bn_set_error_flag(int* flag) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bn_err), &flag, sizeof(flag));
+}
+
+extern "C" int s2ag_bn_fused_supported(int rows, int cols) {
+    return rows > 0 && cols > 0 && (long long)rows * cols <= BN_FUSED_MAX_ELEMS;
+}
+
+extern "C" int s2ag_bn_fused_partial_rows(int rows, int cols, int ld) {
+    if (rows <= 0 || cols <= 0 || ld < cols) return S2AG_E_BADARG;
+    int cb, nrb, rpb, cb2, nrb2, rpb2;
+    bn_plan(rows, cols, bn_flat(cols, ld, ld), &cb, &nrb, &rpb, BN_FUSED_MAX_BLOCKS);
+    bn_plan(rows, cols, false, &cb2, &nrb2, &rpb2, BN_FUSED_MAX_BLOCKS);
+    return nrb > nrb2 ? nrb : nrb2;
+}
+
+extern "C" int s2ag_bn_fwd_fused(const float* x, int rows, int cols, int ldx, const int* chan_of_col, int nchan,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 long long* nbt, float eps, float momentum, int repeat, double* partials, int* bar,
+                                 float* scale_col, float* shift_col, float* mean_col, float* invstd_col, float slope,
+                                 float* y, int ldy, void* stream) {
+    if (repeat < 1) return S2AG_E_BADARG;
+    if (!x || !y || rows <= 0 || cols <= 0 || ldx < cols || ldy < cols || nchan <= 0 || !gamma || !beta || !running_mean ||
+        !running_var || !partials || !bar || !scale_col || !shift_col || !mean_col || !invstd_col)
+        return S2AG_E_BADARG;
+    if (!s2ag_bn_fused_supported(rows, cols)) return S2AG_E_UNSUPPORTED;
+    const bool flat = bn_flat(cols, ldx, ldy);
+    int cb, nrb, rpb;
+    bn_plan(rows, cols, flat, &cb, &nrb, &rpb, BN_FUSED_MAX_BLOCKS);
+    const size_t smem = sizeof(double) * 3 * nchan;
+    if (flat)
+        hipLaunchKernelGGL((bn_fwd_stats_k<true, 256>), dim3(cb, nrb), dim3(256), smem, (hipStream_t)stream, x, rows, cols, ldx,
+                           rpb, partials, nullptr, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt, eps,
+                           momentum, scale_col, shift_col, mean_col, invstd_col, repeat, y, ldy, slope, bar);
+    else
+        hipLaunchKernelGGL((bn_fwd_stats_k<false, 1024>), dim3(cb, nrb), dim3(1024), smem, (hipStream_t)stream, x, rows, cols,
+                           ldx, rpb, partials, nullptr, chan_of_col, nchan, gamma, beta, running_mean, running_var, nbt,
+                           eps, momentum, scale_col, shift_col, mean_col, invstd_col, repeat, y, ldy, slope, bar);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_bn_bwd_fused(const float* x, const float* dy, int rows, int cols, int ldx, int lddy,
+                                 const float* scale_col, const float* shift_col, const float* mean_col,
+                                 const float* invstd_col, float slope, const int* chan_of_col, int nchan, float* dgamma,
+                                 float* dbeta, int accumulate, float* partials, int* bar, float* c1_col, float* c2_col,
+                                 float* dx, int lddx, void* stream) {
+    if (!x || !dy || !dx || rows <= 0 || cols <= 0 || ldx < cols || lddy < cols || lddx < cols || nchan <= 0 || !dgamma ||
+        !dbeta || !partials || !bar || !c1_col || !c2_col)
+        return S2AG_E_BADARG;
+    if (!s2ag_bn_fused_supported(rows, cols)) return S2AG_E_UNSUPPORTED;
+    const bool flat = bn_flat(cols, ldx, lddy) && lddx == cols;
+    int cb, nrb, rpb;
+    bn_plan(rows, cols, flat, &cb, &nrb, &rpb, BN_FUSED_MAX_BLOCKS);
+    const size_t smem = sizeof(float) * 3 * nchan;
+    if (flat)
+        hipLaunchKernelGGL((bn_bwd_stats_k<true, 256>), dim3(cb, nrb), dim3(256), smem, (hipStream_t)stream, x, dy, rows, cols,
+                           ldx, lddy, rpb, scale_col, shift_col, mean_col, invstd_col, slope, partials, nullptr,
+                           chan_of_col, nchan, dgamma, dbeta, accumulate, c1_col, c2_col, dx, lddx, bar);
+    else
+        hipLaunchKernelGGL((bn_bwd_stats_k<false, 1024>), dim3(cb, nrb), dim3(1024), smem, (hipStream_t)stream, x, dy, rows, cols,
+                           ldx, lddy, rpb, scale_col, shift_col, mean_col, invstd_col, slope, partials, nullptr,
+                           chan_of_col, nchan, dgamma, dbeta, accumulate, c1_col, c2_col, dx, lddx, bar);
     S2AG_LAUNCH_CHECK();
     return 0;
 }
@@ -673,11 +860,11 @@ extern "C" int s2ag_bn_bwd_stats(const float* x, const float* dy, int rows, int 
     if (flat)
         hipLaunchKernelGGL((bn_bwd_stats_k<true, 256>), dim3(cb, nrb), dim3(256), smem, (hipStream_t)stream, x, dy, rows, cols,
                            ldx, lddy, rpb, scale_col, shift_col, mean_col, invstd_col, slope, partials, ticket,
-                           chan_of_col, nchan, dgamma, dbeta, accumulate, c1_col, c2_col);
+                           chan_of_col, nchan, dgamma, dbeta, accumulate, c1_col, c2_col, nullptr, 0, nullptr);
     else
         hipLaunchKernelGGL((bn_bwd_stats_k<false, 1024>), dim3(cb, nrb), dim3(1024), smem, (hipStream_t)stream, x, dy, rows, cols,
                            ldx, lddy, rpb, scale_col, shift_col, mean_col, invstd_col, slope, partials, ticket,
-                           chan_of_col, nchan, dgamma, dbeta, accumulate, c1_col, c2_col);
+                           chan_of_col, nchan, dgamma, dbeta, accumulate, c1_col, c2_col, nullptr, 0, nullptr);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

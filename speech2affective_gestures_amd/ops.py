@@ -275,6 +275,7 @@ def normal_noise(noise: Tensor, site: int, shape: Sequence[int]) -> Tensor:
 _TICKETS = {}
 _TICKET_POOL = 1 << 15
 _COOP_FLAG = {}
+_BARRIERS = {}
 
 
 class CoopGruTimeout(RuntimeError):
@@ -295,6 +296,9 @@ def check_coop_flag(host_value) -> None:
     """Raise if a read-back of coop_error_flag() is non-zero (any bit pattern but +0.0)."""
     import struct
     bits = struct.unpack('<I', struct.pack('<f', float(host_value)))[0]
+    if bits & 4:
+        raise CoopGruTimeout('a one-launch BatchNorm kernel timed out waiting for its folding workgroup (its workgroups '
+                             'were not co-resident): results since the last check are invalid. Set S2AG_BN_FUSED=0')
     if bits & 2:
         raise RuntimeError('touched-row exchange: a batch held more distinct word ids than the row capacity the trainer '
                            'was built with (args.max_words_per_clip too small): the embedding gradient was truncated')
@@ -318,6 +322,19 @@ def init_tickets(device) -> None:
         # read-back and raises: a recurrence that lost a peer continues with wrong values)
         _COOP_FLAG[key] = torch.zeros(1, dtype=torch.int32, device=dev)
         L.check(_lib().s2ag_gru_coop_set_error_flag(_p(_COOP_FLAG[key])), 'gru_coop_set_error_flag')
+        L.check(_lib().s2ag_bn_set_error_flag(_p(_COOP_FLAG[key])), 'bn_set_error_flag')     # bit 4: one-launch BatchNorm
+        _BARRIERS[key] = [torch.zeros(3 * _TICKET_POOL, dtype=torch.int32, device=dev), 0]
+
+
+def _barrier(dev):
+    """Next triple of barrier words of the one-launch BatchNorm kernels (round robin like _ticket)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _BARRIERS:
+        init_tickets(dev)
+    ent = _BARRIERS[key]
+    i = ent[1]
+    ent[1] = (i + 1) % _TICKET_POOL
+    return C.c_void_p(ent[0].data_ptr() + 12 * i)
 
 
 def _ticket(dev):
@@ -573,6 +590,13 @@ def generation() -> int:
     return _GENERATION[0]
 
 
+# One-launch BatchNorm (statistics + apply with a grid-wide wait, norm_elementwise.hip).  Measured on the step
+# (profiles/r02_bn_one_launch.txt): -69 launches per step, kernel time = the sum of the two kernels it replaces, step time
+# unchanged (14 620 / 14 820 vs 14 690 / 14 740 clips/s) -- so it stays an option; the default keeps the two launches,
+# whose workgroups never wait for each other.
+BN_FUSED = __import__('os').environ.get('S2AG_BN_FUSED', '0') == '1'
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, nbt, chan_map, slope, training, eps, momentum):
@@ -590,6 +614,19 @@ class _BNAct(torch.autograd.Function):
             L.check(lib.s2ag_bn_fold(_p(part), int(prow), rows, cols, _p(chan_map), nchan, _p(gamma), _p(beta), _p(rmean),
                                      _p(rvar), _p(nbt), float(eps), float(momentum), int(_BN_REPEAT[0]), _p(coef[0]),
                                      _p(coef[1]), _p(coef[2]), _p(coef[3]), _stream()), 'bn_fold')
+        elif training and BN_FUSED and lib.s2ag_bn_fused_supported(rows, cols):
+            # ONE launch for statistics, fold, coefficients and the apply (grid-wide wait inside the kernel)
+            nrb = lib.s2ag_bn_fused_partial_rows(rows, cols, max(ldx, cols))
+            part = torch.empty(2 * nrb * cols, dtype=torch.float64, device=dev)
+            y = torch.empty(rows, cols, dtype=torch.float32, device=dev)
+            L.check(lib.s2ag_bn_fwd_fused(_p(x), rows, cols, ldx, _p(chan_map), nchan, _p(gamma), _p(beta), _p(rmean),
+                                          _p(rvar), _p(nbt), float(eps), float(momentum), int(_BN_REPEAT[0]), _p(part),
+                                          _barrier(dev), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), float(slope),
+                                          _p(y), cols, _stream()), 'bn_fwd_fused')
+            ctx.save_for_backward(x, coef, chan_map)
+            ctx.meta = (rows, cols, ldx, nchan, float(slope), bool(training))
+            ctx.leaves = (gamma, beta)
+            return y
         elif training:
             # one launch: fp64 partial column sums per row block, folded into coefficients by the last block
             nrb = lib.s2ag_bn_partial_rows(rows, cols, ldx)
@@ -630,6 +667,12 @@ class _BNAct(torch.autograd.Function):
                 dgb = torch.empty(2, nchan, dtype=torch.float32, device=dev)
                 sg, sb = dgb[0], dgb[1]
                 dgamma, dbeta = dgb[0], dgb[1]
+            if BN_FUSED and lib.s2ag_bn_fused_supported(rows, cols):
+                L.check(lib.s2ag_bn_bwd_fused(_p(x), _p(dy), rows, cols, ldx, lddy, _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                              _p(coef[3]), slope, _p(chan_map), nchan, _p(sg), _p(sb), int(direct),
+                                              _p(part), _barrier(dev), _p(tmp[0]), _p(tmp[1]), _p(dx), cols, _stream()),
+                        'bn_bwd_fused')
+                return dx.view(ctx.in_shape), dgamma, dbeta, None, None, None, None, None, None, None, None
             L.check(lib.s2ag_bn_bwd_stats(_p(x), _p(dy), rows, cols, ldx, lddy, _p(coef[0]), _p(coef[1]), _p(coef[2]),
                                           _p(coef[3]), slope, _p(chan_map), nchan, _p(sg), _p(sb), int(direct),
                                           _p(part), _ticket(dev), _p(tmp[0]), _p(tmp[1]), _stream()), 'bn_bwd_stats')

@@ -369,12 +369,16 @@ def test_batch_norm_narrow_matrix_lane_dense_path(S):
     assert rel(bn_g.bias.grad, bn_r.bias.grad) < TOL
 
 
+@pytest.mark.parametrize('one_launch', [False, True])
 @pytest.mark.parametrize('rows,cols,strided', [(4352, 900, False), (70000, 64, False), (300000, 8, False),
                                                (4352, 96, True), (33, 257, False), (1, 5, False)])
-def test_batch_norm_fused_statistics_shapes_and_ticket_rearm(S, rows, cols, strided):
+def test_batch_norm_fused_statistics_shapes_and_ticket_rearm(S, rows, cols, strided, one_launch, monkeypatch):
     """The one-launch statistics kernels (row-block partial sums, last block folds them): wide / tall / narrow / strided
-    matrices, launched repeatedly on the same ticket words (each launch must leave its ticket at zero)."""
+    matrices, launched repeatedly on the same ticket words (each launch must leave its ticket at zero).  ``one_launch``:
+    the form that also applies the coefficients in the same kernel behind a grid-wide wait (ops.BN_FUSED; its barrier words
+    must be left zero too, and the sticky error word must stay clear)."""
     ops = S['ops']
+    monkeypatch.setattr(ops, 'BN_FUSED', one_launch)
     g = torch.Generator().manual_seed(rows + cols)
     x = torch.randn(rows, cols, generator=g) * 1.7 + 0.4
     bn_r, bn_g = torch.nn.BatchNorm1d(cols), torch.nn.BatchNorm1d(cols).cuda()
@@ -405,6 +409,8 @@ def test_batch_norm_fused_statistics_shapes_and_ticket_rearm(S, rows, cols, stri
         assert rel(bn_g.weight.grad, bn_r.weight.grad) < 2 * TOL and rel(bn_g.bias.grad, bn_r.bias.grad) < 2 * TOL
     pool = ops._TICKETS[torch.cuda.current_device()][0]
     assert int(pool.abs().sum()) == 0
+    assert int(ops._BARRIERS[torch.cuda.current_device()][0].abs().sum()) == 0
+    assert int(ops._COOP_FLAG[torch.cuda.current_device()].item()) == 0
 
 
 def test_batch_norm_channel_map_is_batchnorm2d(S):
