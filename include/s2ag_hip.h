@@ -502,6 +502,15 @@ int s2ag_bf16_conv_wgrad_multi(const s2ag_bf16_wgrad_args* jobs /*host*/, int nj
 long long s2ag_bf16_conv_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs);
 int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs, float* scratch, long long scratch_floats,
                             void* stream);
+/* The same kernel shape for fp32 operands (gy, x: fp32 rows, pitches / Cvalid multiples of 4 floats): every value is
+ * split by the loader into two bf16 pieces, a tile pair costs three MFMAs (16 mantissa bits per product, fp32
+ * accumulation).  replaces: the weight gradients of nn.GRU in the fp32 step -- dW_ih = dgi^T x and dW_hh = dgh^T h_prev
+ * (x = y shifted by one frame: pos_off = -1 / +1), net/multimodal_context_net_v2.py:281,406,480 -- up to 8 per call. */
+/* diagnostics (tools/bench_wgrad_tr32.py): 256 x u64 device buffer for s_memtime stamps of block 0; NULL = off */
+int s2ag_wgrad_tr_set_trace(void* buf);
+long long s2ag_f32_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs);
+int s2ag_f32_wgrad_tr(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs, float* scratch, long long scratch_floats,
+                      void* stream);
 
 /* Measurement aid (tools/pmc_traffic.py): touches `bytes` of `buf` with a known access pattern so the rocprofv3 counters
  * FETCH_SIZE / WRITE_SIZE can be calibrated against a known byte count in OUR access shapes: 0 = 16 B/lane coalesced

@@ -153,6 +153,9 @@ SIGNATURES = {
     's2ag_bf16_conv_wgrad_multi': [vp, ci, vp],
     's2ag_bf16_conv_wgrad_tr_scratch_floats': [vp, ci],
     's2ag_bf16_conv_wgrad_tr': [vp, ci, vp, cll, vp],
+    's2ag_f32_wgrad_tr_scratch_floats': [vp, ci],
+    's2ag_f32_wgrad_tr': [vp, ci, vp, cll, vp],
+    's2ag_wgrad_tr_set_trace': [vp],
     's2ag_rows_unique': [vp, ci, ci, ci, vp, vp, vp, vp, vp],
     's2ag_rows_pack': [vp, vp, ci, ci, ci, vp, vp],
     's2ag_rows_merge': [vp, ci, ci, ci, ci, vp, vp],
@@ -192,7 +195,8 @@ def load():
             raise S2AGLibraryError(f'{path} lacks symbol {name}; rebuild it') from e
         fn.argtypes = args
         fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes', 's2ag_bf16_tcn_keep_bytes',
-                              's2ag_bf16_conv_wgrad_scratch_floats', 's2ag_bf16_conv_wgrad_tr_scratch_floats') else ci
+                              's2ag_bf16_conv_wgrad_scratch_floats', 's2ag_bf16_conv_wgrad_tr_scratch_floats',
+                              's2ag_f32_wgrad_tr_scratch_floats') else ci
     if lib.s2ag_abi_version() != 1:
         raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
     _lib = lib

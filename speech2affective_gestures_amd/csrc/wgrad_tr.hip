@@ -33,8 +33,8 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 typedef unsigned short bf16_t;
 
 struct TrP {
-    const bf16_t* gy;
-    const bf16_t* x;
+    const void* gy;             // bf16 rows (wgrad_tr_k) or fp32 rows (wgrad_tr32_k)
+    const void* x;
     float* dw;
     float* db;                  // nullable
     int M, Lq, Lin;
@@ -53,7 +53,10 @@ struct TrP {
 
 struct TrJobs {
     TrP j[S2AG_BF16_MAX_WGRAD_JOBS];
+    int start[S2AG_BF16_MAX_WGRAD_JOBS + 1];   // first block of every job in the compact 1-D grid (tile fastest, then split)
+    int njobs;
     int xcd_remap;
+    unsigned long long* trace;                 // diagnostics (s2ag_wgrad_tr_set_trace): s_memtime stamps of block 0, thread 0
 };
 
 __device__ __forceinline__ float bf16_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
@@ -65,13 +68,15 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
     // (tile fastest) the 8 tiles of a group land on 8 different XCDs and every L2 fetches its own copy through the
     // Infinity Cache (356 MB for 89 MB of operands: the TCN launch ran at that fabric's ~3.7 TB/s).  The bijective remap
     // gives every XCD a contiguous range of virtual ids, so a group's tiles share one L2.
-    const int nwg = gridDim.x * gridDim.y * gridDim.z;
-    const int hw = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int nwg = gridDim.x;                                   // compact 1-D grid: every block has work
+    const int hw = blockIdx.x;
     const int xcd = hw & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int v = js.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (hw >> 3) : hw;
-    const int tile = v % gridDim.x, split = (v / gridDim.x) % gridDim.y;
-    const TrP& p = js.j[v / (gridDim.x * gridDim.y)];
-    if (tile >= p.ntiles || split >= p.splits) return;
+    int job = 0;
+    while (job + 1 < js.njobs && v >= js.start[job + 1]) ++job;
+    const TrP& p = js.j[job];
+    const int local = v - js.start[job];
+    const int tile = local % p.ntiles, split = local / p.ntiles;
     constexpr int PA = TCO + 8, PB = TK + 8;                    // LDS row pitches (bf16): rows stay 16-byte aligned
     constexpr int CA = TCO / 8, CB = TK / 8;                    // 16-byte chunks per row
     constexpr int NA = (32 * CA + 255) / 256, NB = (32 * CB + 255) / 256;
@@ -111,14 +116,16 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
     const bf16_t* gptr[NA];
     const bf16_t* xptr[NB];
     int xq[NB];
+    const bf16_t* gy0 = static_cast<const bf16_t*>(p.gy);
+    const bf16_t* x0 = static_cast<const bf16_t*>(p.x);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) gptr[i] = p.gy + (long long)(m_beg + ra[i]) * p.ldg + co0 + ca[i] * 8;
+    for (int i = 0; i < NA; ++i) gptr[i] = gy0 + (long long)(m_beg + ra[i]) * p.ldg + co0 + ca[i] * 8;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int m = min(m_beg + rb[i], p.M - 1);
         const int n = m / p.Lq;
         xq[i] = m - n * p.Lq;
-        xptr[i] = p.x + (long long)n * p.x_clip + (long long)(xq[i] * p.pos_mul + p.pos_off + tap * p.pos_tap) * p.ldx + c0 + cb[i] * 8;
+        xptr[i] = x0 + (long long)n * p.x_clip + (long long)(xq[i] * p.pos_mul + p.pos_off + tap * p.pos_tap) * p.ldx + c0 + cb[i] * 8;
     }
     const long long g_step = 32ll * p.ldg, x_step = 32ll * p.pos_mul * p.ldx;
     const long long x_wrap = p.x_clip - (long long)p.Lq * p.pos_mul * p.ldx;      // extra advance across a clip boundary
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
         for (int i = 0; i < NA; ++i) {
             const bool v = oka[i] && mb + ra[i] < m_end;
             vm |= v ? (1u << i) : 0u;
-            rg[set][i] = *reinterpret_cast<const u32x4*>(v ? gptr[i] : p.gy);
+            rg[set][i] = *reinterpret_cast<const u32x4*>(v ? gptr[i] : gy0);
             gptr[i] += g_step;
         }
 #pragma unroll
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
             const int row = xq[i] * p.pos_mul + row_off;
             const bool v = okb[i] && mb + rb[i] < m_end && (unsigned)row < (unsigned)p.Lin;
             vm |= v ? (1u << (8 + i)) : 0u;
-            rx[set][i] = *reinterpret_cast<const u32x4*>(v ? xptr[i] : p.x);
+            rx[set][i] = *reinterpret_cast<const u32x4*>(v ? xptr[i] : x0);
             // next step: 32 rows on (plan() guarantees Lq >= 32: at most one clip boundary per step)
             const bool wrap = xq[i] + 32 >= p.Lq;
             xq[i] += wrap ? 32 - p.Lq : 32;
@@ -254,6 +261,219 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
     }
 }
 
+// ---- fp32 operands (the GRU's weight gradients of the default, fp32 step) ----------------------------------------------
+// dW_ih / dW_hh of nn.GRU (net/multimodal_context_net_v2.py:281,406,480) are 56 GFLOP per step on the f32 MFMA
+// (wgrad_multi_k: 1.1 ms of kernel time at ~45 TFLOP/s, beside -- and slowing down -- the next layer's recurrence).
+// Same kernel shape as above, but the operand rows arrive as fp32 and every value is split by the loader into two bf16
+// pieces (hi = rn(v), lo = rn(v - hi): 16 mantissa bits, the precision of the step's other large products, bench.py
+// `matrix_products`); LDS holds a hi and a lo image per operand, the transpose read serves both, and a tile pair costs
+// three MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulation).  Row pitches / column offsets in floats, multiples of 4.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+
+template <int TCO, int TK>
+__global__ __launch_bounds__(256) void wgrad_tr32_k(const TrJobs js) {
+    const int nwg = gridDim.x;                                   // compact 1-D grid: every block has work
+    const int hw = blockIdx.x;
+    const int xcd = hw & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int v = js.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (hw >> 3) : hw;
+    int job = 0;
+    while (job + 1 < js.njobs && v >= js.start[job + 1]) ++job;
+    const TrP& p = js.j[job];
+    const int local = v - js.start[job];
+    const int tile = local % p.ntiles, split = local / p.ntiles;
+    constexpr int PA = TCO + 8, PB = TK + 8;                    // LDS row pitches (bf16)
+    constexpr int CA = TCO / 4, CB = TK / 4;                    // 16-byte (4-float) chunks per row
+    constexpr int NA = (32 * CA + 255) / 256, NB = (32 * CB + 255) / 256;
+    constexpr int WA = TCO / 32, WB = TK / 32;
+    constexpr int RING = 3;
+    __shared__ __attribute__((aligned(16))) bf16_t Gs[2][2][32 * PA];       // [buffer][hi / lo]
+    __shared__ __attribute__((aligned(16))) bf16_t Xs[2][2][32 * PB];
+    __shared__ float bsum[TCO];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int cot = tile % p.nco, kt = tile / p.nco;
+    const int tap = kt / p.kct, c0 = (kt - tap * p.kct) * TK, co0 = cot * TCO;
+    const bool do_bias = p.db != nullptr && kt == 0;
+    for (int i = tid; i < TCO; i += 256) bsum[i] = 0.f;
+    const int m_beg = split * p.m_chunk;
+    const int m_end = min(p.M, m_beg + p.m_chunk);
+    int ra[NA], ca[NA], rb[NB], cb[NB];
+    bool oka[NA], okb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int id = tid + 256 * i;
+        ra[i] = id / CA;
+        ca[i] = id - ra[i] * CA;
+        oka[i] = id < 32 * CA && co0 + ca[i] * 4 < p.Cout;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int id = tid + 256 * i;
+        rb[i] = id / CB;
+        cb[i] = id - rb[i] * CB;
+        okb[i] = id < 32 * CB && c0 + cb[i] * 4 < p.Cvalid;
+    }
+    const float* gy0 = static_cast<const float*>(p.gy);
+    const float* x0 = static_cast<const float*>(p.x);
+    const float* gptr[NA];
+    const float* xptr[NB];
+    int xq[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) gptr[i] = gy0 + (long long)(m_beg + ra[i]) * p.ldg + co0 + ca[i] * 4;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int m = min(m_beg + rb[i], p.M - 1);
+        const int n = m / p.Lq;
+        xq[i] = m - n * p.Lq;
+        xptr[i] = x0 + (long long)n * p.x_clip + (long long)(xq[i] * p.pos_mul + p.pos_off + tap * p.pos_tap) * p.ldx + c0 + cb[i] * 4;
+    }
+    const long long g_step = 32ll * p.ldg, x_step = 32ll * p.pos_mul * p.ldx;
+    const long long x_wrap = p.x_clip - (long long)p.Lq * p.pos_mul * p.ldx;
+    const int row_off = p.pos_off + tap * p.pos_tap;
+    int next_mb = m_beg;
+    f32x4 rg[RING][NA], rx[RING][NB];
+    unsigned vmask[RING];
+    auto fetch = [&](int set) {
+        const int mb = next_mb;
+        unsigned vm = 0u;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const bool ok = oka[i] && mb + ra[i] < m_end;
+            vm |= ok ? (1u << i) : 0u;
+            rg[set][i] = *reinterpret_cast<const f32x4*>(ok ? gptr[i] : gy0);
+            gptr[i] += g_step;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = xq[i] * p.pos_mul + row_off;
+            const bool ok = okb[i] && mb + rb[i] < m_end && (unsigned)row < (unsigned)p.Lin;
+            vm |= ok ? (1u << (8 + i)) : 0u;
+            rx[set][i] = *reinterpret_cast<const f32x4*>(ok ? xptr[i] : x0);
+            const bool wrap = xq[i] + 32 >= p.Lq;
+            xq[i] += wrap ? 32 - p.Lq : 32;
+            xptr[i] += wrap ? x_step + x_wrap : x_step;
+        }
+        vmask[set] = vm;
+        next_mb = mb + 32;
+    };
+    float bacc[NA][4];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bacc[i][j] = 0.f;
+    // 4 floats -> 4 hi + 4 lo bf16 (8 bytes each)
+    auto split_store = [&](bf16_t* hi_img, bf16_t* lo_img, int off, f32x4 v) {
+        const unsigned h01 = pk_bf16(v[0], v[1]), h23 = pk_bf16(v[2], v[3]);
+        const unsigned l01 = pk_bf16(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));
+        const unsigned l23 = pk_bf16(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));
+        *reinterpret_cast<uint2*>(hi_img + off) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(lo_img + off) = make_uint2(l01, l23);
+    };
+    auto stash = [&](int set, int buf) {
+        const unsigned vm = vmask[set];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (!((vm >> i) & 1u)) rg[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((32 * CA) % 256 == 0 || i + 1 < NA || tid + 256 * i < 32 * CA)
+                split_store(Gs[buf][0], Gs[buf][1], ra[i] * PA + ca[i] * 4, rg[set][i]);
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bacc[i][j] += rg[set][i][j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (!((vm >> (8 + i)) & 1u)) rx[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((32 * CB) % 256 == 0 || i + 1 < NB || tid + 256 * i < 32 * CB)
+                split_store(Xs[buf][0], Xs[buf][1], rb[i] * PB + cb[i] * 4, rx[set][i]);
+        }
+    };
+    f32x4 acc[WA][WB];
+#pragma unroll
+    for (int a = 0; a < WA; ++a)
+#pragma unroll
+        for (int b = 0; b < WB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, t = lane & 15;
+    const int tr_a = (8 * g + (t >> 2)) * PA + (t & 3) * 4 + wr * (TCO / 2);
+    const int tr_b = (8 * g + (t >> 2)) * PB + (t & 3) * 4 + wc * (TK / 2);
+    auto frag = [&](const bf16_t* img, int off, int pitch) {
+        using lds_p = __attribute__((address_space(3))) s16x4*;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + off + 4 * pitch));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto mma = [&](int buf) {
+        bf16x8 bh[WB], bl[WB];
+#pragma unroll
+        for (int b = 0; b < WB; ++b) {
+            bh[b] = frag(Xs[buf][0], tr_b + b * 16, PB);
+            bl[b] = frag(Xs[buf][1], tr_b + b * 16, PB);
+        }
+#pragma unroll
+        for (int a = 0; a < WA; ++a) {
+            const bf16x8 ah = frag(Gs[buf][0], tr_a + a * 16, PA), al = frag(Gs[buf][1], tr_a + a * 16, PA);
+            // the three piece products of a tile are five MFMAs apart: back to back they wait for each other's result
+#pragma unroll
+            for (int b = 0; b < WB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < WB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < WB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[b], acc[a][b], 0, 0, 0);
+        }
+    };
+    // m_chunk is a multiple of 32 * 6 rows (ring of 3 register sets x 2 LDS buffers); steps past m_end multiply zeros
+#pragma unroll
+    for (int r = 0; r < RING; ++r) fetch(r);
+    int nst = 0;
+    const bool tr_on = js.trace != nullptr && blockIdx.x == 0 && tid == 0;
+#define TR32_STAMP() do { if (tr_on && nst < 250) js.trace[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
+    for (int mb = m_beg; mb < m_end; mb += 32 * 2 * RING) {
+#pragma unroll
+        for (int r = 0; r < 2 * RING; ++r) {
+            TR32_STAMP();
+            stash(r % RING, r & 1);
+            TR32_STAMP();
+            fetch(r % RING);
+            __syncthreads();
+            TR32_STAMP();
+            mma(r & 1);
+        }
+    }
+    TR32_STAMP();
+#undef TR32_STAMP
+    float* dst = p.part + ((long long)split * p.ntiles + tile) * (TCO * TK);
+#pragma unroll
+    for (int a = 0; a < WA; ++a)
+#pragma unroll
+        for (int b = 0; b < WB; ++b) {
+            const int kcol = wc * (TK / 2) + b * 16 + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = wr * (TCO / 2) + a * 16 + (lane >> 4) * 4 + q;
+                if (co0 + col < p.Cout) dst[col * TK + kcol] = acc[a][b][q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    if (do_bias) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            if (tid + 256 * i < 32 * CA) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(&bsum[ca[i] * 4 + j], bacc[i][j]);
+            }
+        __syncthreads();
+        for (int i = tid; i < TCO; i += 256)
+            if (co0 + i < p.Cout) p.part_b[((long long)split * p.nco + cot) * TCO + i] = bsum[i];
+    }
+}
+
+
 // dw (+ db) += sum over the splits of the stored tiles; blockIdx.y = job; 32 consecutive elements per block, the 8 thread
 // rows share the splits
 // (DIRECT: few splits -- one thread per element sums them all, 256 consecutive elements per block)
@@ -314,12 +534,13 @@ __global__ __launch_bounds__(256) void wgrad_tr_reduce_k(const TrJobs js) {
     p.dw[(long long)co * p.d_co + (long long)t * p.d_t + (long long)c * p.d_c] += sum;
 }
 
-int plan(const s2ag_bf16_wgrad_args* g, TrP& p, int TCO, int TK, int blocks_for_job) {
+int plan(const s2ag_bf16_wgrad_args* g, TrP& p, int TCO, int TK, int rows_per_block, int elems16 = 8, int row_multiple = 128) {
     if (!g || !g->gy || !g->x || !g->dw || g->N <= 0 || g->Lq <= 0 || g->ks <= 0) return S2AG_E_BADARG;
-    if ((g->Cvalid & 7) || (g->ldx & 7) || (g->ldg & 7) || g->Cvalid > g->Cp) return S2AG_E_BADARG;
+    const int am = elems16 - 1;                                  // elements per 16 bytes - 1
+    if ((g->Cvalid & am) || (g->ldx & am) || (g->ldg & am) || g->Cvalid > g->Cp) return S2AG_E_BADARG;
     if (g->Lq < 32) return S2AG_E_UNSUPPORTED;                  // the loader steps (clip, frame) by 32 rows with one wrap
     if ((reinterpret_cast<uintptr_t>(g->x) | reinterpret_cast<uintptr_t>(g->gy)) & 15) return S2AG_E_BADARG;
-    p.gy = static_cast<const bf16_t*>(g->gy); p.x = static_cast<const bf16_t*>(g->x); p.dw = g->dw; p.db = g->db;
+    p.gy = g->gy; p.x = g->x; p.dw = g->dw; p.db = g->db;
     p.M = g->N * g->Lq; p.Lq = g->Lq; p.Lin = g->Lin; p.x_clip = g->x_clip; p.ldx = g->ldx; p.ldg = g->ldg;
     p.pos_mul = g->pos_mul; p.pos_off = g->pos_off; p.pos_tap = g->pos_tap;
     p.ks = g->ks; p.Cp = g->Cp; p.Cvalid = g->Cvalid; p.Cout = g->Cout; p.Cin = g->Cin;
@@ -328,13 +549,32 @@ int plan(const s2ag_bf16_wgrad_args* g, TrP& p, int TCO, int TK, int blocks_for_
     p.nco = cdiv(g->Cout, TCO);
     p.kct = cdiv(g->Cvalid, TK);
     p.ntiles = p.nco * g->ks * p.kct;
-    int splits = cdiv(blocks_for_job, p.ntiles);
-    const int max_splits = cdiv(p.M, 256);                      // at least 8 steps of 32 rows per block
-    if (splits > max_splits) splits = max_splits;
+    int splits = cdiv(p.M, rows_per_block > 256 ? rows_per_block : 256);     // at least 8 steps of 32 rows per block
     if (splits < 1) splits = 1;
-    p.m_chunk = cdiv(cdiv(p.M, splits), 128) * 128;             // multiple of 32 rows * the kernel's ring of 4
+    p.m_chunk = cdiv(cdiv(p.M, splits), row_multiple) * row_multiple;      // 32 rows * the kernel's ring
     p.splits = cdiv(p.M, p.m_chunk);
     return 0;
+}
+
+// rows of the contraction per block such that all jobs together make ~`target` equally long blocks
+int rows_per_block(const s2ag_bf16_wgrad_args* jobs, int njobs, int TCO, int TK, int target) {
+    long long tile_rows = 0;
+    for (int k = 0; k < njobs; ++k)
+        tile_rows += (long long)cdiv(jobs[k].Cout, TCO) * jobs[k].ks * cdiv(jobs[k].Cvalid, TK) * jobs[k].N * jobs[k].Lq;
+    // rounded UP to the kernels' row granularity: a block count just above the number of CUs would cost a whole second
+    // round (one workgroup per CU at these register counts: 288 blocks took twice the time of 256)
+    long long r = (tile_rows + target - 1) / (target > 0 ? target : 1);
+    r = (r + 191) / 192 * 192;
+    if (r < 384) r = 384;
+    for (int it = 0; it < 64; ++it) {                            // grow until the block count really is <= target
+        long long blocks = 0;
+        for (int k = 0; k < njobs; ++k)
+            blocks += (long long)cdiv(jobs[k].Cout, TCO) * jobs[k].ks * cdiv(jobs[k].Cvalid, TK) *
+                      cdiv((long long)jobs[k].N * jobs[k].Lq, r);
+        if (blocks <= target) break;
+        r += 192;
+    }
+    return (int)r;
 }
 
 long long part_floats(const TrP& p, int TCO, int TK) {
@@ -346,6 +586,8 @@ bool big_tiles(const s2ag_bf16_wgrad_args* jobs, int n) {
         if (jobs[k].Cout <= 128 || jobs[k].flat_cin > 0 || jobs[k].Cvalid < 160) return false;
     return true;
 }
+
+unsigned long long* g_tr_trace = nullptr;
 
 int target_blocks() {
     static const int t = [] { const char* e = getenv("S2AG_BF16_WGRAD_TR_BLOCKS"); return e ? atoi(e) : 0; }();
@@ -359,9 +601,10 @@ extern "C" long long s2ag_bf16_conv_wgrad_tr_scratch_floats(const s2ag_bf16_wgra
     const int TCO = big ? 160 : 64, TK = big ? 160 : 64;
     const int target = target_blocks() > 0 ? target_blocks() : (big ? 256 : 1024);
     long long tot = 0;
+    const int rpb = rows_per_block(jobs, njobs, TCO, TK, target);
     for (int k = 0; k < njobs; ++k) {
         TrP p{};
-        const int rc = plan(jobs + k, p, TCO, TK, cdiv(target, njobs));
+        const int rc = plan(jobs + k, p, TCO, TK, rpb);
         if (rc) return rc;
         tot += part_floats(p, TCO, TK);
     }
@@ -378,22 +621,26 @@ extern "C" int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njo
     static const int remap = [] { const char* e = getenv("S2AG_WGRAD_TR_XCD"); return e ? atoi(e) : 1; }();
     js.xcd_remap = remap;
     long long off = 0, max_red = 0;
-    int mt = 0, ms = 0;
+    int ms = 0, nblk = 0;
+    const int rpb = rows_per_block(jobs, njobs, TCO, TK, target);
+    js.njobs = njobs;
     for (int k = 0; k < njobs; ++k) {
         TrP& p = js.j[k];
-        const int rc = plan(jobs + k, p, TCO, TK, cdiv(target, njobs));
+        const int rc = plan(jobs + k, p, TCO, TK, rpb);
         if (rc) return rc;
         p.part = scratch + off;
         p.part_b = p.part + (long long)p.splits * p.ntiles * TCO * TK;
         off += part_floats(p, TCO, TK);
-        mt = p.ntiles > mt ? p.ntiles : mt;
+        js.start[k] = nblk;
+        nblk += p.ntiles * p.splits;
         ms = p.splits > ms ? p.splits : ms;
         const long long red = (long long)p.ntiles * TCO * TK + p.nco * TCO;
         max_red = red > max_red ? red : max_red;
     }
+    js.start[njobs] = nblk;
     if (off > scratch_floats) return S2AG_E_BADARG;
     const bool direct = ms <= 16;
-    const dim3 grid(mt, ms, njobs), rgrid(cdiv(max_red, direct ? 256 : 32), njobs);
+    const dim3 grid(nblk), rgrid(cdiv(max_red, direct ? 256 : 32), njobs);
     hipStream_t st = (hipStream_t)stream;
     if (big) {
         hipLaunchKernelGGL((wgrad_tr_k<160, 160>), grid, dim3(256), 0, st, js);
@@ -405,5 +652,64 @@ extern "C" int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njo
         else hipLaunchKernelGGL((wgrad_tr_reduce_k<64, 64, false>), rgrid, dim3(256), 0, st, js);
     }
     S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* fp32 operands (row pitches in floats): the GRU weight gradients of the fp32 step.  Same job struct; Cvalid / ldx / ldg
+ * multiples of 4; products from two bf16 pieces per operand (16 mantissa bits), fp32 accumulation. */
+extern "C" long long s2ag_f32_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args* jobs, int njobs) {
+    if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS) return S2AG_E_BADARG;
+    const int target = target_blocks() > 0 ? target_blocks() : 256;
+    long long tot = 0;
+    const int rpb = rows_per_block(jobs, njobs, 160, 160, target);
+    for (int k = 0; k < njobs; ++k) {
+        TrP p{};
+        const int rc = plan(jobs + k, p, 160, 160, rpb, 4, 192);
+        if (rc) return rc;
+        tot += part_floats(p, 160, 160);
+    }
+    return tot;
+}
+
+extern "C" int s2ag_f32_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njobs, float* scratch, long long scratch_floats,
+                                 void* stream) {
+    if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS || !scratch) return S2AG_E_BADARG;
+    const int target = target_blocks() > 0 ? target_blocks() : 256;
+    TrJobs js{};
+    static const int remap = [] { const char* e = getenv("S2AG_WGRAD_TR_XCD"); return e ? atoi(e) : 1; }();
+    js.xcd_remap = remap;
+    js.trace = g_tr_trace;
+    long long off = 0, max_red = 0;
+    int ms = 0, nblk = 0;
+    const int rpb = rows_per_block(jobs, njobs, 160, 160, target);
+    js.njobs = njobs;
+    for (int k = 0; k < njobs; ++k) {
+        TrP& p = js.j[k];
+        const int rc = plan(jobs + k, p, 160, 160, rpb, 4, 192);
+        if (rc) return rc;
+        if ((reinterpret_cast<uintptr_t>(jobs[k].x) | reinterpret_cast<uintptr_t>(jobs[k].gy)) & 15) return S2AG_E_BADARG;
+        p.part = scratch + off;
+        p.part_b = p.part + (long long)p.splits * p.ntiles * 160 * 160;
+        off += part_floats(p, 160, 160);
+        js.start[k] = nblk;
+        nblk += p.ntiles * p.splits;
+        ms = p.splits > ms ? p.splits : ms;
+        const long long red = (long long)p.ntiles * 160 * 160 + p.nco * 160;
+        max_red = red > max_red ? red : max_red;
+    }
+    js.start[njobs] = nblk;
+    if (off > scratch_floats) return S2AG_E_BADARG;
+    const bool direct = ms <= 16;
+    const dim3 grid(nblk), rgrid(cdiv(max_red, direct ? 256 : 32), njobs);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((wgrad_tr32_k<160, 160>), grid, dim3(256), 0, st, js);
+    if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, true>), rgrid, dim3(256), 0, st, js);
+    else hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, false>), rgrid, dim3(256), 0, st, js);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_wgrad_tr_set_trace(void* buf) {
+    g_tr_trace = static_cast<unsigned long long*>(buf);
     return 0;
 }

@@ -1127,6 +1127,23 @@ def _gru_proj_split(inp, wih, wih_r, wih2, bih2, gi, In):
     gemm_split_raw(split_planes_raw(inp), ent[1], bih2.reshape(-1), gi, In)
 
 
+GRU_WGRAD_TR = __import__('os').environ.get('S2AG_GRU_WGRAD_TR', '1') != '0'
+_GRU_WG_SCRATCH = {}
+
+
+def _gru_wgrad_scratch(dev, owner, floats):
+    """Tile store of a GRU layer's transpose-read weight-gradient launch (one buffer per layer; grown only outside
+    hipGraph capture)."""
+    key = (dev.index, owner)
+    t = _GRU_WG_SCRATCH.get(key)
+    if t is None or t.numel() < floats:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('GRU weight-gradient scratch must exist before hipGraph capture (run one eager step first)')
+        t = torch.empty(floats, dtype=torch.float32, device=dev)
+        _GRU_WG_SCRATCH[key] = t
+    return t
+
+
 class _GRU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, H, Lyr, training, drop_p, noise, site0, sum_dirs, need_grad, *weights):
@@ -1262,7 +1279,23 @@ class _GRU(torch.autograd.Function):
             pair_bi = _pair(slots[2], slots[6]) if all(need) else None
             if all(sl is not None for sl in slots) and pair_ih is not None and pair_bi is not None:
                 # arena layout: the two directions are adjacent, so dW_ih / db_ih of both are one launch each
-                def leaves(dgi=dgi, dgh=dgh, y=y, inp=inp, In=In, pair_ih=pair_ih, pair_bi=pair_bi, slots=slots):
+                def leaves(dgi=dgi, dgh=dgh, y=y, inp=inp, In=In, pair_ih=pair_ih, pair_bi=pair_bi, slots=slots, l=l):
+                    if (GRU_WGRAD_TR and lib.s2ag_gru_coop_split_pieces() != 0 and T >= 32 and In % 4 == 0 and H % 4 == 0
+                            and 2.0 * B * T * In * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
+                        # the layer's three weight gradients on the bf16 pipe through the LDS transpose read
+                        # (csrc/wgrad_tr.hip, fp32 rows split into two bf16 pieces by the loader): one launch + reduce
+                        xin, _, _, ldi = as_rows(inp)
+                        jobs = (L.BF16Wgrad * 3)()
+                        jobs[0] = L.BF16Wgrad(_p(dgi), _p(xin), _p(pair_ih), _p(pair_bi), B, T, T, T * ldi, ldi, 2 * H3, 1, 0,
+                                              0, 1, In, In, 2 * H3, In, In, 0, 1, 0, 1)
+                        for d in range(2):
+                            jobs[1 + d] = L.BF16Wgrad(C.c_void_p(dgh[d].data_ptr()), C.c_void_p(y.data_ptr() + 4 * d * H),
+                                                      _p(slots[4 * d + 1]), _p(slots[4 * d + 3]), B, T, T, T * 2 * H, 2 * H,
+                                                      H3, 1, -1 if d == 0 else 1, 0, 1, H, H, H3, H, H, 0, 1, 0, 1)
+                        need_f = int(lib.s2ag_f32_wgrad_tr_scratch_floats(jobs, 3))
+                        sc = _gru_wgrad_scratch(dev, (id(ctx.w_leaves[8 * l]), B, T), need_f)
+                        L.check(lib.s2ag_f32_wgrad_tr(jobs, 3, _p(sc), sc.numel(), _stream()), 'f32_wgrad_tr')
+                        return
                     if (SPLIT_WGRAD and SPLIT_GEMM and lib.s2ag_gru_coop_split_pieces() != 0
                             and 2.0 * B * T * In * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
                         # weight gradients on the bf16 pipe: transposed splits (contraction over clips * frames; the bias
