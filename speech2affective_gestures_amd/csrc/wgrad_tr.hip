@@ -274,8 +274,8 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 
-template <int TCO, int TK>
-__global__ __launch_bounds__(256) void wgrad_tr32_k(const TrJobs js) {
+template <int TCO, int TK, int RING, int BPC>
+__global__ __launch_bounds__(256, BPC) void wgrad_tr32_k(const TrJobs js) {
     const int nwg = gridDim.x;                                   // compact 1-D grid: every block has work
     const int hw = blockIdx.x;
     const int xcd = hw & 7, q8 = nwg >> 3, r8 = nwg & 7;
@@ -289,7 +289,6 @@ __global__ __launch_bounds__(256) void wgrad_tr32_k(const TrJobs js) {
     constexpr int CA = TCO / 4, CB = TK / 4;                    // 16-byte (4-float) chunks per row
     constexpr int NA = (32 * CA + 255) / 256, NB = (32 * CB + 255) / 256;
     constexpr int WA = TCO / 32, WB = TK / 32;
-    constexpr int RING = 3;
     __shared__ __attribute__((aligned(16))) bf16_t Gs[2][2][32 * PA];       // [buffer][hi / lo]
     __shared__ __attribute__((aligned(16))) bf16_t Xs[2][2][32 * PB];
     __shared__ float bsum[TCO];
@@ -426,15 +425,16 @@ __global__ __launch_bounds__(256) void wgrad_tr32_k(const TrJobs js) {
             for (int b = 0; b < WB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[b], acc[a][b], 0, 0, 0);
         }
     };
-    // m_chunk is a multiple of 32 * 6 rows (ring of 3 register sets x 2 LDS buffers); steps past m_end multiply zeros
+    // m_chunk is a multiple of 192 rows (covers a ring of 2 or 3 register sets x 2 LDS buffers); steps past m_end multiply zeros
 #pragma unroll
     for (int r = 0; r < RING; ++r) fetch(r);
     int nst = 0;
     const bool tr_on = js.trace != nullptr && blockIdx.x == 0 && tid == 0;
 #define TR32_STAMP() do { if (tr_on && nst < 250) js.trace[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
-    for (int mb = m_beg; mb < m_end; mb += 32 * 2 * RING) {
+    constexpr int PERIOD = (RING % 2) ? 2 * RING : RING;         // steps until (register set, LDS buffer) repeats
+    for (int mb = m_beg; mb < m_end; mb += 32 * PERIOD) {
 #pragma unroll
-        for (int r = 0; r < 2 * RING; ++r) {
+        for (int r = 0; r < PERIOD; ++r) {
             TR32_STAMP();
             stash(r % RING, r & 1);
             TR32_STAMP();
@@ -657,16 +657,19 @@ extern "C" int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njo
 
 /* fp32 operands (row pitches in floats): the GRU weight gradients of the fp32 step.  Same job struct; Cvalid / ldx / ldg
  * multiples of 4; products from two bf16 pieces per operand (16 mantissa bits), fp32 accumulation. */
+// (A 160 x 128 variant with two register sets and two workgroups per CU -- one's loader beside the other's MFMAs -- spilled
+// 87 VGPRs at the 256-register cap and ran at half the speed: measured, removed.)
 extern "C" long long s2ag_f32_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args* jobs, int njobs) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS) return S2AG_E_BADARG;
+    const int TCO = 160, TK = 160;
     const int target = target_blocks() > 0 ? target_blocks() : 256;
     long long tot = 0;
-    const int rpb = rows_per_block(jobs, njobs, 160, 160, target);
+    const int rpb = rows_per_block(jobs, njobs, TCO, TK, target);
     for (int k = 0; k < njobs; ++k) {
         TrP p{};
-        const int rc = plan(jobs + k, p, 160, 160, rpb, 4, 192);
+        const int rc = plan(jobs + k, p, TCO, TK, rpb, 4, 192);
         if (rc) return rc;
-        tot += part_floats(p, 160, 160);
+        tot += part_floats(p, TCO, TK);
     }
     return tot;
 }
@@ -674,6 +677,7 @@ extern "C" long long s2ag_f32_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args
 extern "C" int s2ag_f32_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njobs, float* scratch, long long scratch_floats,
                                  void* stream) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS || !scratch) return S2AG_E_BADARG;
+    const int TCO = 160, TK = 160;
     const int target = target_blocks() > 0 ? target_blocks() : 256;
     TrJobs js{};
     static const int remap = [] { const char* e = getenv("S2AG_WGRAD_TR_XCD"); return e ? atoi(e) : 1; }();
@@ -681,20 +685,20 @@ extern "C" int s2ag_f32_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njobs, fl
     js.trace = g_tr_trace;
     long long off = 0, max_red = 0;
     int ms = 0, nblk = 0;
-    const int rpb = rows_per_block(jobs, njobs, 160, 160, target);
+    const int rpb = rows_per_block(jobs, njobs, TCO, TK, target);
     js.njobs = njobs;
     for (int k = 0; k < njobs; ++k) {
         TrP& p = js.j[k];
-        const int rc = plan(jobs + k, p, 160, 160, rpb, 4, 192);
+        const int rc = plan(jobs + k, p, TCO, TK, rpb, 4, 192);
         if (rc) return rc;
         if ((reinterpret_cast<uintptr_t>(jobs[k].x) | reinterpret_cast<uintptr_t>(jobs[k].gy)) & 15) return S2AG_E_BADARG;
         p.part = scratch + off;
-        p.part_b = p.part + (long long)p.splits * p.ntiles * 160 * 160;
-        off += part_floats(p, 160, 160);
+        p.part_b = p.part + (long long)p.splits * p.ntiles * TCO * TK;
+        off += part_floats(p, TCO, TK);
         js.start[k] = nblk;
         nblk += p.ntiles * p.splits;
         ms = p.splits > ms ? p.splits : ms;
-        const long long red = (long long)p.ntiles * 160 * 160 + p.nco * 160;
+        const long long red = (long long)p.ntiles * TCO * TK + p.nco * TCO;
         max_red = red > max_red ? red : max_red;
     }
     js.start[njobs] = nblk;
@@ -702,7 +706,7 @@ extern "C" int s2ag_f32_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njobs, fl
     const bool direct = ms <= 16;
     const dim3 grid(nblk), rgrid(cdiv(max_red, direct ? 256 : 32), njobs);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((wgrad_tr32_k<160, 160>), grid, dim3(256), 0, st, js);
+    hipLaunchKernelGGL((wgrad_tr32_k<160, 160, 3, 1>), grid, dim3(256), 0, st, js);
     if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, true>), rgrid, dim3(256), 0, st, js);
     else hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, false>), rgrid, dim3(256), 0, st, js);
     S2AG_LAUNCH_CHECK();

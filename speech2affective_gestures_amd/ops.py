@@ -1281,7 +1281,7 @@ class _GRU(torch.autograd.Function):
                 # arena layout: the two directions are adjacent, so dW_ih / db_ih of both are one launch each
                 def leaves(dgi=dgi, dgh=dgh, y=y, inp=inp, In=In, pair_ih=pair_ih, pair_bi=pair_bi, slots=slots, l=l):
                     if (GRU_WGRAD_TR and lib.s2ag_gru_coop_split_pieces() != 0 and T >= 32 and In % 4 == 0 and H % 4 == 0
-                            and 2.0 * B * T * In * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
+                            and 2.0 * B * T * (In + H) * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
                         # the layer's three weight gradients on the bf16 pipe through the LDS transpose read
                         # (csrc/wgrad_tr.hip, fp32 rows split into two bf16 pieces by the loader): one launch + reduce
                         xin, _, _, ldi = as_rows(inp)
