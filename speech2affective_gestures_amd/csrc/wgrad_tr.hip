@@ -589,6 +589,15 @@ bool big_tiles(const s2ag_bf16_wgrad_args* jobs, int n) {
 
 unsigned long long* g_tr_trace = nullptr;
 
+// Workgroups of the fp32 form (one per CU: 506 VGPRs).  96, not 256: the launch runs beside the next layer's cooperative
+// recurrence, whose 160 workgroups each need a CU of their own -- a chip-filling weight-gradient launch that starts first
+// makes them queue (gru_coop_bwd_k 224 us inside the step against 157 us alone); 96 + 160 = the chip.  Measured on the step:
+// 15 210-15 310 (96) / 15 300 (128) / 14 900 (160) / 15 110-15 120 (256) clips/s.
+int target_blocks32() {
+    static const int t = [] { const char* e = getenv("S2AG_F32_WGRAD_TR_BLOCKS"); return e ? atoi(e) : 96; }();
+    return t > 0 ? t : 96;
+}
+
 int target_blocks() {
     static const int t = [] { const char* e = getenv("S2AG_BF16_WGRAD_TR_BLOCKS"); return e ? atoi(e) : 0; }();
     return t;
@@ -662,7 +671,7 @@ extern "C" int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njo
 extern "C" long long s2ag_f32_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args* jobs, int njobs) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS) return S2AG_E_BADARG;
     const int TCO = 160, TK = 160;
-    const int target = target_blocks() > 0 ? target_blocks() : 256;
+    const int target = target_blocks32();
     long long tot = 0;
     const int rpb = rows_per_block(jobs, njobs, TCO, TK, target);
     for (int k = 0; k < njobs; ++k) {
@@ -678,7 +687,7 @@ extern "C" int s2ag_f32_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njobs, fl
                                  void* stream) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS || !scratch) return S2AG_E_BADARG;
     const int TCO = 160, TK = 160;
-    const int target = target_blocks() > 0 ? target_blocks() : 256;
+    const int target = target_blocks32();
     TrJobs js{};
     static const int remap = [] { const char* e = getenv("S2AG_WGRAD_TR_XCD"); return e ? atoi(e) : 1; }();
     js.xcd_remap = remap;
