@@ -493,6 +493,32 @@ int s2ag_bf16_tcn_fwd(const s2ag_bf16_tcn_args* a, void* stream);
  * boundaries (forward from word 0, backward from word 128); NULL switches it off.  Not on the training path. */
 int s2ag_bf16_tcn_set_trace(void* buf);
 int s2ag_bf16_tcn_bwd(const s2ag_bf16_tcn_args* a, void* stream);
+/* ---- clip-resident TemporalConvNet forward of the fp32 step (csrc/tcn_fused32.hip) -----------------------------------
+ * Replaces the forward of the four TemporalBlocks of net/tcn.py:16-64 (the 8 dilated causal convs + ReLU + dropout +
+ * residuals of TextEncoderTCN, net/multimodal_context_net_v2.py:61-91) by ONE launch: a workgroup owns one clip, fp32 rows
+ * resident in LDS, products from two bf16 pieces per operand with fp32 accumulation (as s2ag_conv1d_nlc_fwd_split).
+ * x, h1[b], h2[b], y[b]: fp32 (clips*T, C) rows; h1 / h2 = dropout(relu(conv)) of the block's two convs, y = relu(h2 + x_b):
+ * what the layer-by-layer backward kernels need.  w[k] for s2ag_tcn32_pack: fp32 (C, 2, C) tap-major normalised weights.
+ * keep: workspace of s2ag_tcn32_keep_bytes (drop_p > 0).  T <= 40, 256 < C <= 320, C % 4 == 0. */
+typedef struct {
+    const float* x;
+    float* h1[S2AG_TCN_MAX_BLOCKS];
+    float* h2[S2AG_TCN_MAX_BLOCKS];
+    float* y[S2AG_TCN_MAX_BLOCKS];
+    const void* wfrag;
+    const float* bias[2 * S2AG_TCN_MAX_BLOCKS];
+    int dil[S2AG_TCN_MAX_BLOCKS];
+    int n_blocks, n_clips, T, C;
+    float drop_p;
+    const void* rng;
+    unsigned site[2 * S2AG_TCN_MAX_BLOCKS];
+    void* keep;
+} s2ag_tcn32_args;
+int s2ag_tcn32_supported(int T, int C, int ksize);
+long long s2ag_tcn32_pack_elems(int n_convs);
+long long s2ag_tcn32_keep_bytes(int n_clips, int n_blocks);
+int s2ag_tcn32_pack(const float* const* w, int n_convs, int C, void* wfrag, void* stream);
+int s2ag_tcn32_fwd(const s2ag_tcn32_args* a, void* stream);
 /* up to 8 s2ag_bf16_conv_wgrad jobs in one launch (the TCN's eight weight gradients fill the chip together) */
 #define S2AG_BF16_MAX_WGRAD_JOBS 8
 int s2ag_bf16_conv_wgrad_multi(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs, void* stream);

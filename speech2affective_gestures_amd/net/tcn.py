@@ -104,7 +104,17 @@ class TemporalConvNet(nn.Module):
 
     def forward_nlc(self, x, noise):
         ws = [w for g in self._weight_groups() for w in g.tensors()]
-        for i, blk in enumerate(self.network):
+        blks = list(self.network)
+        if (x.dim() == 3 and all(b.kernel_size == 2 and b.p == blks[0].p and b.downsample is None for b in blks)
+                and ops.tcn_fused32_supported(x.shape[1], blks[0].conv1.out_channels, 2, len(blks))
+                and x.shape[2] == blks[0].conv1.in_channels == blks[0].conv1.out_channels):
+            # clip-resident forward (csrc/tcn_fused32.hip): every block in ONE launch; backward layer by layer
+            if self.__dict__.get('_frag32') is None:
+                self.__dict__['_frag32'] = ops.TcnFragments32()
+            p = blks[0].p if self.training else 0.0
+            return ops.tcn_fused32(x, self.__dict__['_frag32'], ws, [c.bias for b in blks for c in (b.conv1, b.conv2)],
+                                   [b.dilation for b in blks], [s for b in blks for s in b.sites], p, noise)
+        for i, blk in enumerate(blks):
             x = blk.forward_nlc(x, noise, weights=ws[2 * i:2 * i + 2])
         return x
 

@@ -730,6 +730,121 @@ def add_act(a: Tensor, b: Optional[Tensor], slope: float) -> Tensor:
 
 
 # ----------------------------------------------------------------------------------------------------
+# clip-resident TemporalConvNet forward of the fp32 step (csrc/tcn_fused32.hip)
+# ----------------------------------------------------------------------------------------------------
+TCN_FUSED32 = __import__('os').environ.get('S2AG_TCN_FUSED32', '1') != '0'
+
+
+def tcn_fused32_supported(T: int, Cch: int, ks: int, n_blocks: int) -> bool:
+    lib = _lib()
+    return (TCN_FUSED32 and SPLIT_CONV and 1 <= n_blocks <= 4 and lib.s2ag_gru_coop_split_pieces() != 0
+            and bool(lib.s2ag_tcn32_supported(int(T), int(Cch), int(ks))))
+
+
+class TcnFragments32:
+    """hi / lo bf16 planes of the normalised conv weights in MFMA-fragment order, refreshed once per optimizer step."""
+
+    def __init__(self):
+        self._key, self._frag = None, None
+
+    def get(self, ws):
+        key = (_GENERATION[0],) + tuple((id(w), w._version, w.data_ptr()) for w in ws)
+        if key != self._key:
+            lib = _lib()
+            frag = torch.empty(int(lib.s2ag_tcn32_pack_elems(len(ws))), dtype=torch.bfloat16, device=ws[0].device)
+            ptrs = (C.c_void_p * len(ws))(*[w.detach().data_ptr() for w in ws])
+            L.check(lib.s2ag_tcn32_pack(ptrs, len(ws), ws[0].shape[0], _p(frag), _stream()), 'tcn32_pack')
+            self._key, self._frag = key, frag
+        return self._frag
+
+
+class _FakeCtx:
+    """What _ConvNLC.backward reads from its context, for a conv whose forward ran inside the fused kernel."""
+    pass
+
+
+class _TcnFused32(torch.autograd.Function):
+    """x (B, T, C) fp32 -> the last TemporalBlock's output; ``params`` = the 2*nb normalised (C, 2, C) tap-major weights
+    followed by the 2*nb biases.  Forward: one launch (+ the keep bits).  Backward: the layer-by-layer kernels on the
+    tensors the forward left behind (h1, h2, y per block) -- exactly what the per-layer path would have saved."""
+
+    @staticmethod
+    def forward(ctx, x, frags, meta, noise, *params):
+        dils, sites, drop_p = meta
+        nb = len(dils)
+        ws, bs = params[:2 * nb], params[2 * nb:]
+        lib = _lib()
+        B, T, Cch = x.shape
+        x2, rows, cols, ldx = as_rows(x)
+        if ldx != cols:
+            x2 = x2.contiguous()
+        frag = frags.get(ws)
+        saved = torch.empty(3 * nb, rows, Cch, dtype=torch.float32, device=x.device)     # h1, h2, y per block
+        a = L.Tcn32()
+        a.x, a.wfrag = x2.data_ptr(), frag.data_ptr()
+        for b in range(nb):
+            a.h1[b], a.h2[b], a.y[b] = saved[3 * b].data_ptr(), saved[3 * b + 1].data_ptr(), saved[3 * b + 2].data_ptr()
+            a.dil[b] = int(dils[b])
+            for j in range(2):
+                a.bias[2 * b + j] = bs[2 * b + j].data_ptr() if bs[2 * b + j] is not None else None
+                a.site[2 * b + j] = int(sites[2 * b + j])
+        a.n_blocks, a.n_clips, a.T, a.C = nb, B, T, Cch
+        a.drop_p = float(drop_p)
+        if drop_p > 0:
+            keep = torch.empty(int(lib.s2ag_tcn32_keep_bytes(B, nb)), dtype=torch.uint8, device=x.device)
+            a.rng, a.keep = noise.data_ptr(), keep.data_ptr()
+        L.check(lib.s2ag_tcn32_fwd(C.byref(a), _stream()), 'tcn32_fwd')
+        ctx.meta, ctx.noise, ctx.params, ctx.shape = meta, noise, params, (B, T, Cch)
+        ctx.save_for_backward(x2, saved)
+        return saved[3 * nb - 1].view(B, T, Cch)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, saved = ctx.saved_tensors
+        dils, sites, drop_p = ctx.meta
+        nb = len(dils)
+        params = ctx.params
+        ws, bs = params[:2 * nb], params[2 * nb:]
+        B, T, Cch = ctx.shape
+        rows = B * T
+        grads = [None] * (4 * nb)
+        g = gy.reshape(rows, Cch)
+        for b in range(nb - 1, -1, -1):
+            d = int(dils[b])
+            h1, h2, yb = saved[3 * b], saved[3 * b + 1], saved[3 * b + 2]
+            xin = x2.view(rows, Cch) if b == 0 else saved[3 * (b - 1) + 2]
+            gs = torch.empty(rows, Cch, dtype=torch.float32, device=g.device)
+            epilogue_bwd_raw(g, yb, gs, L.ACT_LEAKY, 0.0, 0.0, None, 0)                 # through relu(h2 + x)
+            cur = gs
+            for j, (xop, yop) in ((1, (h1, h2)), (0, (xin, h1))):
+                k = 2 * b + j
+                fc = _FakeCtx()
+                fc.saved_tensors = (xop, ws[k], yop)
+                fc.geom = (B, T, T, Cch, Cch, 2, 1, d, d, 1)
+                fc.epi = (L.ACT_LEAKY, 0.0, float(drop_p), int(sites[k]))
+                fc.noise, fc.w_leaf, fc.b_leaf, fc.has_bias = ctx.noise, ws[k], bs[k], bs[k] is not None
+                fc.wtm_k, fc.w_shape = 1, ws[k].shape
+                need_x = True if (j == 1 or b > 0) else ctx.needs_input_grad[0]
+                fc.needs_input_grad = (need_x, ctx.needs_input_grad[4 + k],
+                                       bs[k] is not None and ctx.needs_input_grad[4 + 2 * nb + k])
+                out = _ConvNLC.backward(fc, cur.view(B, T, Cch))
+                grads[k], grads[2 * nb + k] = out[1], out[2]
+                cur = out[0].reshape(rows, Cch) if out[0] is not None else None
+            if cur is None:
+                g = None
+                break
+            gn = torch.empty(rows, Cch, dtype=torch.float32, device=cur.device)
+            add_act_raw(cur, gs, gn, 1.0)                                                # + the residual branch
+            g = gn
+        gx = g.view(B, T, Cch) if (g is not None and ctx.needs_input_grad[0]) else None
+        return (gx, None, None, None) + tuple(grads)
+
+
+def tcn_fused32(x: Tensor, frags: TcnFragments32, ws, biases, dils, sites, drop_p: float, noise) -> Tensor:
+    return _TcnFused32.apply(x, frags, (tuple(dils), tuple(sites), float(drop_p)), noise, *ws, *biases)
+
+
+# ----------------------------------------------------------------------------------------------------
 # embedding (+ dropout)
 # ----------------------------------------------------------------------------------------------------
 class _Embedding(torch.autograd.Function):

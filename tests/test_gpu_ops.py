@@ -823,3 +823,47 @@ def test_touched_row_exchange_kernels(S, n_entries, dim, world, cap, n_tok):
     with pytest.raises(RuntimeError, match='row capacity'):
         ops.check_coop_flag(ops.coop_error_flag().cpu()[0].item())
     ops._COOP_FLAG[0].zero_()
+
+
+@pytest.mark.parametrize('B,train', [(5, True), (33, True), (4, False)])
+def test_clip_resident_tcn_forward_fp32_equals_the_layer_by_layer_path(S, B, train, monkeypatch):
+    """csrc/tcn_fused32.hip (the four TemporalBlocks in one launch, fp32 rows in LDS, two-piece bf16 products) against the
+    layer-by-layer kernels (conv_sp_k: the same two-piece products) on the same weights and noise stream: outputs and
+    every parameter gradient (the backward pass is the layer-by-layer one on the tensors the fused forward leaves)."""
+    import types
+    ops = S['ops']
+    from speech2affective_gestures_amd import noise
+    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import TextEncoderTCN
+    cfg = types.SimpleNamespace(hidden_size=300, n_layers=4, dropout_prob=0.3, freeze_wordembed=False)
+    torch.manual_seed(3)
+    noise.reset_sites(0)
+    txt = TextEncoderTCN(cfg, 400, 300, dropout=0.3).cuda().train(train)
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(0, 400, (B, 34), generator=g)
+    ids[:, 20:] = 0
+    dt = torch.randn(B, 34, 32, generator=g).cuda()
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(ops, 'TCN_FUSED32', fused)
+        for p in txt.parameters():
+            p.grad = None
+        ops.begin_step()
+        noise.manual_seed(5)
+        assert ops.tcn_fused32_supported(34, 300, 2, 4) == fused
+        t = txt(ids.cuda())[0]
+        if train:
+            (t * dt).sum().backward()
+        torch.cuda.synchronize()
+        res[fused] = (t.detach().clone(), {k: p.grad.clone() for k, p in txt.named_parameters()
+                                            if '.net.' not in k and p.grad is not None})
+    (t0, g0), (t1, g1) = res[False], res[True]
+    assert rel(t1, t0) < 1e-4, rel(t1, t0)
+    assert set(g0) == set(g1)
+    for k in g0:
+        # two summation orders of the same two-piece products differ by ~1e-6, so the few ReLU inputs that close to zero
+        # take the other branch: single terms of single gradient entries come and go (one term of a bias-gradient entry is
+        # ~1 % of the largest entry).  A flip in a late block changes what flows back through all earlier ones a little.  Kink-flip tolerant: relative L2 distance
+        # (measured <= 1.1e-3) and a loose bound on the largest single entry.
+        a, b = g1[k].double().flatten(), g0[k].double().flatten()
+        l2 = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        assert l2 < 5e-3 and rel(g1[k], g0[k]) < 5e-2, (k, l2, rel(g1[k], g0[k]))
