@@ -513,12 +513,19 @@ typedef struct {
     const void* rng;
     unsigned site[2 * S2AG_TCN_MAX_BLOCKS];
     void* keep;
+    /* s2ag_tcn32_bwd: the whole chain of data gradients in one launch; gp1[b] / gp2[b] (fp32 (clips*T, C)) receive the
+     * gradients w.r.t. the pre-activations of block b's conv1 / conv2 -- the `gy` operands of s2ag_f32_wgrad_tr */
+    const float* gy;
+    float* gx;
+    float* gp1[S2AG_TCN_MAX_BLOCKS];
+    float* gp2[S2AG_TCN_MAX_BLOCKS];
 } s2ag_tcn32_args;
 int s2ag_tcn32_supported(int T, int C, int ksize);
 long long s2ag_tcn32_pack_elems(int n_convs);
 long long s2ag_tcn32_keep_bytes(int n_clips, int n_blocks);
 int s2ag_tcn32_pack(const float* const* w, int n_convs, int C, void* wfrag, void* stream);
 int s2ag_tcn32_fwd(const s2ag_tcn32_args* a, void* stream);
+int s2ag_tcn32_bwd(const s2ag_tcn32_args* a, void* stream);
 /* up to 8 s2ag_bf16_conv_wgrad jobs in one launch (the TCN's eight weight gradients fill the chip together) */
 #define S2AG_BF16_MAX_WGRAD_JOBS 8
 int s2ag_bf16_conv_wgrad_multi(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs, void* stream);
@@ -537,6 +544,11 @@ int s2ag_wgrad_tr_set_trace(void* buf);
 long long s2ag_f32_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs);
 int s2ag_f32_wgrad_tr(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs, float* scratch, long long scratch_floats,
                       void* stream);
+/* the same with an explicit workgroup count (0 = the default of 96, chosen for launches that run beside a cooperative
+ * recurrence; a launch that has the chip to itself wants 256) */
+long long s2ag_f32_wgrad_tr_scratch_floats_n(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs, int blocks);
+int s2ag_f32_wgrad_tr_n(const s2ag_bf16_wgrad_args* jobs /*host*/, int njobs, float* scratch, long long scratch_floats,
+                        int blocks, void* stream);
 
 /* Measurement aid (tools/pmc_traffic.py): touches `bytes` of `buf` with a known access pattern so the rocprofv3 counters
  * FETCH_SIZE / WRITE_SIZE can be calibrated against a known byte count in OUR access shapes: 0 = 16 B/lane coalesced

@@ -66,7 +66,7 @@ class BF16Tcn(C.Structure):       # s2ag_bf16_tcn_args
 class Tcn32(C.Structure):         # s2ag_tcn32_args
     _fields_ = [('x', vp), ('h1', vp * 4), ('h2', vp * 4), ('y', vp * 4), ('wfrag', vp), ('bias', vp * 8), ('dil', ci * 4),
                 ('n_blocks', ci), ('n_clips', ci), ('T', ci), ('C', ci), ('drop_p', cf), ('rng', vp), ('site', cu * 8),
-                ('keep', vp)]
+                ('keep', vp), ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4)]
 
 
 MAX_JOBS = 8
@@ -162,10 +162,13 @@ SIGNATURES = {
     's2ag_tcn32_keep_bytes': [ci, ci],
     's2ag_tcn32_pack': [vp, ci, ci, vp, vp],
     's2ag_tcn32_fwd': [vp, vp],
+    's2ag_tcn32_bwd': [vp, vp],
     's2ag_bf16_conv_wgrad_tr_scratch_floats': [vp, ci],
     's2ag_bf16_conv_wgrad_tr': [vp, ci, vp, cll, vp],
     's2ag_f32_wgrad_tr_scratch_floats': [vp, ci],
     's2ag_f32_wgrad_tr': [vp, ci, vp, cll, vp],
+    's2ag_f32_wgrad_tr_scratch_floats_n': [vp, ci, ci],
+    's2ag_f32_wgrad_tr_n': [vp, ci, vp, cll, ci, vp],
     's2ag_wgrad_tr_set_trace': [vp],
     's2ag_rows_unique': [vp, ci, ci, ci, vp, vp, vp, vp, vp],
     's2ag_rows_pack': [vp, vp, ci, ci, ci, vp, vp],
@@ -207,7 +210,7 @@ def load():
         fn.argtypes = args
         fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes', 's2ag_bf16_tcn_keep_bytes',
                               's2ag_bf16_conv_wgrad_scratch_floats', 's2ag_bf16_conv_wgrad_tr_scratch_floats',
-                              's2ag_f32_wgrad_tr_scratch_floats', 's2ag_tcn32_pack_elems', 's2ag_tcn32_keep_bytes') else ci
+                              's2ag_f32_wgrad_tr_scratch_floats', 's2ag_f32_wgrad_tr_scratch_floats_n', 's2ag_tcn32_pack_elems', 's2ag_tcn32_keep_bytes') else ci
     if lib.s2ag_abi_version() != 1:
         raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
     _lib = lib

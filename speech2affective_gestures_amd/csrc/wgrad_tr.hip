@@ -668,10 +668,10 @@ extern "C" int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njo
  * multiples of 4; products from two bf16 pieces per operand (16 mantissa bits), fp32 accumulation. */
 // (A 160 x 128 variant with two register sets and two workgroups per CU -- one's loader beside the other's MFMAs -- spilled
 // 87 VGPRs at the 256-register cap and ran at half the speed: measured, removed.)
-extern "C" long long s2ag_f32_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args* jobs, int njobs) {
+extern "C" long long s2ag_f32_wgrad_tr_scratch_floats_n(const s2ag_bf16_wgrad_args* jobs, int njobs, int blocks) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS) return S2AG_E_BADARG;
     const int TCO = 160, TK = 160;
-    const int target = target_blocks32();
+    const int target = blocks > 0 ? blocks : target_blocks32();
     long long tot = 0;
     const int rpb = rows_per_block(jobs, njobs, TCO, TK, target);
     for (int k = 0; k < njobs; ++k) {
@@ -683,11 +683,11 @@ extern "C" long long s2ag_f32_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args
     return tot;
 }
 
-extern "C" int s2ag_f32_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njobs, float* scratch, long long scratch_floats,
-                                 void* stream) {
+extern "C" int s2ag_f32_wgrad_tr_n(const s2ag_bf16_wgrad_args* jobs, int njobs, float* scratch, long long scratch_floats,
+                                   int blocks, void* stream) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS || !scratch) return S2AG_E_BADARG;
     const int TCO = 160, TK = 160;
-    const int target = target_blocks32();
+    const int target = blocks > 0 ? blocks : target_blocks32();
     TrJobs js{};
     static const int remap = [] { const char* e = getenv("S2AG_WGRAD_TR_XCD"); return e ? atoi(e) : 1; }();
     js.xcd_remap = remap;
@@ -720,6 +720,15 @@ extern "C" int s2ag_f32_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njobs, fl
     else hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, false>), rgrid, dim3(256), 0, st, js);
     S2AG_LAUNCH_CHECK();
     return 0;
+}
+
+// default workgroup count (96: beside a cooperative recurrence, see target_blocks32)
+extern "C" long long s2ag_f32_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args* jobs, int njobs) {
+    return s2ag_f32_wgrad_tr_scratch_floats_n(jobs, njobs, 0);
+}
+extern "C" int s2ag_f32_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njobs, float* scratch, long long scratch_floats,
+                                 void* stream) {
+    return s2ag_f32_wgrad_tr_n(jobs, njobs, scratch, scratch_floats, 0, stream);
 }
 
 extern "C" int s2ag_wgrad_tr_set_trace(void* buf) {

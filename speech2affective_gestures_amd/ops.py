@@ -733,6 +733,12 @@ def add_act(a: Tensor, b: Optional[Tensor], slope: float) -> Tensor:
 # clip-resident TemporalConvNet forward of the fp32 step (csrc/tcn_fused32.hip)
 # ----------------------------------------------------------------------------------------------------
 TCN_FUSED32 = __import__('os').environ.get('S2AG_TCN_FUSED32', '1') != '0'
+TCN_FUSED32_BWD = __import__('os').environ.get('S2AG_TCN_FUSED32_BWD', '1') != '0'
+# the TCN's eight weight gradients right behind its data-gradient chain on the SAME stream: forked, they queue behind the last
+# GRU layer's weight gradients on the weight-gradient stream and the step ends waiting for them (15 190 forked vs 15 700
+# inline clips/s; layer-by-layer backward 14 980-15 290)
+TCN32_WGRAD_INLINE = __import__('os').environ.get('S2AG_TCN32_WGRAD_INLINE', '1') == '1'
+TCN32_WGRAD_BLOCKS = int(__import__('os').environ.get('S2AG_TCN32_WGRAD_BLOCKS', '256'))
 
 
 def tcn_fused32_supported(T: int, Cch: int, ks: int, n_blocks: int) -> bool:
@@ -794,7 +800,7 @@ class _TcnFused32(torch.autograd.Function):
             keep = torch.empty(int(lib.s2ag_tcn32_keep_bytes(B, nb)), dtype=torch.uint8, device=x.device)
             a.rng, a.keep = noise.data_ptr(), keep.data_ptr()
         L.check(lib.s2ag_tcn32_fwd(C.byref(a), _stream()), 'tcn32_fwd')
-        ctx.meta, ctx.noise, ctx.params, ctx.shape = meta, noise, params, (B, T, Cch)
+        ctx.meta, ctx.noise, ctx.params, ctx.shape, ctx.frags = meta, noise, params, (B, T, Cch), frags
         ctx.save_for_backward(x2, saved)
         return saved[3 * nb - 1].view(B, T, Cch)
 
@@ -809,6 +815,53 @@ class _TcnFused32(torch.autograd.Function):
         rows = B * T
         grads = [None] * (4 * nb)
         g = gy.reshape(rows, Cch)
+        need_w = [ctx.needs_input_grad[4 + k] for k in range(2 * nb)]
+        need_b = [bs[k] is not None and ctx.needs_input_grad[4 + 2 * nb + k] for k in range(2 * nb)]
+        wsl = [_grad_slot(ws[k]) if need_w[k] else None for k in range(2 * nb)]
+        bsl = [_grad_slot(bs[k]) if need_b[k] else None for k in range(2 * nb)]
+        if (TCN_FUSED32_BWD and T >= 32 and all(need_w) and all(sl is not None for sl in wsl)
+                and all((not nb_) or sl is not None for nb_, sl in zip(need_b, bsl))):
+            # the whole chain of data gradients in ONE launch (csrc/tcn_fused32.hip), the eight weight (+ bias) gradients
+            # in one transpose-read launch on the weight-gradient stream
+            lib = _lib()
+            g2, _, _, ldg = as_rows(g)
+            if ldg != Cch:
+                g2 = g2.contiguous()
+            gx = torch.empty(rows, Cch, dtype=torch.float32, device=g2.device)
+            gp = torch.empty(2 * nb, rows, Cch, dtype=torch.float32, device=g2.device)
+            a = L.Tcn32()
+            a.wfrag = ctx.frags.get(ws).data_ptr()
+            for b in range(nb):
+                a.h1[b], a.h2[b], a.y[b] = saved[3 * b].data_ptr(), saved[3 * b + 1].data_ptr(), saved[3 * b + 2].data_ptr()
+                a.gp1[b], a.gp2[b] = gp[2 * b].data_ptr(), gp[2 * b + 1].data_ptr()
+                a.dil[b] = int(dils[b])
+            a.n_blocks, a.n_clips, a.T, a.C = nb, B, T, Cch
+            a.drop_p = float(drop_p)
+            a.gy, a.gx = g2.data_ptr(), gx.data_ptr()
+            L.check(lib.s2ag_tcn32_bwd(C.byref(a), _stream()), 'tcn32_bwd')
+            jobs = (L.BF16Wgrad * (2 * nb))()
+            for b in range(nb):
+                d = int(dils[b])
+                for j in range(2):
+                    k = 2 * b + j
+                    xin = (x2.view(rows, Cch) if b == 0 else saved[3 * (b - 1) + 2]) if j == 0 else saved[3 * b]
+                    jobs[k] = L.BF16Wgrad(_p(gp[k]), _p(xin), _p(wsl[k]), _p(bsl[k]), B, T, T, T * Cch, Cch, Cch, 1, -d, d, 2,
+                                          Cch, Cch, Cch, Cch, 2 * Cch, Cch, 1, 0, 2)
+            nblk = TCN32_WGRAD_BLOCKS           # no recurrence runs beside this launch: the whole chip
+            sc = _gru_wgrad_scratch(g2.device, (id(ctx.frags), 'tcn32', B, T),
+                                    int(lib.s2ag_f32_wgrad_tr_scratch_floats_n(jobs, 2 * nb, nblk)))
+
+            def launch(jobs=jobs, sc=sc):
+                L.check(lib.s2ag_f32_wgrad_tr_n(jobs, 2 * nb, _p(sc), sc.numel(), nblk, _stream()), 'f32_wgrad_tr')
+            if TCN32_WGRAD_INLINE:
+                launch()
+            else:
+                run_wgrad(launch, keep=(gp, saved, x2), flops=2.0 * rows * Cch * Cch * 2 * 2 * nb)
+            for k in range(2 * nb):
+                _note_staged(ws[k])
+                if bs[k] is not None:
+                    _note_staged(bs[k])
+            return (gx.view(B, T, Cch) if ctx.needs_input_grad[0] else None, None, None, None) + tuple(grads)
         for b in range(nb - 1, -1, -1):
             d = int(dils[b])
             h1, h2, yb = saved[3 * b], saved[3 * b + 1], saved[3 * b + 2]

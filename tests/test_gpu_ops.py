@@ -825,8 +825,8 @@ def test_touched_row_exchange_kernels(S, n_entries, dim, world, cap, n_tok):
     ops._COOP_FLAG[0].zero_()
 
 
-@pytest.mark.parametrize('B,train', [(5, True), (33, True), (4, False)])
-def test_clip_resident_tcn_forward_fp32_equals_the_layer_by_layer_path(S, B, train, monkeypatch):
+@pytest.mark.parametrize('B,train,slots', [(5, True, False), (33, True, False), (33, True, True), (6, True, True), (4, False, False)])
+def test_clip_resident_tcn_forward_fp32_equals_the_layer_by_layer_path(S, B, train, slots, monkeypatch):
     """csrc/tcn_fused32.hip (the four TemporalBlocks in one launch, fp32 rows in LDS, two-piece bf16 products) against the
     layer-by-layer kernels (conv_sp_k: the same two-piece products) on the same weights and noise stream: outputs and
     every parameter gradient (the backward pass is the layer-by-layer one on the tensors the fused forward leaves)."""
@@ -846,7 +846,9 @@ def test_clip_resident_tcn_forward_fp32_equals_the_layer_by_layer_path(S, B, tra
     for fused in (False, True):
         monkeypatch.setattr(ops, 'TCN_FUSED32', fused)
         for p in txt.parameters():
-            p.grad = None
+            # gradient slots exist (as in the trainer's arenas): the kernels accumulate into them, which is also what
+            # switches on the one-launch data-gradient chain + the one-launch weight gradients of the fused path
+            p.grad = torch.zeros_like(p) if slots else None
         ops.begin_step()
         noise.manual_seed(5)
         assert ops.tcn_fused32_supported(34, 300, 2, 4) == fused
