@@ -97,7 +97,8 @@ def matrix_products_mode():
     np_ = int(L.load().s2ag_gru_coop_split_pieces())
     return {0: 'f32 MFMA (v_mfma_f32_16x16x4_f32) everywhere',
             2: 'fp32 operands as 2 bf16 pieces (3 products, 16 mantissa bits, fp32 accumulation) on the bf16 matrix pipe for '
-               'the GRU recurrence, its input projections / input gradients and the big convs forward; f32 MFMA elsewhere',
+               'the GRU recurrence, its input projections / input gradients / weight gradients and the text TCN (forward, '
+               'data and weight gradients); f32 MFMA elsewhere',
             3: 'fp32 operands as 3 bf16 pieces (6 products, fp32-equivalent, fp32 accumulation) on the bf16 matrix pipe for '
                'the GRU recurrence, its input projections / input gradients and the big convs forward; f32 MFMA elsewhere'
             }[np_]

@@ -743,7 +743,7 @@ TCN32_WGRAD_BLOCKS = int(__import__('os').environ.get('S2AG_TCN32_WGRAD_BLOCKS',
 
 def tcn_fused32_supported(T: int, Cch: int, ks: int, n_blocks: int) -> bool:
     lib = _lib()
-    return (TCN_FUSED32 and SPLIT_CONV and 1 <= n_blocks <= 4 and lib.s2ag_gru_coop_split_pieces() != 0
+    return (TCN_FUSED32 and SPLIT_CONV and 1 <= n_blocks <= 4 and lib.s2ag_gru_coop_split_pieces() == 2
             and bool(lib.s2ag_tcn32_supported(int(T), int(Cch), int(ks))))
 
 
@@ -1448,7 +1448,7 @@ class _GRU(torch.autograd.Function):
             if all(sl is not None for sl in slots) and pair_ih is not None and pair_bi is not None:
                 # arena layout: the two directions are adjacent, so dW_ih / db_ih of both are one launch each
                 def leaves(dgi=dgi, dgh=dgh, y=y, inp=inp, In=In, pair_ih=pair_ih, pair_bi=pair_bi, slots=slots, l=l):
-                    if (GRU_WGRAD_TR and lib.s2ag_gru_coop_split_pieces() != 0 and T >= 32 and In % 4 == 0 and H % 4 == 0
+                    if (GRU_WGRAD_TR and lib.s2ag_gru_coop_split_pieces() == 2 and T >= 32 and In % 4 == 0 and H % 4 == 0
                             and 2.0 * B * T * (In + H) * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
                         # the layer's three weight gradients on the bf16 pipe through the LDS transpose read
                         # (csrc/wgrad_tr.hip, fp32 rows split into two bf16 pieces by the loader): one launch + reduce
