@@ -587,6 +587,13 @@ bool big_tiles(const s2ag_bf16_wgrad_args* jobs, int n) {
     return true;
 }
 
+// fp32 form: 160 x 160 tiles unless a weight is small or flat-window (the wave encoder's convs)
+bool big_tiles32(const s2ag_bf16_wgrad_args* jobs, int n) {
+    for (int k = 0; k < n; ++k)
+        if (jobs[k].Cout <= 128 || jobs[k].flat_cin > 0) return false;
+    return true;
+}
+
 unsigned long long* g_tr_trace = nullptr;
 
 // Workgroups of the fp32 form (one per CU: 506 VGPRs).  96, not 256: the launch runs beside the next layer's cooperative
@@ -670,8 +677,9 @@ extern "C" int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njo
 // 87 VGPRs at the 256-register cap and ran at half the speed: measured, removed.)
 extern "C" long long s2ag_f32_wgrad_tr_scratch_floats_n(const s2ag_bf16_wgrad_args* jobs, int njobs, int blocks) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS) return S2AG_E_BADARG;
-    const int TCO = 160, TK = 160;
-    const int target = blocks > 0 ? blocks : target_blocks32();
+    const bool big = big_tiles32(jobs, njobs);                    // small / flat-window weights (the wave encoder): 64 x 64 tiles
+    const int TCO = big ? 160 : 64, TK = big ? 160 : 64;
+    const int target = blocks > 0 ? blocks : (big ? target_blocks32() : 1024);
     long long tot = 0;
     const int rpb = rows_per_block(jobs, njobs, TCO, TK, target);
     for (int k = 0; k < njobs; ++k) {
@@ -686,8 +694,9 @@ extern "C" long long s2ag_f32_wgrad_tr_scratch_floats_n(const s2ag_bf16_wgrad_ar
 extern "C" int s2ag_f32_wgrad_tr_n(const s2ag_bf16_wgrad_args* jobs, int njobs, float* scratch, long long scratch_floats,
                                    int blocks, void* stream) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS || !scratch) return S2AG_E_BADARG;
-    const int TCO = 160, TK = 160;
-    const int target = blocks > 0 ? blocks : target_blocks32();
+    const bool big = big_tiles32(jobs, njobs);                    // small / flat-window weights (the wave encoder): 64 x 64 tiles
+    const int TCO = big ? 160 : 64, TK = big ? 160 : 64;
+    const int target = blocks > 0 ? blocks : (big ? target_blocks32() : 1024);
     TrJobs js{};
     static const int remap = [] { const char* e = getenv("S2AG_WGRAD_TR_XCD"); return e ? atoi(e) : 1; }();
     js.xcd_remap = remap;
@@ -715,9 +724,15 @@ extern "C" int s2ag_f32_wgrad_tr_n(const s2ag_bf16_wgrad_args* jobs, int njobs, 
     const bool direct = ms <= 16;
     const dim3 grid(nblk), rgrid(cdiv(max_red, direct ? 256 : 32), njobs);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((wgrad_tr32_k<160, 160, 3, 1>), grid, dim3(256), 0, st, js);
-    if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, true>), rgrid, dim3(256), 0, st, js);
-    else hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, false>), rgrid, dim3(256), 0, st, js);
+    if (big) {
+        hipLaunchKernelGGL((wgrad_tr32_k<160, 160, 3, 1>), grid, dim3(256), 0, st, js);
+        if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, true>), rgrid, dim3(256), 0, st, js);
+        else hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, false>), rgrid, dim3(256), 0, st, js);
+    } else {
+        hipLaunchKernelGGL((wgrad_tr32_k<64, 64, 3, 2>), grid, dim3(256), 0, st, js);
+        if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<64, 64, true>), rgrid, dim3(256), 0, st, js);
+        else hipLaunchKernelGGL((wgrad_tr_reduce_k<64, 64, false>), rgrid, dim3(256), 0, st, js);
+    }
     S2AG_LAUNCH_CHECK();
     return 0;
 }

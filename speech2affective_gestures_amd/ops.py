@@ -430,8 +430,24 @@ class _ConvNLC(torch.autograd.Function):
         elif need_db:
             colsum_raw(g, db)
         if wslot is not None or bslot is not None:
+            lib = _lib()
+            xr, _, _, ldx_ = as_rows(x)
+            # strided convs whose window is contiguous in memory (no padding, dilation 1, reference-layout weight: the wave
+            # encoder's conv2-4): weight gradient through the LDS transpose read with the window as ONE tap of ks*Cin channels
+            flat_tr = (CONV_WGRAD_TR and wslot is not None and not wtm and pad == 0 and dil == 1 and ks > 1 and ldx_ == Cin
+                       and Cin % 4 == 0 and Cout % 4 == 0 and Lout >= 32 and flops >= 4e8
+                       and lib.s2ag_gru_coop_split_pieces() == 2)
+
             def leaves():
-                if wslot is not None:      # the bias gradient rides along in the same launch
+                if flat_tr:
+                    gg, _, _, ldg_ = as_rows(g)
+                    job = (L.BF16Wgrad * 1)()
+                    job[0] = L.BF16Wgrad(_p(gg), _p(xr), _p(wslot), _p(bslot), N, Lout, Lin, Lin * ldx_, ldx_, ldg_, stride, 0, 0,
+                                         1, (ks * Cin + 3) // 4 * 4, ks * Cin, Cout, Cin, Cin * ks, 1, ks, Cin, ks)
+                    sc = _gru_wgrad_scratch(g.device, (id(ctx.w_leaf), N, Lout),
+                                            int(lib.s2ag_f32_wgrad_tr_scratch_floats(job, 1)))
+                    L.check(lib.s2ag_f32_wgrad_tr(job, 1, _p(sc), sc.numel(), _stream()), 'f32_wgrad_tr')
+                elif wslot is not None:      # the bias gradient rides along in the same launch
                     conv_bwd_weight_raw(g, x, wslot, N, Lin, Lout, Cin, Cout, ks, stride, pad, dil, True, wtm,
                                         dbias=bslot)
                 elif bslot is not None:
@@ -1296,6 +1312,7 @@ def _gru_proj_split(inp, wih, wih_r, wih2, bih2, gi, In):
 
 
 GRU_WGRAD_TR = __import__('os').environ.get('S2AG_GRU_WGRAD_TR', '1') != '0'
+CONV_WGRAD_TR = __import__('os').environ.get('S2AG_CONV_WGRAD_TR', '1') != '0'
 _GRU_WG_SCRATCH = {}
 
 
