@@ -234,6 +234,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_stats_k(const float* __restrict__ x
         static_assert(!FLAT || NT == 256, "flat walk: 256 threads");
         const long long total = (long long)rows * cols;
         double a = 0.0, b = 0.0;
+#pragma unroll 8
         for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long long)nrb * 256) {
             const double v = (double)x[i];
             a += v;
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_stats_k(const float* __restrict__ x
         const long long total = (long long)rows * cols;
         const int c = threadIdx.x % cols;
         const float sc = ld_agent(scale_col + c), sh = ld_agent(shift_col + c);
+#pragma unroll 8
         for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long long)nrb * 256)
             y[i] = leaky(x[i] * sc + sh, act_slope);
     } else {
@@ -516,6 +518,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_k(const float* __restrict__ x
         const int c = threadIdx.x % cols;
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
         float p = 0.f, q = 0.f;
+#pragma unroll 8
         for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long long)nrb * 256) {
             const float xv = x[i];
             const float pre = xv * sc + sh;
@@ -591,6 +594,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_k(const float* __restrict__ x
         const int c = threadIdx.x % cols;
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
         const float k1 = ld_agent(c1 + c), k2 = ld_agent(c2 + c);
+#pragma unroll 8
         for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long long)nrb * 256) {
             const float xv = x[i];
             const float d = dy[i] * (xv * sc + sh > 0.f ? 1.f : slope);
