@@ -329,6 +329,17 @@ int s2ag_gru_coop_set_split_pieces(int pieces /*0, 2, 3; anything else: back to 
 long long s2ag_gru_coop_workspace_bytes(int B, int T, int H, int backward);
 int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* ydrop, float* gates,
                       int B, int T, int H, const s2ag_epilogue* e /*host, nullable*/, void* workspace, void* stream);
+/* One layer of up to four forward passes over the SAME weights in ONE launch (the trainer's three generator passes of
+ * a step -- processor_v2.py:798, :823, :909 -- run layer by layer in lockstep): pass i has its own input projections
+ * gi[i], outputs y[i] / ydrop[i] / gates[i] (arrays of n device pointers on the HOST; ydrop / gates nullable as a
+ * whole or per pass) and noise snapshot rng[i]; drop_p and site are the layer's.  A launch is bound by the latency of
+ * its T exchanges, not by its width.  _supported = 0: issue s2ag_gru_coop_fwd per pass instead. */
+int s2ag_gru_coop_fwd_multi_supported(int n, int B, int H);
+long long s2ag_gru_coop_fwd_multi_workspace_bytes(int n, int B, int T, int H);
+int s2ag_gru_coop_fwd_multi(int n, const float* const* gi, const float* whh, const float* bhh, float* const* y,
+                            float* const* ydrop, float* const* gates, int B, int T, int H, float drop_p,
+                            const unsigned long long* const* rng, unsigned site, void* workspace, void* stream);
+int s2ag_gru_coop_fwd_multi_error_word_offset(int n, int B, int T, int H, long long* offset /*host*/);
 int s2ag_gru_coop_bwd(const float* dy, int lddy, int dy_dir_stride, const float* whh, const float* y,
                       const float* gates, float* dgi, float* dgh, int B, int T, int H,
                       const s2ag_epilogue* e /*host, nullable*/, void* workspace, void* stream);

@@ -128,6 +128,10 @@ SIGNATURES = {
     's2ag_gru_coop_set_split_pieces': [ci],
     's2ag_gru_coop_workspace_bytes': [ci, ci, ci, ci],
     's2ag_gru_coop_fwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp, vp],
+    's2ag_gru_coop_fwd_multi_supported': [ci, ci, ci],
+    's2ag_gru_coop_fwd_multi_workspace_bytes': [ci, ci, ci, ci],
+    's2ag_gru_coop_fwd_multi': [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, vp, cu, vp, vp],
+    's2ag_gru_coop_fwd_multi_error_word_offset': [ci, ci, ci, ci, C.POINTER(cll)],
     's2ag_gru_coop_bwd': [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp, vp],
     's2ag_gru_coop_error_word_offset': [ci, ci, ci, ci, C.POINTER(cll)],
     's2ag_gru_coop_set_error_flag': [vp],
@@ -208,7 +212,7 @@ def load():
         except AttributeError as e:
             raise S2AGLibraryError(f'{path} lacks symbol {name}; rebuild it') from e
         fn.argtypes = args
-        fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes', 's2ag_bf16_tcn_keep_bytes',
+        fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_gru_coop_fwd_multi_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes', 's2ag_bf16_tcn_keep_bytes',
                               's2ag_bf16_conv_wgrad_scratch_floats', 's2ag_bf16_conv_wgrad_tr_scratch_floats',
                               's2ag_f32_wgrad_tr_scratch_floats', 's2ag_f32_wgrad_tr_scratch_floats_n', 's2ag_tcn32_pack_elems', 's2ag_tcn32_keep_bytes') else ci
     if lib.s2ag_abi_version() != 1:

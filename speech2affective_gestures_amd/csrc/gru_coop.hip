@@ -513,12 +513,33 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_sp_k(const float* __restrict
 // Roles: waves 0..3 do the gate math, two (clip, unit) pairs per thread, and all the stores; waves 4..11 gather -- a
 // wave's loads cannot be consumed before its earlier stores are acknowledged (one in-order counter), and the gate waves
 // have just published the other slice.  Ten cells per gathering thread, all in flight at once.
+// Several PASSES per launch: the trainer runs the generator three times per step on the same weights (for D, for the
+// loss, with shuffled speakers; processor_v2.py:798, :823, :909); run layer by layer in lockstep, the recurrences of a
+// layer are independent slices of one launch -- blockIdx.y = pass * pairs_per_pass + slice pair -- with their own
+// input projections, outputs, exchange cells and noise snapshot.  A launch is bound by the latency of its T exchanges,
+// not by its width: three passes cost one pass's time.
+constexpr int COOP_MAX_PASSES = 4;
+struct CoopFwdPasses {
+    const float* gi[COOP_MAX_PASSES];
+    float* y[COOP_MAX_PASSES];
+    float* ydrop[COOP_MAX_PASSES];
+    float* gates[COOP_MAX_PASSES];
+    const unsigned long long* rng[COOP_MAX_PASSES];
+    int pairs_per_pass;
+    long long cells_per_pass;
+};
+
 template <int H, int HW_, int NP, int NS>
-__global__ __launch_bounds__(CNT) void gru_coop_fwd_sp2_k(const float* __restrict__ gi, const float* __restrict__ whh,
-                                                          const float* __restrict__ bhh, float* __restrict__ y,
-                                                          float* __restrict__ ydrop, float* __restrict__ gates,
-                                                          u64* xbuf, int* err, int B, int T, float drop_p,
-                                                          float inv_keep, const unsigned long long* rng, unsigned site) {
+__global__ __launch_bounds__(CNT) void gru_coop_fwd_sp2_k(const CoopFwdPasses P, const float* __restrict__ whh,
+                                                          const float* __restrict__ bhh, u64* xbuf, int* err, int B,
+                                                          int T, float drop_p, float inv_keep, unsigned site) {
+    const int pass = blockIdx.y / P.pairs_per_pass;
+    const float* __restrict__ gi = P.gi[pass];
+    float* __restrict__ y = P.y[pass];
+    float* __restrict__ ydrop = P.ydrop[pass];
+    float* __restrict__ gates = P.gates[pass];
+    const unsigned long long* rng = P.rng[pass];
+    xbuf += (size_t)pass * P.cells_per_pass;
     constexpr int H3 = 3 * H;
     constexpr int NW_ = 3 * HW_;
     constexpr int NTILES = NW_ / 16;
@@ -537,7 +558,7 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_sp2_k(const float* __restric
     extern __shared__ __attribute__((aligned(16))) unsigned short hsb2[];          // [slice][piece][clip][k]
     __shared__ float red[KSPLIT][CBS][RP];
 
-    const int s = blockIdx.x, bpair = blockIdx.y, dir = blockIdx.z;
+    const int s = blockIdx.x, bpair = blockIdx.y - pass * P.pairs_per_pass, dir = blockIdx.z;
     const int nbs = (B + CBS - 1) / CBS;           // 16-clip slices in the batch
     const int u0 = s * HW_;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1044,6 +1065,51 @@ extern "C" long long s2ag_gru_coop_workspace_bytes(int B, int T, int H, int back
     return (long long)(coop_payload_bytes(B, H, backward) + 256);
 }
 
+namespace {
+// one launch of the two-slice kernel over ``n`` passes (see CoopFwdPasses); workspace = n exchange buffers + error word
+int launch_fwd_sp2(int n, const float* const* gi, const float* whh, const float* bhh, float* const* y,
+                   float* const* ydrop, float* const* gates, int B, int T, float p,
+                   const unsigned long long* const* rng, unsigned site, void* workspace, hipStream_t stream) {
+    const size_t per_pass = coop_payload_bytes(B, 300, 0);
+    u64* x = reinterpret_cast<u64*>(workspace);
+    int* err = g_sticky_err ? g_sticky_err : reinterpret_cast<int*>(static_cast<char*>(workspace) + n * per_pass);
+    hipError_t ze = zero_async(x, n * per_pass + 256, stream);
+    if (ze != hipSuccess) return (int)ze;
+    const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const int np = coop_split_pieces();
+    int smem2 = 2 * np * CBS * (5 * 2 * 32 + 8) * 2;                   // [slice][piece][clip][k] bf16
+    static const int reserve_f = [] { const char* e = getenv("S2AG_COOP_FWD_LDS_RESERVE"); return (e ? atoi(e) : 0) * 1024; }();
+    if (reserve_f > smem2) smem2 = reserve_f;                          // CU reservation, see s2ag_gru_coop_bwd
+    const void* fn2 = np == 3 ? reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 3, 2>)
+                              : reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 2, 2>);
+    static bool granted2[4] = {false, false, false, false};
+    if (!granted2[np]) {
+        hipError_t ae = hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+        if (ae != hipSuccess) return (int)ae;
+        granted2[np] = true;
+    }
+    CoopFwdPasses P{};
+    for (int i = 0; i < n; ++i) {
+        P.gi[i] = gi[i];
+        P.y[i] = y[i];
+        P.ydrop[i] = ydrop ? ydrop[i] : nullptr;
+        P.gates[i] = gates ? gates[i] : nullptr;
+        P.rng[i] = rng ? rng[i] : nullptr;
+    }
+    P.pairs_per_pass = cdiv(B, 2 * CBS);
+    P.cells_per_pass = (long long)(per_pass / sizeof(u64));
+    const dim3 grid2(10, n * P.pairs_per_pass, 2);
+    if (np == 3)
+        hipLaunchKernelGGL((gru_coop_fwd_sp2_k<300, 32, 3, 2>), grid2, dim3(CNT), smem2, stream, P, whh, bhh, x, err, B, T,
+                           p, ik, site);
+    else
+        hipLaunchKernelGGL((gru_coop_fwd_sp2_k<300, 32, 2, 2>), grid2, dim3(CNT), smem2, stream, P, whh, bhh, x, err, B, T,
+                           p, ik, site);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
 extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* ydrop,
                                  float* gates, int B, int T, int H, const s2ag_epilogue* e, void* workspace,
                                  void* stream) {
@@ -1051,36 +1117,15 @@ extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float*
     if (!s2ag_gru_coop_supported(H)) return S2AG_E_UNSUPPORTED;
     const float p = (e && ydrop) ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
+    const unsigned long long* rg = e ? e->rng : nullptr;
+    const unsigned site = e ? e->site : 0u;
+    if (coop_split_pieces() != 0 && B > CBS && coop_two_slices())
+        return launch_fwd_sp2(1, &gi, whh, bhh, &y, &ydrop, &gates, B, T, p, &rg, site, workspace, (hipStream_t)stream);
     Ws w = carve(workspace, B, H, 0);
     hipError_t ze = zero_async(w.x, w.zero_bytes, (hipStream_t)stream);
     if (ze != hipSuccess) return (int)ze;
     const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    const unsigned long long* rg = e ? e->rng : nullptr;
-    const unsigned site = e ? e->site : 0u;
     const dim3 grid(10, cdiv(B, CBS), 2);
-    if (coop_split_pieces() != 0 && B > CBS && coop_two_slices()) {
-        const int np = coop_split_pieces();
-        int smem2 = 2 * np * CBS * (5 * 2 * 32 + 8) * 2;                   // [slice][piece][clip][k] bf16
-        static const int reserve_f = [] { const char* e = getenv("S2AG_COOP_FWD_LDS_RESERVE"); return (e ? atoi(e) : 0) * 1024; }();
-        if (reserve_f > smem2) smem2 = reserve_f;                          // CU reservation, see s2ag_gru_coop_bwd
-        const void* fn2 = np == 3 ? reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 3, 2>)
-                                  : reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 2, 2>);
-        static bool granted2[4] = {false, false, false, false};
-        if (!granted2[np]) {
-            hipError_t ae = hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
-            if (ae != hipSuccess) return (int)ae;
-            granted2[np] = true;
-        }
-        const dim3 grid2(10, cdiv(B, 2 * CBS), 2);
-        if (np == 3)
-            hipLaunchKernelGGL((gru_coop_fwd_sp2_k<300, 32, 3, 2>), grid2, dim3(CNT), smem2, (hipStream_t)stream, gi, whh,
-                               bhh, y, ydrop, gates, w.x, w.err, B, T, p, ik, rg, site);
-        else
-            hipLaunchKernelGGL((gru_coop_fwd_sp2_k<300, 32, 2, 2>), grid2, dim3(CNT), smem2, (hipStream_t)stream, gi, whh,
-                               bhh, y, ydrop, gates, w.x, w.err, B, T, p, ik, rg, site);
-        S2AG_LAUNCH_CHECK();
-        return 0;
-    }
     switch (coop_split_pieces()) {
         case 2:
             hipLaunchKernelGGL((gru_coop_fwd_sp_k<300, 32, 2>), grid, dim3(CNT), 0, (hipStream_t)stream, gi, whh, bhh, y,
@@ -1095,6 +1140,40 @@ extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float*
                                gates, w.x, w.err, B, T, p, ik, rg, site);
     }
     S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same layer of up to four passes over the SAME weights in one launch (passes differ in input projections, outputs
+// and noise snapshot; drop_p / site are the layer's).  1 = the launch exists for this configuration, else the caller
+// issues s2ag_gru_coop_fwd per pass.
+extern "C" int s2ag_gru_coop_fwd_multi_supported(int n, int B, int H) {
+    return (s2ag_gru_coop_supported(H) && n >= 1 && n <= COOP_MAX_PASSES && coop_split_pieces() != 0 && B > CBS &&
+            coop_two_slices() && 10 * n * cdiv(B, 2 * CBS) * 2 <= 256) ? 1 : 0;
+}
+extern "C" long long s2ag_gru_coop_fwd_multi_workspace_bytes(int n, int B, int T, int H) {
+    if (n <= 0 || B <= 0 || T <= 0 || !s2ag_gru_coop_supported(H)) return 0;
+    return (long long)(n * coop_payload_bytes(B, H, 0) + 256);
+}
+extern "C" int s2ag_gru_coop_fwd_multi(int n, const float* const* gi, const float* whh, const float* bhh,
+                                       float* const* y, float* const* ydrop, float* const* gates, int B, int T, int H,
+                                       float drop_p, const unsigned long long* const* rng, unsigned site,
+                                       void* workspace, void* stream) {
+    if (!gi || !whh || !bhh || !y || !workspace || B <= 0 || T <= 0) return S2AG_E_BADARG;
+    if (!s2ag_gru_coop_fwd_multi_supported(n, B, H)) return S2AG_E_UNSUPPORTED;
+    float p = 0.f;
+    for (int i = 0; i < n; ++i) {
+        if (!gi[i] || !y[i]) return S2AG_E_BADARG;
+        if (ydrop && ydrop[i]) p = drop_p;
+    }
+    if (p > 0.f)
+        for (int i = 0; i < n; ++i)
+            if (!ydrop[i] || !rng || !rng[i]) return S2AG_E_BADARG;       // a dropping layer drops in every pass
+    return launch_fwd_sp2(n, gi, whh, bhh, y, ydrop, gates, B, T, p, rng, site, workspace, (hipStream_t)stream);
+}
+extern "C" int s2ag_gru_coop_fwd_multi_error_word_offset(int n, int B, int T, int H, long long* offset) {
+    (void)T;
+    if (!offset || !s2ag_gru_coop_supported(H) || n <= 0) return S2AG_E_BADARG;
+    *offset = (long long)(n * coop_payload_bytes(B, H, 0));
     return 0;
 }
 

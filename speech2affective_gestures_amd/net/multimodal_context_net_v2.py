@@ -77,12 +77,14 @@ class GRU(nn.Module):
                         getattr(self, f'bias_ih_l{l}{suf}'), getattr(self, f'bias_hh_l{l}{suf}')]
         return out
 
-    def run(self, x, noise, sum_dirs):
+    def run(self, x, noise, sum_dirs, mates=()):
+        """``mates`` = [(x_i, noise_i), ...]: no-grad passes run in lockstep with this one (ops._GRU.forward); the
+        result is then (out, *mate_outs)."""
         if not self._packed_checked:
             self._pack_frozen()
             self._packed_checked = True
         return ops.gru(x, self.flat_weights(), self.hidden_size, self.num_layers, self.training, self.dropout, noise,
-                       self.site0, sum_dirs)
+                       self.site0, sum_dirs, mates)
 
     def forward(self, x, hx=None):
         if hx is not None:
@@ -511,6 +513,42 @@ class PoseGenerator(nn.Module, _SpeakerZ):
             out = self._decode(self._context(pre, audio, text), z_context, nz, out_slope=0.01)
             z_mu, z_log_var = self._cut_here(z_mu, z_log_var)
         return out, z_context, z_mu, z_log_var
+
+
+    def forward_passes(self, pre_seq, in_text, in_mfcc, passes):
+        """Several passes of this generator over the same inputs in LOCKSTEP: ``passes`` = [(vid_indices, noise
+        snapshot, grad), ...]; only the first may carry autograd.  The trainer's three passes of a step
+        (processor_v2.py:798, :823, :909) differ in noise (and speakers) only, and the recurrent decoder is bound by
+        the latency of its T exchanges, not by its width: each decoder layer of all passes is ONE cooperative launch.
+        Needs the shared encoders (``share_passes``).  Returns [(out, z_context, z_mu, z_log_var), ...]."""
+        from ..noise import use_pass
+        assert self.share_passes and self.input_context != 'none' and not any(g for _, _, g in passes[1:])
+        outer = torch.is_grad_enabled()
+        feats = []
+        for k, (vid, nz, grad) in enumerate(passes):
+            with torch.set_grad_enabled(bool(grad) and outer), use_pass(nz):
+                z_context, z_mu, z_log_var = self._z(in_text, vid, nz)
+                text = self.text_encoder(in_text)[0]
+                pre, audio = self._shared_encoders(pre_seq, in_mfcc)
+                assert audio.shape[1] == text.shape[1]
+                in_data = self._context(pre, audio, text)
+                if z_context is not None:
+                    in_data = torch.cat((in_data, z_context.unsqueeze(1).expand(-1, in_data.shape[1], -1)), dim=2)
+                (in_data,) = self._cut_here(in_data)
+                feats.append((in_data, z_context, z_mu, z_log_var))
+        with torch.set_grad_enabled(bool(passes[0][2]) and outer):
+            hs = self.gru.run(feats[0][0], passes[0][1], True,
+                              mates=[(f[0], p[1]) for f, p in zip(feats[1:], passes[1:])])
+        if len(passes) == 1:
+            hs = (hs,)
+        res = []
+        for k, (h, (_, z_context, z_mu, z_log_var), (_, _, grad)) in enumerate(zip(hs, feats, passes)):
+            with torch.set_grad_enabled(bool(grad) and outer):
+                h = ops.linear(h, self.out[0].weight, self.out[0].bias, act=ACT_LEAKY, slope=0.01)
+                out = ops.linear(h, self.out[2].weight, self.out[2].bias)
+                z_mu, z_log_var = self._cut_here(z_mu, z_log_var)
+            res.append((out, z_context, z_mu, z_log_var))
+        return res
 
 
 class AffDiscriminator(nn.Module):

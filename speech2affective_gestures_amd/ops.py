@@ -1281,7 +1281,10 @@ def coop_gru_timeouts() -> int:
         return sum(int(f.item() != 0) for f in _COOP_FLAG.values())
     for ws, B, T, H, bwd in list(_COOP_WS):
         off = C.c_longlong(0)
-        L.check(lib.s2ag_gru_coop_error_word_offset(B, T, H, bwd, C.byref(off)), 'error_word_offset')
+        if bwd < 0:          # a lockstep forward launch over -bwd passes
+            L.check(lib.s2ag_gru_coop_fwd_multi_error_word_offset(-bwd, B, T, H, C.byref(off)), 'error_word_offset')
+        else:
+            L.check(lib.s2ag_gru_coop_error_word_offset(B, T, H, bwd, C.byref(off)), 'error_word_offset')
         bad += int(ws[off.value:off.value + 4].view(torch.int32).item() != 0)
     return bad
 
@@ -1331,74 +1334,104 @@ def _gru_wgrad_scratch(dev, owner, floats):
 
 class _GRU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, H, Lyr, training, drop_p, noise, site0, sum_dirs, need_grad, *weights):
+    def forward(ctx, x, H, Lyr, training, drop_p, noise, site0, sum_dirs, need_grad, mates, *weights):
+        """``mates``: [(x_i, noise_i), ...] -- further passes of the same stack over the same weights, without autograd
+        (the trainer's other generator passes of the step): run layer by layer in lockstep with the main pass, their
+        recurrences ride in the main pass's cooperative launch (s2ag_gru_coop_fwd_multi).  Returns (out, *mate_outs)
+        when given, else out."""
         _need_cuda(x, *weights)
         lib = _lib()
         B, T, I = x.shape
         dev = x.device
-        inp, _, _, _ = as_rows(x)
+        inps = [as_rows(x)[0]] + [as_rows(xm)[0] for xm, _ in mates]
+        noises = [noise] + [nm for _, nm in mates]
+        nP = len(inps)
+        for xm, _ in mates:
+            if tuple(xm.shape) != (B, T, I):
+                raise ValueError('lockstep passes must share the input shape')
         saved = []
         H3 = 3 * H
-        y = None
+        ys = None
         for l in range(Lyr):
             wih, whh, bih, bhh, wih_r, whh_r, bih_r, bhh_r = weights[8 * l:8 * l + 8]
             In = wih.shape[1]
-            gi = torch.empty(B * T, 2 * H3, dtype=torch.float32, device=dev)
             wih2, bih2 = _pair(wih, wih_r), _pair(bih, bih_r)
-            if (wih2 is not None and bih2 is not None and SPLIT_GEMM and lib.s2ag_gru_coop_split_pieces() != 0
-                    and 2.0 * B * T * In * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
-                # the big projections are bound by the f32 matrix pipe: same fp32 products on the bf16 pipe from
-                # operands split once (the weight: once per optimizer step), see gemm_sp.hip
-                _gru_proj_split(inp, wih, wih_r, wih2, bih2, gi, In)
-            elif wih2 is not None and bih2 is not None:          # both directions' input projections: one GEMM
-                conv_fwd_raw(inp, wih2, bih2, gi, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1)
-            else:
-                conv_fwd_raw(inp, wih, bih, gi[:, :H3], B * T, 1, 1, In, H3, 1, 1, 0, 1)
-                conv_fwd_raw(inp, wih_r, bih_r, gi[:, H3:], B * T, 1, 1, In, H3, 1, 1, 0, 1)
+            gis = []
+            for inp in inps:
+                gi = torch.empty(B * T, 2 * H3, dtype=torch.float32, device=dev)
+                if (wih2 is not None and bih2 is not None and SPLIT_GEMM and lib.s2ag_gru_coop_split_pieces() != 0
+                        and 2.0 * B * T * In * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
+                    # the big projections are bound by the f32 matrix pipe: same fp32 products on the bf16 pipe from
+                    # operands split once (the weight: once per optimizer step), see gemm_sp.hip
+                    _gru_proj_split(inp, wih, wih_r, wih2, bih2, gi, In)
+                elif wih2 is not None and bih2 is not None:          # both directions' input projections: one GEMM
+                    conv_fwd_raw(inp, wih2, bih2, gi, B * T, 1, 1, In, 2 * H3, 1, 1, 0, 1)
+                else:
+                    conv_fwd_raw(inp, wih, bih, gi[:, :H3], B * T, 1, 1, In, H3, 1, 1, 0, 1)
+                    conv_fwd_raw(inp, wih_r, bih_r, gi[:, H3:], B * T, 1, 1, In, H3, 1, 1, 0, 1)
+                gis.append(gi)
             whh2 = _pair(whh, whh_r)
             if whh2 is None:
                 whh2 = torch.stack((whh, whh_r))
             bhh2 = _pair(bhh, bhh_r)
             if bhh2 is None:
                 bhh2 = torch.stack((bhh, bhh_r))
-            y = torch.empty(B * T, 2 * H, dtype=torch.float32, device=dev)
-            gates = torch.empty(2, B * T, 4 * H, dtype=torch.float32, device=dev) if need_grad else None
             last = l == Lyr - 1
             use_drop = bool(training) and drop_p > 0 and not last
-            ydrop = torch.empty_like(y) if use_drop else None
-            e = _epi(L.ACT_NONE, 1.0, drop_p if use_drop else 0.0, noise, site0 + l)
-            if USE_COOP_GRU and H >= COOP_GRU_MIN_H and lib.s2ag_gru_coop_supported(H):
-                ws = torch.empty(lib.s2ag_gru_coop_workspace_bytes(B, T, H, 0), dtype=torch.uint8, device=dev)
-                L.check(lib.s2ag_gru_coop_fwd(_p(gi), _p(whh2), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T, H,
-                                              C.byref(e), _p(ws), _stream()), 'gru_coop_fwd')
-                if H > 64:                       # H = 64 runs without an exchange: its error word is never written
-                    _COOP_WS.append((ws, B, T, H, 0))
+            ys = [torch.empty(B * T, 2 * H, dtype=torch.float32, device=dev) for _ in range(nP)]
+            gates = torch.empty(2, B * T, 4 * H, dtype=torch.float32, device=dev) if need_grad else None
+            ydrops = [torch.empty_like(y) if use_drop else None for y in ys]
+            coop = USE_COOP_GRU and H >= COOP_GRU_MIN_H and lib.s2ag_gru_coop_supported(H)
+            if coop and nP > 1 and lib.s2ag_gru_coop_fwd_multi_supported(nP, B, H):
+                arr = lambda ts: (C.c_void_p * nP)(*[None if t is None else t.data_ptr() for t in ts])
+                ws = torch.empty(lib.s2ag_gru_coop_fwd_multi_workspace_bytes(nP, B, T, H), dtype=torch.uint8, device=dev)
+                L.check(lib.s2ag_gru_coop_fwd_multi(nP, arr(gis), _p(whh2), _p(bhh2), arr(ys), arr(ydrops),
+                                                    arr([gates] + [None] * (nP - 1)), B, T, H,
+                                                    drop_p if use_drop else 0.0, arr(noises), site0 + l, _p(ws),
+                                                    _stream()), 'gru_coop_fwd_multi')
+                _COOP_WS.append((ws, B, T, H, -nP))
             else:
-                whhT = None
-                if lib.s2ag_gru_seq_needs_transposed(H):
-                    whhT = torch.empty(2, H, H3, dtype=torch.float32, device=dev)
-                    transpose_raw(whh2[0], whhT[0])
-                    transpose_raw(whh2[1], whhT[1])
-                L.check(lib.s2ag_gru_seq_fwd(_p(gi), _p(whh2), _p(whhT), _p(bhh2), _p(y), _p(ydrop), _p(gates), B, T,
-                                             H, C.byref(e), _stream()), 'gru_seq_fwd')
-            saved += [inp, y, gates]
-            inp = ydrop if use_drop else y
-        if sum_dirs:
-            out = torch.empty(B * T, H, dtype=torch.float32, device=dev)
-            add_act_raw(y[:, :H], y[:, H:], out, 1.0)
-            out = out.view(B, T, H)
-        else:
-            out = y.view(B, T, 2 * H)
+                for i in range(nP):
+                    e = _epi(L.ACT_NONE, 1.0, drop_p if use_drop else 0.0, noises[i], site0 + l)
+                    g_i = gates if i == 0 else None
+                    if coop:
+                        ws = torch.empty(lib.s2ag_gru_coop_workspace_bytes(B, T, H, 0), dtype=torch.uint8, device=dev)
+                        L.check(lib.s2ag_gru_coop_fwd(_p(gis[i]), _p(whh2), _p(bhh2), _p(ys[i]), _p(ydrops[i]), _p(g_i), B,
+                                                      T, H, C.byref(e), _p(ws), _stream()), 'gru_coop_fwd')
+                        if H > 64:                   # H = 64 runs without an exchange: its error word is never written
+                            _COOP_WS.append((ws, B, T, H, 0))
+                    else:
+                        whhT = None
+                        if lib.s2ag_gru_seq_needs_transposed(H):
+                            whhT = torch.empty(2, H, H3, dtype=torch.float32, device=dev)
+                            transpose_raw(whh2[0], whhT[0])
+                            transpose_raw(whh2[1], whhT[1])
+                        L.check(lib.s2ag_gru_seq_fwd(_p(gis[i]), _p(whh2), _p(whhT), _p(bhh2), _p(ys[i]), _p(ydrops[i]),
+                                                     _p(g_i), B, T, H, C.byref(e), _stream()), 'gru_seq_fwd')
+            saved += [inps[0], ys[0], gates]
+            inps = ydrops if use_drop else ys
+        outs = []
+        for y in ys:
+            if sum_dirs:
+                out = torch.empty(B * T, H, dtype=torch.float32, device=dev)
+                add_act_raw(y[:, :H], y[:, H:], out, 1.0)
+                outs.append(out.view(B, T, H))
+            else:
+                outs.append(y.view(B, T, 2 * H))
         ctx.meta = (B, T, H, Lyr, bool(training), float(drop_p), site0, bool(sum_dirs))
         ctx.noise = noise
         ctx.n_w = len(weights)
         ctx.w_leaves = weights
+        ctx.n_mates = nP - 1
         ctx.save_for_backward(*weights, *[s for s in saved])
         ctx.none_mask = [s is None for s in saved]
-        return out
+        if nP == 1:
+            return outs[0]
+        ctx.mark_non_differentiable(*outs[1:])
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_mate_grads):
         B, T, H, Lyr, training, drop_p, site0, sum_dirs = ctx.meta
         lib = _lib()
         tens = ctx.saved_tensors
@@ -1458,7 +1491,7 @@ class _GRU(torch.autograd.Function):
                     conv_bwd_data_raw(dgi[:, H3:], wih_r, dx, B * T, 1, 1, In, H3, 1, 1, 0, 1, True)
             # parameter gradients
             base = 8 * l
-            need = [ctx.needs_input_grad[9 + base + i] for i in range(8)]
+            need = [ctx.needs_input_grad[10 + base + i] for i in range(8)]
             slots = [_grad_slot(ctx.w_leaves[base + i]) if need[i] else None for i in range(8)]
             pair_ih = _pair(slots[0], slots[4]) if all(need) else None         # (2, 3H, In) gradient of both W_ih
             pair_bi = _pair(slots[2], slots[6]) if all(need) else None
@@ -1529,15 +1562,18 @@ class _GRU(torch.autograd.Function):
                         grads[bd], grads[bd + 1], grads[bd + 2], grads[bd + 3] = dwi, dwh, dbi, dbh
             dy, lddy, dir_stride = dx, 2 * H, H
         dxo = dx.view(B, T, -1) if ctx.needs_input_grad[0] else None
-        return (dxo, None, None, None, None, None, None, None, None, *grads)
+        return (dxo, None, None, None, None, None, None, None, None, None, *grads)
 
 
 def gru(x: Tensor, weights: Sequence[Tensor], hidden: int, layers: int, training: bool, drop_p: float, noise,
-        site0: int, sum_dirs: bool) -> Tensor:
-    """weights: per layer [w_ih, w_hh, b_ih, b_hh, w_ih_reverse, w_hh_reverse, b_ih_reverse, b_hh_reverse]."""
+        site0: int, sum_dirs: bool, mates=()):
+    """weights: per layer [w_ih, w_hh, b_ih, b_hh, w_ih_reverse, w_hh_reverse, b_ih_reverse, b_hh_reverse].
+    ``mates`` = [(x_i, noise_i), ...]: no-grad passes of the same stack run in lockstep (see _GRU.forward); the result
+    is then (out, *mate_outs)."""
     need_grad = torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights))
+    mates = tuple((xm.detach(), nm) for xm, nm in mates)
     return _GRU.apply(x, hidden, layers, bool(training), float(drop_p), noise, site0, bool(sum_dirs), need_grad,
-                      *weights)
+                      mates, *weights)
 
 
 # ----------------------------------------------------------------------------------------------------

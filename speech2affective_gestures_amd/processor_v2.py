@@ -222,7 +222,10 @@ class Processor(object):
         self.early_real_backward = bool(getattr(args, 'early_real_backward',
                                                 os.environ.get('S2AG_EARLY_REAL_BWD', '1') != '0'))
         self.early_rand = bool(getattr(args, 'early_rand', os.environ.get('S2AG_EARLY_RAND', '1') != '0'))
-        self._side = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+        # the loss pass of the generator (with autograd) and the frozen tri-modal baseline read nothing the D step
+        # writes: they run beside the D step instead of at the head of the generator phase (see _dis_phase)
+        self.early_main = int(getattr(args, 'early_main', os.environ.get('S2AG_EARLY_MAIN', '3')))
+        self._side = [torch.cuda.Stream(device=self.device) for _ in range(4)]
         self._graphed = None
         self.last_losses = {}
 
@@ -498,14 +501,14 @@ class Processor(object):
         ops.mark_side_stream(s)
         return s
 
-    def _dis_phase(self, in_text, in_mfcc, target_poses, vid_indices, pre_seq, train):
+    def _dis_phase(self, in_text, in_mfcc, target_poses, vid_indices, pre_seq, train, in_audio=None, cut=False):
         """processor_v2.py:792-814 up to (and including) dis_error.backward().
 
         Noise snapshots are drawn in the reference's pass order (G, D(real), D(fake)) on the main stream; the generator
         forward then runs on a forked stream beside D(real).  D(fake) starts after both, so D's BatchNorm running
         statistics are still updated real-then-fake."""
         ops.set_main_stream()
-        self._early_rand = None
+        self._early_rand = self._early_main = self._early_tri = None
         ops.stamp('D:start')
         self.s2ag_dis_optimizer.zero_grad()
         dev = pre_seq.device
@@ -520,10 +523,106 @@ class Processor(object):
                 enc = self._fork(1)
                 with torch.cuda.stream(enc), ops.sequential_branches():
                     self.s2ag_generator.prepare_shared(pre_seq, in_mfcc)
-            ops.stamp('D:G(dis) begin [main]')
-            with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
-                out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
-            ops.stamp('D:G(dis) end [main]')
+            hoist = bool(train and self.early_main and self.s2ag_generator.share_passes and in_audio is not None)
+
+            def early_rand_pass(side1):
+                # The generator's third forward (shuffled speakers, no_grad) depends on nothing the D step changes, and
+                # with the pose/audio encoders shared it contains no BatchNorm (no ordering of running statistics): it
+                # runs beside the D step (small kernels that leave most CUs idle) instead of on the critical path of the
+                # generator phase.  Its noise is that of pass 7 of the step, as upstream.
+                if not (self.s2ag_generator.share_passes and self.early_rand):
+                    return
+                with torch.cuda.stream(side1):
+                    nz_rand = nz_g.clone()
+                    nz_rand[1] += PASSES_PER_STEP - 1
+                with torch.cuda.stream(side1), torch.no_grad(), noise.use_pass(nz_rand), ops.sequential_branches():
+                    rand_vids = vid_indices[torch.randperm(vid_indices.shape[0], device=vid_indices.device)]
+                    ops.stamp('D:G(rand) begin [side1]')
+                    out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, rand_vids)
+                    ops.stamp('D:G(rand) end [side1]')
+                out_rand.record_stream(cur)
+                z_rand.record_stream(cur)
+                self._early_rand = (out_rand, z_rand)
+
+            lockstep = hoist and self.early_main == 3 and self.early_rand and \
+                hasattr(self.s2ag_generator, 'forward_passes')
+            if lockstep:
+                # All three generator passes of the step (for D, for the loss, with shuffled speakers) read the same
+                # weights and inputs -- G's weights move only at the end of the step, and with the pose/audio encoders
+                # shared the passes hold no BatchNorm -- and differ in noise only: they run here in LOCKSTEP, each
+                # decoder layer of the three as one cooperative launch (PoseGenerator.forward_passes).  The loss pass
+                # is the one with autograd; each pass keeps the noise snapshot of its place in the reference's order
+                # (1, 5, 7).  The frozen baseline (pass 4) follows on a forked stream, beside D(fake) and D's backward.
+                nz_main, nz_rand = nz_g.clone(), nz_g.clone()
+                nz_main[1] += 4
+                nz_rand[1] += PASSES_PER_STEP - 1
+                rand_vids = vid_indices[torch.randperm(vid_indices.shape[0], device=vid_indices.device)]
+                self.s2ag_generator.cut_backward = bool(cut)
+                self.s2ag_generator._cut = None
+                ops.stamp('D:G(x3) begin [main]')
+                r_main, r_dis, r_rand = self.s2ag_generator.forward_passes(
+                    pre_seq, in_text, in_mfcc, [(vid_indices, nz_main, True), (vid_indices, nz_g, False),
+                                                (rand_vids, nz_rand, False)])
+                ops.stamp('D:G(x3) end [main]')
+                self._early_main = r_main
+                self._early_rand = (r_rand[0], r_rand[1])
+                out_dir_vec = r_dis[0]
+                nz_tri = nz_g.clone()
+                nz_tri[1] += 3
+                s_tri = self._fork(1)
+                with torch.cuda.stream(s_tri), torch.no_grad(), noise.use_pass(nz_tri), ops.sequential_branches():
+                    out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
+                    ops.stamp('D:tri-modal end [side1]')
+                out_tri.record_stream(cur)
+                self._early_tri = out_tri
+            elif hoist:
+                # The generator's LOSS pass (pass 5 of the step, with autograd) and the frozen tri-modal baseline (pass
+                # 4) depend on nothing the D step changes -- G's weights move only at the end of the step, and with the
+                # pose/audio encoders shared the passes hold no BatchNorm.  The loss pass takes the main stream (its
+                # backward nodes then run on the main stream of the generator phase, where weight gradients fork from);
+                # the D step's own generator pass and the baseline run on forked streams beside it.  Each pass keeps
+                # the noise snapshot of its place in the reference's pass order.
+                nz_tri, nz_main = nz_g.clone(), nz_g.clone()
+                nz_tri[1] += 3
+                nz_main[1] += 4
+                # four streams in all (the runtime maps streams onto four hardware queues; a fifth concurrent stream
+                # shares a queue and serialises behind another pass): main = loss pass, side0 = D(real), side1 = shared
+                # encoders then G(rand), side2 = G(dis) then the baseline
+                tri_apart = self.early_main == 1     # 1: baseline on a stream of its own; 2: behind G(dis)
+                if tri_apart:
+                    s_tri = self._fork(3)
+                    with torch.cuda.stream(s_tri), torch.no_grad(), noise.use_pass(nz_tri), ops.sequential_branches():
+                        out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
+                        ops.stamp('D:tri-modal end [side3]')
+                s_gd = self._fork(2)
+                g_dis_done = torch.cuda.Event()
+                with torch.cuda.stream(s_gd), torch.no_grad(), ops.sequential_branches():
+                    ops.stamp('D:G(dis) begin [side2]')
+                    with noise.use_pass(nz_g):
+                        out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
+                    ops.stamp('D:G(dis) end [side2]')
+                    g_dis_done.record(s_gd)
+                    if not tri_apart:
+                        with noise.use_pass(nz_tri):
+                            out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
+                        ops.stamp('D:tri-modal end [side2]')
+                out_dir_vec.record_stream(cur)
+                out_tri.record_stream(cur)
+                self._early_tri = out_tri
+                rand_first = self.encoders_aside and self.early_main == 2
+                if rand_first:
+                    early_rand_pass(enc)                # behind the shared encoders, on their stream
+                self.s2ag_generator.cut_backward = bool(cut)
+                self.s2ag_generator._cut = None
+                ops.stamp('D:G(main) begin [main]')
+                with noise.use_pass(nz_main):
+                    self._early_main = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
+                ops.stamp('D:G(main) fwd end [main]')
+            else:
+                ops.stamp('D:G(dis) begin [main]')
+                with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
+                    out_dir_vec, *_ = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
+                ops.stamp('D:G(dis) end [main]')
             l_real = real_bwd_done = None
             real_fwd_done = torch.cuda.Event()
             with torch.cuda.stream(side), noise.use_pass(nz_real), ops.sequential_branches():
@@ -542,22 +641,10 @@ class Processor(object):
                     real_bwd_done = torch.cuda.Event()
                     real_bwd_done.record(side)
             cur.wait_event(real_fwd_done)       # D(fake) follows D(real)'s FORWARD (BatchNorm running statistics order)
-            if self.s2ag_generator.share_passes and self.early_rand:
-                # The generator's third forward (shuffled speakers, no_grad) depends on nothing the D step changes, and
-                # with the pose/audio encoders shared it contains no BatchNorm (no ordering of running statistics): it
-                # runs HERE, beside D(fake) and D's backward (small kernels that leave most CUs idle), instead of on
-                # the critical path of the generator phase.  Its noise is that of pass 7 of the step, as upstream.
-                nz_rand = nz_g.clone()
-                nz_rand[1] += PASSES_PER_STEP - 1
-                rand_vids = vid_indices[torch.randperm(vid_indices.shape[0], device=vid_indices.device)]
-                side1 = self._fork(1)
-                with torch.cuda.stream(side1), torch.no_grad(), noise.use_pass(nz_rand), ops.sequential_branches():
-                    ops.stamp('D:G(rand) begin [side1]')
-                    out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, rand_vids)
-                    ops.stamp('D:G(rand) end [side1]')
-                out_rand.record_stream(cur)
-                z_rand.record_stream(cur)
-                self._early_rand = (out_rand, z_rand)
+            if hoist and not lockstep:
+                cur.wait_event(g_dis_done)
+            if not lockstep and not (hoist and rand_first):
+                early_rand_pass(self._fork(1))          # beside D(fake) and D's backward
         else:
             l_real = None
             with torch.no_grad(), noise.use_pass(nz_g):    # upstream builds this graph and never uses it
@@ -592,8 +679,12 @@ class Processor(object):
         cfg = self.s2ag_config_args
         if not self.use_mfcc:                 # the audio-ablation generator reads the raw waveform (processor_v2.py:794-797)
             in_mfcc = in_audio
-        self.s2ag_generator.cut_backward = bool(cut and train)
-        self.s2ag_generator._cut = None
+        early_main = getattr(self, '_early_main', None)   # the loss pass / the baseline already ran beside the D step
+        early_tri = getattr(self, '_early_tri', None)
+        self._early_main = self._early_tri = None
+        if early_main is None:
+            self.s2ag_generator.cut_backward = bool(cut and train)
+            self.s2ag_generator._cut = None
         ops.set_main_stream()
         ops.stamp('G:start')
         self.s2ag_gen_optimizer.zero_grad()
@@ -606,7 +697,9 @@ class Processor(object):
             rand_idx = torch.randperm(vid_indices.shape[0], device=vid_indices.device)
             rand_vids = vid_indices[rand_idx]
         cur = torch.cuda.current_stream()
-        if self.overlap_passes:      # the frozen baseline shares nothing with G/D: run it beside the main forward
+        if early_tri is not None:
+            out_tri = early_tri
+        elif self.overlap_passes:    # the frozen baseline shares nothing with G/D: run it beside the main forward
             side0 = self._fork(0)
             with torch.cuda.stream(side0), torch.no_grad(), noise.use_pass(nz_tri), ops.sequential_branches():
                 ops.stamp('G:tri-modal begin [side0]')
@@ -615,10 +708,13 @@ class Processor(object):
         else:
             with torch.no_grad(), noise.use_pass(nz_tri):
                 out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
-        ops.stamp('G:G(main) begin [main]')
-        with noise.use_pass(nz_main):
-            out, z, z_mu, z_log_var = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
-        ops.stamp('G:G(main) fwd end [main]')
+        if early_main is not None:
+            out, z, z_mu, z_log_var = early_main
+        else:
+            ops.stamp('G:G(main) begin [main]')
+            with noise.use_pass(nz_main):
+                out, z, z_mu, z_log_var = self.s2ag_generator(pre_seq, in_text, in_mfcc, vid_indices)
+            ops.stamp('G:G(main) fwd end [main]')
         if early is not None:
             out_rand, z_rand = early
         elif self.overlap_passes:    # G(rand) follows G(main) (BatchNorm running stats order) but runs beside D(gen)
@@ -639,7 +735,8 @@ class Processor(object):
             for p, f in zip(self.dis_arena.params, flags):
                 p.requires_grad_(f)
         if self.overlap_passes:
-            cur.wait_stream(side0)
+            if early_tri is None:
+                cur.wait_stream(side0)
             if early is None:
                 cur.wait_stream(side1)
         elif early is None:
@@ -709,13 +806,13 @@ class Processor(object):
     def _step(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, train):
         pre_seq = self._make_pre_seq(target_poses)
         dis_error = None
+        ex = self._exchange() if train else None
         if self._use_gan():
             dis_error = self._dis_phase(in_text, in_mfcc if self.use_mfcc else in_audio, target_poses, vid_indices,
-                                        pre_seq, train)
+                                        pre_seq, train, in_audio=in_audio, cut=ex is not None)
             if train:
                 self.dp.all_reduce_grads(self.dis_arena)
                 self.s2ag_dis_optimizer.step(self.dp.grad_scale)
-        ex = self._exchange() if train else None
         comps = self._gen_phase(in_text, in_audio, in_mfcc, target_poses, vid_indices, pre_seq, train, cut=ex is not None)
         if train:
             if ex is not None:
@@ -732,15 +829,15 @@ class Processor(object):
                   vid=vid_indices.clone())
         out = {}
         use_gan = self._use_gan()
+        ex = self._exchange()
 
         def seg_dis():
             ops.begin_step()
             self.s2ag_generator.share_passes = (3 if use_gan else 2) if self.share_encoders else None
             out['pre'] = self._make_pre_seq(st['target'])
             out['dis'] = self._dis_phase(st['text'], st['mfcc'] if self.use_mfcc else st['audio'], st['target'],
-                                         st['vid'], out['pre'], True) if use_gan else None
-
-        ex = self._exchange()
+                                         st['vid'], out['pre'], True, in_audio=st['audio'],
+                                         cut=ex is not None) if use_gan else None
 
         def seg_gen():
             if use_gan:

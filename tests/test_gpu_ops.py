@@ -486,6 +486,47 @@ def test_gru_forward_backward(S, B, T, I, H, L, sum_dirs, p):
     assert ops.coop_gru_timeouts() == 0          # cooperative (H = 300) launches never timed out on a peer
 
 
+@pytest.mark.parametrize('B,I,H,L,sum_dirs,n_mates', [(128, 108, 300, 4, True, 2), (37, 88, 300, 2, False, 2),
+                                                        (48, 88, 300, 2, True, 3), (128, 108, 300, 2, True, 1),
+                                                        (9, 20, 32, 2, True, 2), (16, 88, 300, 2, True, 2)])
+def test_lockstep_gru_passes_equal_separate_launches(S, B, I, H, L, sum_dirs, n_mates):
+    """ops.gru(..., mates=[...]): further no-grad passes over the same weights run layer by layer in lockstep with the
+    main pass -- at H = 300 their recurrences ride in ONE cooperative launch (s2ag_gru_coop_fwd_multi), each with its own
+    noise snapshot.  Every pass must equal its stand-alone launch bit for bit, and the main pass's gradients too."""
+    ops, noise = S['ops'], S['noise']
+    T, p, site0 = 34, 0.3, 300
+    sd = _gru_sd(I, H, L, B + H)
+    g = torch.Generator().manual_seed(B + I)
+    xs = [torch.randn(B, T, I, generator=g).cuda() for _ in range(1 + n_mates)]
+    noise.manual_seed(11)
+    nzs = [noise.begin_pass('cuda') for _ in xs]
+    dy = torch.randn(B, T, H if sum_dirs else 2 * H, generator=g).cuda()
+
+    def run(lockstep):
+        wg = [w.cuda().requires_grad_(True) for w in _flat(sd, L)]
+        x0 = xs[0].clone().requires_grad_(True)
+        if lockstep:
+            outs = ops.gru(x0, wg, H, L, True, p, nzs[0], site0, sum_dirs, mates=list(zip(xs[1:], nzs[1:])))
+            assert not any(o.requires_grad for o in outs[1:])
+        else:
+            outs = [ops.gru(x0, wg, H, L, True, p, nzs[0], site0, sum_dirs)]
+            with torch.no_grad():
+                outs += [ops.gru(x, wg, H, L, True, p, nz, site0, sum_dirs) for x, nz in zip(xs[1:], nzs[1:])]
+        outs[0].backward(dy)
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs], x0.grad.clone(), [w.grad.clone() for w in wg]
+    o1, gx1, gw1 = run(True)
+    o0, gx0, gw0 = run(False)
+    assert len(o1) == 1 + n_mates
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    assert not torch.equal(o1[0], o1[1])                 # different inputs and noise per pass
+    assert torch.equal(gx1, gx0)
+    for a, b in zip(gw1, gw0):
+        assert rel(a, b) < 1e-6                         # (weight-gradient tiles are summed in launch-dependent order)
+    assert ops.coop_gru_timeouts() == 0
+
+
 @pytest.mark.parametrize('pieces,tol', [(0, 3e-6), (3, 3e-6), (2, 2e-5)])
 def test_coop_gru_products_on_the_bf16_pipe(S, pieces, tol):
     """H = 300 recurrence: the per-step products as exact bf16-piece splits of the fp32 operands (3 pieces = default,

@@ -361,6 +361,61 @@ def test_shared_encoder_pass_equals_three_separate_passes(monkeypatch):
                 assert ok, (step, k, info)
 
 
+@pytest.mark.parametrize('hidden,B,hip_graph', [(32, 6, False), (300, 33, False), (300, 33, True)])
+def test_lockstep_generator_passes_equal_separate_passes(monkeypatch, hidden, B, hip_graph):
+    """early_main = 3 (default): the generator's three passes of a step run in lockstep beside the D step -- one
+    cooperative launch per decoder layer for all three -- each with the noise snapshot of its place in the reference's
+    pass order (1, 5, 7).  Losses and weights must end up where the pass-by-pass schedule (early_main = 0) leaves them."""
+    from speech2affective_gestures_amd import noise
+    from speech2affective_gestures_amd import processor_v2 as P
+    n_words, n_spk, s0 = 64, 12, 7100
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+    monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm)
+    batches = [to_cuda(O.recipe_inputs(B, 34, s0 + 50 + s, n_words, n_spk)) for s in range(2)]
+
+    def run(mode):
+        noise.reset_sites(100)
+        pr, _ = make_processor(hidden, n_words, n_spk, B, s0, 0.3, early_main=mode, hip_graph=hip_graph)
+        if hip_graph:   # capture (3 warm-up steps touch the state) ... then rewind everything to the start state
+            mods = (pr.s2ag_generator, pr.s2ag_discriminator, pr.trimodal_generator, pr.s2ag_gen_optimizer,
+                    pr.s2ag_dis_optimizer)
+            state = [copy.deepcopy(m.state_dict()) for m in mods]
+            b = batches[0]
+            pr._build_graphed(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'])
+            for m, st in zip(mods, state):
+                m.load_state_dict(st)
+        noise.manual_seed(STEP_SEED)
+        losses, states = [], []
+        for b in batches:
+            pr.train_step(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'])
+            losses.append(dict(pr.last_losses))
+            states.append({k: v.clone() for k, v in pr.s2ag_generator.state_dict().items()})
+        return losses, states
+    l1, st1 = run(3)
+    l0, st0 = run(0)
+    for a, b in zip(l1, l0):
+        for k in a:
+            assert a[k] == pytest.approx(b[k], rel=1e-4, abs=1e-6), k
+    for step, (sd1, sd0) in enumerate(zip(st1, st0)):
+        for k in sd0:
+            if k.endswith('num_batches_tracked'):
+                assert int(sd1[k]) == int(sd0[k]), k
+            elif k.endswith('running_var') or (k.endswith('running_mean') and step == 0):
+                # (running means follow Adam's random walk of the dead conv biases from the second step on)
+                assert rel(sd1[k], sd0[k]) < 1e-4, (step, k)
+            elif 'running' in k:
+                continue
+            elif not is_noise_driven_after_adam(k):
+                ok, info = adam_close(sd1[k], sd0[k], 5e-4, step + 1)
+                assert ok, (step, k, info)
+    assert ops_timeouts() == 0
+
+
+def ops_timeouts():
+    from speech2affective_gestures_amd import ops
+    return ops.coop_gru_timeouts()
+
+
 @pytest.mark.gpu
 def test_prefetching_batch_feeder_matches_the_host_path():
     """Processor.yield_batch through data.BatchFeeder (pinned staging, background gather, device-side decode) yields
