@@ -462,26 +462,41 @@ class PoseGenerator(nn.Module, _SpeakerZ):
     # their BatchNorm running statistics advance k times (ops.bn_repeat), exactly as k separate passes would.
     share_passes = None
 
-    def prepare_shared(self, pre_seq, in_mfcc):
-        """Compute this step's shared encoder outputs on the CURRENT stream (the trainer calls this on a forked stream,
-        beside the text encoder of the first pass); later passes wait for the event recorded here before using them."""
-        self._shared_encoders(pre_seq, in_mfcc)
+    def prepare_shared(self, pre_seq, in_mfcc, audio_stream=None):
+        """Compute this step's shared encoder outputs: the pose encoder on the CURRENT stream (the trainer calls this on
+        a forked stream, beside the text encoder of the first pass), the audio encoder on ``audio_stream`` when given (a
+        second stream forked by the trainer -- the two encoders share nothing, and because backward kernels run on the
+        stream of their forward op their two backward chains, the tail of the generator's backward pass, then overlap
+        as well).  Later passes wait for the events recorded here before using the outputs."""
+        self._shared_encoders(pre_seq, in_mfcc, audio_stream)
 
-    def _shared_encoders(self, pre_seq, in_mfcc):
+    def _shared_encoders(self, pre_seq, in_mfcc, audio_stream=None):
         k = self.share_passes
         if not k or self.input_context == 'none':
             return None
         key = (ops.generation(), pre_seq.data_ptr(), in_mfcc.data_ptr(), self.training, int(k))
         if getattr(self, '_shared', None) is None or self._shared[0] != key:
+            cur = torch.cuda.current_stream()
             with torch.set_grad_enabled(self.training), ops.bn_repeat(k if self.training else 1):
                 pre = self.aff_encoder(pre_seq[..., :-1])
-                audio = self.audio_encoder(in_mfcc)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._shared = (key, pre, audio, ev, torch.cuda.current_stream())
-        _, pre, audio, ev, made_on = self._shared
-        if torch.cuda.current_stream() != made_on:
-            torch.cuda.current_stream().wait_event(ev)
+                evs = [torch.cuda.Event()]
+                evs[0].record()
+                if audio_stream is None or audio_stream == cur:
+                    audio = self.audio_encoder(in_mfcc)
+                    evs[0].record()
+                    made_on = (cur,)
+                else:
+                    with torch.cuda.stream(audio_stream):
+                        audio = self.audio_encoder(in_mfcc)
+                        evs.append(torch.cuda.Event())
+                        evs[1].record()
+                    made_on = (cur, audio_stream)
+            self._shared = (key, pre, audio, evs, made_on)
+        _, pre, audio, evs, made_on = self._shared
+        now = torch.cuda.current_stream()
+        for ev, s in zip(evs, made_on):
+            if now != s:
+                now.wait_event(ev)
         if not torch.is_grad_enabled():
             pre, audio = pre.detach(), audio.detach()
         return pre, audio

@@ -219,6 +219,10 @@ class Processor(object):
         self.share_encoders = bool(getattr(args, 'share_encoders', os.environ.get('S2AG_SHARE_ENCODERS', '1') != '0')) \
             and hasattr(self.s2ag_generator, '_shared_encoders')
         self.encoders_aside = bool(getattr(args, 'encoders_aside', os.environ.get('S2AG_ENCODERS_ASIDE', '1') != '0'))
+        # ... and the audio encoder of the shared pair on a stream of its own (forward and, since backward kernels run on
+        # the stream of their forward op, backward: the two chains of small launches end the generator's backward pass)
+        self.encoders_apart = self.encoders_aside and \
+            bool(getattr(args, 'encoders_apart', os.environ.get('S2AG_ENCODERS_APART', '1') != '0'))
         self.early_real_backward = bool(getattr(args, 'early_real_backward',
                                                 os.environ.get('S2AG_EARLY_REAL_BWD', '1') != '0'))
         self.early_rand = bool(getattr(args, 'early_rand', os.environ.get('S2AG_EARLY_RAND', '1') != '0'))
@@ -518,12 +522,17 @@ class Processor(object):
             # The generator forward is the long pole of this phase (D(fake) needs its output): it stays on the main
             # stream and is issued FIRST; D(real) is issued after it on a stream forked from the phase start.
             side = self._fork(0)
+            hoist = bool(train and self.early_main and self.s2ag_generator.share_passes and in_audio is not None)
+            lockstep = hoist and self.early_main == 3 and self.early_rand and \
+                hasattr(self.s2ag_generator, 'forward_passes')
             if self.s2ag_generator.share_passes and self.encoders_aside:
                 # the generator's shared pose/audio encoders run on a forked stream beside its text encoder
                 enc = self._fork(1)
+                # the audio encoder ahead of D(real) on ITS stream (a fifth captured stream made graph replays crash now and
+                # then; D(real)'s backward still ends well before D(fake)'s forward does)
+                enc_audio = side if (self.encoders_apart and lockstep) else None
                 with torch.cuda.stream(enc), ops.sequential_branches():
-                    self.s2ag_generator.prepare_shared(pre_seq, in_mfcc)
-            hoist = bool(train and self.early_main and self.s2ag_generator.share_passes and in_audio is not None)
+                    self.s2ag_generator.prepare_shared(pre_seq, in_mfcc, audio_stream=enc_audio)
 
             def early_rand_pass(side1):
                 # The generator's third forward (shuffled speakers, no_grad) depends on nothing the D step changes, and
@@ -544,8 +553,6 @@ class Processor(object):
                 z_rand.record_stream(cur)
                 self._early_rand = (out_rand, z_rand)
 
-            lockstep = hoist and self.early_main == 3 and self.early_rand and \
-                hasattr(self.s2ag_generator, 'forward_passes')
             if lockstep:
                 # All three generator passes of the step (for D, for the loss, with shuffled speakers) read the same
                 # weights and inputs -- G's weights move only at the end of the step, and with the pose/audio encoders
@@ -748,6 +755,8 @@ class Processor(object):
         ops.stamp('G:losses done, backward begins')
         if self.overlap_passes and self.encoders_aside and self.s2ag_generator.share_passes and self._use_gan():
             ops.mark_side_stream(self._side[1])      # the shared encoders' backward runs on the stream of their forward
+            if self.encoders_apart:
+                ops.mark_side_stream(self._side[0])
         if train:
             total.backward()
         ops.join_side_streams()
@@ -764,6 +773,8 @@ class Processor(object):
         ops.set_main_stream()
         if self.overlap_passes and self.encoders_aside and G.share_passes and self._use_gan():
             ops.mark_side_stream(self._side[1])
+            if self.encoders_apart:
+                ops.mark_side_stream(self._side[0])
         torch.autograd.backward([f for f, _ in pairs], [g for _, g in pairs])
         ops.join_side_streams()
         ex.pack_rows(in_text)

@@ -39,3 +39,13 @@ for s, e, n, _ in win:
     by[key][1] += e - s
 for n, (cnt, v) in sorted(by.items(), key=lambda x: -x[1][1])[:int(sys.argv[2]) if len(sys.argv) > 2 else 30]:
     print(f'  {n:<50} x{cnt:<4} {v/1e3:9.1f} us  {100*v/tot:5.1f}%')
+if len(sys.argv) > 3:      # full listing of the window: start offset, duration, queue, grid, kernel
+    gcol = [r[1] for r in c.execute(f"pragma table_info({kd})")]
+    gx = 'grid_size_x' if 'grid_size_x' in gcol else None
+    wgx = 'workgroup_size_x' if 'workgroup_size_x' in gcol else None
+    extra = list(c.execute(f"select d.start, {'d.' + gx if gx else 0}, {'d.' + wgx if wgx else 1} from {kd} d order by d.start"))[lo:hi]
+    qn = {q: i for i, q in enumerate(sorted(set(r[3] for r in win)))}
+    with open(sys.argv[3], 'w') as f:
+        for (s, e, n, q), (_, g, w) in zip(win, extra):
+            key = re.sub(r'^_ZN12_GLOBAL__N_1\d+|^_ZN4s2agL\d+', '', n)[:60]
+            f.write(f'{(s - win[0][0]) / 1e3:9.1f} {(e - s) / 1e3:7.1f} q{qn[q]} {int(g) // max(int(w), 1):6d}  {key}\n')
