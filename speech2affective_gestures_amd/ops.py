@@ -1536,7 +1536,16 @@ class _GRU(torch.autograd.Function):
                         # dW_hh = sum_t dgh_t^T h_{t-1}: h_{prev} is y shifted by one frame (zero at the boundary)
                         conv_bwd_weight_raw(dgh[d], y[:, d * H:(d + 1) * H], slots[4 * d + 1], B, T, T, H, H3, 1, 1,
                                             1 if d == 0 else -1, 1, True, dbias=slots[4 * d + 3])
-                run_wgrad(leaves, keep=(dgi, dgh, y, inp), flops=2.0 * B * T * 2 * H3 * (In + H))
+                big = H >= COOP_GRU_BWD_MIN_H and Lyr > 1 and 2.0 * B * T * 2 * H3 * (In + H) >= ASYNC_WGRAD_MIN_FLOPS
+                if big and l == 0 and GRU_WGRAD_L0 == 2:
+                    # the LAST big weight-gradient launch of the pass is issued when the backward pass ends: issued at
+                    # its place it ended up ahead of the rest of the backward pass (text TCN, encoders) on one hardware
+                    # queue of the replayed graph, and that chain waited ~0.3 ms for it (+2.4 % on the step)
+                    defer_wgrad(leaves, keep=(dgi, dgh, y, inp))
+                elif not big and GRU_WGRAD_SMALL_DEFER:
+                    defer_wgrad(leaves, keep=(dgi, dgh, y, inp))
+                else:
+                    run_wgrad(leaves, keep=(dgi, dgh, y, inp), flops=2.0 * B * T * 2 * H3 * (In + H))
             else:
                 for d, (w_ih, w_hh) in enumerate(((wih, whh), (wih_r, whh_r))):
                     gsl = dgi[:, d * H3:(d + 1) * H3]
@@ -1725,6 +1734,47 @@ def run_wgrad(fn, keep=(), flops=float('inf')) -> None:
     _KEEPALIVE.extend(keep)
     with torch.cuda.stream(s):
         fn()
+
+
+GRU_WGRAD_L0 = int(__import__('os').environ.get('S2AG_GRU_WGRAD_L0', '2'))
+GRU_WGRAD_SMALL_DEFER = __import__('os').environ.get('S2AG_GRU_WGRAD_SMALL_DEFER', '1') != '0'
+
+
+def wgrad_launcher(fn, keep=()):
+    """Bind ``fn`` (weight-gradient kernels, see run_wgrad) to what has been queued on the current stream SO FAR (an
+    event, not the stream) and return a callable that issues it on the weight-gradient stream -- to be called after the
+    next kernels of the dependent chain have been issued.  Why the order of ISSUE matters: hipGraph (ROCm 7.2) walks
+    the captured graph depth first and lets the FIRST captured successor of a node inherit its hardware queue, every
+    further successor takes the next of the four queues; a side chain issued right at the fork therefore keeps the
+    queue and the dependent chain hops to another one at every fork (15-35 us per cross-queue edge, and chains that
+    happen to land on one queue serialise).  Returns None when forking is not armed (then ``fn`` has run inline)."""
+    cur = torch.cuda.current_stream()
+    main = _MAIN_STREAM[0]
+    if not ASYNC_WGRAD or main is None or cur != main:
+        fn()
+        return None
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    dev = cur.device_index
+
+    def later(keep=tuple(keep)):
+        if dev not in _WGRAD_STREAMS:
+            _WGRAD_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        s = _WGRAD_STREAMS[dev]
+        s.wait_event(ev)
+        mark_side_stream(s)
+        _KEEPALIVE.extend(keep)
+        with torch.cuda.stream(s):
+            fn()
+    return later
+
+
+def defer_wgrad(fn, keep=()) -> None:
+    """Like run_wgrad, but ``fn`` is ISSUED when the running backward pass ends (autograd engine callback), ordered only
+    behind what has been queued on the current stream so far."""
+    later = wgrad_launcher(fn, keep)
+    if later is not None:
+        torch.autograd.Variable._execution_engine.queue_callback(later)
 
 
 def mark_side_stream(s) -> None:
