@@ -956,6 +956,9 @@ int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, flo
                           float drop_p, const unsigned long long* rng, unsigned site, double* stats, hipStream_t stream);
 int s2ag_gemm_conv_tm_bwd_data(const float* gy, const float* w, float* dx, int nclips, int L, int Cin, int Cout, int ks,
                                int pad, int dil, int ldg, int ldx, int accumulate, hipStream_t stream);
+// conv_pp.hip
+int s2ag_conv_dgrad_pp(const float* gy, const float* w, float* dx, int N, int Lin, int Lout, int Cin, int Cout, int ks,
+                       int stride, int pad, int dil, int ldg, int ldx, int wtm, int accumulate, hipStream_t stream);
 
 extern "C" int s2ag_abi_version(void) { return S2AG_ABI_VERSION; }
 
@@ -1048,6 +1051,14 @@ extern "C" int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* 
     if (use_gemm_lin() && g->ksize > 1 && g->w_tap_major && g->stride == 1 && g->Lin == g->Lout &&
         s2ag_gemm_conv_tm_bwd_data(gy, w, dx, g->N, g->Lin, g->Cin, g->Cout, g->ksize, g->pad, g->dil, g->ldy, g->ldx,
                                    accumulate, (hipStream_t)stream)) {
+        S2AG_LAUNCH_CHECK();
+        return 0;
+    }
+    // the wave encoder's strided convs: poly-phase kernel (S2AG_DGRAD_PP=0: the general kernel's residue mode)
+    static const bool use_pp = [] { const char* e = getenv("S2AG_DGRAD_PP"); return !(e && e[0] == '0'); }();
+    if (use_pp && g->stride > 1 &&
+        s2ag_conv_dgrad_pp(gy, w, dx, g->N, g->Lin, g->Lout, g->Cin, g->Cout, g->ksize, g->stride, g->pad, g->dil, g->ldy,
+                           g->ldx, g->w_tap_major, accumulate, (hipStream_t)stream)) {
         S2AG_LAUNCH_CHECK();
         return 0;
     }

@@ -1,0 +1,173 @@
+// Poly-phase data gradient of the STRIDED wave-encoder convs (fp32, f32 MFMA) -- replaces ConvolutionBackward (input
+// grad) of net/multimodal_context_net_v2.py:18-27 (Conv1d(16,32,15,stride=6), (32,64,15,6), (64,32,15,6)), which the
+// general implicit-GEMM kernel ran in "residue mode" at 341 / 135 / 28 us (B = 256).
+//
+//   dx[n, p, ci] = sum_{t, co} gy[n, (p - t) / S, co] * w[co, ci, t]     over the taps t = p (mod S), 0 <= (p - t)/S < Lout
+//
+// With p = S*q + r the taps of PHASE r are t = r + S*i, i = 0 .. ceil((KS - r) / S) - 1, and the source frame is q - i:
+// every phase is a stride-1 conv of gy with 2-3 taps whose output rows lie S frames apart in dx.  The contraction is
+// short (K = taps * Cout <= 192) and the output narrow (Cin = 16 .. 64), so the 64 x 64 x 32 block tile of the general
+// kernels wastes most of its MFMAs here and the work is really bound by moving gy in and dx out once:
+//   * a wave keeps the B operands -- w[.., ci-tile, r + S*i] for ITS (phase, 16-column tile) pairs -- in registers for
+//     the whole launch (<= 144 VGPRs), read once straight from the leaf's layout (reference (Cout, Cin, KS) or the
+//     cached tap-major copy);
+//   * a sub-tile = 16 consecutive q: its 16 + 2 source frames go through a wave-private LDS image (16-byte global loads,
+//     next sub-tile in flight in registers, no block barrier anywhere), the A fragment of (tap i, 4 channels) is read
+//     ONCE and serves every phase -- gy[q - i] does not depend on r;
+//   * 16 x 16 accumulator tiles are stored straight to dx (64-byte row segments; the S phases of a sub-tile are written
+//     back to back by the same wave, so the lines merge in L2).
+// Wave teams: Cin = 16 -> one wave does all S phases of its own sub-tiles; Cin = 32 -> four waves share a sub-tile
+// (column tile = wave & 1, phases of one parity); Cin = 64 -> wave = column tile, all phases.
+#include "s2ag_common.h"
+
+namespace {
+using namespace s2ag;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct PpP {
+    const float* gy;
+    const float* w;
+    float* dx;
+    int N, Lin, Lout, ldg, ldx, wtm, accumulate;
+    int Q;        // ceil(Lin / S): q positions per clip
+    int chunks;   // q chunks per clip
+    int QC;       // q per chunk (multiple of 16)
+};
+
+template <int COUT, int CIN, int KS, int S>
+__global__ __launch_bounds__(256) void conv_dgrad_pp_k(const PpP p) {
+    constexpr int NCT = CIN / 16;                    // 16-column tiles of dx
+    constexpr int WT = NCT == 1 ? 1 : 4;             // waves per team (one team works on one sub-tile)
+    constexpr int PSTEP = NCT == 2 ? 2 : 1;          // phase step of a wave
+    constexpr int NPH = S / PSTEP;                   // phases per wave
+    constexpr int NTAP = (KS + S - 1) / S;           // taps per phase (max)
+    constexpr int KC = COUT / 4;                     // 4-channel chunks of the contraction per tap
+    constexpr int ROWS = 16 + NTAP - 1;              // source frames under a sub-tile
+    constexpr int PITCH = COUT + 4;                  // LDS row pitch: 16 rows x 4 k land on 64 distinct banks
+    constexpr int NLD = (ROWS * COUT / 4 + 63) / 64; // float4 loads per lane and sub-tile
+    static_assert(S % PSTEP == 0 && COUT % 4 == 0 && CIN % 16 == 0, "shape");
+    __shared__ float lds[4][ROWS * PITCH];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int team = wave / WT, tw = wave % WT;
+    const int ct = NCT == 1 ? 0 : tw % NCT;
+    const int pstart = NCT == 2 ? tw / NCT : 0;
+    const int lr = lane & 15, lk = lane >> 4;
+
+    // ---- B operands of this wave: b[j][i][c] = w[co = 4c + lk][ci = 16 ct + lr][t = r_j + S i], r_j = pstart + j PSTEP
+    float b[NPH][NTAP][KC];
+#pragma unroll
+    for (int j = 0; j < NPH; ++j) {
+        const int r = pstart + j * PSTEP;
+#pragma unroll
+        for (int i = 0; i < NTAP; ++i) {
+            const int t = r + S * i;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int co = 4 * c + lk, ci = 16 * ct + lr;
+                float v = 0.f;
+                if (t < KS) v = p.wtm ? p.w[((long long)co * KS + t) * CIN + ci] : p.w[((long long)co * CIN + ci) * KS + t];
+                b[j][i][c] = v;
+            }
+        }
+    }
+
+    const int n = blockIdx.x / p.chunks;
+    const int q_lo = (blockIdx.x - n * p.chunks) * p.QC;
+    int q_hi = q_lo + p.QC;
+    if (q_hi > p.Q) q_hi = p.Q;
+    const float* gyc = p.gy + (long long)n * p.Lout * p.ldg;
+    float* dxc = p.dx + (long long)n * p.Lin * p.ldx;
+    float* img = lds[wave];
+    constexpr int TEAMS = 4 / WT;
+
+    // source frames q0 - (NTAP - 1) .. q0 + 15 of a sub-tile, zero outside [0, Lout)
+    float4 st[NLD];
+    auto fetch = [&](int q0) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = (u * 64 + lane) * 4;                 // float index inside the (ROWS, COUT) block
+            const int row = e / COUT, col = e - row * COUT;
+            const int l = q0 - (NTAP - 1) + row;
+            st[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < ROWS && (unsigned)l < (unsigned)p.Lout)
+                st[u] = *reinterpret_cast<const float4*>(gyc + (long long)l * p.ldg + col);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = (u * 64 + lane) * 4;
+            const int row = e / COUT, col = e - row * COUT;
+            if (row < ROWS) *reinterpret_cast<float4*>(img + row * PITCH + col) = st[u];
+        }
+    };
+
+    int q0 = q_lo + team * 16;
+    if (q0 < q_hi) fetch(q0);
+    for (; q0 < q_hi; q0 += TEAMS * 16) {
+        __builtin_amdgcn_wave_barrier();
+        stash();
+        __builtin_amdgcn_wave_barrier();
+        const int qn = q0 + TEAMS * 16;
+        if (qn < q_hi) fetch(qn);
+        // A fragments: a[i][c] = gy[q0 + lr - i][4c + lk]  (image row lr + NTAP - 1 - i)
+        float a[NTAP][KC];
+#pragma unroll
+        for (int i = 0; i < NTAP; ++i)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) a[i][c] = img[(lr + NTAP - 1 - i) * PITCH + 4 * c + lk];
+#pragma unroll
+        for (int j = 0; j < NPH; ++j) {
+            const int r = pstart + j * PSTEP;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NTAP; ++i) {
+                if (r + S * i < KS) {                          // wave-uniform: the last phases have one tap less
+#pragma unroll
+                    for (int c = 0; c < KC; ++c)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c], b[j][i][c], acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int q = q0 + lk * 4 + v;
+                const int pos = S * q + r;
+                if (q < q_hi && pos < p.Lin) {
+                    float* d = dxc + (long long)pos * p.ldx + 16 * ct + lr;
+                    *d = p.accumulate ? *d + acc[v] : acc[v];
+                }
+            }
+        }
+    }
+}
+
+template <int COUT, int CIN, int KS, int S>
+int launch_pp(const PpP& p0, hipStream_t stream) {
+    PpP p = p0;
+    p.Q = cdiv(p.Lin, S);
+    // ~3 workgroups per CU; a chunk is a multiple of the 4 x 16 (or 16, in team mode) q a workgroup covers per round
+    const int round = (CIN == 16 ? 4 : 1) * 16;
+    int per_clip = cdiv(768, p.N);
+    if (per_clip < 1) per_clip = 1;
+    p.QC = cdiv(cdiv(p.Q, per_clip), round) * round;
+    p.chunks = cdiv(p.Q, p.QC);
+    hipLaunchKernelGGL((conv_dgrad_pp_k<COUT, CIN, KS, S>), dim3(p.N * p.chunks), dim3(256), 0, stream, p);
+    return 1;
+}
+}  // namespace
+
+// 1 = launched; 0 = shape outside this kernel (the caller falls back to the general one)
+int s2ag_conv_dgrad_pp(const float* gy, const float* w, float* dx, int N, int Lin, int Lout, int Cin, int Cout, int ks,
+                       int stride, int pad, int dil, int ldg, int ldx, int wtm, int accumulate, hipStream_t stream) {
+    if (ks != 15 || stride != 6 || pad != 0 || dil != 1 || ldg % 4 != 0 || ((uintptr_t)gy & 15) != 0) return 0;
+    if ((long long)N * cdiv(cdiv(Lin, 6), 16) > 0x7fffffffLL) return 0;
+    PpP p{};
+    p.gy = gy; p.w = w; p.dx = dx; p.N = N; p.Lin = Lin; p.Lout = Lout; p.ldg = ldg; p.ldx = ldx; p.wtm = wtm;
+    p.accumulate = accumulate;
+    if (Cout == 32 && Cin == 16) return launch_pp<32, 16, 15, 6>(p, stream);
+    if (Cout == 64 && Cin == 32) return launch_pp<64, 32, 15, 6>(p, stream);
+    if (Cout == 32 && Cin == 64) return launch_pp<32, 64, 15, 6>(p, stream);
+    return 0;
+}

@@ -238,6 +238,34 @@ def test_tap_major_strided_conv(S, case):
     assert rel(bg.grad, br.grad) < TOL
 
 
+@pytest.mark.parametrize('Cin,Cout', [(16, 32), (32, 64), (64, 32)])
+@pytest.mark.parametrize('N,Lin', [(1, 15), (3, 16), (2, 97), (5, 1000), (2, 7891)])
+@pytest.mark.parametrize('tap_major', [False, True])
+def test_polyphase_strided_data_gradient(S, Cin, Cout, N, Lin, tap_major):
+    """The poly-phase data-gradient kernel of the wave encoder's strided convs (csrc/conv_pp.hip; k = 15, stride 6) against
+    torch's conv_transpose1d: one output frame, ragged tails (frames no window touches stay zero), several q chunks per
+    clip, both weight layouts, a column-sliced gy and the accumulate flag."""
+    ops = S['ops']
+    k, stride = 15, 6
+    Lout = (Lin - k) // stride + 1
+    g = torch.Generator().manual_seed(Cin + Cout + N + Lin)
+    w = torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)
+    wide = torch.randn(N, Lout, Cout + 8, generator=g)
+    gy = wide[..., 4:4 + Cout]
+    ref = F.conv_transpose1d(gy.transpose(1, 2), w, stride=stride).transpose(1, 2)        # (N, 6 (Lout - 1) + 15, Cin)
+    ref = F.pad(ref, (0, 0, 0, Lin - ref.shape[1]))
+    wg = (w.permute(0, 2, 1).contiguous() if tap_major else w).cuda()
+    gyg = wide.cuda()[..., 4:4 + Cout]
+    dx = torch.full((N * Lin, Cin), float('nan'), device='cuda')
+    ops.conv_bwd_data_raw(gyg.view(N * Lout, Cout), wg, dx, N, Lin, Lout, Cin, Cout, k, stride, 0, 1, False, int(tap_major))
+    assert torch.isfinite(dx).all()
+    assert rel(dx.view(N, Lin, Cin), ref) < TOL
+    base = torch.randn(N * Lin, Cin, generator=g)
+    dx2 = base.cuda()
+    ops.conv_bwd_data_raw(gyg.view(N * Lout, Cout), wg, dx2, N, Lin, Lout, Cin, Cout, k, stride, 0, 1, True, int(tap_major))
+    assert rel(dx2.view(N, Lin, Cin), ref + base.view(N, Lin, Cin)) < TOL
+
+
 @pytest.mark.parametrize('M,K,N', [(4352, 600, 1800), (70, 36, 5), (33, 100, 64), (257, 88, 900), (64, 4, 16)])
 def test_linear_straight_line_kernels_with_tails(S, M, K, N):
     """Linear forward / data gradient / weight gradient (+ bias gradient in the same launch) at shapes whose row, column
