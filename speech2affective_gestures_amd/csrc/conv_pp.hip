@@ -14,8 +14,9 @@
 //   * a sub-tile = 16 consecutive q: its 16 + 2 source frames go through a wave-private LDS image (16-byte global loads,
 //     next sub-tile in flight in registers, no block barrier anywhere), the A fragment of (tap i, 4 channels) is read
 //     ONCE and serves every phase -- gy[q - i] does not depend on r;
-//   * 16 x 16 accumulator tiles are stored straight to dx (64-byte row segments; the S phases of a sub-tile are written
-//     back to back by the same wave, so the lines merge in L2).
+//   * the S phases of a sub-tile interleave into 16 S consecutive frames of dx: the 16 x 16 accumulator tiles go to a
+//     double-buffered LDS image of the workgroup's round and leave as 16-byte stores of whole rows, one barrier per
+//     round (written straight from the accumulators -- 64-byte segments 1.5 KB apart -- the kernel ran at 1.8 TB/s).
 // Wave teams: Cin = 16 -> one wave does all S phases of its own sub-tiles; Cin = 32 -> four waves share a sub-tile
 // (column tile = wave & 1, phases of one parity); Cin = 64 -> wave = column tile, all phases.
 #include "s2ag_common.h"
@@ -46,7 +47,12 @@ __global__ __launch_bounds__(256) void conv_dgrad_pp_k(const PpP p) {
     constexpr int PITCH = COUT + 4;                  // LDS row pitch: 16 rows x 4 k land on 64 distinct banks
     constexpr int NLD = (ROWS * COUT / 4 + 63) / 64; // float4 loads per lane and sub-tile
     static_assert(S % PSTEP == 0 && COUT % 4 == 0 && CIN % 16 == 0, "shape");
+    constexpr int TEAMS = 4 / WT;
+    constexpr int OROWS = TEAMS * 16 * S;            // dx frames a workgroup produces per round
+    constexpr int OPITCH = CIN + 4;                  // pitch of the output image (the 4 row groups of a tile: 2 banks sets)
+    constexpr int C4 = CIN / 4;
     __shared__ float lds[4][ROWS * PITCH];
+    __shared__ float oimg[2][OROWS * OPITCH];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -80,7 +86,6 @@ __global__ __launch_bounds__(256) void conv_dgrad_pp_k(const PpP p) {
     const float* gyc = p.gy + (long long)n * p.Lout * p.ldg;
     float* dxc = p.dx + (long long)n * p.Lin * p.ldx;
     float* img = lds[wave];
-    constexpr int TEAMS = 4 / WT;
 
     // source frames q0 - (NTAP - 1) .. q0 + 15 of a sub-tile, zero outside [0, Lout)
     float4 st[NLD];
@@ -104,41 +109,59 @@ __global__ __launch_bounds__(256) void conv_dgrad_pp_k(const PpP p) {
         }
     };
 
-    int q0 = q_lo + team * 16;
-    if (q0 < q_hi) fetch(q0);
-    for (; q0 < q_hi; q0 += TEAMS * 16) {
-        __builtin_amdgcn_wave_barrier();
-        stash();
-        __builtin_amdgcn_wave_barrier();
-        const int qn = q0 + TEAMS * 16;
-        if (qn < q_hi) fetch(qn);
-        // A fragments: a[i][c] = gy[q0 + lr - i][4c + lk]  (image row lr + NTAP - 1 - i)
-        float a[NTAP][KC];
+    // a round: every team one sub-tile (the round's frames of dx are contiguous: S * 16 * TEAMS rows from S * qr)
+    int buf = 0;
+    if (q_lo + team * 16 < q_hi) fetch(q_lo + team * 16);
+    for (int qr = q_lo; qr < q_hi; qr += TEAMS * 16, buf ^= 1) {
+        const int q0 = qr + team * 16;
+        float* out = oimg[buf];
+        if (q0 < q_hi) {
+            __builtin_amdgcn_wave_barrier();
+            stash();
+            __builtin_amdgcn_wave_barrier();
+            const int qn = q0 + TEAMS * 16;
+            if (qn < q_hi) fetch(qn);
+            // A fragments: a[i][c] = gy[q0 + lr - i][4c + lk]  (image row lr + NTAP - 1 - i)
+            float a[NTAP][KC];
 #pragma unroll
-        for (int i = 0; i < NTAP; ++i)
+            for (int i = 0; i < NTAP; ++i)
 #pragma unroll
-            for (int c = 0; c < KC; ++c) a[i][c] = img[(lr + NTAP - 1 - i) * PITCH + 4 * c + lk];
+                for (int c = 0; c < KC; ++c) a[i][c] = img[(lr + NTAP - 1 - i) * PITCH + 4 * c + lk];
+            // the phases' accumulator chains interleaved (independent MFMAs back to back)
+            f32x4 acc[NPH];
 #pragma unroll
-        for (int j = 0; j < NPH; ++j) {
-            const int r = pstart + j * PSTEP;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NPH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < NTAP; ++i) {
-                if (r + S * i < KS) {                          // wave-uniform: the last phases have one tap less
+            for (int i = 0; i < NTAP; ++i)
 #pragma unroll
-                    for (int c = 0; c < KC; ++c)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c], b[j][i][c], acc, 0, 0, 0);
-                }
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int j = 0; j < NPH; ++j)
+                        if (pstart + j * PSTEP + S * i < KS)       // wave-uniform: the last phases have one tap less
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c], b[j][i][c], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NPH; ++j) {
+                const int r = pstart + j * PSTEP;
+                float* o = out + ((team * 16 + lk * 4) * S + r) * OPITCH + 16 * ct + lr;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) o[v * S * OPITCH] = acc[j][v];
             }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int q = q0 + lk * 4 + v;
-                const int pos = S * q + r;
-                if (q < q_hi && pos < p.Lin) {
-                    float* d = dxc + (long long)pos * p.ldx + 16 * ct + lr;
-                    *d = p.accumulate ? *d + acc[v] : acc[v];
-                }
+        }
+        __syncthreads();
+        // the round's rows of dx: frames S*qr .. , whole rows as 16-byte stores (the other image is being filled meanwhile)
+        int rows = (q_hi - qr) * S;
+        if (rows > OROWS) rows = OROWS;
+        const int pos0 = S * qr;
+        if (pos0 + rows > p.Lin) rows = p.Lin - pos0;
+        for (int e = threadIdx.x; e < rows * C4; e += 256) {
+            const int row = e / C4, c4 = e - row * C4;
+            float4 v = *reinterpret_cast<const float4*>(out + row * OPITCH + 4 * c4);
+            float4* d = reinterpret_cast<float4*>(dxc + (long long)(pos0 + row) * p.ldx + 4 * c4);
+            if (p.accumulate) {
+                const float4 u = *d;
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
             }
+            *d = v;
         }
     }
 }
@@ -147,9 +170,10 @@ template <int COUT, int CIN, int KS, int S>
 int launch_pp(const PpP& p0, hipStream_t stream) {
     PpP p = p0;
     p.Q = cdiv(p.Lin, S);
-    // ~3 workgroups per CU; a chunk is a multiple of the 4 x 16 (or 16, in team mode) q a workgroup covers per round
+    // two workgroups per CU (one round of the chip: measured 256 / 512 / 768 / 1024 workgroups = 67 / 61 / 75 / 71 us at the
+    // conv2 shape); a chunk is a multiple of the 4 x 16 (or 16, in team mode) q a workgroup covers per round
     const int round = (CIN == 16 ? 4 : 1) * 16;
-    int per_clip = cdiv(768, p.N);
+    int per_clip = cdiv(512, p.N);
     if (per_clip < 1) per_clip = 1;
     p.QC = cdiv(cdiv(p.Q, per_clip), round) * round;
     p.chunks = cdiv(p.Q, p.QC);
@@ -161,7 +185,9 @@ int launch_pp(const PpP& p0, hipStream_t stream) {
 // 1 = launched; 0 = shape outside this kernel (the caller falls back to the general one)
 int s2ag_conv_dgrad_pp(const float* gy, const float* w, float* dx, int N, int Lin, int Lout, int Cin, int Cout, int ks,
                        int stride, int pad, int dil, int ldg, int ldx, int wtm, int accumulate, hipStream_t stream) {
-    if (ks != 15 || stride != 6 || pad != 0 || dil != 1 || ldg % 4 != 0 || ((uintptr_t)gy & 15) != 0) return 0;
+    if (ks != 15 || stride != 6 || pad != 0 || dil != 1 || ldg % 4 != 0 || ((uintptr_t)gy & 15) != 0 || ldx % 4 != 0 ||
+        ((uintptr_t)dx & 15) != 0)
+        return 0;
     if ((long long)N * cdiv(cdiv(Lin, 6), 16) > 0x7fffffffLL) return 0;
     PpP p{};
     p.gy = gy; p.w = w; p.dx = dx; p.N = N; p.Lin = Lin; p.Lout = Lout; p.ldg = ldg; p.ldx = ldx; p.wtm = wtm;
