@@ -153,16 +153,43 @@ def gru_roofline(B, iters=20, T=T):
         else:
             L.check(lib.s2ag_gru_seq_fwd(C.c_void_p(gi.data_ptr()), C.c_void_p(whh.data_ptr()),
                                          C.c_void_p(whhT.data_ptr()), *tail, sp), 'gru_seq_fwd')
-    for _ in range(3):
-        launch()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for a, b in evs:
-        a.record(s)
-        launch()
-        b.record(s)
-    torch.cuda.synchronize()
-    ms = sum(a.elapsed_time(b) for a, b in evs) / iters
-    flops = 2.0 * B * T * 2 * H * 3 * H           # recurrent mat-vec MACs x2, both directions
+    # The generator's three passes of a step run each decoder layer as ONE cooperative launch (s2ag_gru_coop_fwd_multi:
+    # same kernel, three passes' slices side by side); the frozen baseline's four layers are single-pass launches.  A step
+    # holds four launches of each kind, so the kernel's average launch -- what a rocprof summary of the step shows -- is
+    # the mean of the two, with (3 + 1) / 2 passes of work.
+    nP = 3
+    multi = coop and bool(lib.s2ag_gru_coop_fwd_multi_supported(nP, B, H))
+    if multi:
+        gis = [gi] + [torch.randn_like(gi) * 0.5 for _ in range(nP - 1)]
+        ys = [y] + [torch.empty_like(y) for _ in range(nP - 1)]
+        yds = [yd] + [torch.empty_like(yd) for _ in range(nP - 1)]
+        rngs = [rng] + [torch.tensor([1, k + 1], dtype=torch.int64, device=dev) for k in range(nP - 1)]
+        arr = lambda ts: (C.c_void_p * nP)(*[None if t is None else t.data_ptr() for t in ts])
+        wsm = torch.empty(lib.s2ag_gru_coop_fwd_multi_workspace_bytes(nP, B, T, H), dtype=torch.uint8, device=dev)
+        a_gi, a_y, a_yd, a_g, a_r = arr(gis), arr(ys), arr(yds), arr([gates] + [None] * (nP - 1)), arr(rngs)
+
+    def launch_multi():
+        L.check(lib.s2ag_gru_coop_fwd_multi(nP, a_gi, C.c_void_p(whh.data_ptr()), C.c_void_p(bhh.data_ptr()), a_y, a_yd,
+                                            a_g, B, T, H, 0.3, a_r, 1, C.c_void_p(wsm.data_ptr()), sp), 'gru_coop_fwd_multi')
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in evs:
+            a.record(s)
+            fn()
+            b.record(s)
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) / iters
+    ms1 = timed(launch)
+    flops1 = 2.0 * B * T * 2 * H * 3 * H          # recurrent mat-vec MACs x2, both directions, one pass
+    if multi:
+        ms3 = timed(launch_multi)
+        ms, flops = 0.5 * (ms1 + ms3), 0.5 * (1 + nP) * flops1
+    else:
+        ms3 = None
+        ms, flops = ms1, flops1
     achieved = flops / (ms * 1e-3) / 1e12
     np_ = int(lib.s2ag_gru_coop_split_pieces()) if coop else 0
     ns_ = int(lib.s2ag_gru_coop_fwd_slices(B)) if coop else 1
@@ -176,10 +203,16 @@ def gru_roofline(B, iters=20, T=T):
             3: '12 waves x 30 bf16 MFMAs (16x16x32; the 6 leading piece products of exact 3-piece splits: '
                'fp32-equivalent) per CU and step'}[np_]
     algo_bytes = 4.0 * B * T * (6 * H + 2 * 2 * H + 2 * 4 * H) + 4.0 * 2 * 3 * H * H
-    return dict(bound='mfma', kernel=name + f' (H=300, T={T}, 2 directions)',
+    if multi:      # the two mate passes save no gates; W_hh is read once per launch
+        algo_bytes = 0.5 * (algo_bytes + algo_bytes + (nP - 1) * 4.0 * B * T * (6 * H + 2 * 2 * H))
+    return dict(bound='mfma', kernel=name + f' (H=300, T={T}, 2 directions' + ('; average launch of the step: 4 three-pass lockstep launches + 4 one-pass launches)' if multi else ')'),
                 achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3, traffic=traffic,
                 traffic_source=source, algorithmic_bytes_per_launch=algo_bytes, ms_per_launch=ms,
                 algorithmic_flops_per_launch=flops,
+                launch_mix=(None if not multi else dict(
+                    per_step='4 x three-pass lockstep launches (generator) + 4 x one-pass launches (frozen baseline)',
+                    three_pass=dict(ms=ms3, tflops=nP * flops1 / (ms3 * 1e-3) / 1e12, frac=nP * flops1 / (ms3 * 1e-3) / 1e12 / 157.3),
+                    one_pass=dict(ms=ms1, tflops=flops1 / (ms1 * 1e-3) / 1e12, frac=flops1 / (ms1 * 1e-3) / 1e12 / 157.3))),
                 note='peak = dense f32 MFMA peak (the arithmetic is fp32); algorithmic FLOPs = 2 x 3H x H per clip, frame '
                      'and direction; algorithmic bytes = gi in, y / dropped y / saved gates out, W_hh once.  Sequential '
                      'recurrence, bound by the per-step exchange latency, not by a pipe: per time step ~1.3 us for the new '
