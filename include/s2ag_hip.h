@@ -610,6 +610,23 @@ int s2ag_counter_inc(int* counter /*nullable*/, unsigned long long* rng /*nullab
 /* noise state of one forward pass: snap[0:2] = rng[0:2], then rng[1] += 1 (the reference draws fresh torch RNG per
  * F.dropout / randn call -- net/tcn.py:22,28, net/embedding_net.py:10-13; here a pass = one counter value) */
 int s2ag_rng_snapshot(unsigned long long* rng, unsigned long long* snap, void* stream);
+/* The snapshots of n consecutive passes in one launch: out (n + n_extra, 2) words; row i < n = {seed, counter + i}, row
+ * n + j = {seed, counter + extra_offsets[j]} (a pass further down the step's pass order, drawn early: the trainer runs the
+ * generator's three passes of a step -- processor_v2.py:798, :823, :909 -- side by side); then counter += n.
+ * extra_offsets: host, <= 8 entries. */
+int s2ag_rng_snapshots(unsigned long long* rng, unsigned long long* out, int n, const int* extra_offsets /*host*/,
+                       int n_extra, void* stream);
+/* pre_seq of a step (processor_v2.py:786-789: new_zeros + two slice assignments): pre (B, T, D + 1) = the first n_pre
+ * frames of target (B, T, D) with 1 in the extra column, 0 elsewhere. */
+int s2ag_make_pre_seq(const float* target, float* pre, int B, int T, int D, int n_pre, void* stream);
+/* The decoder's input of a generator pass -- torch.cat((pre, audio, text), dim=2) and torch.cat((in_data,
+ * z_context.unsqueeze(1).repeat(1, T, 1)), dim=2), net/multimodal_context_net_v2.py:522-536 (:327-331 tri-modal) -- in one
+ * launch: out (rows, sum cols) = the n <= 4 sources side by side; a source with per_clip != 0 has one row per clip of T
+ * frames (the speaker code).  src / cols / ld / per_clip: host arrays.  s2ag_sum_frames is the gradient of such a source:
+ * dz (B, cols) = sum over the T frames of g[:, col0 : col0 + cols] (cols <= 64). */
+int s2ag_concat_cols(const float* const* src, const int* cols, const int* ld, const int* per_clip, int n, float* out,
+                     long long rows, int T, void* stream);
+int s2ag_sum_frames(const float* g, int ldg, int col0, int cols, int B, int T, float* dz, void* stream);
 
 /* materialise the noise a kernel will use (parity tests / debugging only) */
 int s2ag_dropout_mask(const unsigned long long* rng, unsigned site, float p, long long n, float* mask, void* stream);

@@ -184,6 +184,10 @@ SIGNATURES = {
     's2ag_adam_step': [vp, vp, vp, vp, cll, cf, cf, cf, cf, vp, cf, vp],
     's2ag_counter_inc': [vp, vp, vp],
     's2ag_rng_snapshot': [vp, vp, vp],
+    's2ag_rng_snapshots': [vp, vp, ci, vp, ci, vp],
+    's2ag_make_pre_seq': [vp, vp, ci, ci, ci, ci, vp],
+    's2ag_concat_cols': [vp, vp, vp, vp, ci, vp, cll, ci, vp],
+    's2ag_sum_frames': [vp, ci, ci, ci, ci, ci, vp, vp],
     's2ag_dropout_mask': [vp, cu, cf, cll, vp, vp],
     's2ag_normal_noise': [vp, cu, cll, vp, vp],
 }

@@ -423,6 +423,66 @@ __global__ void rng_snapshot_k(unsigned long long* rng, unsigned long long* snap
     }
 }
 
+// the snapshots of SEVERAL consecutive passes (and of passes further down the step's pass order: snapshot 0 with the
+// counter advanced by off[j]) in one launch -- a trainer phase drew them with 3-4 launches plus clone + add pairs
+struct SnapOff { int off[8]; };
+__global__ void rng_snapshots_k(unsigned long long* rng, unsigned long long* out, int n, int n_extra, SnapOff o) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const unsigned long long s = rng[0], c = rng[1];
+        for (int i = 0; i < n; ++i) {
+            out[2 * i] = s;
+            out[2 * i + 1] = c + (unsigned long long)i;
+        }
+        for (int j = 0; j < n_extra; ++j) {
+            out[2 * (n + j)] = s;
+            out[2 * (n + j) + 1] = c + (unsigned long long)o.off[j];
+        }
+        rng[1] = c + (unsigned long long)n;
+    }
+}
+
+// pre_seq (B, T, D + 1): the first n_pre frames of the target poses with a 1 in the extra column, zero elsewhere
+__global__ __launch_bounds__(256) void pre_seq_k(const float* target, float* pre, long long rows, int T, int D, int n_pre) {
+    const long long n = rows * (D + 1);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / (D + 1);
+        const int c = (int)(i - row * (D + 1));
+        const bool on = (int)(row % T) < n_pre;
+        pre[i] = on ? (c < D ? target[row * D + c] : 1.f) : 0.f;
+    }
+}
+
+// out[row, :] = [src0[row] | src1[row] | ...]; a source with per_clip != 0 has one row per clip (row / T): the speaker
+// code z broadcast over the frames of its clip
+struct CatSrc { const float* p; int cols, ld, per_clip; };
+struct CatP { CatSrc s[4]; int n; };
+__global__ __launch_bounds__(256) void concat_cols_k(CatP c, float* out, long long rows, int T, int total) {
+    const long long n = rows * total;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / total;
+        int col = (int)(i - row * total);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < c.n) {
+                if (col >= 0 && col < c.s[k].cols) v = c.s[k].p[(c.s[k].per_clip ? row / T : row) * c.s[k].ld + col];
+                col -= c.s[k].cols;
+            }
+        }
+        out[i] = v;
+    }
+}
+
+// dz[b, c] = sum_t g[(b, t), col0 + c]: gradient of the broadcast source above
+__global__ __launch_bounds__(64) void sum_frames_k(const float* g, int ldg, int col0, int cols, int T, float* dz) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (c >= cols) return;
+    const float* q = g + (long long)b * T * ldg + col0 + c;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += q[(long long)t * ldg];
+    dz[(long long)b * cols + c] = s;
+}
+
 __global__ __launch_bounds__(256) void dropout_mask_k(const unsigned long long* rng, unsigned site, float p,
                                                       float inv_keep, long long n, float* mask) {
     const SiteKey key = site_key(rng, site);
@@ -711,6 +771,48 @@ extern "C" int s2ag_counter_inc(int* counter, unsigned long long* rng, void* str
 extern "C" int s2ag_rng_snapshot(unsigned long long* rng, unsigned long long* snap, void* stream) {
     if (!rng || !snap) return S2AG_E_BADARG;
     hipLaunchKernelGGL(rng_snapshot_k, dim3(1), dim3(64), 0, (hipStream_t)stream, rng, snap);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_rng_snapshots(unsigned long long* rng, unsigned long long* out, int n, const int* extra_offsets,
+                                  int n_extra, void* stream) {
+    if (!rng || !out || n < 1 || n_extra < 0 || n_extra > 8 || (n_extra > 0 && !extra_offsets)) return S2AG_E_BADARG;
+    SnapOff o{};
+    for (int j = 0; j < n_extra; ++j) o.off[j] = extra_offsets[j];
+    hipLaunchKernelGGL(rng_snapshots_k, dim3(1), dim3(64), 0, (hipStream_t)stream, rng, out, n, n_extra, o);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_concat_cols(const float* const* src, const int* cols, const int* ld, const int* per_clip, int n,
+                                float* out, long long rows, int T, void* stream) {
+    if (!src || !cols || !ld || !per_clip || n < 1 || n > 4 || !out || rows < 1 || T < 1) return S2AG_E_BADARG;
+    CatP c{};
+    c.n = n;
+    int total = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!src[k] || cols[k] < 1) return S2AG_E_BADARG;
+        c.s[k] = CatSrc{src[k], cols[k], ld[k], per_clip[k]};
+        total += cols[k];
+    }
+    hipLaunchKernelGGL(concat_cols_k, dim3(ew_grid(rows * total)), dim3(256), 0, (hipStream_t)stream, c, out, rows, T, total);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_sum_frames(const float* g, int ldg, int col0, int cols, int B, int T, float* dz, void* stream) {
+    if (!g || !dz || B < 1 || T < 1 || cols < 1 || cols > 64) return S2AG_E_BADARG;
+    hipLaunchKernelGGL(sum_frames_k, dim3(B), dim3(64), 0, (hipStream_t)stream, g, ldg, col0, cols, T, dz);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_make_pre_seq(const float* target, float* pre, int B, int T, int D, int n_pre, void* stream) {
+    if (!target || !pre || B < 1 || T < 1 || D < 1 || n_pre < 0) return S2AG_E_BADARG;
+    const long long rows = (long long)B * T;
+    hipLaunchKernelGGL(pre_seq_k, dim3(ew_grid(rows * (D + 1))), dim3(256), 0, (hipStream_t)stream, target, pre, rows, T, D,
+                       n_pre);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

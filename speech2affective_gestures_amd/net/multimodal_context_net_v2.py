@@ -320,24 +320,27 @@ class _SpeakerZ:
             out.append(leaf)
         return tuple(out)
 
-    def _decode(self, in_data, z_context, nz, out_slope):
-        if z_context is not None:
-            in_data = torch.cat((in_data, z_context.unsqueeze(1).expand(-1, in_data.shape[1], -1)), dim=2)
+    def _decode(self, in_data, nz, out_slope):
         (in_data,) = self._cut_here(in_data)
         h = self.gru.run(in_data, nz, sum_dirs=True)                                     # (B, T, H), halves summed
         h = ops.linear(h, self.out[0].weight, self.out[0].bias, act=ACT_LEAKY, slope=out_slope)
         return ops.linear(h, self.out[2].weight, self.out[2].bias)
 
-    def _context(self, pre, audio, text):
+    def _context(self, pre, audio, text, z_context=None):
+        """the decoder's input: [pre | audio | text | z broadcast over the frames] (one launch)"""
         if self.input_context == 'both':
-            return torch.cat((pre, audio, text), dim=2)
-        if self.input_context == 'audio':
-            return torch.cat((pre, audio), dim=2)
-        if self.input_context == 'text':
-            return torch.cat((pre, text), dim=2)
-        if self.input_context == 'none':
+            parts = (pre, audio, text)
+        elif self.input_context == 'audio':
+            parts = (pre, audio)
+        elif self.input_context == 'text':
+            parts = (pre, text)
+        elif self.input_context == 'none':
+            parts = (pre,)
+        else:
+            assert False
+        if len(parts) == 1 and z_context is None:
             return pre
-        assert False
+        return ops.context_cat(parts, z_context)
 
 
 class PoseGeneratorTriModal(nn.Module, _SpeakerZ):
@@ -378,7 +381,7 @@ class PoseGeneratorTriModal(nn.Module, _SpeakerZ):
             if self.input_context != 'none':
                 audio, text = res[0], res[1]
                 assert audio.shape[1] == text.shape[1]
-            out = self._decode(self._context(pre_seq, audio, text), z_context, nz, out_slope=1.0)
+            out = self._decode(self._context(pre_seq, audio, text, z_context), nz, out_slope=1.0)
         return out, z_context, z_mu, z_log_var
 
 
@@ -525,7 +528,7 @@ class PoseGenerator(nn.Module, _SpeakerZ):
                 assert audio.shape[1] == text.shape[1], \
                     'Audio and text features must have the same number of time steps. ' \
                     'Found time steps: audio features: {}, text features: {}.'.format(audio.shape[1], text.shape[1])
-            out = self._decode(self._context(pre, audio, text), z_context, nz, out_slope=0.01)
+            out = self._decode(self._context(pre, audio, text, z_context), nz, out_slope=0.01)
             z_mu, z_log_var = self._cut_here(z_mu, z_log_var)
         return out, z_context, z_mu, z_log_var
 
@@ -546,9 +549,7 @@ class PoseGenerator(nn.Module, _SpeakerZ):
                 text = self.text_encoder(in_text)[0]
                 pre, audio = self._shared_encoders(pre_seq, in_mfcc)
                 assert audio.shape[1] == text.shape[1]
-                in_data = self._context(pre, audio, text)
-                if z_context is not None:
-                    in_data = torch.cat((in_data, z_context.unsqueeze(1).expand(-1, in_data.shape[1], -1)), dim=2)
+                in_data = self._context(pre, audio, text, z_context)
                 (in_data,) = self._cut_here(in_data)
                 feats.append((in_data, z_context, z_mu, z_log_var))
         with torch.set_grad_enabled(bool(passes[0][2]) and outer):

@@ -55,6 +55,6 @@ class PoseGenerator(nn.Module, _SpeakerZ):
                 assert audio.shape[1] == text.shape[1], \
                     'Audio and text features must have the same number of time steps. ' \
                     'Found time steps: audio features: {}, text features: {}.'.format(audio.shape[1], text.shape[1])
-            out = self._decode(self._context(pre_seq, audio, text), z_context, nz, out_slope=0.01)
+            out = self._decode(self._context(pre_seq, audio, text, z_context), nz, out_slope=0.01)
             z_mu, z_log_var = self._cut_here(z_mu, z_log_var)
         return out, z_context, z_mu, z_log_var

@@ -54,6 +54,19 @@ def begin_pass(device) -> torch.Tensor:
     return snap
 
 
+def begin_passes(device, n: int, derived=()):
+    """The snapshots of ``n`` consecutive passes (what n ``begin_pass`` calls return) plus, for every offset in
+    ``derived``, the first snapshot with its pass counter advanced by that offset -- ONE launch.  Returns a list of
+    n + len(derived) two-word tensors (rows of one buffer)."""
+    st = _dev_state(device)
+    out = torch.empty((n + len(derived), 2), dtype=st.dtype, device=st.device)
+    offs = (C.c_int * max(1, len(derived)))(*[int(d) for d in derived])
+    L.check(L.load().s2ag_rng_snapshots(C.c_void_p(st.data_ptr()), C.c_void_p(out.data_ptr()), int(n), offs,
+                                        len(derived), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            'rng_snapshots')
+    return [out[i] for i in range(n + len(derived))]
+
+
 @contextmanager
 def noise_pass(device):
     """Scope of one forward pass: nested module forwards share the outermost pass's snapshot."""

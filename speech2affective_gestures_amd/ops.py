@@ -1615,6 +1615,87 @@ def reparametrize(mu: Tensor, log_var: Tensor, noise: Tensor, site: int) -> Tens
     return _Reparam.apply(mu, log_var, noise, site)
 
 
+def make_pre_seq(target: Tensor, n_pre: int) -> Tensor:
+    """(B, T, D) target poses -> (B, T, D + 1) seed sequence: the first ``n_pre`` frames with 1 in the extra column, zero
+    elsewhere (processor_v2.py:786-789) -- one launch."""
+    _need_cuda(target)
+    target = target.contiguous()
+    B, T, D = target.shape
+    pre = torch.empty(B, T, D + 1, dtype=torch.float32, device=target.device)
+    L.check(_lib().s2ag_make_pre_seq(_p(target), _p(pre), B, T, D, int(n_pre), _stream()), 'make_pre_seq')
+    return pre
+
+
+class _ContextCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, *parts):
+        """parts: (B, T, c_k) tensors; z: (B, cz) or None -- broadcast over the frames and appended last."""
+        B, T = parts[0].shape[:2]
+        srcs = [as_rows(t) for t in parts]
+        if z is not None:
+            srcs.append(as_rows(z))
+        n = len(srcs)
+        total = sum(sr[2] for sr in srcs)
+        out = torch.empty(B, T, total, dtype=torch.float32, device=parts[0].device)
+        L.check(_lib().s2ag_concat_cols((C.c_void_p * n)(*[sr[0].data_ptr() for sr in srcs]),
+                                        (C.c_int * n)(*[sr[2] for sr in srcs]), (C.c_int * n)(*[sr[3] for sr in srcs]),
+                                        (C.c_int * n)(*([0] * len(parts) + ([1] if z is not None else []))), n, _p(out),
+                                        B * T, T, _stream()), 'concat_cols')
+        ctx.cols = [sr[2] for sr in srcs]
+        ctx.has_z = z is not None
+        ctx.bt = (B, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T = ctx.bt
+        g = g.contiguous()
+        grads, c0 = [], 0
+        n_parts = len(ctx.cols) - (1 if ctx.has_z else 0)
+        for k in range(n_parts):
+            grads.append(g[..., c0:c0 + ctx.cols[k]] if ctx.needs_input_grad[1 + k] else None)   # views, like CatBackward
+            c0 += ctx.cols[k]
+        dz = None
+        if ctx.has_z and ctx.needs_input_grad[0]:
+            cz = ctx.cols[-1]
+            dz = torch.empty(B, cz, dtype=torch.float32, device=g.device)
+            L.check(_lib().s2ag_sum_frames(_p(g), g.shape[-1], c0, cz, B, T, _p(dz), _stream()), 'sum_frames')
+        return (dz, *grads)
+
+
+def context_cat(parts: Sequence[Tensor], z: Optional[Tensor] = None) -> Tensor:
+    """[parts ... | z broadcast over the frames] along the channel axis in ONE launch (the reference's two torch.cat +
+    repeat, net/multimodal_context_net_v2.py:522-536); the gradient of z is its sum over the frames."""
+    _need_cuda(*parts)
+    if len(parts) + (z is not None) > 4 or (z is not None and z.shape[-1] > 64):
+        x = torch.cat(tuple(parts), dim=2)
+        return x if z is None else torch.cat((x, z.unsqueeze(1).expand(-1, x.shape[1], -1)), dim=2)
+    return _ContextCat.apply(z, *parts)
+
+
+_UNIT_ROOT = [False]
+_ONES = {}
+
+
+def backward_from(loss: Tensor) -> None:
+    """``loss.backward()`` for a loss made by the functions below, without the ATen launches of the implicit root: the
+    gradient of the root is a persistent 1.0 (no fill) and the loss functions hand out the gradients their forward
+    kernel already wrote instead of multiplying them by that 1.0 (was: 1 fill + 1-4 elementwise launches per call, on
+    the critical path between the loss and the first backward kernel)."""
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('run one eager step before hipGraph capture (persistent root gradient)')
+        one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        _ONES[key] = one
+    _UNIT_ROOT[0] = True
+    try:
+        torch.autograd.backward([loss], [one.view(loss.shape)])
+    finally:
+        _UNIT_ROOT[0] = False
+
+
 class _DisLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, d_real, d_fake):
@@ -1630,6 +1711,8 @@ class _DisLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dl):
         gr, gf = ctx.saved_tensors
+        if _UNIT_ROOT[0]:
+            return gr, gf
         return gr * dl, gf * dl
 
 
@@ -1653,6 +1736,8 @@ class _DisLossHalf(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dl):
         (g,) = ctx.saved_tensors
+        if _UNIT_ROOT[0]:
+            return g, None
         return g * dl, None
 
 
@@ -1687,6 +1772,8 @@ class _GenLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dl, _dc):
         g_out, g_dis, g_mu, g_lv = ctx.saved_tensors
+        if _UNIT_ROOT[0]:
+            return g_out, g_dis, g_mu, g_lv, None, None, None, None, None, None
         return g_out * dl, g_dis * dl, g_mu * dl, g_lv * dl, None, None, None, None, None, None
 
 

@@ -493,10 +493,7 @@ class Processor(object):
 
     def _make_pre_seq(self, target_poses):
         n_pre = self.s2ag_config_args.n_pre_poses
-        pre_seq = target_poses.new_zeros((target_poses.shape[0], target_poses.shape[1], target_poses.shape[2] + 1))
-        pre_seq[:, 0:n_pre, :-1] = target_poses[:, 0:n_pre]
-        pre_seq[:, 0:n_pre, -1] = 1
-        return pre_seq
+        return ops.make_pre_seq(target_poses, n_pre)
 
     def _fork(self, idx):
         """side stream ``idx`` picks up after everything queued on the current stream"""
@@ -516,7 +513,9 @@ class Processor(object):
         ops.stamp('D:start')
         self.s2ag_dis_optimizer.zero_grad()
         dev = pre_seq.device
-        nz_g, nz_real, nz_fake = noise.begin_pass(dev), noise.begin_pass(dev), noise.begin_pass(dev)
+        # the three passes of this phase + the generator-phase passes that run early (tri-modal 4th, loss pass 5th, shuffled
+        # speakers 7th of the step): one launch
+        nz_g, nz_real, nz_fake, d_tri, d_main, d_rand = noise.begin_passes(dev, 3, derived=(3, 4, PASSES_PER_STEP - 1))
         cur = torch.cuda.current_stream()
         if self.overlap_passes:
             # The generator forward is the long pole of this phase (D(fake) needs its output): it stays on the main
@@ -542,8 +541,7 @@ class Processor(object):
                 if not (self.s2ag_generator.share_passes and self.early_rand):
                     return
                 with torch.cuda.stream(side1):
-                    nz_rand = nz_g.clone()
-                    nz_rand[1] += PASSES_PER_STEP - 1
+                    nz_rand = d_rand
                 with torch.cuda.stream(side1), torch.no_grad(), noise.use_pass(nz_rand), ops.sequential_branches():
                     rand_vids = vid_indices[torch.randperm(vid_indices.shape[0], device=vid_indices.device)]
                     ops.stamp('D:G(rand) begin [side1]')
@@ -560,9 +558,7 @@ class Processor(object):
                 # decoder layer of the three as one cooperative launch (PoseGenerator.forward_passes).  The loss pass
                 # is the one with autograd; each pass keeps the noise snapshot of its place in the reference's order
                 # (1, 5, 7).  The frozen baseline (pass 4) follows on a forked stream, beside D(fake) and D's backward.
-                nz_main, nz_rand = nz_g.clone(), nz_g.clone()
-                nz_main[1] += 4
-                nz_rand[1] += PASSES_PER_STEP - 1
+                nz_main, nz_rand = d_main, d_rand
                 rand_vids = vid_indices[torch.randperm(vid_indices.shape[0], device=vid_indices.device)]
                 self.s2ag_generator.cut_backward = bool(cut)
                 self.s2ag_generator._cut = None
@@ -574,8 +570,7 @@ class Processor(object):
                 self._early_main = r_main
                 self._early_rand = (r_rand[0], r_rand[1])
                 out_dir_vec = r_dis[0]
-                nz_tri = nz_g.clone()
-                nz_tri[1] += 3
+                nz_tri = d_tri
                 s_tri = self._fork(1)
                 with torch.cuda.stream(s_tri), torch.no_grad(), noise.use_pass(nz_tri), ops.sequential_branches():
                     out_tri, *_ = self.trimodal_generator(pre_seq, in_text, in_audio, vid_indices)
@@ -589,9 +584,7 @@ class Processor(object):
                 # backward nodes then run on the main stream of the generator phase, where weight gradients fork from);
                 # the D step's own generator pass and the baseline run on forked streams beside it.  Each pass keeps
                 # the noise snapshot of its place in the reference's pass order.
-                nz_tri, nz_main = nz_g.clone(), nz_g.clone()
-                nz_tri[1] += 3
-                nz_main[1] += 4
+                nz_tri, nz_main = d_tri, d_main
                 # four streams in all (the runtime maps streams onto four hardware queues; a fifth concurrent stream
                 # shares a queue and serialises behind another pass): main = loss pass, side0 = D(real), side1 = shared
                 # encoders then G(rand), side2 = G(dis) then the baseline
@@ -643,7 +636,7 @@ class Processor(object):
                     # is still running -- only the fake half is left for the critical path behind D(fake).
                     l_real = ops.dis_loss_half(dis_real, True)
                     with ops.local_backward():
-                        l_real.backward()
+                        ops.backward_from(l_real)
                     ops.stamp('D:D(real) backward end [side]')
                     real_bwd_done = torch.cuda.Event()
                     real_bwd_done.record(side)
@@ -667,7 +660,7 @@ class Processor(object):
             # the fake half accumulates into the same stages, so it must start after that flush.  D(real)'s backward
             # (~1 ms) began while the generator pass was still running: the wait is normally already satisfied.
             cur.wait_event(real_bwd_done)
-            l_fake.backward()
+            ops.backward_from(l_fake)
             dis_error = l_fake.detach()
             ops.join_side_streams()
             dis_error = dis_error + l_real.detach()
@@ -675,7 +668,7 @@ class Processor(object):
             dis_error = ops.dis_loss(dis_real, dis_fake)
             ops.stamp('D:D(fake) end, backward begins')
             if train:
-                dis_error.backward()
+                ops.backward_from(dis_error)
             ops.join_side_streams()      # backward kernels ran on the forked streams too
         ops.stamp('D:end')
         return dis_error.detach()
@@ -697,7 +690,7 @@ class Processor(object):
         self.s2ag_gen_optimizer.zero_grad()
         dev = pre_seq.device
         # pass order of the reference: tri-modal baseline, G(main), D(gen), G(rand)
-        nz_tri, nz_main, nz_dgen, nz_rand = (noise.begin_pass(dev) for _ in range(4))
+        nz_tri, nz_main, nz_dgen, nz_rand = noise.begin_passes(dev, 4)
         early = getattr(self, '_early_rand', None)        # G(rand) already ran beside the D step (see _dis_phase)
         self._early_rand = None
         if early is None:
@@ -758,7 +751,7 @@ class Processor(object):
             if self.encoders_apart:
                 ops.mark_side_stream(self._side[0])
         if train:
-            total.backward()
+            ops.backward_from(total)
         ops.join_side_streams()
         ops.stamp('G:end' if not self.s2ag_generator.cut_backward else 'G:decoder backward done (bucket A complete)')
         return comps
