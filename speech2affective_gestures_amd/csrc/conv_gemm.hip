@@ -957,6 +957,9 @@ int s2ag_gemm_conv_tm_fwd(const float* x, const float* w, const float* bias, flo
 int s2ag_gemm_conv_tm_bwd_data(const float* gy, const float* w, float* dx, int nclips, int L, int Cin, int Cout, int ks,
                                int pad, int dil, int ldg, int ldx, int accumulate, hipStream_t stream);
 // conv_pp.hip
+int s2ag_conv_fwd_fw(const float* x, const float* w, const float* bias, float* y, int N, int Lin, int Lout, int Cin,
+                     int Cout, int ks, int stride, int pad, int dil, int ldx, int ldy, int wtm, int act, float slope,
+                     float drop_p, double* stats, hipStream_t stream);
 int s2ag_conv_dgrad_pp(const float* gy, const float* w, float* dx, int N, int Lin, int Lout, int Cin, int Cout, int ks,
                        int stride, int pad, int dil, int ldg, int ldx, int wtm, int accumulate, hipStream_t stream);
 
@@ -986,6 +989,15 @@ static int conv1d_nlc_fwd_impl(const float* x, const float* w, const float* bias
     if (use_gemm_lin() && g->ksize == 1 && g->stride == 1 && g->pad == 0 && g->Lin == g->Lout &&
         (rows_ = s2ag_gemm_lin_fwd(x, w, bias, y, p.M, g->Cin, g->Cout, g->ldx, g->ldy, p.act, p.slope, p.drop_p, p.rng,
                                    p.site, stats, (hipStream_t)stream))) {
+        S2AG_LAUNCH_CHECK();
+        if (stat_rows && stats) *stat_rows = rows_;
+        return 0;
+    }
+    // the wave encoder's Conv1d(16, 32, 15, stride 6): flat-window kernel with the weights in registers (conv_pp.hip)
+    static const bool use_fw = [] { const char* e = getenv("S2AG_FWD_FW"); return !(e && e[0] == '0'); }();
+    if (use_fw && g->stride > 1 &&
+        (rows_ = s2ag_conv_fwd_fw(x, w, bias, y, g->N, g->Lin, g->Lout, g->Cin, g->Cout, g->ksize, g->stride, g->pad, g->dil,
+                                  g->ldx, g->ldy, g->w_tap_major, p.act, p.slope, p.drop_p, stats, (hipStream_t)stream))) {
         S2AG_LAUNCH_CHECK();
         if (stat_rows && stats) *stat_rows = rows_;
         return 0;

@@ -180,6 +180,159 @@ int launch_pp(const PpP& p0, hipStream_t stream) {
     hipLaunchKernelGGL((conv_dgrad_pp_k<COUT, CIN, KS, S>), dim3(p.N * p.chunks), dim3(256), 0, stream, p);
     return 1;
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward of the same layers in the same style (Conv1d(16, 32, 15, stride=6) of the wave encoder; the general straight-
+// line kernel spent half of its 64-wide column tile on nothing at Cout = 32: 154 us at B = 256).  Without padding and with
+// channels-last rows of exactly Cin floats the window of output frame l is ONE run of K = KS * Cin contiguous floats that
+// starts S * Cin floats after the previous one ("flat window"):
+//     y[n, l, co] = act( bias[co] + sum_k x[n, S Cin l + k] * W[co, k] ),    W = the tap-major weight (Cout, KS * Cin)
+// A wave keeps W for all its column tiles in registers (K / 4 x Cout / 16 <= 120 VGPRs), stages the (15 S + KS) Cin floats
+// under 16 output frames in a wave-private LDS image (a 4-float pad after every S Cin floats puts the 16 rows x 4 k of a
+// fragment read on 64 different banks), and emits the fp64 column sums of the BatchNorm that follows (one partial row per
+// workgroup).
+struct FwP {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    double* stats;
+    int N, Lin, Lout, ldy, wtm, act;
+    float slope;
+    int chunks, LC;     // output-frame chunks per clip, frames per chunk (multiple of 64)
+};
+
+template <int CIN, int COUT, int KS, int S>
+__global__ __launch_bounds__(256) void conv_fwd_fw_k(const FwP p) {
+    constexpr int K = KS * CIN, KC = K / 4, NCT = COUT / 16;
+    constexpr int RS = S * CIN;                          // floats between the windows of consecutive frames
+    constexpr int SPAN = 15 * RS + K;                    // floats under a sub-tile of 16 frames
+    constexpr int IMG = SPAN + 4 * (SPAN / RS) + 4;
+    constexpr int NLD = (SPAN / 4 + 63) / 64;
+    static_assert(RS % 4 == 0 && K % 4 == 0 && KC * NCT <= 128, "shape");
+    __shared__ float lds[4][IMG];
+    __shared__ double red[4][2][COUT];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+
+    // b[ct][c] = W[co = 16 ct + lr][k = 4 c + lk]
+    float b[NCT][KC];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int co = 16 * ct + lr, k = 4 * c + lk;
+            const int t = k / CIN, ci = k - t * CIN;
+            b[ct][c] = p.wtm ? p.w[(long long)co * K + k] : p.w[((long long)co * CIN + ci) * KS + t];
+        }
+    float bias[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) bias[ct] = p.bias ? p.bias[16 * ct + lr] : 0.f;
+
+    const int n = blockIdx.x / p.chunks;
+    const int l_lo = (blockIdx.x - n * p.chunks) * p.LC;
+    int l_hi = l_lo + p.LC;
+    if (l_hi > p.Lout) l_hi = p.Lout;
+    const float* xc = p.x + (long long)n * p.Lin * CIN;
+    const long long xlen = (long long)p.Lin * CIN;
+    float* yc = p.y + (long long)n * p.Lout * p.ldy;
+    float* img = lds[wave];
+
+    float4 st[NLD];
+    auto fetch = [&](int l0) {
+        const long long base = (long long)l0 * RS;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = (u * 64 + lane) * 4;
+            st[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < SPAN && base + e + 3 < xlen) st[u] = *reinterpret_cast<const float4*>(xc + base + e);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = (u * 64 + lane) * 4;
+            if (e < SPAN) *reinterpret_cast<float4*>(img + e + 4 * (e / RS)) = st[u];
+        }
+    };
+
+    double s1[NCT], s2[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) s1[ct] = s2[ct] = 0.0;
+
+    int l0 = l_lo + wave * 16;
+    if (l0 < l_hi) fetch(l0);
+    for (; l0 < l_hi; l0 += 64) {
+        __builtin_amdgcn_wave_barrier();
+        stash();
+        __builtin_amdgcn_wave_barrier();
+        if (l0 + 64 < l_hi) fetch(l0 + 64);
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* arow = img + (RS + 4) * lr + lk;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const float a = arow[4 * c + 4 * ((4 * c) / RS)];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[ct][c], acc[ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int l = l0 + 4 * lk + v;
+                if (l < l_hi) {
+                    const float r = apply_act(acc[ct][v] + bias[ct], p.act, p.slope);
+                    yc[(long long)l * p.ldy + 16 * ct + lr] = r;
+                    s1[ct] += (double)r;
+                    s2[ct] += (double)r * (double)r;
+                }
+            }
+    }
+    if (p.stats) {          // (2, gridDim.x, COUT): one partial row per workgroup
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            double a1 = s1[ct], a2 = s2[ct];
+            a1 += __shfl_xor(a1, 16, 64);
+            a1 += __shfl_xor(a1, 32, 64);
+            a2 += __shfl_xor(a2, 16, 64);
+            a2 += __shfl_xor(a2, 32, 64);
+            if (lane < 16) {
+                red[wave][0][16 * ct + lane] = a1;
+                red[wave][1][16 * ct + lane] = a2;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * COUT) {
+            const int which = threadIdx.x / COUT, c = threadIdx.x - which * COUT;
+            const double v = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+            p.stats[((size_t)which * gridDim.x + blockIdx.x) * COUT + c] = v;
+        }
+    }
+}
+}  // namespace
+
+// rows of BatchNorm partials written (= workgroups) if launched, 0 if the shape is outside this kernel
+int s2ag_conv_fwd_fw(const float* x, const float* w, const float* bias, float* y, int N, int Lin, int Lout, int Cin,
+                     int Cout, int ks, int stride, int pad, int dil, int ldx, int ldy, int wtm, int act, float slope,
+                     float drop_p, double* stats, hipStream_t stream) {
+    if (ks != 15 || stride != 6 || pad != 0 || dil != 1 || Cin != 16 || Cout != 32 || ldx != Cin || drop_p > 0.f ||
+        (act != S2AG_ACT_NONE && act != S2AG_ACT_LEAKY) || ((uintptr_t)x & 15) != 0 || Lout < 64)
+        return 0;
+    FwP p{};
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.stats = stats; p.N = N; p.Lin = Lin; p.Lout = Lout; p.ldy = ldy; p.wtm = wtm;
+    p.act = act; p.slope = slope;
+    int per_clip = cdiv(512, N);
+    if (per_clip < 1) per_clip = 1;
+    p.LC = cdiv(cdiv(Lout, per_clip), 64) * 64;
+    p.chunks = cdiv(Lout, p.LC);
+    hipLaunchKernelGGL((conv_fwd_fw_k<16, 32, 15, 6>), dim3(N * p.chunks), dim3(256), 0, stream, p);
+    return N * p.chunks;
+}
+
+namespace {
 }  // namespace
 
 // 1 = launched; 0 = shape outside this kernel (the caller falls back to the general one)

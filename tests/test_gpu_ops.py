@@ -63,6 +63,7 @@ def test_rng_matches_numpy_restatement(S):
 CONV_CASES = [
     (3, 700, 1, 16, 15, 5, 160, 1, False),     # WavEncoder conv1 shape family (Cin = 1, big padding)
     (3, 300, 16, 32, 15, 6, 0, 1, False),      # strided
+    (3, 800, 16, 32, 15, 6, 0, 1, False),      # strided, flat-window forward kernel with reference-layout weights
     (2, 37, 71, 64, 5, 1, 2, 1, False),        # MFCCEncoder conv1 (odd channel count -> scalar loads)
     (4, 34, 300, 300, 2, 1, 4, 4, True),       # TCN block, dilation 4, causal + chomp
     (5, 34, 27, 16, 3, 1, 0, 1, False),        # ConvDiscriminator pre_conv
@@ -203,6 +204,9 @@ def test_one_channel_wave_conv_direct_kernels(S, N, Lin, stride, pad):
 # forward + weight gradient on the straight-line kernels, data gradient on the general residue kernel
 TM_STRIDED = [
     (3, 300, 16, 32, 15, 6, 0),               # WavEncoder conv2 (Cin < 32: several taps per 32-wide K tile)
+    (3, 1000, 16, 32, 15, 6, 0),              # ... long enough for the flat-window forward kernel (Lout = 165: ragged tail)
+    (2, 7891, 16, 32, 15, 6, 0),              # ... at the encoder's own length (Lout = 1313, several chunks per clip)
+    (70, 399, 16, 32, 15, 6, 0),              # ... Lout = 65: one chunk per clip, second wave round nearly empty
     (2, 260, 32, 64, 15, 6, 0),               # WavEncoder conv3
     (5, 250, 64, 32, 15, 6, 0),               # WavEncoder conv4: Lout = 40
     (4, 77, 20, 24, 5, 2, 3),                 # padding + stride, K = 100 (tail), Lout = 40
