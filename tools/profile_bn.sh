@@ -1,3 +1,4 @@
+export S2AG_BENCH_SUPERVISE=0   # bench.py in THIS process (rocprofv3 then sees one process)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/bnp; mkdir -p $O; cd $R
 for v in 0 1; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel traces of BASELINE configs[3] in both modes (writes gpurun_out/r02q; summaries are copied to profiles/)
+export S2AG_BENCH_SUPERVISE=0   # bench.py in THIS process (rocprofv3 then sees one process)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02q; mkdir -p $O
 cd $R

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-2 profiles on the GPU box (writes under gpurun_out/r02p; the summaries are copied to profiles/ afterwards).
 set -x
+export S2AG_BENCH_SUPERVISE=0   # bench.py in THIS process (rocprofv3 then sees one process)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02p; mkdir -p $O
 cd $R

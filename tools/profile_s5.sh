@@ -1,5 +1,6 @@
 #!/bin/bash
 # session profile: ATen inventory, phase stamps, kernel trace of the graph-replayed step (+ one-step window)
+export S2AG_BENCH_SUPERVISE=0   # bench.py in THIS process (rocprofv3 then sees one process)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG:-s5}; mkdir -p $O; cd $R
 [ -n "$ATEN" ] && timeout 300 python tools/aten_in_step.py > $O/aten.txt 2>&1
