@@ -536,6 +536,14 @@ long long s2ag_tcn32_pack_elems(int n_convs);
 long long s2ag_tcn32_keep_bytes(int n_clips, int n_blocks);
 int s2ag_tcn32_pack(const float* const* w, int n_convs, int C, void* wfrag, void* stream);
 int s2ag_tcn32_fwd(const s2ag_tcn32_args* a, void* stream);
+/* Several forward passes over the SAME weights and token ids as one batch of a->n_clips = n_passes * B clips (the trainer's
+ * three generator passes of a step, processor_v2.py:798, :823, :909, differ in noise only; one workgroup per clip leaves
+ * half of the chip idle at B = 128): pass k = clips [k B, (k + 1) B) draws its dropout keep bits from rngs[k] (host array
+ * of device pointers; a->rng is ignored) with clip indices relative to the pass -- bit-identical to the pass run alone.
+ * Only clips < save_clips (the pass with autograd) leave h1 / h2 / y of every block -- those buffers need save_clips * T
+ * rows --, the others only the last block's y (a->y[n_blocks - 1]: n_clips * T rows). */
+int s2ag_tcn32_fwd_passes(const s2ag_tcn32_args* a, int n_passes, const void* const* rngs /*host*/, int save_clips,
+                          void* stream);
 int s2ag_tcn32_bwd(const s2ag_tcn32_args* a, void* stream);
 /* up to 8 s2ag_bf16_conv_wgrad jobs in one launch (the TCN's eight weight gradients fill the chip together) */
 #define S2AG_BF16_MAX_WGRAD_JOBS 8

@@ -166,6 +166,7 @@ SIGNATURES = {
     's2ag_tcn32_keep_bytes': [ci, ci],
     's2ag_tcn32_pack': [vp, ci, ci, vp, vp],
     's2ag_tcn32_fwd': [vp, vp],
+    's2ag_tcn32_fwd_passes': [vp, ci, vp, ci, vp],
     's2ag_tcn32_bwd': [vp, vp],
     's2ag_bf16_conv_wgrad_tr_scratch_floats': [vp, ci],
     's2ag_bf16_conv_wgrad_tr': [vp, ci, vp, cll, vp],

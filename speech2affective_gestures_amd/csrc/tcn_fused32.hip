@@ -53,6 +53,8 @@ struct T32P {
     const unsigned long long* rng;
     unsigned site[2 * S2AG_TCN_MAX_BLOCKS];
     u32x4* keep;                                // one u32x4 per thread, workgroup and conv (tcn32_keep_k)
+    int keep_total, keep_off;                   // clips of the keep layout [conv][clip][256]; first clip of this pass in it
+    int save_clips;                             // clips < save_clips leave h1 / h2 / y of every block, the others only the last y
 };
 
 // keep bits of one pass in the epilogue's register layout: bit (i*MT + mt)*4 + c of thread (wave, lane)
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void tcn32_keep_k(const T32P p) {
             }
         }
     }
-    p.keep[((size_t)cv * gridDim.x + wg) * 256 + tid] = u32x4{w[0], w[1], w[2], w[3]};
+    p.keep[((size_t)cv * p.keep_total + p.keep_off + wg) * 256 + tid] = u32x4{w[0], w[1], w[2], w[3]};
 }
 
 // acc += conv over the fp32 LDS rows at `src`: K tile kt = tap kt / KT_TAP (rows q - d forward, q + d backward for tap 0;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void tcn32_fwd_k(const T32P p) {
                 for (int c = 0; c < 4; ++c) bv[i][c] = (bias && co + c < C) ? bias[co + c] : 0.f;
             }
             u32x4 kv = u32x4{0u, 0u, 0u, 0u};
-            if (drop) kv = p.keep[((size_t)cv * gridDim.x + blockIdx.x) * 256 + tid];
+            if (drop) kv = p.keep[((size_t)cv * p.keep_total + blockIdx.x) * 256 + tid];
 #pragma unroll
             for (int i = 0; i < CT_W; ++i)
 #pragma unroll
@@ -223,11 +225,15 @@ __global__ __launch_bounds__(256) void tcn32_fwd_k(const T32P p) {
             for (int idx = tid; idx < T * cpr; idx += 256) {
                 const int m = idx / cpr, kc = idx - m * cpr;
                 const long long go = (row0 + m) * C + kc * 4;
+                const bool save = (int)blockIdx.x < p.save_clips;      // a no-grad pass of a lockstep batch keeps nothing
                 if (j == 0) {
-                    *reinterpret_cast<f32x4*>(p.h1[blk] + go) = *reinterpret_cast<const f32x4*>(sm + H1 + m * PITCH + kc * 4);
+                    if (save)
+                        *reinterpret_cast<f32x4*>(p.h1[blk] + go) = *reinterpret_cast<const f32x4*>(sm + H1 + m * PITCH + kc * 4);
                 } else {
-                    *reinterpret_cast<f32x4*>(p.h2[blk] + go) = *reinterpret_cast<const f32x4*>(sm + H2 + m * PITCH + kc * 4);
-                    *reinterpret_cast<f32x4*>(p.y[blk] + go) = *reinterpret_cast<const f32x4*>(sm + X + m * PITCH + kc * 4);
+                    if (save)
+                        *reinterpret_cast<f32x4*>(p.h2[blk] + go) = *reinterpret_cast<const f32x4*>(sm + H2 + m * PITCH + kc * 4);
+                    if (save || blk == p.n_blocks - 1)
+                        *reinterpret_cast<f32x4*>(p.y[blk] + go) = *reinterpret_cast<const f32x4*>(sm + X + m * PITCH + kc * 4);
                 }
             }
         }
@@ -389,10 +395,11 @@ extern "C" int s2ag_tcn32_pack(const float* const* w, int n_convs, int C, void* 
     return 0;
 }
 
-extern "C" int s2ag_tcn32_fwd(const s2ag_tcn32_args* a, void* stream) {
+static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* const* rngs, int save_clips, void* stream) {
     if (!a || !a->x || !a->wfrag || a->n_blocks < 1 || a->n_blocks > S2AG_TCN_MAX_BLOCKS || a->n_clips <= 0) return S2AG_E_BADARG;
     if (!s2ag_tcn32_supported(a->T, a->C, 2)) return S2AG_E_UNSUPPORTED;
-    if (a->drop_p < 0.f || a->drop_p >= 1.f || (a->drop_p > 0.f && (!a->rng || !a->keep))) return S2AG_E_BADARG;
+    if (n_passes < 1 || a->n_clips % n_passes != 0 || save_clips < 0 || save_clips > a->n_clips) return S2AG_E_BADARG;
+    if (a->drop_p < 0.f || a->drop_p >= 1.f || (a->drop_p > 0.f && (!rngs || !a->keep))) return S2AG_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(a->x)) & 15) return S2AG_E_BADARG;
     T32P p{};
     p.x = a->x; p.wfrag = static_cast<const bf16_t*>(a->wfrag);
@@ -408,8 +415,8 @@ extern "C" int s2ag_tcn32_fwd(const s2ag_tcn32_args* a, void* stream) {
     p.n_blocks = a->n_blocks; p.n_clips = a->n_clips; p.T = a->T; p.C = a->C;
     p.drop_p = a->drop_p;
     p.inv_keep = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
-    p.rng = static_cast<const unsigned long long*>(a->rng);
     p.keep = static_cast<u32x4*>(a->keep);
+    p.keep_total = a->n_clips; p.keep_off = 0; p.save_clips = save_clips;
     const size_t lds = (size_t)(3 * p.T + 1) * PITCH * sizeof(float);
     static bool attr = false;
     if (!attr) {
@@ -417,11 +424,30 @@ extern "C" int s2ag_tcn32_fwd(const s2ag_tcn32_args* a, void* stream) {
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
-    if (p.drop_p > 0.f)
-        hipLaunchKernelGGL(tcn32_keep_k, dim3(p.n_clips, 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.drop_p > 0.f) {
+        const int per = a->n_clips / n_passes;          // the keep bits of every pass from ITS noise snapshot, clip index
+        for (int k = 0; k < n_passes; ++k) {            // relative to the pass: exactly the bits of a pass run alone
+            if (!rngs[k]) return S2AG_E_BADARG;
+            T32P q = p;
+            q.rng = static_cast<const unsigned long long*>(rngs[k]);
+            q.keep_off = k * per;
+            hipLaunchKernelGGL(tcn32_keep_k, dim3(per, 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, q);
+        }
+    }
     hipLaunchKernelGGL(tcn32_fwd_k, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int s2ag_tcn32_fwd(const s2ag_tcn32_args* a, void* stream) {
+    if (!a) return S2AG_E_BADARG;
+    const void* r[1] = {a->rng};
+    return tcn32_fwd_impl(a, 1, r, a->n_clips, stream);
+}
+
+extern "C" int s2ag_tcn32_fwd_passes(const s2ag_tcn32_args* a, int n_passes, const void* const* rngs, int save_clips,
+                                     void* stream) {
+    return tcn32_fwd_impl(a, n_passes, rngs, save_clips, stream);
 }
 
 extern "C" int s2ag_tcn32_bwd(const s2ag_tcn32_args* a, void* stream) {

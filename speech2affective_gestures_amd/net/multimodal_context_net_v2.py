@@ -211,6 +211,35 @@ class TextEncoderTCN(nn.Module):
             y = ops.linear(y, self.decoder.weight, self.decoder.bias)
         return y.contiguous(), 0
 
+    def lockstep_capable(self, in_data):
+        """forward_passes covers the default fp32 training path with the clip-resident TemporalConvNet."""
+        from .. import bf16
+        return bool(self.training and not bf16.enabled() and in_data.dim() == 2
+                    and self.tcn.lockstep_capable(in_data.shape[1], self.embedding.weight.shape[1]))
+
+    def forward_passes(self, in_data, noises, grad=True):
+        """Several passes over the same token ids in LOCKSTEP (the trainer's generator passes of a step differ in noise
+        only): ``noises[k]`` is pass k's snapshot; only pass 0 carries autograd.  The passes' embedding rows go into one
+        (nP * B, T, E) batch and the TemporalConvNet runs once over it -- one workgroup per clip leaves half of the chip
+        idle at B = 128 -- then the decoder once for pass 0 and once for the rest.  Returns [(B, T, 32)] * nP, bit-identical to
+        the passes run one after the other."""
+        nP, (B, T) = len(noises), in_data.shape
+        E = self.embedding.weight.shape[1]
+        p = self.drop.p if self.training else 0.0
+        big = torch.empty(nP * B, T, E, dtype=torch.float32, device=in_data.device)
+        outer = torch.is_grad_enabled()
+        with torch.set_grad_enabled(bool(grad) and outer):
+            emb0 = ops.embedding(in_data, self.embedding.weight, p, noises[0], self.site, out=big[:B])
+        with torch.no_grad():
+            for k in range(1, nP):
+                ops.embedding(in_data, self.embedding.weight, p, noises[k], self.site, out=big[k * B:(k + 1) * B])
+        with torch.set_grad_enabled(bool(grad) and outer):
+            y0, ym = self.tcn.forward_nlc(emb0, noises[0], batch=big, noises=noises)
+            out0 = ops.linear(y0, self.decoder.weight, self.decoder.bias)
+        with torch.no_grad():
+            outm = ops.linear(ym, self.decoder.weight, self.decoder.bias)
+        return [out0.contiguous()] + [outm[(k - 1) * B:k * B] for k in range(1, nP)]
+
 
 class AffEncoder(nn.Module):
     """:94-175.  (B, T, 27) -> (B, T, 8).  A1/A2 are non-persistent buffers (the reference keeps them as plain
@@ -418,6 +447,11 @@ class ConvDiscriminatorTriModal(nn.Module):
 ConvDiscriminator = ConvDiscriminatorTriModal     # name used by net/multimodal_context_net_v2_abl_aff.py:394
 
 
+# the three text-encoder passes of a step as one batch (TextEncoderTCN.forward_passes): measured neutral on the step
+# (-0.5 %: the clip-resident TemporalConvNet is bound by its weight stream from L2, not by its 128 workgroups), off
+LOCKSTEP_TEXT = __import__('os').environ.get('S2AG_LOCKSTEP_TEXT', '0') != '0'
+
+
 class PoseGenerator(nn.Module, _SpeakerZ):
     """:438-546.  forward(pre_seq (B,T,28), in_text (B,T) i64, in_mfcc (B,37,71), vid_indices (B,) i64)
     -> (poses (B,T,27), z_context, z_mu, z_log_var)."""
@@ -543,10 +577,13 @@ class PoseGenerator(nn.Module, _SpeakerZ):
         assert self.share_passes and self.input_context != 'none' and not any(g for _, _, g in passes[1:])
         outer = torch.is_grad_enabled()
         feats = []
+        texts = None
+        if LOCKSTEP_TEXT and len(passes) > 1 and self.text_encoder.lockstep_capable(in_text):
+            texts = self.text_encoder.forward_passes(in_text, [nz for _, nz, _ in passes], grad=passes[0][2])
         for k, (vid, nz, grad) in enumerate(passes):
             with torch.set_grad_enabled(bool(grad) and outer), use_pass(nz):
                 z_context, z_mu, z_log_var = self._z(in_text, vid, nz)
-                text = self.text_encoder(in_text)[0]
+                text = texts[k] if texts is not None else self.text_encoder(in_text)[0]
                 pre, audio = self._shared_encoders(pre_seq, in_mfcc)
                 assert audio.shape[1] == text.shape[1]
                 in_data = self._context(pre, audio, text, z_context)

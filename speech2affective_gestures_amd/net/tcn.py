@@ -102,21 +102,31 @@ class TemporalConvNet(nn.Module):
                                                 [c.weight_g for c in convs[i:i + n]]) for i in range(0, len(convs), n)]
         return self._groups
 
-    def forward_nlc(self, x, noise):
+    def _fused32_ok(self, x, blks):
+        return (x.dim() == 3 and all(b.kernel_size == 2 and b.p == blks[0].p and b.downsample is None for b in blks)
+                and ops.tcn_fused32_supported(x.shape[1], blks[0].conv1.out_channels, 2, len(blks))
+                and x.shape[2] == blks[0].conv1.in_channels == blks[0].conv1.out_channels)
+
+    def forward_nlc(self, x, noise, batch=None, noises=None):
+        """``batch`` / ``noises``: x is the first pass of a lockstep batch (ops.tcn_fused32); then (out, mate outputs)."""
         ws = [w for g in self._weight_groups() for w in g.tensors()]
         blks = list(self.network)
-        if (x.dim() == 3 and all(b.kernel_size == 2 and b.p == blks[0].p and b.downsample is None for b in blks)
-                and ops.tcn_fused32_supported(x.shape[1], blks[0].conv1.out_channels, 2, len(blks))
-                and x.shape[2] == blks[0].conv1.in_channels == blks[0].conv1.out_channels):
+        if self._fused32_ok(x, blks):
             # clip-resident forward (csrc/tcn_fused32.hip): every block in ONE launch; backward layer by layer
             if self.__dict__.get('_frag32') is None:
                 self.__dict__['_frag32'] = ops.TcnFragments32()
             p = blks[0].p if self.training else 0.0
             return ops.tcn_fused32(x, self.__dict__['_frag32'], ws, [c.bias for b in blks for c in (b.conv1, b.conv2)],
-                                   [b.dilation for b in blks], [s for b in blks for s in b.sites], p, noise)
+                                   [b.dilation for b in blks], [s for b in blks for s in b.sites], p, noise,
+                                   batch=batch, noises=noises)
+        assert batch is None, 'lockstep batches need the clip-resident kernel (check lockstep_capable first)'
         for i, blk in enumerate(blks):
             x = blk.forward_nlc(x, noise, weights=ws[2 * i:2 * i + 2])
         return x
+
+    def lockstep_capable(self, T, C):
+        blks = list(self.network)
+        return self._fused32_ok(torch.empty(0, T, C), blks)
 
     def bf16_capable(self):
         """The bf16 path covers the shape the S2AG text encoder uses: no down-sampling residual (in == out channels)."""

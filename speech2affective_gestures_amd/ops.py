@@ -792,7 +792,8 @@ class _TcnFused32(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, frags, meta, noise, *params):
-        dils, sites, drop_p = meta
+        dils, sites, drop_p = meta[:3]
+        big, noises = (meta[3], meta[4]) if len(meta) > 3 else (None, None)
         nb = len(dils)
         ws, bs = params[:2 * nb], params[2 * nb:]
         lib = _lib()
@@ -800,31 +801,50 @@ class _TcnFused32(torch.autograd.Function):
         x2, rows, cols, ldx = as_rows(x)
         if ldx != cols:
             x2 = x2.contiguous()
+        nP = 1
+        if big is not None:
+            # lockstep batch: x is the first B clips of ``big`` (nP * B clips, one pass after the other; pass k draws its keep
+            # bits from noises[k]); only x's pass keeps what the backward pass needs
+            nP = len(noises)
+            assert big.is_contiguous() and big.shape == (nP * B, T, Cch) and x2.data_ptr() == big.data_ptr() and noises[0] is noise
         frag = frags.get(ws)
-        saved = torch.empty(3 * nb, rows, Cch, dtype=torch.float32, device=x.device)     # h1, h2, y per block
+        saved = torch.empty(3 * nb - 1, rows, Cch, dtype=torch.float32, device=x.device)     # h1, h2, y per block ...
+        y_last = torch.empty(nP * rows, Cch, dtype=torch.float32, device=x.device)           # ... the last y of every pass
         a = L.Tcn32()
         a.x, a.wfrag = x2.data_ptr(), frag.data_ptr()
         for b in range(nb):
-            a.h1[b], a.h2[b], a.y[b] = saved[3 * b].data_ptr(), saved[3 * b + 1].data_ptr(), saved[3 * b + 2].data_ptr()
+            a.h1[b], a.h2[b] = saved[3 * b].data_ptr(), saved[3 * b + 1].data_ptr()
+            a.y[b] = saved[3 * b + 2].data_ptr() if b < nb - 1 else y_last.data_ptr()
             a.dil[b] = int(dils[b])
             for j in range(2):
                 a.bias[2 * b + j] = bs[2 * b + j].data_ptr() if bs[2 * b + j] is not None else None
                 a.site[2 * b + j] = int(sites[2 * b + j])
-        a.n_blocks, a.n_clips, a.T, a.C = nb, B, T, Cch
+        a.n_blocks, a.n_clips, a.T, a.C = nb, nP * B, T, Cch
         a.drop_p = float(drop_p)
         if drop_p > 0:
-            keep = torch.empty(int(lib.s2ag_tcn32_keep_bytes(B, nb)), dtype=torch.uint8, device=x.device)
+            keep = torch.empty(int(lib.s2ag_tcn32_keep_bytes(nP * B, nb)), dtype=torch.uint8, device=x.device)
             a.rng, a.keep = noise.data_ptr(), keep.data_ptr()
-        L.check(lib.s2ag_tcn32_fwd(C.byref(a), _stream()), 'tcn32_fwd')
-        ctx.meta, ctx.noise, ctx.params, ctx.shape, ctx.frags = meta, noise, params, (B, T, Cch), frags
-        ctx.save_for_backward(x2, saved)
-        return saved[3 * nb - 1].view(B, T, Cch)
+        if nP == 1:
+            L.check(lib.s2ag_tcn32_fwd(C.byref(a), _stream()), 'tcn32_fwd')
+        else:
+            rngs = (C.c_void_p * nP)(*[nz.data_ptr() for nz in noises])
+            L.check(lib.s2ag_tcn32_fwd_passes(C.byref(a), nP, rngs, B, _stream()), 'tcn32_fwd_passes')
+        ctx.meta, ctx.noise, ctx.params, ctx.shape, ctx.frags = (dils, sites, drop_p), noise, params, (B, T, Cch), frags
+        ctx.save_for_backward(x2, saved, y_last)
+        out = y_last[:rows].view(B, T, Cch)
+        if nP == 1:
+            return out
+        mates = y_last[rows:].view((nP - 1) * B, T, Cch)
+        ctx.mark_non_differentiable(mates)
+        return out, mates
 
     @staticmethod
-    def backward(ctx, gy):
-        x2, saved = ctx.saved_tensors
+    def backward(ctx, gy, *_mates):
+        x2, saved_t, y_last = ctx.saved_tensors
         dils, sites, drop_p = ctx.meta
         nb = len(dils)
+        # h1, h2, y per block as before; the last block's y lives at the head of the passes' output buffer
+        saved = [saved_t[i] for i in range(3 * nb - 1)] + [y_last[:x2.numel() // x2.shape[-1]]]
         params = ctx.params
         ws, bs = params[:2 * nb], params[2 * nb:]
         B, T, Cch = ctx.shape
@@ -872,7 +892,7 @@ class _TcnFused32(torch.autograd.Function):
             if TCN32_WGRAD_INLINE:
                 launch()
             else:
-                run_wgrad(launch, keep=(gp, saved, x2), flops=2.0 * rows * Cch * Cch * 2 * 2 * nb)
+                run_wgrad(launch, keep=(gp, saved_t, y_last, x2), flops=2.0 * rows * Cch * Cch * 2 * 2 * nb)
             for k in range(2 * nb):
                 _note_staged(ws[k])
                 if bs[k] is not None:
@@ -909,8 +929,12 @@ class _TcnFused32(torch.autograd.Function):
         return (gx, None, None, None) + tuple(grads)
 
 
-def tcn_fused32(x: Tensor, frags: TcnFragments32, ws, biases, dils, sites, drop_p: float, noise) -> Tensor:
-    return _TcnFused32.apply(x, frags, (tuple(dils), tuple(sites), float(drop_p)), noise, *ws, *biases)
+def tcn_fused32(x: Tensor, frags: TcnFragments32, ws, biases, dils, sites, drop_p: float, noise, batch=None, noises=None):
+    """``batch`` (nP * B, T, C) + ``noises``: x is the first B clips of a lockstep batch of nP passes (see _TcnFused32);
+    returns (out of x's pass, outputs of the other passes ((nP - 1) * B, T, C), no autograd)."""
+    if batch is None:
+        return _TcnFused32.apply(x, frags, (tuple(dils), tuple(sites), float(drop_p)), noise, *ws, *biases)
+    return _TcnFused32.apply(x, frags, (tuple(dils), tuple(sites), float(drop_p), batch, tuple(noises)), noise, *ws, *biases)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -918,11 +942,15 @@ def tcn_fused32(x: Tensor, frags: TcnFragments32, ws, biases, dils, sites, drop_
 # ----------------------------------------------------------------------------------------------------
 class _Embedding(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, table, drop_p, noise, site):
+    def forward(ctx, ids, table, drop_p, noise, site, out=None):
         _need_cuda(ids, table)
         ids = ids.contiguous().view(-1)
         rows, dim = ids.numel(), table.shape[1]
-        out = torch.empty(rows, dim, dtype=torch.float32, device=table.device)
+        if out is None:
+            out = torch.empty(rows, dim, dtype=torch.float32, device=table.device)
+        else:       # the caller's buffer (a slice of a lockstep batch): rows x dim, contiguous
+            assert out.is_contiguous() and out.numel() == rows * dim and out.dtype == torch.float32
+            out = out.view(rows, dim)
         e = _epi(L.ACT_NONE, 1.0, drop_p, noise, site)
         L.check(_lib().s2ag_embedding_fwd(_p(ids), _p(table), rows, dim, table.shape[0], _p(out), dim, C.byref(e),
                                           _stream()), 'embedding_fwd')
@@ -942,16 +970,17 @@ class _Embedding(torch.autograd.Function):
         if slot is not None:        # dense (n_words x dim) gradient: scatter straight into the arena
             L.check(_lib().s2ag_embedding_bwd(_p(ids), _p(dy), ldg, rows, dim, n_entries, _p(slot), 1, C.byref(e),
                                               _stream()), 'embedding_bwd')
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         dt = torch.empty(n_entries, dim, dtype=torch.float32, device=dy.device)
         L.check(_lib().s2ag_embedding_bwd(_p(ids), _p(dy), ldg, rows, dim, n_entries, _p(dt), 0, C.byref(e),
                                           _stream()), 'embedding_bwd')
-        return None, dt, None, None, None
+        return None, dt, None, None, None, None
 
 
-def embedding(ids: Tensor, table: Tensor, drop_p: float = 0.0, noise=None, site=0) -> Tensor:
-    out = _Embedding.apply(ids, table, float(drop_p), noise, site)
-    return out.view(*ids.shape, table.shape[1])
+def embedding(ids: Tensor, table: Tensor, drop_p: float = 0.0, noise=None, site=0, out: Optional[Tensor] = None) -> Tensor:
+    """``out``: write the rows into the caller's contiguous (ids.numel(), dim) buffer instead of a fresh one."""
+    res = _Embedding.apply(ids, table, float(drop_p), noise, site, out)
+    return res.view(*ids.shape, table.shape[1])
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -109,6 +109,46 @@ def _g_noise(G, nz, B, T, hidden, p, p_emb):
     return pin
 
 
+@pytest.mark.parametrize('B', [5, 40])
+def test_text_encoder_passes_in_lockstep_equal_separate_passes(B):
+    """TextEncoderTCN.forward_passes (S2AG_LOCKSTEP_TEXT=1: three passes as one batch through the clip-resident
+    TemporalConvNet, s2ag_tcn32_fwd_passes) against the same passes run one after the other: outputs bit-identical, the
+    autograd pass's parameter gradients equal (accumulation order of the atomics aside)."""
+    from speech2affective_gestures_amd import noise, ops
+    hidden, n_words = 300, 500
+    cfg, mods, sds = build_product(hidden, n_words, 12, 0.3, 5200, which=('G',))
+    enc = mods['G'].text_encoder.train()
+    ids = to_cuda(O.recipe_inputs(B, 34, 5210, n_words, 12))['in_text']
+    noises = [torch.tensor([91, k], dtype=torch.int64, device='cuda') for k in (0, 4, 6)]
+    if not enc.lockstep_capable(ids):
+        pytest.skip('clip-resident fp32 TemporalConvNet not selected in this mode')
+    params = [q for q in enc.parameters() if q.requires_grad]
+    gy = torch.randn(B, 34, 32, device='cuda')
+
+    def grads(outs):
+        for q in params:
+            q.grad = None
+        ops.begin_step()
+        outs[0].backward(gy)
+        ops.flush_derived()
+        torch.cuda.synchronize()
+        return [q.grad.clone() for q in params]
+    ops.begin_step()
+    sep = []
+    for k, nz in enumerate(noises):
+        with torch.set_grad_enabled(k == 0), noise.use_pass(nz):
+            sep.append(enc(ids)[0])
+    g_sep = grads(sep)
+    ops.begin_step()
+    lock = enc.forward_passes(ids, noises)
+    for a, b in zip(lock, sep):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert lock[0].requires_grad and not lock[1].requires_grad and not lock[2].requires_grad
+    g_lock = grads(lock)
+    for a, b in zip(g_lock, g_sep):
+        assert rel(a, b) < 1e-5
+
+
 @pytest.mark.parametrize('which,hidden,n_words,B', [('G', 32, 64, 3), ('GA', 32, 64, 3), ('G', 300, 2000, 88)])
 def test_generator_train_mode_with_dropout_forward_and_all_gradients(which, hidden, n_words, B):
     """Forward and every parameter gradient against the oracle fed the product's materialised masks.  The H = 300,
