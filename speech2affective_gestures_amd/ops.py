@@ -606,11 +606,13 @@ def generation() -> int:
     return _GENERATION[0]
 
 
-# One-launch BatchNorm (statistics + apply with a grid-wide wait, norm_elementwise.hip).  Measured on the step
-# (profiles/r02_bn_one_launch.txt): -69 launches per step, kernel time = the sum of the two kernels it replaces, step time
-# unchanged (14 620 / 14 820 vs 14 690 / 14 740 clips/s) -- so it stays an option; the default keeps the two launches,
-# whose workgroups never wait for each other.
-BN_FUSED = __import__('os').environ.get('S2AG_BN_FUSED', '0') == '1'
+# One-launch BatchNorm (statistics + apply with a grid-wide wait, norm_elementwise.hip): -69 launches per step, kernel time
+# = the sum of the two kernels it replaces.  Neutral when it was built (profiles/r02_bn_one_launch.txt: 14 620 / 14 820 vs
+# 14 690 / 14 740 clips/s); since the chains of a replayed graph start ~2.5 us later per node captured ahead of them
+# (lessons) fewer nodes now pay: +0.95 % (17 890 vs 17 720 clips/s, same-box A/B x 4), so it is the
+# default.  <= 64 workgroups per launch, bounded poll, sticky error bit read with the step's losses (check_coop_flag);
+# S2AG_BN_FUSED=0 keeps the two launches, whose workgroups never wait for each other.
+BN_FUSED = __import__('os').environ.get('S2AG_BN_FUSED', '1') == '1'
 
 
 class _BNAct(torch.autograd.Function):
