@@ -944,3 +944,41 @@ def test_clip_resident_tcn_forward_fp32_equals_the_layer_by_layer_path(S, B, tra
         a, b = g1[k].double().flatten(), g0[k].double().flatten()
         l2 = float((a - b).norm() / b.norm().clamp_min(1e-12))
         assert l2 < 5e-3 and rel(g1[k], g0[k]) < 5e-2, (k, l2, rel(g1[k], g0[k]))
+
+
+def test_step_helpers_pre_seq_snapshots_and_context_concat(S):
+    """The small step-level kernels that replaced chains of ATen launches: s2ag_make_pre_seq, s2ag_rng_snapshots,
+    s2ag_concat_cols (+ s2ag_sum_frames as the gradient of the broadcast speaker code) against their torch forms."""
+    ops, noise = S['ops'], S['noise']
+    g = torch.Generator().manual_seed(5)
+    B, T, D, n_pre = 7, 34, 27, 4
+    target = torch.randn(B, T, D, generator=g)
+    ref = target.new_zeros(B, T, D + 1)
+    ref[:, :n_pre, :-1] = target[:, :n_pre]
+    ref[:, :n_pre, -1] = 1
+    assert torch.equal(ops.make_pre_seq(target.cuda(), n_pre).cpu(), ref)
+    # snapshots: n consecutive passes + derived offsets == n begin_pass calls (+ clone / add)
+    noise.manual_seed(321)
+    a = [noise.begin_pass('cuda').cpu() for _ in range(3)]
+    noise.manual_seed(321)
+    b = [t.cpu() for t in noise.begin_passes('cuda', 3, derived=(3, 6))]
+    assert len(b) == 5 and all(torch.equal(x, y) for x, y in zip(a, b[:3]))
+    assert b[3].tolist() == [a[0][0].item(), a[0][1].item() + 3] and b[4].tolist() == [a[0][0].item(), a[0][1].item() + 6]
+    assert noise.begin_pass('cuda').cpu()[1].item() == a[0][1].item() + 3          # the counter advanced by n only
+    # [pre | audio (a column slice of a wider tensor) | text | z over the frames]
+    pre = torch.randn(B, T, 8, generator=g)
+    wide = torch.randn(B, T, 40, generator=g)
+    text = torch.randn(B, T, 32, generator=g)
+    z = torch.randn(B, 16, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (pre, wide, text, z)]
+    ref_out = torch.cat((leaves[0], leaves[1][..., 4:36], leaves[2], leaves[3].unsqueeze(1).expand(-1, T, -1)), dim=2)
+    gl = [t.cuda().requires_grad_(True) for t in (pre, wide, text, z)]
+    out = ops.context_cat((gl[0], gl[1][..., 4:36], gl[2]), gl[3])
+    assert torch.equal(out.cpu(), ref_out.detach())
+    dy = torch.randn(B, T, 88, generator=g)
+    ref_out.backward(dy)
+    out.backward(dy.cuda())
+    for a_, b_ in zip(gl, leaves):
+        assert rel(a_.grad, b_.grad) < 1e-6
+    out2 = ops.context_cat((gl[0], gl[2]))                                          # no speaker code
+    assert torch.equal(out2.cpu(), torch.cat((pre, text), dim=2))
