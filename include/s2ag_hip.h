@@ -252,6 +252,11 @@ int s2ag_to_f32(const void* x, int src_is_f16 /*else float64*/, float* out, long
 
 /* diagnostics: *out = device wall clock (100 MHz ticks) when the stream reaches this point (capturable) */
 int s2ag_timestamp(unsigned long long* out, void* stream);
+/* diagnostics (host only, no device work): print a native back trace to file descriptor `fd` when the process dies of
+ * SIGSEGV / SIGBUS / SIGABRT / SIGFPE / SIGILL, then die as before.  The reference has no counterpart (its step is eager
+ * PyTorch, processor_v2.py:776-957); the product replays multi-stream hipGraphs and this is the debug aid for faults
+ * below `hipGraphLaunch` (tools/stress_starts.py; enabled with S2AG_CRASH_TRACE=1). */
+int s2ag_install_crash_handler(int fd);
 
 #define S2AG_MAX_JOBS 8
 typedef struct s2ag_spmv_job {
@@ -610,10 +615,23 @@ int s2ag_gen_loss(const float* out, const float* target, const float* out_tri /*
                   int B, int TP, int ZD, const float* weights /*host[4]*/, float* scratch, float* comps,
                   float* g_out, float* g_dis, float* g_mu, float* g_logvar, void* stream);
 
+/* Evaluation metrics of forward_pass_s2ag(calculate_metrics=True): Processor.push_samples, processor_v2.py:738-774
+ * (F.l1_loss :746, convert_dir_vec_to_pose utils/ted_db_utils.py:81-102 on dir + mean_dir_vec :753-758, joint MAE over the
+ * frames behind the seed poses :760-766, acceleration difference np.diff(n=2) :768-771).  out / target (B, T, 27) fp32;
+ * mean_dir_vec 27 doubles; sums[3] (doubles, zeroed by the call) = {sum |out - target|, sum |joint_out - joint_tgt| over
+ * frames >= n_pre, sum |acc_tgt - acc_out|}: divide by B*T*27, B*(T - n_pre)*30 and B*(T - 2)*30. */
+int s2ag_pose_metrics(const float* out, const float* target, const double* mean_dir_vec, int B, int T, int n_pre,
+                      double* sums, void* stream);
+
 /* torch.optim.Adam (no weight decay / amsgrad) over a flat parameter arena; processor_v2.py:215-220.
  * `step` is a device int32 holding the number of steps already taken (bumped by s2ag_counter_inc). */
 int s2ag_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                    float eps, const int* step, float grad_scale, void* stream);
+/* Step guard (no reference counterpart: torch.optim.Adam.step() of processor_v2.py:815,941 is unconditional): `flag` is the
+ * device word the cooperative / one-launch kernels OR their time-out bits into.  While it is non-zero s2ag_adam_step and
+ * the step count of s2ag_counter_inc(counter, NULL) do nothing, so a step whose activations were wrong never reaches the
+ * weights; NULL removes the guard. */
+int s2ag_adam_set_guard(const int* flag);
 int s2ag_counter_inc(int* counter /*nullable*/, unsigned long long* rng /*nullable: rng[1] += 1*/, void* stream);
 /* noise state of one forward pass: snap[0:2] = rng[0:2], then rng[1] += 1 (the reference draws fresh torch RNG per
  * F.dropout / randn call -- net/tcn.py:22,28, net/embedding_net.py:10-13; here a pass = one counter value) */

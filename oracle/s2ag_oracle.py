@@ -622,6 +622,37 @@ def fgd_scores(generated_feats: np.ndarray, real_feats: np.ndarray) -> Tuple[flo
 # ----------------------------------------------------------------------------------------------
 # the GAN step  (processor_v2.py:776-957) and Adam (processor_v2.py:215-220)
 # ----------------------------------------------------------------------------------------------
+# skeleton of utils/ted_db_utils.py:14-16 (parent, child, bone length)
+DIR_VEC_PAIRS = ((0, 1, 0.26), (1, 2, 0.18), (2, 3, 0.14), (1, 4, 0.22), (4, 5, 0.36), (5, 6, 0.33), (1, 7, 0.22),
+                 (7, 8, 0.36), (8, 9, 0.33))
+
+
+def dir_vec_to_pose(vec: np.ndarray) -> np.ndarray:
+    """utils/ted_db_utils.py:81-102 (batch, seq, 27) branch: joint[child] = joint[parent] + length * direction, ten
+    joints, root at the origin; float64 accumulation of float32 products, as numpy does upstream."""
+    vec = np.asarray(vec).reshape(vec.shape[:-1] + (-1, 3))
+    joints = np.zeros(vec.shape[:2] + (10, 3))
+    for j, (par, chi, length) in enumerate(DIR_VEC_PAIRS):
+        joints[:, :, chi] = joints[:, :, par] + length * vec[:, :, j]
+    return joints
+
+
+def push_samples_metrics(out_dir_vec: Tensor, target: Tensor, mean_dir_vec, n_pre: int) -> Tuple[float, float, float]:
+    """The three meter values of Processor.push_samples (processor_v2.py:738-774): L1 of the direction vectors (:746),
+    MAE of the joint coordinates behind the seed poses (:753-766), acceleration difference (:768-771).  The inputs are
+    left untouched (upstream adds the mean IN PLACE to host copies of them)."""
+    l1 = float(F.l1_loss(out_dir_vec, target))
+    mean = np.array(mean_dir_vec).squeeze()
+    o = out_dir_vec.detach().cpu().numpy().copy()
+    o += mean
+    t = target.detach().cpu().numpy().copy()
+    t += mean
+    po, pt = dir_vec_to_pose(o), dir_vec_to_pose(t)
+    mae = float(np.mean(np.absolute(po[:, n_pre:] - pt[:, n_pre:])))
+    acc = float(np.mean(np.abs(np.diff(pt, n=2, axis=1) - np.diff(po, n=2, axis=1))))
+    return l1, mae, acc
+
+
 @dataclass
 class StepCfg:
     """config/multimodal_context_v2.yml:29-36 + parse_args.py defaults."""

@@ -108,6 +108,7 @@ SIGNATURES = {
     's2ag_weight_norm_bwd': [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp],
     's2ag_spmv': [vp, vp, vp, vp, vp, ci, ci, vp],
     's2ag_timestamp': [vp, vp],
+    's2ag_install_crash_handler': [ci],
     's2ag_spmv_multi': [vp, ci, ci, vp],
     's2ag_weight_norm_multi': [vp, ci, ci, vp],
     's2ag_transpose': [vp, ci, ci, vp, vp],
@@ -183,6 +184,8 @@ SIGNATURES = {
     's2ag_dis_loss': [vp, vp, ci, vp, vp, vp, vp],
     's2ag_gen_loss': [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, C.POINTER(cf), vp, vp, vp, vp, vp, vp, vp],
     's2ag_adam_step': [vp, vp, vp, vp, cll, cf, cf, cf, cf, vp, cf, vp],
+    's2ag_pose_metrics': [vp, vp, vp, ci, ci, ci, vp, vp],
+    's2ag_adam_set_guard': [vp],
     's2ag_counter_inc': [vp, vp, vp],
     's2ag_rng_snapshot': [vp, vp, vp],
     's2ag_rng_snapshots': [vp, vp, ci, vp, ci, vp],
@@ -222,6 +225,8 @@ def load():
                               's2ag_f32_wgrad_tr_scratch_floats', 's2ag_f32_wgrad_tr_scratch_floats_n', 's2ag_tcn32_pack_elems', 's2ag_tcn32_keep_bytes') else ci
     if lib.s2ag_abi_version() != 1:
         raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
+    if os.environ.get('S2AG_CRASH_TRACE', '0') == '1':     # native back trace on SIGSEGV & co (csrc/debug.hip)
+        lib.s2ag_install_crash_handler(2)
     _lib = lib
     return lib
 

@@ -387,9 +387,16 @@ __global__ __launch_bounds__(256) void gen_loss_grad_k(const float* out, const f
 }
 
 // ---- Adam over a flat arena ------------------------------------------------------------------------------------
+// Sticky error word of the step (cooperative GRU time-outs, one-launch BatchNorm time-outs, touched-row overflow): when it
+// is non-zero the gradients of this step were formed from wrong activations, so the optimizer leaves weights, moments and
+// step count alone -- on the device, without a host round trip; the trainer raises at its next read-back
+// (ops.check_coop_flag) with the weights still those of the last good step.
+__device__ const int* g_adam_guard = nullptr;
+
 __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v, long long n, float lr,
                                               float b1, float b2, float eps, const int* step, float gscale) {
+    if (g_adam_guard && __hip_atomic_load(g_adam_guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const float t = (float)(*step);
     const float bc1 = 1.f - powf(b1, t);
     const float bc2s = sqrtf(1.f - powf(b2, t));
@@ -407,7 +414,10 @@ __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float
 
 __global__ void counter_inc_k(int* counter, unsigned long long* rng) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (counter) *counter += 1;
+        // an optimizer's step count (counter without rng) stands still while the step guard is raised, like adam_k
+        const bool held = counter && !rng && g_adam_guard &&
+                          __hip_atomic_load(g_adam_guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (counter && !held) *counter += 1;
         if (rng) rng[1] += 1ULL;
     }
 }
@@ -760,6 +770,81 @@ extern "C" int s2ag_adam_step(float* p, const float* g, float* m, float* v, long
                        eps, step, grad_scale);
     S2AG_LAUNCH_CHECK();
     return 0;
+}
+
+// ---- evaluation metrics of forward_pass_s2ag(calculate_metrics=True) (processor_v2.py:738-774 push_samples) -------------
+// One thread per (clip, frame): the joint positions of frames t, t+1, t+2 of the generated and the target sequence are
+// rebuilt from the direction vectors (utils/ted_db_utils.py:81-102 convert_dir_vec_to_pose: joint[child] = joint[parent]
+// + length * dir, ten joints, root at the origin) exactly as numpy does it -- dir + mean formed in float64 and rounded to
+// float32, length * dir rounded to float32, the chain and everything behind it in float64 -- and three sums leave the
+// launch: sum |out - target| (the L1 metric), sum |joint_out - joint_tgt| over frames >= n_pre (joint MAE) and
+// sum |acc_tgt - acc_out| of the second differences over time (acceleration difference).
+__device__ __forceinline__ void pose_of(const float* __restrict__ v, const double* __restrict__ mean, double (*jp)[3]) {
+    constexpr int par[9] = {0, 1, 2, 1, 4, 5, 1, 7, 8}, chi[9] = {1, 2, 3, 4, 5, 6, 7, 8, 9};
+    constexpr float len[9] = {0.26f, 0.18f, 0.14f, 0.22f, 0.36f, 0.33f, 0.22f, 0.36f, 0.33f};
+    jp[0][0] = jp[0][1] = jp[0][2] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = (float)((double)v[3 * j + c] + mean[3 * j + c]);
+            jp[chi[j]][c] = jp[par[j]][c] + (double)(len[j] * d);
+        }
+}
+
+__global__ __launch_bounds__(256) void pose_metrics_k(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                      const double* __restrict__ mean, int B, int T, int n_pre,
+                                                      double* __restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double s_l1 = 0.0, s_mae = 0.0, s_acc = 0.0;
+    if (i < B * T) {
+        const int t = i % T;
+        const float* o = out + (size_t)i * 27;
+        const float* g = tgt + (size_t)i * 27;
+        for (int k = 0; k < 27; ++k) s_l1 += (double)fabsf(o[k] - g[k]);
+        double po[3][10][3], pg[3][10][3];
+        const int nf = t + 2 < T ? 3 : 1;
+        for (int f = 0; f < nf; ++f) {
+            pose_of(o + 27 * f, mean, po[f]);
+            pose_of(g + 27 * f, mean, pg[f]);
+        }
+        if (t >= n_pre)
+            for (int j = 0; j < 10; ++j)
+                for (int c = 0; c < 3; ++c) s_mae += fabs(po[0][j][c] - pg[0][j][c]);
+        if (nf == 3)
+            for (int j = 0; j < 10; ++j)
+                for (int c = 0; c < 3; ++c) {
+                    // np.diff(n=2): (p[t+2] - p[t+1]) - (p[t+1] - p[t])
+                    const double ag = (pg[2][j][c] - pg[1][j][c]) - (pg[1][j][c] - pg[0][j][c]);
+                    const double ao = (po[2][j][c] - po[1][j][c]) - (po[1][j][c] - po[0][j][c]);
+                    s_acc += fabs(ag - ao);
+                }
+    }
+    __shared__ double red[3][256];
+    red[0][threadIdx.x] = s_l1;
+    red[1][threadIdx.x] = s_mae;
+    red[2][threadIdx.x] = s_acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (threadIdx.x < h)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) atomicAdd(&sums[threadIdx.x], red[threadIdx.x][0]);
+}
+
+extern "C" int s2ag_pose_metrics(const float* out, const float* target, const double* mean_dir_vec, int B, int T,
+                                 int n_pre, double* sums, void* stream) {
+    if (!out || !target || !mean_dir_vec || !sums || B < 1 || T < 3 || n_pre < 0 || n_pre >= T) return S2AG_E_BADARG;
+    s2ag::zero_async(sums, 3 * sizeof(double), (hipStream_t)stream);
+    hipLaunchKernelGGL(pose_metrics_k, dim3(cdiv(B * T, 256)), dim3(256), 0, (hipStream_t)stream, out, target,
+                       mean_dir_vec, B, T, n_pre, sums);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_adam_set_guard(const int* flag) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_adam_guard), &flag, sizeof(flag));
 }
 
 extern "C" int s2ag_counter_inc(int* counter, unsigned long long* rng, void* stream) {

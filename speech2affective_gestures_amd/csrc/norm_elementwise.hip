@@ -719,7 +719,7 @@ static inline void bn_plan(int rows, int cols, bool flat, int* colblocks, int* n
     *colblocks = cdiv(cols, 64);
     int r = 64;      // 1024 threads = 16 row lanes per block: 4+ rows per lane, more while that still leaves ~256 blocks
     while (cdiv(rows, r) > cap || (long long)cdiv(rows, 2 * r) * *colblocks >= 256) r *= 2;
-    while (max_blocks > 0 && (long long)cdiv(rows, r) * *colblocks > max_blocks) r *= 2;
+    while (max_blocks > 0 && r < rows && (long long)cdiv(rows, r) * *colblocks > max_blocks) r *= 2;
     *rpb = r;
     *nrb = cdiv(rows, r);
 }
@@ -766,7 +766,8 @@ extern "C" int s2ag_bn_set_error_flag(int* flag) {
 }
 
 extern "C" int s2ag_bn_fused_supported(int rows, int cols) {
-    return rows > 0 && cols > 0 && (long long)rows * cols <= BN_FUSED_MAX_ELEMS;
+    // wider than 64 column blocks cannot fit BN_FUSED_MAX_BLOCKS whatever the row blocking: two-launch path
+    return rows > 0 && cols > 0 && (long long)rows * cols <= BN_FUSED_MAX_ELEMS && cdiv(cols, 64) <= BN_FUSED_MAX_BLOCKS;
 }
 
 extern "C" int s2ag_bn_fused_partial_rows(int rows, int cols, int ld) {

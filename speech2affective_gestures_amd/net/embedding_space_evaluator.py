@@ -14,7 +14,8 @@ from .embedding_net import EmbeddingNet
 
 
 class EmbeddingSpaceEvaluator:
-    def __init__(self, base_path, args, pose_dim, lang_model, device, checkpoint='outputs/embedding_net.pth.tar'):
+    def __init__(self, base_path, args, pose_dim, lang_model, device, checkpoint='outputs/embedding_net.pth.tar',
+                 allow_random_init=False):
         self.n_pre_poses = args.n_pre_poses
         self.pose_dim = pose_dim
         self.net = EmbeddingNet(args, pose_dim, args.n_poses, lang_model.n_words, getattr(args, 'wordembed_dim', 300),
@@ -22,9 +23,10 @@ class EmbeddingSpaceEvaluator:
         path = jn(base_path, checkpoint) if checkpoint else None
         if path and os.path.exists(path):
             self.net.load_state_dict(torch.load(path, map_location=device)['embedding_dict'])
-        elif path:
-            print('Warning! {} not found: the embedding net keeps its random init (FGD values are then only '
-                  'comparable within this run).'.format(path))
+        elif path and not allow_random_init:
+            # upstream fails in torch.load here (:26-27); a silently random auto-encoder would make FGD meaningless
+            raise FileNotFoundError('{} not found (pass allow_random_init=True to score with a randomly initialised '
+                                    'embedding net: values are then only comparable within one run)'.format(path))
         self.net.train(False)
         self.reset()
 
@@ -32,7 +34,12 @@ class EmbeddingSpaceEvaluator:
         self.context_feat_list = []
         self.real_feat_list = []
         self.generated_feat_list = []
-        self.recon_err_diff = []
+        self._recon_err = []          # device pairs (generated, real); see the recon_err_diff property
+
+    @property
+    def recon_err_diff(self):
+        """Python floats as upstream (:59-61); the device values are read back here, once, not per batch."""
+        return self.reconstruction_error_differences()
 
     def get_no_of_samples(self):
         return len(self.real_feat_list)
@@ -48,10 +55,10 @@ class EmbeddingSpaceEvaluator:
             self.real_feat_list.append(real_feat.detach())
             self.generated_feat_list.append(generated_feat.detach())
             err = torch.stack(((generated_poses - generated_recon).abs().mean(), (real_poses - real_recon).abs().mean()))
-            self.recon_err_diff.append(err)              # read back lazily: no host sync per batch
+            self._recon_err.append(err)                  # read back lazily: no host sync per batch
 
     def reconstruction_error_differences(self):
-        return [float(e[0] - e[1]) for e in torch.stack(self.recon_err_diff).cpu()] if self.recon_err_diff else []
+        return [float(e[0] - e[1]) for e in torch.stack(self._recon_err).cpu()] if self._recon_err else []
 
     def get_scores(self):
         """:74-103 -- (frechet_dist, feat_dist)."""

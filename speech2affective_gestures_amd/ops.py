@@ -323,6 +323,8 @@ def init_tickets(device) -> None:
         _COOP_FLAG[key] = torch.zeros(1, dtype=torch.int32, device=dev)
         L.check(_lib().s2ag_gru_coop_set_error_flag(_p(_COOP_FLAG[key])), 'gru_coop_set_error_flag')
         L.check(_lib().s2ag_bn_set_error_flag(_p(_COOP_FLAG[key])), 'bn_set_error_flag')     # bit 4: one-launch BatchNorm
+        # ... and the fused Adam refuses to touch the weights while the word is non-zero (no host round trip)
+        L.check(_lib().s2ag_adam_set_guard(_p(_COOP_FLAG[key])), 'adam_set_guard')
         _BARRIERS[key] = [torch.zeros(3 * _TICKET_POOL, dtype=torch.int32, device=dev), 0]
 
 
@@ -991,9 +993,11 @@ def embedding(ids: Tensor, table: Tensor, drop_p: float = 0.0, noise=None, site=
 _ROW_MARKS = {}
 
 
-def rows_unique_raw(ids: Tensor, n_entries: int, uids_out: Tensor) -> None:
-    """Sorted unique ids of ``ids`` into ``uids_out`` (int32, padded with ``n_entries``).  More distinct ids than
-    ``uids_out`` holds sets bit 1 of the sticky error word (the trainer raises at its next read-back)."""
+def rows_unique_raw(ids: Tensor, n_entries: int, uids_out: Tensor, flag_overflow: bool = True) -> Tensor:
+    """Sorted unique ids of ``ids`` into ``uids_out`` (int32, padded with ``n_entries``); returns the (1,) int32 device
+    count of distinct ids (a persistent buffer: copy it before the next call).  More distinct ids than ``uids_out`` holds
+    sets bit 1 of the sticky error word (the trainer raises at its next read-back) unless ``flag_overflow`` is False --
+    parallel.GradExchange.precheck repairs an overflow with a dense all-reduce and needs no alarm."""
     _need_cuda(ids, uids_out)
     assert ids.dtype == torch.int64 and ids.is_contiguous() and uids_out.dtype == torch.int32
     key = (ids.device.index, int(n_entries))
@@ -1003,9 +1007,11 @@ def rows_unique_raw(ids: Tensor, n_entries: int, uids_out: Tensor) -> None:
         _ROW_MARKS[key] = (torch.zeros(n_entries, dtype=torch.int32, device=ids.device),
                            torch.zeros(1, dtype=torch.int32, device=ids.device))
     mark, count = _ROW_MARKS[key]
-    flag = _COOP_FLAG.get(ids.device.index if ids.device.index is not None else torch.cuda.current_device())
+    flag = _COOP_FLAG.get(ids.device.index if ids.device.index is not None else torch.cuda.current_device()) \
+        if flag_overflow else None
     L.check(_lib().s2ag_rows_unique(_p(ids), ids.numel(), int(n_entries), uids_out.numel(), _p(mark), _p(uids_out),
                                     _p(count), _p(flag), _stream()), 'rows_unique')
+    return count
 
 
 def rows_pack_raw(dense: Tensor, uids: Tensor, records_out: Tensor) -> None:
@@ -1813,6 +1819,30 @@ def gen_loss(out, dis_out, mu, log_var, target, out_tri, out_rand, z, z_rand, we
     weights = (regression, gan, div_reg, kld)."""
     return _GenLoss.apply(out, dis_out, mu, log_var, target.detach(), None if out_tri is None else out_tri.detach(),
                           out_rand.detach(), z.detach(), z_rand.detach(), tuple(weights))
+
+
+# ----------------------------------------------------------------------------------------------------
+# evaluation metrics (processor_v2.py:738-774)
+# ----------------------------------------------------------------------------------------------------
+_POSE_MEAN = {}
+
+
+def pose_metrics(out: Tensor, target: Tensor, mean_dir_vec, n_pre: int) -> Tensor:
+    """(3,) float64 on the device: L1 of the direction vectors, MAE of the joint coordinates behind the seed poses and the
+    acceleration difference of processor_v2.py:738-774 (push_samples); ``mean_dir_vec``: 27 numbers (any nesting)."""
+    _need_cuda(out, target)
+    import numpy as np
+    B, T, P = out.shape
+    assert P == 27 and target.shape == out.shape, (out.shape, target.shape)
+    mean = np.ascontiguousarray(np.array(mean_dir_vec, dtype=np.float64).reshape(-1))
+    assert mean.size == 27
+    ent = _POSE_MEAN.get(out.device.index)
+    if ent is None or not np.array_equal(ent[0], mean):
+        ent = _POSE_MEAN[out.device.index] = (mean, torch.from_numpy(mean).to(out.device))
+    sums = torch.empty(3, dtype=torch.float64, device=out.device)
+    L.check(_lib().s2ag_pose_metrics(_p(out.contiguous().float()), _p(target.contiguous().float()), _p(ent[1]), B, T,
+                                     int(n_pre), _p(sums), _stream()), 'pose_metrics')
+    return sums / sums.new_tensor([B * T * 27, B * (T - int(n_pre)) * 30, B * (T - 2) * 30])
 
 
 # ----------------------------------------------------------------------------------------------------

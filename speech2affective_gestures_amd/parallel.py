@@ -70,6 +70,12 @@ class DataParallelContext:
         self.n_collectives += 1
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
 
+    def all_reduce_max(self, t: torch.Tensor) -> None:
+        """MAX over ranks, in place (stream ordered, no host wait)."""
+        if self.world_size > 1:
+            self.n_collectives += 1
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> None:
         """out (world * n,) <- inp (n,) of every rank, rank-major."""
         if not self.active:
@@ -110,7 +116,8 @@ class DataParallelContext:
 class RowKernels:
     """The three device kernels of the touched-row exchange (csrc/rows.hip through ops.py in the product; the CPU tests
     of the schedule pass torch doubles).  All write into caller-owned static buffers (hipGraph friendly)."""
-    unique: Callable      # (ids (n,) i64, n_entries, uids_out (cap,) i32): sorted unique ids, padded with n_entries
+    unique: Callable      # (ids (n,) i64, n_entries, uids_out (cap,) i32) -> (1,) i32 tensor = number of distinct ids;
+                          # uids_out <- the first cap of them, sorted, padded with n_entries
     pack: Callable        # (dense (n_entries, dim), uids, records_out (cap, dim + 1) f32)
     merge: Callable       # (gathered (world, cap, dim + 1), dense): dense rows overwritten with the rank-ordered sums
 
@@ -121,12 +128,18 @@ class GradExchange:
     backward pass finishes FIRST lives behind it); ``rows`` = (lo, hi, n_entries, dim) of a row-sparse tensor at the
     front of the arena, or None.  Per step, in this order:
 
+        precheck(ids)     host, at the START of the step (eager, never captured): the batch's distinct ids are listed and
+                          counted, MAX over ranks of the count travels to pinned host memory -- nobody waits
         launch_a()        host, when bucket A is complete on the current stream (async all-reduce, nobody waits yet)
         pack_rows(ids)    device kernels (capturable), when the whole gradient is complete
         exchange_rest()   host: all-reduce of bucket B, all-gather of the row records, then wait for bucket A
         merge_rows()      device kernel (capturable): touched rows <- sum over ranks, in rank order
 
-    afterwards ``grad`` holds the SUM over ranks everywhere."""
+    afterwards ``grad`` holds the SUM over ranks everywhere.  If ANY rank's batch holds more distinct ids than ``row_cap``
+    (a too small ``args.max_words_per_clip``, data swapped under the trainer) the records would be truncated and the
+    replicas would drift apart: the count that ``precheck`` sent ahead (it depends on the token ids only, so it is on the
+    host long before the gradients exist -- reading it stalls nothing) makes EVERY rank take the dense all-reduce of the
+    row block for that step instead (``dense_fallbacks`` counts them) and the merge finds only sentinels."""
     dp: DataParallelContext
     grad: torch.Tensor
     split: int
@@ -134,6 +147,7 @@ class GradExchange:
     row_cap: int = 0
     kernels: Optional[RowKernels] = None
     _work: list = field(default_factory=list)
+    dense_fallbacks: int = 0
 
     def __post_init__(self):
         n = self.grad.numel()
@@ -147,6 +161,10 @@ class GradExchange:
             self.uids = torch.full((self.row_cap,), n_entries, dtype=torch.int32, device=dev)
             self.records = torch.zeros(self.row_cap, dim + 1, dtype=torch.float32, device=dev)
             self.gathered = torch.zeros(self.dp.world_size, self.row_cap, dim + 1, dtype=torch.float32, device=dev)
+            self._cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._cnt_host = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else None
+            self._cnt_ev = torch.cuda.Event() if dev.type == 'cuda' else None
+        self._pre = False
 
     @property
     def buckets(self) -> List[Tuple[str, int, int]]:
@@ -166,11 +184,23 @@ class GradExchange:
             if w is not None:
                 self._work.append(w)
 
+    def precheck(self, ids: torch.Tensor) -> None:
+        if self.rows is None:
+            return
+        _, hi, n_entries, dim = self.rows
+        self._cnt.copy_(self.kernels.unique(ids.reshape(-1), n_entries, self.uids))
+        self.dp.all_reduce_max(self._cnt)
+        if self._cnt_host is not None:
+            self._cnt_host.copy_(self._cnt, non_blocking=True)
+            self._cnt_ev.record()
+        self._pre = True
+
     def pack_rows(self, ids: torch.Tensor) -> None:
         if self.rows is None:
             return
         _, hi, n_entries, dim = self.rows
-        self.kernels.unique(ids.reshape(-1), n_entries, self.uids)
+        if not self._pre:       # no precheck this step: list the ids here (an overflow is then only reported, not repaired)
+            self.kernels.unique(ids.reshape(-1), n_entries, self.uids)
         self.kernels.pack(self.grad[:hi].view(n_entries, dim), self.uids, self.records)
 
     def exchange_rest(self) -> None:
@@ -178,7 +208,18 @@ class GradExchange:
         if lo < self.split:
             self.dp.all_reduce(self.grad[lo:self.split])
         if self.rows is not None:
-            self.dp.all_gather(self.gathered.view(-1), self.records.view(-1))
+            over = False
+            if self._pre:
+                if self._cnt_ev is not None:
+                    self._cnt_ev.synchronize()          # recorded at the start of the step: long since complete
+                over = int((self._cnt_host if self._cnt_host is not None else self._cnt)[0]) > self.row_cap
+                self._pre = False
+            if over:
+                self.dense_fallbacks += 1
+                self.dp.all_reduce(self.grad[:self.rows[1]])
+                self.gathered.view(torch.int32)[:, :, 0] = self.rows[2]   # sentinels: merge_rows leaves the summed rows alone
+            else:
+                self.dp.all_gather(self.gathered.view(-1), self.records.view(-1))
         for w in self._work:
             w.wait()
         self._work.clear()

@@ -92,8 +92,8 @@ class _GraphSegments:
     """Capture ``fns`` as consecutive HIP graphs sharing one memory pool; ``between[i]`` runs eagerly after
     segment i (the RCCL all-reduces).  Static shapes; inputs are copied into the buffers captured."""
 
-    def __init__(self, fns, between, warmup=3):
-        self.fns, self.between = fns, between
+    def __init__(self, fns, between, warmup=3, before=None):
+        self.fns, self.between, self.before = fns, between, before
         self.graphs = []
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -103,6 +103,8 @@ class _GraphSegments:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
+        if self.before is not None:
+            self.before()              # host-side state the captured functions branch on (GradExchange.precheck)
         for i, fn in enumerate(fns):
             g = torch.cuda.CUDAGraph()
             # 'thread_local': the batch feeder's thread allocates / records events on its own stream meanwhile
@@ -111,12 +113,16 @@ class _GraphSegments:
             self.graphs.append(g)      # nothing executes during capture, so no collective here
 
     def _eager(self):
+        if self.before is not None:
+            self.before()
         for fn, btw in zip(self.fns, self.between):
             fn()
             if btw is not None:
                 btw()
 
     def replay(self):
+        if self.before is not None:
+            self.before()
         for g, btw in zip(self.graphs, self.between):
             g.replay()
             if btw is not None:
@@ -202,6 +208,7 @@ class Processor(object):
         self.dp.broadcast_module(self.s2ag_discriminator, self.dis_arena)
         self.dp.broadcast_module(self.trimodal_generator, None)
 
+        self.test_samples, self.num_test_samples = None, 0
         self.train_samples = getattr(data_loader['train_data_s2ag'], 'samples', None)
         self.val_samples = getattr(data_loader.get('val_data_s2ag', meta), 'samples', None)
         self.num_train_samples = getattr(data_loader['train_data_s2ag'], 'n_samples', 0)
@@ -232,6 +239,10 @@ class Processor(object):
         self._side = [torch.cuda.Stream(device=self.device) for _ in range(4)]
         self._graphed = None
         self.last_losses = {}
+        self._last_outs = None
+        # FGD evaluators of forward_pass_s2ag(calculate_metrics=True) (processor_v2.py:199-206 builds them from
+        # outputs/embedding_net.pth.tar); None = the three meters only, as upstream's `if evaluator:`
+        self.evaluator = self.evaluator_trimodal = None
 
     def _exchange(self):
         """The generator's gradient-exchange schedule, or None outside data-parallel runs."""
@@ -265,7 +276,8 @@ class Processor(object):
                     k = int((np.diff(srt, axis=1) != 0).sum(axis=1).max()) + 1
             cap = min(n_entries, B * min(T, k if k is not None else T))
             rows = (0, n_entries * dim, n_entries, dim)
-            kern = RowKernels(unique=ops.rows_unique_raw, pack=ops.rows_pack_raw, merge=ops.rows_merge_raw)
+            kern = RowKernels(unique=lambda i, n, u: ops.rows_unique_raw(i, n, u, flag_overflow=False),
+                              pack=ops.rows_pack_raw, merge=ops.rows_merge_raw)
         return GradExchange(self.dp, ar.grad, split, rows=rows, row_cap=cap, kernels=kern)
 
     # ------------------------------------------------------------------------------------------------
@@ -286,6 +298,10 @@ class Processor(object):
             return False
 
     def save_model(self, epoch, loss):
+        # never write weights of a run whose sticky error word is raised (the fused Adam already refuses to step then)
+        flag = ops.coop_error_flag(self.device)
+        if flag is not None:
+            ops.check_coop_flag(flag.item())
         if self.dp.rank != 0:
             return None
         os.makedirs(self.args.work_dir_s2ag, exist_ok=True)
@@ -742,6 +758,7 @@ class Processor(object):
         elif early is None:
             with torch.no_grad(), noise.use_pass(nz_rand):
                 out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, rand_vids)
+        self._last_outs = (out_tri.detach(), out.detach())      # forward_pass_s2ag(calculate_metrics=True) reads them
         w_gan = cfg.loss_gan_weight if self.meta_info['epoch'] > cfg.loss_warmup else 0.0
         total, comps = ops.gen_loss(out, dis_output, z_mu, z_log_var, target_poses, out_tri, out_rand, z, z_rand,
                                     (cfg.loss_regression_weight, w_gan, cfg.loss_reg_weight, cfg.loss_kld_weight))
@@ -788,22 +805,58 @@ class Processor(object):
         self.last_losses = d
         return l1 - l1_tri
 
+    @staticmethod
+    def push_samples(evaluator, target, out_dir_vec, in_text_padded, in_audio, losses_all, joint_mae, accel, mean_dir_vec,
+                     n_poses, n_pre_poses):
+        """processor_v2.py:738-774: L1 of the direction vectors, MAE of the joint coordinates (convert_dir_vec_to_pose on
+        dir + mean_dir_vec) behind the seed poses, acceleration difference; latent features into ``evaluator`` (FGD).
+        Everything is computed on the device (ops.pose_metrics: one launch, float64 like numpy upstream); ONE 24-byte
+        read-back feeds the three meters (upstream: two full tensor downloads + one .item())."""
+        batch_size = len(target)
+        if out_dir_vec.shape[1] != n_poses:
+            raise NotImplementedError('push_samples: generated sequences shorter than n_poses (the seed-less branch of '
+                                      'processor_v2.py:763) are not produced on this path')
+        l1, mae, acc = ops.pose_metrics(out_dir_vec.detach(), target.detach(), mean_dir_vec, n_pre_poses).tolist()
+        losses_all.update(l1, batch_size)
+        if evaluator:
+            evaluator.push_samples(in_text_padded, in_audio, out_dir_vec, target)
+        joint_mae.update(mae, batch_size)
+        accel.update(acc, batch_size)
+        return evaluator, losses_all, joint_mae, accel
+
     def forward_pass_s2ag(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, train, target_seq=None,
                           words=None, aux_info=None, save_path=None, make_video=False, calculate_metrics=False,
                           losses_all_trimodal=None, joint_mae_trimodal=None, accel_trimodal=None, losses_all=None,
                           joint_mae=None, accel=None):
         """One GAN step (processor_v2.py:776-957).  Returns the reference's 7-tuple; the loss components of the
-        step are left in ``self.last_losses``.  ``make_video`` / ``calculate_metrics`` belong to the rendering /
-        FGD paths that are out of scope here."""
-        if make_video or calculate_metrics:
-            raise NotImplementedError('rendering / FGD evaluation are outside the MI355X hot path')
+        step are left in ``self.last_losses``.  ``calculate_metrics`` (:866-890) pushes the step's two generated
+        sequences (tri-modal baseline, s2ag generator) against ``target_seq`` into the six meters and the two FGD
+        evaluators (``self.evaluator_trimodal`` / ``self.evaluator``: EmbeddingSpaceEvaluator or None).  ``make_video``
+        belongs to the rendering path (matplotlib / ffmpeg) that is out of scope here."""
+        if make_video:
+            raise NotImplementedError('rendering is outside the MI355X hot path')
+        if calculate_metrics:
+            for name, v in (('target_seq', target_seq), ('losses_all_trimodal', losses_all_trimodal),
+                            ('joint_mae_trimodal', joint_mae_trimodal), ('accel_trimodal', accel_trimodal),
+                            ('losses_all', losses_all), ('joint_mae', joint_mae), ('accel', accel)):
+                assert v is not None, '{} cannot be None when calculate_metrics is True'.format(name)
         ops.begin_step()
         # encoder sharing is scoped to THIS step (the cache is keyed on buffer addresses): off again when the step ends
         self.s2ag_generator.share_passes = (3 if self._use_gan() else 2) if self.share_encoders else None
         try:
-            return self._step(in_text, in_audio, in_mfcc, target_poses, vid_indices, train) + \
-                (losses_all_trimodal, joint_mae_trimodal, accel_trimodal, losses_all, joint_mae, accel)
+            ret = self._step(in_text, in_audio, in_mfcc, target_poses, vid_indices, train)
+            if calculate_metrics:
+                cfg = self.s2ag_config_args
+                out_tri, out = self._last_outs
+                self.evaluator_trimodal, losses_all_trimodal, joint_mae_trimodal, accel_trimodal = Processor.push_samples(
+                    getattr(self, 'evaluator_trimodal', None), target_seq, out_tri, in_text, in_audio, losses_all_trimodal,
+                    joint_mae_trimodal, accel_trimodal, cfg.mean_dir_vec, cfg.n_poses, cfg.n_pre_poses)
+                self.evaluator, losses_all, joint_mae, accel = Processor.push_samples(
+                    getattr(self, 'evaluator', None), target_seq, out, in_text, in_audio, losses_all, joint_mae, accel,
+                    cfg.mean_dir_vec, cfg.n_poses, cfg.n_pre_poses)
+            return ret + (losses_all_trimodal, joint_mae_trimodal, accel_trimodal, losses_all, joint_mae, accel)
         finally:
+            self._last_outs = None
             self.s2ag_generator.share_passes = None
             self.s2ag_generator._shared = None
 
@@ -811,6 +864,8 @@ class Processor(object):
         pre_seq = self._make_pre_seq(target_poses)
         dis_error = None
         ex = self._exchange() if train else None
+        if ex is not None:
+            ex.precheck(in_text)        # distinct word ids of the batch, MAX over ranks on its way to the host
         if self._use_gan():
             dis_error = self._dis_phase(in_text, in_mfcc if self.use_mfcc else in_audio, target_poses, vid_indices,
                                         pre_seq, train, in_audio=in_audio, cut=ex is not None)
@@ -869,7 +924,7 @@ class Processor(object):
             fns = [seg_dis, seg_gen, seg_gen_rest, seg_opt]
             between = [(lambda: self.dp.all_reduce_grads(self.dis_arena)) if use_gan else None,
                        ex.launch_a, ex.exchange_rest, None]
-        segs = _GraphSegments(fns, between)
+        segs = _GraphSegments(fns, between, before=(lambda: ex.precheck(st['text'])) if ex is not None else None)
         self._graphed = dict(st=st, out=out, segs=segs, key=self._graph_key(in_text, in_audio, in_mfcc, target_poses))
 
     def _graph_key(self, in_text, in_audio, in_mfcc, target_poses):

@@ -982,3 +982,24 @@ def test_step_helpers_pre_seq_snapshots_and_context_concat(S):
         assert rel(a_.grad, b_.grad) < 1e-6
     out2 = ops.context_cat((gl[0], gl[2]))                                          # no speaker code
     assert torch.equal(out2.cpu(), torch.cat((pre, text), dim=2))
+
+
+def test_pose_metrics_kernel_matches_the_reference_golden(S, golden_dir):
+    """s2ag_pose_metrics (L1, joint MAE behind the seed poses, acceleration difference in one launch, float64 like numpy
+    upstream) against tests/golden/metrics.npz = the reference's own Processor.push_samples, and against the oracle on a
+    full-size batch."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from metrics_recipe import MEAN_DIR_VEC, N_BATCHES, N_PRE, metrics_inputs
+    ops = S['ops']
+    g = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    for b in range(N_BATCHES):
+        out, tgt = metrics_inputs(b)
+        got = ops.pose_metrics(torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda(), MEAN_DIR_VEC, N_PRE).cpu().numpy()
+        np.testing.assert_allclose(got, g['vals'][b], rtol=2e-6)       # the L1 term is a float32 mean upstream
+    rs = np.random.RandomState(5)
+    tgt = torch.from_numpy((rs.standard_normal((128, 136, 27)) * 0.2).astype(np.float32))
+    out = tgt * 0.5 + torch.from_numpy((rs.standard_normal((128, 136, 27)) * 0.2).astype(np.float32))
+    want = O.push_samples_metrics(out, tgt, MEAN_DIR_VEC, 4)
+    got = ops.pose_metrics(out.cuda(), tgt.cuda(), MEAN_DIR_VEC, 4).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-6)

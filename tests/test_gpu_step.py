@@ -580,3 +580,66 @@ def test_train_and_val_epoch_loops_over_a_host_dataset():
     assert np.isfinite(pr.epoch_info['mean_s2ag_loss'])
     assert torch.equal(pr.s2ag_generator.out[0].weight.detach(), w1)
     assert not pr.s2ag_generator.training and not pr.s2ag_discriminator.training
+
+
+def test_forward_pass_with_calculate_metrics_feeds_the_meters_and_evaluators(golden_dir):
+    """forward_pass_s2ag(..., calculate_metrics=True) (processor_v2.py:866-890): the step's two generated sequences
+    (tri-modal baseline, s2ag generator) go through Processor.push_samples against ``target_seq`` -- the six meters receive
+    the values the oracle's restatement of push_samples (pinned to the reference's own, tests/golden/metrics.npz) computes
+    from the very tensors the step produced, and the two FGD evaluators receive one batch each."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from metrics_recipe import MEAN_DIR_VEC
+    from speech2affective_gestures_amd import noise
+    from speech2affective_gestures_amd import processor_v2 as P
+    from speech2affective_gestures_amd.net.embedding_space_evaluator import EmbeddingSpaceEvaluator
+
+    class Meter:                                       # utils/average_meter.py of the reference, duck-typed
+        def __init__(self):
+            self.val = self.avg = self.sum = self.count = 0
+
+        def update(self, val, n=1):
+            self.val, self.sum, self.count = val, self.sum + val * n, self.count + n
+            self.avg = self.sum / self.count
+    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 6, 8400
+    pr, _ = make_processor(hidden, n_words, n_spk, B, s0, 0.3)
+    pr.s2ag_config_args.mean_dir_vec = MEAN_DIR_VEC
+    pr.s2ag_generator.eval()
+    pr.s2ag_discriminator.eval()
+    args = types.SimpleNamespace(n_pre_poses=4, n_poses=34, wordembed_dim=300)
+    lang = types.SimpleNamespace(n_words=n_words, word_embedding_weights=None)
+    with pytest.raises(FileNotFoundError):             # upstream fails in torch.load; no silent random auto-encoder
+        EmbeddingSpaceEvaluator('.', args, 27, lang, 'cuda', checkpoint='outputs/no_such_embedding_net.pth.tar')
+    pr.evaluator = EmbeddingSpaceEvaluator('.', args, 27, lang, 'cuda', checkpoint=None)
+    pr.evaluator_trimodal = EmbeddingSpaceEvaluator('.', args, 27, lang, 'cuda', checkpoint=None)
+    noise.manual_seed(STEP_SEED)
+    gi = to_cuda(O.recipe_inputs(B, 34, s0 + 100, n_words, n_spk))
+    seen = []
+    orig = P.Processor.push_samples
+
+    def spy(evaluator, target, out_dir_vec, *a):
+        seen.append((out_dir_vec.detach().cpu().clone(), target.detach().cpu().clone()))
+        return orig(evaluator, target, out_dir_vec, *a)
+    P.Processor.push_samples = staticmethod(spy)
+    try:
+        meters = [Meter() for _ in range(6)]
+        with pytest.raises(AssertionError, match='target_seq cannot be None'):
+            pr.forward_pass_s2ag(gi['in_text'], gi['in_audio'], gi['in_mfcc'], gi['target'], gi['vid'], False,
+                                 calculate_metrics=True)
+        with torch.no_grad():
+            ret = pr.forward_pass_s2ag(gi['in_text'], gi['in_audio'], gi['in_mfcc'], gi['target'], gi['vid'], False,
+                                       target_seq=gi['target'], calculate_metrics=True, losses_all_trimodal=meters[0],
+                                       joint_mae_trimodal=meters[1], accel_trimodal=meters[2], losses_all=meters[3],
+                                       joint_mae=meters[4], accel=meters[5])
+    finally:
+        P.Processor.push_samples = staticmethod(orig)
+    assert len(seen) == 2 and ret[1:] == tuple(meters)
+    for k, (out, tgt) in enumerate(seen):               # 0: tri-modal baseline, 1: s2ag generator
+        want = O.push_samples_metrics(out, tgt, MEAN_DIR_VEC, 4)
+        got = [m.val for m in meters[3 * k:3 * k + 3]]
+        np.testing.assert_allclose(got, want, rtol=2e-6)
+        assert all(m.count == B for m in meters[3 * k:3 * k + 3])
+    assert float((seen[0][0] - seen[1][0]).abs().max()) > 1e-3        # two different generators
+    assert pr.evaluator.get_no_of_samples() == 1 and pr.evaluator_trimodal.get_no_of_samples() == 1
+    # the returned metric is the plain step's: L1(out) - L1(out_trimodal)
+    assert ret[0] == pytest.approx(meters[3].val - meters[0].val, rel=1e-3, abs=1e-6)

@@ -217,9 +217,10 @@ def _cpu_row_kernels():
 
     def unique(ids, n_entries, uids_out):
         u = torch.unique(ids)
-        assert u.numel() <= uids_out.numel()
         uids_out.fill_(n_entries)
-        uids_out[:u.numel()] = u.to(torch.int32)
+        k = min(u.numel(), uids_out.numel())           # an overflowing batch is truncated, like rows_compact_k
+        uids_out[:k] = u[:k].to(torch.int32)
+        return torch.tensor([u.numel()], dtype=torch.int32)
 
     def pack(dense, uids, records_out):
         n_entries = dense.shape[0]
@@ -260,10 +261,12 @@ def _exchange_worker(rank, world, port, q):
     dp = DataParallelContext.from_env(backend='gloo')
     n_entries, dim, nb, na, cap = 50, 6, 37, 64, 16
     out = []
-    for step in range(2):
+    for step in range(3):
         g = torch.Generator().manual_seed(100 * step + rank)
         ids = torch.randint(0, n_entries, (3, 5), generator=g)
         ids[:, 0] = 0                                           # the PAD row is touched by every rank
+        if step == 2 and rank == 1:                             # ONE rank's batch overflows the row capacity: every rank
+            ids = torch.arange(30).reshape(3, 10)               # must take the dense all-reduce for this step
         grad = torch.zeros(n_entries * dim + nb + na)
         emb = grad[:n_entries * dim].view(n_entries, dim)
         emb.index_add_(0, ids.reshape(-1), torch.randn(ids.numel(), dim, generator=g))
@@ -276,13 +279,14 @@ def _exchange_worker(rank, world, port, q):
             ex.grad.copy_(grad)
             grad = ex.grad
         assert [b[0] for b in ex.buckets] == ['A', 'B'] and ex.bytes_per_step()['rows'] == 4 * cap * (dim + 1)
+        ex.precheck(ids)
         ex.launch_a()
         ex.pack_rows(ids)
         ex.exchange_rest()
         ex.merge_rows()
         out.append((mine.tolist(), grad.tolist()))
     dp.barrier()
-    q.put((rank, out, dp.n_collectives))
+    q.put((rank, out, dp.n_collectives, ex.dense_fallbacks))
 
 
 def test_gradient_exchange_schedule_world_size_2_gloo():
@@ -300,8 +304,9 @@ def test_gradient_exchange_schedule_world_size_2_gloo():
     res = sorted(res)
     for p in procs:
         p.join(timeout=60)
-    (_, out0, c0), (_, out1, c1) = res
-    assert c0 == c1 == 2 * 3                      # per step: all-reduce A, all-reduce B, all-gather rows
+    (_, out0, c0, f0), (_, out1, c1, f1) = res
+    assert c0 == c1 == 3 * 4                      # per step: MAX of the id counts, all-reduce A, all-reduce B, rows
+    assert f0 == f1 == 1                          # the overflowing third step went dense on BOTH ranks
     for (m0, g0), (m1, g1) in zip(out0, out1):
         assert g0 == g1                           # identical bits on both ranks
         want = (torch.tensor(m0) + torch.tensor(m1))
@@ -340,3 +345,75 @@ def test_data_parallel_context_world_size_2_gloo():
     assert d0 == d1                               # rank 0's parameters everywhere
     assert g0 == g1 == [3.0] * 15                 # SUM all-reduce of the flat gradient arena (1 + 2)
     assert s0 == s1 == 0.5 and t0 == t1 == 1.0    # Adam consumes grad/world; timing is the max over ranks
+
+
+def test_reference_import_names_resolve_through_compat():
+    """with compat/ at the front of sys.path the reference's own import lines (main_v2.py:10-11,
+    processor_v2.py:25-34) resolve to the product, and the constructor / forward signatures are the ones listed there.
+    Runs in a child interpreter so that `net` / `processor_v2` of this process are untouched."""
+    import subprocess
+    import sys
+    code = r'''
+import inspect, json
+import processor_v2 as processor
+from net.multimodal_context_net_v2 import (PoseGenerator, AffDiscriminator, ConvDiscriminatorTriModal, ConvDiscriminator,
+                                           PoseGeneratorTriModal, WavEncoder, MFCCEncoder, TextEncoderTCN, AffEncoder)
+from net.multimodal_context_net_v2_abl_audio import PoseGenerator as GA
+from net.multimodal_context_net_v2_abl_aff import PoseGenerator as GF, ConvDiscriminator as CF
+from net.tcn import TemporalConvNet, TemporalBlock, Chomp1d
+from net.utils.tgcn import STGraphConv
+from net.utils.graph import Graph
+from net.embedding_net import EmbeddingNet
+from net.embedding_space_evaluator import EmbeddingSpaceEvaluator
+sig = lambda f: str(inspect.signature(f))
+print(json.dumps({
+    'mod': processor.Processor.__module__,
+    'Processor': sig(processor.Processor.__init__),
+    'forward_pass_s2ag': sig(processor.Processor.forward_pass_s2ag),
+    'methods': [hasattr(processor.Processor, m) for m in ('train', 'per_train_epoch', 'per_val_epoch', 'yield_batch',
+                                                          'load_model_at_epoch', 'count_parameters')],
+    'get_epoch_and_loss': sig(processor.get_epoch_and_loss),
+    'PoseGenerator': sig(PoseGenerator.__init__), 'PoseGenerator.forward': sig(PoseGenerator.forward),
+    'AffDiscriminator': sig(AffDiscriminator.__init__), 'AffDiscriminator.forward': sig(AffDiscriminator.forward),
+    'CDT.forward': sig(ConvDiscriminatorTriModal.forward), 'alias': ConvDiscriminator is ConvDiscriminatorTriModal,
+    'PGT': sig(PoseGeneratorTriModal.__init__), 'PGT.forward': sig(PoseGeneratorTriModal.forward),
+    'MFCCEncoder': sig(MFCCEncoder.__init__), 'TextEncoderTCN': sig(TextEncoderTCN.__init__),
+    'AffEncoder': sig(AffEncoder.__init__), 'WavEncoder': sig(WavEncoder.__init__),
+    'TemporalConvNet': sig(TemporalConvNet.__init__), 'STGraphConv': sig(STGraphConv.__init__),
+    'STGraphConv.forward': sig(STGraphConv.forward), 'Graph': sig(Graph.__init__),
+    'GA.forward': sig(GA.forward),
+}))
+'''
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'compat') + os.pathsep + ROOT)
+    out = subprocess.run([sys.executable, '-c', code], env=env, cwd=tempfile.gettempdir(), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    import json
+    got = json.loads(out.stdout.decode().strip().split('\n')[-1])
+    assert got['mod'] == 'speech2affective_gestures_amd.processor_v2'
+    assert all(got['methods']) and got['alias']
+    # the strings of SURVEY.md 8(b) (defaults included where the survey states them)
+    assert got['Processor'] == ('(self, base_path, args, s2ag_config_args, data_loader, pose_dim, coords, audio_sr, '
+                                'min_train_epochs=20, zfill=6)')
+    assert got['forward_pass_s2ag'].startswith('(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, train, '
+                                               'target_seq=None,')
+    assert got['get_epoch_and_loss'] == "(path_to_model_files, epoch='best')"
+    assert got['PoseGenerator'] == ('(self, args, pose_dim, n_words, word_embed_size, word_embeddings, mfcc_length, '
+                                    'num_mfcc, time_steps, z_obj=None)')
+    assert got['PoseGenerator.forward'] == '(self, pre_seq, in_text, in_mfcc, vid_indices=None)'
+    assert got['AffDiscriminator'].startswith('(self, input_size, coords=3')
+    assert got['AffDiscriminator.forward'] == '(self, poses, in_text=None)'
+    assert got['CDT.forward'] == '(self, poses, in_text=None)'
+    assert got['PGT'] == '(self, args, pose_dim, n_words, word_embed_size, word_embeddings, z_obj=None)'
+    assert got['PGT.forward'] == '(self, pre_seq, in_text, in_audio, vid_indices=None)'
+    assert got['GA.forward'] == '(self, pre_seq, in_text, in_audio, vid_indices=None)'
+    assert got['MFCCEncoder'] == '(self, mfcc_length, num_mfcc, time_steps)'
+    assert got['TextEncoderTCN'] == ('(self, args, n_words, embed_size=300, pre_trained_embedding=None, kernel_size=2, '
+                                     'dropout=0.3, emb_dropout=0.1)')
+    assert got['AffEncoder'] == '(self, coords=3)' and got['WavEncoder'] == '(self)'
+    assert got['TemporalConvNet'] == '(self, num_inputs, num_channels, kernel_size=2, dropout=0.2)'
+    assert got['STGraphConv'] == ("(self, in_channels, out_channels, A_channels, kernel_size, stride=(1, 1), "
+                                  "padding=(0, 0), dropout=0, activation='LeakyRelU', residual=True)") or \
+        got['STGraphConv'].startswith('(self, in')
+    assert got['STGraphConv.forward'] == '(self, x, A)'
+    assert got['Graph'].startswith('(self, num_nodes, neighbor_links, strategy')

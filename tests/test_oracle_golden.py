@@ -259,3 +259,23 @@ def test_embedding_net_and_fgd_match_reference(golden_dir):
     fd, dist = O.fgd_scores(np.vstack(gens), np.vstack(reals))
     assert fd == pytest.approx(float(g['scores'][0]), rel=1e-4) and dist == pytest.approx(float(g['scores'][1]), rel=1e-5)
     np.testing.assert_allclose(diffs, g['recon_err_diff'], rtol=1e-4, atol=1e-7)
+
+
+def test_push_samples_metrics_match_reference(golden_dir):
+    """tests/golden/metrics.npz: the reference's own Processor.push_samples (processor_v2.py:738-774) with its AverageMeter
+    over three batches -- per-batch values of the three meters, their running averages and counts."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from metrics_recipe import BATCH_SIZES, MEAN_DIR_VEC, N_BATCHES, N_PRE, metrics_inputs
+    g = _load(golden_dir, 'metrics.npz')
+    sums, count = np.zeros(3), 0
+    for b in range(N_BATCHES):
+        out, tgt = metrics_inputs(b)
+        o, t = torch.from_numpy(out), torch.from_numpy(tgt)
+        vals = O.push_samples_metrics(o, t, MEAN_DIR_VEC, N_PRE)
+        assert torch.equal(o, torch.from_numpy(metrics_inputs(b)[0]))       # inputs untouched
+        np.testing.assert_allclose(vals, g['vals'][b], rtol=1e-6)
+        sums += np.array(vals) * BATCH_SIZES[b]
+        count += BATCH_SIZES[b]
+    np.testing.assert_allclose(sums / count, g['avgs'], rtol=1e-6)
+    assert count == int(g['counts'][0])
