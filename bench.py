@@ -104,21 +104,42 @@ def matrix_products_mode():
             }[np_]
 
 
+def dtype_label():
+    """What the step computes in (storage / products), for the line's `dtype`."""
+    from speech2affective_gestures_amd import _lib as L
+    return {0: 'f32 (f32 MFMA products)', 2: 'f32-storage/bf16x2-products', 3: 'f32-storage/bf16x3-products'}[
+        int(L.load().s2ag_gru_coop_split_pieces())]
+
+
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the kernel whose name starts with ``kernel_prefix``, from the tracked summary of the two
     separate rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, written by tools/pmc_traffic.py from
     FETCH_SIZE / WRITE_SIZE with the gfx950 corrections of the micro-architecture guide).  None when the file or the
     kernel is absent: the line then says traffic = null instead of quoting a stale constant."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    for fname in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+        path = os.path.join(ROOT, 'profiles', fname)
+        try:
+            with open(path) as f:
+                table = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for name, ent in table.get('kernels', {}).items():
+            if name.startswith(kernel_prefix):
+                return float(ent['bytes_per_launch']), 'profiles/' + fname + ' (' + table.get('source', '?') + ')'
+    return None, None
+
+
+def pmc_traffic_per_iteration(mode):
+    """HBM bytes of ONE iteration of the Conv1d roofline run (all its kernels), from the tracked summary of the two separate
+    rocprofv3 --pmc passes over tools/run_cfg4.py (profiles/r03_pmc_traffic_cfg3_<mode>.json, tools/pmc_traffic.py).  None
+    when the file is absent."""
+    path = os.path.join(ROOT, 'profiles', f'r03_pmc_traffic_cfg3_{mode}.json')
     try:
         with open(path) as f:
             table = json.load(f)
-    except (OSError, ValueError):
+        return float(table['bytes_per_iteration']), 'profiles/' + os.path.basename(path) + ' (' + table.get('source', '?') + ')'
+    except (OSError, ValueError, KeyError):
         return None, None
-    for name, ent in table.get('kernels', {}).items():
-        if name.startswith(kernel_prefix):
-            return float(ent['bytes_per_launch']), 'profiles/r02_pmc_traffic.json (' + table.get('source', '?') + ')'
-    return None, None
 
 
 def gru_roofline(B, iters=20, T=T):
@@ -205,8 +226,12 @@ def gru_roofline(B, iters=20, T=T):
     algo_bytes = 4.0 * B * T * (6 * H + 2 * 2 * H + 2 * 4 * H) + 4.0 * 2 * 3 * H * H
     if multi:      # the two mate passes save no gates; W_hh is read once per launch
         algo_bytes = 0.5 * (algo_bytes + algo_bytes + (nP - 1) * 4.0 * B * T * (6 * H + 2 * 2 * H))
+    # the products execute as `issued` bf16 MFMAs per fp32 product (2 pieces: 3, 3 pieces: 6; f32 MFMA: the f32 pipe itself)
+    issued = {0: None, 2: 3, 3: 6}[np_]
     return dict(bound='mfma', kernel=name + f' (H=300, T={T}, 2 directions' + ('; average launch of the step: 4 three-pass lockstep launches + 4 one-pass launches)' if multi else ')'),
-                achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3, traffic=traffic,
+                achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3,
+                frac_of_bf16_pipe=(achieved * issued / 2500.0) if issued else None,
+                bf16_pipe_tflops_issued=(achieved * issued) if issued else None, traffic=traffic,
                 traffic_source=source, algorithmic_bytes_per_launch=algo_bytes, ms_per_launch=ms,
                 algorithmic_flops_per_launch=flops,
                 launch_mix=(None if not multi else dict(
@@ -361,18 +386,33 @@ def conv1d_roofline_run(device, B=256, iters=30, cpu=True, mode='fp32'):
         ops.join_side_streams()
         cur.wait_stream(side)
     with bf16.precision(mode):
-        ms = _graph_timer(fn, iters)
+        if os.environ.get('S2AG_CFG3_EAGER', '0') == '1':       # counter passes (tools/profile_r03.sh): exactly `iters` eager runs
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / iters * 1e3
+            print(f'iterations_run={iters}', flush=True)
+        else:
+            ms = _graph_timer(fn, iters)
     clips = B / (ms * 1e-3)
     bytes_per_clip, flops_per_clip = (5.75e6 if mode == 'fp32' else 2.95e6), 413.8e6
+    traffic, tsrc = pmc_traffic_per_iteration(mode) if B == 256 else (None, None)
     out = dict(workload=f'BASELINE configs[3]: WavEncoder + TextEncoderTCN fwd+bwd, B=256, T=34, {mode}, dropout on',
-               ms_per_iter=ms, clips_per_s=clips, dtype='f32' if mode == 'fp32' else 'bf16',
+               ms_per_iter=ms, clips_per_s=clips,
+               dtype='f32 storage, bf16x2 products (TCN, weight gradients) / f32 MFMA' if mode == 'fp32'
+               else 'bf16 storage, fp32 accumulation / statistics / master weights',
                roofline=dict(bound='hbm', achieved=clips * bytes_per_clip / 1e9, peak=8000.0, unit='GB/s',
-                             frac=clips * bytes_per_clip / 8e12, traffic=None,
+                             frac=clips * bytes_per_clip / 8e12, traffic=traffic, traffic_source=tsrc,
+                             traffic_over_algorithmic=(traffic / (B * bytes_per_clip)) if traffic else None,
                              algorithmic_bytes_per_clip=bytes_per_clip,
+                             algorithmic_bytes_per_iteration=B * bytes_per_clip,
                              frac_at_fp32_bytes=clips * 5.75e6 / 8e12,
                              note=f'{clips * flops_per_clip / 1e12:.1f} TFLOP/s of matrix work at this rate '
-                                  '(413.8 MFLOP/clip); kernel-level trace: profiles/r02_cfg3_kernel_stats.txt (fp32), '
-                                  'profiles/r02_cfg3_bf16_kernel_stats.txt (bf16)'))
+                                  '(413.8 MFLOP/clip); one "launch" of this line = one iteration (all kernels of the two '
+                                  'encoders, forward + backward); kernel-level trace: profiles/r03_cfg3_fp32_kernel_stats.txt, '
+                                  'profiles/r03_cfg3_bf16_kernel_stats.txt'))
     if cpu and mode == 'fp32':
         from oracle import s2ag_oracle as O
         phys, cand = _cpu_threads()
@@ -431,6 +471,56 @@ def cpu_baseline(B, steps=2, frames=T, audio_len=AUDIO_LEN):
                 sample=f'{steps} timed GAN steps (+1 warm-up, +1 probe per thread count) of the CPU oracle at batch {B}, '
                        f'T={frames}, fp32, torch {torch.__version__}, {cores} threads (fastest of {cand}: the step is a '
                        f'chain of small ops, more threads are slower); {dt * 1e3:.0f} ms/step')
+
+
+def dp_structure_run(steps):
+    """The data-parallel STRUCTURE of the step on one GPU: a child process with S2AG_FORCE_DIST=1 opens a world-size-1 RCCL
+    group, so the step runs as four graph segments with the eager collectives (id-count MAX, D arena, bucket A beside the
+    encoders' backward, bucket B, touched-row all-gather) between them -- what every rank of an N-GPU run executes, minus the
+    wire time.  Its rate against `value` is the cost of the segment / host round-trip structure itself."""
+    import subprocess
+    env = dict(os.environ, S2AG_FORCE_DIST='1', S2AG_BENCH_CHILD='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29400 + os.getpid() % 500))
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--no-extras', '--no-cpu-baseline', '--steps', str(steps),
+                            '--warmup', '5'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        line = json.loads(r.stdout.decode(errors='replace').strip().split('\n')[-1])
+        return dict(clips_per_s=line['value'], ms_per_step=line['ms_per_step'], steps=steps,
+                    gradient_exchange_bytes_per_rank=line['config'].get('gradient_exchange_bytes_per_rank'),
+                    note='S2AG_FORCE_DIST=1: world-size-1 RCCL group, 4 graph segments + eager collectives between them')
+    except Exception as e:       # noqa: BLE001  (an extra: never takes the headline down)
+        return dict(error=repr(e)[:200])
+
+
+def epoch_loop_rate(pr, B, n_clips=4096):
+    """PCIe-inclusive rate (never `value`): Processor.per_train_epoch's loop -- yield_batch -> train_step -- over a synthetic
+    TED-shaped numpy dataset resident in HOST memory (raw int16 audio, float64 poses, float16 MFCCs as the reference's cache
+    holds them), with the prefetching feeder (data.BatchFeeder: pinned staging, own copy stream, device-side decode)."""
+    import numpy as np
+    rs = np.random.RandomState(0)
+    text = np.zeros((n_clips, T), dtype=np.int64)
+    for i in range(n_clips):
+        k = rs.randint(2, MAX_WORDS_PER_CLIP + 1)
+        text[i, rs.permutation(T)[:k]] = rs.randint(4, N_WORDS, k)
+    samples = dict(extended_word_seq=text, vec_seq=rs.randn(n_clips, T, POSE_DIM) * 0.2,
+                   audio=np.clip(rs.randn(n_clips, AUDIO_LEN) * 0.05 * 32767, -32767, 32767).astype(np.int16),
+                   audio_max=np.ones(n_clips), mfcc_features=(rs.randn(n_clips, NUM_MFCC, MFCC_LEN) * 0.1).astype(np.float16),
+                   vid_indices=rs.randint(0, N_SPK, n_clips))
+    pr.train_samples, pr.num_train_samples = samples, n_clips
+    pr.args.prefetch_batches = True
+    rate = None
+    for ep in range(2):                                  # epoch 0 warms up (pinned allocations, feeder thread)
+        np.random.seed(ep)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for text_b, vec, audio, mfcc, vids in pr.yield_batch(train=True):
+            pr.train_step(text_b, audio, mfcc, vec, vids, sync=False)
+            n += B
+        torch.cuda.synchronize()
+        rate = n / (time.perf_counter() - t0)
+    return dict(clips_per_s=rate, clips_per_epoch=n_clips,
+                note='host-resident dataset: gather + PCIe + device-side decode inside the timed loop (data.BatchFeeder)')
 
 
 def timed_steps(pr, dp, batch, steps, warmup, sync):
@@ -518,7 +608,7 @@ def main():
         line = {
             'metric': 'gan_train_step_clips_per_sec', 'value': value, 'unit': 'clips/s', 'n_gpus': dp.world_size,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': dtype_label(), 'data': 'synthetic',
             'config': {'workload': wl['name'], 'batch_per_gpu': B, 'global_batch': B * dp.world_size, 'frames': frames,
                        'audio_samples': audio_len, 'n_words': N_WORDS, 'n_speakers': N_SPK,
                        'parallelism': f'dp{dp.world_size}', 'hip_graph': not a.no_graph,
@@ -528,6 +618,9 @@ def main():
             'value_with_per_step_loss_readback': sync_value,
         }
         line['roofline'] = gru_roofline(B, T=frames)
+        if dp.world_size == 1 and not a.no_extras and not dp.active:
+            line['value_epoch_loop'] = epoch_loop_rate(pr, B) if a.config == 'step' else None
+            line['value_dp_structure'] = dp_structure_run(a.steps)
         if dp.world_size == 1 and not a.no_extras:
             line['alt_modes'] = alt_modes(pr, dp, batch, B)
             line['gen_fwd_ms'] = gen_forward_ms(pr, pr.device, cpu=not a.no_cpu_baseline)

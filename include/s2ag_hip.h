@@ -462,6 +462,43 @@ int s2ag_bf16_conv_c1_fwd(const float* x, const float* w, const float* bias, voi
 int s2ag_bf16_conv_c1_wgrad(const void* gy, const float* x, float* dw, float* db, const s2ag_conv_geom* g, void* stream);
 int s2ag_bf16_conv_c1_rows(const s2ag_conv_geom* g);      /* statistics partial rows s2ag_bf16_conv_c1_fwd writes */
 
+/* ---- wave encoder with BatchNorm folded into the neighbouring convs, bf16 mode (csrc/wave_fused.hip) ------------------
+ * Replaces, for the training-mode WavEncoder (net/multimodal_context_net_v2.py:14-33: feat_extractor.{3,4,5,6,7,8,9} and the
+ * backward of feat_extractor.{0..9}), the cudnn_convolution / native_batch_norm / leaky_relu_ and their backward ATen calls:
+ * a conv stores its RAW output (bf16) + fp64 column-sum partials; the next conv applies a = leaky(scale * y + shift) in its
+ * loader; backward: the data gradient of conv i+1 emits dz_i = da_i * leaky'(.) and the column sums of dz_i, dz_i * xhat_i;
+ * the consumers of dy_i form dy_i = A dz_i + C y_i + B in their loaders (coefficients from s2ag_wave_bn_bwd_fold).
+ * Shapes: (Cin, Cout) in {(16, 32), (32, 64), (64, 32)}, 15 taps, stride 6, no padding; x / y channels-last bf16. */
+int s2ag_wave_fwd_rows(int N, int Lout, int Cin, int Cout);      /* statistics partial rows of s2ag_wave_conv_fwd */
+/* w_packed: (Cout, KP) bf16, k = tap * Cin + ci, zero beyond 15 Cin (bf16.WeightPack 'fwd' layout of a reference weight);
+ * stats: (2, rows, Cout) doubles or NULL; out_f32: y is fp32 (the last conv). */
+int s2ag_wave_conv_fwd(const void* x, const float* in_scale, const float* in_shift, float slope, const void* w_packed, int KP,
+                       const float* bias, void* y, int out_f32, double* stats, int N, int Lin, int Lout, int Cin, int Cout,
+                       void* stream);
+
+/* data gradient of conv i (poly-phase) + the backward of BatchNorm i-1 / LeakyReLU on its result: reads dy_i = ca dz + cc y
+ * + cb (or the fp32 output gradient when g_f32: the last conv), writes dz_{i-1} = da_{i-1} * leaky'(p_scale y_prev + p_shift)
+ * and the partial column sums (2, rows, Cin) of dz_{i-1} and dz_{i-1} * xhat_{i-1}.  w_phases: (6, Cin, 3, CPO) bf16 =
+ * W[co][ci][r + 6 i] (bf16.WeightPack 'phases' layout). */
+int s2ag_wave_dgrad_rows(int N, int Lin, int Cin);
+int s2ag_wave_conv_dgrad(const void* dz, const void* y, const float* ca, const float* cb, const float* cc, int g_f32,
+                         const void* w_phases, int CPO, const void* y_prev, const float* p_scale, const float* p_shift,
+                         const float* p_mean, const float* p_invstd, float slope, void* dz_prev, double* stats, int N, int Lin,
+                         int Lout, int Cin, int Cout, void* stream);
+/* weight (+ bias) gradient of conv i: dw (Cout, Cin, 15) += sum dy_i a_{i-1}, a_{i-1} = leaky(p_scale y_prev + p_shift)
+ * recomputed in the loader; partials: s2ag_wave_wgrad_blocks * Cout * 15 * Cin floats, partials_b: blocks * Cout. */
+int s2ag_wave_wgrad_blocks(int N, int Lout, int Cin, int Cout);
+int s2ag_wave_conv_wgrad(const void* dz, const void* y, const float* ca, const float* cb, const float* cc, int g_f32,
+                         const void* y_prev, const float* p_scale, const float* p_shift, float slope, float* partials,
+                         float* partials_b, float* dw, float* db, int N, int Lin, int Lout, int Cin, int Cout, void* stream);
+/* fold of the partial sums of s2ag_wave_conv_dgrad: dgamma += sum dz xhat, dbeta += sum dz (nullable), and the
+ * coefficients of dy = ca dz + cc y + cb for the BatchNorm over `rows` rows */
+int s2ag_wave_bn_bwd_fold(const double* partials, int partial_rows, int C, long long rows, const float* gamma, const float* mean,
+                          const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb, float* cc, void* stream);
+/* conv1's weight gradient (net/multimodal_context_net_v2.py:18) from dz_1 and y_1 (both bf16 (N, Lout, 16)) */
+int s2ag_wave_conv1_wgrad(const void* dz, const void* y1, const float* ca, const float* cb, const float* cc, const float* x,
+                          float* dw, float* db, const s2ag_conv_geom* g, void* stream);
+
 /* ---- clip-resident TemporalConvNet in bf16 mode (csrc/tcn_fused.hip) ----------------------------------------------
  * Replaces the whole stack of TemporalBlocks of net/tcn.py:16-64 (conv1 -> chomp -> ReLU -> dropout -> conv2 -> chomp ->
  * ReLU -> dropout, + residual, ReLU; kernel size 2, dilations dil[b], in == out channels C <= 320) by ONE launch

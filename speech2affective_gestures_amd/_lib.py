@@ -153,6 +153,14 @@ SIGNATURES = {
     's2ag_bf16_conv_c1_fwd': [vp, vp, vp, vp, PG, vp, vp, vp],
     's2ag_bf16_conv_c1_wgrad': [vp, vp, vp, vp, PG, vp],
     's2ag_bf16_conv_c1_rows': [PG],
+    's2ag_wave_fwd_rows': [ci, ci, ci, ci],
+    's2ag_wave_conv_fwd': [vp, vp, vp, cf, vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp],
+    's2ag_wave_dgrad_rows': [ci, ci, ci],
+    's2ag_wave_conv_dgrad': [vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, ci, ci, ci, vp],
+    's2ag_wave_wgrad_blocks': [ci, ci, ci, ci],
+    's2ag_wave_conv_wgrad': [vp, vp, vp, vp, vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    's2ag_wave_bn_bwd_fold': [vp, ci, ci, cll, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    's2ag_wave_conv1_wgrad': [vp, vp, vp, vp, vp, vp, vp, vp, PG, vp],
     's2ag_bf16_tcn_clips_per_block': [ci, ci, ci],
     's2ag_bf16_tcn_pack_elems': [ci],
     's2ag_bf16_tcn_sign_bytes': [ci, ci],

@@ -729,3 +729,147 @@ class _Embedding16(torch.autograd.Function):
 
 def embedding(ids: Tensor, table: Tensor, drop_p: float = 0.0, noise=None, site=0) -> Tensor:
     return _Embedding16.apply(ids, table, float(drop_p), noise, int(site), pad32(table.shape[1]))
+
+
+# ----------------------------------------------------------------------------------------------------
+# the wave encoder with BatchNorm folded into the neighbouring convs (csrc/wave_fused.hip)
+# ----------------------------------------------------------------------------------------------------
+WAVE_FUSED = os.environ.get('S2AG_WAVE_FUSED', '1') != '0'
+_WAVE_LAYERS = ((16, 32), (32, 64), (64, 32))          # (Cin, Cout) of conv2..4: 15 taps, stride 6, no padding
+
+
+def wave_fused_supported(fe) -> bool:
+    """``fe`` = WavEncoder.feat_extractor (net/multimodal_context_net_v2.py:17-28)."""
+    if not WAVE_FUSED:
+        return False
+    c1 = fe[0]
+    ok = (c1.in_channels, c1.out_channels, c1.kernel_size[0], c1.stride[0]) == (1, 16, 15, 5)
+    for i, (ci, co) in zip((3, 6, 9), _WAVE_LAYERS):
+        c = fe[i]
+        ok = ok and (c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0]) == \
+            (ci, co, 15, 6, 0, 1)
+    return ok
+
+
+class _WaveFused16(torch.autograd.Function):
+    """WavEncoder.forward in training mode: (N, samples) fp32 -> (N, frames, 32) fp32.  The three BatchNorms never run as
+    kernels of their own: forward, a conv stores its raw output (bf16) + column-sum partials and the next conv applies
+    scale / shift / LeakyReLU in its loader; backward, a data gradient emits dz = da * leaky'(.) + the column sums of dz
+    and dz * xhat, and the consumers of dy = A dz + C y + B form it in their loaders (wave_fused.hip)."""
+
+    @staticmethod
+    def forward(ctx, wav, pack, bns, slope, *params):
+        lib = _lib()
+        w1, b1, g1, e1, w2, b2, g2, e2, w3, b3, g3, e3, w4, b4 = params
+        N, Lin0 = wav.shape
+        dev = wav.device
+        wav = wav.contiguous()
+        pad1 = 1600
+        L1 = (Lin0 + 2 * pad1 - 15) // 5 + 1
+        lens = [L1]
+        for _ in _WAVE_LAYERS:
+            lens.append((lens[-1] - 15) // 6 + 1)
+        geom1 = L.ConvGeom(N, Lin0, L1, 1, 16, 15, 5, pad1, 1, 1, 16, 0)
+        y1 = torch.empty(N, L1, 16, dtype=torch.bfloat16, device=dev)
+        rows = lib.s2ag_bf16_conv_c1_rows(C.byref(geom1))
+        part = torch.empty(2 * rows * 16, dtype=torch.float64, device=dev)
+        got = C.c_int(0)
+        L.check(lib.s2ag_bf16_conv_c1_fwd(_p(wav), _p(w1), _p(b1), _p(y1), C.byref(geom1), _p(part), C.byref(got), _s()),
+                'bf16_conv_c1_fwd')
+        ys, coefs = [y1], []
+        gb = ((g1, e1), (g2, e2), (g3, e3))
+
+        def fold(part, prow, rows_total, k):
+            bn, (gamma, beta) = bns[k], gb[k]
+            cols = gamma.numel()
+            coef = torch.empty(4, cols, dtype=torch.float32, device=dev)
+            L.check(lib.s2ag_bn_fold(_p(part), int(prow), int(rows_total), cols, None, cols, _p(gamma), _p(beta),
+                                     _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), float(bn.eps),
+                                     float(bn.momentum), int(ops._BN_REPEAT[0]), _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                     _p(coef[3]), _s()), 'bn_fold')
+            return coef
+        coefs.append(fold(part, got.value, N * L1, 0))
+        names = ('c3', 'c6', 'c9')
+        ws, bs = (w2, w3, w4), (b2, b3, b4)
+        for k, (ci, co) in enumerate(_WAVE_LAYERS):
+            last = k == 2
+            w16 = pack.get(names[k], 'fwd')                         # (co, 1, KP)
+            Lin, Lout = lens[k], lens[k + 1]
+            y = torch.empty(N, Lout, co, dtype=torch.float32 if last else torch.bfloat16, device=dev)
+            st = None
+            if not last:
+                prow = lib.s2ag_wave_fwd_rows(N, Lout, ci, co)
+                st = torch.empty(2 * prow * co, dtype=torch.float64, device=dev)
+            L.check(lib.s2ag_wave_conv_fwd(_p(ys[-1]), _p(coefs[-1][0]), _p(coefs[-1][1]), float(slope), _p(w16),
+                                           int(w16.shape[2]), _p(bs[k]), _p(y), int(last), _p(st), N, Lin, Lout, ci, co, _s()),
+                    'wave_conv_fwd')
+            if not last:
+                coefs.append(fold(st, prow, N * Lout, k + 1))
+                ys.append(y)
+        ctx.pack, ctx.slope, ctx.lens, ctx.params, ctx.pad1 = pack, float(slope), lens, params, pad1
+        ctx.save_for_backward(wav, *ys, *coefs)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        wav, y1, y2, y3, c1, c2, c3 = ctx.saved_tensors
+        w1, b1, g1, e1, w2, b2, g2, e2, w3, b3, g3, e3, w4, b4 = ctx.params
+        lens, slope, pack = ctx.lens, ctx.slope, ctx.pack
+        N, dev = wav.shape[0], wav.device
+        g = g.contiguous().float()
+        grads = [None] * 14
+
+        def slot(idx):
+            p = ctx.params[idx]
+            if p is None or not ctx.needs_input_grad[4 + idx]:
+                return None
+            s = ops._grad_slot(p)
+            if s is None:
+                s = grads[idx] = torch.zeros_like(p)
+            else:
+                ops._note_staged(p)
+            return s
+        ys, coefs = (y1, y2, y3), (c1, c2, c3)
+        names = ('c3', 'c6', 'c9')
+        widx = (4, 8, 12)                                           # positions of w2, w3, w4 in params (bias = +1)
+        gidx = (2, 6, 10)                                           # gamma of BatchNorm 1..3 (beta = +1)
+        dz, yy, cabc = g, None, None                               # the operands of dy of the layer being processed
+        for k in (2, 1, 0):
+            ci, co = _WAVE_LAYERS[k]
+            Lin, Lout = lens[k], lens[k + 1]
+            g_f32 = k == 2
+            yp, cp = ys[k], coefs[k]
+            wslot, bslot = slot(widx[k]), slot(widx[k] + 1)
+            ca, cb, cc = (None, None, None) if g_f32 else (cabc[0], cabc[1], cabc[2])
+            if wslot is not None:
+                nb = lib.s2ag_wave_wgrad_blocks(N, Lout, ci, co)
+                part = torch.empty(nb * co * 15 * ci + nb * co, dtype=torch.float32, device=dev)
+                L.check(lib.s2ag_wave_conv_wgrad(_p(dz), _p(yy), _p(ca), _p(cb), _p(cc), int(g_f32), _p(yp), _p(cp[0]), _p(cp[1]),
+                                                 slope, _p(part), _p(part[nb * co * 15 * ci:]), _p(wslot), _p(bslot), N, Lin, Lout,
+                                                 ci, co, _s()), 'wave_conv_wgrad')
+            wph = pack.get(names[k], 'phases')                      # (6, ci, 3, CPO)
+            prow = lib.s2ag_wave_dgrad_rows(N, Lin, ci)
+            st = torch.empty(2 * prow * ci, dtype=torch.float64, device=dev)
+            dzp = torch.empty(N, Lin, ci, dtype=torch.bfloat16, device=dev)
+            L.check(lib.s2ag_wave_conv_dgrad(_p(dz), _p(yy), _p(ca), _p(cb), _p(cc), int(g_f32), _p(wph), int(wph.shape[3]),
+                                             _p(yp), _p(cp[0]), _p(cp[1]), _p(cp[2]), _p(cp[3]), slope, _p(dzp), _p(st), N, Lin,
+                                             Lout, ci, co, _s()), 'wave_conv_dgrad')
+            cabc = torch.empty(3, ci, dtype=torch.float32, device=dev)
+            L.check(lib.s2ag_wave_bn_bwd_fold(_p(st), prow, ci, N * Lin, _p(ctx.params[gidx[k]]), _p(cp[2]), _p(cp[3]),
+                                              _p(slot(gidx[k])), _p(slot(gidx[k] + 1)), _p(cabc[0]), _p(cabc[1]), _p(cabc[2]),
+                                              _s()), 'wave_bn_bwd_fold')
+            dz, yy = dzp, yp
+        wslot, bslot = slot(0), slot(1)
+        if wslot is not None:
+            geom1 = L.ConvGeom(N, wav.shape[1], lens[0], 1, 16, 15, 5, ctx.pad1, 1, 1, 16, 0)
+            L.check(lib.s2ag_wave_conv1_wgrad(_p(dz), _p(yy), _p(cabc[0]), _p(cabc[1]), _p(cabc[2]), _p(wav), _p(wslot),
+                                              _p(bslot), C.byref(geom1), _s()), 'wave_conv1_wgrad')
+        return (None, None, None, None) + tuple(grads)
+
+
+def wave_encoder_fused(wav: Tensor, fe, pack: WeightPack) -> Tensor:
+    """Training-mode WavEncoder on ``fe`` = its feat_extractor; ``pack`` holds the bf16 layouts of fe[3], fe[6], fe[9]."""
+    return _WaveFused16.apply(wav, pack, (fe[1], fe[4], fe[7]), 0.3,
+                              fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, fe[3].weight, fe[3].bias, fe[4].weight,
+                              fe[4].bias, fe[6].weight, fe[6].bias, fe[7].weight, fe[7].bias, fe[9].weight, fe[9].bias)

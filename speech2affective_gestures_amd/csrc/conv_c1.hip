@@ -34,6 +34,12 @@ struct C1P {
     int N, Lin, Lout, stride, pad, ldx, ldy;
     int runs_per_clip;            // cdiv(Lout, C1_RUN)
     int total_runs;               // N * runs_per_clip
+    // wgrad with the BatchNorm backward folded into the loader (wave_fused.hip): gy = ca * dz + cc * y1 + cb per channel,
+    // `y` then holds dz (bf16) and y1 the raw conv output (bf16)
+    const unsigned short* y1;
+    const float* ca;
+    const float* cb;
+    const float* cc;
 };
 
 __device__ __forceinline__ unsigned c1_bf16_rn(float v) {
@@ -139,13 +145,23 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_fwd_k(const C1P p) {
     }
 }
 
-template <int CO, int KS, bool BF>
+template <int CO, int KS, bool BF, bool XF = false>
 __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
     static_assert(CO == 16, "thread mapping: 4 channel quads");
+    static_assert(BF || !XF, "the folded BatchNorm backward reads bf16 rows");
     extern __shared__ float seg[];
     __shared__ float red[4][CO * KS + CO];                           // per-wave sums: dw (CO x KS) then db (CO)
     const int tid = threadIdx.x, q = tid & 3, fr = tid >> 2;
     const int lane = tid & 63, wave = tid >> 6;
+    float xa[4] = {0.f, 0.f, 0.f, 0.f}, xb[4] = {0.f, 0.f, 0.f, 0.f}, xc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (XF) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            xa[c] = p.ca[q * 4 + c];
+            xb[c] = p.cb[q * 4 + c];
+            xc[c] = p.cc[q * 4 + c];
+        }
+    }
     float acc[4][KS], bsum[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -170,6 +186,13 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
                                                                     ((long long)n * p.Lout + l) * p.ldy + q * 4);
                     gq[i] = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u),
                                         __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+                    if (XF) {
+                        const uint2 v = *reinterpret_cast<const uint2*>(p.y1 + ((long long)n * p.Lout + l) * p.ldy + q * 4);
+                        gq[i].x = fmaf(xa[0], gq[i].x, fmaf(xc[0], __uint_as_float(v.x << 16), xb[0]));
+                        gq[i].y = fmaf(xa[1], gq[i].y, fmaf(xc[1], __uint_as_float(v.x & 0xffff0000u), xb[1]));
+                        gq[i].z = fmaf(xa[2], gq[i].z, fmaf(xc[2], __uint_as_float(v.y << 16), xb[2]));
+                        gq[i].w = fmaf(xa[3], gq[i].w, fmaf(xc[3], __uint_as_float(v.y & 0xffff0000u), xb[3]));
+                    }
                 } else {
                     gq[i] = *reinterpret_cast<const float4*>(p.y + ((long long)n * p.Lout + l) * p.ldy + q * 4);
                 }
@@ -304,6 +327,26 @@ extern "C" int s2ag_bf16_conv_c1_wgrad(const void* gy, const float* x, float* dw
     p.total_runs = g->N * p.runs_per_clip;
     const int blocks = p.total_runs < 1024 ? p.total_runs : 1024;
     hipLaunchKernelGGL((conv_c1_wgrad_k<16, 15, true>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(g->stride), (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+// conv1's weight gradient with the BatchNorm backward folded into the loader (see wave_fused.hip): gy = ca dz + cc y1 + cb
+extern "C" int s2ag_wave_conv1_wgrad(const void* dz, const void* y1, const float* ca, const float* cb, const float* cc,
+                                     const float* x, float* dw, float* db, const s2ag_conv_geom* g, void* stream) {
+    if (!dz || !y1 || !ca || !cb || !cc || !x || !dw || !g) return S2AG_E_BADARG;
+    if (!c1_shape_ok(g->Cin, g->Cout, g->ksize, g->dil, g->ldx, g->ldy, g->stride) || (reinterpret_cast<uintptr_t>(dz) & 7) ||
+        (reinterpret_cast<uintptr_t>(y1) & 7))
+        return S2AG_E_UNSUPPORTED;
+    C1P p{};
+    p.x = x; p.y = static_cast<float*>(const_cast<void*>(dz)); p.dw = dw; p.db = db;
+    p.y1 = static_cast<const unsigned short*>(y1); p.ca = ca; p.cb = cb; p.cc = cc;
+    p.N = g->N; p.Lin = g->Lin; p.Lout = g->Lout; p.stride = g->stride; p.pad = g->pad; p.ldx = g->ldx; p.ldy = g->ldy;
+    p.runs_per_clip = cdiv(g->Lout, C1_RUN);
+    p.total_runs = g->N * p.runs_per_clip;
+    const int blocks = p.total_runs < 1024 ? p.total_runs : 1024;
+    hipLaunchKernelGGL((conv_c1_wgrad_k<16, 15, true, true>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(g->stride),
+                       (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

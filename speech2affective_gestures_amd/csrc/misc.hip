@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256) void pose_metrics_k(const float* __restrict__ 
 extern "C" int s2ag_pose_metrics(const float* out, const float* target, const double* mean_dir_vec, int B, int T,
                                  int n_pre, double* sums, void* stream) {
     if (!out || !target || !mean_dir_vec || !sums || B < 1 || T < 3 || n_pre < 0 || n_pre >= T) return S2AG_E_BADARG;
-    s2ag::zero_async(sums, 3 * sizeof(double), (hipStream_t)stream);
+    (void)s2ag::zero_async(sums, 3 * sizeof(double), (hipStream_t)stream);
     hipLaunchKernelGGL(pose_metrics_k, dim3(cdiv(B * T, 256)), dim3(256), 0, (hipStream_t)stream, out, target,
                        mean_dir_vec, B, T, n_pre, sums);
     S2AG_LAUNCH_CHECK();

@@ -122,6 +122,8 @@ class WavEncoder(nn.Module):
             for i, (ci, co) in zip((3, 6, 9), ((16, 32), (32, 64), (64, 32))):
                 self.__dict__['_pack16'].add(f'c{i}', (lambda c=fe[i]: c.weight), 'reference', co, ci, 15, stride=6)
         pk = self.__dict__['_pack16']
+        if all(fe[i].training for i in (1, 4, 7)) and bf16.wave_fused_supported(fe):
+            return bf16.wave_encoder_fused(wav_data, fe, pk)       # BatchNorm folded into the convs (wave_fused.hip)
         x = bf16.conv_c1(wav_data, fe[0].weight, fe[0].bias, 5, 1600, bn_stats=fe[1].training)
         x = bf16.batch_norm_act(x, fe[1], slope=0.3)
         x = bf16.conv(x, fe[3].weight, fe[3].bias, pk, 'c3', 16, 32, 15, stride=6, bn_stats=fe[4].training)

@@ -47,7 +47,9 @@ class DataParallelContext:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             if backend is None:
-                backend = 'nccl' if torch.cuda.is_available() else 'gloo'      # 'nccl' IS RCCL on ROCm
+                # 'nccl' IS RCCL on ROCm.  S2AG_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses
+                # duplicate devices): the two-rank test of the real step on a single MI355X (tests/test_gpu_step.py)
+                backend = os.environ.get('S2AG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             if backend == 'nccl':
                 torch.cuda.set_device(local)
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -82,7 +84,10 @@ class DataParallelContext:
             out.copy_(inp)
             return
         self.n_collectives += 1
-        dist.all_gather_into_tensor(out, inp)
+        if dist.get_backend() == 'gloo':         # no all_gather_into_tensor for device tensors there
+            dist.all_gather(list(out.view(self.world_size, -1).unbind(0)), inp)
+        else:
+            dist.all_gather_into_tensor(out, inp)
 
     def all_reduce_grads(self, arena) -> None:
         """SUM over ranks into ``arena.grad`` (scaled by 1/world inside the fused Adam)."""

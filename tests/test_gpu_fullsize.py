@@ -174,3 +174,125 @@ def test_long_context_full_size_steps():
         G.train()
         T3.train()
     assert ops.coop_gru_timeouts() == 0
+
+
+def _grad_report(named_params, ref_grads, skip=lambda k: '.net.' in k):
+    """(relative L2 error over all parameters together, {key: (max-norm error, relative L2 error)})."""
+    from s2ag_testing import grad_err
+    per, num, den = {}, 0.0, 0.0
+    for k, p in named_params:
+        if skip(k):
+            continue
+        assert p.grad is not None, k
+        a, b = p.grad.detach().cpu().double(), ref_grads[k].double()
+        e = grad_err(a, b, k)
+        per[k] = (e, 0.0 if e == 0.0 else float((a - b).norm() / max(1e-12, float(b.norm()))))
+        if e != 0.0:
+            num += float((a - b).square().sum())
+            den += float(b.square().sum())
+    return (num / max(den, 1e-300)) ** 0.5, per
+
+
+@pytest.mark.parametrize('config', ['step', 'long'])
+def test_full_size_step_matches_the_oracle(monkeypatch, config):
+    """ONE training step at the full BASELINE size against the oracle's gan_step fed the product's materialised masks:
+    configs[1] (B = 128, T = 34) and configs[4] (B = 64, T = 136, audio 146 000), both at H = 300, n_words 20 000, 1 371
+    speakers, dropout on -- the sizes bench.py times, through the kernels it times (three-pass lockstep cooperative GRU,
+    two-slice recurrence, clip-resident TCN, split-operand GEMMs).  Losses and metric strictly; every generator and
+    discriminator gradient with the kink-tolerant criteria of test_gpu_modules.py (at this width a few of the ~10^7 ReLU /
+    LeakyReLU inputs per pass lie within rounding distance of zero); BatchNorm running statistics strictly."""
+    from oracle import s2ag_oracle as O
+    from s2ag_testing import PASSES_PER_STEP, STEP_SEED, oracle_cfg, to_cuda
+    from test_gpu_step import _materialise_step_noise, make_processor
+    from speech2affective_gestures_amd import noise, ops
+    from speech2affective_gestures_amd import processor_v2 as P
+    wl = bench.CONFIGS[config]
+    B, T, AL = wl['batch'], wl['frames'], wl['audio_len']
+    hidden, n_words, n_spk, s0 = 300, bench.N_WORDS, bench.N_SPK, 8800
+    mfcc_len = -(-AL // 512)
+    pr, sds = make_processor(hidden, n_words, n_spk, B, s0, 0.3, T=T, audio_len=AL)
+    G, D, T3 = ({k: v.clone() for k, v in sds[n].items()} for n in ('G', 'D', 'T3'))
+    noise.manual_seed(STEP_SEED)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
+    monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm.cuda())
+    inp = O.recipe_inputs(B, T, s0 + 100, n_words, n_spk, audio_len=AL, mfcc_len=mfcc_len)
+    gi = to_cuda(inp)
+    nz = _materialise_step_noise(pr, 0, B, T, hidden)
+    nz.perm = perm
+    ret = pr.forward_pass_s2ag(gi['in_text'], gi['in_audio'], gi['in_mfcc'], gi['target'], gi['vid'], True)
+    monkeypatch.undo()
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    # a copy of D's gradient: the generator phase never touches D's arena (frozen there), so it is still the D step's
+    metric, losses, grads = O.gan_step(G, D, T3, O.AdamState(), O.AdamState(), oracle_cfg(hidden, 0.3, T), O.StepCfg(),
+                                       inp['in_text'], inp['in_audio'], inp['in_mfcc'], inp['target'], inp['vid'], epoch=1,
+                                       noise=nz)
+    for k in ('dis', 'total', 'loss', 'KLD', 'DIV_REG', 'gen'):
+        assert pr.last_losses[k] == pytest.approx(losses[k], rel=3e-4, abs=1e-6), k
+    assert ret[0] == pytest.approx(metric, rel=5e-3, abs=2e-6)
+    # (D: its 0.3 M parameters all sit behind the ST-GCN encoder's ReLU / LeakyReLU stack, one flipped activation moves a
+    # larger share of its gradient than of G's 13 M -- at T = 136 there are four times as many candidates)
+    for tag, mod, lim in (('G', pr.s2ag_generator, 5e-3), ('D', pr.s2ag_discriminator, 1e-2)):
+        total, per = _grad_report(mod.named_parameters(), grads[tag])
+        worst = sorted(per.items(), key=lambda kv: -kv[1][1])[:3]
+        print(f'[full-size step {config}] {tag}: relative L2 error over all parameters {total:.2e}; worst tensors: ' +
+              ', '.join(f'{k} max {e:.1e} L2 {l:.1e}' for k, (e, l) in worst))
+        assert total < lim, (tag, total)
+        for k, (e, l) in per.items():
+            assert l < 5e-2 and e < 0.2, (tag, k, e, l)
+    for k, v in pr.s2ag_generator.state_dict().items():
+        if 'running_var' in k:
+            assert rel(v.cpu(), G[k]) < 3e-4, k
+    for k, v in pr.s2ag_discriminator.state_dict().items():
+        if 'running_var' in k:
+            assert rel(v.cpu(), D[k]) < 3e-4, k
+    assert ops.coop_gru_timeouts() == 0
+
+
+def test_conv1d_roofline_run_gradients_match_the_oracle_at_batch_256():
+    """BASELINE configs[3] at its own size (B = 256): WavEncoder + TextEncoderTCN forward + backward, train mode, dropout
+    on, against the oracle fed the product's masks -- outputs strictly, every parameter gradient (kink-tolerant criteria,
+    see above) -- in fp32 mode; bf16 mode has its own tests with its own tolerances (test_gpu_bf16.py)."""
+    from oracle import s2ag_oracle as O
+    from s2ag_testing import grad_err
+    from speech2affective_gestures_amd import noise, ops
+    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import TextEncoderTCN, WavEncoder
+    B, T = 256, 34
+    cfg = bench.make_cfg()
+    oc = O.ModelCfg()
+    sd = O.recipe_state_dict({**O._wav_encoder_shapes('wav.'),
+                              **O._text_encoder_shapes('txt.', bench.N_WORDS, 300, oc.hidden_size, oc.n_layers)}, 11)
+    wav, txt = WavEncoder().cuda().train(), TextEncoderTCN(cfg, bench.N_WORDS, 300, dropout=cfg.dropout_prob).cuda().train()
+    wav.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith('wav.')}, strict=True)
+    txt.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith('txt.')}, strict=True)
+    inp = O.recipe_inputs(B, T, 5, bench.N_WORDS, bench.N_SPK)
+    noise.manual_seed(31)
+    nz = torch.tensor([31, 0], dtype=torch.int64, device='cuda')
+    with noise.noise_pass('cuda'):
+        yw = wav(inp['in_audio'].cuda())
+        yt = txt(inp['in_text'].cuda())[0]
+    pin = {'txt.emb_drop': ops.dropout_mask(nz, txt.site, txt.drop.p, (B, T, 300)).cpu()}
+    for i, blk in enumerate(txt.tcn.network):
+        for j in (0, 1):
+            pin[f'txt.tcn.{i}.drop{j + 1}'] = ops.dropout_mask(nz, blk.sites[j], blk.p, (B, T, 300)).cpu().transpose(1, 2)
+    leaf = {k: (v.detach().clone().requires_grad_(True) if O.is_param(k) and '.net.' not in k else v.clone())
+            for k, v in sd.items()}
+    for k in list(leaf):
+        if '.net.0.' in k or '.net.4.' in k:
+            leaf[k] = leaf[k.replace('.net.0.', '.conv1.').replace('.net.4.', '.conv2.')]
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    rw = O.wav_encoder(leaf, 'wav.', inp['in_audio'], True)
+    rt = O.text_encoder_tcn(leaf, 'txt.', inp['in_text'], True, oc.dropout_prob, O.Noise(pin))
+    assert rel(yw.cpu(), rw) < 3e-4 and rel(yt.cpu(), rt) < 3e-4
+    g = torch.Generator().manual_seed(2)
+    dw, dt = torch.randn(rw.shape, generator=g), torch.randn(rt.shape, generator=g)
+    ((rw * dw).sum() + (rt * dt).sum()).backward()
+    ((yw * dw.cuda()).sum() + (yt * dt.cuda()).sum()).backward()
+    dead = ('feat_extractor.0.bias', 'feat_extractor.3.bias', 'feat_extractor.6.bias')      # a BatchNorm cancels them: true gradient 0
+    named = [('wav.' + k, p) for k, p in wav.named_parameters() if k not in dead] + \
+        [('txt.' + k, p) for k, p in txt.named_parameters()]
+    total, per = _grad_report(named, {k: leaf[k].grad for k, _ in named if '.net.' not in k})
+    print(f'[configs[3] B=256] relative L2 error over all parameters {total:.2e}; worst: ' +
+          ', '.join(f'{k} max {e:.1e} L2 {l:.1e}' for k, (e, l) in sorted(per.items(), key=lambda kv: -kv[1][1])[:3]))
+    assert total < 5e-3
+    for k, (e, l) in per.items():
+        assert l < 5e-2 and e < 0.2, (k, e, l)

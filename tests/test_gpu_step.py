@@ -643,3 +643,67 @@ def test_forward_pass_with_calculate_metrics_feeds_the_meters_and_evaluators(gol
     assert pr.evaluator.get_no_of_samples() == 1 and pr.evaluator_trimodal.get_no_of_samples() == 1
     # the returned metric is the plain step's: L1(out) - L1(out_trimodal)
     assert ret[0] == pytest.approx(meters[3].val - meters[0].val, rel=1e-3, abs=1e-6)
+
+
+@pytest.mark.parametrize('mode', ['graph', 'eager', 'eager-overflow'])
+def test_two_ranks_on_one_gpu_match_the_averaged_gradient_emulation(tmp_path, mode):
+    """The REAL data-parallel step with TWO ranks (processor_v2.py:167-172 is the reference's nn.DataParallel counterpart):
+    two processes share cuda:0 over gloo (RCCL refuses duplicate devices; same DataParallelContext / GradExchange code,
+    S2AG_DIST_BACKEND=gloo), different batches and noise seeds per rank, hidden 32, three steps.  Checked:
+      (i)   rank 1 starts from rank 0's weights (broadcast) and both ranks hold IDENTICAL weights after every step;
+      (ii)  the exchanged gradients equal, and the weights follow, a single-process emulation that sums the two batches'
+            gradients per optimizer and lets Adam consume sum / 2 (tests/s2ag_dist2_probe.py emu);
+      (iii) the touched-row merge of the embedding gradient ran on genuinely different id sets -- or, in the overflow
+            variant (row capacity B * 1), every rank took the dense all-reduce instead, with the same result."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), 's2ag_dist2_probe.py')
+    port = str(29900 + os.getpid() % 90)
+    flags = (['graph'] if mode == 'graph' else []) + (['overflow'] if mode.endswith('overflow') else [])
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                   S2AG_DIST_BACKEND='gloo', S2AG_FORCE_DIST='0')
+        procs.append(subprocess.Popen([sys.executable, probe, 'rank', str(tmp_path / f'rank{r}.pt')] + flags, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-4000:]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, probe, 'emu', str(tmp_path / 'emu.pt')] + flags, env=dict(env, S2AG_FORCE_DIST='0'),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    r0, r1, emu = (torch.load(tmp_path / n, weights_only=False) for n in ('rank0.pt', 'rank1.pt', 'emu.pt'))
+    assert r0['timeouts'] == r1['timeouts'] == emu['timeouts'] == 0
+    # (i) broadcast + replica equality, bit for bit
+    for net in ('G', 'D'):
+        for k, v in r0['start'][net].items():
+            assert torch.equal(v, r1['start'][net][k]) and torch.equal(v, emu['start'][net][k]), k
+    for s in range(3):
+        for net in ('G', 'D'):
+            assert torch.equal(r0['steps'][s]['g'][net], r1['steps'][s]['g'][net]), (s, net)
+            for k, v in r0['steps'][s]['w'][net].items():
+                assert torch.equal(v, r1['steps'][s]['w'][net][k]), (s, k)
+    # (iii) the ranks' batches touch different rows; sparse path unless the capacity was made too small
+    assert all(set(a) != set(b) and (set(a) & set(b)) for a, b in zip(r0['ids'], r1['ids']))
+    if mode.endswith('overflow'):
+        assert r0['row_cap'] == 6 and r0['dense_fallbacks'] == r1['dense_fallbacks'] == 3
+    else:
+        assert r0['dense_fallbacks'] == r1['dense_fallbacks'] == 0
+    # per step: id-count MAX, D arena, bucket A, bucket B, rows; graph mode: + 3 warm-up steps and the precheck at capture
+    assert r0['collectives'] == r1['collectives'] == (6 * 5 + 1 if mode == 'graph' else 3 * 5)
+    # (ii) the summed gradients themselves -- strictly where both sides start from the same weights (eager: step 0)
+    nsteps0 = 3 if mode == 'graph' else 0               # Adam steps before the first recorded one
+    for net in ('G', 'D'):
+        a, e = r0['steps'][0]['g'][net].double(), emu['steps'][0]['g'][net].double()
+        tol = 1e-5 if nsteps0 == 0 else 2e-2             # (after warm-up steps the weights already differ at Adam's noise level)
+        assert float((a - e).abs().max()) <= tol * float(e.abs().max()), (net, float((a - e).abs().max()), float(e.abs().max()))
+        n_emb = 64 * 300
+        if net == 'G':      # the embedding block on its own scale (it is the touched-row exchange's)
+            assert float((a[:n_emb] - e[:n_emb]).abs().max()) <= tol * float(e[:n_emb].abs().max())
+    for s in range(3):      # ... and the weights after every Adam step (see adam_close)
+        for net, lr in (('G', 5e-4), ('D', 1e-4)):
+            for k, v in r0['steps'][s]['w'][net].items():
+                if not is_noise_driven_after_adam(k):
+                    ok, info = adam_close(v, emu['steps'][s]['w'][net][k], lr, nsteps0 + s + 1)
+                    assert ok, (s, k, info)

@@ -29,7 +29,7 @@ def per_kernel(path, counter):
     return out
 
 
-def main(fetch_db, write_db, fetch_cal, write_cal):
+def main(fetch_db, write_db, fetch_cal, write_cal, per_iteration=0):
     GiB = float(1 << 30)
     fc, wc = per_kernel(fetch_cal, 'FETCH_SIZE'), per_kernel(write_cal, 'WRITE_SIZE')
     unit = 1024.0                                   # both counters report KB
@@ -53,10 +53,18 @@ def main(fetch_db, write_db, fetch_cal, write_cal):
         kernels[k] = dict(launches=(fk or wk)['launches'], fetch_size_kb_per_launch=rd / unit,
                           write_size_kb_per_launch=wr / unit, read_factor=fr, write_factor=fw,
                           bytes_per_launch=rd * fr + wr * fw)
-    print(json.dumps(dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager step at B=128, '
-                                 'T=34) + calibration on 1 GiB known patterns (tools/pmc_calib.py)',
-                          calibration_bytes_per_counted_byte=cal, kernels=kernels), indent=1))
+    out = dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager runs) + calibration on 1 GiB '
+                      'known patterns (tools/pmc_calib.py)', calibration_bytes_per_counted_byte=cal, kernels=kernels)
+    if per_iteration:       # every kernel of `per_iteration` identical iterations: HBM bytes of ONE iteration
+        out['iterations'] = per_iteration
+        out['bytes_per_iteration'] = sum(k['bytes_per_launch'] * k['launches'] for k in kernels.values()) / per_iteration
+        out['read_bytes_per_iteration'] = sum(k['fetch_size_kb_per_launch'] * 1024.0 * k['read_factor'] * k['launches']
+                                              for k in kernels.values()) / per_iteration
+        out['write_bytes_per_iteration'] = sum(k['write_size_kb_per_launch'] * 1024.0 * k['write_factor'] * k['launches']
+                                               for k in kernels.values()) / per_iteration
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:5])
+    n = int(sys.argv[sys.argv.index('--per-iteration') + 1]) if '--per-iteration' in sys.argv else 0
+    main(*sys.argv[1:5], per_iteration=n)
