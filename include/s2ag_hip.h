@@ -470,21 +470,47 @@ int s2ag_bf16_conv_c1_rows(const s2ag_conv_geom* g);      /* statistics partial 
  * the consumers of dy_i form dy_i = A dz_i + C y_i + B in their loaders (coefficients from s2ag_wave_bn_bwd_fold).
  * Shapes: (Cin, Cout) in {(16, 32), (32, 64), (64, 32)}, 15 taps, stride 6, no padding; x / y channels-last bf16. */
 int s2ag_wave_fwd_rows(int N, int Lout, int Cin, int Cout);      /* statistics partial rows of s2ag_wave_conv_fwd */
+/* the fold of a conv's statistics partials into the coefficients of the BatchNorm behind it (what s2ag_bn_fold does as a
+ * launch of its own, native_batch_norm's running-estimate update included), done by the workgroup that finishes last, in
+ * two levels (groups of 16 partial rows).  With R = the partial rows of the launch: `ticket` points at 1 + ceil(R / 16)
+ * zero words (left zero) and the statistics buffer holds (2, R + ceil(R / 16), C) doubles. */
+typedef struct s2ag_bn_fold_args {
+    int* ticket;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    long long* num_batches_tracked;   /* nullable */
+    float eps, momentum;
+    int repeat;                       /* running-estimate updates (>= 1), as s2ag_bn_fold */
+    float* scale;                     /* out: per-channel scale, shift, mean, invstd */
+    float* shift;
+    float* mean;
+    float* invstd;
+} s2ag_bn_fold_args;
 /* w_packed: (Cout, KP) bf16, k = tap * Cin + ci, zero beyond 15 Cin (bf16.WeightPack 'fwd' layout of a reference weight);
- * stats: (2, rows, Cout) doubles or NULL; out_f32: y is fp32 (the last conv). */
+ * stats: (2, rows, Cout) doubles or NULL; fold (nullable): fold them in this launch; out_f32: y is fp32 (the last conv). */
 int s2ag_wave_conv_fwd(const void* x, const float* in_scale, const float* in_shift, float slope, const void* w_packed, int KP,
-                       const float* bias, void* y, int out_f32, double* stats, int N, int Lin, int Lout, int Cin, int Cout,
-                       void* stream);
+                       const float* bias, void* y, int out_f32, double* stats, const s2ag_bn_fold_args* fold, int N, int Lin,
+                       int Lout, int Cin, int Cout, void* stream);
+/* conv1 (Conv1d(1, 16, 15, stride 5, padding 1600), net/multimodal_context_net_v2.py:18) with bf16 output, ONE statistics
+ * row per block and the same in-launch fold; partials: (2, s2ag_wave_conv1_fwd_rows, 16) doubles */
+int s2ag_wave_conv1_fwd_rows(const s2ag_conv_geom* g);
+int s2ag_wave_conv1_fwd(const float* x, const float* w, const float* bias, void* y, const s2ag_conv_geom* g, double* partials,
+                        const s2ag_bn_fold_args* fold, void* stream);
 
 /* data gradient of conv i (poly-phase) + the backward of BatchNorm i-1 / LeakyReLU on its result: reads dy_i = ca dz + cc y
  * + cb (or the fp32 output gradient when g_f32: the last conv), writes dz_{i-1} = da_{i-1} * leaky'(p_scale y_prev + p_shift)
  * and the partial column sums (2, rows, Cin) of dz_{i-1} and dz_{i-1} * xhat_{i-1}.  w_phases: (6, Cin, 3, CPO) bf16 =
- * W[co][ci][r + 6 i] (bf16.WeightPack 'phases' layout). */
+ * W[co][ci][r + 6 i] (bf16.WeightPack 'phases' layout).  ticket != NULL (a zero word that is left zero): the workgroup that
+ * finishes last also does the work of s2ag_wave_bn_bwd_fold (dgamma / dbeta += ..., out_ca / out_cb / out_cc): 1 + ceil(R / 16)
+ * ticket words and (2, R + ceil(R / 16), Cin) doubles of `stats` as for s2ag_bn_fold_args. */
 int s2ag_wave_dgrad_rows(int N, int Lin, int Cin);
 int s2ag_wave_conv_dgrad(const void* dz, const void* y, const float* ca, const float* cb, const float* cc, int g_f32,
                          const void* w_phases, int CPO, const void* y_prev, const float* p_scale, const float* p_shift,
-                         const float* p_mean, const float* p_invstd, float slope, void* dz_prev, double* stats, int N, int Lin,
-                         int Lout, int Cin, int Cout, void* stream);
+                         const float* p_mean, const float* p_invstd, float slope, void* dz_prev, double* stats, int* ticket,
+                         const float* p_gamma, float* dgamma, float* dbeta, float* out_ca, float* out_cb, float* out_cc, int N,
+                         int Lin, int Lout, int Cin, int Cout, void* stream);
 /* weight (+ bias) gradient of conv i: dw (Cout, Cin, 15) += sum dy_i a_{i-1}, a_{i-1} = leaky(p_scale y_prev + p_shift)
  * recomputed in the loader; partials: s2ag_wave_wgrad_blocks * Cout * 15 * Cin floats, partials_b: blocks * Cout. */
 int s2ag_wave_wgrad_blocks(int N, int Lout, int Cin, int Cout);
@@ -495,9 +521,11 @@ int s2ag_wave_conv_wgrad(const void* dz, const void* y, const float* ca, const f
  * coefficients of dy = ca dz + cc y + cb for the BatchNorm over `rows` rows */
 int s2ag_wave_bn_bwd_fold(const double* partials, int partial_rows, int C, long long rows, const float* gamma, const float* mean,
                           const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb, float* cc, void* stream);
-/* conv1's weight gradient (net/multimodal_context_net_v2.py:18) from dz_1 and y_1 (both bf16 (N, Lout, 16)) */
+/* conv1's weight gradient (net/multimodal_context_net_v2.py:18) from dz_1 and y_1 (both bf16 (N, Lout, 16)); partials:
+ * s2ag_wave_conv1_wgrad_blocks * 256 floats (per-block sums, folded in order into dw / db: no atomics) */
+int s2ag_wave_conv1_wgrad_blocks(const s2ag_conv_geom* g);
 int s2ag_wave_conv1_wgrad(const void* dz, const void* y1, const float* ca, const float* cb, const float* cc, const float* x,
-                          float* dw, float* db, const s2ag_conv_geom* g, void* stream);
+                          float* partials, float* dw, float* db, const s2ag_conv_geom* g, void* stream);
 
 /* ---- clip-resident TemporalConvNet in bf16 mode (csrc/tcn_fused.hip) ----------------------------------------------
  * Replaces the whole stack of TemporalBlocks of net/tcn.py:16-64 (conv1 -> chomp -> ReLU -> dropout -> conv2 -> chomp ->

@@ -52,6 +52,12 @@ class BF16Wgrad(C.Structure):     # s2ag_bf16_wgrad_args
                 ('ks_out', ci)]
 
 
+class BnFoldArgs(C.Structure):    # s2ag_bn_fold_args
+    _fields_ = [('ticket', vp), ('gamma', vp), ('beta', vp), ('running_mean', vp), ('running_var', vp),
+                ('num_batches_tracked', vp), ('eps', cf), ('momentum', cf), ('repeat', ci), ('scale', vp), ('shift', vp),
+                ('mean', vp), ('invstd', vp)]
+
+
 class BF16PackJob(C.Structure):   # s2ag_bf16_pack_job
     _fields_ = [('src', vp), ('dst', vp), ('rows', ci), ('taps', ci), ('Cp', ci), ('cols', ci), ('tap0', ci),
                 ('tap_step', ci), ('src_taps', ci), ('s_o', cll), ('s_t', ci), ('s_c', ci), ('flat_cin', ci)]
@@ -154,13 +160,16 @@ SIGNATURES = {
     's2ag_bf16_conv_c1_wgrad': [vp, vp, vp, vp, PG, vp],
     's2ag_bf16_conv_c1_rows': [PG],
     's2ag_wave_fwd_rows': [ci, ci, ci, ci],
-    's2ag_wave_conv_fwd': [vp, vp, vp, cf, vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp],
+    's2ag_wave_conv_fwd': [vp, vp, vp, cf, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp],
+    's2ag_wave_conv1_fwd_rows': [PG],
+    's2ag_wave_conv1_fwd': [vp, vp, vp, vp, PG, vp, vp, vp],
     's2ag_wave_dgrad_rows': [ci, ci, ci],
-    's2ag_wave_conv_dgrad': [vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, ci, ci, ci, vp],
+    's2ag_wave_conv_dgrad': [vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     's2ag_wave_wgrad_blocks': [ci, ci, ci, ci],
     's2ag_wave_conv_wgrad': [vp, vp, vp, vp, vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     's2ag_wave_bn_bwd_fold': [vp, ci, ci, cll, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    's2ag_wave_conv1_wgrad': [vp, vp, vp, vp, vp, vp, vp, vp, PG, vp],
+    's2ag_wave_conv1_wgrad_blocks': [PG],
+    's2ag_wave_conv1_wgrad': [vp, vp, vp, vp, vp, vp, vp, vp, vp, PG, vp],
     's2ag_bf16_tcn_clips_per_block': [ci, ci, ci],
     's2ag_bf16_tcn_pack_elems': [ci],
     's2ag_bf16_tcn_sign_bytes': [ci, ci],

@@ -770,41 +770,42 @@ class _WaveFused16(torch.autograd.Function):
         for _ in _WAVE_LAYERS:
             lens.append((lens[-1] - 15) // 6 + 1)
         geom1 = L.ConvGeom(N, Lin0, L1, 1, 16, 15, 5, pad1, 1, 1, 16, 0)
-        y1 = torch.empty(N, L1, 16, dtype=torch.bfloat16, device=dev)
-        rows = lib.s2ag_bf16_conv_c1_rows(C.byref(geom1))
-        part = torch.empty(2 * rows * 16, dtype=torch.float64, device=dev)
-        got = C.c_int(0)
-        L.check(lib.s2ag_bf16_conv_c1_fwd(_p(wav), _p(w1), _p(b1), _p(y1), C.byref(geom1), _p(part), C.byref(got), _s()),
-                'bf16_conv_c1_fwd')
-        ys, coefs = [y1], []
         gb = ((g1, e1), (g2, e2), (g3, e3))
+        keep = []                                                   # ctypes structs must outlive their launches
 
-        def fold(part, prow, rows_total, k):
+        def fold_args(k, prow):
+            """BatchNorm k's fold, done by the producing conv's last workgroup: -> (coef (4, C), s2ag_bn_fold_args)"""
             bn, (gamma, beta) = bns[k], gb[k]
-            cols = gamma.numel()
-            coef = torch.empty(4, cols, dtype=torch.float32, device=dev)
-            L.check(lib.s2ag_bn_fold(_p(part), int(prow), int(rows_total), cols, None, cols, _p(gamma), _p(beta),
-                                     _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), float(bn.eps),
-                                     float(bn.momentum), int(ops._BN_REPEAT[0]), _p(coef[0]), _p(coef[1]), _p(coef[2]),
-                                     _p(coef[3]), _s()), 'bn_fold')
-            return coef
-        coefs.append(fold(part, got.value, N * L1, 0))
+            coef = torch.empty(4, gamma.numel(), dtype=torch.float32, device=dev)
+            fa = L.BnFoldArgs(ops._tickets(dev, 1 + (prow + 15) // 16), _p(gamma), _p(beta), _p(bn.running_mean), _p(bn.running_var),
+                              _p(bn.num_batches_tracked), float(bn.eps), float(bn.momentum), int(ops._BN_REPEAT[0]),
+                              _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]))
+            keep.append(fa)
+            return coef, fa
+        y1 = torch.empty(N, L1, 16, dtype=torch.bfloat16, device=dev)
+        prow = lib.s2ag_wave_conv1_fwd_rows(C.byref(geom1))
+        part = torch.empty(2 * (prow + (prow + 15) // 16) * 16, dtype=torch.float64, device=dev)
+        coef, fa = fold_args(0, prow)
+        L.check(lib.s2ag_wave_conv1_fwd(_p(wav), _p(w1), _p(b1), _p(y1), C.byref(geom1), _p(part), C.byref(fa), _s()),
+                'wave_conv1_fwd')
+        ys, coefs = [y1], [coef]
         names = ('c3', 'c6', 'c9')
-        ws, bs = (w2, w3, w4), (b2, b3, b4)
+        bs = (b2, b3, b4)
         for k, (ci, co) in enumerate(_WAVE_LAYERS):
             last = k == 2
             w16 = pack.get(names[k], 'fwd')                         # (co, 1, KP)
             Lin, Lout = lens[k], lens[k + 1]
             y = torch.empty(N, Lout, co, dtype=torch.float32 if last else torch.bfloat16, device=dev)
-            st = None
+            st, fa, coef = None, None, None
             if not last:
                 prow = lib.s2ag_wave_fwd_rows(N, Lout, ci, co)
-                st = torch.empty(2 * prow * co, dtype=torch.float64, device=dev)
+                st = torch.empty(2 * (prow + (prow + 15) // 16) * co, dtype=torch.float64, device=dev)
+                coef, fa = fold_args(k + 1, prow)
             L.check(lib.s2ag_wave_conv_fwd(_p(ys[-1]), _p(coefs[-1][0]), _p(coefs[-1][1]), float(slope), _p(w16),
-                                           int(w16.shape[2]), _p(bs[k]), _p(y), int(last), _p(st), N, Lin, Lout, ci, co, _s()),
-                    'wave_conv_fwd')
+                                           int(w16.shape[2]), _p(bs[k]), _p(y), int(last), _p(st),
+                                           C.byref(fa) if fa is not None else None, N, Lin, Lout, ci, co, _s()), 'wave_conv_fwd')
             if not last:
-                coefs.append(fold(st, prow, N * Lout, k + 1))
+                coefs.append(coef)
                 ys.append(y)
         ctx.pack, ctx.slope, ctx.lens, ctx.params, ctx.pad1 = pack, float(slope), lens, params, pad1
         ctx.save_for_backward(wav, *ys, *coefs)
@@ -845,25 +846,33 @@ class _WaveFused16(torch.autograd.Function):
             if wslot is not None:
                 nb = lib.s2ag_wave_wgrad_blocks(N, Lout, ci, co)
                 part = torch.empty(nb * co * 15 * ci + nb * co, dtype=torch.float32, device=dev)
-                L.check(lib.s2ag_wave_conv_wgrad(_p(dz), _p(yy), _p(ca), _p(cb), _p(cc), int(g_f32), _p(yp), _p(cp[0]), _p(cp[1]),
-                                                 slope, _p(part), _p(part[nb * co * 15 * ci:]), _p(wslot), _p(bslot), N, Lin, Lout,
-                                                 ci, co, _s()), 'wave_conv_wgrad')
+
+                def launch(dz=dz, yy=yy, ca=ca, cb=cb, cc=cc, g_f32=g_f32, yp=yp, cp=cp, part=part, nb=nb, wslot=wslot,
+                           bslot=bslot, Lin=Lin, Lout=Lout, ci=ci, co=co):
+                    L.check(lib.s2ag_wave_conv_wgrad(_p(dz), _p(yy), _p(ca), _p(cb), _p(cc), int(g_f32), _p(yp), _p(cp[0]),
+                                                     _p(cp[1]), slope, _p(part), _p(part[nb * co * 15 * ci:]), _p(wslot),
+                                                     _p(bslot), N, Lin, Lout, ci, co, _s()), 'wave_conv_wgrad')
+                # a leaf of the backward graph: the two big ones run beside the data-gradient chain when the trainer armed
+                # the weight-gradient stream (ops.run_wgrad); the trainer joins before the optimizer
+                ops.run_wgrad(launch, keep=(dz, yy, yp, cp, part, cabc), flops=2.0 * N * Lout * co * ci * 15)
             wph = pack.get(names[k], 'phases')                      # (6, ci, 3, CPO)
             prow = lib.s2ag_wave_dgrad_rows(N, Lin, ci)
-            st = torch.empty(2 * prow * ci, dtype=torch.float64, device=dev)
+            st = torch.empty(2 * (prow + (prow + 15) // 16) * ci, dtype=torch.float64, device=dev)
             dzp = torch.empty(N, Lin, ci, dtype=torch.bfloat16, device=dev)
-            L.check(lib.s2ag_wave_conv_dgrad(_p(dz), _p(yy), _p(ca), _p(cb), _p(cc), int(g_f32), _p(wph), int(wph.shape[3]),
-                                             _p(yp), _p(cp[0]), _p(cp[1]), _p(cp[2]), _p(cp[3]), slope, _p(dzp), _p(st), N, Lin,
-                                             Lout, ci, co, _s()), 'wave_conv_dgrad')
             cabc = torch.empty(3, ci, dtype=torch.float32, device=dev)
-            L.check(lib.s2ag_wave_bn_bwd_fold(_p(st), prow, ci, N * Lin, _p(ctx.params[gidx[k]]), _p(cp[2]), _p(cp[3]),
-                                              _p(slot(gidx[k])), _p(slot(gidx[k] + 1)), _p(cabc[0]), _p(cabc[1]), _p(cabc[2]),
-                                              _s()), 'wave_bn_bwd_fold')
+            # the workgroup that finishes last folds the partial sums: gamma / beta gradients + the coefficients of dy_{k}
+            L.check(lib.s2ag_wave_conv_dgrad(_p(dz), _p(yy), _p(ca), _p(cb), _p(cc), int(g_f32), _p(wph), int(wph.shape[3]),
+                                             _p(yp), _p(cp[0]), _p(cp[1]), _p(cp[2]), _p(cp[3]), slope, _p(dzp), _p(st),
+                                             ops._tickets(dev, 1 + (prow + 15) // 16), _p(ctx.params[gidx[k]]), _p(slot(gidx[k])),
+                                             _p(slot(gidx[k] + 1)),
+                                             _p(cabc[0]), _p(cabc[1]), _p(cabc[2]), N, Lin, Lout, ci, co, _s()),
+                    'wave_conv_dgrad')
             dz, yy = dzp, yp
         wslot, bslot = slot(0), slot(1)
         if wslot is not None:
             geom1 = L.ConvGeom(N, wav.shape[1], lens[0], 1, 16, 15, 5, ctx.pad1, 1, 1, 16, 0)
-            L.check(lib.s2ag_wave_conv1_wgrad(_p(dz), _p(yy), _p(cabc[0]), _p(cabc[1]), _p(cabc[2]), _p(wav), _p(wslot),
+            part = torch.empty(lib.s2ag_wave_conv1_wgrad_blocks(C.byref(geom1)) * 256, dtype=torch.float32, device=dev)
+            L.check(lib.s2ag_wave_conv1_wgrad(_p(dz), _p(yy), _p(cabc[0]), _p(cabc[1]), _p(cabc[2]), _p(wav), _p(part), _p(wslot),
                                               _p(bslot), C.byref(geom1), _s()), 'wave_conv1_wgrad')
         return (None, None, None, None) + tuple(grads)
 

@@ -16,6 +16,7 @@
 //     block's 16 x KS (+16) sums to dw / db with contiguous atomics; blocks loop over several runs to keep that count low.
 // With Cin == 1 the reference (Cout, 1, k) and tap-major (Cout, k, 1) weight layouts coincide.
 #include "s2ag_common.h"
+#include "bn_fold_inl.h"
 
 namespace {
 using namespace s2ag;
@@ -40,6 +41,8 @@ struct C1P {
     const float* ca;
     const float* cb;
     const float* cc;
+    float* part;                  // wgrad, nullable: (gridDim.x, CO * KS + CO) per-block sums instead of atomics into dw / db
+    s2ag_fold::FwdFold fold;      // fwd: fold.ticket != null: ONE partial row per block, folded by the block that finishes last
 };
 
 __device__ __forceinline__ unsigned c1_bf16_rn(float v) {
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_fwd_k(const C1P p) {
     if (p.stats) {
         // one partial row per wave for all the block's runs; lanes that share a channel quad differ in lane bits 2..5
         const size_t R = (size_t)gridDim.x * 4, r = (size_t)blockIdx.x * 4 + wave;
+        __shared__ double wred[4][2][CO];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -138,8 +142,26 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_fwd_k(const C1P p) {
                 s2[c] += __shfl_xor(s2[c], m, 64);
             }
             if (lane < 4) {
-                p.stats[r * CO + q * 4 + c] = s1[c];
-                p.stats[(R + r) * CO + q * 4 + c] = s2[c];
+                if (p.fold.ticket) {
+                    wred[wave][0][q * 4 + c] = s1[c];
+                    wred[wave][1][q * 4 + c] = s2[c];
+                } else {
+                    p.stats[r * CO + q * 4 + c] = s1[c];
+                    p.stats[(R + r) * CO + q * 4 + c] = s2[c];
+                }
+            }
+        }
+        if (p.fold.ticket) {        // (2, gridDim.x, CO): one row per block, published for the block that finishes last
+            __syncthreads();
+            if (tid < 2 * CO) {
+                const int which = tid / CO, c = tid - which * CO;
+                s2ag_fold::st_agent(p.stats + ((size_t)which * gridDim.x + blockIdx.x) * CO + c,
+                                    (wred[0][which][c] + wred[1][which][c]) + (wred[2][which][c] + wred[3][which][c]));
+            }
+            if (s2ag_fold::two_level_done(p.stats, gridDim.x, CO, p.fold.ticket)) {
+                __shared__ double fred[2][256];
+                s2ag_fold::bn_fwd_fold_body(p.stats + (size_t)2 * gridDim.x * CO, s2ag_fold::fold_groups(gridDim.x), CO, p.fold,
+                                            fred);
             }
         }
     }
@@ -172,6 +194,25 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
     const int seg_len = (C1_RUN - 1) * p.stride + KS;
     float sr[C1_SEG_REGS];
     if ((int)blockIdx.x < p.total_runs) fetch_segment(p, sr, blockIdx.x, seg_len);
+    // XF: the raw rows (dz, y1) of the NEXT run are in flight while the current run is multiplied (a block is a chain of
+    // runs at two blocks per CU: with the loads of a run requested when the run begins it was a chain of memory round trips)
+    uint2 nz[XF ? C1_RUN / 64 : 1], ny[XF ? C1_RUN / 64 : 1];
+    auto fetch_rows = [&](int run) {
+        if constexpr (XF) {
+            const int n = run / p.runs_per_clip, l0 = (run - n * p.runs_per_clip) * C1_RUN;
+#pragma unroll
+            for (int i = 0; i < C1_RUN / 64; ++i) {
+                const int l = l0 + i * 64 + fr;
+                nz[i] = ny[i] = make_uint2(0u, 0u);
+                if (run < p.total_runs && l < p.Lout) {
+                    const long long off = ((long long)n * p.Lout + l) * p.ldy + q * 4;
+                    nz[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.y) + off);
+                    ny[i] = *reinterpret_cast<const uint2*>(p.y1 + off);
+                }
+            }
+        }
+    };
+    fetch_rows(blockIdx.x);
     for (int run = blockIdx.x; run < p.total_runs; run += gridDim.x) {
         const int n = run / p.runs_per_clip, l0 = (run - n * p.runs_per_clip) * C1_RUN;
         // all of the run's output-gradient rows of this thread are requested up front (one round trip per run, not four)
@@ -181,18 +222,17 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
             const int l = l0 + i * 64 + fr;
             gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (l < p.Lout) {
-                if (BF) {
+                if (XF) {
+                    const uint2 h = nz[i], v = ny[i];
+                    gq[i].x = fmaf(xa[0], __uint_as_float(h.x << 16), fmaf(xc[0], __uint_as_float(v.x << 16), xb[0]));
+                    gq[i].y = fmaf(xa[1], __uint_as_float(h.x & 0xffff0000u), fmaf(xc[1], __uint_as_float(v.x & 0xffff0000u), xb[1]));
+                    gq[i].z = fmaf(xa[2], __uint_as_float(h.y << 16), fmaf(xc[2], __uint_as_float(v.y << 16), xb[2]));
+                    gq[i].w = fmaf(xa[3], __uint_as_float(h.y & 0xffff0000u), fmaf(xc[3], __uint_as_float(v.y & 0xffff0000u), xb[3]));
+                } else if (BF) {
                     const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.y) +
                                                                     ((long long)n * p.Lout + l) * p.ldy + q * 4);
                     gq[i] = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u),
                                         __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
-                    if (XF) {
-                        const uint2 v = *reinterpret_cast<const uint2*>(p.y1 + ((long long)n * p.Lout + l) * p.ldy + q * 4);
-                        gq[i].x = fmaf(xa[0], gq[i].x, fmaf(xc[0], __uint_as_float(v.x << 16), xb[0]));
-                        gq[i].y = fmaf(xa[1], gq[i].y, fmaf(xc[1], __uint_as_float(v.x & 0xffff0000u), xb[1]));
-                        gq[i].z = fmaf(xa[2], gq[i].z, fmaf(xc[2], __uint_as_float(v.y << 16), xb[2]));
-                        gq[i].w = fmaf(xa[3], gq[i].w, fmaf(xc[3], __uint_as_float(v.y & 0xffff0000u), xb[3]));
-                    }
                 } else {
                     gq[i] = *reinterpret_cast<const float4*>(p.y + ((long long)n * p.Lout + l) * p.ldy + q * 4);
                 }
@@ -202,6 +242,7 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
         store_segment(seg, sr, seg_len);
         __syncthreads();
         if (run + (int)gridDim.x < p.total_runs) fetch_segment(p, sr, run + gridDim.x, seg_len);
+        fetch_rows(run + gridDim.x);
 #pragma unroll
         for (int i = 0; i < C1_RUN / 64; ++i) {
             const int f = i * 64 + fr, l = l0 + f;
@@ -245,10 +286,41 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
     __syncthreads();
     for (int i = tid; i < CO * KS + CO; i += C1_NT) {
         const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-        if (i < CO * KS)
+        if (p.part)             // 1 024 blocks x 256 atomics on the same 256 addresses were most of this kernel's time
+            p.part[(size_t)blockIdx.x * (CO * KS + CO) + i] = v;
+        else if (i < CO * KS)
             atomicAdd(p.dw + i, v);
         else if (p.db)
             atomicAdd(p.db + (i - CO * KS), v);
+    }
+}
+
+// dw[i] += sum_b part[b][i] (i < CO * KS), db[c] += sum_b part[b][CO * KS + c]: one block, 256 = CO * KS + CO threads,
+// 16 rows in flight per thread
+__global__ __launch_bounds__(256) void conv_c1_wgrad_fold_k(const float* __restrict__ part, int nblocks, float* __restrict__ dw,
+                                                           float* __restrict__ db, int n_w, int n_all) {
+    __shared__ float red[4][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float s = 0.f;
+    if (i < n_all) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        int b = grp;
+        for (; b + 60 < nblocks; b += 64) {          // 16 rows in flight per thread
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = part[(size_t)(b + 4 * j) * n_all + i];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j & 3] += v[j];
+        }
+        for (; b < nblocks; b += 4) a[0] += part[(size_t)b * n_all + i];
+        s = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    red[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && i < n_all) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (i < n_w) dw[i] += v;
+        else if (db) db[i - n_w] += v;
     }
 }
 
@@ -332,21 +404,60 @@ extern "C" int s2ag_bf16_conv_c1_wgrad(const void* gy, const float* x, float* dw
 }
 
 // conv1's weight gradient with the BatchNorm backward folded into the loader (see wave_fused.hip): gy = ca dz + cc y1 + cb
+extern "C" int s2ag_wave_conv1_wgrad_blocks(const s2ag_conv_geom* g) {
+    if (!g) return S2AG_E_BADARG;
+    const int runs = g->N * cdiv(g->Lout, C1_RUN);
+    return runs < 1024 ? runs : 1024;
+}
+
 extern "C" int s2ag_wave_conv1_wgrad(const void* dz, const void* y1, const float* ca, const float* cb, const float* cc,
-                                     const float* x, float* dw, float* db, const s2ag_conv_geom* g, void* stream) {
-    if (!dz || !y1 || !ca || !cb || !cc || !x || !dw || !g) return S2AG_E_BADARG;
+                                     const float* x, float* partials, float* dw, float* db, const s2ag_conv_geom* g,
+                                     void* stream) {
+    if (!dz || !y1 || !ca || !cb || !cc || !x || !partials || !dw || !g) return S2AG_E_BADARG;
     if (!c1_shape_ok(g->Cin, g->Cout, g->ksize, g->dil, g->ldx, g->ldy, g->stride) || (reinterpret_cast<uintptr_t>(dz) & 7) ||
         (reinterpret_cast<uintptr_t>(y1) & 7))
         return S2AG_E_UNSUPPORTED;
     C1P p{};
     p.x = x; p.y = static_cast<float*>(const_cast<void*>(dz)); p.dw = dw; p.db = db;
-    p.y1 = static_cast<const unsigned short*>(y1); p.ca = ca; p.cb = cb; p.cc = cc;
+    p.y1 = static_cast<const unsigned short*>(y1); p.ca = ca; p.cb = cb; p.cc = cc; p.part = partials;
     p.N = g->N; p.Lin = g->Lin; p.Lout = g->Lout; p.stride = g->stride; p.pad = g->pad; p.ldx = g->ldx; p.ldy = g->ldy;
     p.runs_per_clip = cdiv(g->Lout, C1_RUN);
     p.total_runs = g->N * p.runs_per_clip;
     const int blocks = p.total_runs < 1024 ? p.total_runs : 1024;
     hipLaunchKernelGGL((conv_c1_wgrad_k<16, 15, true, true>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(g->stride),
                        (hipStream_t)stream, p);
+    const int n_w = 16 * 15, n_all = n_w + 16;
+    hipLaunchKernelGGL(conv_c1_wgrad_fold_k, dim3(cdiv(n_all, 64)), dim3(256), 0, (hipStream_t)stream, partials, blocks, dw, db,
+                       n_w, n_all);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+// conv1 forward of the fused wave encoder: bf16 output + ONE statistics row per block, folded into the BatchNorm
+// coefficients by the block that finishes last (no s2ag_bn_fold launch).  partials: (2, s2ag_wave_conv1_fwd_rows, 16) doubles.
+extern "C" int s2ag_wave_conv1_fwd_rows(const s2ag_conv_geom* g) {
+    if (!g) return S2AG_E_BADARG;
+    const int runs = g->N * cdiv(g->Lout, C1_RUN);
+    return runs < 1024 ? runs : 1024;
+}
+
+extern "C" int s2ag_wave_conv1_fwd(const float* x, const float* w, const float* bias, void* y, const s2ag_conv_geom* g,
+                                   double* partials, const s2ag_bn_fold_args* fold, void* stream) {
+    if (!x || !w || !y || !g || !partials || !fold || !fold->ticket || !fold->gamma || !fold->beta || !fold->running_mean ||
+        !fold->running_var || !fold->scale || !fold->shift || !fold->mean || !fold->invstd || fold->repeat < 1)
+        return S2AG_E_BADARG;
+    if (!c1_shape_ok(g->Cin, g->Cout, g->ksize, g->dil, g->ldx, g->ldy, g->stride) || (reinterpret_cast<uintptr_t>(y) & 7))
+        return S2AG_E_UNSUPPORTED;
+    C1P p{};
+    p.x = x; p.w = w; p.bias = bias; p.y = static_cast<float*>(y); p.stats = partials;
+    p.N = g->N; p.Lin = g->Lin; p.Lout = g->Lout; p.stride = g->stride; p.pad = g->pad; p.ldx = g->ldx; p.ldy = g->ldy;
+    p.runs_per_clip = cdiv(g->Lout, C1_RUN);
+    p.total_runs = g->N * p.runs_per_clip;
+    p.fold = s2ag_fold::FwdFold{fold->ticket, fold->gamma, fold->beta, fold->running_mean, fold->running_var,
+                                fold->num_batches_tracked, fold->eps, fold->momentum, fold->repeat, (long long)g->N * g->Lout,
+                                fold->scale, fold->shift, fold->mean, fold->invstd};
+    const int blocks = p.total_runs < 1024 ? p.total_runs : 1024;
+    hipLaunchKernelGGL((conv_c1_fwd_k<16, 15, true>), dim3(blocks), dim3(C1_NT), c1_seg_bytes(g->stride), (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

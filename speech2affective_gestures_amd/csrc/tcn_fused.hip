@@ -35,7 +35,7 @@ constexpr int NCT = CP / 16;            // 16-channel tiles of the output
 constexpr int KT_TAP = CP / 32;         // K tiles per tap
 constexpr int NKT = 2 * KT_TAP;         // K tiles per conv (2 taps)
 constexpr int PITCH = 328;              // LDS row pitch in bf16 (656 B)
-constexpr int MT = 5;                   // 16-row tiles per workgroup: up to 80 rows
+constexpr int MT_MAX = 5;               // 16-row tiles per workgroup: up to 80 rows (the kernels are templates on MT = 3 / 5)
 constexpr int CT_W = NCT / 4;           // channel tiles per wave (4 waves)
 constexpr long long FRAG = (long long)NCT * NKT * 64 * 8;      // bf16 elements of one conv's fragment-ordered weights
 
@@ -88,7 +88,7 @@ struct TcnP {
 // matrix-pipe cycles for the L2 round trip), the activation fragments of tile kt + 1 are read from LDS before the MFMAs
 // of tile kt.  sched_barrier pins that order -- left alone the compiler sinks every load next to its first use
 // (s_waitcnt vmcnt(1) in front of each group of 5 MFMAs: 21 us per conv instead of 4).
-template <bool BWD>
+template <bool BWD, int MT>
 __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_off, const u32x4* __restrict__ wa, int d, int T,
                                           int R, int lane, f32x4 (&acc)[CT_W][MT]) {
     int off0[MT], off1[MT];
@@ -140,6 +140,7 @@ __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_o
     }
 }
 
+template <int MT>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[CT_W][MT]) {
 #pragma unroll
     for (int i = 0; i < CT_W; ++i)
@@ -166,6 +167,7 @@ __device__ __forceinline__ void rows_in(bf16_t* lds, const bf16_t* __restrict__ 
 // "kept".  The hashes are the counter-based ones of every other kernel (index row*C + channel), but generated here they
 // run on all 256 CUs at full occupancy and off the forward kernel's dependent chain: inside its epilogue (one wave per
 // SIMD) they were 2/3 of its time -- 28 000 of 43 000 cycles per conv.
+template <int MT>
 __global__ __launch_bounds__(256) void tcn_keep_k(const TcnP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x, cv = blockIdx.y;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(256) void tcn_keep_k(const TcnP p) {
 __host__ __device__ inline int sign_s1(int rows) { return (rows * 40 + 15) / 16 * 16; }
 __host__ __device__ inline int sign_s2(int rows) { return (rows * 80 + 15) / 16 * 16; }
 
+template <int MT>
 __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sm = reinterpret_cast<bf16_t*>(smem_raw);
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
             u32x4 kv = u32x4{0u, 0u, 0u, 0u};                    // this thread's keep bits: requested now, used after the K loop
             if (drop) kv = p.keep[((size_t)cv * gridDim.x + blockIdx.x) * 256 + tid];
             zero_acc(acc);
-            conv_tile<false>(sm, j == 0 ? X : H1, Z, wa, d, p.T, R, lane, acc);
+            conv_tile<false, MT>(sm, j == 0 ? X : H1, Z, wa, d, p.T, R, lane, acc);
             TCN_STAMP();
             const unsigned kw[4] = {kv.x, kv.y, kv.z, kv.w};
             const float ik = p.inv_keep;
@@ -308,6 +311,7 @@ __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
     }
 }
 
+template <int MT>
 __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sm = reinterpret_cast<bf16_t*>(smem_raw);
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
             const int cv = 2 * blk + 1;
             const u32x4* wa = reinterpret_cast<const u32x4*>(p.wfrag + (long long)(2 * cv + 1) * FRAG) + (wave * CT_W * NKT) * 64 + lane;
             zero_acc(acc);
-            conv_tile<true>(sm, P2, Z, wa, d, p.T, R, lane, acc);
+            conv_tile<true, MT>(sm, P2, Z, wa, d, p.T, R, lane, acc);
             TCN_STAMP();
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
             const int cv = 2 * blk;
             const u32x4* wa = reinterpret_cast<const u32x4*>(p.wfrag + (long long)(2 * cv + 1) * FRAG) + (wave * CT_W * NKT) * 64 + lane;
             zero_acc(acc);
-            conv_tile<true>(sm, P1, Z, wa, d, p.T, R, lane, acc);
+            conv_tile<true, MT>(sm, P1, Z, wa, d, p.T, R, lane, acc);
             TCN_STAMP();
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
@@ -450,10 +454,22 @@ __global__ __launch_bounds__(256) void tcn_pack_k(const PackP p) {
 
 unsigned long long* g_trace = nullptr;
 
+// Clips per workgroup.  Two clips (68 rows = 5 row tiles) amortise a workgroup's weight stream best, but at B = 256 that is
+// 128 workgroups on 256 CUs, every one a chain of eight convs of ~22 k cycles: with one clip per workgroup (3 row tiles)
+// the K loop and the epilogue of a conv shrink to 3 / 5 and all CUs work -- the L2 then serves the weights twice as often
+// (742 MB per launch, well inside its bandwidth).  S2AG_TCN_CPB forces a value.
+int plan_cpb(int n_clips, int T) {
+    const int max_cpb = (MT_MAX * 16) / T > 2 ? 2 : (MT_MAX * 16) / T;
+    static const int forced = [] { const char* e = getenv("S2AG_TCN_CPB"); return e ? atoi(e) : 0; }();
+    if (forced >= 1 && forced <= max_cpb) return forced;
+    if (max_cpb >= 2 && T <= 48 && n_clips >= 192) return 1;
+    return max_cpb;
+}
+
 int fill(const s2ag_bf16_tcn_args* a, TcnP& p, bool bwd) {
     if (!a || !a->x || !a->wfrag || a->n_blocks < 1 || a->n_blocks > S2AG_TCN_MAX_BLOCKS || a->n_clips <= 0) return S2AG_E_BADARG;
-    const int cpb = s2ag_bf16_tcn_clips_per_block(a->T, a->C, 2);
-    if (cpb <= 0) return S2AG_E_UNSUPPORTED;
+    if (s2ag_bf16_tcn_clips_per_block(a->T, a->C, 2) <= 0) return S2AG_E_UNSUPPORTED;
+    const int cpb = plan_cpb(a->n_clips, a->T);
     if (a->drop_p < 0.f || a->drop_p >= 1.f || (a->drop_p > 0.f && !a->rng)) return S2AG_E_BADARG;
     p.x = static_cast<const bf16_t*>(a->x);
     p.wfrag = static_cast<const bf16_t*>(a->wfrag);
@@ -493,9 +509,9 @@ size_t lds_bytes(int cpb, int T, bool bwd) {
 }
 }  // namespace
 
-extern "C" int s2ag_bf16_tcn_clips_per_block(int T, int C, int ksize) {
-    if (ksize != 2 || C < 1 || C > CP || T < 1 || T > MT * 16) return 0;
-    return (MT * 16) / T > 2 ? 2 : (MT * 16) / T;           // two clips: 128 workgroups at B = 256 beside the wave encoder
+extern "C" int s2ag_bf16_tcn_clips_per_block(int T, int C, int ksize) {      // the most a workgroup takes (see plan_cpb)
+    if (ksize != 2 || C < 1 || C > CP || T < 1 || T > MT_MAX * 16) return 0;
+    return (MT_MAX * 16) / T > 2 ? 2 : (MT_MAX * 16) / T;
 }
 
 extern "C" int s2ag_bf16_tcn_set_trace(void* buf) {
@@ -504,14 +520,14 @@ extern "C" int s2ag_bf16_tcn_set_trace(void* buf) {
 }
 
 extern "C" long long s2ag_bf16_tcn_sign_bytes(int n_clips, int T) {
-    const int cpb = s2ag_bf16_tcn_clips_per_block(T, CP, 2);
-    if (cpb <= 0 || n_clips <= 0) return 0;
+    if (s2ag_bf16_tcn_clips_per_block(T, CP, 2) <= 0 || n_clips <= 0) return 0;
+    const int cpb = plan_cpb(n_clips, T);
     return (long long)cdiv(n_clips, cpb) * (sign_s1(cpb * T) + sign_s2(cpb * T));
 }
 
 extern "C" long long s2ag_bf16_tcn_keep_bytes(int n_clips, int T, int n_blocks) {
-    const int cpb = s2ag_bf16_tcn_clips_per_block(T, CP, 2);
-    if (cpb <= 0 || n_clips <= 0 || n_blocks < 1) return 0;
+    if (s2ag_bf16_tcn_clips_per_block(T, CP, 2) <= 0 || n_clips <= 0 || n_blocks < 1) return 0;
+    const int cpb = plan_cpb(n_clips, T);
     return (long long)cdiv(n_clips, cpb) * 2 * n_blocks * 256 * 16;
 }
 
@@ -537,13 +553,18 @@ extern "C" int s2ag_bf16_tcn_fwd(const s2ag_bf16_tcn_args* a, void* stream) {
     const size_t lds = lds_bytes(p.cpb, p.T, false);
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)tcn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)tcn_fwd_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)tcn_fwd_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
-    if (p.drop_p > 0.f)
-        hipLaunchKernelGGL(tcn_keep_k, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
-    hipLaunchKernelGGL(tcn_fwd_k, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    const bool small = p.cpb * p.T <= 48;           // three row tiles cover the workgroup's rows
+    if (p.drop_p > 0.f) {
+        if (small) hipLaunchKernelGGL(tcn_keep_k<3>, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(tcn_keep_k<5>, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
+    }
+    if (small) hipLaunchKernelGGL(tcn_fwd_k<3>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(tcn_fwd_k<5>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }
@@ -555,11 +576,13 @@ extern "C" int s2ag_bf16_tcn_bwd(const s2ag_bf16_tcn_args* a, void* stream) {
     const size_t lds = lds_bytes(p.cpb, p.T, true);
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)tcn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)tcn_bwd_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)tcn_bwd_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
-    hipLaunchKernelGGL(tcn_bwd_k, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    if (p.cpb * p.T <= 48) hipLaunchKernelGGL(tcn_bwd_k<3>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(tcn_bwd_k<5>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -28,9 +28,11 @@
 // Every global access is a coalesced 16-byte load / store of a contiguous span; every operand element is read from HBM
 // once per kernel; the weights (<= 120 KB) live in registers.  v_mfma_f32_16x16x32_bf16, fp32 accumulation.
 #include "s2ag_common.h"
+#include "bn_fold_inl.h"
 
 namespace {
 using namespace s2ag;
+using namespace s2ag_fold;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using s16x4 = __attribute__((ext_vector_type(4))) short;
@@ -93,6 +95,7 @@ struct WvFwdP {
     double* stats;            // (2, gridDim.x, COUT) or null
     int N, Lin, Lout, KP;
     int chunks, LC;           // output-frame chunks per clip, frames per chunk (multiple of 16 * teams)
+    FwdFold fold;             // fold.ticket != null: the last workgroup turns the partials into BatchNorm coefficients
 };
 
 // TEAM = 1: every wave owns sub-tiles of 16 output frames (all COUT channels; its own LDS image, no block barrier).
@@ -262,7 +265,11 @@ __global__ __launch_bounds__(256) void wv_fwd_k(const WvFwdP p) {
             double v;
             if (TEAM == 1) v = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
             else v = red[(c / 16) % NCT][which][c];       // the K-part-0 wave of this channel tile
-            p.stats[((size_t)which * gridDim.x + blockIdx.x) * COUT + c] = v;
+            st_agent(p.stats + ((size_t)which * gridDim.x + blockIdx.x) * COUT + c, v);
+        }
+        if (p.fold.ticket && two_level_done(p.stats, gridDim.x, COUT, p.fold.ticket)) {
+            __shared__ double fred[2][256];
+            bn_fwd_fold_body(p.stats + (size_t)2 * gridDim.x * COUT, fold_groups(gridDim.x), COUT, p.fold, fred);
         }
     }
 }
@@ -299,6 +306,16 @@ struct WvDgP {
     bf16_t* dzp;              // (N, Lin, CIN) out: dz_{i-1} = da_{i-1} * leaky'(psc yp + psh)
     double* stats;            // (2, gridDim.x, CIN): column sums of dz_{i-1} and of dz_{i-1} * xhat_{i-1}
     int N, Lin, Lout, Q, chunks, QC;
+    // fold of those sums by the workgroup that finishes last (ticket != null): gradients of gamma / beta of BatchNorm i-1
+    // and the coefficients of dy_{i-1} = oca dz + occ y + ocb
+    int* ticket;
+    const float* pgamma;
+    float* dgamma;
+    float* dbeta;
+    float* oca;
+    float* ocb;
+    float* occ;
+    double inv_rows;
 };
 
 template <int COUT, int CIN, int TEAM, bool G_F32>
@@ -493,8 +510,13 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
     __syncthreads();
     if (tid < 2 * CIN) {
         const int which = tid / CIN, c = tid - which * CIN;
-        p.stats[((size_t)which * gridDim.x + blockIdx.x) * CIN + c] =
-            red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+        st_agent(p.stats + ((size_t)which * gridDim.x + blockIdx.x) * CIN + c,
+                 red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c]);
+    }
+    if (p.ticket && two_level_done(p.stats, gridDim.x, CIN, p.ticket)) {
+        __shared__ double fred[2][256];
+        bn_bwd_fold_body<true>(p.stats + (size_t)2 * gridDim.x * CIN, fold_groups(gridDim.x), CIN, p.inv_rows, p.pgamma, p.pmean,
+                               p.pinv, p.dgamma, p.dbeta, p.oca, p.ocb, p.occ, fred);
     }
 }
 
@@ -535,30 +557,38 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int off, int pitch)
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// One workgroup = 4 waves on shared, double-buffered images of a 32-q step.  The accumulator tiles (co tile, ci tile,
-// phase r, tap index i) are split over the waves:  (32, 16): wave = (co tile, phase half);  (64, 32): wave = co tile;
-// (32, 64): wave = ci tile.
-template <int COUT, int CIN, bool G_F32>
+// One workgroup = 4 waves on shared, double-buffered images of a 32-q step; the raw loads of the next RING - 1 steps are in
+// flight in registers (a step's ~10 KB arrive ~2 us after they are requested, its MFMAs take a fraction of that: with one
+// step in flight the kernel was a chain of memory round trips).  The accumulator tiles (co tile, ci tile, phase r, tap
+// index i) are split over the waves -- (32, 16): wave = (co tile, phase half);  (64, 32): wave = co tile;  (32, 64): wave =
+// ci tile -- and, for the two small layers, the phases over blockIdx.y (PSPLIT = 3: a workgroup stages the frames of ITS two
+// phases only, so the input is still read once; the 123 KB partial tile of a workgroup is shared by the three).
+template <int COUT, int CIN, bool G_F32, int PSPLIT>
 __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
     constexpr int NCOT = COUT / 16, NCIT = CIN / 16;
     constexpr int WCOT = (NCOT == 2 && NCIT == 4) ? 2 : 1;    // co tiles per wave
     constexpr int WCIT = (NCOT == 4) ? 2 : 1;                  // ci tiles per wave
-    constexpr int NR = (NCOT == 2 && NCIT == 1) ? 3 : WS;      // phases per wave
+    constexpr int RSPLIT = (NCOT == 2 && NCIT == 1) ? 2 : 1;   // phase halves over the waves (32, 16)
+    constexpr int NPW = WS / PSPLIT;                           // phases a workgroup stages
+    constexpr int NR = NPW / RSPLIT;                           // phases per wave
     constexpr int QT = 32;                                     // q per step = one MFMA K
     constexpr int DROWS = QT + WNT - 1;
     constexpr int PG = COUT + 8, PA = CIN + 8;                 // image pitches
-    constexpr int NDC = DROWS * COUT / 8, NAC = QT * WS * CIN / 8;
+    constexpr int NDC = DROWS * COUT / 8, NAC = QT * NPW * CIN / 8;
     constexpr int NLD = (NDC + 255) / 256, NLA = (NAC + 255) / 256;
+    constexpr int RING = 3;
     static_assert(2048 % COUT == 0 && 2048 % CIN == 0, "a thread's chunks must all start at the same channel");
+    static_assert(WS % PSPLIT == 0 && NPW % RSPLIT == 0, "phase split");
     __shared__ __attribute__((aligned(16))) bf16_t dimg[2][DROWS * PG];
-    __shared__ __attribute__((aligned(16))) bf16_t aimg[2][WS * QT * PA];
+    __shared__ __attribute__((aligned(16))) bf16_t aimg[2][NPW * QT * PA];
     __shared__ float bred[4][COUT];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cot0 = NCOT == 4 ? wave : (NCIT == 1 ? (wave & 1) : 0);
     const int cit0 = (NCOT == 2 && NCIT == 4) ? wave : 0;
-    const int r0 = (NCOT == 2 && NCIT == 1) ? 3 * (wave >> 1) : 0;
+    const int ph0 = blockIdx.y * NPW;                          // first phase of this workgroup
+    const int r0 = RSPLIT == 2 ? NR * (wave >> 1) : 0;         // first phase of this wave (relative to ph0)
 
     float ca[8], cb[8], cc[8], psc[8], psh[8];
     {
@@ -592,47 +622,64 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
     const int s_beg = blockIdx.x * per + min((int)blockIdx.x, extra);
     const int s_end = s_beg + per + ((int)blockIdx.x < extra ? 1 : 0);
 
-    u32x4 rd[NLD], ra[NLA];
-    auto fetch = [&](int s) {
-        const int n = s / p.QS, q0 = (s - n * p.QS) * QT;
+    // raw loads of a step: rd = dz chunks (or the first four floats of g), ry = y chunks (or the second four), ra = y_prev
+    u32x4 rd[RING][NLD], ry[RING][NLD], ra[RING][NLA];
+    auto fetch = [&](int s, int set) {
+        const bool live = s < s_end;
+        const int n = live ? s / p.QS : 0, q0 = live ? (s - n * p.QS) * QT : 0;
         const long long gclip = (long long)n * p.Lout * COUT;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int e = (u * 256 + tid) * 8;
             const int row = e / COUT, col = e - row * COUT;
             const int l = q0 - (WNT - 1) + row;
-            rd[u] = u32x4{0u, 0u, 0u, 0u};
-            if (row < DROWS && (unsigned)l < (unsigned)p.Lout) {
+            rd[set][u] = ry[set][u] = u32x4{0u, 0u, 0u, 0u};
+            if (live && row < DROWS && (unsigned)l < (unsigned)p.Lout) {
                 const long long off = gclip + (long long)l * COUT + col;
                 if constexpr (G_F32) {
                     const float* g = static_cast<const float*>(p.dz) + off;
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(g), b = *reinterpret_cast<const f32x4*>(g + 4);
-                    rd[u] = u32x4{bf_pack(a[0], a[1]), bf_pack(a[2], a[3]), bf_pack(b[0], b[1]), bf_pack(b[2], b[3])};
+                    rd[set][u] = *reinterpret_cast<const u32x4*>(g);
+                    ry[set][u] = *reinterpret_cast<const u32x4*>(g + 4);
                 } else {
-                    rd[u] = bn_bwd8(*reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off),
-                                    *reinterpret_cast<const u32x4*>(p.y + off), ca, cb, cc);
+                    rd[set][u] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off);
+                    ry[set][u] = *reinterpret_cast<const u32x4*>(p.y + off);
                 }
             }
         }
         const bf16_t* ypc = p.yp + ((long long)n * p.Lin + (long long)WS * q0) * CIN;
-        const int frames = p.Lin - WS * q0;                    // valid frames from the block start
+        const int frames = live ? p.Lin - WS * q0 : 0;         // valid frames from the block start
 #pragma unroll
         for (int u = 0; u < NLA; ++u) {
-            const int e = (u * 256 + tid) * 8;
-            const int fl = e / CIN;
-            ra[u] = u32x4{0u, 0u, 0u, 0u};
-            if (fl < QT * WS && fl < frames) ra[u] = bn_act8(*reinterpret_cast<const u32x4*>(ypc + e), psc, psh, p.slope);
+            const int e = (u * 256 + tid) * 8;                 // element among this workgroup's NPW phases x 32 q x CIN
+            const int fp = e / CIN, col = e - fp * CIN;        // frame index among the staged ones: fp = ql * NPW + rl
+            const int ql = fp / NPW, rl = fp - ql * NPW;
+            const int fl = ql * WS + ph0 + rl;                 // frame inside the block of 192
+            ra[set][u] = u32x4{0u, 0u, 0u, 0u};
+            if (fp < QT * NPW && fl < frames) ra[set][u] = *reinterpret_cast<const u32x4*>(ypc + (long long)fl * CIN + col);
         }
     };
-    auto stash = [&](int buf) {
+    // transform + LDS stores of a fetched step; a live flag travels with the data (zeros stay zeros: B != 0 otherwise)
+    auto stash = [&](int s, int set, int buf) {
+        const bool live = s < s_end;
+        const int q0 = live ? (s - (s / p.QS) * p.QS) * QT : 0;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int e = (u * 256 + tid) * 8;
             const int row = e / COUT, col = e - row * COUT;
+            const int l = q0 - (WNT - 1) + row;
             if (row < DROWS) {
-                *reinterpret_cast<u32x4*>(&dimg[buf][row * PG + col]) = rd[u];
-                if (row >= WNT - 1) {                          // the halo rows are the previous step's core rows
-                    const unsigned w[4] = {rd[u].x, rd[u].y, rd[u].z, rd[u].w};
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (live && (unsigned)l < (unsigned)p.Lout) {
+                    if constexpr (G_F32) {
+                        const f32x4 a = __builtin_bit_cast(f32x4, rd[set][u]), b = __builtin_bit_cast(f32x4, ry[set][u]);
+                        v = u32x4{bf_pack(a[0], a[1]), bf_pack(a[2], a[3]), bf_pack(b[0], b[1]), bf_pack(b[2], b[3])};
+                    } else {
+                        v = bn_bwd8(rd[set][u], ry[set][u], ca, cb, cc);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(&dimg[buf][row * PG + col]) = v;
+                if (row >= WNT - 1 && blockIdx.y == 0) {       // the halo rows are the previous step's core rows
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         bacc[2 * j] += bf_lo(w[j]);
@@ -641,23 +688,23 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
                 }
             }
         }
+        const int frames = live ? p.Lin - WS * q0 : 0;
 #pragma unroll
         for (int u = 0; u < NLA; ++u) {
             const int e = (u * 256 + tid) * 8;
-            const int fl = e / CIN, col = e - fl * CIN;
-            const int ql = fl / WS, r = fl - ql * WS;
-            if (fl < QT * WS) *reinterpret_cast<u32x4*>(&aimg[buf][(r * QT + ql) * PA + col]) = ra[u];
+            const int fp = e / CIN, col = e - fp * CIN;
+            const int ql = fp / NPW, rl = fp - ql * NPW;
+            if (fp < QT * NPW) {
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (ql * WS + ph0 + rl < frames) v = bn_act8(ra[set][u], psc, psh, p.slope);
+                *reinterpret_cast<u32x4*>(&aimg[buf][(rl * QT + ql) * PA + col]) = v;
+            }
         }
     };
 
     const int g = lane >> 4, t = lane & 15;
     const int tr_row = 8 * g + (t >> 2), tr_col = 4 * (t & 3);
-    if (s_beg < s_end) fetch(s_beg);
-    for (int s = s_beg; s < s_end; ++s) {
-        const int buf = (s - s_beg) & 1;
-        stash(buf);
-        __syncthreads();
-        if (s + 1 < s_end) fetch(s + 1);
+    auto mma = [&](int buf) {
         // A = dy^T shifted by the tap index: af[i][a] holds dy[q0 + 8 g .. + 8 - i][co tile a]
         bf16x8 af[WNT][WCOT];
 #pragma unroll
@@ -673,7 +720,7 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
                 bfr[b] = tr_frag(aimg[buf], ((r0 + r) * QT + tr_row) * PA + 16 * (cit0 + b) + tr_col, PA);
 #pragma unroll
             for (int i = 0; i < WNT; ++i)
-                if (r0 + r + WS * i < WKS) {                   // wave-uniform
+                if (ph0 + r0 + r + WS * i < WKS) {             // wave-uniform
 #pragma unroll
                     for (int a = 0; a < WCOT; ++a)
 #pragma unroll
@@ -681,8 +728,22 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
                             acc[a][b][r][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][a], bfr[b], acc[a][b][r][i], 0, 0, 0);
                 }
         }
+    };
+
+#pragma unroll
+    for (int r = 0; r < RING; ++r) fetch(s_beg + r, r);
+    int buf = 0;
+    for (int s = s_beg; s < s_end; s += RING) {
+#pragma unroll
+        for (int r = 0; r < RING; ++r) {
+            stash(s + r, r, buf);
+            fetch(s + r + RING, r);
+            __syncthreads();
+            mma(buf);
+            buf ^= 1;
+        }
     }
-    // D[co][ci]: co = 16 (cot0 + a) + 4 (lane >> 4) + v, ci = 16 (cit0 + b) + (lane & 15); tap r0 + r + 6 i
+    // D[co][ci]: co = 16 (cot0 + a) + 4 (lane >> 4) + v, ci = 16 (cit0 + b) + (lane & 15); tap ph0 + r0 + r + 6 i
     float* dst = p.part + (size_t)blockIdx.x * COUT * WKS * CIN;
 #pragma unroll
     for (int a = 0; a < WCOT; ++a)
@@ -692,7 +753,7 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
             for (int r = 0; r < NR; ++r)
 #pragma unroll
                 for (int i = 0; i < WNT; ++i) {
-                    const int tap = r0 + r + WS * i;
+                    const int tap = ph0 + r0 + r + WS * i;
                     if (tap < WKS) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
@@ -701,7 +762,8 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
                         }
                     }
                 }
-    // bias gradient: threads with the same (tid * 8) % COUT hold the same 8 channels
+    // bias gradient (the workgroups of phase group 0): threads with the same (tid * 8) % COUT hold the same 8 channels
+    if (blockIdx.y != 0) return;
     constexpr int G = COUT / 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -752,37 +814,14 @@ __global__ __launch_bounds__(256) void wv_wgrad_reduce_k(const float* __restrict
     }
 }
 
-// BatchNorm backward fold: the partial column sums of dz and dz * xhat (2, R, C) -> gradients of gamma / beta (added to
-// their slots) and the coefficients of dy = A dz + C y + B
+// BatchNorm backward fold as a kernel of its own (the data-gradient kernels do it themselves when given a ticket word)
 __global__ __launch_bounds__(256) void wv_bn_bwd_fold_k(const double* __restrict__ part, int R, int C, double inv_rows,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, float* __restrict__ ca,
                                                         float* __restrict__ cb, float* __restrict__ cc) {
     __shared__ double red[2][256];
-    const int per = 256 / C;                      // threads per column (C <= 64, power of two)
-    const int c = threadIdx.x % C, k = threadIdx.x / C;
-    double a = 0.0, b = 0.0;
-    for (int r = k; r < R; r += per) {
-        a += part[(size_t)r * C + c];
-        b += part[((size_t)R + r) * C + c];
-    }
-    red[0][threadIdx.x] = a;
-    red[1][threadIdx.x] = b;
-    __syncthreads();
-    if (threadIdx.x < C) {
-        for (int j = 1; j < per; ++j) {
-            a += red[0][j * C + c];
-            b += red[1][j * C + c];
-        }
-        if (dbeta) atomicAdd(dbeta + c, (float)a);
-        if (dgamma) atomicAdd(dgamma + c, (float)b);
-        const double m1 = a * inv_rows, m2 = b * inv_rows;
-        const double g = gamma[c], r = invstd[c], mu = mean[c];
-        ca[c] = (float)(g * r);
-        cc[c] = (float)(-g * r * r * m2);
-        cb[c] = (float)(g * r * (r * mu * m2 - m1));
-    }
+    bn_bwd_fold_body<false>(part, R, C, inv_rows, gamma, mean, invstd, dgamma, dbeta, ca, cb, cc, red);
 }
 }  // namespace
 
@@ -797,15 +836,22 @@ extern "C" int s2ag_wave_fwd_rows(int N, int Lout, int Cin, int Cout) {
 }
 
 extern "C" int s2ag_wave_conv_fwd(const void* x, const float* in_scale, const float* in_shift, float slope, const void* w_packed,
-                                  int KP, const float* bias, void* y, int out_f32, double* stats, int N, int Lin, int Lout,
-                                  int Cin, int Cout, void* stream) {
+                                  int KP, const float* bias, void* y, int out_f32, double* stats, const s2ag_bn_fold_args* fold,
+                                  int N, int Lin, int Lout, int Cin, int Cout, void* stream) {
     if (!x || !in_scale || !in_shift || !w_packed || !y || N <= 0 || Lin <= 0 || Lout <= 0) return S2AG_E_BADARG;
+    if (fold && (!stats || !fold->ticket || !fold->gamma || !fold->beta || !fold->running_mean || !fold->running_var ||
+                 !fold->scale || !fold->shift || !fold->mean || !fold->invstd || fold->repeat < 1))
+        return S2AG_E_BADARG;
     if ((long long)(Lout - 1) * WS + WKS > Lin) return S2AG_E_BADARG;
     if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)y & 15)) return S2AG_E_BADARG;
     WvFwdP p{};
     p.x = static_cast<const bf16_t*>(x); p.sc = in_scale; p.sh = in_shift; p.slope = slope;
     p.w = static_cast<const bf16_t*>(w_packed); p.bias = bias; p.y = y; p.stats = stats;
     p.N = N; p.Lin = Lin; p.Lout = Lout; p.KP = KP;
+    if (fold)
+        p.fold = FwdFold{fold->ticket, fold->gamma, fold->beta, fold->running_mean, fold->running_var, fold->num_batches_tracked,
+                         fold->eps, fold->momentum, fold->repeat, (long long)N * Lout, fold->scale, fold->shift, fold->mean,
+                         fold->invstd};
     hipStream_t s = (hipStream_t)stream;
     if (Cin == 16 && Cout == 32 && !out_f32 && KP >= 256) launch_fwd<16, 32, 1, false>(p, s);
     else if (Cin == 32 && Cout == 64 && !out_f32 && KP >= 480) launch_fwd<32, 64, 4, false>(p, s);
@@ -828,11 +874,13 @@ extern "C" int s2ag_wave_dgrad_rows(int N, int Lin, int Cin) {
 extern "C" int s2ag_wave_conv_dgrad(const void* dz, const void* y, const float* ca, const float* cb, const float* cc, int g_f32,
                                     const void* w_phases, int CPO, const void* y_prev, const float* p_scale,
                                     const float* p_shift, const float* p_mean, const float* p_invstd, float slope, void* dz_prev,
-                                    double* stats, int N, int Lin, int Lout, int Cin, int Cout, void* stream) {
+                                    double* stats, int* ticket, const float* p_gamma, float* dgamma, float* dbeta, float* out_ca,
+                                    float* out_cb, float* out_cc, int N, int Lin, int Lout, int Cin, int Cout, void* stream) {
     if (!dz || !w_phases || !y_prev || !p_scale || !p_shift || !p_mean || !p_invstd || !dz_prev || !stats || N <= 0 ||
         Lin <= 0 || Lout <= 0)
         return S2AG_E_BADARG;
     if (!g_f32 && (!y || !ca || !cb || !cc)) return S2AG_E_BADARG;
+    if (ticket && (!p_gamma || !out_ca || !out_cb || !out_cc)) return S2AG_E_BADARG;
     if ((long long)(Lout - 1) * WS + WKS > Lin) return S2AG_E_BADARG;
     if (((uintptr_t)dz & 15) || ((uintptr_t)y & 15) || ((uintptr_t)w_phases & 15) || ((uintptr_t)y_prev & 15) ||
         ((uintptr_t)dz_prev & 15))
@@ -842,6 +890,8 @@ extern "C" int s2ag_wave_conv_dgrad(const void* dz, const void* y, const float* 
     p.w = static_cast<const bf16_t*>(w_phases); p.CPO = CPO; p.yp = static_cast<const bf16_t*>(y_prev);
     p.psc = p_scale; p.psh = p_shift; p.pmean = p_mean; p.pinv = p_invstd; p.slope = slope;
     p.dzp = static_cast<bf16_t*>(dz_prev); p.stats = stats; p.N = N; p.Lin = Lin; p.Lout = Lout;
+    p.ticket = ticket; p.pgamma = p_gamma; p.dgamma = dgamma; p.dbeta = dbeta; p.oca = out_ca; p.ocb = out_cb; p.occ = out_cc;
+    p.inv_rows = 1.0 / ((double)N * Lin);
     hipStream_t s = (hipStream_t)stream;
     if (Cout == 32 && Cin == 16 && !g_f32 && CPO >= 32) launch_dgrad<32, 16, 1, false>(p, s);
     else if (Cout == 64 && Cin == 32 && !g_f32 && CPO >= 64) launch_dgrad<64, 32, 4, false>(p, s);
@@ -852,7 +902,8 @@ extern "C" int s2ag_wave_conv_dgrad(const void* dz, const void* y, const float* 
 }
 
 static int wgrad_blocks(int total_steps, int Cin, int Cout) {
-    // the partials are (blocks, Cout, 15, Cin) fp32: keep them under ~16 MB, and at least 64 workgroups streaming
+    // the partials are (blocks, Cout, 15, Cin) fp32: keep them under ~16 MB (the two small layers then run three workgroups
+    // -- one per pair of phases -- on every partial tile), and at least 64 workgroups streaming
     long long cap = (16ll << 20) / ((long long)Cout * WKS * Cin * 4);
     if (cap > 512) cap = 512;
     if (cap < 64) cap = 64;
@@ -881,9 +932,9 @@ extern "C" int s2ag_wave_conv_wgrad(const void* dz, const void* y, const float* 
     p.total_steps = N * p.QS;
     const int blocks = wgrad_blocks(p.total_steps, Cin, Cout);
     hipStream_t s = (hipStream_t)stream;
-    if (Cout == 32 && Cin == 16 && !g_f32) hipLaunchKernelGGL((wv_wgrad_k<32, 16, false>), dim3(blocks), dim3(256), 0, s, p);
-    else if (Cout == 64 && Cin == 32 && !g_f32) hipLaunchKernelGGL((wv_wgrad_k<64, 32, false>), dim3(blocks), dim3(256), 0, s, p);
-    else if (Cout == 32 && Cin == 64 && g_f32) hipLaunchKernelGGL((wv_wgrad_k<32, 64, true>), dim3(blocks), dim3(256), 0, s, p);
+    if (Cout == 32 && Cin == 16 && !g_f32) hipLaunchKernelGGL((wv_wgrad_k<32, 16, false, 1>), dim3(blocks), dim3(256), 0, s, p);
+    else if (Cout == 64 && Cin == 32 && !g_f32) hipLaunchKernelGGL((wv_wgrad_k<64, 32, false, 3>), dim3(blocks, 3), dim3(256), 0, s, p);
+    else if (Cout == 32 && Cin == 64 && g_f32) hipLaunchKernelGGL((wv_wgrad_k<32, 64, true, 3>), dim3(blocks, 3), dim3(256), 0, s, p);
     else return S2AG_E_UNSUPPORTED;
     const int total = Cout * WKS * Cin + Cout;
     hipLaunchKernelGGL(wv_wgrad_reduce_k, dim3(cdiv(total, 32)), dim3(256), 0, s, partials, partials_b, blocks, Cout, Cin, dw, db);

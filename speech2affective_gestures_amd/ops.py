@@ -351,6 +351,17 @@ def _ticket(dev):
     return C.c_void_p(ent[0].data_ptr() + 4 * i)
 
 
+def _tickets(dev, n: int):
+    """``n`` consecutive ticket words (two-level folds: one per group of 16 partial rows + the global one)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _TICKETS:
+        init_tickets(dev)
+    ent = _TICKETS[key]
+    i = ent[1] if ent[1] + n <= _TICKET_POOL else 0
+    ent[1] = (i + n) % _TICKET_POOL
+    return C.c_void_p(ent[0].data_ptr() + 4 * i)
+
+
 # ----------------------------------------------------------------------------------------------------
 # direct gradient accumulation
 # ----------------------------------------------------------------------------------------------------

@@ -67,16 +67,34 @@ def test_fused_forward_conv(Cin, Cout, N, Lout):
     xd = x.to(torch.bfloat16).cuda()
     y = torch.empty(N, Lout, Cout, dtype=torch.float32 if out_f32 else torch.bfloat16, device='cuda')
     rows = lib.s2ag_wave_fwd_rows(N, Lout, Cin, Cout)
-    stats = None if out_f32 else torch.full((2, rows, Cout), float('nan'), dtype=torch.float64, device='cuda')
+    ng = (rows + 15) // 16                       # group rows of the two-level fold behind the partial rows
+    stats_buf = None if out_f32 else torch.full((2 * (rows + ng) * Cout,), float('nan'), dtype=torch.float64, device='cuda')
+    stats = None if out_f32 else stats_buf[:2 * rows * Cout].view(2, rows, Cout)
     scd, shd, wd, bd = sc.cuda(), sh.cuda(), pack_fwd(w, KP), b.cuda()      # (keep the device tensors alive over the launch)
-    L.check(lib.s2ag_wave_conv_fwd(_p(xd), _p(scd), _p(shd), 0.3, _p(wd), KP, _p(bd), _p(y), int(out_f32), _p(stats), N, Lin,
-                                   Lout, Cin, Cout, _stream()), 'wave_conv_fwd')
+    # with a fold: the BatchNorm behind this conv gets its coefficients + running estimates from the last workgroup
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
+    rm, rv, nbt = torch.zeros(Cout, device='cuda'), torch.ones(Cout, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda')
+    coef, ticket = torch.full((4, Cout), float('nan'), device='cuda'), torch.zeros(1 + ng, dtype=torch.int32, device='cuda')
+    fa = None if out_f32 else L.BnFoldArgs(_p(ticket), _p(gamma), _p(beta), _p(rm), _p(rv), _p(nbt), 1e-5, 0.1, 2, _p(coef[0]),
+                                           _p(coef[1]), _p(coef[2]), _p(coef[3]))
+    L.check(lib.s2ag_wave_conv_fwd(_p(xd), _p(scd), _p(shd), 0.3, _p(wd), KP, _p(bd), _p(y), int(out_f32), _p(stats_buf),
+                                   C.byref(fa) if fa is not None else None, N, Lin, Lout, Cin, Cout, _stream()), 'wave_conv_fwd')
     torch.cuda.synchronize()
     assert rel(y, want) < (2e-5 if out_f32 else 6e-3)
     if stats is not None:       # column sums of the ROUNDED outputs, exactly
         yd = y.double().reshape(-1, Cout)
         assert torch.allclose(stats[0].sum(0), yd.sum(0), rtol=1e-12, atol=1e-9)
         assert torch.allclose(stats[1].sum(0), (yd * yd).sum(0), rtol=1e-12, atol=1e-9)
+        # the fold == training-mode F.batch_norm statistics of the stored tensor, two running-estimate updates (repeat = 2)
+        mean, var = yd.mean(0), yd.var(0, unbiased=False)
+        invstd = (var + 1e-5).rsqrt()
+        assert int(ticket.abs().sum()) == 0 and int(nbt) == 2
+        assert torch.allclose(coef[2].double(), mean, rtol=1e-6, atol=1e-7) and torch.allclose(coef[3].double(), invstd, rtol=1e-6)
+        assert torch.allclose(coef[0].double(), gamma.double() * invstd, rtol=1e-6)
+        assert torch.allclose(coef[1].double(), beta.double() - mean * gamma.double() * invstd, rtol=1e-5, atol=1e-6)
+        unb = yd.var(0, unbiased=True)
+        assert torch.allclose(rm.double(), 0.19 * mean, rtol=1e-5, atol=1e-7)            # 0 -> 0.1 m -> 0.19 m
+        assert torch.allclose(rv.double(), 0.81 + 0.19 * unb, rtol=1e-5)
 
 
 def pack_phases(w, CPO):
@@ -122,14 +140,29 @@ def test_fused_data_gradient(Cin, Cout, N, Lout):
     want = torch.where(z > 0, da, da * 0.3)
     xhat = yp * pinv - pmean * pinv
     rows = lib.s2ag_wave_dgrad_rows(N, Lin, Cin)
-    stats = torch.full((2, rows, Cin), float('nan'), dtype=torch.float64, device='cuda')
+    ng = (rows + 15) // 16
+    stats_buf = torch.full((2 * (rows + ng) * Cin,), float('nan'), dtype=torch.float64, device='cuda')
+    stats = stats_buf[:2 * rows * Cin].view(2, rows, Cin)
     out = torch.full((N, Lin, Cin), float('nan'), dtype=torch.bfloat16, device='cuda')
     CPO = (Cout + 31) // 32 * 32
     wd, ypd, dv = pack_phases(w, CPO), yp.to(torch.bfloat16).cuda(), [t.cuda() for t in (psc, psh, pmean, pinv)]
+    # ... and, given a ticket word, the fold of those sums by the workgroup that finishes last
+    gamma = torch.rand(Cin, generator=g) + 0.5
+    gd, ticket, dgb, coef = gamma.cuda(), torch.zeros(1 + ng, dtype=torch.int32, device='cuda'), torch.zeros(2, Cin, device='cuda'), \
+        torch.full((3, Cin), float('nan'), device='cuda')
     L.check(lib.s2ag_wave_conv_dgrad(_p(args['dz']), _p(args['y']), _p(args['ca']), _p(args['cb']), _p(args['cc']), int(g_f32),
-                                     _p(wd), CPO, _p(ypd), _p(dv[0]), _p(dv[1]), _p(dv[2]), _p(dv[3]), 0.3, _p(out), _p(stats),
+                                     _p(wd), CPO, _p(ypd), _p(dv[0]), _p(dv[1]), _p(dv[2]), _p(dv[3]), 0.3, _p(out), _p(stats_buf),
+                                     _p(ticket), _p(gd), _p(dgb[0]), _p(dgb[1]), _p(coef[0]), _p(coef[1]), _p(coef[2]),
                                      N, Lin, Lout, Cin, Cout, _stream()), 'wave_conv_dgrad')
     torch.cuda.synchronize()
+    assert int(ticket.abs().sum()) == 0                                      # re-armed
+    m1, m2 = stats[0].sum(0).cpu() / (N * Lin), stats[1].sum(0).cpu() / (N * Lin)
+    gm, rr, mu = gamma.double(), pinv.double(), pmean.double()
+    assert torch.allclose(dgb[0].cpu().double(), stats[1].sum(0).cpu(), rtol=1e-5, atol=1e-6)      # dgamma = sum dz xhat
+    assert torch.allclose(dgb[1].cpu().double(), stats[0].sum(0).cpu(), rtol=1e-5, atol=1e-6)      # dbeta = sum dz
+    assert torch.allclose(coef[0].cpu().double(), gm * rr, rtol=1e-6)
+    assert torch.allclose(coef[2].cpu().double(), -gm * rr * rr * m2, rtol=1e-5, atol=1e-9)
+    assert torch.allclose(coef[1].cpu().double(), gm * rr * (rr * mu * m2 - m1), rtol=1e-5, atol=1e-9)
     assert rel(out, want) < 6e-3
     s1, s2 = stats[0].sum(0).cpu(), stats[1].sum(0).cpu()
     w1, w2 = want.double().reshape(-1, Cin).sum(0), (want.double() * xhat.double()).reshape(-1, Cin).sum(0)
@@ -204,7 +237,8 @@ def test_bn_backward_fold_and_conv1_weight_gradient():
     geom = L.ConvGeom(N, Lin, Lout, 1, 16, 15, 5, 1600, 1, 1, 16, 0)
     dw, db = torch.zeros(16, 1, 15, device='cuda'), torch.zeros(16, device='cuda')
     dzd, yd, xd = dz.to(torch.bfloat16).cuda(), y.to(torch.bfloat16).cuda(), x.cuda()
-    L.check(lib.s2ag_wave_conv1_wgrad(_p(dzd), _p(yd), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(xd), _p(dw), _p(db),
+    part1 = torch.full((lib.s2ag_wave_conv1_wgrad_blocks(ctypes.byref(geom)) * 256,), float('nan'), device='cuda')
+    L.check(lib.s2ag_wave_conv1_wgrad(_p(dzd), _p(yd), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(xd), _p(part1), _p(dw), _p(db),
                                       ctypes.byref(geom), _stream()), 'wave_conv1_wgrad')
     dyf = dy.float().reshape(N, Lout, C)
     want = torch.nn.grad.conv1d_weight(x.unsqueeze(1), (16, 1, 15), dyf.transpose(1, 2), stride=5, padding=1600)
