@@ -157,16 +157,51 @@ def _bn(sd: SD, p: str, x: Tensor, training: bool) -> Tensor:
                         training, 0.1, 1e-5)
 
 
+# ---- branch decisions of the piecewise-linear activations --------------------------------------------------------------
+# An activation input within rounding distance of its kink may legitimately land on different sides in two correct
+# implementations (another summation order is enough), and ONE flipped element moves a gradient by far more than any
+# rounding error.  ``with use_signs({site: bool tensor}):`` makes every named ReLU / LeakyReLU site take the branches recorded
+# there (True = the positive side) instead of deciding from its own input -- the parity tests record them from the product's
+# outputs, so both sides differentiate the SAME piecewise-linear function and gradients can be compared strictly.
+# Site names: '<BatchNorm prefix>' for BN + activation pairs (e.g. 'audio_encoder.batch_norm1.'), '<prefix>linear1.',
+# '<prefix>tcn.<i>.relu1|relu2|relu3', '<prefix>st_gcn<k>.tcn.0.' / '<prefix>st_gcn<k>.out', 'out.1.'.
+_SIGNS: List[Optional[Dict[str, Tensor]]] = [None]
+
+
+class use_signs:
+    def __init__(self, signs: Optional[Dict[str, Tensor]]):
+        self.signs = signs
+        self.used: List[str] = []
+
+    def __enter__(self):
+        self.prev = _SIGNS[0]
+        _SIGNS[0] = self
+        return self
+
+    def __exit__(self, *a):
+        _SIGNS[0] = self.prev
+
+
+def _act(x: Tensor, slope: float, name: str) -> Tensor:
+    ctx = _SIGNS[0]
+    if ctx is not None and ctx.signs is not None and name in ctx.signs:
+        m = ctx.signs[name]
+        assert m.shape == x.shape and m.dtype == torch.bool, (name, m.shape, x.shape)
+        ctx.used.append(name)
+        return torch.where(m, x, x * slope)
+    return F.leaky_relu(x, slope) if slope != 0.0 else F.relu(x)
+
+
 def wav_encoder(sd: SD, p: str, wav: Tensor, training: bool) -> Tensor:
     """WavEncoder (net/multimodal_context_net_v2.py:14-33): (B, n_samples) -> (B, frames, 32)."""
     fe = p + 'feat_extractor.'
     x = wav.unsqueeze(1)
     x = F.conv1d(x, sd[fe + '0.weight'], sd[fe + '0.bias'], stride=5, padding=1600)
-    x = F.leaky_relu(_bn(sd, fe + '1.', x, training), 0.3)
+    x = _act(_bn(sd, fe + '1.', x, training), 0.3, fe + '1.')
     x = F.conv1d(x, sd[fe + '3.weight'], sd[fe + '3.bias'], stride=6)
-    x = F.leaky_relu(_bn(sd, fe + '4.', x, training), 0.3)
+    x = _act(_bn(sd, fe + '4.', x, training), 0.3, fe + '4.')
     x = F.conv1d(x, sd[fe + '6.weight'], sd[fe + '6.bias'], stride=6)
-    x = F.leaky_relu(_bn(sd, fe + '7.', x, training), 0.3)
+    x = _act(_bn(sd, fe + '7.', x, training), 0.3, fe + '7.')
     x = F.conv1d(x, sd[fe + '9.weight'], sd[fe + '9.bias'], stride=6)
     return x.transpose(1, 2)
 
@@ -177,8 +212,8 @@ def mfcc_encoder(sd: SD, p: str, mfcc: Tensor, training: bool) -> Tensor:
     x = mfcc.permute(0, 2, 1)
     for i, pad in ((1, 2), (2, 2), (3, 1), (4, 1)):
         x = F.conv1d(x, sd[f'{p}conv{i}.weight'], sd[f'{p}conv{i}.bias'], padding=pad)
-        x = F.leaky_relu(_bn(sd, f'{p}batch_norm{i}.', x, training), 0.3)
-    return F.leaky_relu(F.linear(x, sd[p + 'linear1.weight'], sd[p + 'linear1.bias']), 0.3)
+        x = _act(_bn(sd, f'{p}batch_norm{i}.', x, training), 0.3, f'{p}batch_norm{i}.')
+    return _act(F.linear(x, sd[p + 'linear1.weight'], sd[p + 'linear1.bias']), 0.3, p + 'linear1.')
 
 
 def weight_norm_weight(g: Tensor, v: Tensor) -> Tensor:
@@ -196,12 +231,12 @@ def temporal_block(sd: SD, p: str, x: Tensor, dilation: int, training: bool, dro
         k = w.shape[2]
         pad = (k - 1) * dilation
         out = F.conv1d(out, w, sd[f'{p}{tag}.bias'], padding=pad, dilation=dilation)
-        out = F.relu(out[:, :, :-pad])
+        out = _act(out[:, :, :-pad], 0.0, f'{name}.relu{j}')
         if training:
             out = noise.dropout(f'{name}.drop{j}', out, drop_p)
     if (p + 'downsample.weight') in sd:
         x = F.conv1d(x, sd[p + 'downsample.weight'], sd[p + 'downsample.bias'])
-    return F.relu(out + x)
+    return _act(out + x, 0.0, f'{name}.relu3')
 
 
 def text_encoder_tcn(sd: SD, p: str, ids: Tensor, training: bool, drop_p: float, noise: Noise,
@@ -230,11 +265,11 @@ def st_graph_conv(sd: SD, p: str, x: Tensor, A: Tensor, training: bool) -> Tenso
     n, kc, t, v = g.shape
     K = A.shape[0]
     g = torch.einsum('nkctv,kvw->nctw', g.view(n, K, kc // K, t, v), A)
-    h = F.relu(_bn(sd, p + 'tcn.0.', g, training))
+    h = _act(_bn(sd, p + 'tcn.0.', g, training), 0.0, p + 'tcn.0.')
     wt = sd[p + 'tcn.2.weight']
     h = F.conv2d(h, wt, sd[p + 'tcn.2.bias'], padding=(wt.shape[2] // 2, wt.shape[3] // 2))
     h = _bn(sd, p + 'tcn.3.', h, training)
-    return F.leaky_relu(h + res, 0.01)
+    return _act(h + res, 0.01, p + 'out')
 
 
 def aff_encoder(sd: SD, p: str, poses: Tensor, training: bool) -> Tensor:
@@ -253,9 +288,9 @@ def aff_encoder(sd: SD, p: str, poses: Tensor, training: bool) -> Tensor:
     c2 = f2.shape[1]
     f2 = _bn(sd, p + 'batch_norm2.', f2.permute(0, 1, 3, 2).reshape(n, c2 * N_BODY_PARTS, t), training)
     x3 = F.conv1d(f2, sd[p + 'conv3.weight'], sd[p + 'conv3.bias'], padding=sd[p + 'conv3.weight'].shape[2] // 2)
-    x3 = F.leaky_relu(_bn(sd, p + 'batch_norm3.', x3, training), 0.01)
+    x3 = _act(_bn(sd, p + 'batch_norm3.', x3, training), 0.01, p + 'batch_norm3.')
     x4 = F.conv1d(x3, sd[p + 'conv4.weight'], sd[p + 'conv4.bias'], padding=sd[p + 'conv4.weight'].shape[2] // 2)
-    x4 = F.leaky_relu(_bn(sd, p + 'batch_norm4.', x4, training), 0.01)
+    x4 = _act(_bn(sd, p + 'batch_norm4.', x4, training), 0.01, p + 'batch_norm4.')
     return x4.permute(0, 2, 1)
 
 
@@ -346,7 +381,7 @@ def _decode(sd: SD, cfg_drop: float, in_data: Tensor, training: bool, noise: Noi
     H = y.shape[2] // 2
     y = y[:, :, :H] + y[:, :, H:]
     y = F.linear(y, sd['out.0.weight'], sd['out.0.bias'])
-    y = F.leaky_relu(y, out_slope)
+    y = _act(y, out_slope, 'out.1.') if out_slope != 1.0 else y
     return F.linear(y, sd['out.2.weight'], sd['out.2.bias'])
 
 

@@ -149,6 +149,52 @@ def test_text_encoder_passes_in_lockstep_equal_separate_passes(B):
         assert rel(a, b) < 1e-5
 
 
+@pytest.mark.parametrize('which,hidden,n_words,B', [('G', 300, 2000, 88), ('G', 300, 2000, 128), ('GA', 300, 2000, 88)])
+def test_full_width_gradients_strictly_with_the_products_branch_decisions(which, hidden, n_words, B):
+    """Forward and EVERY parameter gradient of the full-width generators (H = 300; B = 88: five full cooperative-GRU slices
+    and a ragged one; B = 128: the bench's batch) against the oracle -- strictly.  At this width a few of the ~10^7 ReLU /
+    LeakyReLU inputs of a pass lie within rounding distance of zero and two correct implementations may take different
+    sides there; so the oracle is told which side the PRODUCT took at every such site (s2ag_testing.SignTap records it from
+    the product's own outputs, oracle.use_signs replays it), both then differentiate the same piecewise-linear function,
+    and every gradient tensor must agree to 1e-3 of its largest element -- a wrong index in a ragged slice can no longer
+    hide behind a statistical criterion."""
+    from speech2affective_gestures_amd import noise, ops
+    from s2ag_testing import SignTap
+    n_spk, s0 = 12, 5000
+    cfg, mods, sds = build_product(hidden, n_words, n_spk, 0.3, s0, which=(which,))
+    G = mods[which].train()
+    inp = O.recipe_inputs(B, 34, s0 + 10, n_words, n_spk)
+    gi = to_cuda(inp)
+    pre_seq = O.make_pre_seq(inp['target'], 4)
+    noise.manual_seed(77)
+    nz = torch.tensor([77, 0], dtype=torch.int64, device='cuda')
+    audio_in = gi['in_mfcc'] if which == 'G' else gi['in_audio']
+    with SignTap(G) as tap:
+        out, z, mu, lv = G(pre_seq.cuda(), gi['in_text'], audio_in, gi['vid'])
+    signs = tap.signs()
+    pin = _g_noise(G, nz, B, 34, hidden, 0.3, 0.1)
+    sd = {k: (v.clone().requires_grad_(True) if O.is_param(k) and '.net.' not in k else v.clone())
+          for k, v in sds[which].items()}
+    fn = O.pose_generator if which == 'G' else O.pose_generator_abl_audio
+    with O.use_signs(signs) as used:
+        o_r, z_r, mu_r, lv_r = fn(sd, oracle_cfg(hidden, 0.3), pre_seq, inp['in_text'],
+                                  inp['in_mfcc'] if which == 'G' else inp['in_audio'], inp['vid'], True, O.Noise(pin))
+    assert set(used.used) == set(signs), set(signs) ^ set(used.used)           # every recorded site was consumed
+    assert len(signs) == (5 if which == 'G' else 3) + 12 + 6 + 1
+    assert rel(out, o_r) < TOL and rel(z, z_r) < TOL and rel(mu, mu_r) < TOL and rel(lv, lv_r) < TOL
+    gen = torch.Generator().manual_seed(1)
+    d_out, d_mu = torch.randn(o_r.shape, generator=gen), torch.randn(mu_r.shape, generator=gen)
+    (o_r * d_out).sum().add((mu_r * d_mu).sum()).add((lv_r * d_mu).sum()).backward()
+    (out * d_out.cuda()).sum().add((mu * d_mu.cuda()).sum()).add((lv * d_mu.cuda()).sum()).backward()
+    errs = {k: grad_err(p.grad, sd[k].grad, k) for k, p in G.named_parameters() if '.net.' not in k}
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f'[strict grad parity {which} H={hidden} B={B}] out {rel(out, o_r):.2e}; worst gradients (max-norm): ' +
+          ', '.join(f'{k} {v:.2e}' for k, v in top))
+    for k, e in errs.items():
+        assert e < 1e-3, (k, e)
+    assert ops.coop_gru_timeouts() == 0
+
+
 @pytest.mark.parametrize('which,hidden,n_words,B', [('G', 32, 64, 3), ('GA', 32, 64, 3), ('G', 300, 2000, 88)])
 def test_generator_train_mode_with_dropout_forward_and_all_gradients(which, hidden, n_words, B):
     """Forward and every parameter gradient against the oracle fed the product's materialised masks.  The H = 300,
