@@ -527,6 +527,72 @@ int s2ag_wave_conv1_wgrad_blocks(const s2ag_conv_geom* g);
 int s2ag_wave_conv1_wgrad(const void* dz, const void* y1, const float* ca, const float* cb, const float* cc, const float* x,
                           float* partials, float* dw, float* db, const s2ag_conv_geom* g, void* stream);
 
+/* ---- head of the wave encoder without its (N, L1, 16) tensor in HBM (csrc/wave12.hip) ---------------------------------
+ * Replaces feat_extractor[0..3] of WavEncoder (net/multimodal_context_net_v2.py:18-21: Conv1d(1,16,15,stride 5,padding)
+ * BatchNorm1d(16) LeakyReLU(0.3) Conv1d(16,32,15,stride 6)) in training mode, forward and backward: conv1's output is
+ * recomputed from the waveform wherever it is needed (BatchNorm statistics, conv2's forward, conv2's two gradients,
+ * BatchNorm's backward, conv1's weight gradient) instead of being stored.  L1 = (Lin + 2 pad - 15) / 5 + 1,
+ * L2 = (L1 - 15) / 6 + 1.  `packed`: s2ag_wave12_pack_elems() bf16 elements written by s2ag_wave12_pack from the fp32
+ * weights w1 (16, 1, 15) and w2 (32, 16, 15) (once per optimizer step).
+ *   s2ag_wave12_stats  column sums of z1 / z1^2 -> BatchNorm 1's running estimates and scale / shift / mean / invstd
+ *                      (fold, done by the workgroup that finishes last); partials: (2, rows + ceil(rows / 16), 16) doubles
+ *                      with rows = s2ag_wave12_stats_rows, fold->ticket: 1 + ceil(rows / 16) zero words (left zero).
+ *                      round_bf16: statistics of the bf16-rounded z1 (bf16 mode).
+ *   s2ag_wave12_fwd    z2 (N, L2, 32) = conv2(leaky(scale1 z1 + shift1)) + b2 as bf16 (out_f32 = 0; bf16 mode: z1, the
+ *                      activation and z2 rounded to bf16, one bf16 product) or fp32 (out_f32 = 1: nothing rounded, operands
+ *                      as two bf16 pieces, three products); partials (nullable): (2, rows (+ ceil(rows / 16)), 32) doubles,
+ *                      rows = s2ag_wave12_fwd_rows: column sums of z2 / z2^2; fold (nullable): BatchNorm 2's fold in the
+ *                      same launch.
+ *   s2ag_wave12_bwd    from dy2 = the gradient w.r.t. z2 -- fp32 rows (dz_f32 = 1) or, in bf16 mode, ca2 dz + cc2 z2 + cb2
+ *                      formed from the bf16 rows dz / z2 (wave_fused.hip) --: dw2 (32, 16, 15) +=,
+ *                      dw1 (16, 1, 15) += (each nullable), dgamma1 / dbeta1 += (nullable), and ca1 / cb1 / cc1 (16 each:
+ *                      dz1 = ca1 du1 + cc1 z1 + cb1, kept for inspection).  0 <= slope <= 1.  The gradients of the two biases are identically
+ *                      zero (each feeds a BatchNorm) and are not formed.  Scratch, with b = s2ag_wave12_bwd_blocks(N, L1, dz_f32):
+ *                      part_w2 b * 7680 floats, part_s (b + ceil(b / 16)) * 528, stats
+ *                      (2, b + ceil(b / 16), 16) doubles, ticket 1 + ceil(b / 16) zero words (left zero). */
+typedef struct s2ag_wave12_bwd_args {
+    const float* x;                   /* (N, Lin) waveform */
+    const void* packed;
+    const float* b1;                  /* conv1 bias (16) */
+    const float* scale1;              /* BatchNorm 1: scale, shift, mean, invstd of the forward pass; gamma */
+    const float* shift1;
+    const float* mean1;
+    const float* invstd1;
+    const float* gamma1;
+    float slope;
+    const void* dz;
+    int dz_f32;
+    const void* z2;
+    const float* ca2;
+    const float* cb2;
+    const float* cc2;
+    float* part_w2;
+    float* part_s;
+    double* stats;
+    int* ticket;
+    float* dgamma1;
+    float* dbeta1;
+    float* ca1;
+    float* cb1;
+    float* cc1;
+    float* dw2;
+    float* dw1;
+    int N, Lin, L1, L2, pad;
+} s2ag_wave12_bwd_args;
+int s2ag_wave12_pack_elems(void);
+int s2ag_wave12_pack(const float* w1, const float* w2, void* packed, void* stream);
+int s2ag_wave12_stats_rows(int N, int L1);
+int s2ag_wave12_stats(const float* x, const void* packed, const float* b1, double* partials, const s2ag_bn_fold_args* fold,
+                      int round_bf16, int N, int Lin, int L1, int pad, void* stream);
+int s2ag_wave12_fwd_rows(int N, int L2);
+int s2ag_wave12_fwd(const float* x, const void* packed, const float* b1, const float* scale1, const float* shift1, float slope,
+                    const float* b2, void* z2, int out_f32, double* partials, const s2ag_bn_fold_args* fold, int N, int Lin,
+                    int L1, int L2, int pad, void* stream);
+int s2ag_wave12_bwd_blocks(int N, int L1, int dz_f32);
+/* tests / diagnostics: at most `cap` workgroups in s2ag_wave12_bwd (0: the default, 2 per CU); returns the previous value */
+int s2ag_wave12_set_bwd_block_cap(int cap);
+int s2ag_wave12_bwd(const s2ag_wave12_bwd_args* a, void* stream);
+
 /* ---- clip-resident TemporalConvNet in bf16 mode (csrc/tcn_fused.hip) ----------------------------------------------
  * Replaces the whole stack of TemporalBlocks of net/tcn.py:16-64 (conv1 -> chomp -> ReLU -> dropout -> conv2 -> chomp ->
  * ReLU -> dropout, + residual, ReLU; kernel size 2, dilations dil[b], in == out channels C <= 320) by ONE launch

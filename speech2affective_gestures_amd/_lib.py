@@ -58,6 +58,14 @@ class BnFoldArgs(C.Structure):    # s2ag_bn_fold_args
                 ('mean', vp), ('invstd', vp)]
 
 
+class Wave12Bwd(C.Structure):     # s2ag_wave12_bwd_args
+    _fields_ = [('x', vp), ('packed', vp), ('b1', vp), ('scale1', vp), ('shift1', vp), ('mean1', vp), ('invstd1', vp),
+                ('gamma1', vp), ('slope', cf), ('dz', vp), ('dz_f32', ci), ('z2', vp), ('ca2', vp), ('cb2', vp), ('cc2', vp),
+                ('part_w2', vp), ('part_s', vp), ('stats', vp), ('ticket', vp),
+                ('dgamma1', vp), ('dbeta1', vp), ('ca1', vp), ('cb1', vp), ('cc1', vp), ('dw2', vp), ('dw1', vp),
+                ('N', ci), ('Lin', ci), ('L1', ci), ('L2', ci), ('pad', ci)]
+
+
 class BF16PackJob(C.Structure):   # s2ag_bf16_pack_job
     _fields_ = [('src', vp), ('dst', vp), ('rows', ci), ('taps', ci), ('Cp', ci), ('cols', ci), ('tap0', ci),
                 ('tap_step', ci), ('src_taps', ci), ('s_o', cll), ('s_t', ci), ('s_c', ci), ('flat_cin', ci)]
@@ -168,6 +176,15 @@ SIGNATURES = {
     's2ag_wave_wgrad_blocks': [ci, ci, ci, ci],
     's2ag_wave_conv_wgrad': [vp, vp, vp, vp, vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     's2ag_wave_bn_bwd_fold': [vp, ci, ci, cll, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    's2ag_wave12_pack_elems': [],
+    's2ag_wave12_pack': [vp, vp, vp, vp],
+    's2ag_wave12_stats_rows': [ci, ci],
+    's2ag_wave12_stats': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    's2ag_wave12_fwd_rows': [ci, ci],
+    's2ag_wave12_fwd': [vp, vp, vp, vp, vp, cf, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp],
+    's2ag_wave12_bwd_blocks': [ci, ci, ci],
+    's2ag_wave12_set_bwd_block_cap': [ci],
+    's2ag_wave12_bwd': [vp, vp],
     's2ag_wave_conv1_wgrad_blocks': [PG],
     's2ag_wave_conv1_wgrad': [vp, vp, vp, vp, vp, vp, vp, vp, vp, PG, vp],
     's2ag_bf16_tcn_clips_per_block': [ci, ci, ci],

@@ -782,16 +782,28 @@ class _WaveFused16(torch.autograd.Function):
                               _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]))
             keep.append(fa)
             return coef, fa
-        y1 = torch.empty(N, L1, 16, dtype=torch.bfloat16, device=dev)
-        prow = lib.s2ag_wave_conv1_fwd_rows(C.byref(geom1))
-        part = torch.empty(2 * (prow + (prow + 15) // 16) * 16, dtype=torch.float64, device=dev)
-        coef, fa = fold_args(0, prow)
-        L.check(lib.s2ag_wave_conv1_fwd(_p(wav), _p(w1), _p(b1), _p(y1), C.byref(geom1), _p(part), C.byref(fa), _s()),
-                'wave_conv1_fwd')
-        ys, coefs = [y1], [coef]
+        from . import wave12
+        use12 = wave12.ENABLED and b1 is not None
+        if use12:
+            # conv1's (N, L1, 16) output never exists in HBM: statistics pass, then conv1 -> BatchNorm 1 -> conv2 in one
+            # launch; the backward pass recomputes it from the waveform (wave12.hip)
+            pk12 = wave12.packed_weights(w1, w2)
+            coef = wave12.stats(wav, pk12, b1, bns[0], g1, e1, True, pad1)
+            y2, _, _, coef2 = wave12.forward(wav, pk12, b1, coef, slope, b2, False, fold=(bns[1], g2, e2), pad=pad1)
+            ys, coefs = [pk12, y2], [coef, coef2]
+        else:
+            y1 = torch.empty(N, L1, 16, dtype=torch.bfloat16, device=dev)
+            prow = lib.s2ag_wave_conv1_fwd_rows(C.byref(geom1))
+            part = torch.empty(2 * (prow + (prow + 15) // 16) * 16, dtype=torch.float64, device=dev)
+            coef, fa = fold_args(0, prow)
+            L.check(lib.s2ag_wave_conv1_fwd(_p(wav), _p(w1), _p(b1), _p(y1), C.byref(geom1), _p(part), C.byref(fa), _s()),
+                    'wave_conv1_fwd')
+            ys, coefs = [y1], [coef]
         names = ('c3', 'c6', 'c9')
         bs = (b2, b3, b4)
         for k, (ci, co) in enumerate(_WAVE_LAYERS):
+            if use12 and k == 0:
+                continue
             last = k == 2
             w16 = pack.get(names[k], 'fwd')                         # (co, 1, KP)
             Lin, Lout = lens[k], lens[k + 1]
@@ -807,8 +819,8 @@ class _WaveFused16(torch.autograd.Function):
             if not last:
                 coefs.append(coef)
                 ys.append(y)
-        ctx.pack, ctx.slope, ctx.lens, ctx.params, ctx.pad1 = pack, float(slope), lens, params, pad1
-        ctx.save_for_backward(wav, *ys, *coefs)
+        ctx.pack, ctx.slope, ctx.lens, ctx.params, ctx.pad1, ctx.use12 = pack, float(slope), lens, params, pad1, use12
+        ctx.save_for_backward(wav, *ys, *coefs)             # ys[0]: conv1's output -- or, without it, the packed weights
         return y
 
     @staticmethod
@@ -836,7 +848,7 @@ class _WaveFused16(torch.autograd.Function):
         widx = (4, 8, 12)                                           # positions of w2, w3, w4 in params (bias = +1)
         gidx = (2, 6, 10)                                           # gamma of BatchNorm 1..3 (beta = +1)
         dz, yy, cabc = g, None, None                               # the operands of dy of the layer being processed
-        for k in (2, 1, 0):
+        for k in ((2, 1) if ctx.use12 else (2, 1, 0)):
             ci, co = _WAVE_LAYERS[k]
             Lin, Lout = lens[k], lens[k + 1]
             g_f32 = k == 2
@@ -868,6 +880,15 @@ class _WaveFused16(torch.autograd.Function):
                                              _p(cabc[0]), _p(cabc[1]), _p(cabc[2]), N, Lin, Lout, ci, co, _s()),
                     'wave_conv_dgrad')
             dz, yy = dzp, yp
+        if ctx.use12:
+            # conv2's two gradients, BatchNorm 1's backward and conv1's weight gradient: ONE launch over dy2 and the waveform
+            from . import wave12
+            slots = {'w1': slot(0), 'g1': slot(2), 'e1': slot(3), 'w2': slot(4)}
+            for i, b in ((1, b1), (5, b2)):                         # exactly zero: these biases feed a BatchNorm
+                if b is not None and ctx.needs_input_grad[4 + i] and ops._grad_slot(b) is None:
+                    grads[i] = torch.zeros_like(b)
+            wave12.backward(wav, y1, b1, c1, g1, slope, dz, yy, cabc, slots, ctx.pad1)
+            return (None, None, None, None) + tuple(grads)
         wslot, bslot = slot(0), slot(1)
         if wslot is not None:
             geom1 = L.ConvGeom(N, wav.shape[1], lens[0], 1, 16, 15, 5, ctx.pad1, 1, 1, 16, 0)

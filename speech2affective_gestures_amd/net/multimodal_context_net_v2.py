@@ -136,11 +136,16 @@ class WavEncoder(nn.Module):
         from .. import bf16
         if bf16.enabled() and self.training:
             return self._forward_bf16(wav_data)
+        from .. import wave12
         fe = self.feat_extractor
-        x = wav_data.unsqueeze(2)                                     # (B, L, 1) channels-last
-        x = ops.conv1d_nlc(x, fe[0].weight, fe[0].bias, stride=5, pad=1600, bn_stats=fe[1].training)
-        x = ops.batch_norm_act(x, fe[1], slope=0.3)
-        x = ops.conv1d_nlc(x, fe[3].weight, fe[3].bias, stride=6, tm_copy=True, bn_stats=fe[4].training)
+        if fe[1].training and fe[4].training and wav_data.is_cuda and wave12.supported(fe):
+            # conv1 -> BatchNorm -> LeakyReLU -> conv2 without conv1's (B, 7891, 16) output in HBM (csrc/wave12.hip)
+            x = wave12.head_f32(wav_data, fe)
+        else:
+            x = wav_data.unsqueeze(2)                                 # (B, L, 1) channels-last
+            x = ops.conv1d_nlc(x, fe[0].weight, fe[0].bias, stride=5, pad=1600, bn_stats=fe[1].training)
+            x = ops.batch_norm_act(x, fe[1], slope=0.3)
+            x = ops.conv1d_nlc(x, fe[3].weight, fe[3].bias, stride=6, tm_copy=True, bn_stats=fe[4].training)
         x = ops.batch_norm_act(x, fe[4], slope=0.3)
         x = ops.conv1d_nlc(x, fe[6].weight, fe[6].bias, stride=6, tm_copy=True, bn_stats=fe[7].training)
         x = ops.batch_norm_act(x, fe[7], slope=0.3)

@@ -246,7 +246,7 @@ def test_bn_backward_fold_and_conv1_weight_gradient():
     assert float(db.abs().max().cpu()) < 1e-3 * float(dyf.abs().sum(dim=(0, 1)).max())      # sum dy = 0 behind a BatchNorm
 
 
-@pytest.mark.parametrize('B', [3, 40])
+@pytest.mark.parametrize('B', [6, 40])
 def test_fused_wave_encoder_against_its_fp32_mode_and_the_layer_by_layer_bf16_path(B):
     """WavEncoder (train mode) in bf16 mode with the BatchNorms folded into the convs against (a) the same module in fp32
     mode and (b) the layer-by-layer bf16 path (S2AG_WAVE_FUSED=0): output, every parameter gradient, running statistics.
