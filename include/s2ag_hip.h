@@ -584,6 +584,10 @@ int s2ag_wave12_pack(const float* w1, const float* w2, void* packed, void* strea
 int s2ag_wave12_stats_rows(int N, int L1);
 int s2ag_wave12_stats(const float* x, const void* packed, const float* b1, double* partials, const s2ag_bn_fold_args* fold,
                       int round_bf16, int N, int Lin, int L1, int pad, void* stream);
+/* parity tests / diagnostics: signs (N, L1, 16) bytes = 1 where scale1 z1 + shift1 > 0 -- the branch every LeakyReLU(0.3)
+ * behind BatchNorm 1 takes inside s2ag_wave12_fwd / s2ag_wave12_bwd (z1 is formed by the same instructions) */
+int s2ag_wave12_act_signs(const float* x, const void* packed, const float* b1, const float* scale1, const float* shift1,
+                          int round_bf16, unsigned char* signs, int N, int Lin, int L1, int pad, void* stream);
 int s2ag_wave12_fwd_rows(int N, int L2);
 int s2ag_wave12_fwd(const float* x, const void* packed, const float* b1, const float* scale1, const float* shift1, float slope,
                     const float* b2, void* z2, int out_f32, double* partials, const s2ag_bn_fold_args* fold, int N, int Lin,

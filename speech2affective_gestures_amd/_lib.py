@@ -180,6 +180,7 @@ SIGNATURES = {
     's2ag_wave12_pack': [vp, vp, vp, vp],
     's2ag_wave12_stats_rows': [ci, ci],
     's2ag_wave12_stats': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    's2ag_wave12_act_signs': [vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, vp],
     's2ag_wave12_fwd_rows': [ci, ci],
     's2ag_wave12_fwd': [vp, vp, vp, vp, vp, cf, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp],
     's2ag_wave12_bwd_blocks': [ci, ci, ci],

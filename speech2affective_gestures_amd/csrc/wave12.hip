@@ -22,13 +22,16 @@
 // last kernel combines them.  Both biases feed a BatchNorm: their gradients are exactly zero (the column sums of a
 // BatchNorm's input gradient vanish identically) and are not formed.
 //
-// conv1 itself is an MFMA here (16 channels x 16 frames x 16 taps, v_mfma_f32_16x16x16_bf16): the waveform and the weights
-// enter as two bf16 pieces each (hi = rn(v), lo = rn(v - hi); hi*lo + lo*hi + hi*hi in fp32: 16 mantissa bits per product,
-// the precision of the step's other large products), 4 LDS reads per lane and tile instead of 60 multiply-adds.  The three
-// kernels form z1 with the same instruction on the same operands, so they see bit-identical values.
+// conv1 itself is an MFMA here (16 channels x 16 frames x 16 taps; fp32 mode: four v_mfma_f32_16x16x4_f32 -- fp32 in, fp32
+// out, the arithmetic of an fmaf chain --; bf16 mode, where z1 is rounded to bf16 anyway: three v_mfma_f32_16x16x16_bf16 on two
+// bf16 pieces per operand): 4 LDS reads per lane and tile instead of 60 multiply-adds.  The kernels of a mode form z1 with the
+// same instructions on the same operands, so they see bit-identical values.
 //
-// NP = 1: bf16 mode (z1, a1, z2 rounded to bf16 as the layer-by-layer kernels of wave_fused.hip store them; one product per
-// MFMA pair); NP = 2: fp32 mode (nothing rounded; a1, dy2 and conv2's weights as two bf16 pieces, three products).
+// NP = 1: bf16 mode (z1, a1, z2 rounded to bf16 as the layer-by-layer kernels of wave_fused.hip store them; conv2 and the
+// backward products on v_mfma_f32_16x16x32_bf16).  NP = 2: fp32 mode: the FORWARD pass (conv1, conv2) runs on the f32 MFMA --
+// the reference's fp32 arithmetic, so activations and branch decisions are those of the layer-by-layer fp32 kernels --, the
+// backward products take their operands as two bf16 pieces (hi = rn(v), lo = rn(v - hi); hi*lo + lo*hi + hi*hi in fp32: 16
+// mantissa bits per product, the precision of the step's other large gradient products, bench.py `matrix_products`).
 #include <type_traits>
 
 #include "s2ag_common.h"
@@ -52,10 +55,14 @@ constexpr int C1 = 16, C2 = 32;   // channels of z1 / z2
 constexpr int NT = 3;             // taps per phase of conv2's poly-phase form
 constexpr int K2P = 256;          // 15 * 16 padded to MFMA K tiles
 // packed weights (bf16 elements, every section two piece planes: hi then lo)
-constexpr int O_W1 = 0;                           // [2][16 c][16 t]          t = 15: zero
-constexpr int O_W2F = O_W1 + 2 * C1 * 16;         // [2][32 co][256 k]        k = t * 16 + ci, zero from 240
+constexpr int O_W2F = 0;                          // [2][32 co][256 k]        k = t * 16 + ci, zero from 240
 constexpr int O_W2P = O_W2F + 2 * C2 * K2P;       // [2][6 r][16 ci][3 i][32 co] = W2[co][ci][r + 6 i], zero where r + 6 i >= 15
-constexpr int W12_PACK = O_W2P + 2 * S2 * C1 * NT * C2;
+// ... and fp32 copies for the forward products on the f32 MFMA, k-major so that a wave-level load is one contiguous run
+// (offsets in bf16 elements: an fp32 value takes two)
+constexpr int O_W1F = O_W2P + 2 * S2 * C1 * NT * C2;   // fp32 [16 t][16 c]   t = 15: zero
+constexpr int O_W2K = O_W1F + 2 * 16 * C1;             // fp32 [240 k][32 co]  k = t * 16 + ci
+constexpr int O_W1 = O_W2K + 2 * KS * C1 * C2;         // bf16 [2][16 c][16 t]  t = 15: zero (conv1 of bf16 mode)
+constexpr int W12_PACK = O_W1 + 2 * C1 * 16;
 
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
@@ -66,42 +73,91 @@ __device__ __forceinline__ float bf_round(float v) { return bf_lo(bf_pack(v, 0.f
 // what the hi piece leaves: exact in fp32
 __device__ __forceinline__ unsigned bf_pack_rest(float a, float b, unsigned hi) { return bf_pack(a - bf_lo(hi), b - bf_hi(hi)); }
 
-__device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ bf16x8 ld8(const bf16_t* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p)); }
 
-// z1 of 16 frames x 16 channels: lane (n = lane & 15, g = lane >> 4) passes the four samples under taps 4 g .. 4 g + 3 of
-// ITS frame's window (sp = first of them in LDS) and receives channels 4 g + v of that frame.  wh / wl: W1[c = n][4 g ..].
-__device__ __forceinline__ f32x4 conv1_tile(const float* sp, s16x4 wh, s16x4 wl, f32x4 bias, float (&xv)[4]) {
+// z1 of 16 frames x 16 channels on the f32 MFMA (v_mfma_f32_16x16x4_f32, bit-for-bit an fmaf chain: the forward pass of fp32
+// mode keeps the reference's arithmetic, and no vector-ALU work goes into operand splitting): lane (n = lane & 15, g = lane >> 4)
+// passes taps g, 4 + g, 8 + g, 12 + g of ITS frame's window (sp = &window[g] in LDS) and receives channels 4 g + v of that
+// frame.  w[kb] = W1[c = n][4 kb + g] (tap 15: zero).  All three kernels form z1 this way: bit-identical values.
+__device__ __forceinline__ f32x4 conv1_tile(const float* sp, const float (&w)[4], f32x4 bias) {
+    f32x4 acc = bias;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xv[j] = sp[j];
-    const unsigned h0 = bf_pack(xv[0], xv[1]), h1 = bf_pack(xv[2], xv[3]);
-    const unsigned l0 = bf_pack_rest(xv[0], xv[1], h0), l1 = bf_pack_rest(xv[2], xv[3], h1);
+    for (int kb = 0; kb < 4; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kb], sp[4 * kb], acc, 0, 0, 0);
+    return acc;
+}
+// bf16 mode rounds z1 to bf16 anyway: there conv1 runs on v_mfma_f32_16x16x16_bf16 from two bf16 pieces per operand (hi =
+// rn(v), lo = rn(v - hi); lo*hi + hi*lo + hi*hi: 16 mantissa bits), 24 MFMA cycles per tile instead of 128.  Lane (n, g) passes
+// the samples under taps 4 g .. 4 g + 3 (sp = &window[4 g]) -- or, pre-split, words hi | lo << 16 (conv1_tile_sp).
+__device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 conv1_tile2(const float* sp, s16x4 wh, s16x4 wl, f32x4 bias) {
+    const float x0 = sp[0], x1 = sp[1], x2 = sp[2], x3 = sp[3];
+    const unsigned h0 = bf_pack(x0, x1), h1 = bf_pack(x2, x3);
+    const unsigned l0 = bf_pack_rest(x0, x1, h0), l1 = bf_pack_rest(x2, x3, h1);
     const s16x4 xh = __builtin_bit_cast(s16x4, u32x2{h0, h1}), xl = __builtin_bit_cast(s16x4, u32x2{l0, l1});
     f32x4 acc = mfma16(wl, xh, bias);
     acc = mfma16(wh, xl, acc);
     return mfma16(wh, xh, acc);
+}
+__device__ __forceinline__ f32x4 conv1_tile_sp(const unsigned* sp, s16x4 wh, s16x4 wl, f32x4 bias) {
+    const unsigned w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3];
+    const s16x4 xh = __builtin_bit_cast(s16x4, u32x2{__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u)});
+    const s16x4 xl = __builtin_bit_cast(s16x4, u32x2{__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u)});
+    f32x4 acc = mfma16(wl, xh, bias);
+    acc = mfma16(wh, xl, acc);
+    return mfma16(wh, xh, acc);
+}
+// conv1's weights of a lane, for either form
+struct W1Regs {
+    float f[4];
+    s16x4 h, l;
+};
+template <bool BF>
+__device__ __forceinline__ W1Regs load_w1(const bf16_t* wp, int n, int g) {
+    W1Regs w{};
+    if (BF) {
+        w.h = *reinterpret_cast<const s16x4*>(wp + O_W1 + n * 16 + 4 * g);
+        w.l = *reinterpret_cast<const s16x4*>(wp + O_W1 + C1 * 16 + n * 16 + 4 * g);
+    } else {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) w.f[kb] = reinterpret_cast<const float*>(wp + O_W1F)[(4 * kb + g) * C1 + n];
+    }
+    return w;
+}
+// win = the window of this lane's frame in an fp32 segment
+template <bool BF>
+__device__ __forceinline__ f32x4 conv1_any(const float* win, int g, const W1Regs& w, f32x4 bias) {
+    if (BF) return conv1_tile2(win + 4 * g, w.h, w.l, bias);
+    return conv1_tile(win + g, w.f, bias);
 }
 
 // ---- weights: fp32 masters -> the three operand layouts, two pieces each ---------------------------------------------------
 __global__ __launch_bounds__(256) void wv12_pack_k(const float* __restrict__ w1, const float* __restrict__ w2,
                                                    bf16_t* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    constexpr int n1 = C1 * 16, n2 = C2 * K2P, n3 = S2 * C1 * NT * C2;
+    constexpr int n2 = C2 * K2P, n3 = S2 * C1 * NT * C2, n4 = 16 * C1, n5 = KS * C1 * C2;
     float v = 0.f;
     int dst, plane;
-    if (i < n1) {
-        const int c = i / 16, t = i % 16;
-        if (t < KS) v = w1[c * KS + t];
-        dst = O_W1 + i; plane = n1;
-    } else if (i < n1 + n2) {
-        const int j = i - n1, co = j / K2P, k = j % K2P, t = k / C1, ci = k % C1;
+    if (i < n2) {
+        const int co = i / K2P, k = i % K2P, t = k / C1, ci = k % C1;
         if (t < KS) v = w2[(co * C1 + ci) * KS + t];
-        dst = O_W2F + j; plane = n2;
-    } else if (i < n1 + n2 + n3) {
-        const int j = i - n1 - n2, co = j % C2, ii = (j / C2) % NT, ci = (j / (C2 * NT)) % C1, r = j / (C2 * NT * C1);
+        dst = O_W2F + i; plane = n2;
+    } else if (i < n2 + n3) {
+        const int j = i - n2, co = j % C2, ii = (j / C2) % NT, ci = (j / (C2 * NT)) % C1, r = j / (C2 * NT * C1);
         if (r + S2 * ii < KS) v = w2[(co * C1 + ci) * KS + r + S2 * ii];
         dst = O_W2P + j; plane = n3;
+    } else if (i < n2 + n3 + n4) {
+        const int j = i - n2 - n3, t = j / C1, c = j % C1;
+        reinterpret_cast<float*>(out + O_W1F)[j] = t < KS ? w1[c * KS + t] : 0.f;
+        return;
+    } else if (i < n2 + n3 + n4 + n5) {
+        const int j = i - n2 - n3 - n4, k = j / C2, co = j % C2, t = k / C1, ci = k % C1;
+        reinterpret_cast<float*>(out + O_W2K)[j] = w2[(co * C1 + ci) * KS + t];
+        return;
+    } else if (i < n2 + n3 + n4 + n5 + n4) {
+        const int j = i - n2 - n3 - n4 - n5, c = j / 16, t = j % 16;
+        if (t < KS) v = w1[c * KS + t];
+        dst = O_W1 + j; plane = n4;
     } else {
         return;
     }
@@ -109,6 +165,7 @@ __global__ __launch_bounds__(256) void wv12_pack_k(const float* __restrict__ w1,
     out[dst] = (bf16_t)(h & 0xffffu);
     out[dst + plane] = (bf16_t)(bf_pack(v - bf_lo(h), 0.f) & 0xffffu);
 }
+constexpr int W12_PACK_THREADS = C2 * K2P + S2 * C1 * NT * C2 + 16 * C1 + KS * C1 * C2 + 16 * C1;
 
 // =====================================================================================================================
 // statistics of z1
@@ -132,8 +189,7 @@ __global__ __launch_bounds__(256) void wv12_stats_k(const W12StatsP p) {
     __shared__ double red[4][2][C1];
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const s16x4 wh = *reinterpret_cast<const s16x4*>(p.wp + O_W1 + n * 16 + 4 * g);
-    const s16x4 wl = *reinterpret_cast<const s16x4*>(p.wp + O_W1 + C1 * 16 + n * 16 + 4 * g);
+    const W1Regs w1r = load_w1<RB>(p.wp, n, g);
     const f32x4 bias = f32x4{p.b1[4 * g], p.b1[4 * g + 1], p.b1[4 * g + 2], p.b1[4 * g + 3]};
     float* seg = seg_s[wave];
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -161,8 +217,7 @@ __global__ __launch_bounds__(256) void wv12_stats_k(const W12StatsP p) {
         float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tile = 0; tile < CH / 16; ++tile) {
-            float xv[4];
-            const f32x4 z = conv1_tile(seg + S1 * (16 * tile + n) + 4 * g, wh, wl, bias, xv);
+            const f32x4 z = conv1_any<RB>(seg + S1 * (16 * tile + n), g, w1r, bias);
             if (f0 + 16 * tile + n < p.L1) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -202,6 +257,57 @@ __global__ __launch_bounds__(256) void wv12_stats_k(const W12StatsP p) {
     }
 }
 
+// Branch decisions of the LeakyReLU behind BatchNorm 1 (parity tests: the oracle replays them, tests/s2ag_testing.py
+// SignTap): sign[(clip, frame, channel)] = scale1 z1 + shift1 > 0, with z1 formed exactly as the three kernels form it.
+struct W12SignP {
+    const float* x;
+    const bf16_t* wp;
+    const float* b1;
+    const float* sc1;
+    const float* sh1;
+    unsigned char* sign;      // (N, L1, 16)
+    int N, Lin, L1, pad, cpc, total;
+};
+
+template <bool RB>
+__global__ __launch_bounds__(256) void wv12_signs_k(const W12SignP p) {
+    constexpr int CH = 128;
+    constexpr int SEG = S1 * (CH - 1) + 16;
+    constexpr int NLD = (SEG + 63) / 64;
+    __shared__ float seg_s[4][NLD * 64];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const W1Regs w1r = load_w1<RB>(p.wp, n, g);
+    const f32x4 bias = f32x4{p.b1[4 * g], p.b1[4 * g + 1], p.b1[4 * g + 2], p.b1[4 * g + 3]};
+    float* seg = seg_s[wave];
+    for (int ch = blockIdx.x * 4 + wave; ch < p.total; ch += gridDim.x * 4) {
+        const int clip = ch / p.cpc, f0 = (ch - clip * p.cpc) * CH;
+        const long long base = (long long)f0 * S1 - p.pad;
+        const float* xc = p.x + (long long)clip * p.Lin;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = u * 64 + lane;
+            const long long pos = base + i;
+            seg[i] = (i < SEG && pos >= 0 && pos < p.Lin) ? xc[pos] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int tile = 0; tile < CH / 16; ++tile) {
+            const f32x4 z = conv1_any<RB>(seg + S1 * (16 * tile + n), g, w1r, bias);
+            const int f = f0 + 16 * tile + n;
+            if (f < p.L1) {
+                unsigned w = 0u;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float zr = RB ? bf_round(z[v]) : z[v];
+                    w |= (fmaf(p.sc1[4 * g + v], zr, p.sh1[4 * g + v]) > 0.f ? 1u : 0u) << (8 * v);
+                }
+                *reinterpret_cast<unsigned*>(p.sign + ((long long)clip * p.L1 + f) * C1 + 4 * g) = w;
+            }
+        }
+    }
+}
+
 // =====================================================================================================================
 // forward: waveform -> z2
 // =====================================================================================================================
@@ -221,31 +327,42 @@ struct W12FwdP {
 
 // Every wave owns sub-tiles of 16 output frames: the 571 samples under them go through its own LDS segment (next sub-tile's
 // in flight in registers), seven conv1 tiles leave a1 (112 frames) in its own image in the flat-window layout of
-// wave_fused.hip (element e = 16 frame + channel at e + 16 (e / 96): the 16 rows x 8 k of a fragment read spread over the
-// banks), then K = 240 (256) against the weights in registers.
+// wave_fused.hip, then K = 240 against the weights in registers.
+//   NP = 1  bf16 image, element e = 16 frame + channel at e + 16 (e / 96) (the 16 rows x 8 k of a fragment read spread over
+//           the banks), 8 K tiles of v_mfma_f32_16x16x32_bf16, z2 stored as bf16;
+//   NP = 2  fp32 image at e + 2 (e / 96) (row pitch 98 floats: the 16 frames x 2 taps of a half-wave read hit 32 different
+//           banks), 60 K steps of v_mfma_f32_16x16x4_f32 -- the reference's fp32 arithmetic, no operand splitting --, z2 fp32.
 template <int NP>
 __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
-    constexpr int RS = S2 * C1, PITCH = RS + 16, NKT = K2P / 32;
+    constexpr bool F32 = NP == 2;
+    constexpr int RS = S2 * C1, NKT = K2P / 32, NKB = KS * C1 / 4;
+    constexpr int RPAD = F32 ? 2 : 16, PITCH = RS + RPAD;         // elements between the windows of consecutive output frames
     constexpr int AFR = 112;                                      // a1 frames per sub-tile: 6 * 15 + 15 = 105 -> 7 tiles
-    constexpr int IMG = AFR * C1 + 16 * (AFR * C1 / RS + 1);
+    constexpr int IMG = AFR * C1 + RPAD * (AFR * C1 / RS + 1);
     constexpr int SEG = S1 * (AFR - 1) + 16;
     constexpr int NLD = (SEG + 63) / 64;
-    __shared__ __attribute__((aligned(16))) bf16_t img_s[4][NP][IMG];
+    __shared__ __attribute__((aligned(16))) unsigned char img_s[4][IMG * (F32 ? 4 : 2)];
     __shared__ float seg_s[4][NLD * 64];
     __shared__ double red[4][2][C2];
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    bf16x8 wa[NP][2][NKT];
-#pragma unroll
-    for (int np = 0; np < NP; ++np)
+    // conv2's weights: bf16 A[co = 16 ct + n][k = 32 kt + 8 g ..]  /  fp32 A[co = 16 ct + n][k = 4 kb + g]
+    bf16x8 wa[F32 ? 1 : 2][F32 ? 1 : NKT];
+    float wf[F32 ? 2 : 1][F32 ? NKB : 1];
+    if constexpr (F32) {
+        const float* w2k = reinterpret_cast<const float*>(p.wp + O_W2K);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
-                wa[np][ct][kt] = ld8(p.wp + O_W2F + np * C2 * K2P + (16 * ct + n) * K2P + 32 * kt + 8 * g);
-    const s16x4 wh = *reinterpret_cast<const s16x4*>(p.wp + O_W1 + n * 16 + 4 * g);
-    const s16x4 wl = *reinterpret_cast<const s16x4*>(p.wp + O_W1 + C1 * 16 + n * 16 + 4 * g);
+            for (int kb = 0; kb < NKB; ++kb) wf[ct][kb] = w2k[(4 * kb + g) * C2 + 16 * ct + n];
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) wa[ct][kt] = ld8(p.wp + O_W2F + (16 * ct + n) * K2P + 32 * kt + 8 * g);
+    }
+    const W1Regs w1r = load_w1<!F32>(p.wp, n, g);
     const f32x4 bias1 = f32x4{p.b1[4 * g], p.b1[4 * g + 1], p.b1[4 * g + 2], p.b1[4 * g + 3]};
     float sc[4], sh[4], bias2[2][4];
 #pragma unroll
@@ -261,6 +378,8 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
     if (l_hi > p.L2) l_hi = p.L2;
     const float* xc = p.x + (long long)clip * p.Lin;
     float* seg = seg_s[wave];
+    bf16_t* img16 = reinterpret_cast<bf16_t*>(img_s[wave]);
+    float* img32 = reinterpret_cast<float*>(img_s[wave]);
 
     float sr[NLD];
     auto fetch = [&](int l0) {
@@ -289,10 +408,9 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
         // a1 of the 112 frames from 6 l0 on
 #pragma unroll
         for (int tile = 0; tile < AFR / 16; ++tile) {
-            float xv[4];
-            const f32x4 z = conv1_tile(seg + S1 * (16 * tile + n) + 4 * g, wh, wl, bias1, xv);
+            const f32x4 z = conv1_any<!F32>(seg + S1 * (16 * tile + n), g, w1r, bias1);
             float zr[4] = {z[0], z[1], z[2], z[3]}, a[4];
-            if (NP == 1) {                                          // z1 as bf16 mode stores it
+            if (!F32) {                                             // z1 as bf16 mode stores it
                 const unsigned z0 = bf_pack(z[0], z[1]), z1 = bf_pack(z[2], z[3]);
                 zr[0] = bf_lo(z0); zr[1] = bf_hi(z0); zr[2] = bf_lo(z1); zr[3] = bf_hi(z1);
             }
@@ -302,30 +420,41 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
                 a[v] = fmaxf(t, t * p.slope);                       // leaky, 0 <= slope <= 1
             }
             const int fl = 16 * tile + n;
-            const int off = fl * C1 + 4 * g + 16 * (fl / S2);
-            const unsigned h0 = bf_pack(a[0], a[1]), h1 = bf_pack(a[2], a[3]);
-            *reinterpret_cast<u32x2*>(&img_s[wave][0][off]) = u32x2{h0, h1};
-            if (NP == 2)
-                *reinterpret_cast<u32x2*>(&img_s[wave][NP - 1][off]) =
-                    u32x2{bf_pack_rest(a[0], a[1], h0), bf_pack_rest(a[2], a[3], h1)};
+            const int off = fl * C1 + 4 * g + RPAD * (fl / S2);
+            if constexpr (F32) {
+                *reinterpret_cast<f32x2*>(img32 + off) = f32x2{a[0], a[1]};
+                *reinterpret_cast<f32x2*>(img32 + off + 2) = f32x2{a[2], a[3]};
+            } else {
+                *reinterpret_cast<u32x2*>(img16 + off) = u32x2{bf_pack(a[0], a[1]), bf_pack(a[2], a[3])};
+            }
         }
         __builtin_amdgcn_wave_barrier();
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        const int frow = n * PITCH + 8 * g;
+        if constexpr (F32) {
+            // four accumulator chains (channel tile x K parity): a dependent f32 MFMA waits for its predecessor's result
+            f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            const float* frow = img32 + n * PITCH + g;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            const int k0 = 32 * kt, j = k0 / RS;
-            const bf16x8 bh = ld8(&img_s[wave][0][frow + j * PITCH + (k0 - j * RS)]);
-            if (NP == 2) {
-                const bf16x8 bl = ld8(&img_s[wave][NP - 1][frow + j * PITCH + (k0 - j * RS)]);
+            for (int kb = 0; kb < NKB; kb += 2) {
+                const int k0 = 4 * kb, j0 = k0 / RS, k1 = k0 + 4, j1 = k1 / RS;      // compile time
+                const float b0 = frow[j0 * PITCH + (k0 - j0 * RS)], b1 = frow[j1 * PITCH + (k1 - j1 * RS)];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    acc[ct] = mfma32(wa[NP - 1][ct][kt], bh, acc[ct]);
-                    acc[ct] = mfma32(wa[0][ct][kt], bl, acc[ct]);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][kb], b0, acc[ct], 0, 0, 0);
+                    acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][kb + 1], b1, acc2[ct], 0, 0, 0);
                 }
             }
+            acc[0] += acc2[0];
+            acc[1] += acc2[1];
+        } else {
+            const bf16_t* frow = img16 + n * PITCH + 8 * g;
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) acc[ct] = mfma32(wa[0][ct][kt], bh, acc[ct]);
+            for (int kt = 0; kt < NKT; ++kt) {
+                const int k0 = 32 * kt, j = k0 / RS;
+                const bf16x8 b = ld8(frow + j * PITCH + (k0 - j * RS));
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[ct] = mfma32(wa[ct][kt], b, acc[ct]);
+            }
         }
         // D[co][frame]: this lane holds channels 16 ct + 4 g + v of frame l0 + n
         const int l = l0 + n;
@@ -336,7 +465,7 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
                 float r[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) r[v] = acc[ct][v] + bias2[ct][v];
-                if (NP == 2) {
+                if (F32) {
                     *reinterpret_cast<f32x4*>(static_cast<float*>(p.z2) + ((long long)clip * p.L2 + l) * C2 + co) =
                         f32x4{r[0], r[1], r[2], r[3]};
                 } else {
@@ -424,21 +553,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int off, int pitch)
 __device__ __forceinline__ void st_agent_f(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// z1 tile from a segment whose samples are stored ALREADY split (word = hi piece | lo piece << 16: split once per sample
-// by the thread that stages it, not once per use)
-__device__ __forceinline__ f32x4 conv1_tile_sp(const unsigned* sp, s16x4 wh, s16x4 wl, f32x4 bias) {
-    const unsigned w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3];
-    const s16x4 xh = __builtin_bit_cast(s16x4, u32x2{__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u)});
-    const s16x4 xl = __builtin_bit_cast(s16x4, u32x2{__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u)});
-    f32x4 acc = mfma16(wl, xh, bias);
-    acc = mfma16(wh, xl, acc);
-    return mfma16(wh, xh, acc);
-}
-
 // A step = 32 q of one clip (q = frame of z2's grid; a1 frame 6 q + r, r = phase); a workgroup walks a contiguous range of
 // steps, the raw loads of the next RING - 1 steps in flight in registers.  Per step:
-//   stash   dy2 rows q0 - 2 .. q0 + 31 (bf16 pieces) and the 971 samples under the step (split into two bf16 pieces) -> LDS
-//           (double buffered)
+//   stash   dy2 rows q0 - 2 .. q0 + 31 (bf16 pieces) and the 971 samples under the step (as they are, and as two bf16 pieces)
+//           -> LDS (double buffered)
 //   phase 2 wave = (q half h, phase triple pt): da1 of ITS 16 q x 3 phases (9 MFMAs against weights in registers) and z1 of
 //           the same frames in the same lane layout (conv1 tiles whose 16 frames lie 6 apart), then in registers a1, du1 =
 //           da1 leaky'(.), the BatchNorm sums; a1 / du1 / z1 -> LDS, phase major [r][q][16]
@@ -452,7 +570,8 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
     constexpr int SEGN = 1024;                                     // >= 30 * 31 + 5 * 5 + 15 + 1 = 971
     constexpr int RING = 3;                                       // steps whose raw loads are in flight in registers
     __shared__ __attribute__((aligned(16))) bf16_t dimg[2][NP][DROWS * PG];
-    __shared__ __attribute__((aligned(16))) unsigned seg_s[2][SEGN];
+    __shared__ __attribute__((aligned(16))) float seg_s[NP == 1 ? 1 : 2][NP == 1 ? 4 : SEGN];   // fp32 mode: the samples (conv1 on the f32 MFMA) ...
+    __shared__ __attribute__((aligned(16))) unsigned spl_s[2][SEGN];   // ... and split: hi piece | lo piece << 16 (bf16-pipe products)
     __shared__ __attribute__((aligned(16))) bf16_t aimg[NP][S2 * QT * PA];
     __shared__ __attribute__((aligned(16))) bf16_t uimg[NP][S2 * QT * PA];
     __shared__ __attribute__((aligned(16))) bf16_t zimg[NP][S2 * QT * PA];
@@ -473,8 +592,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
         for (int i = tid * 8; i < W2PN; i += 256 * 8)
             *reinterpret_cast<u32x4*>(&wlds[np][i]) = *reinterpret_cast<const u32x4*>(p.wp + O_W2P + np * W2PN + i);
     __syncthreads();
-    const s16x4 wh = *reinterpret_cast<const s16x4*>(p.wp + O_W1 + n * 16 + 4 * g);
-    const s16x4 wl = *reinterpret_cast<const s16x4*>(p.wp + O_W1 + C1 * 16 + n * 16 + 4 * g);
+    const W1Regs w1r = load_w1<NP == 1>(p.wp, n, g);
     const f32x4 bias1 = f32x4{p.b1[4 * g], p.b1[4 * g + 1], p.b1[4 * g + 2], p.b1[4 * g + 3]};
     float sc[4], sh[4];
 #pragma unroll
@@ -566,13 +684,17 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
                     u32x4{bf_pack_rest(v[0], v[1], hi[0]), bf_pack_rest(v[2], v[3], hi[1]), bf_pack_rest(v[4], v[5], hi[2]),
                           bf_pack_rest(v[6], v[7], hi[3])};
         }
-        // samples: hi piece | lo piece << 16
+        // samples, and their two bf16 pieces (split once per sample by the thread that stages it, not once per use)
 #pragma unroll
         for (int u = 0; u < 4; u += 2) {
             const float x0 = rx[set][u], x1 = rx[set][u + 1];
             const unsigned hh = bf_pack(x0, x1), ll = bf_pack_rest(x0, x1, hh);
-            seg_s[buf][u * 256 + tid] = __builtin_amdgcn_perm(ll, hh, 0x05040100u);
-            seg_s[buf][(u + 1) * 256 + tid] = __builtin_amdgcn_perm(ll, hh, 0x07060302u);
+            if (NP == 2) {
+                seg_s[buf * (NP - 1)][u * 256 + tid] = x0;
+                seg_s[buf * (NP - 1)][(u + 1) * 256 + tid] = x1;
+            }
+            spl_s[buf][u * 256 + tid] = __builtin_amdgcn_perm(ll, hh, 0x05040100u);
+            spl_s[buf][(u + 1) * 256 + tid] = __builtin_amdgcn_perm(ll, hh, 0x07060302u);
         }
     };
 
@@ -580,7 +702,8 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
     // FULL: every frame of the step lies inside the clip (all but the last step of a clip): no masks
     auto step = [&](int buf, auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
-        const unsigned* seg = seg_s[buf];
+        const float* seg = seg_s[buf * (NP - 1)];
+        const unsigned* spl = spl_s[buf];
         // ---- phase 2 -------------------------------------------------------------------------------------------------
         {
             bf16x8 b[NP][NT];
@@ -603,7 +726,8 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
                         }
                         da = mfma32(wf, b[0][i], da);
                     }
-                const f32x4 z = conv1_tile_sp(seg + (S2 * S1) * (16 * h + n) + S1 * r + 4 * g, wh, wl, bias1);
+                const int woff = (S2 * S1) * (16 * h + n) + S1 * r;       // window of this lane's frame
+                const f32x4 z = NP == 1 ? conv1_tile_sp(spl + woff + 4 * g, w1r.h, w1r.l, bias1) : conv1_tile(seg + woff + g, w1r.f, bias1);
                 const bool valid = FULL || S2 * (c_q0 + 16 * h + n) + r < p.L1;
                 float a[4], du[4], zr[4];
                 unsigned z0, z1;
@@ -675,7 +799,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
                 // conv1: M^T (16 c x 32 q) against the windows (32 q x 16 taps): lane (t = n, g) holds q = 8 g .. 8 g + 7
                 unsigned xw[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xw[j] = seg[(S2 * S1) * (8 * g + j) + S1 * r + n];
+                for (int j = 0; j < 8; ++j) xw[j] = spl[(S2 * S1) * (8 * g + j) + S1 * r + n];
                 unsigned xh[4], xl[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -891,7 +1015,7 @@ extern "C" int s2ag_wave12_pack_elems(void) { return W12_PACK; }
 
 extern "C" int s2ag_wave12_pack(const float* w1, const float* w2, void* packed, void* stream) {
     if (!w1 || !w2 || !packed || ((uintptr_t)packed & 15)) return S2AG_E_BADARG;
-    hipLaunchKernelGGL(wv12_pack_k, dim3(cdiv(W12_PACK / 2, 256)), dim3(256), 0, (hipStream_t)stream, w1, w2,
+    hipLaunchKernelGGL(wv12_pack_k, dim3(cdiv(W12_PACK_THREADS, 256)), dim3(256), 0, (hipStream_t)stream, w1, w2,
                        static_cast<bf16_t*>(packed));
     S2AG_LAUNCH_CHECK();
     return 0;
@@ -910,6 +1034,21 @@ extern "C" int s2ag_wave12_stats(const float* x, const void* packed, const float
     const int blocks = stats_blocks(N, L1);
     if (round_bf16) hipLaunchKernelGGL(wv12_stats_k<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wv12_stats_k<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    S2AG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int s2ag_wave12_act_signs(const float* x, const void* packed, const float* b1, const float* scale1,
+                                     const float* shift1, int round_bf16, unsigned char* signs, int N, int Lin, int L1, int pad,
+                                     void* stream) {
+    if (!x || !packed || !b1 || !scale1 || !shift1 || !signs || N <= 0 || Lin <= 0 || L1 <= 0) return S2AG_E_BADARG;
+    if (L1 != (Lin + 2 * pad - KS) / S1 + 1 || ((uintptr_t)signs & 3)) return S2AG_E_BADARG;
+    W12SignP p{};
+    p.x = x; p.wp = static_cast<const bf16_t*>(packed); p.b1 = b1; p.sc1 = scale1; p.sh1 = shift1; p.sign = signs;
+    p.N = N; p.Lin = Lin; p.L1 = L1; p.pad = pad; p.cpc = cdiv(L1, 128); p.total = N * p.cpc;
+    const int blocks = stats_blocks(N, L1);
+    if (round_bf16) hipLaunchKernelGGL(wv12_signs_k<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wv12_signs_k<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -61,8 +61,13 @@ struct TrJobs {
 
 __device__ __forceinline__ float bf16_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
-template <int TCO, int TK>
-__global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
+// WR x WC waves share the TCO x TK tile (a wave: TCO / WR output channels x TK / WC columns).  <160, 160, 2, 2> and
+// <64, 64, 2, 2>: four waves, one per SIMD.  <320, 160, 4, 2> (the TCN's 300-channel layers): eight waves -- two per SIMD, so
+// one wave's transpose reads and LDS stores run beside the other's 25 MFMAs -- on a tile that reads every gy element twice
+// instead of four times: a step of the four-wave kernel was ~3 000 cycles for 400 cycles of MFMA per SIMD.
+template <int TCO, int TK, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC) void wgrad_tr_k(const TrJobs js) {
+    constexpr int NTH = 64 * WR * WC;
     // XCD-aware block order: the dispatcher places hardware block b on XCD b % 8, each XCD has its own L2, and the tiles of
     // one (layer, split) read the same operand rows (the k tiles share gy, the co tiles share x).  In hardware order
     // (tile fastest) the 8 tiles of a group land on 8 different XCDs and every L2 fetches its own copy through the
@@ -79,18 +84,19 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
     const int tile = local % p.ntiles, split = local / p.ntiles;
     constexpr int PA = TCO + 8, PB = TK + 8;                    // LDS row pitches (bf16): rows stay 16-byte aligned
     constexpr int CA = TCO / 8, CB = TK / 8;                    // 16-byte chunks per row
-    constexpr int NA = (32 * CA + 255) / 256, NB = (32 * CB + 255) / 256;
-    constexpr int WA = TCO / 32, WB = TK / 32;                  // 16-wide tiles per wave along co / along k
+    constexpr int NA = (32 * CA + NTH - 1) / NTH, NB = (32 * CB + NTH - 1) / NTH;
+    constexpr int WA = TCO / (16 * WR), WB = TK / (16 * WC);      // 16-wide tiles per wave along co / along k
+    static_assert(TCO % (16 * WR) == 0 && TK % (16 * WC) == 0, "wave tiling");
     __shared__ __attribute__((aligned(16))) bf16_t Gs[2][32 * PA];
     __shared__ __attribute__((aligned(16))) bf16_t Xs[2][32 * PB];
     __shared__ float bsum[TCO];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
     const int cot = tile % p.nco, kt = tile / p.nco;
     const int tap = kt / p.kct, c0 = (kt - tap * p.kct) * TK, co0 = cot * TCO;
     const bool do_bias = p.db != nullptr && kt == 0;
-    for (int i = tid; i < TCO; i += 256) bsum[i] = 0.f;
+    for (int i = tid; i < TCO; i += NTH) bsum[i] = 0.f;
 
     const int m_beg = split * p.m_chunk;
     const int m_end = min(p.M, m_beg + p.m_chunk);
@@ -98,14 +104,14 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
     bool oka[NA], okb[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NTH * i;
         ra[i] = id / CA;
         ca[i] = id - ra[i] * CA;
         oka[i] = id < 32 * CA && co0 + ca[i] * 8 < p.ldg;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NTH * i;
         rb[i] = id / CB;
         cb[i] = id - rb[i] * CB;
         okb[i] = id < 32 * CB && c0 + cb[i] * 8 < p.Cvalid;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
     const long long x_wrap = p.x_clip - (long long)p.Lq * p.pos_mul * p.ldx;      // extra advance across a clip boundary
     const int row_off = p.pos_off + tap * p.pos_tap;
     int next_mb = m_beg;                                         // fetches are issued for consecutive steps
-    constexpr int RING = 4;                                      // register sets = steps in flight (+ the one being stored)
+    constexpr int RING = WR * WC > 4 ? 2 : 4;                     // register sets = steps in flight (+ the one being stored)
     u32x4 rg[RING][NA], rx[RING][NB];
     unsigned vmask[RING];                                           // bit i: G chunk i valid, bit 8 + i: X chunk i valid
     // branch-free: an invalid chunk loads from a safe address and is zeroed when it is stored to LDS
@@ -169,13 +175,13 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (!((vm >> i) & 1u)) rg[set][i] = u32x4{0u, 0u, 0u, 0u};
-            if ((32 * CA) % 256 == 0 || i + 1 < NA || tid + 256 * i < 32 * CA)
+            if ((32 * CA) % NTH == 0 || i + 1 < NA || tid + NTH * i < 32 * CA)
                 *reinterpret_cast<u32x4*>(&Gs[buf][ra[i] * PA + ca[i] * 8]) = rg[set][i];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (!((vm >> (8 + i)) & 1u)) rx[set][i] = u32x4{0u, 0u, 0u, 0u};
-            if ((32 * CB) % 256 == 0 || i + 1 < NB || tid + 256 * i < 32 * CB)
+            if ((32 * CB) % NTH == 0 || i + 1 < NB || tid + NTH * i < 32 * CB)
                 *reinterpret_cast<u32x4*>(&Xs[buf][rb[i] * PB + cb[i] * 8]) = rx[set][i];
         }
         if (do_bias) {
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
         for (int b = 0; b < WB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     // transpose-read address of this lane inside a 16-column tile: row 8g + t/4, column 4*(t % 4)
     const int g = lane >> 4, t = lane & 15;
-    const int tr_a = (8 * g + (t >> 2)) * PA + (t & 3) * 4 + wr * (TCO / 2);
-    const int tr_b = (8 * g + (t >> 2)) * PB + (t & 3) * 4 + wc * (TK / 2);
+    const int tr_a = (8 * g + (t >> 2)) * PA + (t & 3) * 4 + wr * (TCO / WR);
+    const int tr_b = (8 * g + (t >> 2)) * PB + (t & 3) * 4 + wc * (TK / WC);
     auto frag = [&](const bf16_t* img, int off, int pitch) {
         using lds_p = __attribute__((address_space(3))) s16x4*;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + off));
@@ -239,10 +245,10 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
     for (int a = 0; a < WA; ++a)
 #pragma unroll
         for (int b = 0; b < WB; ++b) {
-            const int kcol = wc * (TK / 2) + b * 16 + (lane & 15);
+            const int kcol = wc * (TK / WC) + b * 16 + (lane & 15);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = wr * (TCO / 2) + a * 16 + (lane >> 4) * 4 + q;
+                const int col = wr * (TCO / WR) + a * 16 + (lane >> 4) * 4 + q;
                 if (co0 + col < p.Cout) dst[col * TK + kcol] = acc[a][b][q];
             }
             __builtin_amdgcn_sched_barrier(0);                  // tile by tile: 100 store addresses at once cost 200 registers
@@ -251,12 +257,12 @@ __global__ __launch_bounds__(256) void wgrad_tr_k(const TrJobs js) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            if (tid + 256 * i < 32 * CA) {
+            if (tid + NTH * i < 32 * CA) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) atomicAdd(&bsum[ca[i] * 8 + j], bacc[i][j]);
             }
         __syncthreads();
-        for (int i = tid; i < TCO; i += 256)
+        for (int i = tid; i < TCO; i += NTH)
             if (co0 + i < p.Cout) p.part_b[((long long)split * p.nco + cot) * TCO + i] = bsum[i];
     }
 }
@@ -609,12 +615,21 @@ int target_blocks() {
     static const int t = [] { const char* e = getenv("S2AG_BF16_WGRAD_TR_BLOCKS"); return e ? atoi(e) : 0; }();
     return t;
 }
+
+// 320 x 160 tiles on eight waves when every weight has more than 160 output channels (the TCN: 300)
+bool wide_tiles(const s2ag_bf16_wgrad_args* jobs, int n) {
+    static const int on = [] { const char* e = getenv("S2AG_BF16_WGRAD_TR_WIDE"); return e ? atoi(e) : 1; }();
+    if (!on || !big_tiles(jobs, n)) return false;
+    for (int k = 0; k < n; ++k)
+        if (jobs[k].Cout <= 160 || jobs[k].Cout > 320) return false;
+    return true;
+}
 }  // namespace
 
 extern "C" long long s2ag_bf16_conv_wgrad_tr_scratch_floats(const s2ag_bf16_wgrad_args* jobs, int njobs) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS) return S2AG_E_BADARG;
-    const bool big = big_tiles(jobs, njobs);
-    const int TCO = big ? 160 : 64, TK = big ? 160 : 64;
+    const bool big = big_tiles(jobs, njobs), wide = wide_tiles(jobs, njobs);
+    const int TCO = wide ? 320 : (big ? 160 : 64), TK = big ? 160 : 64;
     const int target = target_blocks() > 0 ? target_blocks() : (big ? 256 : 1024);
     long long tot = 0;
     const int rpb = rows_per_block(jobs, njobs, TCO, TK, target);
@@ -630,8 +645,8 @@ extern "C" long long s2ag_bf16_conv_wgrad_tr_scratch_floats(const s2ag_bf16_wgra
 extern "C" int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njobs, float* scratch, long long scratch_floats,
                                        void* stream) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS || !scratch) return S2AG_E_BADARG;
-    const bool big = big_tiles(jobs, njobs);
-    const int TCO = big ? 160 : 64, TK = big ? 160 : 64;
+    const bool big = big_tiles(jobs, njobs), wide = wide_tiles(jobs, njobs);
+    const int TCO = wide ? 320 : (big ? 160 : 64), TK = big ? 160 : 64;
     const int target = target_blocks() > 0 ? target_blocks() : (big ? 256 : 1024);
     TrJobs js{};
     static const int remap = [] { const char* e = getenv("S2AG_WGRAD_TR_XCD"); return e ? atoi(e) : 1; }();
@@ -658,12 +673,16 @@ extern "C" int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njo
     const bool direct = ms <= 16;
     const dim3 grid(nblk), rgrid(cdiv(max_red, direct ? 256 : 32), njobs);
     hipStream_t st = (hipStream_t)stream;
-    if (big) {
-        hipLaunchKernelGGL((wgrad_tr_k<160, 160>), grid, dim3(256), 0, st, js);
+    if (wide) {
+        hipLaunchKernelGGL((wgrad_tr_k<320, 160, 4, 2>), grid, dim3(512), 0, st, js);
+        if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<320, 160, true>), rgrid, dim3(256), 0, st, js);
+        else hipLaunchKernelGGL((wgrad_tr_reduce_k<320, 160, false>), rgrid, dim3(256), 0, st, js);
+    } else if (big) {
+        hipLaunchKernelGGL((wgrad_tr_k<160, 160, 2, 2>), grid, dim3(256), 0, st, js);
         if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, true>), rgrid, dim3(256), 0, st, js);
         else hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, false>), rgrid, dim3(256), 0, st, js);
     } else {
-        hipLaunchKernelGGL((wgrad_tr_k<64, 64>), grid, dim3(256), 0, st, js);
+        hipLaunchKernelGGL((wgrad_tr_k<64, 64, 2, 2>), grid, dim3(256), 0, st, js);
         if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<64, 64, true>), rgrid, dim3(256), 0, st, js);
         else hipLaunchKernelGGL((wgrad_tr_reduce_k<64, 64, false>), rgrid, dim3(256), 0, st, js);
     }

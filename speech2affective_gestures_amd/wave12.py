@@ -131,6 +131,16 @@ def backward(wav: Tensor, pk: Tensor, b1: Tensor, coef1: Tensor, gamma1: Tensor,
     return cabc1
 
 
+def act_signs(wav: Tensor, pk: Tensor, b1: Tensor, coef1: Tensor, round_bf16: bool, pad: int = PAD1) -> Tensor:
+    """(N, L1, 16) bool: the branch the LeakyReLU behind BatchNorm 1 takes inside the fused launches (parity tests)."""
+    N, Lin = wav.shape
+    L1, _ = lengths(Lin, pad)
+    out = torch.empty(N, L1, 16, dtype=torch.uint8, device=wav.device)
+    L.check(_lib().s2ag_wave12_act_signs(_p(wav), _p(pk), _p(b1), _p(coef1[0]), _p(coef1[1]), int(round_bf16), _p(out), N, Lin, L1,
+                                         pad, _s()), 'wave12_act_signs')
+    return out.bool()
+
+
 class _HeadF32(torch.autograd.Function):
     """fp32 mode: (N, samples) waveform -> z2 (N, L2, 32) fp32, the raw output of conv2 (BatchNorm 2 follows outside)."""
 

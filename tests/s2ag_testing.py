@@ -133,7 +133,7 @@ class SignTap:
         self.ops, self.module = ops, module
         self.names = {id(m): n for n, m in module.named_modules()}
         self.params = {id(p): n for n, p in module.named_parameters()}
-        self.bn, self.adds, self.lin, self.tcn = [], [], [], []
+        self.bn, self.adds, self.lin, self.tcn, self.heads = [], [], [], [], []
 
     def __enter__(self):
         ops = self.ops
@@ -163,11 +163,23 @@ class SignTap:
             self.tcn.append(r[0] if isinstance(r, tuple) else r)
             return r
         ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32 = bn_act, add_act, linear, tcn
+        # the fused head of the wave encoder (wave12.py): BatchNorm 1 + LeakyReLU happen inside its launches; the branch
+        # decisions come from s2ag_wave12_act_signs, which forms conv1's output exactly as they do
+        from speech2affective_gestures_amd import wave12
+        self._w12, self._o_head = wave12, wave12.head_f32
+
+        def head(wav, fe):
+            z2 = self._o_head(wav, fe)
+            if id(fe[1]) in self.names:
+                self.heads.append((self.names[id(fe[1])], z2, fe[0].bias))
+            return z2
+        wave12.head_f32 = head
         return self
 
     def __exit__(self, *a):
         ops = self.ops
         ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32 = self._orig
+        self._w12.head_f32 = self._o_head
 
     def signs(self):
         import numpy as np
@@ -187,6 +199,9 @@ class SignTap:
                 out[name + '.'] = (vertex_layout(y, cols[pre]) > 0).cpu()
             else:
                 out[name + '.'] = (y > 0).permute(0, 2, 1).cpu()
+        for name, z2, b1 in self.heads:
+            wav, pk, coef1 = z2.grad_fn.saved_tensors
+            out[name + '.'] = self._w12.act_signs(wav, pk, b1, coef1, False, z2.grad_fn.pad).permute(0, 2, 1).cpu()
         for key, y in zip(sorted(cols), self.adds):                      # st_gcn1 runs before st_gcn2
             out[key + 'out'] = (vertex_layout(y, cols[key]) > 0).cpu()
         for pname, y in self.lin:

@@ -1,8 +1,8 @@
 """Head of the wave encoder without conv1's output in HBM (csrc/wave12.hip): Conv1d(1,16,15,s5,p1600) BatchNorm LeakyReLU(0.3)
 Conv1d(16,32,15,s6) of net/multimodal_context_net_v2.py:18-21.  Every launch against torch on the CPU (float64, autograd through
-F.conv1d / training-mode batch norm), in both modes: fp32 (operands as two bf16 pieces: 16 mantissa bits per product, tolerance
-1e-4 of the largest element) and bf16 (z1 / a1 / z2 rounded to bf16: tolerances of 8-mantissa-bit storage, stated per assertion),
-then the WavEncoder module with and without it."""
+F.conv1d / training-mode batch norm), in both modes: fp32 (forward on the f32 MFMA: 2e-6 of the largest element; backward products
+from two bf16 pieces per operand, 16 mantissa bits: 5e-5) and bf16 (z1 / a1 / z2 rounded to bf16: tolerances of 8-mantissa-bit
+storage, stated per assertion), then the WavEncoder module with and without it."""
 import ctypes as C
 import math
 import os
@@ -100,7 +100,7 @@ def test_statistics_and_forward(N, Lin, bf):
     want = z2.transpose(1, 2).contiguous()
     assert out.dtype == (torch.bfloat16 if bf else torch.float32)
     # bf16 mode: a1 is rounded where the kernel's z1 differs from torch's in its last bits, then 240 bf16 products
-    assert rel(out.float(), want) < (1.2e-2 if bf else 1e-4), rel(out.float(), want)
+    assert rel(out.float(), want) < (1.2e-2 if bf else 1e-5), rel(out.float(), want)
     # the column sums are those of the STORED tensor, exactly; their fold == training-mode batch-norm statistics of it
     yd = out.double().reshape(-1, 32).cpu()
     st = part[:2 * prow * 32].view(2, prow, 32).cpu()
