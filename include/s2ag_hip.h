@@ -595,6 +595,9 @@ int s2ag_wave12_fwd(const float* x, const void* packed, const float* b1, const f
 int s2ag_wave12_bwd_blocks(int N, int L1, int dz_f32);
 /* tests / diagnostics: at most `cap` workgroups in s2ag_wave12_bwd (0: the default, 2 per CU); returns the previous value */
 int s2ag_wave12_set_bwd_block_cap(int cap);
+/* diagnostics: 120 uint64 s_memtime stamps of workgroup 0 of s2ag_wave12_bwd (per step: stash begin, loads issued, phase 2
+ * begin, phase 2 end, phase 3 begin); NULL switches it off */
+int s2ag_wave12_set_trace(void* buf);
 int s2ag_wave12_bwd(const s2ag_wave12_bwd_args* a, void* stream);
 
 /* ---- clip-resident TemporalConvNet in bf16 mode (csrc/tcn_fused.hip) ----------------------------------------------

@@ -185,6 +185,7 @@ SIGNATURES = {
     's2ag_wave12_fwd': [vp, vp, vp, vp, vp, cf, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp],
     's2ag_wave12_bwd_blocks': [ci, ci, ci],
     's2ag_wave12_set_bwd_block_cap': [ci],
+    's2ag_wave12_set_trace': [vp],
     's2ag_wave12_bwd': [vp, vp],
     's2ag_wave_conv1_wgrad_blocks': [PG],
     's2ag_wave_conv1_wgrad': [vp, vp, vp, vp, vp, vp, vp, vp, vp, PG, vp],

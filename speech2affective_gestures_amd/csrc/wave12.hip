@@ -542,6 +542,7 @@ struct W12BwdP {
     float* occ;
     double inv_rows;
     int N, Lin, L1, L2, pad, QS, total_steps;
+    unsigned long long* trace;  // diagnostics (s2ag_wave12_set_trace): s_memtime stamps of block 0, wave 0
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int off, int pitch) {
@@ -699,11 +700,15 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
     };
 
     const int tr_row = 8 * g + (n >> 2), tr_col = 4 * (n & 3);
+    int nst = 0;
+    const bool tr_on = p.trace != nullptr && blockIdx.x == 0 && tid == 0;
+#define W12_STAMP() do { if (tr_on && nst < 120) p.trace[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
     // FULL: every frame of the step lies inside the clip (all but the last step of a clip): no masks
     auto step = [&](int buf, auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
         const float* seg = seg_s[buf * (NP - 1)];
         const unsigned* spl = spl_s[buf];
+        W12_STAMP();
         // ---- phase 2 -------------------------------------------------------------------------------------------------
         {
             bf16x8 b[NP][NT];
@@ -769,7 +774,9 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
                 }
             }
         }
+        W12_STAMP();
         __syncthreads();
+        W12_STAMP();
         // ---- phase 3 -------------------------------------------------------------------------------------------------
         {
             bf16x8 af[NP][NT];
@@ -835,8 +842,10 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
 #pragma unroll
         for (int r = 0; r < RING; ++r) {
             if (s + r < s_end) {                                    // uniform over the workgroup
+                W12_STAMP();
                 stash(r, buf);
                 fetch(s + r + RING, r);
+                W12_STAMP();
                 __syncthreads();
                 if (S2 * (c_q0 + QT) <= p.L1) step(buf, std::true_type{});
                 else step(buf, std::false_type{});
@@ -850,6 +859,8 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
         }
     }
 
+    W12_STAMP();
+#undef W12_STAMP
     // ---- the workgroup's partial results ---------------------------------------------------------------------------------
     // dW2 tile: D[co][ci]: co = 16 cot + 4 g + v, ci = n; tap r + 6 i
     float* dst = p.part_w2 + (size_t)blockIdx.x * C2 * KS * C1;
@@ -998,6 +1009,7 @@ int fwd_chunks(int N, int L2, int* LC) {
     *LC = cdiv(cdiv(L2, per_clip), 64) * 64;
     return cdiv(L2, *LC);
 }
+unsigned long long* g_w12_trace = nullptr;
 int g_bwd_block_cap = 0;            // s2ag_wave12_set_bwd_block_cap (tests: few workgroups walk many steps and cross clips)
 int bwd_blocks(int N, int L1, int dz_f32) {
     // two workgroups per CU in bf16 mode; the two-piece form holds twice the operands in registers: one per CU
@@ -1079,6 +1091,11 @@ extern "C" int s2ag_wave12_fwd(const float* x, const void* packed, const float* 
     return 0;
 }
 
+extern "C" int s2ag_wave12_set_trace(void* buf) {
+    g_w12_trace = static_cast<unsigned long long*>(buf);
+    return 0;
+}
+
 extern "C" int s2ag_wave12_set_bwd_block_cap(int cap) {
     const int prev = g_bwd_block_cap;
     g_bwd_block_cap = cap > 0 ? cap : 0;
@@ -1106,6 +1123,7 @@ extern "C" int s2ag_wave12_bwd(const s2ag_wave12_bwd_args* a, void* stream) {
     p.inv_rows = 1.0 / ((double)a->N * a->L1);
     p.N = a->N; p.Lin = a->Lin; p.L1 = a->L1; p.L2 = a->L2; p.pad = a->pad;
     p.QS = cdiv(cdiv(a->L1, S2), 32);
+    p.trace = g_w12_trace;
     p.total_steps = a->N * p.QS;
     const int blocks = bwd_blocks(a->N, a->L1, a->dz_f32);
     hipStream_t s = (hipStream_t)stream;

@@ -81,6 +81,16 @@ __device__ __forceinline__ u32x4 bn_bwd8(u32x4 dz, u32x4 y, const float (&ca)[8]
     return u32x4{o[0], o[1], o[2], o[3]};
 }
 
+__device__ __forceinline__ u32x4 bn_bwd8(u32x4 dz, u32x4 y, const float* ca, const float* cb, const float* cc) {
+    const unsigned d[4] = {dz.x, dz.y, dz.z, dz.w}, w[4] = {y.x, y.y, y.z, y.w};
+    unsigned o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        o[j] = bf_pack(fmaf(ca[2 * j], bf_lo(d[j]), fmaf(cc[2 * j], bf_lo(w[j]), cb[2 * j])),
+                       fmaf(ca[2 * j + 1], bf_hi(d[j]), fmaf(cc[2 * j + 1], bf_hi(w[j]), cb[2 * j + 1])));
+    return u32x4{o[0], o[1], o[2], o[3]};
+}
+
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
@@ -158,21 +168,28 @@ __global__ __launch_bounds__(256) void wv_fwd_k(const WvFwdP p) {
     const bf16_t* xc = p.x + (long long)n * p.Lin * CIN;
     const long long xlen = (long long)p.Lin * CIN;
 
-    u32x4 st[NLD];
-    auto fetch = [&](int l0) {
+    // RING sub-tiles' raw rows in flight in registers: a sub-tile is ~0.3 us of work behind a ~2 us load, and with one set a
+    // workgroup's few sub-tiles were a chain of memory round trips (conv3: 26 us for 29 MB).  The BatchNorm transform runs
+    // when a set goes to LDS, not when it is requested (the request must not wait for the previous set's arithmetic).
+    constexpr int RING = 3;
+    u32x4 st[RING][NLD];
+    auto fetch = [&](int l0, int set) {
         const long long base = (long long)l0 * RS;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int e = (u * NTH + st_id) * 8;
-            st[u] = u32x4{0u, 0u, 0u, 0u};
-            if (e < SPAN && base + e + 7 < xlen) st[u] = bn_act8(*reinterpret_cast<const u32x4*>(xc + base + e), sc, sh, p.slope);
+            st[set][u] = u32x4{0u, 0u, 0u, 0u};
+            if (e < SPAN && base + e + 7 < xlen) st[set][u] = *reinterpret_cast<const u32x4*>(xc + base + e);
         }
     };
-    auto stash = [&](bf16_t* img) {
+    auto stash = [&](bf16_t* img, int l0, int set) {
+        const long long base = (long long)l0 * RS;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int e = (u * NTH + st_id) * 8;
-            if (e < SPAN) *reinterpret_cast<u32x4*>(img + e + 16 * (e / RS)) = st[u];
+            if (e < SPAN)
+                *reinterpret_cast<u32x4*>(img + e + 16 * (e / RS)) =
+                    base + e + 7 < xlen ? bn_act8(st[set][u], sc, sh, p.slope) : u32x4{0u, 0u, 0u, 0u};
         }
     };
 
@@ -183,16 +200,22 @@ __global__ __launch_bounds__(256) void wv_fwd_k(const WvFwdP p) {
         for (int v = 0; v < 4; ++v) s1[ct][v] = s2[ct][v] = 0.0;
 
     constexpr int STEP = TEAM == 1 ? 64 : 16;             // frames a workgroup covers per iteration
-    int l0 = l_lo + (TEAM == 1 ? wave * 16 : 0);
+    const int l_first = l_lo + (TEAM == 1 ? wave * 16 : 0);
     int buf = 0;
-    if (l0 < l_hi) fetch(l0);
-    for (; l0 < l_hi; l0 += STEP, buf ^= 1) {
+#pragma unroll
+    for (int r = 0; r < RING; ++r)
+        if (l_first + r * STEP < l_hi) fetch(l_first + r * STEP, r);
+    for (int lb = l_first; lb < l_hi; lb += RING * STEP)
+#pragma unroll
+    for (int rs = 0; rs < RING; ++rs) {
+        const int l0 = lb + rs * STEP;
+        if (l0 >= l_hi) break;                            // uniform over the workgroup (TEAM = 4) / the wave (TEAM = 1)
         bf16_t* img = TEAM == 1 ? img_s[wave] : img_s[buf];
         if (TEAM == 1) __builtin_amdgcn_wave_barrier();
-        stash(img);
+        stash(img, l0, rs);
         if (TEAM == 1) __builtin_amdgcn_wave_barrier();
         else __syncthreads();
-        if (l0 + STEP < l_hi) fetch(l0 + STEP);
+        if (l0 + RING * STEP < l_hi) fetch(l0 + RING * STEP, rs);
         f32x4 acc[WCT];
 #pragma unroll
         for (int ct = 0; ct < WCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -242,6 +265,7 @@ __global__ __launch_bounds__(256) void wv_fwd_k(const WvFwdP p) {
             }
         }
         if (TEAM != 1 && KSPLIT > 1) __syncthreads();     // kred is reused by the next iteration
+        buf ^= 1;
     }
     if (p.stats) {          // (2, gridDim.x, COUT): one partial row per workgroup
 #pragma unroll
@@ -355,31 +379,26 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
                     bf16x8, *reinterpret_cast<const u32x4*>(
                                 p.w + ((long long)((pstart + j * PSTEP) * CIN + 16 * ct + (lane & 15)) * WNT + i) * p.CPO +
                                 32 * kc + 8 * (lane >> 4)));
-    // coefficient sets of this thread's 8 source channels (loader) and 8 output channels (epilogue)
-    float ca[8], cb[8], cc[8];
-    if (!G_F32) {
-        const int c0 = (st_id * 8) % COUT;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            ca[j] = p.ca[c0 + j];
-            cb[j] = p.cb[c0 + j];
-            cc[j] = p.cc[c0 + j];
-        }
+    // coefficient sets of a thread's 8 source channels (loader) and 8 output channels (epilogue): in LDS, read per use -- as
+    // 56 registers per lane they left no room for a ring of prefetched sub-tiles at two workgroups per CU
+    __shared__ float cf_src[3][COUT], cf_out[4][CIN];
+    for (int i = tid; i < COUT; i += 256) {
+        cf_src[0][i] = G_F32 ? 0.f : p.ca[i];
+        cf_src[1][i] = G_F32 ? 0.f : p.cb[i];
+        cf_src[2][i] = G_F32 ? 0.f : p.cc[i];
     }
-    float psc[8], psh[8], pin[8], pmi[8];
-    {
-        const int c0 = (st_id * 8) % CIN;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            psc[j] = p.psc[c0 + j];
-            psh[j] = p.psh[c0 + j];
-            pin[j] = p.pinv[c0 + j];
-            pmi[j] = -p.pmean[c0 + j] * pin[j];          // xhat = y inv - mean inv
-        }
+    for (int i = tid; i < CIN; i += 256) {
+        cf_out[0][i] = p.psc[i];
+        cf_out[1][i] = p.psh[i];
+        cf_out[2][i] = p.pinv[i];
+        cf_out[3][i] = -p.pmean[i] * p.pinv[i];           // xhat = y inv - mean inv
     }
-    double s1[8], s2[8];
+    __syncthreads();
+    const int c_src = (st_id * 8) % COUT, c_out = (st_id * 8) % CIN;
+    // per lane a few dozen terms: fp32 here, fp64 from the cross-lane sums on
+    float s1[8], s2[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.0;
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
 
     const int n = blockIdx.x / p.chunks;
     const int q_lo = (blockIdx.x - n * p.chunks) * p.QC;
@@ -389,57 +408,81 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
     const bf16_t* ypc = p.yp + (long long)n * p.Lin * CIN;
     bf16_t* dzc = p.dzp + (long long)n * p.Lin * CIN;
 
-    u32x4 st[NLD];
-    auto fetch = [&](int q0) {
+    // RING sub-tiles' raw rows (the operands of dy and the rows of y_{i-1} the epilogue needs) in flight in registers: with
+    // one set a workgroup's sub-tiles were a chain of memory round trips.  The dy transform runs when a set goes to LDS.
+    constexpr int RING = TEAM == 1 ? 2 : 3;
+    u32x4 sd[RING][NLD], sy[RING][NLD], yvr[RING][NOC];
+    auto fetch = [&](int q0, int set) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int e = (u * NTH + st_id) * 8;
             const int row = e / COUT, col = e - row * COUT;
             const int l = q0 - (WNT - 1) + row;
-            st[u] = u32x4{0u, 0u, 0u, 0u};
+            sd[set][u] = sy[set][u] = u32x4{0u, 0u, 0u, 0u};
             if (row < DROWS && (unsigned)l < (unsigned)p.Lout) {
                 const long long off = src_clip + (long long)l * COUT + col;
                 if constexpr (G_F32) {
                     const float* g = static_cast<const float*>(p.dz) + off;
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(g), b = *reinterpret_cast<const f32x4*>(g + 4);
-                    st[u] = u32x4{bf_pack(a[0], a[1]), bf_pack(a[2], a[3]), bf_pack(b[0], b[1]), bf_pack(b[2], b[3])};
+                    sd[set][u] = *reinterpret_cast<const u32x4*>(g);
+                    sy[set][u] = *reinterpret_cast<const u32x4*>(g + 4);
                 } else {
-                    st[u] = bn_bwd8(*reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off),
-                                    *reinterpret_cast<const u32x4*>(p.y + off), ca, cb, cc);
+                    sd[set][u] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off);
+                    sy[set][u] = *reinterpret_cast<const u32x4*>(p.y + off);
                 }
             }
         }
-    };
-    auto stash = [&](bf16_t* img) {
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int e = (u * NTH + st_id) * 8;
-            const int row = e / COUT, col = e - row * COUT;
-            if (row < DROWS) *reinterpret_cast<u32x4*>(img + row * PD + col) = st[u];
-        }
-    };
-
-    constexpr int STEP = TEAM == 1 ? 64 : 16;
-    int q0 = q_lo + (TEAM == 1 ? wave * 16 : 0);
-    if (q0 < q_hi) fetch(q0);
-    for (; q0 < q_hi; q0 += STEP) {
-        bf16_t* dimg = TEAM == 1 ? dimg_s[wave] : dimg_s[0];
-        float* oimg = TEAM == 1 ? oimg_s[wave] : oimg_s[0];
-        if (TEAM == 1) __builtin_amdgcn_wave_barrier();
-        stash(dimg);
-        if (TEAM == 1) __builtin_amdgcn_wave_barrier();
-        else __syncthreads();
         // the rows of y_{i-1} under this sub-tile's 96 output frames, in the order the epilogue consumes them
-        u32x4 yv[NOC];
         const int pos0 = WS * q0;
 #pragma unroll
         for (int u = 0; u < NOC; ++u) {
             const int e = (u * NTH + st_id) * 8;
             const int row = e / CIN;
-            yv[u] = u32x4{0u, 0u, 0u, 0u};
-            if (row < 16 * WS && pos0 + row < p.Lin) yv[u] = *reinterpret_cast<const u32x4*>(ypc + (long long)pos0 * CIN + e);
+            yvr[set][u] = u32x4{0u, 0u, 0u, 0u};
+            if (row < 16 * WS && pos0 + row < p.Lin) yvr[set][u] = *reinterpret_cast<const u32x4*>(ypc + (long long)pos0 * CIN + e);
         }
-        if (q0 + STEP < q_hi) fetch(q0 + STEP);
+    };
+    auto stash = [&](bf16_t* img, int q0, int set) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = (u * NTH + st_id) * 8;
+            const int row = e / COUT, col = e - row * COUT;
+            const int l = q0 - (WNT - 1) + row;
+            if (row < DROWS) {
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if ((unsigned)l < (unsigned)p.Lout) {
+                    if constexpr (G_F32) {
+                        const f32x4 a = __builtin_bit_cast(f32x4, sd[set][u]), b = __builtin_bit_cast(f32x4, sy[set][u]);
+                        v = u32x4{bf_pack(a[0], a[1]), bf_pack(a[2], a[3]), bf_pack(b[0], b[1]), bf_pack(b[2], b[3])};
+                    } else {
+                        v = bn_bwd8(sd[set][u], sy[set][u], cf_src[0] + c_src, cf_src[1] + c_src, cf_src[2] + c_src);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(img + row * PD + col) = v;
+            }
+        }
+    };
+
+    constexpr int STEP = TEAM == 1 ? 64 : 16;
+    const int q_first = q_lo + (TEAM == 1 ? wave * 16 : 0);
+#pragma unroll
+    for (int r = 0; r < RING; ++r)
+        if (q_first + r * STEP < q_hi) fetch(q_first + r * STEP, r);
+    for (int qb = q_first; qb < q_hi; qb += RING * STEP)
+#pragma unroll
+    for (int rs = 0; rs < RING; ++rs) {
+        const int q0 = qb + rs * STEP;
+        if (q0 >= q_hi) break;                            // uniform over the workgroup (TEAM = 4) / the wave (TEAM = 1)
+        bf16_t* dimg = TEAM == 1 ? dimg_s[wave] : dimg_s[0];
+        float* oimg = TEAM == 1 ? oimg_s[wave] : oimg_s[0];
+        if (TEAM == 1) __builtin_amdgcn_wave_barrier();
+        stash(dimg, q0, rs);
+        if (TEAM == 1) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+        u32x4 yv[NOC];
+#pragma unroll
+        for (int u = 0; u < NOC; ++u) yv[u] = yvr[rs][u];
+        const int pos0 = WS * q0;
+        if (q0 + RING * STEP < q_hi) fetch(q0 + RING * STEP, rs);
         // B fragments: b[i][kc] = dy[q0 + (lane & 15) - i][32 kc + 8 (lane >> 4) .. + 8]
         bf16x8 b[WNT][KC];
 #pragma unroll
@@ -482,10 +525,10 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const float yk = (k & 1) ? bf_hi(w[k >> 1]) : bf_lo(w[k >> 1]);
-                    const float z = fmaf(psc[k], yk, psh[k]);
+                    const float z = fmaf(cf_out[0][c_out + k], yk, cf_out[1][c_out + k]);
                     dzv[k] = z > 0.f ? da[k] : da[k] * p.slope;
-                    s1[k] += (double)dzv[k];
-                    s2[k] += (double)(dzv[k] * fmaf(yk, pin[k], pmi[k]));
+                    s1[k] += dzv[k];
+                    s2[k] = fmaf(dzv[k], fmaf(yk, cf_out[2][c_out + k], cf_out[3][c_out + k]), s2[k]);
                 }
                 *reinterpret_cast<u32x4*>(dzc + (long long)pos0 * CIN + e) =
                     u32x4{bf_pack(dzv[0], dzv[1]), bf_pack(dzv[2], dzv[3]), bf_pack(dzv[4], dzv[5]), bf_pack(dzv[6], dzv[7])};
@@ -496,7 +539,7 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
     constexpr int G = CIN / 8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        double a1 = s1[k], a2 = s2[k];
+        double a1 = (double)s1[k], a2 = (double)s2[k];
 #pragma unroll
         for (int m = G; m < 64; m <<= 1) {
             a1 += __shfl_xor(a1, m, 64);

@@ -280,8 +280,9 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 
-template <int TCO, int TK, int RING, int BPC>
-__global__ __launch_bounds__(256, BPC) void wgrad_tr32_k(const TrJobs js) {
+template <int TCO, int TK, int RING, int BPC, int WR = 2, int WC = 2>
+__global__ __launch_bounds__(64 * WR * WC, BPC) void wgrad_tr32_k(const TrJobs js) {
+    constexpr int NTH = 64 * WR * WC;
     const int nwg = gridDim.x;                                   // compact 1-D grid: every block has work
     const int hw = blockIdx.x;
     const int xcd = hw & 7, q8 = nwg >> 3, r8 = nwg & 7;
@@ -293,32 +294,32 @@ __global__ __launch_bounds__(256, BPC) void wgrad_tr32_k(const TrJobs js) {
     const int tile = local % p.ntiles, split = local / p.ntiles;
     constexpr int PA = TCO + 8, PB = TK + 8;                    // LDS row pitches (bf16)
     constexpr int CA = TCO / 4, CB = TK / 4;                    // 16-byte (4-float) chunks per row
-    constexpr int NA = (32 * CA + 255) / 256, NB = (32 * CB + 255) / 256;
-    constexpr int WA = TCO / 32, WB = TK / 32;
+    constexpr int NA = (32 * CA + NTH - 1) / NTH, NB = (32 * CB + NTH - 1) / NTH;
+    constexpr int WA = TCO / (16 * WR), WB = TK / (16 * WC);
     __shared__ __attribute__((aligned(16))) bf16_t Gs[2][2][32 * PA];       // [buffer][hi / lo]
     __shared__ __attribute__((aligned(16))) bf16_t Xs[2][2][32 * PB];
     __shared__ float bsum[TCO];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
     const int cot = tile % p.nco, kt = tile / p.nco;
     const int tap = kt / p.kct, c0 = (kt - tap * p.kct) * TK, co0 = cot * TCO;
     const bool do_bias = p.db != nullptr && kt == 0;
-    for (int i = tid; i < TCO; i += 256) bsum[i] = 0.f;
+    for (int i = tid; i < TCO; i += NTH) bsum[i] = 0.f;
     const int m_beg = split * p.m_chunk;
     const int m_end = min(p.M, m_beg + p.m_chunk);
     int ra[NA], ca[NA], rb[NB], cb[NB];
     bool oka[NA], okb[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NTH * i;
         ra[i] = id / CA;
         ca[i] = id - ra[i] * CA;
         oka[i] = id < 32 * CA && co0 + ca[i] * 4 < p.Cout;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NTH * i;
         rb[i] = id / CB;
         cb[i] = id - rb[i] * CB;
         okb[i] = id < 32 * CB && c0 + cb[i] * 4 < p.Cvalid;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256, BPC) void wgrad_tr32_k(const TrJobs js) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (!((vm >> i) & 1u)) rg[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if ((32 * CA) % 256 == 0 || i + 1 < NA || tid + 256 * i < 32 * CA)
+            if ((32 * CA) % NTH == 0 || i + 1 < NA || tid + NTH * i < 32 * CA)
                 split_store(Gs[buf][0], Gs[buf][1], ra[i] * PA + ca[i] * 4, rg[set][i]);
             if (do_bias) {
 #pragma unroll
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256, BPC) void wgrad_tr32_k(const TrJobs js) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (!((vm >> (8 + i)) & 1u)) rx[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if ((32 * CB) % 256 == 0 || i + 1 < NB || tid + 256 * i < 32 * CB)
+            if ((32 * CB) % NTH == 0 || i + 1 < NB || tid + NTH * i < 32 * CB)
                 split_store(Xs[buf][0], Xs[buf][1], rb[i] * PB + cb[i] * 4, rx[set][i]);
         }
     };
@@ -404,8 +405,8 @@ __global__ __launch_bounds__(256, BPC) void wgrad_tr32_k(const TrJobs js) {
 #pragma unroll
         for (int b = 0; b < WB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int g = lane >> 4, t = lane & 15;
-    const int tr_a = (8 * g + (t >> 2)) * PA + (t & 3) * 4 + wr * (TCO / 2);
-    const int tr_b = (8 * g + (t >> 2)) * PB + (t & 3) * 4 + wc * (TK / 2);
+    const int tr_a = (8 * g + (t >> 2)) * PA + (t & 3) * 4 + wr * (TCO / WR);
+    const int tr_b = (8 * g + (t >> 2)) * PB + (t & 3) * 4 + wc * (TK / WC);
     auto frag = [&](const bf16_t* img, int off, int pitch) {
         using lds_p = __attribute__((address_space(3))) s16x4*;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + off));
@@ -457,10 +458,10 @@ __global__ __launch_bounds__(256, BPC) void wgrad_tr32_k(const TrJobs js) {
     for (int a = 0; a < WA; ++a)
 #pragma unroll
         for (int b = 0; b < WB; ++b) {
-            const int kcol = wc * (TK / 2) + b * 16 + (lane & 15);
+            const int kcol = wc * (TK / WC) + b * 16 + (lane & 15);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = wr * (TCO / 2) + a * 16 + (lane >> 4) * 4 + q;
+                const int col = wr * (TCO / WR) + a * 16 + (lane >> 4) * 4 + q;
                 if (co0 + col < p.Cout) dst[col * TK + kcol] = acc[a][b][q];
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -469,12 +470,12 @@ __global__ __launch_bounds__(256, BPC) void wgrad_tr32_k(const TrJobs js) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            if (tid + 256 * i < 32 * CA) {
+            if (tid + NTH * i < 32 * CA) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) atomicAdd(&bsum[ca[i] * 4 + j], bacc[i][j]);
             }
         __syncthreads();
-        for (int i = tid; i < TCO; i += 256)
+        for (int i = tid; i < TCO; i += NTH)
             if (co0 + i < p.Cout) p.part_b[((long long)split * p.nco + cot) * TCO + i] = bsum[i];
     }
 }
@@ -693,7 +694,9 @@ extern "C" int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njo
 /* fp32 operands (row pitches in floats): the GRU weight gradients of the fp32 step.  Same job struct; Cvalid / ldx / ldg
  * multiples of 4; products from two bf16 pieces per operand (16 mantissa bits), fp32 accumulation. */
 // (A 160 x 128 variant with two register sets and two workgroups per CU -- one's loader beside the other's MFMAs -- spilled
-// 87 VGPRs at the 256-register cap and ran at half the speed: measured, removed.)
+// 87 VGPRs at the 256-register cap and ran at half the speed: measured, removed.  So did the eight-wave 320 x 128 form that
+// works for the bf16 kernel above: hi / lo fragments and fp32 register sets do not fit 256 registers, 35 spilled, 281 us against
+// 158 us for the TCN's eight gradients.)
 extern "C" long long s2ag_f32_wgrad_tr_scratch_floats_n(const s2ag_bf16_wgrad_args* jobs, int njobs, int blocks) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS) return S2AG_E_BADARG;
     const bool big = big_tiles32(jobs, njobs);                    // small / flat-window weights (the wave encoder): 64 x 64 tiles
