@@ -13,7 +13,7 @@ has() { [[ " $PARTS " == *" $1 "* ]]; }
 if has step; then
   rocprofv3 --kernel-trace --stats -d $O/step -o step -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/step.log 2>&1
   python tools/rocpd_stats.py $(db step) 50 > $O/r03_step_kernel_stats.txt
-  tail -1 $O/step.log > $O/r03_step_bench_line.json
+  grep '^{"metric"' $O/step.log | tail -1 > $O/r03_step_bench_line.json
 fi
 if has cfg3; then
   for m in fp32 bf16; do
