@@ -69,6 +69,7 @@ __device__ __forceinline__ void fetch_segment(const C1P& p, float (&r)[C1_SEG_RE
     }
 }
 __device__ __forceinline__ void store_segment(float* seg, const float (&r)[C1_SEG_REGS], int seg_len) {
+    S2AG_DBG_ASSERT(seg_len <= C1_SEG_REGS * C1_NT);
 #pragma unroll
     for (int k = 0; k < C1_SEG_REGS; ++k) {
         const int i = threadIdx.x + k * C1_NT;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_fwd_k(const C1P p) {
         for (int i = 0; i < C1_RUN / 64; ++i) {
             const int f = i * 64 + fr, l = l0 + f;
             if (l < p.Lout) {
+                S2AG_DBG_ASSERT(f * p.stride + KS <= seg_len);
                 const float* sx = seg + f * p.stride;
                 float xv[KS];
 #pragma unroll

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void embedding_fwd_k(const long long* ids, con
          i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / dim), c = (int)(i - (long long)r * dim);
         long long id = ids[r];
+        S2AG_DBG_ASSERT(id >= 0 && id < n_entries);      // nn.Embedding raises here; the release build clamps
         id = id < 0 ? 0 : (id >= n_entries ? n_entries - 1 : id);
         float v = table[id * dim + c];
         if (drop_p > 0.f) v *= keep_scale(key, (unsigned long long)i, drop_p, inv_keep);

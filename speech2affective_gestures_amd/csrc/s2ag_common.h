@@ -11,6 +11,16 @@
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
 
+// Debug flavour (python -m speech2affective_gestures_amd.build --debug, -DS2AG_DEBUG=1): device-side asserts on the indices the
+// loaders compute (LDS image offsets, staged-segment indices, row / column ranges).  A failing assert aborts the kernel and
+// the next HIP call reports it; the release build compiles them away.
+#if defined(S2AG_DEBUG) && S2AG_DEBUG
+#include <assert.h>
+#define S2AG_DBG_ASSERT(cond) assert(cond)
+#else
+#define S2AG_DBG_ASSERT(cond) ((void)0)
+#endif
+
 namespace s2ag {
 
 constexpr int WAVE = 64;

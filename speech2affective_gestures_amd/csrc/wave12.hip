@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void wv12_stats_k(const W12StatsP p) {
         float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tile = 0; tile < CH / 16; ++tile) {
+            S2AG_DBG_ASSERT(S1 * (16 * tile + n) + 15 < NLD * 64);
             const f32x4 z = conv1_any<RB>(seg + S1 * (16 * tile + n), g, w1r, bias);
             if (f0 + 16 * tile + n < p.L1) {
 #pragma unroll
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
             }
             const int fl = 16 * tile + n;
             const int off = fl * C1 + 4 * g + RPAD * (fl / S2);
+            S2AG_DBG_ASSERT(off >= 0 && off + 4 <= IMG && S1 * fl + 15 < NLD * 64);
             if constexpr (F32) {
                 *reinterpret_cast<f32x2*>(img32 + off) = f32x2{a[0], a[1]};
                 *reinterpret_cast<f32x2*>(img32 + off + 2) = f32x2{a[2], a[3]};
@@ -437,6 +439,7 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
 #pragma unroll
             for (int kb = 0; kb < NKB; kb += 2) {
                 const int k0 = 4 * kb, j0 = k0 / RS, k1 = k0 + 4, j1 = k1 / RS;      // compile time
+                S2AG_DBG_ASSERT(n * PITCH + g + j1 * PITCH + (k1 - j1 * RS) < IMG);
                 const float b0 = frow[j0 * PITCH + (k0 - j0 * RS)], b1 = frow[j1 * PITCH + (k1 - j1 * RS)];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
@@ -451,6 +454,7 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 const int k0 = 32 * kt, j = k0 / RS;
+                S2AG_DBG_ASSERT(n * PITCH + 8 * g + j * PITCH + (k0 - j * RS) + 8 <= IMG);
                 const bf16x8 b = ld8(frow + j * PITCH + (k0 - j * RS));
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) acc[ct] = mfma32(wa[ct][kt], b, acc[ct]);
@@ -459,6 +463,7 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
         // D[co][frame]: this lane holds channels 16 ct + 4 g + v of frame l0 + n
         const int l = l0 + n;
         if (l < l_hi) {
+            S2AG_DBG_ASSERT(l >= 0 && l < p.L2 && clip < p.N);
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const int co = 16 * ct + 4 * g;
@@ -628,6 +633,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
         rd[set] = ry[set] = u32x4{0u, 0u, 0u, 0u};
         const int l = f_q0 - (NT - 1) + d_row;
         if (live && d_own && (unsigned)l < (unsigned)p.L2) {
+            S2AG_DBG_ASSERT(f_clip < p.N);
             const long long off = ((long long)f_clip * p.L2 + l) * C2 + d_col;
             if constexpr (XF) {
                 rd[set] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off);
@@ -732,6 +738,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
                         da = mfma32(wf, b[0][i], da);
                     }
                 const int woff = (S2 * S1) * (16 * h + n) + S1 * r;       // window of this lane's frame
+                S2AG_DBG_ASSERT(woff + 15 < SEGN);
                 const f32x4 z = NP == 1 ? conv1_tile_sp(spl + woff + 4 * g, w1r.h, w1r.l, bias1) : conv1_tile(seg + woff + g, w1r.f, bias1);
                 const bool valid = FULL || S2 * (c_q0 + 16 * h + n) + r < p.L1;
                 float a[4], du[4], zr[4];
@@ -758,6 +765,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
                     s2[v] = fmaf(du[v], zr[v], s2[v]);              // sum du1 z1; xhat = (z1 - mean) invstd is applied to the sums
                 }
                 const int off = (r * QT + 16 * h + n) * PA + 4 * g;
+                S2AG_DBG_ASSERT(off + 4 <= S2 * QT * PA);
                 const unsigned a0 = bf_pack(a[0], a[1]), a1 = bf_pack(a[2], a[3]);
                 const unsigned u0 = bf_pack(du[0], du[1]), u1 = bf_pack(du[2], du[3]);
                 if (NP != 1 || !FULL) {
@@ -790,6 +798,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
             for (int rr = 0; rr < 3; ++rr) {
                 const int r = 3 * ph + rr;
                 const int ioff = (r * QT + tr_row) * PA + tr_col;
+                S2AG_DBG_ASSERT(ioff + 4 * PA + 4 <= S2 * QT * PA && (S2 * S1) * (8 * g + 7) + S1 * r + n < SEGN);
                 const bf16x8 bh = tr_frag(aimg[0], ioff, PA);
                 if (NP == 2) {
                     const bf16x8 bl = tr_frag(aimg[NP - 1], ioff, PA);

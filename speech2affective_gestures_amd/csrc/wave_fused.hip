@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void wv_fwd_k(const WvFwdP p) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int e = (u * NTH + st_id) * 8;
+            S2AG_DBG_ASSERT(e >= SPAN || e + 16 * (e / RS) + 8 <= IROWS * PITCH);
             if (e < SPAN)
                 *reinterpret_cast<u32x4*>(img + e + 16 * (e / RS)) =
                     base + e + 7 < xlen ? bn_act8(st[set][u], sc, sh, p.slope) : u32x4{0u, 0u, 0u, 0u};
@@ -448,6 +449,7 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
             const int row = e / COUT, col = e - row * COUT;
             const int l = q0 - (WNT - 1) + row;
             if (row < DROWS) {
+                S2AG_DBG_ASSERT(row * PD + col + 8 <= DROWS * PD);
                 u32x4 v = u32x4{0u, 0u, 0u, 0u};
                 if ((unsigned)l < (unsigned)p.Lout) {
                     if constexpr (G_F32) {
@@ -517,6 +519,7 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
             const int e = (u * NTH + st_id) * 8;
             const int row = e / CIN, col = e - row * CIN;
             if (row < rows) {
+                S2AG_DBG_ASSERT(row * OP + col + 8 <= 16 * WS * OP && pos0 + row < p.Lin);
                 const f32x4 d0 = *reinterpret_cast<const f32x4*>(oimg + row * OP + col);
                 const f32x4 d1 = *reinterpret_cast<const f32x4*>(oimg + row * OP + col + 4);
                 const float da[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};

@@ -33,8 +33,10 @@ def rel(a, b):
 
 def test_library_is_loaded_in_process(S):
     S['lib'].load()
+    import os
+    name = os.path.basename(os.environ.get('S2AG_HIP_LIB', 'libs2ag_hip.so'))      # a debug / asan flavour of the same ABI
     with open('/proc/self/maps') as f:
-        assert 'libs2ag_hip.so' in f.read()
+        assert name in f.read()
 
 
 def test_cpu_tensor_raises(S):
