@@ -565,6 +565,16 @@ def alt_modes(pr, dp, batch, B, steps=20):
             el = timed_steps(pr, dp, batch, steps, 2, False)
             out['bf16_conv_path'] = dict(clips_per_s=B * dp.world_size * steps / el, ms_per_step=el / steps * 1e3, steps=steps,
                                          dtype='bf16 activations in the wave encoder and the text TCN, fp32 elsewhere')
+        # ... and with every large matrix product of the step on ONE bf16 piece per operand (one product instead of three):
+        # the cooperative GRU's recurrence, its input projections / input gradients, the GRU / TCN / wave-encoder weight
+        # gradients (bf16.precision('bf16_step'); storage of gi / y / gates, accumulation, statistics, Adam stay fp32)
+        with bf16.precision('bf16_step'):
+            pr._graphed = None
+            el = timed_steps(pr, dp, batch, steps, 2, False)
+            out['bf16_step'] = dict(clips_per_s=B * dp.world_size * steps / el, ms_per_step=el / steps * 1e3, steps=steps,
+                                    dtype='bf16 products (one piece per fp32 operand) in the GRU, its projections and all large '
+                                          'weight gradients + bf16 activations in the wave encoder and the text TCN; fp32 '
+                                          'storage elsewhere, fp32 accumulation / statistics / master weights')
     finally:
         pr._graphed = None
     return out

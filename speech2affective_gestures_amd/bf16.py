@@ -20,25 +20,43 @@ from . import _lib as L
 from . import ops
 
 Tensor = torch.Tensor
-_MODE = [os.environ.get('S2AG_PRECISION', 'fp32').lower() in ('bf16', 'bfloat16')]
+_ENV = os.environ.get('S2AG_PRECISION', 'fp32').lower()
+_MODE = [_ENV in ('bf16', 'bfloat16', 'bf16_step')]
+# 'bf16_step' (BASELINE configs[1] "bf16"): besides the bf16 Conv1d path, every large matrix product of the step -- the
+# cooperative GRU's recurrence, its input projections and input gradients, the GRU / TCN / wave-encoder weight gradients
+# -- takes its fp32 operands as ONE bf16 piece (one product on the bf16 matrix pipe instead of the default three of the
+# two-piece split); storage, accumulation, BatchNorm statistics, master weights and Adam stay fp32.
+_STEP = [_ENV == 'bf16_step']
 
 
 def enabled() -> bool:
     return _MODE[0]
 
 
+def step_mode() -> bool:
+    return _STEP[0]
+
+
+
+
 class precision:
-    """Context manager: ``precision('bf16')`` / ``precision('fp32')``."""
+    """Context manager: ``precision('bf16')`` (the Conv1d path in bf16), ``precision('bf16_step')`` (that + single-piece
+    bf16 products in the GRU, its projections and the weight gradients) / ``precision('fp32')``."""
 
     def __init__(self, mode: str):
-        self.on = mode.lower() in ('bf16', 'bfloat16')
+        m = mode.lower()
+        self.on = m in ('bf16', 'bfloat16', 'bf16_step')
+        self.step = m == 'bf16_step'
 
     def __enter__(self):
-        self.prev = _MODE[0]
-        _MODE[0] = self.on
+        self.prev = (_MODE[0], _STEP[0])
+        _MODE[0], _STEP[0] = self.on, self.step
+        self.prev_pieces = _lib().s2ag_gru_coop_set_split_pieces(1) if self.step else None
 
     def __exit__(self, *a):
-        _MODE[0] = self.prev
+        _MODE[0], _STEP[0] = self.prev
+        if self.prev_pieces is not None:
+            _lib().s2ag_gru_coop_set_split_pieces(self.prev_pieces)
 
 
 def pad32(c: int) -> int:
@@ -55,6 +73,10 @@ def _s():
 
 def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+if _STEP[0]:                                   # S2AG_PRECISION=bf16_step: single-piece products from the first launch on
+    _lib().s2ag_gru_coop_set_split_pieces(1)
 
 
 def _rows16(t: Tensor):

@@ -227,8 +227,10 @@ __global__ __launch_bounds__(256) void gemm_sp_k(const SpP p) {
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][NP - 1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][1], b[tj][1], c, 0, 0, 0);
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][1], b[tj][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][1], c, 0, 0, 0);
+                if constexpr (NP >= 2) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][NP - 1 ? 1 : 0], b[tj][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][NP - 1 ? 1 : 0], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][0], c, 0, 0, 0);
                 acc[ti][tj] = c;
             }
@@ -396,8 +398,10 @@ __global__ __launch_bounds__(256) void conv_sp_k(const SpcP p) {
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][NP - 1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][1], b[tj][1], c, 0, 0, 0);
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][1], b[tj][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][1], c, 0, 0, 0);
+                if constexpr (NP >= 2) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][NP - 1 ? 1 : 0], b[tj][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][NP - 1 ? 1 : 0], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti][0], b[tj][0], c, 0, 0, 0);
                 acc[ti][tj] = c;
             }
@@ -499,13 +503,15 @@ extern "C" int s2ag_gemm_split_fwd(const void* a_planes, const void* w_planes, c
     // not come here); the planes always hold three pieces, two-piece products simply leave the third unread.
     // Tile: 128 x 128 halves the operand traffic but needs >= ~1.5 blocks per CU to fill the chip; else 64 x 64.
     const bool big = (long long)cdiv(M, 128) * cdiv(N, 128) >= 384;
-    const bool two = s2ag_gru_coop_split_pieces() == 2;
+    const int np = s2ag_gru_coop_split_pieces();      // 1: bf16 step mode (one piece, one product)
     const dim3 grid(cdiv(M, big ? 128 : 64), cdiv(N, big ? 128 : 64));
     if (big) {
-        if (two) hipLaunchKernelGGL((gemm_sp_k<2, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (np == 1) hipLaunchKernelGGL((gemm_sp_k<1, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (np == 2) hipLaunchKernelGGL((gemm_sp_k<2, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((gemm_sp_k<3, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
-        if (two) hipLaunchKernelGGL((gemm_sp_k<2, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (np == 1) hipLaunchKernelGGL((gemm_sp_k<1, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (np == 2) hipLaunchKernelGGL((gemm_sp_k<2, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((gemm_sp_k<3, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
     S2AG_LAUNCH_CHECK();
@@ -539,7 +545,9 @@ extern "C" int s2ag_gemm_split_acc(const void* a_planes, const void* w_planes, f
     SpP p{static_cast<const unsigned short*>(a_planes), static_cast<const unsigned short*>(w_planes), nullptr, y, M, N, Kp,
           ldy, kchunk, 1};
     const dim3 grid(cdiv(M, 64), cdiv(N, 64), nsplit);
-    if (s2ag_gru_coop_split_pieces() == 2)
+    if (s2ag_gru_coop_split_pieces() == 1)
+        hipLaunchKernelGGL((gemm_sp_k<1, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (s2ag_gru_coop_split_pieces() == 2)
         hipLaunchKernelGGL((gemm_sp_k<2, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL((gemm_sp_k<3, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -574,12 +582,14 @@ extern "C" int s2ag_conv1d_nlc_fwd_split(const float* x, const void* w_planes, c
     static const int bm_env = [] { const char* e = getenv("S2AG_CONV_SPLIT_BM"); return e ? atoi(e) : 0; }();
     const bool bm64 = bm_env ? bm_env == 64 : (long long)cdiv(p.M, 64) * cdiv(p.Cout, 64) >= 1024;
     const dim3 grid(cdiv(p.M, bm64 ? 64 : 32), cdiv(p.Cout, 64));
-    const bool two = s2ag_gru_coop_split_pieces() == 2;
+    const int np = s2ag_gru_coop_split_pieces();
     if (bm64) {
-        if (two) hipLaunchKernelGGL((conv_sp_k<2, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (np == 1) hipLaunchKernelGGL((conv_sp_k<1, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (np == 2) hipLaunchKernelGGL((conv_sp_k<2, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((conv_sp_k<3, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
-        if (two) hipLaunchKernelGGL((conv_sp_k<2, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (np == 1) hipLaunchKernelGGL((conv_sp_k<1, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (np == 2) hipLaunchKernelGGL((conv_sp_k<2, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((conv_sp_k<3, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
     if (stat_rows) *stat_rows = (int)grid.x * 2;

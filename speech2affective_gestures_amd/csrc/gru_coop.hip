@@ -288,9 +288,10 @@ __device__ __forceinline__ unsigned bf16_rn(float v) {            // bf16 bits o
 template <int NP>
 __device__ __forceinline__ void split_bf16(float v, unsigned (&pc)[3]) {
     pc[0] = bf16_rn(v);
+    pc[1] = pc[2] = 0u;
+    if (NP == 1) return;                            // bf16 step mode: one piece, one product
     float r = v - __uint_as_float(pc[0] << 16);
     pc[1] = bf16_rn(r);
-    pc[2] = 0u;
     if (NP == 3) {
         r -= __uint_as_float(pc[1] << 16);
         pc[2] = bf16_rn(r);
@@ -332,7 +333,7 @@ __device__ __forceinline__ bool gather_cells_sp(const u64* X, unsigned tag, unsi
             const int c = i / ROW, k = i - c * ROW;
             unsigned short* d = dst + c * PITCH + k;
             d[0] = (unsigned short)v[j];
-            d[PLANE] = (unsigned short)(v[j] >> 16);
+            if (NP >= 2) d[PLANE] = (unsigned short)(v[j] >> 16);
             if (NP == 3) d[2 * PLANE] = (unsigned short)(v[j] >> 32);
         }
     }
@@ -451,9 +452,11 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_sp_k(const float* __restrict
                 b[pc] = __builtin_bit_cast(bf16x8, breg[i][pc]);
             }
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc2, 0, 0, 0);
-            if (NP == 3) {
+            if constexpr (NP >= 2) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[NP - 1 ? 1 : 0], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NP - 1 ? 1 : 0], b[0], acc2, 0, 0, 0);
+            }
+            if constexpr (NP == 3) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc2, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc1, 0, 0, 0);
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_sp2_k(const CoopFwdPasses P,
                         const int c = i / H, k = i - c * H;
                         unsigned short* d = hs + c * HPB + k;
                         d[0] = (unsigned short)v[j];
-                        d[PLANE] = (unsigned short)(v[j] >> 16);
+                        if (NP >= 2) d[PLANE] = (unsigned short)(v[j] >> 16);
                         if (NP == 3) d[2 * PLANE] = (unsigned short)(v[j] >> 32);
                     }
                 }
@@ -681,9 +684,11 @@ __global__ __launch_bounds__(CNT) void gru_coop_fwd_sp2_k(const CoopFwdPasses P,
                     b[pc] = __builtin_bit_cast(bf16x8, breg[i][pc]);
                 }
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc2, 0, 0, 0);
-                if (NP == 3) {
+                if constexpr (NP >= 2) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[NP - 1 ? 1 : 0], acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NP - 1 ? 1 : 0], b[0], acc2, 0, 0, 0);
+                }
+                if constexpr (NP == 3) {
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc1, 0, 0, 0);
                     acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc2, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc1, 0, 0, 0);
@@ -935,8 +940,10 @@ __global__ __launch_bounds__(CNT) void gru_coop_bwd_k(const float* __restrict__ 
                 }
                 f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc1, 0, 0, 0);
+                if constexpr (NP >= 2) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[NP - 1 ? 1 : 0], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NP - 1 ? 1 : 0], b[0], acc1, 0, 0, 0);
+                }
                 if constexpr (NP == 3) {
                     f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
                     acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc2, 0, 0, 0);
@@ -1008,7 +1015,7 @@ inline int coop_split_pieces() {
     static const int v = [] {
         const char* e = getenv("S2AG_GRU_SPLIT");
         const int n = e ? atoi(e) : 2;
-        return (n == 2 || n == 3) ? n : 0;
+        return (n == 1 || n == 2 || n == 3) ? n : 0;
     }();
     return g_split_override >= 0 ? g_split_override : v;
 }
@@ -1051,7 +1058,7 @@ extern "C" int s2ag_gru_coop_split_pieces(void) { return coop_split_pieces(); }
 extern "C" int s2ag_gru_coop_fwd_slices(int B) { return (coop_split_pieces() != 0 && B > CBS && coop_two_slices()) ? 2 : 1; }
 extern "C" int s2ag_gru_coop_set_split_pieces(int pieces) {
     const int prev = coop_split_pieces();
-    g_split_override = (pieces == 2 || pieces == 3) ? pieces : (pieces == 0 ? 0 : -1);
+    g_split_override = (pieces >= 1 && pieces <= 3) ? pieces : (pieces == 0 ? 0 : -1);
     return prev;
 }
 
@@ -1080,8 +1087,9 @@ int launch_fwd_sp2(int n, const float* const* gi, const float* whh, const float*
     int smem2 = 2 * np * CBS * (5 * 2 * 32 + 8) * 2;                   // [slice][piece][clip][k] bf16
     static const int reserve_f = [] { const char* e = getenv("S2AG_COOP_FWD_LDS_RESERVE"); return (e ? atoi(e) : 0) * 1024; }();
     if (reserve_f > smem2) smem2 = reserve_f;                          // CU reservation, see s2ag_gru_coop_bwd
-    const void* fn2 = np == 3 ? reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 3, 2>)
-                              : reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 2, 2>);
+    const void* fn2 = np == 3   ? reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 3, 2>)
+                      : np == 2 ? reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 2, 2>)
+                                : reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 1, 2>);
     static bool granted2[4] = {false, false, false, false};
     if (!granted2[np]) {
         hipError_t ae = hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
@@ -1102,8 +1110,11 @@ int launch_fwd_sp2(int n, const float* const* gi, const float* whh, const float*
     if (np == 3)
         hipLaunchKernelGGL((gru_coop_fwd_sp2_k<300, 32, 3, 2>), grid2, dim3(CNT), smem2, stream, P, whh, bhh, x, err, B, T,
                            p, ik, site);
-    else
+    else if (np == 2)
         hipLaunchKernelGGL((gru_coop_fwd_sp2_k<300, 32, 2, 2>), grid2, dim3(CNT), smem2, stream, P, whh, bhh, x, err, B, T,
+                           p, ik, site);
+    else
+        hipLaunchKernelGGL((gru_coop_fwd_sp2_k<300, 32, 1, 2>), grid2, dim3(CNT), smem2, stream, P, whh, bhh, x, err, B, T,
                            p, ik, site);
     S2AG_LAUNCH_CHECK();
     return 0;
@@ -1127,6 +1138,10 @@ extern "C" int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float*
     const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
     const dim3 grid(10, cdiv(B, CBS), 2);
     switch (coop_split_pieces()) {
+        case 1:
+            hipLaunchKernelGGL((gru_coop_fwd_sp_k<300, 32, 1>), grid, dim3(CNT), 0, (hipStream_t)stream, gi, whh, bhh, y,
+                               ydrop, gates, w.x, w.err, B, T, p, ik, rg, site);
+            break;
         case 2:
             hipLaunchKernelGGL((gru_coop_fwd_sp_k<300, 32, 2>), grid, dim3(CNT), 0, (hipStream_t)stream, gi, whh, bhh, y,
                                ydrop, gates, w.x, w.err, B, T, p, ik, rg, site);
@@ -1201,6 +1216,7 @@ extern "C" int s2ag_gru_coop_bwd(const float* dy, int lddy, int dy_dir_stride, c
     if (reserve > smem) smem = reserve;
     const void* fn = np == 3   ? reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 3>)
                      : np == 2 ? reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 2>)
+                     : np == 1 ? reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 1>)
                                : reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 0>);
     static bool granted[4] = {false, false, false, false};
     if (!granted[np]) {
@@ -1214,6 +1230,9 @@ extern "C" int s2ag_gru_coop_bwd(const float* dy, int lddy, int dy_dir_stride, c
                            dy_dir_stride, whh, y, gates, dgi, dgh, w.x, w.err, B, T, p, ik, rg, site);
     else if (np == 2)
         hipLaunchKernelGGL((gru_coop_bwd_k<300, 32, 2>), grid, dim3(CNT), smem, (hipStream_t)stream, dy, lddy,
+                           dy_dir_stride, whh, y, gates, dgi, dgh, w.x, w.err, B, T, p, ik, rg, site);
+    else if (np == 1)
+        hipLaunchKernelGGL((gru_coop_bwd_k<300, 32, 1>), grid, dim3(CNT), smem, (hipStream_t)stream, dy, lddy,
                            dy_dir_stride, whh, y, gates, dgi, dgh, w.x, w.err, B, T, p, ik, rg, site);
     else
         hipLaunchKernelGGL((gru_coop_bwd_k<300, 32, 0>), grid, dim3(CNT), smem, (hipStream_t)stream, dy, lddy,

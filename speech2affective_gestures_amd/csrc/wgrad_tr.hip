@@ -23,6 +23,8 @@
 
 #include "s2ag_common.h"
 
+extern "C" int s2ag_gru_coop_split_pieces(void);      // the step's product setting (gru_coop.hip)
+
 namespace {
 using namespace s2ag;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -280,7 +282,8 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 
-template <int TCO, int TK, int RING, int BPC, int WR = 2, int WC = 2>
+// NPC: pieces per operand (2: hi + lo, three products, the fp32 step; 1: hi only, one product: the bf16 step mode)
+template <int TCO, int TK, int RING, int BPC, int WR = 2, int WC = 2, int NPC = 2>
 __global__ __launch_bounds__(64 * WR * WC, BPC) void wgrad_tr32_k(const TrJobs js) {
     constexpr int NTH = 64 * WR * WC;
     const int nwg = gridDim.x;                                   // compact 1-D grid: every block has work
@@ -296,8 +299,8 @@ __global__ __launch_bounds__(64 * WR * WC, BPC) void wgrad_tr32_k(const TrJobs j
     constexpr int CA = TCO / 4, CB = TK / 4;                    // 16-byte (4-float) chunks per row
     constexpr int NA = (32 * CA + NTH - 1) / NTH, NB = (32 * CB + NTH - 1) / NTH;
     constexpr int WA = TCO / (16 * WR), WB = TK / (16 * WC);
-    __shared__ __attribute__((aligned(16))) bf16_t Gs[2][2][32 * PA];       // [buffer][hi / lo]
-    __shared__ __attribute__((aligned(16))) bf16_t Xs[2][2][32 * PB];
+    __shared__ __attribute__((aligned(16))) bf16_t Gs[2][NPC][32 * PA];     // [buffer][hi / lo]
+    __shared__ __attribute__((aligned(16))) bf16_t Xs[2][NPC][32 * PB];
     __shared__ float bsum[TCO];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -375,10 +378,12 @@ __global__ __launch_bounds__(64 * WR * WC, BPC) void wgrad_tr32_k(const TrJobs j
     // 4 floats -> 4 hi + 4 lo bf16 (8 bytes each)
     auto split_store = [&](bf16_t* hi_img, bf16_t* lo_img, int off, f32x4 v) {
         const unsigned h01 = pk_bf16(v[0], v[1]), h23 = pk_bf16(v[2], v[3]);
-        const unsigned l01 = pk_bf16(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));
-        const unsigned l23 = pk_bf16(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));
         *reinterpret_cast<uint2*>(hi_img + off) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(lo_img + off) = make_uint2(l01, l23);
+        if (NPC == 2) {
+            const unsigned l01 = pk_bf16(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));
+            const unsigned l23 = pk_bf16(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));
+            *reinterpret_cast<uint2*>(lo_img + off) = make_uint2(l01, l23);
+        }
     };
     auto stash = [&](int set, int buf) {
         const unsigned vm = vmask[set];
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(64 * WR * WC, BPC) void wgrad_tr32_k(const TrJobs j
         for (int i = 0; i < NA; ++i) {
             if (!((vm >> i) & 1u)) rg[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if ((32 * CA) % NTH == 0 || i + 1 < NA || tid + NTH * i < 32 * CA)
-                split_store(Gs[buf][0], Gs[buf][1], ra[i] * PA + ca[i] * 4, rg[set][i]);
+                split_store(Gs[buf][0], Gs[buf][NPC - 1], ra[i] * PA + ca[i] * 4, rg[set][i]);
             if (do_bias) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bacc[i][j] += rg[set][i][j];
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(64 * WR * WC, BPC) void wgrad_tr32_k(const TrJobs j
         for (int i = 0; i < NB; ++i) {
             if (!((vm >> (8 + i)) & 1u)) rx[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if ((32 * CB) % NTH == 0 || i + 1 < NB || tid + NTH * i < 32 * CB)
-                split_store(Xs[buf][0], Xs[buf][1], rb[i] * PB + cb[i] * 4, rx[set][i]);
+                split_store(Xs[buf][0], Xs[buf][NPC - 1], rb[i] * PB + cb[i] * 4, rx[set][i]);
         }
     };
     f32x4 acc[WA][WB];
@@ -414,20 +419,23 @@ __global__ __launch_bounds__(64 * WR * WC, BPC) void wgrad_tr32_k(const TrJobs j
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     auto mma = [&](int buf) {
-        bf16x8 bh[WB], bl[WB];
+        bf16x8 bh[WB], bl[NPC == 2 ? WB : 1];
 #pragma unroll
         for (int b = 0; b < WB; ++b) {
             bh[b] = frag(Xs[buf][0], tr_b + b * 16, PB);
-            bl[b] = frag(Xs[buf][1], tr_b + b * 16, PB);
+            if (NPC == 2) bl[b * (NPC - 1)] = frag(Xs[buf][NPC - 1], tr_b + b * 16, PB);
         }
 #pragma unroll
         for (int a = 0; a < WA; ++a) {
-            const bf16x8 ah = frag(Gs[buf][0], tr_a + a * 16, PA), al = frag(Gs[buf][1], tr_a + a * 16, PA);
+            const bf16x8 ah = frag(Gs[buf][0], tr_a + a * 16, PA);
             // the three piece products of a tile are five MFMAs apart: back to back they wait for each other's result
+            if (NPC == 2) {
+                const bf16x8 al = frag(Gs[buf][NPC - 1], tr_a + a * 16, PA);
 #pragma unroll
-            for (int b = 0; b < WB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < WB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], acc[a][b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < WB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < WB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[b * (NPC - 1)], acc[a][b], 0, 0, 0);
+            }
 #pragma unroll
             for (int b = 0; b < WB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[b], acc[a][b], 0, 0, 0);
         }
@@ -746,10 +754,19 @@ extern "C" int s2ag_f32_wgrad_tr_n(const s2ag_bf16_wgrad_args* jobs, int njobs, 
     const bool direct = ms <= 16;
     const dim3 grid(nblk), rgrid(cdiv(max_red, direct ? 256 : 32), njobs);
     hipStream_t st = (hipStream_t)stream;
-    if (big) {
+    const bool one = s2ag_gru_coop_split_pieces() == 1;       // bf16 step mode: one piece per operand, one product
+    if (big && one) {
+        hipLaunchKernelGGL((wgrad_tr32_k<160, 160, 3, 1, 2, 2, 1>), grid, dim3(256), 0, st, js);
+        if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, true>), rgrid, dim3(256), 0, st, js);
+        else hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, false>), rgrid, dim3(256), 0, st, js);
+    } else if (big) {
         hipLaunchKernelGGL((wgrad_tr32_k<160, 160, 3, 1>), grid, dim3(256), 0, st, js);
         if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, true>), rgrid, dim3(256), 0, st, js);
         else hipLaunchKernelGGL((wgrad_tr_reduce_k<160, 160, false>), rgrid, dim3(256), 0, st, js);
+    } else if (one) {
+        hipLaunchKernelGGL((wgrad_tr32_k<64, 64, 3, 2, 2, 2, 1>), grid, dim3(256), 0, st, js);
+        if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<64, 64, true>), rgrid, dim3(256), 0, st, js);
+        else hipLaunchKernelGGL((wgrad_tr_reduce_k<64, 64, false>), rgrid, dim3(256), 0, st, js);
     } else {
         hipLaunchKernelGGL((wgrad_tr32_k<64, 64, 3, 2>), grid, dim3(256), 0, st, js);
         if (direct) hipLaunchKernelGGL((wgrad_tr_reduce_k<64, 64, true>), rgrid, dim3(256), 0, st, js);

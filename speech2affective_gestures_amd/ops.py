@@ -449,7 +449,7 @@ class _ConvNLC(torch.autograd.Function):
             # encoder's conv2-4): weight gradient through the LDS transpose read with the window as ONE tap of ks*Cin channels
             flat_tr = (CONV_WGRAD_TR and wslot is not None and not wtm and pad == 0 and dil == 1 and ks > 1 and ldx_ == Cin
                        and Cin % 4 == 0 and Cout % 4 == 0 and Lout >= 32 and flops >= 4e8
-                       and lib.s2ag_gru_coop_split_pieces() == 2)
+                       and lib.s2ag_gru_coop_split_pieces() in (1, 2))
 
             def leaves():
                 if flat_tr:
@@ -1546,7 +1546,7 @@ class _GRU(torch.autograd.Function):
             if all(sl is not None for sl in slots) and pair_ih is not None and pair_bi is not None:
                 # arena layout: the two directions are adjacent, so dW_ih / db_ih of both are one launch each
                 def leaves(dgi=dgi, dgh=dgh, y=y, inp=inp, In=In, pair_ih=pair_ih, pair_bi=pair_bi, slots=slots, l=l):
-                    if (GRU_WGRAD_TR and lib.s2ag_gru_coop_split_pieces() == 2 and T >= 32 and In % 4 == 0 and H % 4 == 0
+                    if (GRU_WGRAD_TR and lib.s2ag_gru_coop_split_pieces() in (1, 2) and T >= 32 and In % 4 == 0 and H % 4 == 0
                             and 2.0 * B * T * (In + H) * 2 * H3 >= SPLIT_GEMM_MIN_FLOPS):
                         # the layer's three weight gradients on the bf16 pipe through the LDS transpose read
                         # (csrc/wgrad_tr.hip, fp32 rows split into two bf16 pieces by the loader): one launch + reduce

@@ -269,8 +269,9 @@ def test_clip_resident_tcn_equals_the_layer_by_layer_bf16_path(B):
 
 def test_full_size_steps_with_the_conv_path_in_bf16_mode():
     """BASELINE configs[1] in bf16 mode: the whole GAN step at B = 128, H = 300 with the wave encoder (frozen tri-modal
-    baseline) and the text TCN (clip-resident kernels + transpose-read weight gradients) in bf16 -- eager and graph
-    replayed.  From identical weights and noise the first step's loss components stay within 2 % of the fp32 step's (the
+    baseline) and the text TCN (clip-resident kernels + transpose-read weight gradients) in bf16 -- and, as 'bf16_step', with
+    every large matrix product (GRU recurrence, projections, weight gradients) on one bf16 piece per operand -- eager and
+    graph replayed.  From identical weights and noise the first step's loss components stay within 3 % of the fp32 step's (the
     encoders' features differ by ~1e-2 of their largest element), every later step stays finite, the cooperative GRU loses
     no peer."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -280,7 +281,7 @@ def test_full_size_steps_with_the_conv_path_in_bf16_mode():
     batch = bench.synthetic_batch(128, 3, pr.device)
     g0, d0 = pr.gen_arena.data.clone(), pr.dis_arena.data.clone()
     first = {}
-    for mode in ('fp32', 'bf16'):
+    for mode in ('fp32', 'bf16', 'bf16_step'):
         pr.gen_arena.data.copy_(g0)
         pr.dis_arena.data.copy_(d0)
         pr._graphed = None
@@ -295,6 +296,8 @@ def test_full_size_steps_with_the_conv_path_in_bf16_mode():
                 assert all(math.isfinite(v) for v in pr.last_losses.values()), pr.last_losses
         pr._graphed = None
     assert ops.coop_gru_timeouts() == 0
-    print('[bf16 step] first-step losses fp32', first['fp32'], 'bf16', first['bf16'])
+    print('[bf16 step] first-step losses fp32', first['fp32'], 'bf16', first['bf16'], 'bf16_step', first['bf16_step'])
     for k, v in first['fp32'].items():
-        assert abs(first['bf16'][k] - v) <= 0.02 * max(abs(v), 0.05), (k, v, first['bf16'][k])
+        assert abs(first['bf16'][k] - v) <= 0.03 * max(abs(v), 0.05), (k, v, first['bf16'][k])
+        # ... and with single-piece bf16 products in the GRU, its projections and the weight gradients as well
+        assert abs(first['bf16_step'][k] - v) <= 0.03 * max(abs(v), 0.05), (k, v, first['bf16_step'][k])

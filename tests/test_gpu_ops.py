@@ -561,11 +561,12 @@ def test_lockstep_gru_passes_equal_separate_launches(S, B, I, H, L, sum_dirs, n_
     assert ops.coop_gru_timeouts() == 0
 
 
-@pytest.mark.parametrize('pieces,tol', [(0, 3e-6), (3, 3e-6), (2, 2e-5)])
+@pytest.mark.parametrize('pieces,tol', [(0, 3e-6), (3, 3e-6), (2, 2e-5), (1, 2e-2)])
 def test_coop_gru_products_on_the_bf16_pipe(S, pieces, tol):
     """H = 300 recurrence: the per-step products as exact bf16-piece splits of the fp32 operands (3 pieces = default,
     2 pieces) against the f32-MFMA kernels (0) -- all three checked against an fp64 torch GRU.  Three pieces must be as
-    accurate as the f32 MFMA; two pieces carry 16 mantissa bits."""
+    accurate as the f32 MFMA; two pieces carry 16 mantissa bits; one piece (bf16.precision('bf16_step'): a single bf16 product,
+    8 mantissa bits per operand) is held to 2e-2 of the largest element over the two layers and 34 steps."""
     ops, noise, lib = S['ops'], S['noise'], S['ops']._lib()
     B, T, I, H, L_ = 21, 34, 88, 300, 2
     sd = _gru_sd(I, H, L_, 4242)
