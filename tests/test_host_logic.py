@@ -417,3 +417,35 @@ print(json.dumps({
         got['STGraphConv'].startswith('(self, in')
     assert got['STGraphConv.forward'] == '(self, x, A)'
     assert got['Graph'].startswith('(self, num_nodes, neighbor_links, strategy')
+
+
+def test_precision_modes_select_the_product_setting_and_restore_it():
+    """bf16.precision('bf16_step') switches the library to single-piece bf16 products (s2ag_gru_coop_set_split_pieces(1)) for
+    its extent only; 'bf16' touches the Conv1d path alone.  Host-only state: no GPU needed."""
+    from speech2affective_gestures_amd import _lib as L
+    from speech2affective_gestures_amd import bf16
+    lib = L.load()
+    before = lib.s2ag_gru_coop_split_pieces()
+    assert before in (0, 2, 3) and not bf16.enabled() and not bf16.step_mode()
+    with bf16.precision('bf16'):
+        assert bf16.enabled() and not bf16.step_mode() and lib.s2ag_gru_coop_split_pieces() == before
+        with bf16.precision('bf16_step'):
+            assert bf16.enabled() and bf16.step_mode() and lib.s2ag_gru_coop_split_pieces() == 1
+        assert bf16.enabled() and not bf16.step_mode() and lib.s2ag_gru_coop_split_pieces() == before
+    assert not bf16.enabled() and lib.s2ag_gru_coop_split_pieces() == before
+
+
+def test_fused_wave_head_geometry_and_build_flavours():
+    """wave12.lengths follows Conv1d arithmetic (net/multimodal_context_net_v2.py:18-21); wave12.supported accepts exactly the
+    reference's head; the debug / asan flavours of the library are declared with the same sources."""
+    import torch.nn as nn
+    from speech2affective_gestures_amd import build, wave12
+    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import WavEncoder
+    assert wave12.lengths(36267) == (7891, 1313) and wave12.lengths(146000) == (29838, 4971)
+    fe = WavEncoder().feat_extractor
+    assert wave12.supported(fe)
+    fe2 = nn.Sequential(nn.Conv1d(1, 16, 15, stride=4, padding=1600), *list(fe)[1:])
+    assert not wave12.supported(fe2)
+    assert set(build.FLAVOURS) == {'release', 'debug', 'asan'}
+    assert build.FLAVOURS['debug']['lib'].endswith('libs2ag_hip_debug.so') and '-DS2AG_DEBUG=1' in build.FLAVOURS['debug']['extra']
+    assert 'xnack+' in build.FLAVOURS['asan']['arch']
