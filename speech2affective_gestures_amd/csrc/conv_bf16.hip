@@ -736,6 +736,29 @@ __global__ __launch_bounds__(256) void epilogue_bwd_bf16_k(const bf16_t* __restr
     }
 }
 
+// flat-index form (the default until the row form below has been through the GPU suite)
+__global__ __launch_bounds__(256) void embedding_fwd_bf16_flat_k(const long long* __restrict__ ids, const float* __restrict__ table,
+                                                            long long rows, int dim, int n_entries, int ld, float drop_p,
+                                                            float inv_keep, const unsigned long long* rng, unsigned site,
+                                                            bf16_t* __restrict__ out) {
+    SiteKey key{0, 0};
+    const bool drop = drop_p > 0.f;
+    if (drop) key = site_key(rng, site);
+    const long long total = rows * ld;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / ld;
+        const int c = (int)(i - r * ld);
+        float v = 0.f;
+        if (c < dim) {
+            long long id = ids[r];
+            if (id < 0 || id >= n_entries) id = 0;
+            v = table[id * dim + c];
+            if (drop) v *= keep_scale(key, (unsigned long long)r * dim + c, drop_p, inv_keep);
+        }
+        out[i] = (bf16_t)bf16_rn(v);
+    }
+}
+
 // embedding rows -> bf16 (rows, ld) with dropout; pad columns zero.  A workgroup owns 8 token rows (a wave two), lanes run
 // over channel pairs: no index division per element, 4-byte stores (ld is even: a multiple of 32)
 __global__ __launch_bounds__(256) void embedding_fwd_bf16_k(const long long* __restrict__ ids, const float* __restrict__ table,
@@ -1083,10 +1106,15 @@ extern "C" int s2ag_bf16_embedding_fwd(const long long* ids, const float* table,
     if (!ids || !table || !out || rows <= 0 || dim <= 0 || ld < dim) return S2AG_E_BADARG;
     const float p = e ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
-    if ((ld & 1) || ((uintptr_t)out & 3)) return S2AG_E_UNSUPPORTED;
-    hipLaunchKernelGGL(embedding_fwd_bf16_k, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, ids, table, rows,
-                       dim, n_entries, ld, p, p > 0.f ? 1.f / (1.f - p) : 1.f, e ? e->rng : nullptr, e ? e->site : 0u,
-                       static_cast<bf16_t*>(out));
+    static const int row_form = [] { const char* v = getenv("S2AG_EMB_FWD_ROWS"); return v ? atoi(v) : 0; }();
+    if (row_form && !(ld & 1) && !((uintptr_t)out & 3))
+        hipLaunchKernelGGL(embedding_fwd_bf16_k, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, ids, table,
+                           rows, dim, n_entries, ld, p, p > 0.f ? 1.f / (1.f - p) : 1.f, e ? e->rng : nullptr,
+                           e ? e->site : 0u, static_cast<bf16_t*>(out));
+    else
+        hipLaunchKernelGGL(embedding_fwd_bf16_flat_k, dim3(ew_blocks(rows * ld)), dim3(256), 0, (hipStream_t)stream, ids, table,
+                           rows, dim, n_entries, ld, p, p > 0.f ? 1.f / (1.f - p) : 1.f, e ? e->rng : nullptr,
+                           e ? e->site : 0u, static_cast<bf16_t*>(out));
     S2AG_LAUNCH_CHECK();
     return 0;
 }

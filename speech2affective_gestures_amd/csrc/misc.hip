@@ -1,5 +1,7 @@
 // Embedding gather/scatter, weight-norm, CSR fold, transpose, re-parametrisation, fused GAN losses,
 // flat-arena Adam and the noise materialisers.
+#include <stdlib.h>
+
 #include "s2ag_common.h"
 
 namespace {
@@ -13,6 +15,26 @@ inline int ew_grid(long long total) {
 }
 
 // ---- embedding -------------------------------------------------------------------------------------
+// flat-index form (one element per thread and trip; the default until the row form below has been through the GPU suite)
+__global__ __launch_bounds__(256) void embedding_fwd_flat_k(const long long* ids, const float* __restrict__ table, int rows,
+                                                       int dim, int n_entries, float* __restrict__ out, int ldo,
+                                                       float drop_p, float inv_keep, const unsigned long long* rng,
+                                                       unsigned site) {
+    const long long total = (long long)rows * dim;
+    SiteKey key{0, 0};
+    if (drop_p > 0.f) key = site_key(rng, site);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / dim), c = (int)(i - (long long)r * dim);
+        long long id = ids[r];
+        S2AG_DBG_ASSERT(id >= 0 && id < n_entries);      // nn.Embedding raises here; the release build clamps
+        id = id < 0 ? 0 : (id >= n_entries ? n_entries - 1 : id);
+        float v = table[id * dim + c];
+        if (drop_p > 0.f) v *= keep_scale(key, (unsigned long long)i, drop_p, inv_keep);
+        out[(long long)r * ldo + c] = v;
+    }
+}
+
 // A workgroup owns 8 consecutive token rows (a wave two of them), its lanes run over the columns: no index division per
 // element (the flat-index form spent its time in a 64-bit i / dim: 12.5 us for 20 MB at 256 clips).
 constexpr int EMBF_RB = 8;
@@ -549,9 +571,15 @@ extern "C" int s2ag_embedding_fwd(const long long* ids, const float* table, int 
     if (!ids || !table || !out || rows <= 0 || dim <= 0 || n_entries <= 0 || ldo < dim) return S2AG_E_BADARG;
     const float p = e ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
-    hipLaunchKernelGGL(embedding_fwd_k, dim3(cdiv(rows, EMBF_RB)), dim3(256), 0, (hipStream_t)stream, ids,
-                       table, rows, dim, n_entries, out, ldo, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
-                       e ? e->rng : nullptr, e ? e->site : 0u);
+    static const int row_form = [] { const char* v = getenv("S2AG_EMB_FWD_ROWS"); return v ? atoi(v) : 0; }();
+    if (row_form)
+        hipLaunchKernelGGL(embedding_fwd_k, dim3(cdiv(rows, EMBF_RB)), dim3(256), 0, (hipStream_t)stream, ids,
+                           table, rows, dim, n_entries, out, ldo, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
+                           e ? e->rng : nullptr, e ? e->site : 0u);
+    else
+        hipLaunchKernelGGL(embedding_fwd_flat_k, dim3(ew_grid((long long)rows * dim)), dim3(256), 0, (hipStream_t)stream, ids,
+                           table, rows, dim, n_entries, out, ldo, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
+                           e ? e->rng : nullptr, e ? e->site : 0u);
     S2AG_LAUNCH_CHECK();
     return 0;
 }
