@@ -138,7 +138,8 @@ class WavEncoder(nn.Module):
             return self._forward_bf16(wav_data)
         from .. import wave12
         fe = self.feat_extractor
-        if fe[1].training and fe[4].training and wav_data.is_cuda and wave12.supported(fe):
+        if (fe[1].training and fe[4].training and wav_data.is_cuda and wav_data.dtype == torch.float32 and wav_data.dim() == 2
+                and wave12.supported(fe)):
             # conv1 -> BatchNorm -> LeakyReLU -> conv2 without conv1's (B, 7891, 16) output in HBM (csrc/wave12.hip)
             x = wave12.head_f32(wav_data, fe)
         else:

@@ -63,6 +63,13 @@ def packed_weights(w1: Tensor, w2: Tensor) -> Tensor:
     return ent[1]
 
 
+def _check_wav(wav: Tensor) -> None:
+    """The kernels read (clips, samples) fp32 rows; there is no CPU path (ops.py raises likewise)."""
+    if not (wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.is_contiguous()):
+        raise RuntimeError('wave12: the waveform must be a contiguous (clips, samples) float32 CUDA tensor, got '
+                           f'{tuple(wav.shape)} {wav.dtype} on {wav.device}')
+
+
 def fold_args(bn, gamma, beta, prow: int, dev, keep: list):
     """BatchNorm fold done by the producing launch's last workgroup: -> (coef (4, C): scale, shift, mean, invstd; args)"""
     coef = torch.empty(4, gamma.numel(), dtype=torch.float32, device=dev)
@@ -76,6 +83,7 @@ def fold_args(bn, gamma, beta, prow: int, dev, keep: list):
 def stats(wav: Tensor, pk: Tensor, b1: Tensor, bn1, gamma1: Tensor, beta1: Tensor, round_bf16: bool, pad: int = PAD1) -> Tensor:
     """Batch statistics of conv1's output -> BatchNorm 1's running estimates and coefficients (4, 16)."""
     lib = _lib()
+    _check_wav(wav)
     N, Lin = wav.shape
     L1, _ = lengths(Lin, pad)
     prow = lib.s2ag_wave12_stats_rows(N, L1)
@@ -92,6 +100,7 @@ def forward(wav: Tensor, pk: Tensor, b1: Tensor, coef1: Tensor, slope: float, b2
     """-> (z2 (N, L2, 32), partial column sums (2, rows (+ groups), 32) fp64, rows).  ``fold`` = (bn2, gamma2, beta2):
     BatchNorm 2's coefficients from the same launch (returned as a 4th element)."""
     lib = _lib()
+    _check_wav(wav)
     N, Lin = wav.shape
     L1, L2 = lengths(Lin, pad)
     dev = wav.device

@@ -449,3 +449,11 @@ def test_fused_wave_head_geometry_and_build_flavours():
     assert set(build.FLAVOURS) == {'release', 'debug', 'asan'}
     assert build.FLAVOURS['debug']['lib'].endswith('libs2ag_hip_debug.so') and '-DS2AG_DEBUG=1' in build.FLAVOURS['debug']['extra']
     assert 'xnack+' in build.FLAVOURS['asan']['arch']
+
+
+def test_fused_wave_head_refuses_cpu_and_non_fp32_waveforms():
+    """No CPU fallback in the fused head either: a CPU or non-fp32 waveform raises before any launch."""
+    import pytest
+    from speech2affective_gestures_amd import wave12
+    with pytest.raises(RuntimeError, match='float32 CUDA'):
+        wave12._check_wav(torch.zeros(2, 100))
