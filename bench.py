@@ -96,6 +96,9 @@ def matrix_products_mode():
     from speech2affective_gestures_amd import _lib as L
     np_ = int(L.load().s2ag_gru_coop_split_pieces())
     return {0: 'f32 MFMA (v_mfma_f32_16x16x4_f32) everywhere',
+            1: 'bf16 step mode (S2AG_PRECISION=bf16_step): fp32 operands as ONE bf16 piece (one product, 8 mantissa bits per '
+               'operand, fp32 accumulation) for the GRU recurrence, its input projections / input gradients and all large '
+               'weight gradients; bf16 activations in the wave encoder and the text TCN; f32 MFMA elsewhere',
             2: 'fp32 operands as 2 bf16 pieces (3 products, 16 mantissa bits, fp32 accumulation) on the bf16 matrix pipe for '
                'the GRU recurrence, its input projections / input gradients / weight gradients and the text TCN (forward, '
                'data and weight gradients); f32 MFMA elsewhere',
@@ -107,7 +110,8 @@ def matrix_products_mode():
 def dtype_label():
     """What the step computes in (storage / products), for the line's `dtype`."""
     from speech2affective_gestures_amd import _lib as L
-    return {0: 'f32 (f32 MFMA products)', 2: 'f32-storage/bf16x2-products', 3: 'f32-storage/bf16x3-products'}[
+    return {0: 'f32 (f32 MFMA products)', 1: 'bf16 products (one piece) / f32 storage of the GRU, bf16 Conv1d path',
+            2: 'f32-storage/bf16x2-products', 3: 'f32-storage/bf16x3-products'}[
         int(L.load().s2ag_gru_coop_split_pieces())]
 
 
@@ -554,7 +558,7 @@ def alt_modes(pr, dp, batch, B, steps=20):
             el = timed_steps(pr, dp, batch, steps, 2, False)
             out[tag] = dict(clips_per_s=B * dp.world_size * steps / el, ms_per_step=el / steps * 1e3, steps=steps)
     finally:
-        lib.s2ag_gru_coop_set_split_pieces(prev if prev in (0, 2, 3) else -1)
+        lib.s2ag_gru_coop_set_split_pieces(prev if prev in (0, 1, 2, 3) else -1)
         pr._graphed = None
     # BASELINE configs[1] names bf16: the same step with the Conv1d path (wave encoder, text TCN) in bf16 mode -- bf16
     # activations in HBM, fp32 accumulation / statistics / master weights (bf16.py; its own, looser parity tests)
