@@ -49,5 +49,6 @@ if has mfma; then
     python tools/rocpd_pmc.py $(db c3m_$m) > $O/r03_pmc_cfg3_${m}_MFMA_BUSY.txt
   done
 fi
+for m in step cfg3_fp32 cfg3_bf16; do [ -f $O/r03_pmc_${m}_MFMA_BUSY.txt ] && python tools/mfma_util.py $O/r03_pmc_${m}_MFMA_BUSY.txt > $O/r03_mfma_util_${m}.txt; done
 find $O -name "*.db" -delete
 ls -la $O | head -60
