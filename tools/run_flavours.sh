@@ -6,6 +6,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/flavours; mkdir -p $O
 cd $R
 P=$R/speech2affective_gestures_amd
+[ -f $P/libs2ag_hip_debug.so ] || python -m speech2affective_gestures_amd.build --debug > $O/build_debug.log 2>&1
+[ "$WITH_ASAN" = "1" ] && { [ -f $P/libs2ag_hip_asan.so ] || python -m speech2affective_gestures_amd.build --asan > $O/build_asan.log 2>&1; }
 {
 echo "== debug flavour (S2AG_DBG_ASSERT on, -O1 -g): whole GPU suite =="
 if [ -f $P/libs2ag_hip_debug.so ]; then
