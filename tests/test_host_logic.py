@@ -457,3 +457,44 @@ def test_fused_wave_head_refuses_cpu_and_non_fp32_waveforms():
     from speech2affective_gestures_amd import wave12
     with pytest.raises(RuntimeError, match='float32 CUDA'):
         wave12._check_wav(torch.zeros(2, 100))
+
+
+def test_conv1_weight_gradient_from_three_sums_identity():
+    """The algebra csrc/wave12.hip relies on, in float64 on the CPU: behind a training-mode BatchNorm the gradient w.r.t. conv1's
+    output is dz1 = A du1 + C z1 + B per channel (A = gamma r, C = -gamma r^2 m2, B = gamma r (r mu m2 - m1); m1 = mean(du1),
+    m2 = mean(du1 xhat)), so conv1's weight gradient is A S_du + C S_z + B S_x with three sums over (frame, tap) that do not
+    involve A, B, C -- and the bias gradient is identically zero.  Checked against autograd through
+    Conv1d(1,16,15,s5,p1600) -> BatchNorm1d -> LeakyReLU(0.3) -> Conv1d(16,32,15,s6) (net/multimodal_context_net_v2.py:18-21)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    N, Lin, pad = 2, 700, 1600
+    x = torch.randn(N, Lin, generator=g, dtype=torch.float64) * 0.05
+    w1 = (torch.randn(16, 1, 15, generator=g, dtype=torch.float64) / 4).requires_grad_(True)
+    b1 = (torch.randn(16, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    gam = torch.rand(16, generator=g, dtype=torch.float64) + 0.5
+    bet = torch.randn(16, generator=g, dtype=torch.float64) * 0.3
+    w2 = torch.randn(32, 16, 15, generator=g, dtype=torch.float64) / 15.5
+    z1 = F.conv1d(x.unsqueeze(1), w1, b1, stride=5, padding=pad)                      # (N, 16, L1)
+    mu, var = z1.mean(dim=(0, 2)), z1.var(dim=(0, 2), unbiased=False)
+    r = (var + 1e-5).rsqrt()
+    xhat = (z1 - mu[None, :, None]) * r[None, :, None]
+    t = xhat * gam[None, :, None] + bet[None, :, None]
+    a1 = torch.where(t > 0, t, 0.3 * t)
+    z2 = F.conv1d(a1, w2, None, stride=6)
+    dy2 = torch.randn(z2.shape, generator=g, dtype=torch.float64)
+    (z2 * dy2).sum().backward()
+    with torch.no_grad():
+        da1 = F.conv_transpose1d(dy2, w2, stride=6)
+        da1 = F.pad(da1, (0, z1.shape[2] - da1.shape[2]))
+        du1 = torch.where(t > 0, da1, 0.3 * da1)                                   # gradient w.r.t. BatchNorm 1's output
+        rows = z1.shape[0] * z1.shape[2]
+        m1, m2 = du1.sum(dim=(0, 2)) / rows, (du1 * xhat).sum(dim=(0, 2)) / rows
+        A, C_, B = gam * r, -gam * r * r * m2, gam * r * (r * mu * m2 - m1)
+        win = F.pad(x, (pad, pad)).unfold(1, 15, 5)                                # (N, L1, 15): the window under every frame
+        S_du = torch.einsum('ncf,nft->ct', du1, win)
+        S_z = torch.einsum('ncf,nft->ct', z1, win)
+        S_x = win.sum(dim=(0, 1))
+        dw1 = A[:, None] * S_du + C_[:, None] * S_z + B[:, None] * S_x[None, :]
+        dz1 = A[None, :, None] * du1 + C_[None, :, None] * z1 + B[None, :, None]
+    assert torch.allclose(dw1, w1.grad[:, 0, :], rtol=1e-9, atol=1e-12)
+    assert float(b1.grad.abs().max()) < 1e-12 * float(dy2.abs().sum()) and float(dz1.sum(dim=(0, 2)).abs().max()) < 1e-9
