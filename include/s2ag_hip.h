@@ -527,6 +527,34 @@ int s2ag_wave_conv1_wgrad_blocks(const s2ag_conv_geom* g);
 int s2ag_wave_conv1_wgrad(const void* dz, const void* y1, const float* ca, const float* cb, const float* cc, const float* x,
                           float* partials, float* dw, float* db, const s2ag_conv_geom* g, void* stream);
 
+/* ---- the same folding for the fp32 mode: conv3 / conv4 of the wave encoder on fp32 rows (csrc/wave_fused.hip) ------------
+ * feat_extractor.{4..9} of WavEncoder (net/multimodal_context_net_v2.py:22-27: BatchNorm1d(32) LeakyReLU(0.3)
+ * Conv1d(32,64,15,stride 6) BatchNorm1d(64) LeakyReLU(0.3) Conv1d(64,32,15,stride 6)) and their backward, every tensor fp32
+ * in HBM.  Forward products on the f32 matrix pipe (an fmaf chain: the reference's arithmetic); the two gradients take dy,
+ * the activation and the weights as two bf16 pieces each (hi = rn(v), lo = rn(v - hi): three products, 16 mantissa bits,
+ * as s2ag_f32_wgrad_tr).  (Cin, Cout) in {(32, 64), (64, 32)}.
+ *   s2ag_wave_tail32_pack   w3 (64, 32, 15), w4 (32, 64, 15) -> one buffer of s2ag_wave_tail32_pack_bytes() bytes (16-byte
+ *                           aligned): per layer the k-major fp32 matrix (15 Cin, Cout) of the forward and the phase form
+ *                           (2 pieces, 6, Cin, 3, Cout) bf16 of the data gradient, at s2ag_wave_tail32_pack_offset(layer, phases)
+ *   s2ag_wave_conv_fwd32    y = conv(leaky(in_scale x + in_shift)) + bias; stats / fold as s2ag_wave_conv_fwd
+ *                           (partial rows: s2ag_wave_fwd_rows)
+ *   s2ag_wave_conv_dgrad32  s2ag_wave_conv_dgrad on fp32 rows (g_is_dy: `dz` is dy itself -- the last conv)
+ *   s2ag_wave_conv_wgrad32  s2ag_wave_conv_wgrad on fp32 rows (partials: s2ag_wave_wgrad_blocks) */
+long long s2ag_wave_tail32_pack_bytes(void);
+long long s2ag_wave_tail32_pack_offset(int layer /*0: conv3, 1: conv4*/, int phases /*0: k-major fp32, 1: phase form*/);
+int s2ag_wave_tail32_pack(const float* w3, const float* w4, void* out, void* stream);
+int s2ag_wave_conv_fwd32(const float* x, const float* in_scale, const float* in_shift, float slope, const float* w_kmajor,
+                         const float* bias, float* y, double* stats, const s2ag_bn_fold_args* fold, int N, int Lin, int Lout,
+                         int Cin, int Cout, void* stream);
+int s2ag_wave_conv_dgrad32(const float* dz, const float* y, const float* ca, const float* cb, const float* cc, int g_is_dy,
+                           const void* w_phases2, const float* y_prev, const float* p_scale, const float* p_shift,
+                           const float* p_mean, const float* p_invstd, float slope, float* dz_prev, double* stats, int* ticket,
+                           const float* p_gamma, float* dgamma, float* dbeta, float* out_ca, float* out_cb, float* out_cc, int N,
+                           int Lin, int Lout, int Cin, int Cout, void* stream);
+int s2ag_wave_conv_wgrad32(const float* dz, const float* y, const float* ca, const float* cb, const float* cc, int g_is_dy,
+                           const float* y_prev, const float* p_scale, const float* p_shift, float slope, float* partials,
+                           float* partials_b, float* dw, float* db, int N, int Lin, int Lout, int Cin, int Cout, void* stream);
+
 /* ---- head of the wave encoder without its (N, L1, 16) tensor in HBM (csrc/wave12.hip) ---------------------------------
  * Replaces feat_extractor[0..3] of WavEncoder (net/multimodal_context_net_v2.py:18-21: Conv1d(1,16,15,stride 5,padding)
  * BatchNorm1d(16) LeakyReLU(0.3) Conv1d(16,32,15,stride 6)) in training mode, forward and backward: conv1's output is
@@ -543,7 +571,8 @@ int s2ag_wave_conv1_wgrad(const void* dz, const void* y1, const float* ca, const
  *                      as two bf16 pieces, three products); partials (nullable): (2, rows (+ ceil(rows / 16)), 32) doubles,
  *                      rows = s2ag_wave12_fwd_rows: column sums of z2 / z2^2; fold (nullable): BatchNorm 2's fold in the
  *                      same launch.
- *   s2ag_wave12_bwd    from dy2 = the gradient w.r.t. z2 -- fp32 rows (dz_f32 = 1) or, in bf16 mode, ca2 dz + cc2 z2 + cb2
+ *   s2ag_wave12_bwd    from dy2 = the gradient w.r.t. z2 -- fp32 rows (dz_f32 = 1), or ca2 dz + cc2 z2 + cb2 from bf16 rows
+ *                      (dz_f32 = 0, bf16 mode) or from fp32 rows (dz_f32 = 2: the fp32 tail above it, same blocks as 1)
  *                      formed from the bf16 rows dz / z2 (wave_fused.hip) --: dw2 (32, 16, 15) +=,
  *                      dw1 (16, 1, 15) += (each nullable), dgamma1 / dbeta1 += (nullable), and ca1 / cb1 / cc1 (16 each:
  *                      dz1 = ca1 du1 + cc1 z1 + cb1, kept for inspection).  0 <= slope <= 1.  The gradients of the two biases are identically

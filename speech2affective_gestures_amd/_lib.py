@@ -176,6 +176,12 @@ SIGNATURES = {
     's2ag_wave_wgrad_blocks': [ci, ci, ci, ci],
     's2ag_wave_conv_wgrad': [vp, vp, vp, vp, vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     's2ag_wave_bn_bwd_fold': [vp, ci, ci, cll, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    's2ag_wave_tail32_pack_bytes': [],
+    's2ag_wave_tail32_pack_offset': [ci, ci],
+    's2ag_wave_tail32_pack': [vp, vp, vp, vp],
+    's2ag_wave_conv_fwd32': [vp, vp, vp, cf, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    's2ag_wave_conv_dgrad32': [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    's2ag_wave_conv_wgrad32': [vp, vp, vp, vp, vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     's2ag_wave12_pack_elems': [],
     's2ag_wave12_pack': [vp, vp, vp, vp],
     's2ag_wave12_stats_rows': [ci, ci],
@@ -258,7 +264,8 @@ def load():
         fn.argtypes = args
         fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_gru_coop_fwd_multi_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes', 's2ag_bf16_tcn_keep_bytes',
                               's2ag_bf16_conv_wgrad_scratch_floats', 's2ag_bf16_conv_wgrad_tr_scratch_floats',
-                              's2ag_f32_wgrad_tr_scratch_floats', 's2ag_f32_wgrad_tr_scratch_floats_n', 's2ag_tcn32_pack_elems', 's2ag_tcn32_keep_bytes') else ci
+                              's2ag_f32_wgrad_tr_scratch_floats', 's2ag_f32_wgrad_tr_scratch_floats_n', 's2ag_tcn32_pack_elems', 's2ag_tcn32_keep_bytes', 's2ag_wave_tail32_pack_bytes',
+                              's2ag_wave_tail32_pack_offset') else ci
     if lib.s2ag_abi_version() != 1:
         raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
     if os.environ.get('S2AG_CRASH_TRACE', '0') == '1':     # native back trace on SIGSEGV & co (csrc/debug.hip)

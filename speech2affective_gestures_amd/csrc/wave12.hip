@@ -529,9 +529,10 @@ struct W12BwdP {
     const float* mean1;
     const float* inv1;
     float slope;
-    // dy2: XF: ca du2 + cc z2 + cb from the bf16 rows of du2 and z2 (wave_fused.hip); else fp32 rows in `dz`
+    // dy2: XF = 1: ca du2 + cc z2 + cb from the bf16 rows of du2 and z2 (wave_fused.hip); XF = 2: the same from fp32 rows;
+    // XF = 0: dy2 itself, fp32 rows in `dz`
     const void* dz;
-    const bf16_t* z2;
+    const void* z2;
     const float* ca;
     const float* cb;
     const float* cc;
@@ -569,8 +570,10 @@ __device__ __forceinline__ float ld_agent_f(const float* p) { return __hip_atomi
 //   phase 3 wave = (co tile, phase half): dW2[co, r + 6 i, ci] += sum_q dy2[q - i, co] a1[6 q + r, ci] (transpose reads);
 //           wave = (du1 | z1, phase half): S[c, t] += sum_q M[6 q + r, c] x[5 (6 q + r) + t]; the du1 waves also
 //           S_x[t] += sum_q x[5 (6 q + r) + t] (a ones-matrix against the same windows)
-template <int NP, bool XF>
+template <int NP, int XF>
 __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP p) {
+    static_assert(XF != 2 || NP == 2, "fp32 operands of dy2 belong to the fp32 mode");
+    constexpr int XW = XF == 2 ? 2 : 1;                            // 16-byte loads per 8-channel chunk of an operand of dy2
     constexpr int QT = 32, DROWS = QT + NT - 1;
     constexpr int PG = C2 + 8, PA = C1 + 8;
     constexpr int SEGN = 1024;                                     // >= 30 * 31 + 5 * 5 + 15 + 1 = 971
@@ -626,22 +629,30 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
     int c_clip = f_clip, c_q0 = f_q0;
     const int q_wrap = p.QS * QT;
 
-    u32x4 rd[RING], ry[RING];
+    u32x4 rd[RING][XW], ry[RING][XW];
     float rx[RING][4];
     auto fetch = [&](int s, int set) {
         const bool live = s < s_end;
-        rd[set] = ry[set] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < XW; ++k) rd[set][k] = ry[set][k] = u32x4{0u, 0u, 0u, 0u};
         const int l = f_q0 - (NT - 1) + d_row;
         if (live && d_own && (unsigned)l < (unsigned)p.L2) {
             S2AG_DBG_ASSERT(f_clip < p.N);
             const long long off = ((long long)f_clip * p.L2 + l) * C2 + d_col;
-            if constexpr (XF) {
-                rd[set] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off);
-                ry[set] = *reinterpret_cast<const u32x4*>(p.z2 + off);
+            if constexpr (XF == 1) {
+                rd[set][0] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off);
+                ry[set][0] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.z2) + off);
+            } else if constexpr (XF == 2) {
+                const float* gp = static_cast<const float*>(p.dz) + off;
+                const float* zp = static_cast<const float*>(p.z2) + off;
+                rd[set][0] = *reinterpret_cast<const u32x4*>(gp);
+                rd[set][XW - 1] = *reinterpret_cast<const u32x4*>(gp + 4);
+                ry[set][0] = *reinterpret_cast<const u32x4*>(zp);
+                ry[set][XW - 1] = *reinterpret_cast<const u32x4*>(zp + 4);
             } else {
                 const float* gp = static_cast<const float*>(p.dz) + off;
-                rd[set] = *reinterpret_cast<const u32x4*>(gp);
-                ry[set] = *reinterpret_cast<const u32x4*>(gp + 4);
+                rd[set][0] = *reinterpret_cast<const u32x4*>(gp);
+                ry[set][0] = *reinterpret_cast<const u32x4*>(gp + 4);
             }
         }
         const long long base = (long long)f_q0 * (S2 * S1) - p.pad;
@@ -664,17 +675,25 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = 0.f;
             if ((unsigned)l < (unsigned)p.L2) {
-                if constexpr (XF) {
-                    const unsigned d[4] = {rd[set].x, rd[set].y, rd[set].z, rd[set].w};
-                    const unsigned w[4] = {ry[set].x, ry[set].y, ry[set].z, ry[set].w};
+                if constexpr (XF == 1) {
+                    const unsigned d[4] = {rd[set][0].x, rd[set][0].y, rd[set][0].z, rd[set][0].w};
+                    const unsigned w[4] = {ry[set][0].x, ry[set][0].y, ry[set][0].z, ry[set][0].w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int c = d_col + 2 * j;
                         v[2 * j] = fmaf(coef2[0][c], bf_lo(d[j]), fmaf(coef2[2][c], bf_lo(w[j]), coef2[1][c]));
                         v[2 * j + 1] = fmaf(coef2[0][c + 1], bf_hi(d[j]), fmaf(coef2[2][c + 1], bf_hi(w[j]), coef2[1][c + 1]));
                     }
+                } else if constexpr (XF == 2) {
+                    const f32x4 d0 = __builtin_bit_cast(f32x4, rd[set][0]), d1 = __builtin_bit_cast(f32x4, rd[set][XW - 1]);
+                    const f32x4 w0 = __builtin_bit_cast(f32x4, ry[set][0]), w1 = __builtin_bit_cast(f32x4, ry[set][XW - 1]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = fmaf(coef2[0][d_col + j], d0[j], fmaf(coef2[2][d_col + j], w0[j], coef2[1][d_col + j]));
+                        v[4 + j] = fmaf(coef2[0][d_col + 4 + j], d1[j], fmaf(coef2[2][d_col + 4 + j], w1[j], coef2[1][d_col + 4 + j]));
+                    }
                 } else {
-                    const f32x4 a = __builtin_bit_cast(f32x4, rd[set]), b = __builtin_bit_cast(f32x4, ry[set]);
+                    const f32x4 a = __builtin_bit_cast(f32x4, rd[set][0]), b = __builtin_bit_cast(f32x4, ry[set][0]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         v[j] = a[j];
@@ -1120,12 +1139,13 @@ extern "C" int s2ag_wave12_bwd(const s2ag_wave12_bwd_args* a, void* stream) {
         !a->part_w2 || !a->part_s || !a->stats || !a->ticket || !a->ca1 || !a->cb1 || !a->cc1 ||
         !geom_ok(a->N, a->Lin, a->L1, a->L2, a->pad))
         return S2AG_E_BADARG;
-    if (!a->dz_f32 && (!a->z2 || !a->ca2 || !a->cb2 || !a->cc2)) return S2AG_E_BADARG;
+    if (a->dz_f32 < 0 || a->dz_f32 > 2) return S2AG_E_BADARG;
+    if (a->dz_f32 != 1 && (!a->z2 || !a->ca2 || !a->cb2 || !a->cc2)) return S2AG_E_BADARG;
     if (!(a->slope >= 0.f && a->slope <= 1.f)) return S2AG_E_UNSUPPORTED;      // leaky(t) = max(t, slope t)
     if (((uintptr_t)a->dz & 15) || ((uintptr_t)a->z2 & 15) || ((uintptr_t)a->packed & 15)) return S2AG_E_BADARG;
     W12BwdP p{};
     p.x = a->x; p.wp = static_cast<const bf16_t*>(a->packed); p.b1 = a->b1; p.sc1 = a->scale1; p.sh1 = a->shift1;
-    p.mean1 = a->mean1; p.inv1 = a->invstd1; p.slope = a->slope; p.dz = a->dz; p.z2 = static_cast<const bf16_t*>(a->z2);
+    p.mean1 = a->mean1; p.inv1 = a->invstd1; p.slope = a->slope; p.dz = a->dz; p.z2 = a->z2;
     p.ca = a->ca2; p.cb = a->cb2; p.cc = a->cc2; p.part_w2 = a->part_w2; p.part_s = a->part_s;
     p.stats = a->stats; p.ticket = a->ticket; p.gamma1 = a->gamma1; p.dgamma1 = a->dgamma1;
     p.dbeta1 = a->dbeta1; p.oca = a->ca1; p.ocb = a->cb1; p.occ = a->cc1;
@@ -1136,8 +1156,9 @@ extern "C" int s2ag_wave12_bwd(const s2ag_wave12_bwd_args* a, void* stream) {
     p.total_steps = a->N * p.QS;
     const int blocks = bwd_blocks(a->N, a->L1, a->dz_f32);
     hipStream_t s = (hipStream_t)stream;
-    if (a->dz_f32) hipLaunchKernelGGL((wv12_bwd_k<2, false>), dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((wv12_bwd_k<1, true>), dim3(blocks), dim3(256), 0, s, p);
+    if (a->dz_f32 == 1) hipLaunchKernelGGL((wv12_bwd_k<2, 0>), dim3(blocks), dim3(256), 0, s, p);
+    else if (a->dz_f32 == 2) hipLaunchKernelGGL((wv12_bwd_k<2, 2>), dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wv12_bwd_k<1, 1>), dim3(blocks), dim3(256), 0, s, p);
     W12FinP f{};
     f.part_w2 = a->part_w2; f.group_s = a->part_s + (size_t)blocks * SROW;
     f.ca = a->ca1; f.cb = a->cb1; f.cc = a->cc1; f.dw2 = a->dw2; f.dw1 = a->dw1;
