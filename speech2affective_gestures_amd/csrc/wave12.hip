@@ -596,6 +596,9 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
     // the kernel over the 256 registers two workgroups per CU can have; a fragment is re-read per use (9 reads per step)
     constexpr int W2PN = S2 * C1 * NT * C2;
     __shared__ __attribute__((aligned(16))) bf16_t wlds[NP][W2PN];
+    // dy2 = ca du2 + cc z2 + cb (XF): read per use, not 24 registers; written here so that the barrier below orders it too
+    __shared__ float coef2[3][C2];
+    if (XF && tid < 3 * C2) coef2[tid / C2][tid % C2] = (tid < C2 ? p.ca : tid < 2 * C2 ? p.cb : p.cc)[tid % C2];
 #pragma unroll
     for (int np = 0; np < NP; ++np)
         for (int i = tid * 8; i < W2PN; i += 256 * 8)
@@ -612,8 +615,6 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
     // loader roles: thread tid < 136 owns one chunk of 8 channels of a dy2 row
     const int d_row = (tid * 8) / C2, d_col = (tid * 8) % C2;
     const bool d_own = tid < DROWS * C2 / 8;
-    __shared__ float coef2[3][C2];                                 // dy2 = ca du2 + cc z2 + cb (XF): read per use, not 24 registers
-    if (XF && tid < 3 * C2) coef2[tid / C2][tid % C2] = (tid < C2 ? p.ca : tid < 2 * C2 ? p.cb : p.cc)[tid % C2];
     f32x4 accw[3][NT], acc1 = f32x4{0.f, 0.f, 0.f, 0.f}, accx = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr)

@@ -136,8 +136,11 @@ class WavEncoder(nn.Module):
         from .. import bf16
         if bf16.enabled() and self.training:
             return self._forward_bf16(wav_data)
-        from .. import wave12
+        from .. import wave12, wave32
         fe = self.feat_extractor
+        if (wave32.ENABLED and all(fe[i].training for i in (1, 4, 7)) and wav_data.is_cuda and wav_data.dtype == torch.float32
+                and wav_data.dim() == 2 and wave32.supported(fe)):
+            return wave32.encoder_f32(wav_data, fe)                   # all three BatchNorms folded into the convs (opt-in)
         if (fe[1].training and fe[4].training and wav_data.is_cuda and wav_data.dtype == torch.float32 and wav_data.dim() == 2
                 and wave12.supported(fe)):
             # conv1 -> BatchNorm -> LeakyReLU -> conv2 without conv1's (B, 7891, 16) output in HBM (csrc/wave12.hip)

@@ -498,3 +498,26 @@ def test_conv1_weight_gradient_from_three_sums_identity():
         dz1 = A[None, :, None] * du1 + C_[None, :, None] * z1 + B[None, :, None]
     assert torch.allclose(dw1, w1.grad[:, 0, :], rtol=1e-9, atol=1e-12)
     assert float(b1.grad.abs().max()) < 1e-12 * float(dy2.abs().sum()) and float(dz1.sum(dim=(0, 2)).abs().max()) < 1e-9
+
+
+def test_fp32_tail_of_the_wave_encoder_is_opt_in_and_its_pack_layout_is_consistent():
+    """wave32.py: off unless S2AG_WAVE_TAIL32=1 (not yet run on a GPU); the pack's four blocks are 16-byte aligned, disjoint
+    and fill s2ag_wave_tail32_pack_bytes; lengths follow the reference's conv arithmetic."""
+    import os
+    from speech2affective_gestures_amd import _lib as L
+    from speech2affective_gestures_amd import wave32
+    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import WavEncoder
+    assert wave32.ENABLED == (os.environ.get('S2AG_WAVE_TAIL32', '0') == '1')
+    fe = WavEncoder().feat_extractor
+    assert wave32.supported(fe) == wave32.ENABLED
+    assert wave32.tail_lengths(1313) == (217, 34)             # the TED clip: 36267 samples -> 7891 -> 1313 -> 217 -> 34
+    lib = L.load()
+    total = lib.s2ag_wave_tail32_pack_bytes()
+    offs = sorted((lib.s2ag_wave_tail32_pack_offset(layer, ph), size) for layer, ph, size in
+                  ((0, 0, 15 * 32 * 64 * 4), (1, 0, 15 * 64 * 32 * 4), (0, 1, 2 * 6 * 32 * 3 * 64 * 2), (1, 1, 2 * 6 * 64 * 3 * 32 * 2)))
+    end = 0
+    for off, size in offs:
+        assert off == end and off % 16 == 0
+        end = off + size
+    assert end == total
+    assert lib.s2ag_wave_tail32_pack_offset(2, 0) < 0
