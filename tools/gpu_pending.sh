@@ -1,0 +1,23 @@
+#!/bin/bash
+# What is waiting for a GPU (written while access was closed in r03): run in ONE gpurun call, ~15 min.
+#   1. the full GPU suite on HEAD (defaults)
+#   2. opt-in paths: S2AG_WAVE_TAIL32=1 (fp32 wave-encoder tail, wave32.py) and S2AG_EMB_FWD_ROWS=1 (row-form embedding forward)
+#      -- their own tests, then the suites that go through them
+#   3. configs[3] timings with each switch off / on, and a per-grid kernel trace of fp32 mode with the tail on
+# Results under gpurun_out/pending/; flip a default only when its tests are green AND its timing is not worse.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pending; mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests -q -m gpu -x > $O/t_all.log 2>&1; echo "full suite rc=$?"; tail -3 $O/t_all.log
+S2AG_WAVE_TAIL32=1 timeout 900 python -m pytest tests/test_gpu_wave32.py -q -m gpu -s > $O/t_wave32.log 2>&1; echo "wave32 tests rc=$?"; grep "wave32 bwd\|passed\|failed\|Error" $O/t_wave32.log | tail -30
+S2AG_WAVE_TAIL32=1 timeout 1200 python -m pytest tests/test_gpu_wave12.py tests/test_gpu_modules.py tests/test_gpu_step.py tests/test_gpu_fullsize.py -q -m gpu > $O/t_wave32_suites.log 2>&1; echo "suites with the tail on rc=$?"; tail -5 $O/t_wave32_suites.log
+S2AG_EMB_FWD_ROWS=1 timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_bf16.py tests/test_gpu_modules.py -q -m gpu -k "embedding or encoders_in_bf16 or text or golden" > $O/t_emb_rows.log 2>&1; echo "embedding rows rc=$?"; tail -3 $O/t_emb_rows.log
+for m in fp32 bf16; do
+  MODE=$m timeout 600 python tools/run_cfg4.py > $O/run_$m.log 2>&1; echo "cfg3 $m default: $(tail -1 $O/run_$m.log | cut -c1-160)"
+  S2AG_EMB_FWD_ROWS=1 MODE=$m timeout 600 python tools/run_cfg4.py > $O/run_${m}_embrows.log 2>&1; echo "cfg3 $m emb rows: $(tail -1 $O/run_${m}_embrows.log | cut -c1-160)"
+done
+S2AG_WAVE_TAIL32=1 MODE=fp32 timeout 600 python tools/run_cfg4.py > $O/run_fp32_tail32.log 2>&1; echo "cfg3 fp32 tail32: $(tail -1 $O/run_fp32_tail32.log | cut -c1-160)"
+S2AG_WAVE_TAIL32=1 S2AG_CFG3_STREAMS=1 MODE=fp32 timeout 600 rocprofv3 --kernel-trace --stats -d $O/cfg3_tail32 -o cfg3 -- python tools/run_cfg4.py > $O/prof_tail32.log 2>&1
+python tools/rocpd_by_grid.py $(find $O/cfg3_tail32 -name "*results.db" | head -1) _k > $O/cfg3_fp32_tail32_by_grid.txt; head -30 $O/cfg3_fp32_tail32_by_grid.txt
+S2AG_WAVE_TAIL32=1 timeout 600 python bench.py --steps 30 --warmup 10 > $O/bench_tail32.log 2>&1; grep '^{"metric"' $O/bench_tail32.log | cut -c1-200
+find $O -name "*.db" -delete
