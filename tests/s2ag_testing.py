@@ -133,7 +133,7 @@ class SignTap:
         self.ops, self.module = ops, module
         self.names = {id(m): n for n, m in module.named_modules()}
         self.params = {id(p): n for n, p in module.named_parameters()}
-        self.bn, self.adds, self.lin, self.tcn, self.heads = [], [], [], [], []
+        self.bn, self.adds, self.lin, self.tcn, self.heads, self.encs = [], [], [], [], [], []
 
     def __enter__(self):
         ops = self.ops
@@ -174,12 +174,23 @@ class SignTap:
                 self.heads.append((self.names[id(fe[1])], z2, fe[0].bias))
             return z2
         wave12.head_f32 = head
+        # the fully folded fp32 encoder (wave32.py, opt-in): all three BatchNorm + LeakyReLU pairs happen inside its launches
+        from speech2affective_gestures_amd import wave32
+        self._w32, self._o_enc = wave32, wave32.encoder_f32
+
+        def enc(wav, fe):
+            out = self._o_enc(wav, fe)
+            if id(fe[1]) in self.names:
+                self.encs.append((out, fe))
+            return out
+        wave32.encoder_f32 = enc
         return self
 
     def __exit__(self, *a):
         ops = self.ops
         ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32 = self._orig
         self._w12.head_f32 = self._o_head
+        self._w32.encoder_f32 = self._o_enc
 
     def signs(self):
         import numpy as np
@@ -202,6 +213,9 @@ class SignTap:
         for name, z2, b1 in self.heads:
             wav, pk, coef1 = z2.grad_fn.saved_tensors
             out[name + '.'] = self._w12.act_signs(wav, pk, b1, coef1, False, z2.grad_fn.pad).permute(0, 2, 1).cpu()
+        for enc_out, fe in self.encs:
+            for bn, sg in zip((fe[1], fe[4], fe[7]), self._w32.act_signs(enc_out, fe)):
+                out[self.names[id(bn)] + '.'] = sg.permute(0, 2, 1).cpu()
         for key, y in zip(sorted(cols), self.adds):                      # st_gcn1 runs before st_gcn2
             out[key + 'out'] = (vertex_layout(y, cols[key]) > 0).cpu()
         for pname, y in self.lin:
