@@ -521,3 +521,40 @@ def test_fp32_tail_of_the_wave_encoder_is_opt_in_and_its_pack_layout_is_consiste
         end = off + size
     assert end == total
     assert lib.s2ag_wave_tail32_pack_offset(2, 0) < 0
+
+
+def test_flat_window_forward_and_polyphase_data_gradient_identities():
+    """The two index identities csrc/wave_fused.hip is built on, in float64 on the CPU for Conv1d(32, 64, 15, stride 6)
+    (net/multimodal_context_net_v2.py:24) on channels-last rows:
+      forward   y[l, co] = sum_k a_flat[6 Cin l + k] Wk[k, co], Wk[t Cin + ci, co] = W[co, ci, t]   (the k-major pack)
+      dgrad     da[6 q + r, ci] = sum_i sum_co dy[q - i, co] Wp[r, ci, i, co], Wp = W[co, ci, r + 6 i] (0 beyond tap 14)
+    and the two-piece split of an fp32 value: hi = bf16(v), lo = bf16(v - hi) reproduce v to 2^-16 relative."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(9)
+    N, Lin, Cin, Cout = 2, 100, 32, 64
+    Lout = (Lin - 15) // 6 + 1
+    a = torch.randn(N, Lin, Cin, generator=g, dtype=torch.float64)
+    W = torch.randn(Cout, Cin, 15, generator=g, dtype=torch.float64)
+    y_ref = F.conv1d(a.transpose(1, 2), W, stride=6).transpose(1, 2)                    # (N, Lout, Cout)
+    Wk = W.permute(2, 1, 0).reshape(15 * Cin, Cout)
+    flat = a.reshape(N, Lin * Cin)
+    y = torch.stack([flat[:, 6 * Cin * l: 6 * Cin * l + 15 * Cin] @ Wk for l in range(Lout)], dim=1)
+    assert torch.allclose(y, y_ref, rtol=1e-12, atol=1e-12)
+    dy = torch.randn(N, Lout, Cout, generator=g, dtype=torch.float64)
+    da_ref = F.conv_transpose1d(dy.transpose(1, 2), W, stride=6)
+    da_ref = F.pad(da_ref, (0, Lin - da_ref.shape[2])).transpose(1, 2)                  # (N, Lin, Cin)
+    Wp = torch.zeros(6, Cin, 3, Cout, dtype=torch.float64)
+    for r in range(6):
+        for i in range(3):
+            if r + 6 * i < 15:
+                Wp[r, :, i, :] = W[:, :, r + 6 * i].t()
+    Q = (Lin + 5) // 6
+    dyp = F.pad(dy, (0, 0, 2, Q))                                                       # dy[q - i] with zeros outside [0, Lout)
+    da = torch.zeros(N, 6 * Q, Cin, dtype=torch.float64)
+    for i in range(3):
+        da.view(N, Q, 6, Cin)[:] += torch.einsum('nqo,rcio->nqrc', dyp[:, 2 - i: 2 - i + Q], Wp[:, :, i:i + 1, :])
+    assert torch.allclose(da[:, :Lin], da_ref, rtol=1e-12, atol=1e-12)
+    v = torch.randn(4096, generator=g)
+    hi = v.to(torch.bfloat16).float()
+    lo = (v - hi).to(torch.bfloat16).float()
+    assert float(((hi + lo) - v).abs().max() / v.abs().max()) < 2.0 ** -16
