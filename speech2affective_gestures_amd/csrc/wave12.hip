@@ -34,6 +34,8 @@
 // mantissa bits per product, the precision of the step's other large gradient products, bench.py `matrix_products`).
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "s2ag_common.h"
 #include "bn_fold_inl.h"
 
@@ -333,9 +335,14 @@ struct W12FwdP {
 //           the banks), 8 K tiles of v_mfma_f32_16x16x32_bf16, z2 stored as bf16;
 //   NP = 2  fp32 image at e + 2 (e / 96) (row pitch 98 floats: the 16 frames x 2 taps of a half-wave read hit 32 different
 //           banks), 60 K steps of v_mfma_f32_16x16x4_f32 -- the reference's fp32 arithmetic, no operand splitting --, z2 fp32.
-template <int NP>
+// PIPE (fp32 only; S2AG_W12_FWD_PIPE=1, not yet run on a GPU): the B values of the next two K steps are requested before the
+// current four products are issued.  Left alone the scheduler places each LDS read directly in front of its use and waits
+// for it with the matrix pipe idle (53 % MFMA utilisation, profiles/r03_mfma_util_cfg3_fp32.txt).  Same products in the same
+// order on the same accumulators: bit-identical results.
+template <int NP, bool PIPE = false>
 __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
     constexpr bool F32 = NP == 2;
+    static_assert(!PIPE || F32, "the pipelined K loop is the fp32 one");
     constexpr int RS = S2 * C1, NKT = K2P / 32, NKB = KS * C1 / 4;
     constexpr int RPAD = F32 ? 2 : 16, PITCH = RS + RPAD;         // elements between the windows of consecutive output frames
     constexpr int AFR = 112;                                      // a1 frames per sub-tile: 6 * 15 + 15 = 105 -> 7 tiles
@@ -436,6 +443,28 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
             // four accumulator chains (channel tile x K parity): a dependent f32 MFMA waits for its predecessor's result
             f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             const float* frow = img32 + n * PITCH + g;
+            if constexpr (PIPE) {
+                float bq[2][2];
+                bq[0][0] = frow[0];
+                bq[0][1] = frow[4 / RS * PITCH + (4 - 4 / RS * RS)];
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb += 2) {
+                    const int cur = (kb >> 1) & 1;
+                    if (kb + 2 < NKB) {
+                        const int k0 = 4 * (kb + 2), j0 = k0 / RS, k1 = k0 + 4, j1 = k1 / RS;      // compile time
+                        S2AG_DBG_ASSERT(n * PITCH + g + j1 * PITCH + (k1 - j1 * RS) < IMG);
+                        bq[cur ^ 1][0] = frow[j0 * PITCH + (k0 - j0 * RS)];
+                        bq[cur ^ 1][1] = frow[j1 * PITCH + (k1 - j1 * RS)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][kb], bq[cur][0], acc[ct], 0, 0, 0);
+                        acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][kb + 1], bq[cur][1], acc2[ct], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
             for (int kb = 0; kb < NKB; kb += 2) {
                 const int k0 = 4 * kb, j0 = k0 / RS, k1 = k0 + 4, j1 = k1 / RS;      // compile time
@@ -446,6 +475,7 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
                     acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][kb], b0, acc[ct], 0, 0, 0);
                     acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][kb + 1], b1, acc2[ct], 0, 0, 0);
                 }
+            }
             }
             acc[0] += acc2[0];
             acc[1] += acc2[1];
@@ -1114,7 +1144,9 @@ extern "C" int s2ag_wave12_fwd(const float* x, const void* packed, const float* 
     p.N = N; p.Lin = Lin; p.L1 = L1; p.L2 = L2; p.pad = pad;
     p.chunks = fwd_chunks(N, L2, &p.LC);
     const dim3 grid(N * p.chunks);
-    if (out_f32) hipLaunchKernelGGL(wv12_fwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    static const int pipe = [] { const char* v = getenv("S2AG_W12_FWD_PIPE"); return v ? atoi(v) : 0; }();
+    if (out_f32 && pipe) hipLaunchKernelGGL((wv12_fwd_k<2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (out_f32) hipLaunchKernelGGL(wv12_fwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wv12_fwd_k<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
