@@ -1,0 +1,34 @@
+"""CPU dry run of the opt-in fp32 wave encoder (speech2affective_gestures_amd/wave32.py): the real ctypes signatures and the
+library's own argument validation, with every launch failing for want of a device (its hipError_t is recorded, not raised).
+Catches host-side slips -- argument counts / types, null or misaligned pointers, geometry the entry points reject, shapes,
+attribute names -- before a GPU sees the code.  Prints one JSON line; run by tests/test_host_logic.py."""
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speech2affective_gestures_amd import _lib as L, ops, wave12, wave32          # noqa: E402
+from speech2affective_gestures_amd.net.multimodal_context_net_v2 import WavEncoder  # noqa: E402
+
+rcs = []
+L.check = lambda rc, what='': rcs.append((what, int(rc)))
+wave12._s = wave32._s = lambda: None
+wave12._check_wav = lambda wav: None
+ops.run_wgrad = lambda launch, keep=(), flops=0.0: launch()
+_tk = torch.zeros(256, dtype=torch.int32)
+ops._tickets = lambda dev, n: C.c_void_p(_tk.data_ptr())
+
+enc = WavEncoder().train()
+fe = enc.feat_extractor
+out = wave32.encoder_f32(torch.randn(2, 36267) * 0.05, fe)
+n_fwd = len(rcs)
+signs = wave32.act_signs(out, fe)
+n_sg = len(rcs)
+(out * torch.randn_like(out)).sum().backward()
+print(json.dumps({
+    'out': list(out.shape), 'forward': [w for w, _ in rcs[:n_fwd]], 'signs': [list(s.shape) for s in signs],
+    'backward': [w for w, _ in rcs[n_sg:]], 'codes': sorted(set(rc for _, rc in rcs)),
+    'grads': {k: (None if p.grad is None else list(p.grad.shape)) for k, p in enc.named_parameters()}}))
