@@ -1,4 +1,4 @@
-"""CPU dry run of the opt-in fp32 wave encoder (speech2affective_gestures_amd/wave32.py): the real ctypes signatures and the
+"""CPU dry run of the fused wave encoders (bf16._WaveFused16, and the opt-in fp32 wave32._WaveFused32): the real ctypes signatures and the
 library's own argument validation, with every launch failing for want of a device (its hipError_t is recorded, not raised).
 Catches host-side slips -- argument counts / types, null or misaligned pointers, geometry the entry points reject, shapes,
 attribute names -- before a GPU sees the code.  Prints one JSON line; run by tests/test_host_logic.py."""
@@ -10,12 +10,12 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from speech2affective_gestures_amd import _lib as L, ops, wave12, wave32          # noqa: E402
+from speech2affective_gestures_amd import _lib as L, bf16, ops, wave12, wave32    # noqa: E402
 from speech2affective_gestures_amd.net.multimodal_context_net_v2 import WavEncoder  # noqa: E402
 
 rcs = []
 L.check = lambda rc, what='': rcs.append((what, int(rc)))
-wave12._s = wave32._s = lambda: None
+wave12._s = wave32._s = bf16._s = lambda: None
 wave12._check_wav = lambda wav: None
 ops.run_wgrad = lambda launch, keep=(), flops=0.0: launch()
 _tk = torch.zeros(256, dtype=torch.int32)
@@ -23,10 +23,18 @@ ops._tickets = lambda dev, n: C.c_void_p(_tk.data_ptr())
 
 enc = WavEncoder().train()
 fe = enc.feat_extractor
-out = wave32.encoder_f32(torch.randn(2, 36267) * 0.05, fe)
-n_fwd = len(rcs)
-signs = wave32.act_signs(out, fe)
-n_sg = len(rcs)
+mode = sys.argv[1] if len(sys.argv) > 1 else 'fp32_folded'
+wav = torch.randn(2, 36267) * 0.05
+signs = []
+if mode == 'bf16':                       # the default bf16-mode encoder (bf16._WaveFused16)
+    with bf16.precision('bf16'):
+        out = enc(wav)
+    n_fwd = n_sg = len(rcs)
+else:                                    # the opt-in fp32 encoder (wave32._WaveFused32)
+    out = wave32.encoder_f32(wav, fe)
+    n_fwd = len(rcs)
+    signs = wave32.act_signs(out, fe)
+    n_sg = len(rcs)
 (out * torch.randn_like(out)).sum().backward()
 print(json.dumps({
     'out': list(out.shape), 'forward': [w for w, _ in rcs[:n_fwd]], 'signs': [list(s.shape) for s in signs],

@@ -560,22 +560,28 @@ def test_flat_window_forward_and_polyphase_data_gradient_identities():
     assert float(((hi + lo) - v).abs().max() / v.abs().max()) < 2.0 ** -16
 
 
-def test_fp32_wave_encoder_dry_run_passes_every_entry_points_argument_checks():
-    """tests/s2ag_dry_wave32.py: WavEncoder forward + backward through wave32.py on the CPU with the launches failing for want
-    of a device.  Every call must get as far as the launch (a positive hipError_t), none may be refused by the library's
-    argument validation (negative S2AG_E_*), and the launch sequence is the documented one: 6 forward, 5 backward + the fold."""
+@pytest.mark.parametrize('mode', ['fp32_folded', 'bf16'])
+def test_wave_encoder_dry_run_passes_every_entry_points_argument_checks(mode):
+    """tests/s2ag_dry_wave32.py: WavEncoder forward + backward through the fused encoders (bf16 mode's default, and the opt-in
+    fp32 one of wave32.py) on the CPU with the launches failing for want of a device.  Every call must get as far as the launch
+    (a positive hipError_t), none may be refused by the library's argument validation (negative S2AG_E_*), and the launch
+    sequence is the documented one: 6 launches forward, 5 backward."""
     import json
     import subprocess
     import sys
     if torch.cuda.is_available():
         pytest.skip('the dry run is for boxes without a GPU')
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 's2ag_dry_wave32.py')
-    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, script, mode], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d['out'] == [2, 34, 32]
-    assert d['forward'] == ['wave12_pack', 'wave12_stats', 'wave12_fwd', 'wave_tail32_pack', 'wave_conv_fwd32', 'wave_conv_fwd32']
-    assert d['backward'] == ['wave_conv_wgrad32', 'wave_conv_dgrad32', 'wave_conv_wgrad32', 'wave_conv_dgrad32', 'wave12_bwd']
-    assert d['signs'] == [[2, 7891, 16], [2, 1313, 32], [2, 217, 64]]
+    if mode == 'bf16':
+        assert d['forward'] == ['wave12_pack', 'wave12_stats', 'wave12_fwd', 'bf16_pack_weights', 'wave_conv_fwd', 'wave_conv_fwd']
+        assert d['backward'] == ['wave_conv_wgrad', 'wave_conv_dgrad', 'wave_conv_wgrad', 'wave_conv_dgrad', 'wave12_bwd']
+    else:
+        assert d['forward'] == ['wave12_pack', 'wave12_stats', 'wave12_fwd', 'wave_tail32_pack', 'wave_conv_fwd32', 'wave_conv_fwd32']
+        assert d['backward'] == ['wave_conv_wgrad32', 'wave_conv_dgrad32', 'wave_conv_wgrad32', 'wave_conv_dgrad32', 'wave12_bwd']
+        assert d['signs'] == [[2, 7891, 16], [2, 1313, 32], [2, 217, 64]]
     assert all(c > 0 for c in d['codes']), d['codes']          # hipError_t (no device), never S2AG_E_BADARG / _UNSUPPORTED
     assert all(v is not None for v in d['grads'].values())
