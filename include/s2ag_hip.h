@@ -644,7 +644,8 @@ int s2ag_wave12_bwd(const s2ag_wave12_bwd_args* a, void* stream);
  * s2ag_bf16_tcn_clips_per_block: clips one workgroup holds (0: shape unsupported -- use the layer-by-layer kernels). */
 #define S2AG_TCN_MAX_BLOCKS 4
 typedef struct {
-    const void* x;                              /* bf16 (clips*T, 320): input of the first block */
+    const void* x;                              /* bf16 (clips*T, 320): input of the first block (written by the forward
+                                                   launch when emb_ids is set) */
     void* h1[S2AG_TCN_MAX_BLOCKS];              /* bf16 (clips*T, 320) each: written forward; the weight gradients' operands */
     void* sign[S2AG_TCN_MAX_BLOCKS];            /* s2ag_bf16_tcn_sign_bytes each: "h1 > 0", "h2 > 0", "y > 0" bits, written
                                                    forward, read backward */
@@ -664,6 +665,15 @@ typedef struct {
     /* forward only, drop_p > 0: workspace of s2ag_bf16_tcn_keep_bytes bytes (the pass's dropout keep bits, generated by a
      * launch of their own in front of the forward kernel) */
     void* keep;
+    /* forward only, optional (emb_ids != NULL): the first block's input is nn.Embedding(ids) + dropout
+     * (net/multimodal_context_net_v2.py:83-84), formed in the forward launch's loader exactly as s2ag_bf16_embedding_fwd forms
+     * it (same mask: `rng`, emb_site, index row * emb_dim + channel) -- `x` is then an OUTPUT (the rows the backward pass's
+     * weight gradient reads); emb_dim % 4 == 0, <= 320 */
+    const long long* emb_ids;                   /* (clips*T) token ids */
+    const float* emb_table;                     /* (emb_entries, emb_dim) fp32 */
+    int emb_dim, emb_entries;
+    float emb_drop_p;
+    unsigned emb_site;
 } s2ag_bf16_tcn_args;
 int s2ag_bf16_tcn_clips_per_block(int T, int C, int ksize);
 long long s2ag_bf16_tcn_sign_bytes(int n_clips, int T);  /* bytes of one block's sign buffer */

@@ -74,7 +74,8 @@ class BF16PackJob(C.Structure):   # s2ag_bf16_pack_job
 class BF16Tcn(C.Structure):       # s2ag_bf16_tcn_args
     _fields_ = [('x', vp), ('h1', vp * 4), ('sign', vp * 4), ('y', vp * 4), ('wfrag', vp), ('bias', vp * 8), ('dil', ci * 4),
                 ('n_blocks', ci), ('n_clips', ci), ('T', ci), ('C', ci), ('drop_p', cf), ('rng', vp), ('site', cu * 8),
-                ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4), ('keep', vp)]
+                ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4), ('keep', vp), ('emb_ids', vp), ('emb_table', vp),
+                ('emb_dim', ci), ('emb_entries', ci), ('emb_drop_p', cf), ('emb_site', cu)]
 
 
 class Tcn32(C.Structure):         # s2ag_tcn32_args

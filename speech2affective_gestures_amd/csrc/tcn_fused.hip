@@ -73,6 +73,14 @@ struct TcnP {
     bf16_t* gp1[S2AG_TCN_MAX_BLOCKS];
     bf16_t* gp2[S2AG_TCN_MAX_BLOCKS];
     u32x4* keep;                        // dropout keep bits of the forward pass (tcn_keep_k), one u32x4 per thread and conv
+    // GATHER (forward): the first block's input rows are nn.Embedding rows + dropout, formed in the loader (and written to
+    // `xo` for the backward pass's weight gradient) instead of read from `x`
+    const long long* emb_ids;           // (clips * T) token ids
+    const float* emb_table;             // (entries, emb_dim) fp32
+    bf16_t* xo;
+    int emb_dim, emb_entries;
+    float emb_p, emb_ik;
+    unsigned emb_site;
     unsigned long long* trace;          // diagnostics (s2ag_bf16_tcn_set_trace): s_memtime stamps of workgroup 0, wave 0
 };
 
@@ -140,6 +148,38 @@ __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_o
     }
 }
 
+// the workgroup's rows as embedding rows: row m = table[ids[row0 + m]] * dropout (the counter-based mask of
+// s2ag_bf16_embedding_fwd: index row * dim + channel), rounded to bf16, pad channels zero -- to LDS and to HBM (`xo`)
+__device__ __forceinline__ void rows_gather(bf16_t* lds, const TcnP& p, long long row0, int R, int tid) {
+    SiteKey key{0, 0};
+    const bool drop = p.emb_p > 0.f;
+    if (drop) key = site_key(p.rng, p.emb_site);
+    const int dim = p.emb_dim;
+    for (int idx = tid; idx < R * (CP / 8); idx += 256) {
+        const int m = idx / (CP / 8), kc = idx - m * (CP / 8);
+        const long long row = row0 + m;
+        long long id = p.emb_ids[row];
+        if (id < 0 || id >= p.emb_entries) id = 0;
+        const float* src = p.emb_table + id * dim + kc * 8;
+        float v[8];
+        if (kc * 8 + 8 <= dim) {                       // dim % 4 == 0: both halves are 16-byte aligned
+            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = kc * 8 + j < dim ? src[j] : 0.f;
+        }
+        if (drop) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (kc * 8 + j < dim) v[j] *= keep_scale(key, (unsigned long long)row * dim + kc * 8 + j, p.emb_p, p.emb_ik);
+        }
+        const u32x4 o = u32x4{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+        *reinterpret_cast<u32x4*>(lds + m * PITCH + kc * 8) = o;
+        *reinterpret_cast<u32x4*>(p.xo + row * CP + kc * 8) = o;
+    }
+}
+
 template <int MT>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[CT_W][MT]) {
 #pragma unroll
@@ -201,7 +241,7 @@ __global__ __launch_bounds__(256) void tcn_keep_k(const TcnP p) {
 __host__ __device__ inline int sign_s1(int rows) { return (rows * 40 + 15) / 16 * 16; }
 __host__ __device__ inline int sign_s2(int rows) { return (rows * 80 + 15) / 16 * 16; }
 
-template <int MT>
+template <int MT, bool GATHER = false>
 __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sm = reinterpret_cast<bf16_t*>(smem_raw);
@@ -216,7 +256,8 @@ __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
     const int R = min(p.cpb, p.n_clips - clip0) * p.T;
     const long long row0 = (long long)clip0 * p.T;
 
-    rows_in(sm + X, p.x + row0 * CP, R, tid);
+    if constexpr (GATHER) rows_gather(sm + X, p, row0, R, tid);
+    else rows_in(sm + X, p.x + row0 * CP, R, tid);
     for (int i = tid; i < PITCH / 2; i += 256) reinterpret_cast<unsigned*>(sm + Z)[i] = 0u;
     const bool drop = p.drop_p > 0.f;
     __syncthreads();
@@ -500,6 +541,16 @@ int fill(const s2ag_bf16_tcn_args* a, TcnP& p, bool bwd) {
     p.rng = static_cast<const unsigned long long*>(a->rng);
     p.keep = static_cast<u32x4*>(a->keep);
     if (!bwd && a->drop_p > 0.f && !a->keep) return S2AG_E_BADARG;
+    if (!bwd && a->emb_ids) {
+        if (!a->emb_table || a->emb_dim <= 0 || a->emb_entries <= 0 || !(a->emb_drop_p >= 0.f && a->emb_drop_p < 1.f))
+            return S2AG_E_BADARG;
+        if (a->emb_dim > CP || (a->emb_dim & 3) || ((uintptr_t)a->emb_table & 15)) return S2AG_E_UNSUPPORTED;
+        if (a->emb_drop_p > 0.f && !a->rng) return S2AG_E_BADARG;
+        p.emb_ids = a->emb_ids; p.emb_table = a->emb_table; p.xo = const_cast<bf16_t*>(p.x);
+        p.emb_dim = a->emb_dim; p.emb_entries = a->emb_entries; p.emb_p = a->emb_drop_p;
+        p.emb_ik = a->emb_drop_p > 0.f ? 1.f / (1.f - a->emb_drop_p) : 1.f;
+        p.emb_site = a->emb_site;
+    }
     p.trace = g_trace;
     return 0;
 }
@@ -563,7 +614,17 @@ extern "C" int s2ag_bf16_tcn_fwd(const s2ag_bf16_tcn_args* a, void* stream) {
         if (small) hipLaunchKernelGGL(tcn_keep_k<3>, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(tcn_keep_k<5>, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
     }
-    if (small) hipLaunchKernelGGL(tcn_fwd_k<3>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    if (p.emb_ids) {
+        static bool attr_g = false;
+        if (!attr_g) {
+            if (hipFuncSetAttribute((const void*)tcn_fwd_k<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)tcn_fwd_k<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return S2AG_E_UNSUPPORTED;
+            attr_g = true;
+        }
+        if (small) hipLaunchKernelGGL((tcn_fwd_k<3, true>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((tcn_fwd_k<5, true>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    } else if (small) hipLaunchKernelGGL(tcn_fwd_k<3>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(tcn_fwd_k<5>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;

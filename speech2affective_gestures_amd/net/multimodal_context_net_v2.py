@@ -214,6 +214,11 @@ class TextEncoderTCN(nn.Module):
             p = self.drop.p if self.training else 0.0
             if bf16.enabled() and self.training and self.tcn.bf16_capable():
                 # bf16 mode: (B, T, 320) bf16 rows with zero pad channels from the embedding gather to the decoder
+                if bf16.TCN_GATHER and in_data.dim() == 2:
+                    # the gather + dropout happen in the TCN forward launch's loader (opt-in, csrc/tcn_fused.hip GATHER)
+                    y = self.tcn.forward_nlc_bf16(None, nz, decoder=self.decoder,
+                                                  emb=(in_data, self.embedding.weight, p, self.site))
+                    return y.contiguous(), 0
                 emb = bf16.embedding(in_data, self.embedding.weight, p, nz, self.site)
                 y = self.tcn.forward_nlc_bf16(emb, nz, decoder=self.decoder)
                 return y.contiguous(), 0

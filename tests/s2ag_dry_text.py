@@ -1,0 +1,38 @@
+"""CPU dry run of TextEncoderTCN in bf16 mode (the clip-resident TCN; argv[1] = 1: with the embedding gather inside its forward
+launch, bf16.TCN_GATHER): real ctypes signatures and the library's argument validation, every launch failing for want of a
+device (codes recorded, not raised).  The guards that make the product refuse CPU tensors are patched out HERE only.
+Prints one JSON line; run by tests/test_host_logic.py."""
+import json
+import os
+import sys
+import types
+import warnings
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speech2affective_gestures_amd import _lib as L, bf16, noise, ops                     # noqa: E402
+from speech2affective_gestures_amd.net.multimodal_context_net_v2 import TextEncoderTCN   # noqa: E402
+
+warnings.simplefilter('ignore')
+rcs = []
+L.check = lambda rc, what='': rcs.append((what, int(rc)))
+bf16._s = lambda: None
+bf16._rows16 = lambda t: ((t if t.is_contiguous() else t.contiguous()), t.numel() // t.shape[-1], t.shape[-1])
+ops.run_wgrad = lambda launch, keep=(), flops=0.0: launch()
+ops._stream = lambda: None
+ops._need_cuda = lambda *a: None
+ops.join_side_streams = lambda *a, **k: None
+torch.cuda.is_current_stream_capturing = lambda: False
+noise.begin_pass = lambda device: torch.zeros(2, dtype=torch.int64)
+bf16.TCN_GATHER = len(sys.argv) > 1 and sys.argv[1] == '1'
+
+args = types.SimpleNamespace(hidden_size=300, n_layers=4, freeze_wordembed=False)
+enc = TextEncoderTCN(args, 1000).train()
+with bf16.precision('bf16'):
+    y, _ = enc(torch.randint(0, 1000, (4, 34)))
+    n = len(rcs)
+    (y * torch.randn_like(y)).sum().backward()
+print(json.dumps({'out': list(y.shape), 'forward': [w for w, _ in rcs[:n]], 'backward': [w for w, _ in rcs[n:]],
+                  'refused': sorted(set(w for w, rc in rcs if rc == -1)),
+                  'grads': {k: (None if p.grad is None else list(p.grad.shape)) for k, p in enc.named_parameters()}}))

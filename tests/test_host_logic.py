@@ -585,3 +585,23 @@ def test_wave_encoder_dry_run_passes_every_entry_points_argument_checks(mode):
         assert d['signs'] == [[2, 7891, 16], [2, 1313, 32], [2, 217, 64]]
     assert all(c > 0 for c in d['codes']), d['codes']          # hipError_t (no device), never S2AG_E_BADARG / _UNSUPPORTED
     assert all(v is not None for v in d['grads'].values())
+
+
+@pytest.mark.parametrize('gather', [0, 1])
+def test_text_encoder_bf16_dry_run(gather):
+    """tests/s2ag_dry_text.py: TextEncoderTCN forward + backward in bf16 mode on the CPU, launches failing for want of a device;
+    with the opt-in gather (bf16.TCN_GATHER) the embedding forward launch is gone and the table still receives its gradient.
+    No entry point may refuse its arguments (S2AG_E_BADARG)."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip('the dry run is for boxes without a GPU')
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 's2ag_dry_text.py')
+    r = subprocess.run([sys.executable, script, str(gather)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['out'] == [4, 34, 32] and d['refused'] == []
+    assert ('bf16_embedding_fwd' in d['forward']) == (not gather)
+    assert 'bf16_tcn_fwd' in d['forward'] and 'bf16_tcn_bwd' in d['backward'] and 'bf16_embedding_bwd' in d['backward']
+    assert all(v is not None for v in d['grads'].values())
