@@ -643,6 +643,7 @@ int s2ag_wave12_bwd(const s2ag_wave12_bwd_args* a, void* stream);
  * counter-based ones of s2ag_conv1d_nlc_fwd (index row*C + channel, site[2*b + j]).
  * s2ag_bf16_tcn_clips_per_block: clips one workgroup holds (0: shape unsupported -- use the layer-by-layer kernels). */
 #define S2AG_TCN_MAX_BLOCKS 4
+#define S2AG_TCN32_MAX_PASSES 4
 typedef struct {
     const void* x;                              /* bf16 (clips*T, 320): input of the first block (written by the forward
                                                    launch when emb_ids is set) */
@@ -712,6 +713,16 @@ typedef struct {
     float* gx;
     float* gp1[S2AG_TCN_MAX_BLOCKS];
     float* gp2[S2AG_TCN_MAX_BLOCKS];
+    /* forward only, optional (emb_ids != NULL): the first block's input is nn.Embedding(ids) + dropout
+     * (net/multimodal_context_net_v2.py:83-84) formed in the forward launch's loader exactly as s2ag_embedding_fwd forms it
+     * (the table has C columns; mask: the pass's rng, emb_site, index row * C + channel with the row counted inside the pass)
+     * -- `x` is then an OUTPUT, written for the clips < save_clips only.  With s2ag_tcn32_fwd_passes the passes share the
+     * ids ((n_clips / n_passes) * T of them); at most S2AG_TCN32_MAX_PASSES passes. */
+    const long long* emb_ids;
+    const float* emb_table;                     /* (emb_entries, C) fp32, 16-byte aligned */
+    int emb_entries;
+    float emb_drop_p;
+    unsigned emb_site;
 } s2ag_tcn32_args;
 int s2ag_tcn32_supported(int T, int C, int ksize);
 long long s2ag_tcn32_pack_elems(int n_convs);

@@ -81,7 +81,8 @@ class BF16Tcn(C.Structure):       # s2ag_bf16_tcn_args
 class Tcn32(C.Structure):         # s2ag_tcn32_args
     _fields_ = [('x', vp), ('h1', vp * 4), ('h2', vp * 4), ('y', vp * 4), ('wfrag', vp), ('bias', vp * 8), ('dil', ci * 4),
                 ('n_blocks', ci), ('n_clips', ci), ('T', ci), ('C', ci), ('drop_p', cf), ('rng', vp), ('site', cu * 8),
-                ('keep', vp), ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4)]
+                ('keep', vp), ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4), ('emb_ids', vp), ('emb_table', vp),
+                ('emb_entries', ci), ('emb_drop_p', cf), ('emb_site', cu)]
 
 
 MAX_JOBS = 8
@@ -89,6 +90,7 @@ MAX_WGRAD_JOBS = 4
 BF16_MAX_PACK = 32
 BF16_MAX_WGRAD_JOBS = 8
 TCN_MAX_BLOCKS = 4
+TCN32_MAX_PASSES = 4
 
 SIGNATURES = {
     's2ag_abi_version': [],

@@ -55,6 +55,16 @@ struct T32P {
     u32x4* keep;                                // one u32x4 per thread, workgroup and conv (tcn32_keep_k)
     int keep_total, keep_off;                   // clips of the keep layout [conv][clip][256]; first clip of this pass in it
     int save_clips;                             // clips < save_clips leave h1 / h2 / y of every block, the others only the last y
+    // GATHER: the first block's input rows are nn.Embedding rows + dropout formed in the loader; clips < save_clips also
+    // leave them in `xo` (the weight gradient's operand).  The passes of a lockstep batch share the ids; pass k draws its
+    // mask from prng[k] with the row index inside the pass, as s2ag_embedding_fwd run per pass does.
+    const long long* emb_ids;                   // (per_pass * T) token ids
+    const float* emb_table;                     // (entries, C) fp32
+    float* xo;
+    const unsigned long long* prng[S2AG_TCN32_MAX_PASSES];
+    int per_pass, emb_entries;
+    float emb_p, emb_ik;
+    unsigned emb_site;
 };
 
 // keep bits of one pass in the epilogue's register layout: bit (i*MT + mt)*4 + c of thread (wave, lane)
@@ -147,6 +157,7 @@ __device__ __forceinline__ void conv32_tile(const float* sm, int src, int Z, con
     }
 }
 
+template <bool GATHER>
 __global__ __launch_bounds__(256) void tcn32_fwd_k(const T32P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
@@ -158,10 +169,28 @@ __global__ __launch_bounds__(256) void tcn32_fwd_k(const T32P p) {
     const int cpr = C / 4;                                       // 16-byte chunks of an HBM row
 
     // rows in: (row0 + m, 0..C) -> X[m][0..C), pad channels zero
+    SiteKey ekey{0, 0};
+    const int pass = GATHER ? (int)blockIdx.x / p.per_pass : 0;
+    const long long lrow0 = GATHER ? (long long)((int)blockIdx.x - pass * p.per_pass) * T : 0;     // first row inside the pass
+    if (GATHER && p.emb_p > 0.f) ekey = site_key(p.prng[pass], p.emb_site);
     for (int idx = tid; idx < T * (CP / 4); idx += 256) {
         const int m = idx / (CP / 4), kc = idx - m * (CP / 4);
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (kc < cpr) v = *reinterpret_cast<const f32x4*>(p.x + (row0 + m) * C + kc * 4);
+        if constexpr (GATHER) {
+            if (kc < cpr) {
+                long long id = p.emb_ids[lrow0 + m];
+                id = id < 0 ? 0 : (id >= p.emb_entries ? p.emb_entries - 1 : id);       // as embedding_fwd_k clamps
+                v = *reinterpret_cast<const f32x4*>(p.emb_table + id * C + kc * 4);
+                if (p.emb_p > 0.f) {
+                    const unsigned long long i0 = (unsigned long long)(lrow0 + m) * C + kc * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= keep_scale(ekey, i0 + j, p.emb_p, p.emb_ik);
+                }
+                if ((int)blockIdx.x < p.save_clips) *reinterpret_cast<f32x4*>(p.xo + (row0 + m) * C + kc * 4) = v;
+            }
+        } else {
+            if (kc < cpr) v = *reinterpret_cast<const f32x4*>(p.x + (row0 + m) * C + kc * 4);
+        }
         *reinterpret_cast<f32x4*>(sm + X + m * PITCH + kc * 4) = v;
         *reinterpret_cast<f32x4*>(sm + H1 + m * PITCH + kc * 4) = f32x4{0.f, 0.f, 0.f, 0.f};      // pad channels of H1 stay zero
     }
@@ -403,6 +432,19 @@ static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* co
     if ((reinterpret_cast<uintptr_t>(a->x)) & 15) return S2AG_E_BADARG;
     T32P p{};
     p.x = a->x; p.wfrag = static_cast<const bf16_t*>(a->wfrag);
+    if (a->emb_ids) {
+        if (!a->emb_table || a->emb_entries <= 0 || !(a->emb_drop_p >= 0.f && a->emb_drop_p < 1.f)) return S2AG_E_BADARG;
+        if (n_passes > S2AG_TCN32_MAX_PASSES || ((uintptr_t)a->emb_table & 15)) return S2AG_E_UNSUPPORTED;
+        if (a->emb_drop_p > 0.f && !rngs) return S2AG_E_BADARG;
+        p.emb_ids = a->emb_ids; p.emb_table = a->emb_table; p.xo = const_cast<float*>(a->x);
+        p.per_pass = a->n_clips / n_passes; p.emb_entries = a->emb_entries; p.emb_p = a->emb_drop_p;
+        p.emb_ik = a->emb_drop_p > 0.f ? 1.f / (1.f - a->emb_drop_p) : 1.f;
+        p.emb_site = a->emb_site;
+        for (int k = 0; k < n_passes; ++k) {
+            if (a->emb_drop_p > 0.f && !rngs[k]) return S2AG_E_BADARG;
+            p.prng[k] = rngs ? static_cast<const unsigned long long*>(rngs[k]) : nullptr;
+        }
+    }
     for (int b = 0; b < a->n_blocks; ++b) {
         if (!a->h1[b] || !a->h2[b] || !a->y[b] || a->dil[b] < 1) return S2AG_E_BADARG;
         p.h1[b] = a->h1[b]; p.h2[b] = a->h2[b]; p.y[b] = a->y[b];
@@ -420,7 +462,8 @@ static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* co
     const size_t lds = (size_t)(3 * p.T + 1) * PITCH * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)tcn32_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)tcn32_fwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)tcn32_fwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
@@ -434,7 +477,8 @@ static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* co
             hipLaunchKernelGGL(tcn32_keep_k, dim3(per, 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, q);
         }
     }
-    hipLaunchKernelGGL(tcn32_fwd_k, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
+    if (p.emb_ids) hipLaunchKernelGGL(tcn32_fwd_k<true>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(tcn32_fwd_k<false>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

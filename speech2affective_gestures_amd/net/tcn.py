@@ -107,10 +107,19 @@ class TemporalConvNet(nn.Module):
                 and ops.tcn_fused32_supported(x.shape[1], blks[0].conv1.out_channels, 2, len(blks))
                 and x.shape[2] == blks[0].conv1.in_channels == blks[0].conv1.out_channels)
 
-    def forward_nlc(self, x, noise, batch=None, noises=None):
-        """``batch`` / ``noises``: x is the first pass of a lockstep batch (ops.tcn_fused32); then (out, mate outputs)."""
+    def forward_nlc(self, x, noise, batch=None, noises=None, emb=None):
+        """``batch`` / ``noises``: x is the first pass of a lockstep batch (ops.tcn_fused32); then (out, mate outputs).
+        ``emb`` = (ids, table, drop_p, site) with x = None: the input rows are dropout(table[ids]), gathered by the
+        clip-resident forward launch itself (ops.TCN32_GATHER; callers check gather_capable first)."""
         ws = [w for g in self._weight_groups() for w in g.tensors()]
         blks = list(self.network)
+        if emb is not None:
+            assert x is None and batch is None and self.gather_capable(emb[0].shape[1], emb[1].shape[1])
+            if self.__dict__.get('_frag32') is None:
+                self.__dict__['_frag32'] = ops.TcnFragments32()
+            p = blks[0].p if self.training else 0.0
+            return ops.tcn_fused32(None, self.__dict__['_frag32'], ws, [c.bias for b in blks for c in (b.conv1, b.conv2)],
+                                   [b.dilation for b in blks], [s for b in blks for s in b.sites], p, noise, noises=noises, emb=emb)
         if self._fused32_ok(x, blks):
             # clip-resident forward (csrc/tcn_fused32.hip): every block in ONE launch; backward layer by layer
             if self.__dict__.get('_frag32') is None:
@@ -127,6 +136,10 @@ class TemporalConvNet(nn.Module):
     def lockstep_capable(self, T, C):
         blks = list(self.network)
         return self._fused32_ok(torch.empty(0, T, C), blks)
+
+    def gather_capable(self, T, C):
+        """the clip-resident forward launch can form its input rows from an embedding table with C columns"""
+        return bool(ops.TCN32_GATHER and self.lockstep_capable(T, C))
 
     def bf16_capable(self):
         """The bf16 path covers the shape the S2AG text encoder uses: no down-sampling residual (in == out channels)."""

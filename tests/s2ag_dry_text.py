@@ -1,5 +1,5 @@
-"""CPU dry run of TextEncoderTCN in bf16 mode (the clip-resident TCN; argv[1] = 1: with the embedding gather inside its forward
-launch, bf16.TCN_GATHER): real ctypes signatures and the library's argument validation, every launch failing for want of a
+"""CPU dry run of TextEncoderTCN (argv[2]: bf16 mode, fp32 mode, or fp32 lockstep passes; argv[1] = 1: with the embedding gather
+inside the clip-resident TCN forward launch, bf16.TCN_GATHER / ops.TCN32_GATHER): real ctypes signatures and the library's argument validation, every launch failing for want of a
 device (codes recorded, not raised).  The guards that make the product refuse CPU tensors are patched out HERE only.
 Prints one JSON line; run by tests/test_host_logic.py."""
 import json
@@ -25,14 +25,25 @@ ops._need_cuda = lambda *a: None
 ops.join_side_streams = lambda *a, **k: None
 torch.cuda.is_current_stream_capturing = lambda: False
 noise.begin_pass = lambda device: torch.zeros(2, dtype=torch.int64)
-bf16.TCN_GATHER = len(sys.argv) > 1 and sys.argv[1] == '1'
+gather = len(sys.argv) > 1 and sys.argv[1] == '1'
+mode = sys.argv[2] if len(sys.argv) > 2 else 'bf16'          # bf16 | fp32 | fp32_passes
+bf16.TCN_GATHER = ops.TCN32_GATHER = gather
 
 args = types.SimpleNamespace(hidden_size=300, n_layers=4, freeze_wordembed=False)
 enc = TextEncoderTCN(args, 1000).train()
-with bf16.precision('bf16'):
-    y, _ = enc(torch.randint(0, 1000, (4, 34)))
-    n = len(rcs)
-    (y * torch.randn_like(y)).sum().backward()
+ids = torch.randint(0, 1000, (4, 34))
+if mode == 'bf16':
+    with bf16.precision('bf16'):
+        y, _ = enc(ids)
+elif mode == 'fp32':
+    y, _ = enc(ids)
+else:                                                        # three passes in lockstep, the first with autograd
+    noises = [torch.zeros(2, dtype=torch.int64) for _ in range(3)]
+    outs = enc.forward_passes(ids, noises)
+    assert len(outs) == 3 and all(o.shape == (4, 34, 32) for o in outs) and not outs[1].requires_grad
+    y = outs[0]
+n = len(rcs)
+(y * torch.randn_like(y)).sum().backward()
 print(json.dumps({'out': list(y.shape), 'forward': [w for w, _ in rcs[:n]], 'backward': [w for w, _ in rcs[n:]],
                   'refused': sorted(set(w for w, rc in rcs if rc == -1)),
                   'grads': {k: (None if p.grad is None else list(p.grad.shape)) for k, p in enc.named_parameters()}}))

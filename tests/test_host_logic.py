@@ -587,21 +587,26 @@ def test_wave_encoder_dry_run_passes_every_entry_points_argument_checks(mode):
     assert all(v is not None for v in d['grads'].values())
 
 
+@pytest.mark.parametrize('mode', ['bf16', 'fp32', 'fp32_passes'])
 @pytest.mark.parametrize('gather', [0, 1])
-def test_text_encoder_bf16_dry_run(gather):
-    """tests/s2ag_dry_text.py: TextEncoderTCN forward + backward in bf16 mode on the CPU, launches failing for want of a device;
-    with the opt-in gather (bf16.TCN_GATHER) the embedding forward launch is gone and the table still receives its gradient.
-    No entry point may refuse its arguments (S2AG_E_BADARG)."""
+def test_text_encoder_dry_run(gather, mode):
+    """tests/s2ag_dry_text.py: TextEncoderTCN forward + backward on the CPU (bf16 mode; fp32 mode; three fp32 passes in
+    lockstep), launches failing for want of a device; with the opt-in gather (bf16.TCN_GATHER / ops.TCN32_GATHER) the
+    embedding forward launches are gone and the table still receives its gradient.  No entry point may refuse its arguments
+    (S2AG_E_BADARG)."""
     import json
     import subprocess
     import sys
     if torch.cuda.is_available():
         pytest.skip('the dry run is for boxes without a GPU')
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 's2ag_dry_text.py')
-    r = subprocess.run([sys.executable, script, str(gather)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, script, str(gather), mode], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d['out'] == [4, 34, 32] and d['refused'] == []
-    assert ('bf16_embedding_fwd' in d['forward']) == (not gather)
-    assert 'bf16_tcn_fwd' in d['forward'] and 'bf16_tcn_bwd' in d['backward'] and 'bf16_embedding_bwd' in d['backward']
+    pre = 'bf16_' if mode == 'bf16' else ''
+    n_emb = sum(w == pre + 'embedding_fwd' for w in d['forward'])
+    assert n_emb == (0 if gather else (3 if mode == 'fp32_passes' else 1))
+    fwd = {'bf16': 'bf16_tcn_fwd', 'fp32': 'tcn32_fwd', 'fp32_passes': 'tcn32_fwd_passes'}[mode]
+    assert fwd in d['forward'] and pre + 'embedding_bwd' in d['backward']
     assert all(v is not None for v in d['grads'].values())
