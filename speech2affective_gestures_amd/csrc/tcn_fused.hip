@@ -21,6 +21,8 @@
 // kept and pre > 0 -- and of h2 and of y's sign that ONE BIT per element is all the backward pass needs, so the forward
 // pass leaves sign bytes (3 bits per element) instead of a third activation tensor, and the backward launch reads 8 KB of
 // them per workgroup and block (prefetched a block ahead) instead of 130 KB of activations it would wait for.
+#include <stdlib.h>
+
 #include "s2ag_common.h"
 
 namespace {
@@ -96,7 +98,11 @@ struct TcnP {
 // matrix-pipe cycles for the L2 round trip), the activation fragments of tile kt + 1 are read from LDS before the MFMAs
 // of tile kt.  sched_barrier pins that order -- left alone the compiler sinks every load next to its first use
 // (s_waitcnt vmcnt(1) in front of each group of 5 MFMAs: 21 us per conv instead of 4).
-template <bool BWD, int MT>
+// RING: register sets of weight fragments in flight (default 4 = 20 KB per wave).  The kernels are bound by the bytes they
+// keep in flight against a ~1.8 us loaded L2 round trip (80 KB per CU -> ~44 GB/s per CU, 19 % MFMA utilisation), and a wave
+// alone on its SIMD owns 512 registers of which ~380 are used: RING = 8 doubles the bytes in flight (opt-in, S2AG_TCN_RING=8,
+// not yet run on a GPU; same products in the same order = bit-identical results).
+template <bool BWD, int MT, int RING = 4>
 __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_off, const u32x4* __restrict__ wa, int d, int T,
                                           int R, int lane, f32x4 (&acc)[CT_W][MT]) {
     int off0[MT], off1[MT];
@@ -109,10 +115,10 @@ __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_o
         off1[mt] = (ok ? src_off + m * PITCH : z_off) + (lane >> 4) * 8;
         off0[mt] = (ok0 ? src_off + (BWD ? m + d : m - d) * PITCH : z_off) + (lane >> 4) * 8;
     }
-    static_assert(NKT % 4 == 0, "ring of four");
-    u32x4 a[4][CT_W];
+    static_assert(NKT % 4 == 0 && RING >= 2 && RING <= NKT, "ring");
+    u32x4 a[RING][CT_W];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < RING; ++s)
 #pragma unroll
         for (int i = 0; i < CT_W; ++i) a[s][i] = wa[(i * NKT + s) * 64];
     bf16x8 b[2][MT];
@@ -124,6 +130,7 @@ __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_o
             dst[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sm + (t0 ? off0[mt] : off1[mt]) + c0));
     };
     load_b(0, b[0]);
+    if constexpr (RING == 4) {
 #pragma unroll
     for (int kp = 0; kp < NKT / 4; ++kp) {       // fully unrolled: a rolled loop made the allocator rotate the accumulators
 #pragma unroll
@@ -142,6 +149,27 @@ __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_o
             if (kt + 4 < NKT) {
 #pragma unroll
                 for (int i = 0; i < CT_W; ++i) a[s][i] = wa[(i * NKT + kt + 4) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {       // fully unrolled: the set index kt % RING is a compile-time constant
+            const int s = kt % RING;
+            if (kt + 1 < NKT) load_b(kt + 1, b[(kt + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CT_W; ++i) {
+                const bf16x8 av = __builtin_bit_cast(bf16x8, a[s][i]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[kt & 1][mt], acc[i][mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + RING < NKT) {
+#pragma unroll
+                for (int i = 0; i < CT_W; ++i) a[s][i] = wa[(i * NKT + kt + RING) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -241,7 +269,7 @@ __global__ __launch_bounds__(256) void tcn_keep_k(const TcnP p) {
 __host__ __device__ inline int sign_s1(int rows) { return (rows * 40 + 15) / 16 * 16; }
 __host__ __device__ inline int sign_s2(int rows) { return (rows * 80 + 15) / 16 * 16; }
 
-template <int MT, bool GATHER = false>
+template <int MT, bool GATHER = false, int RING = 4>
 __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sm = reinterpret_cast<bf16_t*>(smem_raw);
@@ -284,7 +312,7 @@ __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
             u32x4 kv = u32x4{0u, 0u, 0u, 0u};                    // this thread's keep bits: requested now, used after the K loop
             if (drop) kv = p.keep[((size_t)cv * gridDim.x + blockIdx.x) * 256 + tid];
             zero_acc(acc);
-            conv_tile<false, MT>(sm, j == 0 ? X : H1, Z, wa, d, p.T, R, lane, acc);
+            conv_tile<false, MT, RING>(sm, j == 0 ? X : H1, Z, wa, d, p.T, R, lane, acc);
             TCN_STAMP();
             const unsigned kw[4] = {kv.x, kv.y, kv.z, kv.w};
             const float ik = p.inv_keep;
@@ -352,7 +380,7 @@ __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
     }
 }
 
-template <int MT>
+template <int MT, int RING = 4>
 __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sm = reinterpret_cast<bf16_t*>(smem_raw);
@@ -419,7 +447,7 @@ __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
             const int cv = 2 * blk + 1;
             const u32x4* wa = reinterpret_cast<const u32x4*>(p.wfrag + (long long)(2 * cv + 1) * FRAG) + (wave * CT_W * NKT) * 64 + lane;
             zero_acc(acc);
-            conv_tile<true, MT>(sm, P2, Z, wa, d, p.T, R, lane, acc);
+            conv_tile<true, MT, RING>(sm, P2, Z, wa, d, p.T, R, lane, acc);
             TCN_STAMP();
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
@@ -444,7 +472,7 @@ __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
             const int cv = 2 * blk;
             const u32x4* wa = reinterpret_cast<const u32x4*>(p.wfrag + (long long)(2 * cv + 1) * FRAG) + (wave * CT_W * NKT) * 64 + lane;
             zero_acc(acc);
-            conv_tile<true, MT>(sm, P1, Z, wa, d, p.T, R, lane, acc);
+            conv_tile<true, MT, RING>(sm, P1, Z, wa, d, p.T, R, lane, acc);
             TCN_STAMP();
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
@@ -614,7 +642,18 @@ extern "C" int s2ag_bf16_tcn_fwd(const s2ag_bf16_tcn_args* a, void* stream) {
         if (small) hipLaunchKernelGGL(tcn_keep_k<3>, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(tcn_keep_k<5>, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
     }
-    if (p.emb_ids) {
+    static const int ring = [] { const char* v = getenv("S2AG_TCN_RING"); return v ? atoi(v) : 4; }();
+    if (ring == 8 && !p.emb_ids) {
+        static bool attr_r = false;
+        if (!attr_r) {
+            if (hipFuncSetAttribute((const void*)tcn_fwd_k<5, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)tcn_fwd_k<3, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return S2AG_E_UNSUPPORTED;
+            attr_r = true;
+        }
+        if (small) hipLaunchKernelGGL((tcn_fwd_k<3, false, 8>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((tcn_fwd_k<5, false, 8>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    } else if (p.emb_ids) {
         static bool attr_g = false;
         if (!attr_g) {
             if (hipFuncSetAttribute((const void*)tcn_fwd_k<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -642,7 +681,18 @@ extern "C" int s2ag_bf16_tcn_bwd(const s2ag_bf16_tcn_args* a, void* stream) {
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
-    if (p.cpb * p.T <= 48) hipLaunchKernelGGL(tcn_bwd_k<3>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    static const int ring = [] { const char* v = getenv("S2AG_TCN_RING"); return v ? atoi(v) : 4; }();
+    if (ring == 8) {
+        static bool attr_r = false;
+        if (!attr_r) {
+            if (hipFuncSetAttribute((const void*)tcn_bwd_k<5, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)tcn_bwd_k<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return S2AG_E_UNSUPPORTED;
+            attr_r = true;
+        }
+        if (p.cpb * p.T <= 48) hipLaunchKernelGGL((tcn_bwd_k<3, 8>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((tcn_bwd_k<5, 8>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    } else if (p.cpb * p.T <= 48) hipLaunchKernelGGL(tcn_bwd_k<3>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(tcn_bwd_k<5>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;

@@ -11,6 +11,8 @@
 // 3 x 2 activation fragments from LDS, 45 MFMAs.
 // What the (layer-by-layer) backward pass needs goes to HBM once: h1, h2 (post-dropout conv outputs) and the block output
 // y, as fp32 (clips*T, C) rows -- exactly the tensors the per-layer forward kernels would have left.
+#include <stdlib.h>
+
 #include "s2ag_common.h"
 
 namespace {
@@ -96,7 +98,10 @@ __global__ __launch_bounds__(256) void tcn32_keep_k(const T32P p) {
 // acc += conv over the fp32 LDS rows at `src`: K tile kt = tap kt / KT_TAP (rows q - d forward, q + d backward for tap 0;
 // q for tap 1), channels (kt % KT_TAP)*32 .. +32.  wh / wl: this wave's hi / lo weight fragments (+ lane); a ring of three
 // K tiles in flight.  The activation fragments are split here: hi = rn(v), lo = rn(v - hi).
-template <bool BWD>
+// RING: K tiles of weight fragments in flight (default 3 = 30 KB per wave; 6 with S2AG_TCN32_RING=6: the kernels wait for their
+// weight stream -- 34 % MFMA utilisation -- and a wave alone on its SIMD has ~170 registers to spare; not yet run on a GPU;
+// same products in the same order = bit-identical results).
+template <bool BWD, int RING = 3>
 __device__ __forceinline__ void conv32_tile(const float* sm, int src, int Z, const u32x4* __restrict__ wh,
                                             const u32x4* __restrict__ wl, int d, int T, int lane, f32x4 (&acc)[CT_W][MT]) {
     int off0[MT], off1[MT];
@@ -107,9 +112,10 @@ __device__ __forceinline__ void conv32_tile(const float* sm, int src, int Z, con
         off1[mt] = (m < T ? src + m * PITCH : Z) + (lane >> 4) * 8;
         off0[mt] = (ok0 ? src + (BWD ? m + d : m - d) * PITCH : Z) + (lane >> 4) * 8;
     }
-    u32x4 ah[3][CT_W], al[3][CT_W];
+    static_assert(RING >= 2 && RING <= NKT, "ring");
+    u32x4 ah[RING][CT_W], al[RING][CT_W];
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < RING; ++s)
 #pragma unroll
         for (int i = 0; i < CT_W; ++i) {
             ah[s][i] = wh[(i * NKT + s) * 64];
@@ -117,7 +123,7 @@ __device__ __forceinline__ void conv32_tile(const float* sm, int src, int Z, con
         }
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        const int s = kt % 3;
+        const int s = kt % RING;
         const bool t0 = kt < KT_TAP;
         const int c0 = (t0 ? kt : kt - KT_TAP) * 32;
         bf16x8 bh[MT], bl[MT];
@@ -146,18 +152,18 @@ __device__ __forceinline__ void conv32_tile(const float* sm, int src, int Z, con
             for (int mt = 0; mt < MT; ++mt) acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avh, bh[mt], acc[i][mt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 3 < NKT) {
+        if (kt + RING < NKT) {
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
-                ah[s][i] = wh[(i * NKT + kt + 3) * 64];
-                al[s][i] = wl[(i * NKT + kt + 3) * 64];
+                ah[s][i] = wh[(i * NKT + kt + RING) * 64];
+                al[s][i] = wl[(i * NKT + kt + RING) * 64];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <bool GATHER>
+template <bool GATHER, int RING = 3>
 __global__ __launch_bounds__(256) void tcn32_fwd_k(const T32P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256) void tcn32_fwd_k(const T32P p) {
             for (int i = 0; i < CT_W; ++i)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            conv32_tile<false>(sm, src, Z, wh, wl, d, T, lane, acc);
+            conv32_tile<false, RING>(sm, src, Z, wh, wl, d, T, lane, acc);
             // epilogue: bias, ReLU, dropout; conv2 also adds the residual and writes the block output over the block input
             const unsigned kw[4] = {kv.x, kv.y, kv.z, kv.w};
             const int dst = j == 0 ? H1 : H2;
@@ -301,6 +307,7 @@ __global__ __launch_bounds__(256) void tcn32_pack_k(const Pack32 p) {
 // The chain of data gradients of all blocks in one launch: G <- G * [y > 0]; P2 <- G * [h2 > 0] / keep (h2 = mask * relu(pre)
 // is positive exactly where the element was kept and pre > 0); P1 <- dgrad_conv2(P2) * [h1 > 0] / keep; G <- dgrad_conv1(P1) + G.
 // P2 / P1 go to HBM as gp2 / gp1: the `gy` operands of the eight weight gradients (s2ag_f32_wgrad_tr, one launch).
+template <int RING = 3>
 __global__ __launch_bounds__(256) void tcn32_bwd_k(const T32P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(256) void tcn32_bwd_k(const T32P p) {
             for (int i = 0; i < CT_W; ++i)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            conv32_tile<true>(sm, P2, Z, wh, wl, d, T, lane, acc);
+            conv32_tile<true, RING>(sm, P2, Z, wh, wl, d, T, lane, acc);
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
                 const int co = (wave * CT_W + i) * 16 + (lane >> 4) * 4;
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(256) void tcn32_bwd_k(const T32P p) {
             for (int i = 0; i < CT_W; ++i)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            conv32_tile<true>(sm, P1, Z, wh, wl, d, T, lane, acc);
+            conv32_tile<true, RING>(sm, P1, Z, wh, wl, d, T, lane, acc);
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
                 const int co = (wave * CT_W + i) * 16 + (lane >> 4) * 4;
@@ -463,7 +470,8 @@ static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* co
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)tcn32_fwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)tcn32_fwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            hipFuncSetAttribute((const void*)tcn32_fwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)tcn32_fwd_k<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
@@ -477,7 +485,9 @@ static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* co
             hipLaunchKernelGGL(tcn32_keep_k, dim3(per, 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, q);
         }
     }
+    static const int ring = [] { const char* v = getenv("S2AG_TCN32_RING"); return v ? atoi(v) : 3; }();
     if (p.emb_ids) hipLaunchKernelGGL(tcn32_fwd_k<true>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
+    else if (ring == 6) hipLaunchKernelGGL((tcn32_fwd_k<false, 6>), dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(tcn32_fwd_k<false>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
@@ -513,11 +523,14 @@ extern "C" int s2ag_tcn32_bwd(const s2ag_tcn32_args* a, void* stream) {
     const size_t lds = (size_t)(3 * p.T + 1) * PITCH * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)tcn32_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)tcn32_bwd_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)tcn32_bwd_k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
-    hipLaunchKernelGGL(tcn32_bwd_k, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
+    static const int ring = [] { const char* v = getenv("S2AG_TCN32_RING"); return v ? atoi(v) : 3; }();
+    if (ring == 6) hipLaunchKernelGGL(tcn32_bwd_k<6>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(tcn32_bwd_k<3>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }
