@@ -30,6 +30,16 @@ if mode == 'bf16':                       # the default bf16-mode encoder (bf16._
     with bf16.precision('bf16'):
         out = enc(wav)
     n_fwd = n_sg = len(rcs)
+elif mode == 'fp32':                     # the default fp32-mode encoder: fused head (wave12) + layer-by-layer tail (ops)
+    ops._stream = lambda: None
+    ops._need_cuda = lambda *a: None
+    ops.join_side_streams = lambda *a, **k: None
+    ops._ticket = lambda dev: C.c_void_p(_tk.data_ptr())
+    ops._barrier = lambda dev: C.c_void_p(_tk.data_ptr())
+    torch.cuda.is_current_stream_capturing = lambda: False
+    enc.forward.__func__.__globals__['torch'].Tensor.is_cuda = property(lambda self: True)
+    out = enc(wav)
+    n_fwd = n_sg = len(rcs)
 else:                                    # the opt-in fp32 encoder (wave32._WaveFused32)
     out = wave32.encoder_f32(wav, fe)
     n_fwd = len(rcs)

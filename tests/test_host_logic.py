@@ -560,7 +560,7 @@ def test_flat_window_forward_and_polyphase_data_gradient_identities():
     assert float(((hi + lo) - v).abs().max() / v.abs().max()) < 2.0 ** -16
 
 
-@pytest.mark.parametrize('mode', ['fp32_folded', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32_folded', 'bf16', 'fp32'])
 def test_wave_encoder_dry_run_passes_every_entry_points_argument_checks(mode):
     """tests/s2ag_dry_wave32.py: WavEncoder forward + backward through the fused encoders (bf16 mode's default, and the opt-in
     fp32 one of wave32.py) on the CPU with the launches failing for want of a device.  Every call must get as far as the launch
@@ -579,6 +579,9 @@ def test_wave_encoder_dry_run_passes_every_entry_points_argument_checks(mode):
     if mode == 'bf16':
         assert d['forward'] == ['wave12_pack', 'wave12_stats', 'wave12_fwd', 'bf16_pack_weights', 'wave_conv_fwd', 'wave_conv_fwd']
         assert d['backward'] == ['wave_conv_wgrad', 'wave_conv_dgrad', 'wave_conv_wgrad', 'wave_conv_dgrad', 'wave12_bwd']
+    elif mode == 'fp32':                   # the default fp32 mode: fused head, then BatchNorm / conv layer by layer
+        assert d['forward'][:3] == ['wave12_pack', 'wave12_stats', 'wave12_fwd'] and d['forward'][-1] == 'conv_fwd'
+        assert d['backward'][-1] == 'wave12_bwd' and d['backward'].count('conv_bwd_weight') == 2
     else:
         assert d['forward'] == ['wave12_pack', 'wave12_stats', 'wave12_fwd', 'wave_tail32_pack', 'wave_conv_fwd32', 'wave_conv_fwd32']
         assert d['backward'] == ['wave_conv_wgrad32', 'wave_conv_dgrad32', 'wave_conv_wgrad32', 'wave_conv_dgrad32', 'wave12_bwd']
