@@ -280,6 +280,15 @@ def load():
 E_UNSUPPORTED = -2          # S2AG_E_UNSUPPORTED (include/s2ag_hip.h)
 
 
+def require_gpu_device(device, what: str):
+    """The one statement of 'no CPU fallback' for state that lives on a device (noise counters, parameter arenas)."""
+    import torch
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise RuntimeError(f'{what} lives on the GPU; there is no CPU fallback')
+    return device
+
+
 def check(rc: int, what: str):
     if rc != 0:
         kind = {-1: 'bad argument', -2: 'unsupported shape'}.get(rc, f'hipError {rc}')

@@ -32,9 +32,7 @@ def reset_sites(start: int = 0) -> None:
 
 
 def _dev_state(device) -> torch.Tensor:
-    device = torch.device(device)
-    if device.type != 'cuda':
-        raise RuntimeError('S2AG noise state lives on the GPU; no CPU fallback')
+    device = L.require_gpu_device(device, 'S2AG noise state')
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _state:
         _state[idx] = torch.tensor([0x5EED5EED, 0], dtype=torch.int64, device=f'cuda:{idx}')

@@ -27,8 +27,7 @@ class ParamArena:
         if not uniq:
             raise ValueError('no trainable parameters')
         dev = uniq[0].device
-        if dev.type != 'cuda':
-            raise RuntimeError('ParamArena needs parameters on the GPU (no CPU fallback)')
+        L.require_gpu_device(dev, 'ParamArena (its parameters)')
         self.params: List[torch.nn.Parameter] = uniq
         self.epoch = 0          # bumped whenever the arena's values change behind torch's back (FusedAdam.step)
         sizes = [(p.numel() + 3) // 4 * 4 for p in uniq]          # keep every view 16-byte aligned

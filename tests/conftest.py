@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+if os.environ.get('S2AG_EMU', '0') == '1':
+    # TEST INFRASTRUCTURE: the GPU parity tests on the CPU device model (tests/emu/README.md) -- the product's kernel sources
+    # compiled for the host, called through the same C ABI; 'cuda' means 'cpu' in THIS test process only.
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
+    import harness as _emu_harness
+    _emu_harness.install()
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

@@ -1,0 +1,140 @@
+"""TEST INFRASTRUCTURE: run the product's Python host code (ops.py, bf16.py, wave12.py, net/, processor_v2.py ...) and the GPU
+parity tests on the CPU device model -- the SAME kernel sources compiled for the host (tests/emu/build_emu.py), called
+through the same C ABI with host pointers.
+
+    S2AG_EMU=1 python -m pytest tests/test_gpu_ops.py -m gpu -k embedding
+
+`install()` (called by tests/conftest.py when S2AG_EMU=1, in that test process only):
+  * builds tests/emu/_build/libs2ag_emu.so and points _lib.load() at it (the S2AG_HIP_LIB override the product already has
+    for A/B-ing builds of one ABI);
+  * makes 'cuda' mean 'cpu' for this process: a TorchFunctionMode rewrites device arguments, Tensor.cuda()/Module.cuda() are
+    identities, Tensor.is_cuda is True, torch.cuda streams / events are inert objects (every launch of the model is
+    synchronous); hipGraph capture is not modelled (tests that need it skip through `emu_active()`).
+Nothing under speech2affective_gestures_amd/ knows about this module."""
+import contextlib
+import os
+import sys
+
+import torch
+from torch.overrides import TorchFunctionMode
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_ACTIVE = False
+
+
+def emu_active() -> bool:
+    return _ACTIVE
+
+
+class _Stream:
+    cuda_stream = 0
+    device = torch.device('cpu')
+
+    def __init__(self, *a, **k):
+        pass
+
+    def wait_stream(self, s):
+        pass
+
+    def wait_event(self, e):
+        pass
+
+    def record_event(self, e=None):
+        return e if e is not None else _Event()
+
+    def synchronize(self):
+        pass
+
+    def query(self):
+        return True
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _Event:
+    def __init__(self, *a, **k):
+        import time
+        self._t = time.perf_counter()
+
+    def record(self, stream=None):
+        import time
+        self._t = time.perf_counter()
+
+    def wait(self, stream=None):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def query(self):
+        return True
+
+    def elapsed_time(self, other):
+        return (other._t - self._t) * 1e3
+
+
+def _is_cuda_dev(d):
+    if isinstance(d, str):
+        return d.startswith('cuda')
+    if isinstance(d, torch.device):
+        return d.type == 'cuda'
+    if isinstance(d, int) and not isinstance(d, bool):
+        return True
+    return False
+
+
+class _DeviceRewrite(TorchFunctionMode):
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if 'device' in kwargs and _is_cuda_dev(kwargs['device']):
+            kwargs = dict(kwargs)
+            kwargs['device'] = 'cpu'
+        if args and getattr(func, '__name__', '') in ('to', 'device') and any(_is_cuda_dev(a) and not isinstance(a, int) for a in args):
+            args = tuple('cpu' if (_is_cuda_dev(a) and not isinstance(a, int)) else a for a in args)
+        if kwargs.get('pin_memory'):
+            kwargs = dict(kwargs)
+            kwargs['pin_memory'] = False
+        return func(*args, **kwargs)
+
+
+_CPU = torch.device('cpu')
+_real_device = torch.device
+
+
+def install():
+    global _ACTIVE
+    if _ACTIVE:
+        return
+    sys.path.insert(0, HERE)
+    import build_emu
+    lib = build_emu.build()
+    os.environ['S2AG_HIP_LIB'] = lib
+    tc = torch.cuda
+    cur = _Stream()
+    tc.is_available = lambda: True
+    tc.device_count = lambda: 1
+    tc.current_device = lambda: 0
+    tc.set_device = lambda d: None
+    tc.synchronize = lambda *a, **k: None
+    tc.current_stream = lambda *a, **k: cur
+    tc.default_stream = lambda *a, **k: cur
+    tc.Stream = _Stream
+    tc.Event = _Event
+    tc.stream = lambda s: contextlib.nullcontext()
+    tc.is_current_stream_capturing = lambda: False
+    tc.empty_cache = lambda: None
+    tc.manual_seed = lambda s: None
+    tc.manual_seed_all = lambda s: None
+    torch.Tensor.cuda = lambda self, *a, **k: self.clone()          # a device copy never aliases its host source
+    torch.Tensor.is_cuda = property(lambda self: True)
+    torch.Tensor.pin_memory = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    _DeviceRewrite().__enter__()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from speech2affective_gestures_amd import _lib as L
+    L.require_gpu_device = lambda device, what: torch.device('cpu')
+    _ACTIVE = True

@@ -1,0 +1,412 @@
+// TEST INFRASTRUCTURE -- not part of the product.  A CPU execution model of the gfx950 device for the kernels of
+// speech2affective_gestures_amd/csrc/*.hip: the SAME kernel sources are compiled for the host against this header (it
+// shadows <hip/hip_runtime.h>) into tests/emu/_build/libs2ag_emu.so, and the CPU test-suite drives them through the same
+// C ABI (include/s2ag_hip.h) with host pointers.  Nothing under speech2affective_gestures_amd/ loads that library.
+//
+// What is modelled (tests/emu/README.md has the statement and how the model itself is pinned):
+//   * a launch = grid of workgroups; a workgroup = blockDim threads, each a fibre on its own stack; 64 consecutive
+//     threads form a wavefront;
+//   * cross-lane operations are COLLECTIVE: a lane that reaches one parks until every live lane of its wavefront has
+//     reached the same operation; then the operation is evaluated for the whole wavefront with the gfx950 lane layouts
+//     (v_mfma_f32_16x16x32_bf16, v_mfma_f32_16x16x16_bf16 (_1k), v_mfma_f32_16x16x4_f32, ds_read_b64_tr_b16, DPP /
+//     bpermute shuffles, v_readfirstlane, ballot);  a wavefront whose lanes disagree on the operation is reported;
+//   * __syncthreads: every live thread of the workgroup; exited threads do not take part (as exited waves on hardware);
+//   * LDS: `__shared__` objects are per-workgroup (one workgroup at a time per OS thread); dynamic LDS from the launch;
+//   * global memory = host memory; agent-scope atomics = host atomics; workgroups of one launch run on a pool of OS
+//     threads, so spin-waits between workgroups (tickets, tagged cells, grid waits) make progress;
+//   * the order in which wavefronts run between barriers is a test parameter (S2AG_EMU_SCHED): a result that changes with
+//     it is a missing barrier.
+// What is NOT modelled: timing, caches, register pressure, bank conflicts, memory-model relaxations weaker than x86-TSO.
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <tuple>
+#include <type_traits>
+#include <utility>
+
+#define S2AG_EMU 1
+
+// ---- language surface ---------------------------------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define HIP_SYMBOL(x) x
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+
+template <typename A, typename B>
+static inline constexpr typename std::common_type<A, B>::type min(A a, B b) {
+    typedef typename std::common_type<A, B>::type T;
+    return (T)b < (T)a ? (T)b : (T)a;
+}
+template <typename A, typename B>
+static inline constexpr typename std::common_type<A, B>::type max(A a, B b) {
+    typedef typename std::common_type<A, B>::type T;
+    return (T)a < (T)b ? (T)b : (T)a;
+}
+
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu {
+    unsigned x, y, z;
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct double2 { double x, y; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+constexpr hipError_t hipErrorInvalidValue = 1;
+typedef struct emu_stream_opaque* hipStream_t;
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDefault = 4 };
+
+namespace emu {
+
+constexpr int WAVE = 64;
+constexpr int MAX_WAVES = 16;
+
+struct Block;
+struct Wave;
+
+struct Fiber {
+    void* sp;                 // saved stack pointer while not running
+    char* stack;
+    uint3_emu tid;
+    int lane, wave_id, lin;
+    int state;                // 0 runnable, 1 waiting on a wave collective, 2 waiting on the block barrier, 3 done
+    Wave* wave;
+    Block* blk;
+    void* rec;                // operand / result record of the collective this lane is parked in
+};
+
+typedef void (*CollectiveFn)(Wave*);
+
+struct Wave {
+    Fiber* lanes[WAVE];
+    int nlanes;               // threads of this wavefront (64 except in a last partial one)
+    int alive;                // not yet exited
+    int arrived;
+    int op;                   // id of the pending collective (all lanes must agree)
+    CollectiveFn fn;
+    unsigned long long ncoll; // collectives completed (statistics)
+};
+
+struct Block {
+    uint3_emu bid, bdim, gdim;
+    int nthreads, nwaves;
+    int alive, arrived;       // block barrier
+    Wave waves[MAX_WAVES];
+    Fiber* fibers;
+    char* dyn_lds;
+    size_t dyn_bytes;
+};
+
+extern thread_local Fiber* g_cur;
+
+void yield_to_scheduler();                 // park the running fibre (its state says why)
+void collective(int op, CollectiveFn fn, void* rec);
+void block_barrier();
+void os_yield();
+[[noreturn]] void fail(const char* what);
+void launch_impl(dim3 grid, dim3 block, size_t dyn, void (*thunk)(void*), void* ctx, const char* name);
+unsigned long long ticks();
+
+static inline void* dyn_smem() { return g_cur->blk->dyn_lds; }
+
+template <typename F>
+static void thunk_of(void* p) {
+    (*static_cast<F*>(p))();
+}
+template <typename F>
+static inline void launch(dim3 grid, dim3 block, size_t dyn, F&& body, const char* name) {
+    typedef typename std::remove_reference<F>::type FT;
+    launch_impl(grid, block, dyn, &thunk_of<FT>, (void*)&body, name);
+}
+
+// Kernel arguments are evaluated once on the launching thread (as a real launch copies them into the kernarg segment);
+// every thread of the grid then calls the kernel with those values.
+template <typename K, typename... A>
+static inline void launch_kernel(const char* name, K kern, dim3 grid, dim3 block, size_t dyn, hipStream_t, A&&... a) {
+    auto args = std::make_tuple(std::forward<A>(a)...);
+    auto body = [&]() { std::apply(kern, args); };
+    launch(grid, block, dyn, body, name);
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::g_cur->tid)
+#define blockIdx (emu::g_cur->blk->bid)
+#define blockDim (emu::g_cur->blk->bdim)
+#define gridDim (emu::g_cur->blk->gdim)
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kern, grid, block, dyn, stream, ...) \
+    emu::launch_kernel(#kern, kern, dim3(grid), dim3(block), (size_t)(dyn), (hipStream_t)(stream), ##__VA_ARGS__)
+
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+template <typename T>
+static inline hipError_t hipFuncSetAttribute(T, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+    memset(p, v, n);
+    return hipSuccess;
+}
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+template <typename T>
+static inline hipError_t hipMemcpyToSymbol(T& sym, const void* src, size_t n, size_t off = 0,
+                                           hipMemcpyKind = hipMemcpyHostToDevice) {
+    memcpy((char*)&sym + off, src, n);
+    return hipSuccess;
+}
+template <typename T>
+static inline hipError_t hipMemcpyFromSymbol(void* dst, const T& sym, size_t n, size_t off = 0,
+                                             hipMemcpyKind = hipMemcpyDeviceToHost) {
+    memcpy(dst, (const char*)&sym + off, n);
+    return hipSuccess;
+}
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+
+// ---- synchronisation ----------------------------------------------------------------------------------------------------
+static inline void __syncthreads() { emu::block_barrier(); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
+// ---- scalar helpers -----------------------------------------------------------------------------------------------------
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline double __longlong_as_double(long long u) { double f; memcpy(&f, &u, 8); return f; }
+static inline long long __double_as_longlong(double f) { long long u; memcpy(&u, &f, 8); return u; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline double rsqrt(double x) { return 1.0 / sqrt(x); }
+static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+static inline float __saturatef(float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); }
+static inline unsigned long long clock64() { return emu::ticks(); }
+static inline unsigned long long wall_clock64() { return emu::ticks(); }
+static inline unsigned long long __builtin_emu_s_memtime() { return emu::ticks(); }
+
+// ---- atomics ------------------------------------------------------------------------------------------------------------
+#define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+
+namespace emu {
+template <typename T>
+static inline T atomic_load(const T* p) {
+    static unsigned n = 0;
+    if ((++n & 63u) == 0) os_yield();          // a polling loop must let the workgroup it waits for run
+    T v;
+    __atomic_load(const_cast<T*>(p), &v, __ATOMIC_SEQ_CST);
+    return v;
+}
+template <typename T, typename V>
+static inline void atomic_store(T* p, V v) {
+    T t = (T)v;
+    __atomic_store(p, &t, __ATOMIC_SEQ_CST);
+}
+template <typename T, typename V>
+static inline T atomic_add(T* p, V v) {
+    if constexpr (std::is_integral<T>::value) {
+        return __atomic_fetch_add(p, (T)v, __ATOMIC_SEQ_CST);
+    } else {
+        T old, nw;
+        __atomic_load(p, &old, __ATOMIC_SEQ_CST);
+        do { nw = old + (T)v; } while (!__atomic_compare_exchange(p, &old, &nw, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST));
+        return old;
+    }
+}
+template <typename T, typename V>
+static inline T atomic_or(T* p, V v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_SEQ_CST); }
+template <typename T, typename V>
+static inline T atomic_max(T* p, V v) {
+    T old = *p;
+    while (old < (T)v && !__atomic_compare_exchange_n(p, &old, (T)v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return old;
+}
+}  // namespace emu
+#define __hip_atomic_load(p, order, scope) emu::atomic_load(p)
+#define __hip_atomic_store(p, v, order, scope) emu::atomic_store(p, v)
+#define __hip_atomic_fetch_add(p, v, order, scope) emu::atomic_add(p, v)
+#define __hip_atomic_fetch_or(p, v, order, scope) emu::atomic_or(p, v)
+template <typename T, typename V> static inline T atomicAdd(T* p, V v) { return emu::atomic_add(p, v); }
+template <typename T, typename V> static inline T atomicOr(T* p, V v) { return emu::atomic_or(p, v); }
+template <typename T, typename V> static inline T atomicMax(T* p, V v) { return emu::atomic_max(p, v); }
+template <typename T, typename V> static inline T atomicExch(T* p, V v) { return __atomic_exchange_n(p, (T)v, __ATOMIC_SEQ_CST); }
+template <typename T> static inline T atomicCAS(T* p, T cmp, T val) {
+    __atomic_compare_exchange_n(p, &cmp, val, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+    return cmp;
+}
+
+// ---- wavefront collectives ----------------------------------------------------------------------------------------------
+namespace emu {
+enum Op { OP_SHFL = 1, OP_BALLOT, OP_RFL, OP_MFMA_BF16_32, OP_MFMA_BF16_16, OP_MFMA_F32_4, OP_TR16, OP_WBAR };
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+struct ShflRec { uint64_t v; int src; int width; uint64_t out; };
+void shfl_fn(Wave*);
+template <typename T>
+static inline T shfl_from(T v, int src_lane_in_width_group, int width) {
+    static_assert(sizeof(T) <= 8, "shuffle of at most 8 bytes");
+    ShflRec r;
+    r.v = 0;
+    memcpy(&r.v, &v, sizeof(T));
+    r.src = src_lane_in_width_group;
+    r.width = width;
+    collective(OP_SHFL, &shfl_fn, &r);
+    T o;
+    memcpy(&o, &r.out, sizeof(T));
+    return o;
+}
+struct BallotRec { int pred; uint64_t out; };
+void ballot_fn(Wave*);
+struct RflRec { uint32_t v; uint32_t out; };
+void rfl_fn(Wave*);
+struct MfmaRec { float a[8]; float b[8]; f32x4_t c; };     // operands widened to float (exact for bf16)
+void mfma_k32_fn(Wave*);
+void mfma_k16_fn(Wave*);
+void mfma_k4_fn(Wave*);
+struct Tr16Rec { const short* addr; s16x4_t out; };
+void tr16_fn(Wave*);
+void wbar_fn(Wave*);
+
+static inline float bf16_bits_to_float(uint16_t h) { return __uint_as_float((unsigned)h << 16); }
+}  // namespace emu
+
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    const int l = emu::g_cur->lane;
+    return emu::shfl_from(v, (l ^ mask) & (width - 1), width);
+}
+template <typename T> static inline T __shfl(T v, int src, int width = 64) { return emu::shfl_from(v, src & (width - 1), width); }
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    const int l = emu::g_cur->lane & (width - 1);
+    return emu::shfl_from(v, (l + (int)d < width) ? l + (int)d : l, width);
+}
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+    const int l = emu::g_cur->lane & (width - 1);
+    return emu::shfl_from(v, (l - (int)d >= 0) ? l - (int)d : l, width);
+}
+static inline unsigned long long __ballot(int pred) {
+    emu::BallotRec r{pred, 0};
+    emu::collective(emu::OP_BALLOT, &emu::ballot_fn, &r);
+    return r.out;
+}
+static inline int __any(int pred) { return __ballot(pred) != 0; }
+
+template <typename T> static inline T emu_readfirstlane(T v) {
+    static_assert(sizeof(T) == 4, "v_readfirstlane_b32");
+    emu::RflRec r;
+    memcpy(&r.v, &v, 4);
+    emu::collective(emu::OP_RFL, &emu::rfl_fn, &r);
+    T o;
+    memcpy(&o, &r.out, 4);
+    return o;
+}
+#define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
+
+static inline emu::f32x4_t emu_mfma_16x16x32_bf16(emu::bf16x8_t a, emu::bf16x8_t b, emu::f32x4_t c, int, int, int) {
+    emu::MfmaRec r;
+    for (int i = 0; i < 8; ++i) { r.a[i] = (float)a[i]; r.b[i] = (float)b[i]; }
+    r.c = c;
+    emu::collective(emu::OP_MFMA_BF16_32, &emu::mfma_k32_fn, &r);
+    return r.c;
+}
+static inline emu::f32x4_t emu_mfma_16x16x16_bf16_1k(emu::s16x4_t a, emu::s16x4_t b, emu::f32x4_t c, int, int, int) {
+    emu::MfmaRec r;
+    for (int i = 0; i < 4; ++i) {
+        r.a[i] = emu::bf16_bits_to_float((uint16_t)a[i]);
+        r.b[i] = emu::bf16_bits_to_float((uint16_t)b[i]);
+    }
+    r.c = c;
+    emu::collective(emu::OP_MFMA_BF16_16, &emu::mfma_k16_fn, &r);
+    return r.c;
+}
+static inline emu::f32x4_t emu_mfma_16x16x4_f32(float a, float b, emu::f32x4_t c, int, int, int) {
+    emu::MfmaRec r;
+    r.a[0] = a;
+    r.b[0] = b;
+    r.c = c;
+    emu::collective(emu::OP_MFMA_F32_4, &emu::mfma_k4_fn, &r);
+    return r.c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16
+#define __builtin_amdgcn_mfma_f32_16x16x16bf16_1k emu_mfma_16x16x16_bf16_1k
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_16x16x4_f32
+
+template <typename P> static inline emu::s16x4_t emu_ds_read_tr16_b64(P p) {
+    emu::Tr16Rec r;
+    r.addr = (const short*)(uintptr_t)p;
+    emu::collective(emu::OP_TR16, &emu::tr16_fn, &r);
+    return r.out;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64(p)
+
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {a (bytes 7..4), b (bytes 3..0)}; 0x0c -> 0x00, >= 0x0d -> 0xff
+static inline unsigned emu_perm(unsigned a, unsigned b, unsigned sel) {
+    const uint64_t src = ((uint64_t)a << 32) | b;
+    unsigned out = 0;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned s = (sel >> (8 * i)) & 0xffu;
+        unsigned byte;
+        if (s < 8) byte = (unsigned)(src >> (8 * s)) & 0xffu;
+        else if (s < 12) byte = ((src >> (16 * (s - 8) + 15)) & 1u) ? 0xffu : 0u;   // sign of the selected word
+        else if (s == 12) byte = 0;
+        else byte = 0xffu;
+        out |= byte << (8 * i);
+    }
+    return out;
+}
+#define __builtin_amdgcn_perm(a, b, sel) emu_perm(a, b, sel)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+// On hardware the lanes of a wavefront execute in lock step and this builtin only pins the compiler's schedule; here the
+// lanes are fibres, so it is where a wave-private LDS exchange (store by one lane, load by another, no workgroup barrier)
+// becomes ordered.
+static inline void emu_wave_barrier() { emu::collective(emu::OP_WBAR, &emu::wbar_fn, nullptr); }
+#define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __builtin_amdgcn_s_sleep(n) emu::os_yield()
+#define __builtin_amdgcn_s_memtime() __builtin_emu_s_memtime()
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_fence(...) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_workgroup_id_x() (blockIdx.x)

@@ -11,7 +11,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pending; mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests -q -m gpu -x > $O/t_all.log 2>&1; echo "full suite rc=$?"; tail -3 $O/t_all.log
+timeout 2400 python -m pytest tests -q -m gpu > $O/t_all.log 2>&1; echo "full suite rc=$?"; tail -3 $O/t_all.log
 S2AG_WAVE_TAIL32=1 timeout 900 python -m pytest tests/test_gpu_wave32.py -q -m gpu -s > $O/t_wave32.log 2>&1; echo "wave32 tests rc=$?"; grep "wave32 bwd\|passed\|failed\|Error" $O/t_wave32.log | tail -30
 S2AG_WAVE_TAIL32=1 timeout 1200 python -m pytest tests/test_gpu_wave12.py tests/test_gpu_modules.py tests/test_gpu_step.py tests/test_gpu_fullsize.py -q -m gpu > $O/t_wave32_suites.log 2>&1; echo "suites with the tail on rc=$?"; tail -5 $O/t_wave32_suites.log
 S2AG_EMB_FWD_ROWS=1 timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_bf16.py tests/test_gpu_modules.py -q -m gpu -k "embedding or encoders_in_bf16 or text or golden" > $O/t_emb_rows.log 2>&1; echo "embedding rows rc=$?"; tail -3 $O/t_emb_rows.log
