@@ -50,8 +50,16 @@ class precision:
 
     def __enter__(self):
         self.prev = (_MODE[0], _STEP[0])
+        # the split-piece count is a library-wide setting: step mode forces one piece; LEAVING step mode (a nested
+        # precision('fp32') / ('bf16'), or either under S2AG_PRECISION=bf16_step) must give the products their default
+        # pieces back, or an 'fp32' reference run would silently keep 8-mantissa-bit products
+        if self.step:
+            self.prev_pieces = _lib().s2ag_gru_coop_set_split_pieces(1)
+        elif self.prev[1]:
+            self.prev_pieces = _lib().s2ag_gru_coop_set_split_pieces(-1)      # -1: S2AG_GRU_SPLIT or the default two
+        else:
+            self.prev_pieces = None
         _MODE[0], _STEP[0] = self.on, self.step
-        self.prev_pieces = _lib().s2ag_gru_coop_set_split_pieces(1) if self.step else None
 
     def __exit__(self, *a):
         _MODE[0], _STEP[0] = self.prev
@@ -808,7 +816,9 @@ def wave_fused_supported(fe) -> bool:
         c = fe[i]
         ok = ok and (c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0]) == \
             (ci, co, 15, 6, 0, 1)
-    return ok
+    from . import wave12                       # BatchNorm / activation flavour the fused launches fold
+    slopes = [wave12.leaky_slope(fe[i]) for i in (2, 5, 8)]
+    return ok and all(wave12.bn_foldable(fe[i]) for i in (1, 4, 7)) and slopes[0] is not None and slopes == [slopes[0]] * 3
 
 
 class _WaveFused16(torch.autograd.Function):
@@ -960,6 +970,6 @@ class _WaveFused16(torch.autograd.Function):
 
 def wave_encoder_fused(wav: Tensor, fe, pack: WeightPack) -> Tensor:
     """Training-mode WavEncoder on ``fe`` = its feat_extractor; ``pack`` holds the bf16 layouts of fe[3], fe[6], fe[9]."""
-    return _WaveFused16.apply(wav, pack, (fe[1], fe[4], fe[7]), 0.3,
+    return _WaveFused16.apply(wav, pack, (fe[1], fe[4], fe[7]), float(fe[2].negative_slope),
                               fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, fe[3].weight, fe[3].bias, fe[4].weight,
                               fe[4].bias, fe[6].weight, fe[6].bias, fe[7].weight, fe[7].bias, fe[9].weight, fe[9].bias)

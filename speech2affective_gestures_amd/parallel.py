@@ -78,6 +78,19 @@ class DataParallelContext:
             self.n_collectives += 1
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
 
+    def sync_error_flag(self, flag: Optional[torch.Tensor]) -> None:
+        """The sticky error word of the step (ops.coop_error_flag: cooperative-GRU / one-launch-BatchNorm time-outs, int32)
+        becomes the MAX over ranks, IN PLACE, stream ordered.  Issued right before every Adam launch: the device-side
+        step guard (csrc/misc.hip adam_k) reads this very word, so either every replica applies the all-reduced gradient
+        or none does -- a rank that timed out would otherwise skip its update while the others step with a gradient that
+        already contains its invalid contribution, and the replicas would drift apart for good.  (RCCL has no bitwise OR;
+        MAX keeps 'non-zero somewhere' and the largest bit pattern, which is all the guard and the trainer's read-back
+        need.)"""
+        if flag is None or self.world_size <= 1:
+            return
+        self.n_collectives += 1
+        dist.all_reduce(flag.view(torch.int32), op=dist.ReduceOp.MAX)
+
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> None:
         """out (world * n,) <- inp (n,) of every rank, rank-major."""
         if not self.active:
@@ -125,6 +138,7 @@ class RowKernels:
                           # uids_out <- the first cap of them, sorted, padded with n_entries
     pack: Callable        # (dense (n_entries, dim), uids, records_out (cap, dim + 1) f32)
     merge: Callable       # (gathered (world, cap, dim + 1), dense): dense rows overwritten with the rank-ordered sums
+    unique_flagged: Optional[Callable] = None   # `unique` that also raises the sticky error word when the ids overflow the cap
 
 
 @dataclass
@@ -143,7 +157,7 @@ class GradExchange:
     afterwards ``grad`` holds the SUM over ranks everywhere.  If ANY rank's batch holds more distinct ids than ``row_cap``
     (a too small ``args.max_words_per_clip``, data swapped under the trainer) the records would be truncated and the
     replicas would drift apart: the count that ``precheck`` sent ahead (it depends on the token ids only, so it is on the
-    host long before the gradients exist -- reading it stalls nothing) makes EVERY rank take the dense all-reduce of the
+    host long before the gradients exist when steps are synchronous; see exchange_rest for run-ahead loops) makes EVERY rank take the dense all-reduce of the
     row block for that step instead (``dense_fallbacks`` counts them) and the merge finds only sentinels."""
     dp: DataParallelContext
     grad: torch.Tensor
@@ -204,8 +218,9 @@ class GradExchange:
         if self.rows is None:
             return
         _, hi, n_entries, dim = self.rows
-        if not self._pre:       # no precheck this step: list the ids here (an overflow is then only reported, not repaired)
-            self.kernels.unique(ids.reshape(-1), n_entries, self.uids)
+        if not self._pre:       # no precheck this step: list the ids here; an overflow cannot be repaired any more (no rank
+            # knows the others' counts), so it must at least be REPORTED: unique_flagged raises the sticky error word
+            (self.kernels.unique_flagged or self.kernels.unique)(ids.reshape(-1), n_entries, self.uids)
         self.kernels.pack(self.grad[:hi].view(n_entries, dim), self.uids, self.records)
 
     def exchange_rest(self) -> None:
@@ -215,8 +230,11 @@ class GradExchange:
         if self.rows is not None:
             over = False
             if self._pre:
-                if self._cnt_ev is not None:
-                    self._cnt_ev.synchronize()          # recorded at the start of the step: long since complete
+                if self._cnt_ev is not None and not self._cnt_ev.query():
+                    # recorded at the START of the step, so normally long since complete; in sync=False / replayed-graph
+                    # loops the host runs ahead of the device and this wait is what bounds the run-ahead to ~one step
+                    # (the branch below must be taken with THIS step's count on every rank)
+                    self._cnt_ev.synchronize()
                 over = int((self._cnt_host if self._cnt_host is not None else self._cnt)[0]) > self.row_cap
                 self._pre = False
             if over:

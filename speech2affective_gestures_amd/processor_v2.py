@@ -21,7 +21,7 @@ from os.path import join as jn
 import numpy as np
 import torch
 
-from . import noise, ops
+from . import bf16, noise, ops
 from .net.multimodal_context_net_v2 import (AffDiscriminator, ConvDiscriminatorTriModal as CDT, PoseGenerator,
                                             PoseGeneratorTriModal as PGT)
 from .optim import FusedAdam, ParamArena
@@ -277,7 +277,8 @@ class Processor(object):
             cap = min(n_entries, B * min(T, k if k is not None else T))
             rows = (0, n_entries * dim, n_entries, dim)
             kern = RowKernels(unique=lambda i, n, u: ops.rows_unique_raw(i, n, u, flag_overflow=False),
-                              pack=ops.rows_pack_raw, merge=ops.rows_merge_raw)
+                              pack=ops.rows_pack_raw, merge=ops.rows_merge_raw,
+                              unique_flagged=lambda i, n, u: ops.rows_unique_raw(i, n, u, flag_overflow=True))
         return GradExchange(self.dp, ar.grad, split, rows=rows, row_cap=cap, kernels=kern)
 
     # ------------------------------------------------------------------------------------------------
@@ -297,8 +298,14 @@ class Processor(object):
                   else 'Warning! No saved model found at epoch {}.'.format(epoch))
             return False
 
+    def _sync_error_flag(self):
+        """Data parallel: the sticky error word becomes the MAX over ranks before an optimizer reads it (parallel.py)."""
+        self.dp.sync_error_flag(ops.coop_error_flag(self.device))
+
     def save_model(self, epoch, loss):
-        # never write weights of a run whose sticky error word is raised (the fused Adam already refuses to step then)
+        # never write weights of a run whose sticky error word is raised ON ANY RANK (the fused Adam already refuses to step
+        # then, on every rank alike); every rank calls save_model, so the reduction is a matched collective
+        self._sync_error_flag()
         flag = ops.coop_error_flag(self.device)
         if flag is not None:
             ops.check_coop_flag(flag.item())
@@ -871,6 +878,7 @@ class Processor(object):
                                         pre_seq, train, in_audio=in_audio, cut=ex is not None)
             if train:
                 self.dp.all_reduce_grads(self.dis_arena)
+                self._sync_error_flag()
                 self.s2ag_dis_optimizer.step(self.dp.grad_scale)
         comps = self._gen_phase(in_text, in_audio, in_mfcc, target_poses, vid_indices, pre_seq, train, cut=ex is not None)
         if train:
@@ -878,6 +886,7 @@ class Processor(object):
                 ex.launch_a()                              # GRU + out gradients travel ...
                 self._gen_backward_rest(in_text, ex)       # ... while the encoders are back-propagated
                 ex.exchange_rest()
+                self._sync_error_flag()
                 ex.merge_rows()
             self.s2ag_gen_optimizer.step(self.dp.grad_scale)
         return (self._finish(comps, dis_error),)
@@ -922,14 +931,22 @@ class Processor(object):
             fns, between = [seg_dis, seg_gen, seg_opt], [None, None, None]
         else:
             fns = [seg_dis, seg_gen, seg_gen_rest, seg_opt]
-            between = [(lambda: self.dp.all_reduce_grads(self.dis_arena)) if use_gan else None,
-                       ex.launch_a, ex.exchange_rest, None]
+            def after_dis():
+                self.dp.all_reduce_grads(self.dis_arena)
+                self._sync_error_flag()              # before D's Adam (first kernel of the next segment)
+
+            def after_gen_rest():
+                ex.exchange_rest()
+                self._sync_error_flag()              # before G's Adam
+            between = [after_dis if use_gan else None, ex.launch_a, after_gen_rest, None]
         segs = _GraphSegments(fns, between, before=(lambda: ex.precheck(st['text'])) if ex is not None else None)
         self._graphed = dict(st=st, out=out, segs=segs, key=self._graph_key(in_text, in_audio, in_mfcc, target_poses))
 
     def _graph_key(self, in_text, in_audio, in_mfcc, target_poses):
+        # a captured graph holds the kernels of ONE precision mode / split-piece count: switching either re-captures
         return (tuple(in_text.shape), tuple(in_audio.shape), tuple(in_mfcc.shape), tuple(target_poses.shape),
-                self._use_gan(), self.meta_info['epoch'] > self.s2ag_config_args.loss_warmup)
+                self._use_gan(), self.meta_info['epoch'] > self.s2ag_config_args.loss_warmup,
+                bf16.enabled(), bf16.step_mode(), ops._lib().s2ag_gru_coop_split_pieces())
 
     def train_step(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, sync=True):
         """The training branch of forward_pass_s2ag, replayed from HIP graphs when shapes are static.

@@ -35,14 +35,25 @@ def lengths(n_samples: int, pad: int = PAD1):
     return l1, (l1 - 15) // 6 + 1
 
 
+def bn_foldable(bn) -> bool:
+    """A BatchNorm the fused launches can fold: affine, with running estimates and a NUMERIC momentum (momentum=None --
+    cumulative averaging -- and track_running_stats=False take the layer-by-layer path)."""
+    return (isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) and bn.affine and bn.track_running_stats
+            and bn.running_mean is not None and bn.running_var is not None and isinstance(bn.momentum, (int, float)))
+
+
+def leaky_slope(act) -> Optional[float]:
+    return float(act.negative_slope) if isinstance(act, torch.nn.LeakyReLU) else None
+
+
 def supported(fe) -> bool:
-    """``fe`` = WavEncoder.feat_extractor: the geometry the kernels are written for."""
+    """``fe`` = WavEncoder.feat_extractor: the geometry (and the BatchNorm / activation flavour) the kernels are written for."""
     if not ENABLED:
         return False
     c1, c2 = fe[0], fe[3]
     return ((c1.in_channels, c1.out_channels, c1.kernel_size[0], c1.stride[0], c1.dilation[0]) == (1, 16, 15, 5, 1)
             and (c2.in_channels, c2.out_channels, c2.kernel_size[0], c2.stride[0], c2.padding[0], c2.dilation[0]) ==
-            (16, 32, 15, 6, 0, 1) and c1.bias is not None)
+            (16, 32, 15, 6, 0, 1) and c1.bias is not None and bn_foldable(fe[1]) and leaky_slope(fe[2]) is not None)
 
 
 def packed_weights(w1: Tensor, w2: Tensor) -> Tensor:
@@ -158,12 +169,12 @@ class _HeadF32(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, wav, bn1, slope_pad, w1, b1, g1, e1, w2, b2):
-        slope, pad = slope_pad
+        slope, pad, box = slope_pad
         wav = wav.contiguous()
         pk = packed_weights(w1, w2)
         coef1 = stats(wav, pk, b1, bn1, g1, e1, False, pad)
         z2, part, prow, _ = forward(wav, pk, b1, coef1, slope, b2, True, pad=pad)
-        _HeadF32.last_stats = (part, prow)
+        box['stats'] = (part, prow)          # handed back through the caller's own object (no class-level state)
         ctx.slope, ctx.pad, ctx.params = float(slope), int(pad), (w1, b1, g1, e1, w2, b2)
         ctx.save_for_backward(wav, pk, coef1)
         return z2
@@ -195,7 +206,8 @@ class _HeadF32(torch.autograd.Function):
 def head_f32(wav: Tensor, fe) -> Tensor:
     """Training-mode feat_extractor[0..3] in fp32 mode; the result carries the column-sum partials BatchNorm 2 folds
     (``_s2ag_stats``, as ops.conv1d_nlc(bn_stats=True) leaves them)."""
-    z2 = _HeadF32.apply(wav, fe[1], (0.3, int(fe[0].padding[0])), fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, fe[3].weight, fe[3].bias)
-    z2._s2ag_stats = _HeadF32.last_stats
-    _HeadF32.last_stats = None
+    box = {}
+    z2 = _HeadF32.apply(wav, fe[1], (leaky_slope(fe[2]), int(fe[0].padding[0]), box), fe[0].weight, fe[0].bias, fe[1].weight,
+                        fe[1].bias, fe[3].weight, fe[3].bias)
+    z2._s2ag_stats = box['stats']
     return z2

@@ -48,7 +48,8 @@ def supported(fe) -> bool:
         c = fe[i]
         ok = ok and (c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0]) == \
             (ci, co, 15, 6, 0, 1)
-    return ok
+    slopes = [wave12.leaky_slope(fe[i]) for i in (2, 5, 8)]
+    return ok and all(wave12.bn_foldable(fe[i]) for i in (4, 7)) and slopes == [slopes[0]] * 3
 
 
 def tail_lengths(l2: int):
@@ -178,7 +179,7 @@ class _WaveFused32(torch.autograd.Function):
 
 def encoder_f32(wav: Tensor, fe) -> Tensor:
     """Training-mode WavEncoder.forward on ``fe`` = its feat_extractor (fp32 mode)."""
-    return _WaveFused32.apply(wav, (fe[1], fe[4], fe[7]), (0.3, int(fe[0].padding[0])),
+    return _WaveFused32.apply(wav, (fe[1], fe[4], fe[7]), (float(fe[2].negative_slope), int(fe[0].padding[0])),
                               fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, fe[3].weight, fe[3].bias, fe[4].weight,
                               fe[4].bias, fe[6].weight, fe[6].bias, fe[7].weight, fe[7].bias, fe[9].weight, fe[9].bias)
 

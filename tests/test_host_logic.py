@@ -326,8 +326,11 @@ def _dp_worker(rank, world, port, q):
     dp.broadcast_module(lin, arena)
     dp.all_reduce_grads(arena)
     t = dp.max_over_ranks(float(rank), 'cpu')
+    # the sticky error word as ops.coop_error_flag() hands it out (float32 view of an int32): raised on rank 1 only
+    flag = torch.tensor([4 if rank == 1 else 0], dtype=torch.int32).view(torch.float32)
+    dp.sync_error_flag(flag)
     dp.barrier()
-    q.put((rank, arena.data.tolist(), arena.grad.tolist(), dp.grad_scale, t))
+    q.put((rank, arena.data.tolist(), arena.grad.tolist(), dp.grad_scale, t, int(flag.view(torch.int32)[0])))
 
 
 def test_data_parallel_context_world_size_2_gloo():
@@ -341,7 +344,8 @@ def test_data_parallel_context_world_size_2_gloo():
     res = sorted(q.get(timeout=120) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
-    (r0, d0, g0, s0, t0), (r1, d1, g1, s1, t1) = res
+    (r0, d0, g0, s0, t0, f0), (r1, d1, g1, s1, t1, f1) = res
+    assert f0 == f1 == 4                          # one rank's time-out holds every rank's Adam
     assert d0 == d1                               # rank 0's parameters everywhere
     assert g0 == g1 == [3.0] * 15                 # SUM all-reduce of the flat gradient arena (1 + 2)
     assert s0 == s1 == 0.5 and t0 == t1 == 1.0    # Adam consumes grad/world; timing is the max over ranks
@@ -432,6 +436,17 @@ def test_precision_modes_select_the_product_setting_and_restore_it():
         with bf16.precision('bf16_step'):
             assert bf16.enabled() and bf16.step_mode() and lib.s2ag_gru_coop_split_pieces() == 1
         assert bf16.enabled() and not bf16.step_mode() and lib.s2ag_gru_coop_split_pieces() == before
+    assert not bf16.enabled() and lib.s2ag_gru_coop_split_pieces() == before
+    # nested the other way round: an 'fp32' (or 'bf16') reference run INSIDE step mode gets the default pieces back
+    # (it used to keep the single-piece, 8-mantissa-bit products silently: ADVICE r03)
+    with bf16.precision('bf16_step'):
+        assert lib.s2ag_gru_coop_split_pieces() == 1
+        with bf16.precision('fp32'):
+            assert not bf16.enabled() and not bf16.step_mode() and lib.s2ag_gru_coop_split_pieces() == before
+        assert bf16.step_mode() and lib.s2ag_gru_coop_split_pieces() == 1
+        with bf16.precision('bf16'):
+            assert bf16.enabled() and not bf16.step_mode() and lib.s2ag_gru_coop_split_pieces() == before
+        assert lib.s2ag_gru_coop_split_pieces() == 1
     assert not bf16.enabled() and lib.s2ag_gru_coop_split_pieces() == before
 
 
