@@ -82,7 +82,7 @@ def build_processor(B, hip_graph, frames=T, audio_len=AUDIO_LEN):
                                  lang_model=lang, speaker_model=Vocab(N_SPK), n_samples=0)
     args = types.SimpleNamespace(batch_size=B, train_s2ag=True, work_dir_s2ag=None, save_log=False, print_log=False,
                                  hip_graph=hip_graph, max_words_per_clip=MAX_WORDS_PER_CLIP,
-                                 overlap_passes=os.environ.get('S2AG_OVERLAP_PASSES', '1') != '0')
+                                 overlap_passes=True)
     pr = P.Processor(ROOT, args, make_cfg(frames), {'train_data_s2ag': meta, 'val_data_s2ag': meta, 'test_data_s2ag': meta},
                      POSE_DIM, 3, 16000)
     pr.meta_info['epoch'] = 1            # discriminator branch active (epoch > loss_warmup)
@@ -223,6 +223,8 @@ def gru_roofline(B, iters=20, T=T):
     # HBM / fabric bytes per launch: measured, from the tracked PMC summary -- only at the profiled shape
     traffic, source = pmc_traffic(name.split('<')[0]) if (coop and (B, T) == (128, 34)) else (None, None)
     pipe = {0: '12 waves x 38 f32 MFMAs (16x16x4) per CU and step',
+            1: '12 waves x 5 bf16 MFMAs (16x16x32; ONE piece per fp32 operand, 8 mantissa bits per product: the bf16 step mode) '
+               'per CU and slice step',
             2: '12 waves x 15 bf16 MFMAs (16x16x32; the 3 leading piece products of 2-piece bf16 splits of the fp32 '
                'operands: 16 mantissa bits per product) per CU and slice step',
             3: '12 waves x 30 bf16 MFMAs (16x16x32; the 6 leading piece products of exact 3-piece splits: '
@@ -231,7 +233,7 @@ def gru_roofline(B, iters=20, T=T):
     if multi:      # the two mate passes save no gates; W_hh is read once per launch
         algo_bytes = 0.5 * (algo_bytes + algo_bytes + (nP - 1) * 4.0 * B * T * (6 * H + 2 * 2 * H))
     # the products execute as `issued` bf16 MFMAs per fp32 product (2 pieces: 3, 3 pieces: 6; f32 MFMA: the f32 pipe itself)
-    issued = {0: None, 2: 3, 3: 6}[np_]
+    issued = {0: None, 1: 1, 2: 3, 3: 6}[np_]
     return dict(bound='mfma', kernel=name + f' (H=300, T={T}, 2 directions' + ('; average launch of the step: 4 three-pass lockstep launches + 4 one-pass launches)' if multi else ')'),
                 achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3,
                 frac_of_bf16_pipe=(achieved * issued / 2500.0) if issued else None,
@@ -670,7 +672,7 @@ def main():
 
 
 if __name__ == '__main__':
-    # No restart supervisor (r02 had one for a once-in-~60-starts death below hipGraphLaunch): 580 fresh-process starts + 15
+    # No restart supervisor (r02 had one for a once-in-~60-starts death below hipGraphLaunch): 500 fresh-process starts + 12
     # loops of the GPU test suite at r03 produced no death (tools/stress_starts.py, profiles/r03_stress_starts.json).  Should
     # one occur, the native frames are printed (csrc/debug.hip) and the process dies with its signal -- rc != 0, no line.
     os.environ.setdefault('S2AG_CRASH_TRACE', '1')

@@ -40,6 +40,18 @@ extern "C" {
 
 int s2ag_abi_version(void);
 
+/* Run-time options of the library.  The library never reads the environment: the one registry of switches
+ * (speech2affective_gestures_amd/config.py: name, default, what it selects, the test that arms it) pushes them here when
+ * the library is loaded, and tests flip them in-process.  Nothing in the reference corresponds (it has no native code);
+ * what the options select are alternative kernels for the reference call sites cited at the entry points they affect.
+ *   "GRU_SPLIT"      0 f32 MFMA | 1 | 2 (default) | 3 bf16 pieces per fp32 operand (nn.GRU, net/multimodal_context_net_v2.py:480)
+ *   "TCN_RING_DEEP"  1: twice the weight fragments in flight in the clip-resident TCN launches (net/tcn.py:16-46)
+ *   "W12_FWD_PIPE"   1: software-pipelined K loop in the wave head's fp32 forward (net/multimodal_context_net_v2.py:18-21)
+ *   "EMB_FWD_ROWS"   1: row-form embedding forward (net/multimodal_context_net_v2.py:70-78)
+ * set: returns the previous value, S2AG_E_BADARG for an unknown name / negative value.  get: the value or S2AG_E_BADARG. */
+int s2ag_set_option(const char* name, int value);
+int s2ag_get_option(const char* name);
+
 /* 1-D convolution geometry, channels-last.  Input rows (n*Lin + pos), output rows (n*Lout + l),
  * pos = l*stride + tap*dil - pad (pad may be negative).  A Linear layer is ksize=1, Lin=Lout=1, N=rows. */
 typedef struct {
@@ -330,7 +342,7 @@ int s2ag_gru_coop_split_pieces(void);
 /* 16-clip slices one forward workgroup alternates between (2 when B > 16 with the 3-piece products: while one slice's
  * new state travels to the peers the other slice is computed; a launch then occupies 10 * ceil(B/32) * 2 CUs) */
 int s2ag_gru_coop_fwd_slices(int B);
-int s2ag_gru_coop_set_split_pieces(int pieces /*0, 2, 3; anything else: back to the environment's choice*/);  /* returns the previous value */
+int s2ag_gru_coop_set_split_pieces(int pieces /*0, 1, 2, 3; anything else: back to option GRU_SPLIT*/);  /* returns the previous value */
 long long s2ag_gru_coop_workspace_bytes(int B, int T, int H, int backward);
 int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* ydrop, float* gates,
                       int B, int T, int H, const s2ag_epilogue* e /*host, nullable*/, void* workspace, void* stream);

@@ -94,6 +94,8 @@ TCN32_MAX_PASSES = 4
 
 SIGNATURES = {
     's2ag_abi_version': [],
+    's2ag_set_option': [C.c_char_p, ci],
+    's2ag_get_option': [C.c_char_p],
     's2ag_conv1d_nlc_fwd': [vp, vp, vp, vp, PG, PE, vp],
     's2ag_conv1d_nlc_bwd_data': [vp, vp, vp, PG, ci, vp],
     's2ag_conv1d_nlc_bwd_weight': [vp, vp, vp, vp, PG, ci, vp],
@@ -253,7 +255,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get('S2AG_HIP_LIB', LIB_PATH)     # override: A/B-testing another build of the same ABI
+    from . import config
+    path = config.get('HIP_LIB') or LIB_PATH     # override: another build of the same ABI (debug / asan flavour)
     if not os.path.exists(path):
         raise S2AGLibraryError(
             f'{path} not found: the S2AG HIP kernels are not built. Run '
@@ -271,8 +274,9 @@ def load():
                               's2ag_wave_tail32_pack_offset') else ci
     if lib.s2ag_abi_version() != 1:
         raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
-    if os.environ.get('S2AG_CRASH_TRACE', '0') == '1':     # native back trace on SIGSEGV & co (csrc/debug.hip)
+    if config.get('CRASH_TRACE'):     # native back trace on SIGSEGV & co (csrc/debug.hip)
         lib.s2ag_install_crash_handler(2)
+    config.push_to_library(lib)        # the library never reads the environment: options come from the registry
     _lib = lib
     return lib
 

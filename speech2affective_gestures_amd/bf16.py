@@ -17,10 +17,11 @@ from typing import Optional
 import torch
 
 from . import _lib as L
+from . import config
 from . import ops
 
 Tensor = torch.Tensor
-_ENV = os.environ.get('S2AG_PRECISION', 'fp32').lower()
+_ENV = str(config.get('PRECISION')).lower()
 _MODE = [_ENV in ('bf16', 'bfloat16', 'bf16_step')]
 # 'bf16_step' (BASELINE configs[1] "bf16"): besides the bf16 Conv1d path, every large matrix product of the step -- the
 # cooperative GRU's recurrence, its input projections and input gradients, the GRU / TCN / wave-encoder weight gradients
@@ -403,8 +404,8 @@ def conv(x: Tensor, w: Tensor, bias: Optional[Tensor], pack: WeightPack, name: s
 
 
 _Conv16.last_stats = None
-SPLIT_WGRAD = os.environ.get('S2AG_BF16_SPLIT_WGRAD', '1') != '0'
-WGRAD_TR = os.environ.get('S2AG_BF16_WGRAD_TR', '1') != '0'      # LDS transpose-read kernels (csrc/wgrad_tr.hip)
+SPLIT_WGRAD = True
+WGRAD_TR = True      # LDS transpose-read kernels (csrc/wgrad_tr.hip)
 _WG_SCRATCH = {}
 
 
@@ -421,7 +422,7 @@ def _wgrad_scratch(dev, owner, floats):
     return t
 
 
-FUSE_EPILOGUE_BWD = os.environ.get('S2AG_BF16_FUSE_EPI', '1') != '0'
+FUSE_EPILOGUE_BWD = True
 _PRODUCER = {}      # data_ptr of a conv output -> (y, act, cols, slope, drop_p, noise, site, token) of its epilogue
 _FUSED = {}         # token -> data_ptr of the gradient tensor that already carries that epilogue's derivative
 
@@ -429,7 +430,7 @@ _FUSED = {}         # token -> data_ptr of the gradient tensor that already carr
 # ----------------------------------------------------------------------------------------------------
 # clip-resident TemporalConvNet (csrc/tcn_fused.hip): all blocks in one launch forward, one for the data gradients
 # ----------------------------------------------------------------------------------------------------
-FUSE_TCN = os.environ.get('S2AG_BF16_FUSE_TCN', '1') != '0'
+FUSE_TCN = True
 
 
 def tcn_fused_supported(T: int, C: int, ks: int, n_blocks: int) -> bool:
@@ -459,7 +460,7 @@ class TcnFragments:
 
 # the embedding gather + dropout in front of the clip-resident TCN done by its forward launch's loader (csrc/tcn_fused.hip,
 # GATHER): one launch and one pass over the (B, T, 320) rows less.  Written without access to a GPU: opt-in until run there.
-TCN_GATHER = os.environ.get('S2AG_TCN_GATHER', '0') == '1'
+TCN_GATHER = config.mirror('TCN_GATHER', globals(), 'TCN_GATHER')
 
 
 class _TcnFused16(torch.autograd.Function):
@@ -802,7 +803,7 @@ def embedding(ids: Tensor, table: Tensor, drop_p: float = 0.0, noise=None, site=
 # ----------------------------------------------------------------------------------------------------
 # the wave encoder with BatchNorm folded into the neighbouring convs (csrc/wave_fused.hip)
 # ----------------------------------------------------------------------------------------------------
-WAVE_FUSED = os.environ.get('S2AG_WAVE_FUSED', '1') != '0'
+WAVE_FUSED = config.mirror('WAVE_FUSED', globals(), 'WAVE_FUSED')
 _WAVE_LAYERS = ((16, 32), (32, 64), (64, 32))          # (Cin, Cout) of conv2..4: 15 taps, stride 6, no padding
 
 

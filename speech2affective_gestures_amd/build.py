@@ -65,7 +65,8 @@ def build(force: bool = False, verbose: bool = True, flavour: str = 'release') -
         if verbose:
             print('[s2ag build]', ' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-    with cf.ThreadPoolExecutor(max_workers=int(os.environ.get('S2AG_BUILD_JOBS', '4'))) as ex:
+    jobs = int(os.environ.get('S2AG_BUILD_JOBS', '4'))     # registered in config.py (BUILD_JOBS); read here so that build.py runs stand-alone
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         list(ex.map(compile_one, todo))
     if todo or not os.path.exists(lib):
         link_extra = ['-fsanitize=address', '-shared-libsan'] if flavour == 'asan' else []

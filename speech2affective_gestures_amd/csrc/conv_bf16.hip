@@ -976,7 +976,7 @@ extern "C" int s2ag_bf16_conv_wgrad_split(const s2ag_bf16_wgrad_args* g, float* 
 
 extern "C" int s2ag_bf16_conv_wgrad_multi(const s2ag_bf16_wgrad_args* jobs, int njobs, void* stream) {
     if (!jobs || njobs < 1 || njobs > S2AG_BF16_MAX_WGRAD_JOBS) return S2AG_E_BADARG;
-    static const int target = [] { const char* e = getenv("S2AG_BF16_WGRAD_MULTI_BLOCKS"); return e ? atoi(e) : 768; }();
+    constexpr int target = 768;
     WgJobs js{};
     int mt = 0, ms = 0;
     for (int k = 0; k < njobs; ++k) {
@@ -1004,8 +1004,8 @@ extern "C" int s2ag_bf16_conv_wgrad(const s2ag_bf16_wgrad_args* g, void* stream)
     p.ks_out = g->flat_cin > 0 ? g->ks_out : g->ks;
     const int tiles = cdiv(g->Cout, 64) * g->ks * (g->Cp / 64);
     // every block ends with 4 096 fp32 atomics: the split count, not the loop, sets the time (768 blocks: 49 us per TCN
-    // layer, S2AG_BF16_WGRAD_BLOCKS to tune)
-    static const int target = [] { const char* e = getenv("S2AG_BF16_WGRAD_BLOCKS"); return e ? atoi(e) : 320; }();
+    // layer; 320 measured best)
+    constexpr int target = 320;
     int splits = cdiv(target, tiles);
     const int max_splits = cdiv(p.M, 512);                      // at least 8 steps of 64 rows per block
     if (splits > max_splits) splits = max_splits;
@@ -1106,7 +1106,7 @@ extern "C" int s2ag_bf16_embedding_fwd(const long long* ids, const float* table,
     if (!ids || !table || !out || rows <= 0 || dim <= 0 || ld < dim) return S2AG_E_BADARG;
     const float p = e ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
-    static const int row_form = [] { const char* v = getenv("S2AG_EMB_FWD_ROWS"); return v ? atoi(v) : 0; }();
+    const int row_form = s2ag::option(s2ag::OPT_EMB_FWD_ROWS);
     if (row_form && !(ld & 1) && !((uintptr_t)out & 3))
         hipLaunchKernelGGL(embedding_fwd_bf16_k, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, ids, table,
                            rows, dim, n_entries, ld, p, p > 0.f ? 1.f / (1.f - p) : 1.f, e ? e->rng : nullptr,

@@ -916,14 +916,9 @@ bool bad_geom(const s2ag_conv_geom* g) {
 }
 }  // namespace
 
-// S2AG_GEMM_LIN=0: route 1-tap layers through the general kernel (A/B switch)
-static bool use_gemm_lin() {
-    static const bool v = [] {
-        const char* e = getenv("S2AG_GEMM_LIN");
-        return !(e && e[0] == '0');
-    }();
-    return v;
-}
+// 1-tap / tap-major stride-1 layers go through the straight-line kernels of gemm_lin.hip (the A/B switch that routed them
+// through the general kernel is gone: +60 % on those layers, r01)
+static constexpr bool use_gemm_lin() { return true; }
 
 int s2ag_bwd_pair(const float* gy, const float* w, const float* x, float* dx, float* dw, float* db, int nclips, int L,
                   int Cin, int Cout, int ks, int pad, int dil, int ldx, int ldg, int wtm, int chunk, int nsplit,
@@ -994,8 +989,7 @@ static int conv1d_nlc_fwd_impl(const float* x, const float* w, const float* bias
         return 0;
     }
     // the wave encoder's Conv1d(16, 32, 15, stride 6): flat-window kernel with the weights in registers (conv_pp.hip)
-    static const bool use_fw = [] { const char* e = getenv("S2AG_FWD_FW"); return !(e && e[0] == '0'); }();
-    if (use_fw && g->stride > 1 &&
+    if (g->stride > 1 &&
         (rows_ = s2ag_conv_fwd_fw(x, w, bias, y, g->N, g->Lin, g->Lout, g->Cin, g->Cout, g->ksize, g->stride, g->pad, g->dil,
                                   g->ldx, g->ldy, g->w_tap_major, p.act, p.slope, p.drop_p, stats, (hipStream_t)stream))) {
         S2AG_LAUNCH_CHECK();
@@ -1066,9 +1060,8 @@ extern "C" int s2ag_conv1d_nlc_bwd_data(const float* gy, const float* w, float* 
         S2AG_LAUNCH_CHECK();
         return 0;
     }
-    // the wave encoder's strided convs: poly-phase kernel (S2AG_DGRAD_PP=0: the general kernel's residue mode)
-    static const bool use_pp = [] { const char* e = getenv("S2AG_DGRAD_PP"); return !(e && e[0] == '0'); }();
-    if (use_pp && g->stride > 1 &&
+    // the wave encoder's strided convs: poly-phase kernel (other strided geometries: the general kernel's residue mode)
+    if (g->stride > 1 &&
         s2ag_conv_dgrad_pp(gy, w, dx, g->N, g->Lin, g->Lout, g->Cin, g->Cout, g->ksize, g->stride, g->pad, g->dil, g->ldy,
                            g->ldx, g->w_tap_major, accumulate, (hipStream_t)stream)) {
         S2AG_LAUNCH_CHECK();

@@ -285,8 +285,7 @@ __global__ __launch_bounds__(512) void gemm_lin_k(LinP p) {
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 inline long long bm64_min_blocks() {
-    static const long long v = [] { const char* e = getenv("S2AG_BM64_MIN"); return e ? atoll(e) : 512LL; }();
-    return v;
+    return 512LL;
 }
 }  // namespace
 

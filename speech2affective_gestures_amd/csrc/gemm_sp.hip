@@ -579,8 +579,7 @@ extern "C" int s2ag_conv1d_nlc_fwd_split(const float* x, const void* w_planes, c
     p.inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
     p.rng = e ? e->rng : nullptr; p.site = e ? e->site : 0u;
     p.stats = partials;
-    static const int bm_env = [] { const char* e = getenv("S2AG_CONV_SPLIT_BM"); return e ? atoi(e) : 0; }();
-    const bool bm64 = bm_env ? bm_env == 64 : (long long)cdiv(p.M, 64) * cdiv(p.Cout, 64) >= 1024;
+    const bool bm64 = (long long)cdiv(p.M, 64) * cdiv(p.Cout, 64) >= 1024;
     const dim3 grid(cdiv(p.M, bm64 ? 64 : 32), cdiv(p.Cout, 64));
     const int np = s2ag_gru_coop_split_pieces();
     if (bm64) {

@@ -1009,25 +1009,17 @@ inline size_t coop_payload_bytes(int B, int H, int backward) {
     return align_up(groups * producers * 2 * (size_t)H * CBS * sizeof(u64), 256);   // [group][parity][...] cells
 }
 
-// S2AG_GRU_SPLIT = 0: f32 MFMA; 2 (default) / 3: fp32 products from 2 / 3 bf16 pieces on the bf16 pipe (see above)
-int g_split_override = -1;          // s2ag_gru_coop_set_split_pieces (tests / diagnostics)
+// option GRU_SPLIT = 0: f32 MFMA; 2 (default) / 3: fp32 products from 2 / 3 bf16 pieces on the bf16 pipe (see above); 1: the
+// bf16 step mode's single piece.  s2ag_gru_coop_set_split_pieces overrides it for an extent (precision contexts, tests).
+int g_split_override = -1;
 inline int coop_split_pieces() {
-    static const int v = [] {
-        const char* e = getenv("S2AG_GRU_SPLIT");
-        const int n = e ? atoi(e) : 2;
-        return (n == 1 || n == 2 || n == 3) ? n : 0;
-    }();
-    return g_split_override >= 0 ? g_split_override : v;
+    const int n = s2ag::option(s2ag::OPT_GRU_SPLIT);
+    return g_split_override >= 0 ? g_split_override : ((n >= 1 && n <= 3) ? n : 0);
 }
 
-// S2AG_GRU_SLICES=1: one 16-clip slice per workgroup (160 workgroups at B = 128); default 2 (see gru_coop_fwd_sp2_k)
-inline bool coop_two_slices() {
-    static const bool v = [] {
-        const char* e = getenv("S2AG_GRU_SLICES");
-        return !(e && atoi(e) == 1);
-    }();
-    return v;
-}
+// two 16-clip slices per forward workgroup whenever B > 16 (see gru_coop_fwd_sp2_k; the one-slice launch of 160 workgroups
+// lost its A/B inside the step, r01-j)
+inline constexpr bool coop_two_slices() { return true; }
 
 // sticky time-out flag of the process (s2ag_gru_coop_set_error_flag): when set, every launch reports a peer time-out
 // THERE (never cleared by the library) instead of in its own workspace word, so a trainer reads one word per step
@@ -1085,8 +1077,6 @@ int launch_fwd_sp2(int n, const float* const* gi, const float* whh, const float*
     const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
     const int np = coop_split_pieces();
     int smem2 = 2 * np * CBS * (5 * 2 * 32 + 8) * 2;                   // [slice][piece][clip][k] bf16
-    static const int reserve_f = [] { const char* e = getenv("S2AG_COOP_FWD_LDS_RESERVE"); return (e ? atoi(e) : 0) * 1024; }();
-    if (reserve_f > smem2) smem2 = reserve_f;                          // CU reservation, see s2ag_gru_coop_bwd
     const void* fn2 = np == 3   ? reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 3, 2>)
                       : np == 2 ? reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 2, 2>)
                                 : reinterpret_cast<const void*>(gru_coop_fwd_sp2_k<300, 32, 1, 2>);
@@ -1212,8 +1202,6 @@ extern "C" int s2ag_gru_coop_bwd(const float* dy, int lddy, int dy_dir_stride, c
     // weight-gradient GEMMs that run beside the recurrence on a forked stream -- off its CU.  The recurrence is a chain of
     // latency-bound steps: sharing the CU's issue slots and LDS pipe with a GEMM made a launch 299 us inside the step
     // against 158 us alone, while 96 of the 256 CUs have no recurrence workgroup at all.
-    static const size_t reserve = [] { const char* e = getenv("S2AG_COOP_BWD_LDS_RESERVE"); return (size_t)(e ? atoi(e) : 0) * 1024; }();
-    if (reserve > smem) smem = reserve;
     const void* fn = np == 3   ? reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 3>)
                      : np == 2 ? reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 2>)
                      : np == 1 ? reinterpret_cast<const void*>(gru_coop_bwd_k<300, 32, 1>)

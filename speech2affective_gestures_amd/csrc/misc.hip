@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "s2ag_common.h"
+#include <string.h>
 
 namespace {
 using namespace s2ag;
@@ -571,7 +572,7 @@ extern "C" int s2ag_embedding_fwd(const long long* ids, const float* table, int 
     if (!ids || !table || !out || rows <= 0 || dim <= 0 || n_entries <= 0 || ldo < dim) return S2AG_E_BADARG;
     const float p = e ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
-    static const int row_form = [] { const char* v = getenv("S2AG_EMB_FWD_ROWS"); return v ? atoi(v) : 0; }();
+    const int row_form = s2ag::option(s2ag::OPT_EMB_FWD_ROWS);
     if (row_form)
         hipLaunchKernelGGL(embedding_fwd_k, dim3(cdiv(rows, EMBF_RB)), dim3(256), 0, (hipStream_t)stream, ids,
                            table, rows, dim, n_entries, out, ldo, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
@@ -978,4 +979,33 @@ extern "C" int s2ag_normal_noise(const unsigned long long* rng, unsigned site, l
     hipLaunchKernelGGL(normal_noise_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, rng, site, n, eps);
     S2AG_LAUNCH_CHECK();
     return 0;
+}
+
+
+// ---- run-time options (the registry is speech2affective_gestures_amd/config.py) ------------------------------------------
+namespace s2ag {
+namespace {
+int g_options[OPT_COUNT] = {2, 0, 0, 0};
+const char* const g_option_names[OPT_COUNT] = {"GRU_SPLIT", "TCN_RING_DEEP", "W12_FWD_PIPE", "EMB_FWD_ROWS"};
+int option_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (strcmp(name, g_option_names[i]) == 0) return i;
+    return -1;
+}
+}  // namespace
+int option(Option o) { return g_options[o]; }
+}  // namespace s2ag
+
+extern "C" int s2ag_set_option(const char* name, int value) {
+    const int i = s2ag::option_index(name);
+    if (i < 0 || value < 0) return S2AG_E_BADARG;
+    if (i == s2ag::OPT_GRU_SPLIT && value > 3) return S2AG_E_BADARG;
+    const int prev = s2ag::g_options[i];
+    s2ag::g_options[i] = value;
+    return prev;
+}
+extern "C" int s2ag_get_option(const char* name) {
+    const int i = s2ag::option_index(name);
+    return i < 0 ? S2AG_E_BADARG : s2ag::g_options[i];
 }

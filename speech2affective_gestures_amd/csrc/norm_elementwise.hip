@@ -837,7 +837,7 @@ extern "C" int s2ag_bn_fold(double* partials, int partial_rows, int rows, int co
         !running_mean || !running_var || !scale_col || !shift_col || !mean_col || !invstd_col)
         return S2AG_E_BADARG;
     int pstep = 1;
-    static const int pre_min = [] { const char* e = getenv("S2AG_BN_PREFOLD_MIN"); return e ? atoi(e) : 1024; }();
+    constexpr int pre_min = 1024;
     if (partial_rows >= pre_min) {
         pstep = FOLD_SLICE;
         hipLaunchKernelGGL(bn_fold_pre_k, dim3(cdiv(partial_rows, FOLD_SLICE), cdiv(cols, 256)), dim3(256), 0,

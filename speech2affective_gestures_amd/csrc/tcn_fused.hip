@@ -100,7 +100,7 @@ struct TcnP {
 // (s_waitcnt vmcnt(1) in front of each group of 5 MFMAs: 21 us per conv instead of 4).
 // RING: register sets of weight fragments in flight (default 4 = 20 KB per wave).  The kernels are bound by the bytes they
 // keep in flight against a ~1.8 us loaded L2 round trip (80 KB per CU -> ~44 GB/s per CU, 19 % MFMA utilisation), and a wave
-// alone on its SIMD owns 512 registers of which ~380 are used: RING = 8 doubles the bytes in flight (opt-in, S2AG_TCN_RING=8,
+// alone on its SIMD owns 512 registers of which ~380 are used: RING = 8 doubles the bytes in flight (opt-in, option TCN_RING_DEEP,
 // not yet run on a GPU; same products in the same order = bit-identical results).
 template <bool BWD, int MT, int RING = 4>
 __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_off, const u32x4* __restrict__ wa, int d, int T,
@@ -526,11 +526,9 @@ unsigned long long* g_trace = nullptr;
 // Clips per workgroup.  Two clips (68 rows = 5 row tiles) amortise a workgroup's weight stream best, but at B = 256 that is
 // 128 workgroups on 256 CUs, every one a chain of eight convs of ~22 k cycles: with one clip per workgroup (3 row tiles)
 // the K loop and the epilogue of a conv shrink to 3 / 5 and all CUs work -- the L2 then serves the weights twice as often
-// (742 MB per launch, well inside its bandwidth).  S2AG_TCN_CPB forces a value.
+// (742 MB per launch, well inside its bandwidth).
 int plan_cpb(int n_clips, int T) {
     const int max_cpb = (MT_MAX * 16) / T > 2 ? 2 : (MT_MAX * 16) / T;
-    static const int forced = [] { const char* e = getenv("S2AG_TCN_CPB"); return e ? atoi(e) : 0; }();
-    if (forced >= 1 && forced <= max_cpb) return forced;
     if (max_cpb >= 2 && T <= 48 && n_clips >= 192) return 1;
     return max_cpb;
 }
@@ -642,7 +640,7 @@ extern "C" int s2ag_bf16_tcn_fwd(const s2ag_bf16_tcn_args* a, void* stream) {
         if (small) hipLaunchKernelGGL(tcn_keep_k<3>, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(tcn_keep_k<5>, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
     }
-    static const int ring = [] { const char* v = getenv("S2AG_TCN_RING"); return v ? atoi(v) : 4; }();
+    const int ring = s2ag::option(s2ag::OPT_TCN_RING_DEEP) ? 8 : 4;
     if (ring == 8 && !p.emb_ids) {
         static bool attr_r = false;
         if (!attr_r) {
@@ -681,7 +679,7 @@ extern "C" int s2ag_bf16_tcn_bwd(const s2ag_bf16_tcn_args* a, void* stream) {
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
-    static const int ring = [] { const char* v = getenv("S2AG_TCN_RING"); return v ? atoi(v) : 4; }();
+    const int ring = s2ag::option(s2ag::OPT_TCN_RING_DEEP) ? 8 : 4;
     if (ring == 8) {
         static bool attr_r = false;
         if (!attr_r) {

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void tcn32_keep_k(const T32P p) {
 // acc += conv over the fp32 LDS rows at `src`: K tile kt = tap kt / KT_TAP (rows q - d forward, q + d backward for tap 0;
 // q for tap 1), channels (kt % KT_TAP)*32 .. +32.  wh / wl: this wave's hi / lo weight fragments (+ lane); a ring of three
 // K tiles in flight.  The activation fragments are split here: hi = rn(v), lo = rn(v - hi).
-// RING: K tiles of weight fragments in flight (default 3 = 30 KB per wave; 6 with S2AG_TCN32_RING=6: the kernels wait for their
+// RING: K tiles of weight fragments in flight (default 3 = 30 KB per wave; 6 with option TCN_RING_DEEP: the kernels wait for their
 // weight stream -- 34 % MFMA utilisation -- and a wave alone on its SIMD has ~170 registers to spare; not yet run on a GPU;
 // same products in the same order = bit-identical results).
 template <bool BWD, int RING = 3>
@@ -485,7 +485,7 @@ static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* co
             hipLaunchKernelGGL(tcn32_keep_k, dim3(per, 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, q);
         }
     }
-    static const int ring = [] { const char* v = getenv("S2AG_TCN32_RING"); return v ? atoi(v) : 3; }();
+    const int ring = s2ag::option(s2ag::OPT_TCN_RING_DEEP) ? 6 : 3;
     if (p.emb_ids) hipLaunchKernelGGL(tcn32_fwd_k<true>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
     else if (ring == 6) hipLaunchKernelGGL((tcn32_fwd_k<false, 6>), dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(tcn32_fwd_k<false>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
@@ -528,7 +528,7 @@ extern "C" int s2ag_tcn32_bwd(const s2ag_tcn32_args* a, void* stream) {
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
-    static const int ring = [] { const char* v = getenv("S2AG_TCN32_RING"); return v ? atoi(v) : 3; }();
+    const int ring = s2ag::option(s2ag::OPT_TCN_RING_DEEP) ? 6 : 3;
     if (ring == 6) hipLaunchKernelGGL(tcn32_bwd_k<6>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(tcn32_bwd_k<3>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();

@@ -1144,7 +1144,7 @@ extern "C" int s2ag_wave12_fwd(const float* x, const void* packed, const float* 
     p.N = N; p.Lin = Lin; p.L1 = L1; p.L2 = L2; p.pad = pad;
     p.chunks = fwd_chunks(N, L2, &p.LC);
     const dim3 grid(N * p.chunks);
-    static const int pipe = [] { const char* v = getenv("S2AG_W12_FWD_PIPE"); return v ? atoi(v) : 0; }();
+    const int pipe = s2ag::option(s2ag::OPT_W12_FWD_PIPE);
     if (out_f32 && pipe) hipLaunchKernelGGL((wv12_fwd_k<2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else if (out_f32) hipLaunchKernelGGL(wv12_fwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wv12_fwd_k<1>, grid, dim3(256), 0, (hipStream_t)stream, p);

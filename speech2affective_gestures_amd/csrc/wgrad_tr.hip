@@ -616,19 +616,16 @@ unsigned long long* g_tr_trace = nullptr;
 // makes them queue (gru_coop_bwd_k 224 us inside the step against 157 us alone); 96 + 160 = the chip.  Measured on the step:
 // 15 210-15 310 (96) / 15 300 (128) / 14 900 (160) / 15 110-15 120 (256) clips/s.
 int target_blocks32() {
-    static const int t = [] { const char* e = getenv("S2AG_F32_WGRAD_TR_BLOCKS"); return e ? atoi(e) : 96; }();
-    return t > 0 ? t : 96;
+    return 96;
 }
 
 int target_blocks() {
-    static const int t = [] { const char* e = getenv("S2AG_BF16_WGRAD_TR_BLOCKS"); return e ? atoi(e) : 0; }();
-    return t;
+    return 0;
 }
 
 // 320 x 160 tiles on eight waves when every weight has more than 160 output channels (the TCN: 300)
 bool wide_tiles(const s2ag_bf16_wgrad_args* jobs, int n) {
-    static const int on = [] { const char* e = getenv("S2AG_BF16_WGRAD_TR_WIDE"); return e ? atoi(e) : 1; }();
-    if (!on || !big_tiles(jobs, n)) return false;
+    if (!big_tiles(jobs, n)) return false;
     for (int k = 0; k < n; ++k)
         if (jobs[k].Cout <= 160 || jobs[k].Cout > 320) return false;
     return true;
@@ -658,8 +655,7 @@ extern "C" int s2ag_bf16_conv_wgrad_tr(const s2ag_bf16_wgrad_args* jobs, int njo
     const int TCO = wide ? 320 : (big ? 160 : 64), TK = big ? 160 : 64;
     const int target = target_blocks() > 0 ? target_blocks() : (big ? 256 : 1024);
     TrJobs js{};
-    static const int remap = [] { const char* e = getenv("S2AG_WGRAD_TR_XCD"); return e ? atoi(e) : 1; }();
-    js.xcd_remap = remap;
+    js.xcd_remap = 1;
     long long off = 0, max_red = 0;
     int ms = 0, nblk = 0;
     const int rpb = rows_per_block(jobs, njobs, TCO, TK, target);
@@ -728,8 +724,7 @@ extern "C" int s2ag_f32_wgrad_tr_n(const s2ag_bf16_wgrad_args* jobs, int njobs, 
     const int TCO = big ? 160 : 64, TK = big ? 160 : 64;
     const int target = blocks > 0 ? blocks : (big ? target_blocks32() : 1024);
     TrJobs js{};
-    static const int remap = [] { const char* e = getenv("S2AG_WGRAD_TR_XCD"); return e ? atoi(e) : 1; }();
-    js.xcd_remap = remap;
+    js.xcd_remap = 1;
     js.trace = g_tr_trace;
     long long off = 0, max_red = 0;
     int ms = 0, nblk = 0;

@@ -482,7 +482,7 @@ ConvDiscriminator = ConvDiscriminatorTriModal     # name used by net/multimodal_
 
 # the three text-encoder passes of a step as one batch (TextEncoderTCN.forward_passes): measured neutral on the step
 # (-0.5 %: the clip-resident TemporalConvNet is bound by its weight stream from L2, not by its 128 workgroups), off
-LOCKSTEP_TEXT = __import__('os').environ.get('S2AG_LOCKSTEP_TEXT', '0') != '0'
+LOCKSTEP_TEXT = False
 
 
 class PoseGenerator(nn.Module, _SpeakerZ):

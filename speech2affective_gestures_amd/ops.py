@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import config
 
 Tensor = torch.Tensor
 
@@ -169,8 +170,8 @@ def conv_bwd_weight_multi_raw(jobs) -> bool:
     return True
 
 
-FUSE_WGRADS = __import__('os').environ.get('S2AG_FUSE_WGRADS', '1') != '0'
-FUSE_BWD_PAIR = __import__('os').environ.get('S2AG_FUSE_BWD', '1') != '0'
+FUSE_WGRADS = True            # (constants below: A/B switches of r01-r03 whose alternative lost; tests may set them)
+FUSE_BWD_PAIR = True
 
 
 def conv_bwd_pair_raw(gy: Tensor, w: Tensor, x: Tensor, dx: Tensor, dw: Tensor, dbias: Optional[Tensor], N, Lin, Lout,
@@ -305,7 +306,7 @@ def check_coop_flag(host_value) -> None:
     if bits:
         raise CoopGruTimeout('a cooperative GRU recurrence timed out waiting for a peer workgroup (the 10 workgroups '
                              'of a group were not co-resident): results since the last check are invalid. Re-run with '
-                             'fewer concurrent passes (S2AG_OVERLAP_PASSES=0) or set ops.USE_COOP_GRU = False')
+                             'fewer concurrent passes (Processor(..., overlap_passes=False)) or set ops.USE_COOP_GRU = False')
 
 
 def init_tickets(device) -> None:
@@ -475,12 +476,12 @@ class _ConvNLC(torch.autograd.Function):
 
 # big stride-1 tap-major convs without a BatchNorm behind them (the TCN): 21.6 us against 27.5 us for the f32 straight-line
 # kernel at M = 4 352, 300 -> 300, 2 taps; +2.1 % on the step
-SPLIT_CONV = __import__('os').environ.get('S2AG_CONV_SPLIT', '1') != '0'
-SPLIT_LINEAR = __import__('os').environ.get('S2AG_LINEAR_SPLIT', '1') != '0'   # 1-tap layers >= 1 GFLOP (GRU layer-0 projections): 22 vs 33 us
-SPLIT_CONV_MIN_FLOPS = float(__import__('os').environ.get('S2AG_CONV_SPLIT_MIN_FLOPS', '1e9'))
-SPLIT_GEMM = __import__('os').environ.get('S2AG_GEMM_SPLIT', '1') != '0'
-SPLIT_GEMM_DX = __import__('os').environ.get('S2AG_DX_SPLIT', '1') != '0'
-SPLIT_GEMM_MIN_FLOPS = float(__import__('os').environ.get('S2AG_GEMM_SPLIT_MIN_FLOPS', '4e9'))
+SPLIT_CONV = True
+SPLIT_LINEAR = True   # 1-tap layers >= 1 GFLOP (GRU layer-0 projections): 22 vs 33 us
+SPLIT_CONV_MIN_FLOPS = 1e9
+SPLIT_GEMM = True
+SPLIT_GEMM_DX = True
+SPLIT_GEMM_MIN_FLOPS = 4e9
 
 
 def split_planes_raw(x: Tensor) -> Tensor:
@@ -512,7 +513,7 @@ def gemm_split_raw(a_planes: Tensor, w_planes: Tensor, bias: Optional[Tensor], y
 
 # off by default: one GRU layer's three weight gradients take 197 us this way (6 transposed splits + 3 split-K GEMMs)
 # against 206 us for the single f32-MFMA wgrad_multi_k launch -- nine launches for nothing (tools/bench history)
-SPLIT_WGRAD = __import__('os').environ.get('S2AG_WGRAD_SPLIT', '0') != '0'
+SPLIT_WGRAD = False
 
 
 def split_planes_t_raw(x: Tensor, shift: int = 0, L_: int = 1, colsum: Optional[Tensor] = None) -> Tensor:
@@ -547,8 +548,8 @@ def tap_major(w: Tensor) -> Tensor:
     return ent[1]
 
 
-TM_COPIES = __import__('os').environ.get('S2AG_TM_COPIES', '1') != '0'
-BN_STATS_EPILOGUE = __import__('os').environ.get('S2AG_BN_EPILOGUE', '1') != '0'
+TM_COPIES = True
+BN_STATS_EPILOGUE = True
 _WANT_STATS = [False]
 _LAST_STATS = [None]
 
@@ -625,7 +626,7 @@ def generation() -> int:
 # (lessons) fewer nodes now pay: +0.95 % (17 890 vs 17 720 clips/s, same-box A/B x 4), so it is the
 # default.  <= 64 workgroups per launch, bounded poll, sticky error bit read with the step's losses (check_coop_flag);
 # S2AG_BN_FUSED=0 keeps the two launches, whose workgroups never wait for each other.
-BN_FUSED = __import__('os').environ.get('S2AG_BN_FUSED', '1') == '1'
+BN_FUSED = config.mirror('BN_FUSED', globals(), 'BN_FUSED')
 
 
 class _BNAct(torch.autograd.Function):
@@ -763,13 +764,13 @@ def add_act(a: Tensor, b: Optional[Tensor], slope: float) -> Tensor:
 # ----------------------------------------------------------------------------------------------------
 # clip-resident TemporalConvNet forward of the fp32 step (csrc/tcn_fused32.hip)
 # ----------------------------------------------------------------------------------------------------
-TCN_FUSED32 = __import__('os').environ.get('S2AG_TCN_FUSED32', '1') != '0'
-TCN_FUSED32_BWD = __import__('os').environ.get('S2AG_TCN_FUSED32_BWD', '1') != '0'
+TCN_FUSED32 = config.mirror('TCN_FUSED32', globals(), 'TCN_FUSED32')
+TCN_FUSED32_BWD = True
 # the TCN's eight weight gradients right behind its data-gradient chain on the SAME stream: forked, they queue behind the last
 # GRU layer's weight gradients on the weight-gradient stream and the step ends waiting for them (15 190 forked vs 15 700
 # inline clips/s; layer-by-layer backward 14 980-15 290)
-TCN32_WGRAD_INLINE = __import__('os').environ.get('S2AG_TCN32_WGRAD_INLINE', '1') == '1'
-TCN32_WGRAD_BLOCKS = int(__import__('os').environ.get('S2AG_TCN32_WGRAD_BLOCKS', '256'))
+TCN32_WGRAD_INLINE = True
+TCN32_WGRAD_BLOCKS = 256
 
 
 def tcn_fused32_supported(T: int, Cch: int, ks: int, n_blocks: int) -> bool:
@@ -803,7 +804,7 @@ class _FakeCtx:
 # the embedding gather + dropout in front of the clip-resident TCN done by its forward launch's loader (csrc/tcn_fused32.hip,
 # GATHER): per text-encoder pass one launch and one pass over the (B, T, 300) rows less; the no-grad passes of a lockstep batch
 # never write their rows at all.  Written without access to a GPU: opt-in until run there.
-TCN32_GATHER = __import__('os').environ.get('S2AG_TCN32_GATHER', '0') == '1'
+TCN32_GATHER = config.mirror('TCN_GATHER', globals(), 'TCN32_GATHER')
 
 
 class _TcnFused32(torch.autograd.Function):
@@ -1415,8 +1416,8 @@ def _gru_proj_split(inp, wih, wih_r, wih2, bih2, gi, In):
     gemm_split_raw(split_planes_raw(inp), ent[1], bih2.reshape(-1), gi, In)
 
 
-GRU_WGRAD_TR = __import__('os').environ.get('S2AG_GRU_WGRAD_TR', '1') != '0'
-CONV_WGRAD_TR = __import__('os').environ.get('S2AG_CONV_WGRAD_TR', '1') != '0'
+GRU_WGRAD_TR = True
+CONV_WGRAD_TR = True
 _GRU_WG_SCRATCH = {}
 
 
@@ -1925,7 +1926,7 @@ def set_main_stream(stream=None) -> None:
     _MAIN_STREAM[0] = stream if stream is not None else torch.cuda.current_stream()
 
 
-ASYNC_WGRAD_MIN_FLOPS = float(__import__('os').environ.get('S2AG_ASYNC_WGRAD_MIN_FLOPS', '3e9'))
+ASYNC_WGRAD_MIN_FLOPS = 3e9
 
 
 def run_wgrad(fn, keep=(), flops=float('inf')) -> None:
@@ -1948,8 +1949,8 @@ def run_wgrad(fn, keep=(), flops=float('inf')) -> None:
         fn()
 
 
-GRU_WGRAD_L0 = int(__import__('os').environ.get('S2AG_GRU_WGRAD_L0', '2'))
-GRU_WGRAD_SMALL_DEFER = __import__('os').environ.get('S2AG_GRU_WGRAD_SMALL_DEFER', '1') != '0'
+GRU_WGRAD_L0 = 2
+GRU_WGRAD_SMALL_DEFER = True
 
 
 def wgrad_launcher(fn, keep=()):
@@ -2043,7 +2044,7 @@ class BranchStreams:
         return out
 
 
-PARALLEL_BRANCHES = __import__('os').environ.get('S2AG_PARALLEL_BRANCHES', '0') == '1'     # measured: fork/join overhead exceeds the overlap gained (20.9 vs 19.0 ms/step); kept for study
+PARALLEL_BRANCHES = False     # measured: fork/join overhead exceeds the overlap gained (20.9 vs 19.0 ms/step); kept for study
 _NO_BRANCH_DEPTH = [0]
 
 

@@ -42,14 +42,15 @@ class DataParallelContext:
         world = int(os.environ.get('WORLD_SIZE', '1'))
         rank = int(os.environ.get('RANK', '0'))
         local = int(os.environ.get('LOCAL_RANK', '0'))
-        force = os.environ.get('S2AG_FORCE_DIST', '0') == '1'     # world-size-1 process group: exercises the RCCL calls
+        from . import config
+        force = bool(config.get('FORCE_DIST'))     # world-size-1 process group: exercises the RCCL calls
         if (world > 1 or force) and not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             if backend is None:
                 # 'nccl' IS RCCL on ROCm.  S2AG_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses
                 # duplicate devices): the two-rank test of the real step on a single MI355X (tests/test_gpu_step.py)
-                backend = os.environ.get('S2AG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+                backend = config.get('DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             if backend == 'nccl':
                 torch.cuda.set_device(local)
             dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -21,7 +21,7 @@ from os.path import join as jn
 import numpy as np
 import torch
 
-from . import bf16, noise, ops
+from . import bf16, config, noise, ops
 from .net.multimodal_context_net_v2 import (AffDiscriminator, ConvDiscriminatorTriModal as CDT, PoseGenerator,
                                             PoseGeneratorTriModal as PGT)
 from .optim import FusedAdam, ParamArena
@@ -223,19 +223,18 @@ class Processor(object):
         # independent forward passes of a step run on forked streams (every kernel here fills only part of the chip)
         self.overlap_passes = bool(getattr(args, 'overlap_passes', True))
         # the generator's dropout-free encoders run once per step instead of once per pass (see PoseGenerator)
-        self.share_encoders = bool(getattr(args, 'share_encoders', os.environ.get('S2AG_SHARE_ENCODERS', '1') != '0')) \
+        self.share_encoders = bool(getattr(args, 'share_encoders', True)) \
             and hasattr(self.s2ag_generator, '_shared_encoders')
-        self.encoders_aside = bool(getattr(args, 'encoders_aside', os.environ.get('S2AG_ENCODERS_ASIDE', '1') != '0'))
+        self.encoders_aside = bool(getattr(args, 'encoders_aside', True))
         # ... and the audio encoder of the shared pair on a stream of its own (forward and, since backward kernels run on
         # the stream of their forward op, backward: the two chains of small launches end the generator's backward pass)
         self.encoders_apart = self.encoders_aside and \
-            bool(getattr(args, 'encoders_apart', os.environ.get('S2AG_ENCODERS_APART', '1') != '0'))
-        self.early_real_backward = bool(getattr(args, 'early_real_backward',
-                                                os.environ.get('S2AG_EARLY_REAL_BWD', '1') != '0'))
-        self.early_rand = bool(getattr(args, 'early_rand', os.environ.get('S2AG_EARLY_RAND', '1') != '0'))
+            bool(getattr(args, 'encoders_apart', True))
+        self.early_real_backward = bool(getattr(args, 'early_real_backward', True))
+        self.early_rand = bool(getattr(args, 'early_rand', True))
         # the loss pass of the generator (with autograd) and the frozen tri-modal baseline read nothing the D step
         # writes: they run beside the D step instead of at the head of the generator phase (see _dis_phase)
-        self.early_main = int(getattr(args, 'early_main', os.environ.get('S2AG_EARLY_MAIN', '3')))
+        self.early_main = int(getattr(args, 'early_main', 3))
         self._side = [torch.cuda.Stream(device=self.device) for _ in range(4)]
         self._graphed = None
         self.last_losses = {}
@@ -262,7 +261,7 @@ class Processor(object):
         split = min(ar.offset_of(p) for p in list(G.gru.parameters()) + list(G.out.parameters()))
         assert all(ar.offset_of(p) >= split for p in list(G.gru.parameters()) + list(G.out.parameters()))
         rows, cap, kern = None, 0, None
-        if emb.requires_grad and os.environ.get('S2AG_SPARSE_EMBEDDING', '1') != '0':
+        if emb.requires_grad and config.get('SPARSE_EMBEDDING'):
             assert ar.offset_of(emb) == 0
             n_entries, dim = emb.shape
             B, T = int(self.args.batch_size), int(self.time_steps)
@@ -357,7 +356,7 @@ class Processor(object):
         spk = self.train_speaker_model if train else self.val_speaker_model
         B = self.args.batch_size
         if torch.device(self.device).type == 'cuda' and getattr(
-                self.args, 'prefetch_batches', os.environ.get('S2AG_PREFETCH', '1') != '0'):
+                self.args, 'prefetch_batches', config.get('PREFETCH')):
             # pinned staging + background gather + device-side decode, two batches ahead (data.BatchFeeder)
             from .data import BatchFeeder
             feeders = self.__dict__.setdefault('_feeders', {})
@@ -475,7 +474,7 @@ class Processor(object):
             pre_g[0, :n_pre, :-1] = out_g[0, -n_pre:]
             cur.wait_stream(side)
 
-        use_graph = getattr(self, 'use_hip_graph', True) and os.environ.get('S2AG_SYNTH_GRAPH', '1') != '0'
+        use_graph = getattr(self, 'use_hip_graph', True) and config.get('SYNTH_GRAPH')
         outs_t = torch.empty(W, T, self.pose_dim, device=dev)
         outs_g = torch.empty(W, T, self.pose_dim, device=dev)
         with torch.no_grad():

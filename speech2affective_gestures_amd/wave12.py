@@ -12,9 +12,10 @@ import torch
 from torch import Tensor
 
 from . import _lib as L
+from . import config
 from . import ops
 
-ENABLED = os.environ.get('S2AG_WAVE12', '1') != '0'
+ENABLED = config.mirror('WAVE12', globals(), 'ENABLED')
 PAD1 = 1600
 
 

@@ -20,10 +20,11 @@ import torch
 from torch import Tensor
 
 from . import _lib as L
+from . import config
 from . import ops
 from . import wave12
 
-ENABLED = os.environ.get('S2AG_WAVE_TAIL32', '0') == '1'
+ENABLED = config.mirror('WAVE_TAIL32', globals(), 'ENABLED')
 _LAYERS = ((32, 64), (64, 32))                    # (Cin, Cout) of conv3, conv4: 15 taps, stride 6, no padding
 
 

@@ -265,51 +265,6 @@ def test_clip_resident_tcn_equals_the_layer_by_layer_bf16_path(B):
     assert rel(t1, t0) < 2e-3
     for k in g0:
         assert l2(g1[k], g0[k]) < 2e-2, (k, l2(g1[k], g0[k]))
-
-
-@pytest.mark.skipif(os.environ.get('S2AG_TCN_GATHER', '0') != '1', reason='opt-in path (not yet run on a GPU): set S2AG_TCN_GATHER=1')
-@pytest.mark.parametrize('B', [5, 64, 200])
-def test_embedding_gather_inside_the_clip_resident_tcn_launch(B):
-    """csrc/tcn_fused.hip GATHER: TextEncoderTCN in bf16 mode with the embedding rows + dropout formed by the TCN forward launch's
-    loader, against the same module with the gather as a launch of its own.  Same table rows, same dropout mask (site and
-    index), same bf16 rounding -> the output is bit-identical; every gradient but the table's likewise (the table's is a sum
-    of fp32 atomics either way: 1e-5)."""
-    import types
-    from speech2affective_gestures_amd import bf16, noise, ops
-    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import TextEncoderTCN
-    cfg = types.SimpleNamespace(hidden_size=300, n_layers=4, dropout_prob=0.3, freeze_wordembed=False)
-    torch.manual_seed(3)
-    noise.reset_sites(0)
-    txt = TextEncoderTCN(cfg, 400, 300, dropout=0.3).cuda().train()
-    g = torch.Generator().manual_seed(4)
-    ids = torch.randint(0, 400, (B, 34), generator=g)
-    ids[:, 20:] = 0
-    dt = torch.randn(B, 34, 32, generator=g).cuda()
-    res = {}
-    prev = bf16.TCN_GATHER
-    try:
-        for gather in (False, True):
-            bf16.TCN_GATHER = gather
-            for p in txt.parameters():
-                p.grad = None
-            ops.begin_step()
-            noise.manual_seed(5)
-            with bf16.precision('bf16'):
-                t = txt(ids.cuda())[0]
-                (t * dt).sum().backward()
-            torch.cuda.synchronize()
-            res[gather] = (t.detach().clone(), {k: p.grad.clone() for k, p in txt.named_parameters()})
-    finally:
-        bf16.TCN_GATHER = prev
-    (t0, g0), (t1, g1) = res[False], res[True]
-    assert torch.equal(t1, t0)
-    for k in g0:
-        if k == 'embedding.weight':
-            assert rel(g1[k], g0[k]) < 1e-5, (k, rel(g1[k], g0[k]))
-        else:
-            assert l2(g1[k], g0[k]) < 1e-5, (k, l2(g1[k], g0[k]))     # weight gradients leave through fp32 atomics / ordered folds
-
-
 def test_full_size_steps_with_the_conv_path_in_bf16_mode():
     """BASELINE configs[1] in bf16 mode: the whole GAN step at B = 128, H = 300 with the wave encoder (frozen tri-modal
     baseline) and the text TCN (clip-resident kernels + transpose-read weight gradients) in bf16 -- and, as 'bf16_step', with

@@ -1,8 +1,9 @@
 """fp32 tail of the wave encoder with BatchNorm folded into conv3 / conv4 (csrc/wave_fused.hip, the *32 entry points;
 speech2affective_gestures_amd/wave32.py) -- feat_extractor.{4..9} of net/multimodal_context_net_v2.py:22-27.
 
-The path is opt-in (S2AG_WAVE_TAIL32=1) until it has been run on a GPU: these tests skip without the variable, so a fresh
-checkout's suite says nothing about it either way.  What they check: each launch against torch on the CPU in float64
+The path is opt-in (config switch WAVE_TAIL32) until it has been run on a GPU.  The tests arm it themselves (wave32.ENABLED /
+direct calls) and live in a file that sorts LAST, so that a hardware surprise in a never-run kernel cannot stop a `pytest -x`
+run before the suites of the default path; on the CPU device model (tests/emu) they pass.  What they check: each launch against torch on the CPU in float64
 (forward on the f32 matrix pipe: 1e-5 of the largest element; gradients from two bf16 pieces per operand, 16 mantissa bits:
 1e-4 without a kink, 5e-3 with the LeakyReLU's kink -- see tests/test_gpu_wave12.py::test_backward for why), then the
 WavEncoder module against the layer-by-layer kernels."""
@@ -14,8 +15,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get('S2AG_WAVE_TAIL32', '0') != '1', reason='opt-in path: set S2AG_WAVE_TAIL32=1')]
+pytestmark = pytest.mark.gpu
 
 
 def rel(a, b):
@@ -209,3 +209,28 @@ def test_wave_encoder_fp32_fully_folded_against_layer_by_layer(B):
             a, b = g1[k].double().cpu(), g0[k].double().cpu()       # kink flips: sparse, see tests/test_gpu_wave12.py
             l2 = float((a - b).norm() / b.norm())
             assert l2 < 4e-3 and rel(g1[k], g0[k]) < 2e-2, (k, l2, rel(g1[k], g0[k]))
+
+
+@pytest.mark.parametrize('N,Lin', [(2, 36267), (3, 3000), (5, 1000)])
+def test_pipelined_fp32_forward_is_bit_identical(N, Lin):
+    """config switch W12_FWD_PIPE (csrc/wave12.hip wv12_fwd_k<2, true>): the head's fp32 forward with the next B operands
+    requested before the current products -- same products, same order, same accumulators: z2 and the BatchNorm partial
+    sums must be bit-identical to the default launch (net/multimodal_context_net_v2.py:18-21)."""
+    from speech2affective_gestures_amd import config, wave12
+    g = torch.Generator().manual_seed(21 + N)
+    x = ((torch.randn(N, Lin, generator=g) * 0.05).clamp(-1, 1)).cuda()
+    w1 = (torch.randn(16, 1, 15, generator=g) / math.sqrt(15)).cuda()
+    b1 = (torch.randn(16, generator=g) * 0.1).cuda()
+    g1, e1 = (torch.rand(16, generator=g) + 0.5).cuda(), (torch.randn(16, generator=g) * 0.3).cuda()
+    w2 = (torch.randn(32, 16, 15, generator=g) / math.sqrt(240)).cuda()
+    b2 = (torch.randn(32, generator=g) * 0.1).cuda()
+    pk = wave12.packed_weights(w1, w2)
+    coef1 = wave12.stats(x, pk, b1, _BN(16, 'cuda'), g1, e1, False)
+    outs = []
+    for pipe in (False, True):
+        with config.override('W12_FWD_PIPE', pipe):
+            z2, part, prow, _ = wave12.forward(x, pk, b1, coef1, 0.3, b2, True)
+            torch.cuda.synchronize()
+            outs.append((z2.clone(), part[:2 * prow * 32].clone()))
+    assert torch.isfinite(outs[0][0]).all() and float(outs[0][0].abs().sum()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

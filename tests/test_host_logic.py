@@ -628,3 +628,46 @@ def test_text_encoder_dry_run(gather, mode):
     fwd = {'bf16': 'bf16_tcn_fwd', 'fp32': 'tcn32_fwd', 'fp32_passes': 'tcn32_fwd_passes'}[mode]
     assert fwd in d['forward'] and pre + 'embedding_bwd' in d['backward']
     assert all(v is not None for v in d['grads'].values())
+
+
+def test_every_switch_is_registered_and_the_library_reads_no_environment():
+    """one registry (speech2affective_gestures_amd/config.py: name, default, what it selects, the test
+    that arms it), at most 20 switches, no getenv in the C library, and no S2AG_* environment name anywhere in the package --
+    read OR merely advertised as `S2AG_X=...` in a comment / message -- that the registry does not know."""
+    from speech2affective_gestures_amd import config
+    pkg = os.path.join(ROOT, 'speech2affective_gestures_amd')
+    assert len(config.REGISTRY) <= 20, sorted(config.REGISTRY)
+    files = []
+    for base, _, names in os.walk(pkg):
+        if '_obj' in base or '__pycache__' in base:
+            continue
+        files += [os.path.join(base, n) for n in names if n.endswith(('.py', '.hip', '.h'))]
+    read = re.compile(r'''(?:environ(?:\.get)?\s*[\[(]\s*|getenv\s*\(\s*)['"]S2AG_([A-Z0-9_]+)['"]''')
+    advertised = re.compile(r'\bS2AG_([A-Z0-9_]+)\s*=\s*[0-9a-z]')
+    unknown = {}
+    for f in files:
+        text = open(f).read()
+        if f.endswith(('.hip', '.h')):
+            assert 'getenv' not in text, f'{f}: the library takes its options through s2ag_set_option, never from the environment'
+        for m in list(read.finditer(text)) + list(advertised.finditer(text)):
+            if m.group(1) not in config.REGISTRY:
+                unknown.setdefault(m.group(1), []).append(os.path.relpath(f, ROOT))
+    assert not unknown, unknown
+    # every switch that selects code names the test that arms it, and that test exists
+    for sw in config.REGISTRY.values():
+        if sw.test is None:
+            continue
+        path, _, fn = sw.test.partition('::')
+        assert os.path.exists(os.path.join(ROOT, path)), sw
+        if fn:
+            assert ('def ' + fn + '(') in open(os.path.join(ROOT, path)).read(), sw
+    # the library's option table and the registry agree; override() reaches the library and restores
+    lib = __import__('speech2affective_gestures_amd._lib', fromlist=['load']).load()
+    for sw in config.REGISTRY.values():
+        if sw.clib:
+            assert lib.s2ag_get_option(sw.name.encode()) == int(config.get(sw.name)), sw.name
+    assert lib.s2ag_get_option(b'NO_SUCH_OPTION') < 0 and lib.s2ag_set_option(b'NO_SUCH_OPTION', 1) < 0
+    before = lib.s2ag_get_option(b'TCN_RING_DEEP')
+    with config.override('TCN_RING_DEEP', not before):
+        assert lib.s2ag_get_option(b'TCN_RING_DEEP') == int(not before)
+    assert lib.s2ag_get_option(b'TCN_RING_DEEP') == before
