@@ -20,6 +20,18 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get('S2AG_EMU', '0') != '1':
+        return
+    keep, gone = [], []
+    for it in items:
+        why = _emu_harness.deselected(it.nodeid)
+        (gone if why else keep).append(it)
+    if gone:
+        config.hook.pytest_deselected(items=gone)
+        items[:] = keep
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
