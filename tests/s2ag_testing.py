@@ -128,9 +128,9 @@ class SignTap:
     BatchNorm + activation pairs, the residual add + LeakyReLU of the ST-GCN blocks, the LeakyReLU Linears and the
     clip-resident TemporalConvNet (h1, h2, y of every block)."""
 
-    def __init__(self, module):
+    def __init__(self, module, tcn_prefix='text_encoder.'):
         from speech2affective_gestures_amd import ops
-        self.ops, self.module = ops, module
+        self.ops, self.module, self.tcn_prefix = ops, module, tcn_prefix
         self.names = {id(m): n for n, m in module.named_modules()}
         self.params = {id(p): n for n, p in module.named_parameters()}
         self.bn, self.adds, self.lin, self.tcn, self.heads, self.encs = [], [], [], [], [], []
@@ -225,7 +225,7 @@ class SignTap:
             x2, saved, y_last = t_out.grad_fn.saved_tensors
             B, T, Cch = t_out.shape
             nb = (saved.shape[0] + 1) // 3
-            prefix = 'text_encoder.'
+            prefix = self.tcn_prefix
             for b in range(nb):
                 tens = [saved[3 * b], saved[3 * b + 1], saved[3 * b + 2] if b < nb - 1 else y_last[:B * T]]
                 for j, t in enumerate(tens):

@@ -214,14 +214,18 @@ def test_encoders_in_bf16_mode_track_their_fp32_mode(B):
     assert rel(a1, a0) < 2e-2 and rel(t1, t0) < 2e-2
     assert rel(rv1, rv0) < 5e-3
     dead = ('wav.feat_extractor.0.bias', 'wav.feat_extractor.3.bias', 'wav.feat_extractor.6.bias')   # BatchNorm cancels them
-    # BatchNorm gamma / beta gradients of the wave encoder are sums of up to 2 M bf16-rounded terms that cancel almost
-    # completely (the next BatchNorm removes the mean of what flows back): the 2^-9 storage rounding of the terms is of
-    # the order of the sum itself -- inherent to bf16 gradient storage, not to a kernel (their fp32 twins agree to 1e-6)
+    # r02 allowed 0.6 for the wave encoder's BatchNorm gamma / beta gradients (sums of up to 2 M bf16-ROUNDED terms that cancel
+    # almost completely).  Since r03 the fused kernels form those sums from the fp32 accumulators before any bf16 rounding
+    # (csrc/wave_fused.hip, csrc/wave12.hip): 0.15 for every tensor but ONE -- BatchNorm 1's beta.  Its gradient is the plain sum
+    # of du1 over all 2 M (clip, frame) positions per channel, behind the LeakyReLU whose 1.7 M inputs per channel are formed
+    # from a bf16-rounded z1 in this mode: the ~0.4 % of them that the rounding moves across the kink each shift the sum by
+    # 0.7 of one element's gradient, and the sum itself nearly cancels (BatchNorm 2 removes the mean of what flows back).
+    # Measured 0.22 (B = 3) / 0.39 (B = 40): a property of bf16 storage of z1, not of a kernel -- gamma's gradient (weighted
+    # by xhat, no cancellation) stays below 0.08.
     for k in g0:
         if k in dead:
             continue
-        tol = 0.6 if k in ('wav.feat_extractor.1.weight', 'wav.feat_extractor.1.bias', 'wav.feat_extractor.4.weight',
-                           'wav.feat_extractor.4.bias', 'wav.feat_extractor.7.weight', 'wav.feat_extractor.7.bias') else 0.15
+        tol = 0.5 if k == 'wav.feat_extractor.1.bias' else 0.15
         assert l2(g1[k], g0[k]) < tol, (k, l2(g1[k], g0[k]))
 
 

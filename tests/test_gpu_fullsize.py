@@ -248,6 +248,63 @@ def test_full_size_step_matches_the_oracle(monkeypatch, config):
     assert ops.coop_gru_timeouts() == 0
 
 
+@pytest.mark.parametrize('B', [4, 256])
+def test_conv1d_roofline_run_gradients_match_the_oracle_strictly(B):
+    """BASELINE configs[3] at its own size (B = 256; B = 4 is what the CPU device model of tests/emu can run): WavEncoder +
+    TextEncoderTCN forward + backward, train mode, dropout on, against the oracle fed the product's masks AND the product's
+    branch decisions (SignTap / oracle.use_signs: the three BatchNorm + LeakyReLU pairs of the wave encoder -- the first
+    recomputed by s2ag_wave12_act_signs --, the twelve ReLU sites of the TCN): outputs 3e-4, EVERY parameter gradient within
+    1e-3 of its largest element.  (r03 accepted 5 % per tensor here; fp32 mode -- bf16 mode has its own tests.)"""
+    from oracle import s2ag_oracle as O
+    from s2ag_testing import SignTap, grad_err
+    from speech2affective_gestures_amd import noise, ops
+    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import TextEncoderTCN, WavEncoder
+    T = 34
+    cfg = bench.make_cfg()
+    oc = O.ModelCfg()
+    n_words = bench.N_WORDS if B > 16 else 500
+    sd = O.recipe_state_dict({**O._wav_encoder_shapes('wav.'),
+                              **O._text_encoder_shapes('txt.', n_words, 300, oc.hidden_size, oc.n_layers)}, 11)
+    both = torch.nn.ModuleDict(dict(wav=WavEncoder(), txt=TextEncoderTCN(cfg, n_words, 300, dropout=cfg.dropout_prob))).cuda().train()
+    wav, txt = both['wav'], both['txt']
+    wav.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith('wav.')}, strict=True)
+    txt.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith('txt.')}, strict=True)
+    inp = O.recipe_inputs(B, T, 5, n_words, bench.N_SPK)
+    noise.manual_seed(31)
+    nz = torch.tensor([31, 0], dtype=torch.int64, device='cuda')
+    with noise.noise_pass('cuda'), SignTap(both, tcn_prefix='txt.') as tap:
+        yw = wav(inp['in_audio'].cuda())
+        yt = txt(inp['in_text'].cuda())[0]
+    signs = tap.signs()
+    pin = {'txt.emb_drop': ops.dropout_mask(nz, txt.site, txt.drop.p, (B, T, 300)).cpu()}
+    for i, blk in enumerate(txt.tcn.network):
+        for j in (0, 1):
+            pin[f'txt.tcn.{i}.drop{j + 1}'] = ops.dropout_mask(nz, blk.sites[j], blk.p, (B, T, 300)).cpu().transpose(1, 2)
+    leaf = {k: (v.detach().clone().requires_grad_(True) if O.is_param(k) and '.net.' not in k else v.clone())
+            for k, v in sd.items()}
+    for k in list(leaf):
+        if '.net.0.' in k or '.net.4.' in k:
+            leaf[k] = leaf[k.replace('.net.0.', '.conv1.').replace('.net.4.', '.conv2.')]
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    with O.use_signs(signs) as used:
+        rw = O.wav_encoder(leaf, 'wav.', inp['in_audio'], True)
+        rt = O.text_encoder_tcn(leaf, 'txt.', inp['in_text'], True, oc.dropout_prob, O.Noise(pin))
+    assert set(used.used) == set(signs) and len(signs) == 3 + 12, (sorted(signs), sorted(used.used))
+    assert rel(yw.cpu(), rw) < 3e-4 and rel(yt.cpu(), rt) < 3e-4
+    g = torch.Generator().manual_seed(2)
+    dw, dt = torch.randn(rw.shape, generator=g), torch.randn(rt.shape, generator=g)
+    ((rw * dw).sum() + (rt * dt).sum()).backward()
+    ((yw * dw.cuda()).sum() + (yt * dt.cuda()).sum()).backward()
+    dead = ('feat_extractor.0.bias', 'feat_extractor.3.bias', 'feat_extractor.6.bias')      # a BatchNorm cancels them: true gradient 0
+    named = [('wav.' + k, p) for k, p in wav.named_parameters() if k not in dead] + \
+        [('txt.' + k, p) for k, p in txt.named_parameters() if '.net.' not in k]
+    errs = {k: grad_err(p.grad, leaf[k].grad, k) for k, p in named}
+    print(f'[configs[3] strict, B={B}] out wav {rel(yw.cpu(), rw):.1e} txt {rel(yt.cpu(), rt):.1e}; worst gradients (max-norm): ' +
+          ', '.join(f'{k} {e:.1e}' for k, e in sorted(errs.items(), key=lambda kv: -kv[1])[:4]))
+    for k, e in errs.items():
+        assert e < 1e-3, (k, e)
+
+
 def test_conv1d_roofline_run_gradients_match_the_oracle_at_batch_256():
     """BASELINE configs[3] at its own size (B = 256): WavEncoder + TextEncoderTCN forward + backward, train mode, dropout
     on, against the oracle fed the product's masks -- outputs strictly, every parameter gradient (kink-tolerant criteria,

@@ -287,6 +287,49 @@ def test_discriminators_train_mode_with_dropout_gradients():
             assert grad_err(p.grad, sd[k].grad, k) < 5 * TOL, (key, k)
 
 
+@pytest.mark.parametrize('B', [5, 128])
+def test_discriminators_strictly_with_the_products_branch_decisions(B):
+    """Both discriminators at the bench's batch (B = 128; B = 5 is the size the CPU device model of tests/emu runs): output,
+    the gradient w.r.t. the poses and EVERY parameter gradient within 1e-3 of the largest element of the oracle's, dropout
+    on.  AffDiscriminator's encoder has ReLU / LeakyReLU kinks (ST-GCN blocks, batch_norm3 / 4): the oracle replays the
+    branch the product took at every site (SignTap / oracle.use_signs, as for the generators above), so both sides
+    differentiate the same piecewise-linear function and no statistical criterion is needed.  ConvDiscriminator's two
+    ``LeakyReLU(True)`` are identities (net/multimodal_context_net_v2.py:399,402): nothing to replay there."""
+    from speech2affective_gestures_amd import noise, ops
+    from s2ag_testing import SignTap
+    s0 = 6100
+    _, mods, sds = build_product(32, 64, 12, 0.3, s0, which=('D', 'CD'))
+    inp = O.recipe_inputs(B, 34, s0 + 10, 64, 12)
+    gen = torch.Generator().manual_seed(3)
+    for key, fn in (('D', O.aff_discriminator), ('CD', O.conv_discriminator)):
+        D = mods[key].train()
+        noise.manual_seed(5)
+        nz = torch.tensor([5, 0], dtype=torch.int64, device='cuda')
+        poses = inp['target'].cuda().requires_grad_(True)
+        with SignTap(D) as tap:
+            y = D(poses)
+        signs = tap.signs()
+        Tq = 34 if key == 'D' else 28
+        pin = {f'gru.drop{l}': ops.dropout_mask(nz, D.gru.site0 + l, 0.3, (B, Tq, 128)).cpu() for l in range(3)}
+        sd = {k: (v.clone().requires_grad_(True) if O.is_param(k) else v.clone()) for k, v in sds[key].items()}
+        pr = inp['target'].clone().requires_grad_(True)
+        with O.use_signs(signs) as used:
+            yr = fn(sd, pr, True, O.Noise(pin))
+        assert set(used.used) == set(signs), set(signs) ^ set(used.used)
+        assert len(signs) == (6 if key == 'D' else 0), sorted(signs)
+        assert rel(y, yr) < TOL
+        dy = torch.randn(yr.shape, generator=gen)
+        (yr * dy).sum().backward()
+        (y * dy.cuda()).sum().backward()
+        errs = {k: grad_err(p.grad, sd[k].grad, k) for k, p in D.named_parameters()}
+        errs['d poses'] = rel(poses.grad, pr.grad)
+        top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+        print(f'[strict discriminator parity {key} B={B}] out {rel(y, yr):.2e}; worst gradients (max-norm): ' +
+              ', '.join(f'{k} {v:.2e}' for k, v in top))
+        for k, e in errs.items():
+            assert e < 1e-3, (key, k, e)
+
+
 def test_long_clip_136_frames_matches_oracle():
     """BASELINE config 5 shape: T = 136, audio 146000 samples, mfcc_length 284; out2 sized from n_poses."""
     from speech2affective_gestures_amd import noise

@@ -38,6 +38,30 @@ def main():
     bmap = {canon(k): k for k in b}
     bmap.update({k: k for k in b})
     rc = 0
+    brief = '--brief' in sys.argv
+
+    def base(name):                 # mangled name up to the template argument list
+        m = re.match(r'(_ZN?[\w]*?_k)(?:I|E)', name)
+        return m.group(1) if m else name
+    renamed = {}                    # old name -> new name: the template gained (defaulted) parameters, the mangled name changed
+    for k, (ops, res) in a.items():
+        if k in bmap:
+            continue
+        cands = [kb for kb in b if kb not in a and base(kb) == base(k)]
+        exact = [kb for kb in cands if b[kb][0] == ops and b[kb][1] == res]
+        pick = exact[0] if exact else None
+        if pick is None:            # same leading template arguments, closest instruction count
+            lead = re.sub(r'E+v.*$', '', k)
+            pref = [kb for kb in cands if kb.startswith(lead)]
+            if not pref:            # a parameter changed its type (bool -> int): same first argument
+                first = re.match(r'.*?_kI(L\w\d+E)', k)
+                pref = [kb for kb in cands if first and re.match(r'.*?_kI' + re.escape(first.group(1)), kb)] or \
+                    ([] if first else cands)
+            if pref:
+                pick = min(pref, key=lambda kb: abs(sum(b[kb][0].values()) - sum(ops.values())))
+        if pick is not None:
+            renamed[k] = pick
+            bmap[k] = pick
     for k, (ops, res) in a.items():
         kb = bmap.get(k)
         if kb is None:
@@ -47,14 +71,18 @@ def main():
         ops2, res2 = b[kb]
         diff = {o: (ops[o], ops2[o]) for o in set(ops) | set(ops2) if ops[o] != ops2[o]}
         same = not diff and res == res2
-        print(('same   ' if same else 'DIFFERS'), k[:90], sum(ops.values()), '->', sum(ops2.values()))
+        print(('same   ' if same else 'DIFFERS'), k[:90], sum(ops.values()), '->', sum(ops2.values()),
+              ('(now ' + kb[:90] + ')') if k in renamed else '')
         if not same:
             rc = 1
             print('   resources', res, '->', res2)
-            for o, (x, y) in sorted(diff.items()):
+            mem = {o: v for o, v in diff.items() if o.startswith(('v_mfma', 'ds_', 'global_', 'buffer_', 'scratch_', 's_barrier'))}
+            for o, (x, y) in sorted((mem if brief else diff).items()):
                 print(f'   {o}: {x} -> {y}')
+            if brief:
+                print(f'   ({len(diff) - len(mem)} other opcodes differ in count: scalar / vector ALU, waits)')
     for k in b:
-        if k not in a and canon(k) not in a:
+        if k not in a and canon(k) not in a and k not in renamed.values():
             print('new    ', k[:100], sum(b[k][0].values()), b[k][1])
     return rc
 

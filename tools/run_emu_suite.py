@@ -40,31 +40,33 @@ def main():
     total = dict(passed=0, failed=0, slow=0, skipped=0)
     for f in files:
         rel = os.path.relpath(f, ROOT)
-        slow, deselect = [], []
+        verdicts, slow, deselect, secs_all = {}, [], [], 0.0
         while True:
             rc, log, secs = run_file(rel, budget, sched, deselect)
-            m = re.search(r'=+ (.*) in [0-9.]+s', log)
-            if m and '+++ Timeout +++' not in log:
-                summary = m.group(1)
+            secs_all += secs
+            seen = re.findall(r'^(tests/\S+::\S+)(?: (PASSED|FAILED|SKIPPED|ERROR|XFAIL))?', log, flags=re.M)
+            for n, v in seen:
+                if v:
+                    verdicts[n] = v
+            done = re.search(r'=+ .* in [0-9.]+s', log) and '+++ Timeout +++' not in log
+            if done:
                 break
-            # the process died inside a test: the last test announced without a verdict is the culprit
-            started = re.findall(r'^(tests/\S+::\S+)(?: (PASSED|FAILED|SKIPPED|ERROR))?', log, flags=re.M)
-            culprit = next((n for n, v in reversed(started) if not v), None)
-            if culprit is None or culprit in deselect:
-                summary = 'driver could not attribute a dead process; log tail: ' + log[-300:].replace('\n', ' | ')
+            # the process died inside a test (a C call cannot be interrupted): the last test announced without a verdict
+            culprit = next((n for n, v in reversed(seen) if not v and n not in verdicts), None)
+            if culprit is None:
+                verdicts['<driver>'] = 'could not attribute a dead process: ' + log[-200:].replace('\n', ' | ')
                 break
             slow.append(culprit)
-            deselect.append(culprit)
-        failed = re.findall(r'^(tests/\S+::\S+) FAILED', log, flags=re.M)
-        n = lambda w: int((re.search(r'(\d+) ' + w, summary) or [0, 0])[1])
-        total['passed'] += n('passed'); total['failed'] += n('failed'); total['skipped'] += n('skipped') + n('deselected')
+            deselect = list(verdicts) + slow                      # the re-run starts behind what has a verdict already
+        cnt = {k: sum(1 for v in verdicts.values() if v == k) for k in ('PASSED', 'FAILED', 'SKIPPED', 'ERROR')}
+        total['passed'] += cnt['PASSED']; total['failed'] += cnt['FAILED'] + cnt['ERROR']; total['skipped'] += cnt['SKIPPED']
         total['slow'] += len(slow)
-        out.append(f'{rel}: {summary}  ({secs:.0f} s, schedule {sched})')
-        out += [f'    FAILED {t}' for t in failed]
-        out += [f'    too slow for the model (> {budget} s): {t}' for t in slow]
-        print(out[-1 - len(failed) - len(slow)], flush=True)
-        for l in out[len(out) - len(failed) - len(slow):]:
-            print(l, flush=True)
+        lines = [f'{rel}: {cnt["PASSED"]} passed, {cnt["FAILED"] + cnt["ERROR"]} failed, {cnt["SKIPPED"]} skipped, {len(slow)} too slow '
+                 f'for the model  ({secs_all:.0f} s, schedule {sched})']
+        lines += [f'    {v} {t}' for t, v in verdicts.items() if v not in ('PASSED', 'SKIPPED')]
+        lines += [f'    too slow for the model (> {budget} s): {t}' for t in slow]
+        out += lines
+        print('\n'.join(lines), flush=True)
     out.append(f'TOTAL: {total}')
     print(out[-1])
     return out
