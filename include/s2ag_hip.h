@@ -51,6 +51,13 @@ int s2ag_abi_version(void);
  * set: returns the previous value, S2AG_E_BADARG for an unknown name / negative value.  get: the value or S2AG_E_BADARG. */
 int s2ag_set_option(const char* name, int value);
 int s2ag_get_option(const char* name);
+/* Deterministic mode (debug): `zero_device_word` = one int32 device word holding 0 (null switches the mode off).  While set,
+ * every workgroup of an accumulating launch (weight / bias gradients, embedding gradient, BatchNorm sums, derived-parameter
+ * flush: the fp32 atomicAdd sites behind loss.backward() at processor_v2.py:841,937) performs its atomics in the order of its
+ * linear workgroup index, and in-workgroup LDS accumulation goes wavefront by wavefront -- two runs of a step on ONE stream
+ * give bit-identical gradients and weights.  The caller serialises the passes of a step (Processor(deterministic=True) /
+ * S2AG_DETERMINISTIC=1 does).  fp32 mode; the bf16-mode kernels of conv_bf16.hip are not covered. */
+int s2ag_set_deterministic(int* zero_device_word);
 
 /* 1-D convolution geometry, channels-last.  Input rows (n*Lin + pos), output rows (n*Lout + l),
  * pos = l*stride + tap*dil - pad (pad may be negative).  A Linear layer is ksize=1, Lin=Lout=1, N=rows. */

@@ -805,7 +805,8 @@ class StepNoise:
 
 def gan_step(G: SD, D: SD, PGT: SD, g_opt: AdamState, d_opt: AdamState, mcfg: ModelCfg, scfg: StepCfg,
              in_text, in_audio, in_mfcc, target, vid, epoch: int, noise: StepNoise, train: bool = True,
-             fast: bool = False, d_drop_noise_off: bool = False, ablation: str = 'none'):
+             fast: bool = False, d_drop_noise_off: bool = False, ablation: str = 'none',
+             signs: Optional[Dict[str, Dict[str, Tensor]]] = None):
     """Processor.forward_pass_s2ag (processor_v2.py:776-957), train branch, use_mfcc = True.
 
     G and D run in train mode (per_train_epoch :961-962); the frozen tri-modal baseline PGT is never
@@ -822,6 +823,22 @@ def gan_step(G: SD, D: SD, PGT: SD, g_opt: AdamState, d_opt: AdamState, mcfg: Mo
         in_mfcc = in_audio
     else:
         pose_generator, aff_discriminator = globals()['pose_generator'], globals()['aff_discriminator']
+    # ``signs``: {pass name: {site: bool tensor}} -- branch decisions to replay per module pass (use_signs above; the parity
+    # tests record them from the product's own step, tests/s2ag_testing.py StepSignTap); ``signs_used`` lists what was consumed
+    sg = signs or {}
+    used: Dict[str, List[str]] = {}
+
+    class _P:                              # use_signs scope of one pass that also remembers which sites were consumed
+        def __init__(self, name):
+            self.name, self.ctx = name, use_signs(sg.get(name))
+
+        def __enter__(self):
+            return self.ctx.__enter__()
+
+        def __exit__(self, *a):
+            used[self.name] = list(self.ctx.used)
+            return self.ctx.__exit__(*a)
+    gan_step.signs_used = used
     pre_seq = make_pre_seq(target, scfg.n_pre_poses)
     use_gan = epoch > scfg.loss_warmup and scfg.loss_gan_weight > 0.0
     losses: Dict[str, float] = {}
@@ -830,10 +847,12 @@ def gan_step(G: SD, D: SD, PGT: SD, g_opt: AdamState, d_opt: AdamState, mcfg: Mo
 
     if use_gan:
         Gl, Dl = _leaf(G, gk), _leaf(D, dk)
-        with torch.no_grad():
+        with torch.no_grad(), _P('g_dis'):
             fake, *_ = pose_generator(Gl, mcfg, pre_seq, in_text, in_mfcc, vid, train, noise.g_dis, fast)
-        d_real = aff_discriminator(Dl, target, train, noise.d_real, fast)
-        d_fake = aff_discriminator(Dl, fake.detach(), train, noise.d_fake, fast)
+        with _P('d_real'):
+            d_real = aff_discriminator(Dl, target, train, noise.d_real, fast)
+        with _P('d_fake'):
+            d_fake = aff_discriminator(Dl, fake.detach(), train, noise.d_fake, fast)
         d_err = dis_loss(d_real, d_fake)
         losses['dis'] = float(d_err.detach())
         if train:
@@ -842,12 +861,14 @@ def gan_step(G: SD, D: SD, PGT: SD, g_opt: AdamState, d_opt: AdamState, mcfg: Mo
             adam_update(D, grads_out['D'], d_opt, scfg.lr_dis, scfg.betas, scfg.adam_eps)
 
     Gl, Dl = _leaf(G, gk), _leaf(D, dk)
-    with torch.no_grad():
+    with torch.no_grad(), _P('pgt'):
         out_tri, *_ = pose_generator_trimodal(PGT, mcfg, pre_seq, in_text, in_audio, vid, True, noise.pgt, fast)
-    out, z, mu, log_var = pose_generator(Gl, mcfg, pre_seq, in_text, in_mfcc, vid, train, noise.g_main, fast)
-    d_out = aff_discriminator(Dl, out, train, noise.d_gen, fast)
+    with _P('g_main'):
+        out, z, mu, log_var = pose_generator(Gl, mcfg, pre_seq, in_text, in_mfcc, vid, train, noise.g_main, fast)
+    with _P('d_gen'):
+        d_out = aff_discriminator(Dl, out, train, noise.d_gen, fast)
     perm = noise.perm if noise.perm is not None else torch.randperm(vid.shape[0])
-    with torch.no_grad():
+    with torch.no_grad(), _P('g_rand'):
         out_rand, z_rand, _, _ = pose_generator(Gl, mcfg, pre_seq, in_text, in_mfcc, vid[perm], train,
                                                 noise.g_rand, fast)
     loss, comp = gen_losses(scfg, out, target, d_out, out_rand, z, z_rand, mu, log_var,

@@ -641,6 +641,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradP p) {
             if (rowlive[1] && collive[1]) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
+    s2ag::det_enter();                                // deterministic mode: the z-slices of a tile add in index order
     if (want_db) {                                    // block-uniform: the four row groups of a column meet in LDS
         __syncthreads();
         As[mq][cidx] = bsum;
@@ -662,6 +663,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradP p) {
                                         : ((long long)row * p.Cin + c2) * p.ks + t2), acc[ti][tj][q]);
             }
         }
+    s2ag::det_leave();
 }
 
 // ---- weight gradient, second generation --------------------------------------------------------------------
@@ -747,7 +749,11 @@ __global__ __launch_bounds__(512) void conv_wgrad2_k(WgradP p) {
         }
     };
     const int nkt = (mend - mbeg + BK2 - 1) / BK2;
-    if (nkt <= 0) return;
+    if (nkt <= 0) {
+        s2ag::det_enter();                            // an empty slice still takes (and passes on) its turn
+        s2ag::det_leave();
+        return;
+    }
     fetch(ra0, rb0, mbeg);
     stash(ra0, rb0, 0);
     if (nkt > 1) fetch(ra0, rb0, mbeg + BK2);
@@ -778,6 +784,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_k(WgradP p) {
                             acc[ti][tj][q];
         }
         __syncthreads();
+        s2ag::det_enter();                            // (all eight waves: the second wave group leaves right below)
         if (want_db && mq == 0 && covalid) {          // wave 0 (kg = 0): eight row groups per column
             float t = 0.f;
 #pragma unroll
@@ -809,6 +816,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_k(WgradP p) {
                                         : ((long long)row * p.Cin + c2) * p.ks + t2), acc[ti][tj][q]);
             }
         }
+    s2ag::det_leave();
 }
 
 // ---- column sums (bias gradients, BatchNorm batch statistics) ---------------------------------------
@@ -829,11 +837,13 @@ __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ x, int
     s1[ry][threadIdx.x & 63] = a;
     s2[ry][threadIdx.x & 63] = b;
     __syncthreads();
+    s2ag::det_enter();
     if (ry == 0 && c < cols) {
         const int i = threadIdx.x;
         atomicAdd(out + c, s1[0][i] + s1[1][i] + s1[2][i] + s1[3][i]);
         if (sq) atomicAdd(sq + c, s2[0][i] + s2[1][i] + s2[2][i] + s2[3][i]);
     }
+    s2ag::det_leave();
 }
 
 __global__ __launch_bounds__(256) void colstats_f64_k(const float* __restrict__ x, int rows, int cols, int ld,
@@ -853,11 +863,13 @@ __global__ __launch_bounds__(256) void colstats_f64_k(const float* __restrict__ 
     s1[ry][threadIdx.x & 63] = a;
     s2[ry][threadIdx.x & 63] = b;
     __syncthreads();
+    s2ag::det_enter();
     if (ry == 0 && c < cols) {
         const int i = threadIdx.x;
         atomicAdd(out + c, s1[0][i] + s1[1][i] + s1[2][i] + s1[3][i]);
         atomicAdd(sq + c, s2[0][i] + s2[1][i] + s2[2][i] + s2[3][i]);
     }
+    s2ag::det_leave();
 }
 
 // ---- lane-dense reductions for narrow contiguous matrices (cols in {1,2,4,...,32}, ld == cols) ----------------------
@@ -885,8 +897,10 @@ __global__ __launch_bounds__(256) void colsum_flat_k(const float* __restrict__ x
         a += v;
         b += v * v;
     }
+    s2ag::det_enter();
     block_col_merge(a, cols, sm, out);
     if (sq) block_col_merge(b, cols, sm, sq);
+    s2ag::det_leave();
 }
 
 __global__ __launch_bounds__(256) void colstats_flat_k(const float* __restrict__ x, long long total, int cols,
@@ -898,8 +912,10 @@ __global__ __launch_bounds__(256) void colstats_flat_k(const float* __restrict__
         a += v;
         b += v * v;
     }
+    s2ag::det_enter();
     block_col_merge(a, cols, sm, out);
     block_col_merge(b, cols, sm, sq);
+    s2ag::det_leave();
 }
 
 inline bool narrow_ok(int cols, int ld) { return ld == cols && cols <= 32 && (cols & (cols - 1)) == 0; }
@@ -1241,3 +1257,4 @@ extern "C" int s2ag_gemm_trace_read(unsigned long long* host8, int reset) {
     return (int)e;
 }
 #endif
+S2AG_DET_HOOK(conv_gemm)

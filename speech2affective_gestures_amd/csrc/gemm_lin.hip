@@ -482,7 +482,11 @@ __device__ __forceinline__ void wgrad_lin_body(const WgP& p, float* smem, const 
         }
     };
     const int nkt = (mend - mbeg + LBK - 1) / LBK;
-    if (nkt <= 0) return;
+    if (nkt <= 0) {
+        s2ag::det_enter();                            // deterministic mode: an empty slice still takes and passes on its turn
+        s2ag::det_leave();
+        return;
+    }
     fetch(ra0, rb0, mbeg);
     stash(ra0, rb0, 0);
     if (nkt > 1) fetch(ra0, rb0, mbeg + LBK);
@@ -511,6 +515,7 @@ __device__ __forceinline__ void wgrad_lin_body(const WgP& p, float* smem, const 
                         redw[(wm * 32 + ti * 16 + (lane >> 4) * 4 + q) * 64 + wn * 32 + tj * 16 + li] = acc[ti][tj][q];
         }
         __syncthreads();
+        s2ag::det_enter();                            // deterministic mode: workgroups add in index order (all eight waves here)
         if (want_db && mq == 0 && co < p.Cout) {      // wave 0 (kg = 0): eight row groups per column
             float t = 0.f;
 #pragma unroll
@@ -541,6 +546,7 @@ __device__ __forceinline__ void wgrad_lin_body(const WgP& p, float* smem, const 
                                         : ((long long)row * p.Cin + c2) * p.ks + t2), acc[ti][tj][q]);
             }
         }
+    s2ag::det_leave();
 }
 
 template <bool SHIFT>
@@ -563,6 +569,8 @@ __global__ __launch_bounds__(512) void bwd_pair_k(LinP p1, WgP p2, int n2, int g
     } else {
         const int b1 = b - n2;
         gemm_lin_body<true, BM_, CONV>(p1, smem, b1 % g1x, b1 / g1x, g1x);
+        s2ag::det_enter();                            // the data-gradient tiles accumulate nothing: they only pass the turn on
+        s2ag::det_leave();
     }
 }
 
@@ -684,3 +692,4 @@ int s2ag_wgrad_multi(const s2ag_wg_job_i* jb, int n, hipStream_t stream) {
     hipLaunchKernelGGL(wgrad_multi_k, dim3(total), dim3(512), 0, stream, J);
     return 1;
 }
+S2AG_DET_HOOK(gemm_lin)

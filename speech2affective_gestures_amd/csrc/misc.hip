@@ -90,6 +90,9 @@ __global__ __launch_bounds__(256) void embedding_bwd_k(const long long* ids, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.y * EMB_CB + lane;
     float pad_acc = 0.f;
+    // deterministic mode: workgroups in index order, and inside a workgroup wave by wave (two waves may hold the same word)
+    s2ag::det_enter();
+    s2ag::det_wave_ordered([&] {
     if (c < dim) {
         const int i0 = wave * (EMB_RB / 4), i1 = min(nr, i0 + EMB_RB / 4);
         // 16 rows are LOADED before any of them is added: a load behind an atomic to memory it may alias waits for it, and
@@ -110,12 +113,14 @@ __global__ __launch_bounds__(256) void embedding_bwd_k(const long long* ids, con
             }
         }
     }
+    });
     pad_s[wave][lane] = pad_acc;
     __syncthreads();
     if (wave == 0 && c < dim) {
         const float t = (pad_s[0][lane] + pad_s[1][lane]) + (pad_s[2][lane] + pad_s[3][lane]);
         if (t != 0.f) atomicAdd(dtable + c, t);
     }
+    s2ag::det_leave();
 }
 
 // ---- weight norm: one wave per output row ------------------------------------------------------------
@@ -224,11 +229,14 @@ __global__ __launch_bounds__(256) void spmv_multi_flush_k(SpmvJobs js) {
     const int k = find_job(js.first_block, js.n);
     const s2ag_spmv_job& J = js.j[k];
     const int i = ((int)blockIdx.x - js.first_block[k]) * 256 + threadIdx.x;
-    if (i >= J.nrows) return;
-    const float g = J.y[i];
-    if (g == 0.f) return;
-    J.y[i] = 0.f;
-    for (int q = J.rowptr[i]; q < J.rowptr[i + 1]; ++q) atomicAdd(J.x + J.col[q], J.val[q] * g);
+    const float g = i < J.nrows ? J.y[i] : 0.f;
+    if (g != 0.f) J.y[i] = 0.f;
+    s2ag::det_enter();                 // deterministic mode: rows share sources -- workgroups in index order, waves in order
+    s2ag::det_wave_ordered([&] {
+        if (g != 0.f)
+            for (int q = J.rowptr[i]; q < J.rowptr[i + 1]; ++q) atomicAdd(J.x + J.col[q], J.val[q] * g);
+    });
+    s2ag::det_leave();
 }
 
 struct WnJobs {
@@ -893,7 +901,9 @@ __global__ __launch_bounds__(256) void pose_metrics_k(const float* __restrict__ 
             for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + h];
         __syncthreads();
     }
+    s2ag::det_enter();
     if (threadIdx.x < 3) atomicAdd(&sums[threadIdx.x], red[threadIdx.x][0]);
+    s2ag::det_leave();
 }
 
 extern "C" int s2ag_pose_metrics(const float* out, const float* target, const double* mean_dir_vec, int B, int T,
@@ -1008,4 +1018,19 @@ extern "C" int s2ag_set_option(const char* name, int value) {
 extern "C" int s2ag_get_option(const char* name) {
     const int i = s2ag::option_index(name);
     return i < 0 ? S2AG_E_BADARG : s2ag::g_options[i];
+}
+
+// ---- deterministic mode (s2ag_common.h: det_enter / det_leave / det_wave_ordered) ------------------------------------------
+S2AG_DET_HOOK(misc)
+extern "C" int s2ag_det_hook_conv_gemm(int*);
+extern "C" int s2ag_det_hook_gemm_lin(int*);
+extern "C" int s2ag_det_hook_norm_elementwise(int*);
+extern "C" int s2ag_det_hook_wgrad_tr(int*);
+extern "C" int s2ag_set_deterministic(int* zero_device_word) {
+    int rc = s2ag_det_hook_misc(zero_device_word);
+    if (!rc) rc = s2ag_det_hook_conv_gemm(zero_device_word);
+    if (!rc) rc = s2ag_det_hook_gemm_lin(zero_device_word);
+    if (!rc) rc = s2ag_det_hook_norm_elementwise(zero_device_word);
+    if (!rc) rc = s2ag_det_hook_wgrad_tr(zero_device_word);
+    return rc;
 }

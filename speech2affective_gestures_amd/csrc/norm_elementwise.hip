@@ -124,6 +124,8 @@ __device__ __forceinline__ void fold_partials(const T* part, int nrb, int cols, 
                                               A* cn) {
     const int t = threadIdx.x;
     const int G = cols >= NT ? 1 : NT / cols;
+    // (deterministic mode: the LDS accumulators take their terms wavefront by wavefront; called by a whole workgroup)
+    s2ag::det_wave_ordered([&] {
     if (G == 1) {
         for (int c = t; c < cols; c += NT) {
             A a, b;
@@ -142,6 +144,7 @@ __device__ __forceinline__ void fold_partials(const T* part, int nrb, int cols, 
         atomicAdd(&c1[ch], b);
         if (sub == 0) atomicAdd(&cn[ch], (A)1);
     }
+    });
 }
 
 // Channel statistics (already summed into cs / cq / cn in LDS) -> running estimates and per-COLUMN coefficients.
@@ -202,12 +205,14 @@ __global__ __launch_bounds__(256) void bn_coeffs_k(const double* colsum, const d
     for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) smd[i] = 0.0;
     __syncthreads();
     if (training) {
-        for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
-            const int ch = chan_of_col ? chan_of_col[c] : c;
-            atomicAdd(&cs[ch], colsum[c]);
-            atomicAdd(&cq[ch], colsq[c]);
-            atomicAdd(&cn[ch], 1.0);
-        }
+        s2ag::det_wave_ordered([&] {
+            for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+                const int ch = chan_of_col ? chan_of_col[c] : c;
+                atomicAdd(&cs[ch], colsum[c]);
+                atomicAdd(&cq[ch], colsq[c]);
+                atomicAdd(&cn[ch], 1.0);
+            }
+        });
         __syncthreads();
     }
     bn_finish_coeffs(cs, cq, cn, chan_of_col, ncols, nchan, rows, gamma, beta, rmean, rvar, nbt, eps, momentum, training,
@@ -356,11 +361,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* __restrict__
     a1[ry][threadIdx.x & 63] = p;
     a2[ry][threadIdx.x & 63] = q;
     __syncthreads();
+    s2ag::det_enter();
     if (ry == 0 && c < cols) {
         const int i = threadIdx.x;
         atomicAdd(s1 + c, a1[0][i] + a1[1][i] + a1[2][i] + a1[3][i]);
         atomicAdd(s2 + c, a2[0][i] + a2[1][i] + a2[2][i] + a2[3][i]);
     }
+    s2ag::det_leave();
 }
 
 // lane-dense variant for narrow contiguous matrices (cols a power of two <= 32, ldx == lddy == cols)
@@ -379,6 +386,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_flat_k(const float* __restr
         p += d;
         q += d * (xv - mu) * is;
     }
+    s2ag::det_enter();
     for (int pass = 0; pass < 2; ++pass) {
         sm[threadIdx.x] = pass ? q : p;
         __syncthreads();
@@ -389,6 +397,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_flat_k(const float* __restr
         }
         __syncthreads();
     }
+    s2ag::det_leave();
 }
 
 __device__ __forceinline__ void bn_bwd_finish(const float* t1, const float* t2, const float* cn,
@@ -422,12 +431,14 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_k(const float* s1, const fl
     float* cn = sm + 2 * nchan;
     for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
-    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
-        const int ch = chan_of_col ? chan_of_col[c] : c;
-        atomicAdd(&t1[ch], s1[c]);
-        atomicAdd(&t2[ch], s2[c]);
-        atomicAdd(&cn[ch], 1.0f);
-    }
+    s2ag::det_wave_ordered([&] {
+        for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+            const int ch = chan_of_col ? chan_of_col[c] : c;
+            atomicAdd(&t1[ch], s1[c]);
+            atomicAdd(&t2[ch], s2[c]);
+            atomicAdd(&cn[ch], 1.0f);
+        }
+    });
     __syncthreads();
     bn_bwd_finish(t1, t2, cn, chan_of_col, ncols, nchan, rows, dgamma, dbeta, accumulate, c1, c2);
 }
@@ -483,6 +494,7 @@ __global__ __launch_bounds__(1024) void bn_fold_k(const double* part, int prow, 
         // rows 0, pstep, 2*pstep, ... of either half (left by bn_fold_pre_k)
         const int nsub = cols >= 1024 ? 1 : 1024 / cols;
         const int sub = cols >= 1024 ? 0 : (int)threadIdx.x / cols;
+        s2ag::det_wave_ordered([&] {
         for (int c = cols >= 1024 ? (int)threadIdx.x : (int)threadIdx.x % cols; c < cols && sub < nsub; c += 1024) {
             double a = 0.0, b = 0.0;
             for (int r = sub * pstep; r < prow; r += nsub * pstep) {
@@ -495,6 +507,7 @@ __global__ __launch_bounds__(1024) void bn_fold_k(const double* part, int prow, 
             if (sub == 0) atomicAdd(&cn[ch], 1.0);
             if (cols < 1024) break;
         }
+        });
     }
     __syncthreads();
     bn_finish_coeffs(cs, cq, cn, chan_of_col, cols, nchan, rows, gamma, beta, rmean, rvar, nbt, eps, momentum, 1,
@@ -959,3 +972,4 @@ extern "C" int s2ag_epilogue_bwd(const float* dy, int lddy, const float* y, int 
     S2AG_LAUNCH_CHECK();
     return 0;
 }
+S2AG_DET_HOOK(norm_elementwise)

@@ -100,6 +100,64 @@ static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---- deterministic mode (option DETERMINISTIC, s2ag_set_deterministic) ---------------------------------------------------
+// fp32 sums formed by atomics depend on the order in which workgroups (and, inside a workgroup, wavefronts) arrive: two runs
+// of the same step differ in the last bits, which is why tests compare runs with a tolerance and why a divergence between
+// data-parallel replicas cannot be bisected.  With the mode on (g_det_turn = a zero device word; the host also serialises
+// the passes of a step onto one stream) every workgroup passes its accumulation phase IN THE ORDER OF ITS LINEAR INDEX:
+// det_enter() waits until the turn word equals the index, det_leave() drains this workgroup's atomics and hands the turn on
+// (the last workgroup re-arms the word).  Progress: a workgroup only ever waits for workgroups with a smaller index, which
+// the dispatcher started earlier (placement-independent).  In-workgroup accumulation into LDS goes wavefront by wavefront
+// (det_wave_ordered).  Off (the default): one scalar load and a not-taken branch per workgroup.  Debug mode: the
+// accumulation phases of a launch run one after the other.
+static __device__ int* g_det_turn = nullptr;             // one copy per translation unit, installed by s2ag_det_hook_<file>
+
+__device__ __forceinline__ bool det_on() { return g_det_turn != nullptr; }
+
+__device__ __forceinline__ void det_enter() {            // workgroup-uniform call
+    int* w = g_det_turn;
+    if (!w) return;
+    if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+        const int me = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != me) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void det_leave() {            // by every thread of the workgroup that is still alive
+    int* w = g_det_turn;
+    if (!w) return;
+    __threadfence();                                     // this thread's atomics have been performed
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+        const int n = (int)(gridDim.x * gridDim.y * gridDim.z);
+        const int me = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        __hip_atomic_store(w, me + 1 == n ? 0 : me + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// f() accumulates into LDS with atomics from several wavefronts: deterministic mode runs it wavefront by wavefront
+template <typename F>
+__device__ __forceinline__ void det_wave_ordered(F&& f) {
+    if (!g_det_turn) {
+        f();
+        return;
+    }
+    const int nt = (int)(blockDim.x * blockDim.y * blockDim.z);
+    const int me = (int)((threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x) >> 6;
+    for (int w = 0; w < (nt + 63) / 64; ++w) {
+        if (w == me) f();
+        __syncthreads();
+    }
+}
+
+static inline int det_install_here(int* word) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_det_turn), &word, sizeof(word));
+}
+// every translation unit with accumulating kernels exports a hook that installs the turn word in ITS copy of g_det_turn
+#define S2AG_DET_HOOK(file) \
+    extern "C" int s2ag_det_hook_##file(int* word) { return s2ag::det_install_here(word); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -628,8 +628,8 @@ class PoseGenerator(nn.Module, _SpeakerZ):
         if len(passes) == 1:
             hs = (hs,)
         res = []
-        for k, (h, (_, z_context, z_mu, z_log_var), (_, _, grad)) in enumerate(zip(hs, feats, passes)):
-            with torch.set_grad_enabled(bool(grad) and outer):
+        for k, (h, (_, z_context, z_mu, z_log_var), (_, nz, grad)) in enumerate(zip(hs, feats, passes)):
+            with torch.set_grad_enabled(bool(grad) and outer), use_pass(nz):       # (each pass's tail in ITS noise scope)
                 h = ops.linear(h, self.out[0].weight, self.out[0].bias, act=ACT_LEAKY, slope=0.01)
                 out = ops.linear(h, self.out[2].weight, self.out[2].bias)
                 z_mu, z_log_var = self._cut_here(z_mu, z_log_var)

@@ -1920,6 +1920,32 @@ _WGRAD_STREAMS = {}
 _MAIN_STREAM = [None]
 
 
+_DET_WORDS = {}
+
+
+def set_deterministic(on: bool, device=None) -> None:
+    """Deterministic mode (config switch DETERMINISTIC; debug): the library orders every accumulating launch's atomics by
+    workgroup index (s2ag_set_deterministic: csrc/s2ag_common.h det_enter / det_leave / det_wave_ordered) and weight-gradient
+    kernels stay on the stream of their backward pass.  The trainer additionally runs the passes of a step on ONE stream
+    (Processor(..., deterministic=True)): two runs from the same state then give bit-identical gradients and weights, at
+    the price of serialised accumulation phases.  fp32 mode."""
+    global ASYNC_WGRAD
+    dev = torch.device('cuda' if device is None else device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if on:
+        if key not in _DET_WORDS:
+            _DET_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(_lib().s2ag_set_deterministic(_p(_DET_WORDS[key])), 'set_deterministic')
+        ASYNC_WGRAD = False
+    else:
+        L.check(_lib().s2ag_set_deterministic(None), 'set_deterministic')
+        ASYNC_WGRAD = True
+
+
+def deterministic() -> bool:
+    return not ASYNC_WGRAD and bool(_DET_WORDS)
+
+
 def set_main_stream(stream=None) -> None:
     """The trainer names the stream its step runs on; only from there are weight-gradient kernels forked (forking
     again from an already forked stream crashes hipGraph capture on ROCm 7.2)."""

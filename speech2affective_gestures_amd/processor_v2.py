@@ -222,6 +222,12 @@ class Processor(object):
         self.use_hip_graph = bool(getattr(args, 'hip_graph', True))
         # independent forward passes of a step run on forked streams (every kernel here fills only part of the chip)
         self.overlap_passes = bool(getattr(args, 'overlap_passes', True))
+        # deterministic mode (debug; config switch DETERMINISTIC): every pass of the step on ONE stream, accumulating launches
+        # ordered by workgroup index inside the library -- two runs from the same state are bit-identical (ops.set_deterministic)
+        self.deterministic = bool(getattr(args, 'deterministic', config.get('DETERMINISTIC')))
+        if self.deterministic:
+            self.overlap_passes = False
+            ops.set_deterministic(True, self.device)
         # the generator's dropout-free encoders run once per step instead of once per pass (see PoseGenerator)
         self.share_encoders = bool(getattr(args, 'share_encoders', True)) \
             and hasattr(self.s2ag_generator, '_shared_encoders')

@@ -41,6 +41,7 @@ emu_switch:
 namespace emu {
 
 thread_local Fiber* g_cur = nullptr;
+thread_local unsigned g_poll = 0;
 
 namespace {
 
@@ -181,6 +182,7 @@ void run_block(Worker* w, long long lin) {
     }
     int cur_wave = (g_sched_mode == 2) ? b.nwaves - 1 : 0;
     int spin_streak = 0;
+    g_poll = 0;
     while (b.alive > 0) {
         // choose a wavefront with a runnable lane
         int wv = -1;
@@ -334,6 +336,10 @@ void collective(int op, CollectiveFn fn, void* rec) {
     ++wv->arrived;
     if (wv->arrived == wv->alive) {
         complete_wave(t_worker, wv);
+        // every segment between two collectives runs the lanes of a wavefront in ASCENDING order (whatever the scheduling
+        // mode): same-address LDS atomics issued by one instruction are resolved in a fixed order on the hardware too
+        t_worker->cursor[f->wave_id] = 0;
+        if (f->lane != 0) yield_to_scheduler();          // (still runnable: taken up again in its turn)
         return;
     }
     set_state(t_worker, f, WAIT_WAVE);
@@ -347,6 +353,8 @@ void block_barrier() {
     ++b.arrived;
     if (b.arrived == b.alive) {
         release_block(w);
+        for (int v = 0; v < b.nwaves; ++v) w->cursor[v] = 0;     // lanes in ascending order behind a barrier as well
+        if (f->lane != 0) yield_to_scheduler();
         return;
     }
     set_state(w, f, WAIT_BLOCK);

@@ -28,6 +28,9 @@ def emu_active() -> bool:
 
 class _Stream:
     cuda_stream = 0
+    device_index = 0
+    stream_id = 0
+    priority = 0
     device = torch.device('cpu')
 
     def __init__(self, *a, **k):
@@ -85,6 +88,9 @@ DESELECT = {
     'graph_replay': 'hipGraph capture / replay is not modelled',
     'rccl': 'a process group on the device is not modelled',
     'two_ranks_on_one_gpu': 'second process sharing the device',
+    'batch_feeder': 'data.BatchFeeder: pinned host memory + a copy stream of the real runtime (no kernels of ours)',
+    'epoch_loops_over_a_host_dataset': 'runs through data.BatchFeeder',
+    'uses_the_current_weights[True]': 'hipGraph replay of the synthesis window',
     'test_gpu_fullsize.py': 'full-size batches (B = 128 / 256, H = 300): hours on the model; their kernels run here at small sizes',
 }
 
@@ -139,6 +145,7 @@ def install():
     import build_emu
     lib = build_emu.build()
     os.environ['S2AG_HIP_LIB'] = lib
+    os.environ['S2AG_SYNTH_GRAPH'] = '0'          # registered switch: synthesis with eager launches (no hipGraph in the model)
     tc = torch.cuda
     cur = _Stream()
     tc.is_available = lambda: True
@@ -158,6 +165,7 @@ def install():
     torch.Tensor.cuda = lambda self, *a, **k: self.clone()          # a device copy never aliases its host source
     torch.Tensor.is_cuda = property(lambda self: True)
     torch.Tensor.pin_memory = lambda self, *a, **k: self
+    torch.Tensor.record_stream = lambda self, s: None
     torch.nn.Module.cuda = lambda self, *a, **k: self
     _DeviceRewrite().__enter__()
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))

@@ -124,6 +124,7 @@ struct Block {
 };
 
 extern thread_local Fiber* g_cur;
+extern thread_local unsigned g_poll;
 
 void yield_to_scheduler();                 // park the running fibre (its state says why)
 void collective(int op, CollectiveFn fn, void* rec);
@@ -230,8 +231,8 @@ static inline unsigned long long __builtin_emu_s_memtime() { return emu::ticks()
 namespace emu {
 template <typename T>
 static inline T atomic_load(const T* p) {
-    static unsigned n = 0;
-    if ((++n & 63u) == 0) os_yield();          // a polling loop must let the workgroup it waits for run
+    if ((++g_poll & 63u) == 0) os_yield();     // (g_poll restarts with every workgroup: a workgroup's own schedule never
+                                               // depends on what other workgroups do)          // a polling loop must let the workgroup it waits for run
     T v;
     __atomic_load(const_cast<T*>(p), &v, __ATOMIC_SEQ_CST);
     return v;

@@ -72,6 +72,125 @@ def to_cuda(d):
     return {k: v.cuda() for k, v in d.items()}
 
 
+class StepSignTap:
+    """SignTap for one whole GAN step (Processor.forward_pass_s2ag): the seven module passes of the step -- G(dis), D(real),
+    D(fake), the frozen baseline, G(main), D(gen), G(rand); processor_v2.py:798-937 -- run inside ``noise.use_pass`` scopes
+    whose snapshot carries the pass counter, so every recorded activation is filed under (module, pass) whatever the order
+    or the stream the trainer issues the passes in.  The generator's dropout-free encoders run ONCE per step for its three
+    passes (PoseGenerator.share_passes): their decisions count for all three.
+
+        with StepSignTap(pr, counter0) as tap:
+            pr.forward_pass_s2ag(...)
+        O.gan_step(..., signs=tap.signs_per_pass())"""
+    PASSES = ('g_dis', 'd_real', 'd_fake', 'pgt', 'g_main', 'd_gen', 'g_rand')
+    OWNER = ('G', 'D', 'D', 'T3', 'G', 'D', 'G')
+
+    def __init__(self, pr, counter0):
+        from speech2affective_gestures_amd import noise, ops, wave12, wave32
+        self.ops, self.noise, self.w12, self.w32, self.c0 = ops, noise, wave12, wave32, int(counter0)
+        self.mods = {'G': pr.s2ag_generator, 'D': pr.s2ag_discriminator, 'T3': pr.trimodal_generator}
+        self.owner = {}
+        for tag, m in self.mods.items():
+            for _, sub in m.named_modules():
+                self.owner[id(sub)] = tag
+            for _, q in m.named_parameters():
+                self.owner[id(q)] = tag
+        self.children = {}
+
+    def _pass(self):
+        stack = getattr(self.noise._tls, 'stack', None)
+        if not stack:
+            return None
+        k = int(stack[-1][1]) - self.c0
+        return k if 0 <= k < 7 else None
+
+    def _child(self, tag, k):
+        key = (tag, k)
+        if key not in self.children:
+            c = SignTap(self.mods[tag])
+            c._w12, c._w32, c.pre = self.w12, self.w32, {}
+            self.children[key] = c
+        return self.children[key]
+
+    def __enter__(self):
+        ops = self.ops
+        self._orig = (ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32, self.w12.head_f32, self.w32.encoder_f32)
+        o_bn, o_add, o_lin, o_tcn, o_head, o_enc = self._orig
+
+        def by_pass(k):                      # modules without an object to identify them by: the pass says whose they are
+            return self.OWNER[k] if k is not None else 'G'
+
+        def bn_act(x, bn, slope=1.0, chan_map=None, training=None):
+            y = o_bn(x, bn, slope=slope, chan_map=chan_map, training=training)
+            if slope != 1.0 and id(bn) in self.owner:
+                c = self._child(self.owner[id(bn)], self._pass())
+                c.bn.append((c.names[id(bn)], y.detach()))
+            return y
+
+        def add_act(a, b, slope):
+            y = o_add(a, b, slope)
+            if slope != 1.0:
+                k = self._pass()
+                self._child(by_pass(k), k).adds.append(y.detach())
+            return y
+
+        def linear(x, w, bias, act=0, slope=1.0):
+            y = o_lin(x, w, bias, act=act, slope=slope)
+            if act == 1 and slope != 1.0 and id(w) in self.owner:
+                c = self._child(self.owner[id(w)], self._pass())
+                c.lin.append((c.params[id(w)], y.detach()))
+            return y
+
+        # (saved tensors are gone once the step has back-propagated: what SignTap.signs() reads from grad_fn is read here)
+        def tcn(*a, **kw):
+            r = o_tcn(*a, **kw)
+            k = self._pass()
+            t = r[0] if isinstance(r, tuple) else r
+            if t.grad_fn is not None:            # (a no_grad pass saves nothing and back-propagates nothing: its decisions
+                c = self._child(by_pass(k), k)   # only enter forward values, where a flipped 1e-7 input changes 1e-7)
+                c.tcn.append(t)
+                c.pre.update(c.signs())
+                c.tcn.clear()
+            return r
+
+        def head(wav, fe):
+            z2 = o_head(wav, fe)
+            if id(fe[1]) in self.owner and z2.grad_fn is not None:
+                c = self._child(self.owner[id(fe[1])], self._pass())
+                c.heads.append((c.names[id(fe[1])], z2, fe[0].bias))
+                c.pre.update(c.signs())
+                c.heads.clear()
+            return z2
+
+        def enc(wav, fe):
+            out = o_enc(wav, fe)
+            if id(fe[1]) in self.owner:
+                self._child(self.owner[id(fe[1])], self._pass()).encs.append((out, fe))
+            return out
+        ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32 = bn_act, add_act, linear, tcn
+        self.w12.head_f32, self.w32.encoder_f32 = head, enc
+        return self
+
+    def __exit__(self, *a):
+        ops = self.ops
+        ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32, self.w12.head_f32, self.w32.encoder_f32 = self._orig
+
+    def signs_per_pass(self):
+        """{pass name: {site: bool tensor}} for oracle.gan_step(signs=...)."""
+        per = {key: {**c.signs(), **c.pre} for key, c in self.children.items()}
+        out = {}
+        for k, (name, tag) in enumerate(zip(self.PASSES, self.OWNER)):
+            d = dict(per.get((tag, None), {}))            # ran outside every pass scope: the generator's shared encoders
+            d.update(per.get((tag, k), {}))
+            for (t2, k2), sg in per.items():              # shared encoders that ran inside the FIRST pass's scope
+                if t2 == tag and k2 is not None and k2 != k:
+                    for site, v in sg.items():
+                        if site not in d and ('aff_encoder.' in site or 'audio_encoder.' in site):
+                            d[site] = v
+            out[name] = d
+        return out
+
+
 import re as _re
 
 _DEAD = _re.compile(r'(audio_encoder\.conv[1-4]\.bias|audio_encoder\.feat_extractor\.[036]\.bias|'

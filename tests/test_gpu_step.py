@@ -165,6 +165,51 @@ def test_two_steps_with_dropout_match_the_oracle(monkeypatch):
     assert int(pr.s2ag_generator.state_dict()['aff_encoder.batch_norm1.num_batches_tracked']) == 6
 
 
+@pytest.mark.parametrize('hidden,B', [(300, 6), (300, 33)])       # (H = 300: the clip-resident TCN SignTap reads)
+def test_one_step_strictly_with_the_products_branch_decisions(monkeypatch, hidden, B):
+    """ONE GAN step against the oracle with the branch decisions of ALL SEVEN module passes replayed (StepSignTap files every
+    ReLU / LeakyReLU output of the product under (module, pass) through the pass counter of its noise scope;
+    oracle.gan_step(signs=...) replays them per pass): losses 3e-4, and EVERY gradient of G and of D within 1e-3 of its largest
+    element -- the criterion the module-level tests use, now for the whole step, where r03 accepted 5 % per tensor.  The
+    full-size twins are in tests/test_gpu_fullsize.py; this size also runs on the CPU device model (tests/emu)."""
+    from speech2affective_gestures_amd import noise, ops
+    from speech2affective_gestures_amd import processor_v2 as P
+    from s2ag_testing import StepSignTap
+    n_words, n_spk, s0 = 64, 12, 8400
+    pr, sds = make_processor(hidden, n_words, n_spk, B, s0, 0.3)
+    G, D, T3 = ({k: v.clone() for k, v in sds[n].items()} for n in ('G', 'D', 'T3'))
+    noise.manual_seed(STEP_SEED)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
+    monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm.cuda())
+    inp = O.recipe_inputs(B, 34, s0 + 100, n_words, n_spk)
+    gi = to_cuda(inp)
+    nz = _materialise_step_noise(pr, 0, B, 34, hidden)
+    nz.perm = perm
+    with StepSignTap(pr, 0) as tap:
+        ret = pr.forward_pass_s2ag(gi['in_text'], gi['in_audio'], gi['in_mfcc'], gi['target'], gi['vid'], True)
+    monkeypatch.undo()
+    signs = tap.signs_per_pass()
+    metric, losses, grads = O.gan_step(G, D, T3, O.AdamState(), O.AdamState(), oracle_cfg(hidden, 0.3), O.StepCfg(),
+                                       inp['in_text'], inp['in_audio'], inp['in_mfcc'], inp['target'], inp['vid'], epoch=1,
+                                       noise=nz, signs=signs)
+    used = O.gan_step.signs_used
+    for name in StepSignTap.PASSES:                     # every recorded site was consumed, in every pass
+        assert set(used[name]) == set(signs[name]), (name, set(signs[name]) ^ set(used[name]))
+    # the passes that back-propagate hold every site: MFCC encoder 5, text TCN 12, pose encoder 6, out 1; discriminator 6
+    assert len(signs['g_main']) == 5 + 12 + 6 + 1 and len(signs['d_gen']) == len(signs['d_real']) == len(signs['d_fake']) == 6, \
+        {k: len(v) for k, v in signs.items()}
+    for k in ('dis', 'total', 'loss', 'KLD', 'DIV_REG', 'gen'):
+        assert pr.last_losses[k] == pytest.approx(losses[k], rel=3e-4, abs=1e-6), k
+    assert ret[0] == pytest.approx(metric, rel=5e-3, abs=2e-6)
+    for tag, mod in (('G', pr.s2ag_generator), ('D', pr.s2ag_discriminator)):
+        errs = {k: grad_err(p.grad, grads[tag][k], k) for k, p in mod.named_parameters() if '.net.' not in k}
+        top = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+        print(f'[strict step parity H={hidden} B={B}] {tag}: worst gradients (max-norm) ' + ', '.join(f'{k} {e:.1e}' for k, e in top))
+        for k, e in errs.items():
+            assert e < 1e-3, (tag, k, e)
+    assert ops.coop_gru_timeouts() == 0
+
+
 def test_long_clip_steps_136_frames_match_the_oracle(monkeypatch):
     """BASELINE configs[4] as a STEP (not only a forward): T = 136 frames, 146 000 audio samples (the wave encoder then
     yields exactly 136 frames), mfcc_length = ceil(146000 / 512) = 286 as the reference derives it (processor_v2.py:124),
@@ -320,6 +365,58 @@ def test_hip_graph_replay_equals_eager(monkeypatch, gan):
         if not k.endswith('num_batches_tracked') and not is_noise_driven_after_adam(k):
             ok, info = adam_close(sd_g[k], sd_e[k], 5e-4, 3) if 'running' not in k else (rel(sd_g[k], sd_e[k]) < 3e-4, None)
             assert ok, (k, info)
+
+
+@pytest.mark.parametrize('hidden,B', [(32, 6), (300, 33)])
+def test_deterministic_mode_two_runs_are_bit_identical(monkeypatch, hidden, B):
+    """Deterministic mode (config switch DETERMINISTIC / Processor(deterministic=True); csrc/s2ag_common.h det_enter /
+    det_leave / det_wave_ordered): two runs of the same two GAN steps from the same state leave EVERY weight, every
+    gradient, every BatchNorm running statistic and every logged loss bit-identical -- where the default mode differs in
+    the last bits of ~95 % of the tensors (fp32 atomics arrive in another order) and the replay test above has to allow for
+    what Adam makes of that.  H = 300 goes through the cooperative GRU, the clip-resident TCN and the transpose-read weight
+    gradients; on the CPU device model (tests/emu) the second run additionally uses another wavefront schedule."""
+    from speech2affective_gestures_amd import noise, ops
+    from speech2affective_gestures_amd import processor_v2 as P
+    n_words, n_spk, s0 = 64, 12, 9300
+    perm = torch.arange(B - 1, -1, -1).cuda()
+    monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm)
+    batches = [to_cuda(O.recipe_inputs(B, 34, s0 + 100 + s, n_words, n_spk)) for s in range(2)]
+    emu = None
+    if os.environ.get('S2AG_EMU') == '1':
+        import ctypes
+        emu = ctypes.CDLL(os.environ['S2AG_HIP_LIB'])
+
+    def run(sched):
+        if emu is not None:
+            emu.s2ag_emu_set_sched(sched, 11)
+        noise.reset_sites(200)
+        pr, _ = make_processor(hidden, n_words, n_spk, B, s0, 0.3, hip_graph=False, deterministic=True)
+        assert pr.deterministic and not pr.overlap_passes and ops.deterministic()
+        noise.manual_seed(STEP_SEED)
+        losses = []
+        for b in batches:
+            pr.forward_pass_s2ag(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'], True)
+            losses.append(dict(pr.last_losses))
+        out = {}
+        for tag, mod in (('G', pr.s2ag_generator), ('D', pr.s2ag_discriminator)):
+            for k, p in mod.named_parameters():
+                out[f'{tag}.{k}'] = p.detach().clone()
+                if p.grad is not None:
+                    out[f'{tag}.{k}.grad'] = p.grad.clone()
+            for k, v in mod.state_dict().items():
+                if 'running' in k:
+                    out[f'{tag}.{k}'] = v.clone()
+        return losses, out
+    try:
+        (l0, a), (l1, b) = run(0), run(2)
+    finally:
+        ops.set_deterministic(False)
+        if emu is not None:
+            emu.s2ag_emu_set_sched(int(os.environ.get('S2AG_EMU_SCHED', '0')), 1)
+    assert l0 == l1
+    differ = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not differ, (len(differ), len(a), differ[:8])
+    assert ops.coop_gru_timeouts() == 0
 
 
 def test_shared_encoder_pass_equals_three_separate_passes(monkeypatch):
