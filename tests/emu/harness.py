@@ -87,7 +87,7 @@ DESELECT = {
     'hip_graph': 'hipGraph capture / replay is not modelled (launches are synchronous)',
     'graph_replay': 'hipGraph capture / replay is not modelled',
     'rccl': 'a process group on the device is not modelled',
-    'two_ranks_on_one_gpu': 'second process sharing the device',
+    'two_ranks_on_one_gpu_match_the_averaged_gradient_emulation[graph]': 'hipGraph segments (the eager variants of the two-rank step DO run: two gloo ranks, each on its own copy of the model)',
     'batch_feeder': 'data.BatchFeeder: pinned host memory + a copy stream of the real runtime (no kernels of ours)',
     'epoch_loops_over_a_host_dataset': 'runs through data.BatchFeeder',
     'uses_the_current_weights[True]': 'hipGraph replay of the synthesis window',

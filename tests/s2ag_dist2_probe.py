@@ -18,6 +18,10 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
+if os.environ.get('S2AG_EMU', '0') == '1':      # TEST INFRASTRUCTURE: both replicas on the CPU device model (tests/emu)
+    sys.path.insert(0, os.path.join(HERE, 'emu'))
+    import harness
+    harness.install()
 
 from oracle import s2ag_oracle as O  # noqa: E402  (input / weight recipes only)
 from s2ag_testing import PASSES_PER_STEP, STEP_SEED, to_cuda  # noqa: E402
@@ -41,7 +45,7 @@ def grads(pr):
     return dict(G=pr.gen_arena.grad.detach().cpu().clone(), D=pr.dis_arena.grad.detach().cpu().clone())
 
 
-def run_rank(out_path, graph, overflow):
+def run_rank(out_path, graph, overflow, flagged=False):
     from speech2affective_gestures_amd import noise, ops
     from speech2affective_gestures_amd import processor_v2 as P
     import torch.distributed as dist
@@ -70,6 +74,21 @@ def run_rank(out_path, graph, overflow):
         torch.cuda.synchronize()
         res['steps'].append(dict(w=weights(pr), g=grads(pr), losses=dict(pr.last_losses)))
         res['ids'].append(sorted(set(b['in_text'].reshape(-1).tolist())))
+    if flagged:
+        # ONE rank's sticky error word goes up (as a cooperative-GRU / BatchNorm time-out would raise it): the step that
+        # follows must leave the weights of EVERY rank alone (the word is MAX-reduced before each Adam) and raise everywhere
+        before = weights(pr)
+        if rank == 1:
+            ops.coop_error_flag(pr.device).view(torch.int32).fill_(4)
+        b = batch(rank, STEPS)
+        raised = False
+        try:
+            pr.forward_pass_s2ag(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'], True)
+        except ops.CoopGruTimeout:
+            raised = True
+        torch.cuda.synchronize()
+        res['flag_step'] = dict(raised=raised, before=before, after=weights(pr),
+                                word=int(ops.coop_error_flag(pr.device).view(torch.int32)[0]))
     ex = pr._exchange()
     res.update(collectives=pr.dp.n_collectives, dense_fallbacks=ex.dense_fallbacks, row_cap=ex.row_cap,
                timeouts=ops.coop_gru_timeouts(), bytes=ex.bytes_per_step())
@@ -127,6 +146,6 @@ def run_emu(out_path, graph):
 if __name__ == '__main__':
     mode, out_path = sys.argv[1], sys.argv[2]
     if mode == 'rank':
-        run_rank(out_path, 'graph' in sys.argv[3:], 'overflow' in sys.argv[3:])
+        run_rank(out_path, 'graph' in sys.argv[3:], 'overflow' in sys.argv[3:], 'flag' in sys.argv[3:])
     else:
         run_emu(out_path, 'graph' in sys.argv[3:])

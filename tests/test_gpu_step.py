@@ -742,7 +742,7 @@ def test_forward_pass_with_calculate_metrics_feeds_the_meters_and_evaluators(gol
     assert ret[0] == pytest.approx(meters[3].val - meters[0].val, rel=1e-3, abs=1e-6)
 
 
-@pytest.mark.parametrize('mode', ['graph', 'eager', 'eager-overflow'])
+@pytest.mark.parametrize('mode', ['graph', 'eager', 'eager-overflow', 'eager-flag'])
 def test_two_ranks_on_one_gpu_match_the_averaged_gradient_emulation(tmp_path, mode):
     """The REAL data-parallel step with TWO ranks (processor_v2.py:167-172 is the reference's nn.DataParallel counterpart):
     two processes share cuda:0 over gloo (RCCL refuses duplicate devices; same DataParallelContext / GradExchange code,
@@ -756,7 +756,8 @@ def test_two_ranks_on_one_gpu_match_the_averaged_gradient_emulation(tmp_path, mo
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), 's2ag_dist2_probe.py')
     port = str(29900 + os.getpid() % 90)
-    flags = (['graph'] if mode == 'graph' else []) + (['overflow'] if mode.endswith('overflow') else [])
+    flags = (['graph'] if mode == 'graph' else []) + (['overflow'] if mode.endswith('overflow') else []) + \
+        (['flag'] if mode.endswith('flag') else [])
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
@@ -771,7 +772,7 @@ def test_two_ranks_on_one_gpu_match_the_averaged_gradient_emulation(tmp_path, mo
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
     r0, r1, emu = (torch.load(tmp_path / n, weights_only=False) for n in ('rank0.pt', 'rank1.pt', 'emu.pt'))
-    assert r0['timeouts'] == r1['timeouts'] == emu['timeouts'] == 0
+    assert r0['timeouts'] == r1['timeouts'] == (1 if mode.endswith('flag') else 0) and emu['timeouts'] == 0
     # (i) broadcast + replica equality, bit for bit
     for net in ('G', 'D'):
         for k, v in r0['start'][net].items():
@@ -787,8 +788,18 @@ def test_two_ranks_on_one_gpu_match_the_averaged_gradient_emulation(tmp_path, mo
         assert r0['row_cap'] == 6 and r0['dense_fallbacks'] == r1['dense_fallbacks'] == 3
     else:
         assert r0['dense_fallbacks'] == r1['dense_fallbacks'] == 0
-    # per step: id-count MAX, D arena, bucket A, bucket B, rows; graph mode: + 3 warm-up steps and the precheck at capture
-    assert r0['collectives'] == r1['collectives'] == (6 * 5 + 1 if mode == 'graph' else 3 * 5)
+    # per step: id-count MAX, D arena, error-word MAX (before D's Adam), bucket A, bucket B, rows, error-word MAX (before G's
+    # Adam: a time-out on ONE rank must hold EVERY rank's update); graph mode: + 3 warm-up steps and the precheck
+    assert r0['collectives'] == r1['collectives'] == (6 * 7 + 1 if mode == 'graph' else (4 if mode.endswith('flag') else 3) * 7)
+    if mode.endswith('flag'):
+        # (iv) rank 1's sticky error word was raised before a fourth step: BOTH ranks hold both Adam updates (the word is
+        # MAX-reduced over the ranks before each optimizer), both raise at their read-back, the replicas stay identical
+        for r in (r0, r1):
+            f = r['flag_step']
+            assert f['raised'] and f['word'] == 4, (r['rank'], f['raised'], f['word'])
+            for net in ('G', 'D'):
+                for k, v in f['before'][net].items():
+                    assert torch.equal(v, f['after'][net][k]), (r['rank'], net, k)
     # (ii) the summed gradients themselves -- strictly where both sides start from the same weights (eager: step 0)
     nsteps0 = 3 if mode == 'graph' else 0               # Adam steps before the first recorded one
     for net in ('G', 'D'):
