@@ -20,13 +20,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'speech2affective_gestures_amd', 'csrc')
-OUT = os.path.join(HERE, '_build')
-LIB = os.path.join(OUT, 'libs2ag_emu.so')
+DEBUG = os.environ.get('S2AG_EMU_DEBUG', '0') == '1'      # -DS2AG_DEBUG=1: the loaders' index asserts (s2ag_common.h) are live
+OUT = os.path.join(HERE, '_build', 'debug') if DEBUG else os.path.join(HERE, '_build')
+LIB = os.path.join(OUT, 'libs2ag_emu_debug.so' if DEBUG else 'libs2ag_emu.so')
 CXX = os.environ.get('S2AG_EMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
 FLAGS = ['-x', 'c++', '-std=c++17', '-O1', '-g1', '-fPIC', '-fno-strict-aliasing', '-ffp-contract=off', '-pthread',
          '-Wno-unknown-attributes', '-Wno-ignored-attributes', '-Wno-unused-value', '-Wno-pass-failed',
          '-Wno-unknown-pragmas', '-Wno-deprecated-declarations',
-         '-I' + HERE, '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(OUT, 'src')]
+         '-I' + HERE, '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(OUT, 'src')] + (['-DS2AG_DEBUG=1'] if DEBUG else [])
 
 _DYN = re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w ]*?)\s+(\w+)\[\];')
 _ASM_BAR = re.compile(r'asm volatile\("s_waitcnt lgkmcnt\(0\)\\n\\ts_barrier"\s*:::\s*"memory"\)')
