@@ -527,8 +527,14 @@ unsigned long long* g_trace = nullptr;
 // 128 workgroups on 256 CUs, every one a chain of eight convs of ~22 k cycles: with one clip per workgroup (3 row tiles)
 // the K loop and the epilogue of a conv shrink to 3 / 5 and all CUs work -- the L2 then serves the weights twice as often
 // (742 MB per launch, well inside its bandwidth).
+// r04: found on the CPU device model (tests/emu enforces the 160 KB limit): at T = 40 two clips are 80 rows, and the backward
+// launch's three row buffers + zero row + sign images are 167 696 bytes -- the launch would have failed on the hardware.  The
+// plan now also asks the LDS budget of the LARGER of the two launches (forward and backward must agree on the clips per
+// workgroup: the sign images are laid out per workgroup).
+size_t lds_bytes(int cpb, int T, bool bwd);
 int plan_cpb(int n_clips, int T) {
-    const int max_cpb = (MT_MAX * 16) / T > 2 ? 2 : (MT_MAX * 16) / T;
+    int max_cpb = (MT_MAX * 16) / T > 2 ? 2 : (MT_MAX * 16) / T;
+    while (max_cpb > 1 && lds_bytes(max_cpb, T, true) > (size_t)160 * 1024) --max_cpb;
     if (max_cpb >= 2 && T <= 48 && n_clips >= 192) return 1;
     return max_cpb;
 }
@@ -588,7 +594,7 @@ size_t lds_bytes(int cpb, int T, bool bwd) {
 
 extern "C" int s2ag_bf16_tcn_clips_per_block(int T, int C, int ksize) {      // the most a workgroup takes (see plan_cpb)
     if (ksize != 2 || C < 1 || C > CP || T < 1 || T > MT_MAX * 16) return 0;
-    return (MT_MAX * 16) / T > 2 ? 2 : (MT_MAX * 16) / T;
+    return plan_cpb(1, T);                                          // (few clips: the most the row tiles AND the LDS allow)
 }
 
 extern "C" int s2ag_bf16_tcn_set_trace(void* buf) {

@@ -183,3 +183,37 @@ def test_embedding_forward_row_form_equals_element_form(mode):
             outs.append(y.detach().clone())
     assert outs[0].shape[:2] == (37, 34) and torch.equal(outs[0], outs[1])
     assert float(outs[0].float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('B,T', [(1, 9), (3, 33), (2, 40), (7, 21)])
+def test_gather_and_deep_rings_at_other_clip_lengths(mode, B, T):
+    """The opt-in TCN paths away from the one geometry everything else uses (34 frames): 9 / 21 / 33 / 40 frames (40 = the
+    clip-resident kernels' limit), single clips and ragged batches -- gather inside the launch + deep weight rings against the
+    default launches: outputs bit-identical, gradients 1e-5."""
+    from speech2affective_gestures_amd import bf16, config, noise, ops
+    txt = _encoder()
+    g = torch.Generator().manual_seed(12 + T)
+    ids = torch.randint(0, 400, (B, T), generator=g).cuda()
+    ids[:, T // 2:] = 0
+    dt = torch.randn(B, T, 32, generator=g).cuda()
+    res = {}
+    prev = (ops.TCN32_GATHER, bf16.TCN_GATHER)
+    try:
+        for on in (False, True):
+            ops.TCN32_GATHER = bf16.TCN_GATHER = on
+            with config.override('TCN_RING_DEEP', on), bf16.precision(mode):
+                for p in txt.parameters():
+                    p.grad = None
+                ops.begin_step()
+                noise.manual_seed(13)
+                t = txt(ids)[0]
+                (t * dt).sum().backward()
+                torch.cuda.synchronize()
+                res[on] = (t.detach().clone(), {k: p.grad.clone() for k, p in txt.named_parameters()})
+    finally:
+        ops.TCN32_GATHER, bf16.TCN_GATHER = prev
+    (t0, g0), (t1, g1) = res[False], res[True]
+    assert t0.shape == (B, T, 32) and torch.equal(t1, t0)
+    for k in g0:
+        assert rel(g1[k], g0[k]) < 1e-5, (k, rel(g1[k], g0[k]))
