@@ -229,6 +229,37 @@ def test_encoders_in_bf16_mode_track_their_fp32_mode(B):
         assert l2(g1[k], g0[k]) < tol, (k, l2(g1[k], g0[k]))
 
 
+@pytest.mark.parametrize('B,dim,n_entries,pad_frac', [(40, 300, 500, 0.85), (9, 300, 12, 0.0), (3, 300, 400, 1.0), (17, 44, 7, 0.5)])
+def test_bf16_embedding_against_torch_with_pad_runs_and_duplicates(B, dim, n_entries, pad_frac):
+    """embedding_fwd_bf16_k / embedding_bwd_bf16_k (csrc/conv_bf16.hip; the backward rewritten in r03 like its fp32 twin: PAD
+    rows summed through LDS) against torch on the bf16-rounded operands: forward = bf16(table[id] * keep), pad channels zero;
+    the table's gradient (fp32 atomics of bf16 dy * keep) at ~85 % PAD, several row blocks, repeated words, all-PAD, PAD-free
+    and a width that is no multiple of the tile (net/multimodal_context_net_v2.py:70-78)."""
+    from speech2affective_gestures_amd import bf16, noise, ops
+    g = torch.Generator().manual_seed(300 + B)
+    table = torch.randn(n_entries, dim, generator=g)
+    ids = torch.randint(1 if n_entries > 1 else 0, n_entries, (B, 34), generator=g)
+    ids[torch.rand(B, 34, generator=g) < pad_frac] = 0
+    ids[0, :7] = ids[0, 0]
+    ids[-1, -1] = ids[0, 0]
+    noise.manual_seed(2)
+    nz = noise.begin_pass('cuda')
+    tg = table.cuda().requires_grad_(True)
+    out = bf16.embedding(ids.cuda(), tg, 0.1, nz, 21)
+    Cp = bf16.pad32(dim)
+    assert out.dtype == torch.bfloat16 and out.shape[-1] == Cp
+    mask = ops.dropout_mask(nz, 21, 0.1, (B, 34, dim)).cpu()
+    ref = r16(F.embedding(ids, table) * mask)
+    o = out.float().cpu().reshape(B, 34, Cp)
+    assert torch.equal(o[..., :dim], ref) and float(o[..., dim:].abs().sum()) == 0.0
+    dy = r16(torch.randn(B, 34, Cp, generator=g))
+    out.backward(dy.to(torch.bfloat16).cuda().reshape(out.shape))
+    want = torch.zeros(n_entries, dim, dtype=torch.float64).index_add_(0, ids.reshape(-1),
+                                                                      (dy[..., :dim] * mask).double().reshape(-1, dim))
+    assert rel(tg.grad, want) < 1e-5
+    assert torch.equal(tg.grad.cpu() == 0, want == 0)
+
+
 @pytest.mark.parametrize('B,T', [(5, 34), (64, 34), (200, 34), (2, 40), (3, 39), (1, 17)])
 def test_clip_resident_tcn_equals_the_layer_by_layer_bf16_path(B, T):
     """csrc/tcn_fused.hip (all TemporalBlocks in one launch, activations resident in LDS; two clips per workgroup, or -- from

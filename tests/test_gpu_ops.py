@@ -671,6 +671,36 @@ def test_embedding_dropout_and_dense_gradient(S):
     assert rel(tg.grad, tr.grad) < TOL
 
 
+@pytest.mark.parametrize('B,dim,n_entries,pad_frac', [(40, 300, 500, 0.85), (9, 300, 12, 0.0), (33, 16, 1371, 0.0),
+                                                      (3, 300, 400, 1.0), (17, 44, 7, 0.5)])
+def test_embedding_gradient_with_pad_runs_and_duplicates(S, B, dim, n_entries, pad_frac):
+    """embedding_bwd_k as rewritten in r03 (csrc/misc.hip: 256 rows x 64 columns per workgroup, the PAD id's rows summed in
+    registers and through LDS, word rows as direct atomics) at the shapes it meets -- transcripts that are ~85 % PAD
+    (utils/vocab.py PAD_token = 0), several row blocks, repeated words inside and across row blocks, the 16-wide speaker
+    table, all-PAD and PAD-free batches, a width that is no multiple of the 64-column tile -- against F.embedding's dense
+    gradient, with dropout (net/multimodal_context_net_v2.py:70-78)."""
+    ops, noise = S['ops'], S['noise']
+    g = torch.Generator().manual_seed(100 + B)
+    table = torch.randn(n_entries, dim, generator=g)
+    ids = torch.randint(1 if n_entries > 1 else 0, n_entries, (B, 34), generator=g)
+    ids[torch.rand(B, 34, generator=g) < pad_frac] = 0
+    ids[0, :7] = ids[0, 0]                                    # a run of one word inside a wave's rows
+    ids[-1, -1] = ids[0, 0]                                   # ... and the same word again in the last row block
+    noise.manual_seed(2)
+    nz = noise.begin_pass('cuda')
+    tg = table.cuda().requires_grad_(True)
+    out = ops.embedding(ids.cuda(), tg, 0.1, nz, 21)
+    mask = ops.dropout_mask(nz, 21, 0.1, (B, 34, dim)).cpu()
+    tr = table.clone().requires_grad_(True)
+    ref = F.embedding(ids, tr) * mask
+    assert rel(out, ref) < 1e-6
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    out.backward(dy.cuda())
+    assert rel(tg.grad, tr.grad) < TOL
+    assert torch.equal(tg.grad.cpu() == 0, tr.grad == 0)      # untouched rows stay exactly zero
+
+
 def test_weight_norm(S):
     ops = S['ops']
     g = torch.Generator().manual_seed(13)
