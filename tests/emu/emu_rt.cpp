@@ -378,6 +378,33 @@ void fail(const char* what) {
 
 unsigned long long ticks() { return __rdtsc(); }
 
+// Dynamic LDS beyond 64 KB is only granted to a kernel whose MaxDynamicSharedMemorySize attribute was raised (per
+// instantiation): a launch that forgets it fails on the hardware with hipErrorInvalidValue -- and nowhere else.
+namespace {
+std::mutex g_attr_mu;
+std::vector<std::pair<const void*, int>> g_attr;
+}
+void set_max_dynamic_lds(const void* kernel, int bytes) {
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    for (auto& e : g_attr)
+        if (e.first == kernel) { e.second = bytes; return; }
+    g_attr.emplace_back(kernel, bytes);
+}
+void check_dynamic_lds(const void* kernel, size_t dyn, const char* name) {
+    if (dyn <= 64 * 1024) return;
+    int granted = 64 * 1024;
+    {
+        std::lock_guard<std::mutex> lk(g_attr_mu);
+        for (auto& e : g_attr)
+            if (e.first == kernel) granted = e.second;
+    }
+    if ((size_t)granted < dyn) {
+        fprintf(stderr, "[s2ag emu] kernel %s launched with %zu bytes of dynamic LDS but its MaxDynamicSharedMemorySize is %d\n", name,
+                dyn, granted);
+        abort();
+    }
+}
+
 void launch_impl(dim3 grid, dim3 block, size_t dyn, void (*thunk)(void*), void* ctx, const char* name) {
     std::call_once(g_once, init_once);
     const long long nblocks = (long long)grid.x * grid.y * grid.z;
@@ -385,6 +412,7 @@ void launch_impl(dim3 grid, dim3 block, size_t dyn, void (*thunk)(void*), void* 
     if (nblocks <= 0 || nthreads <= 0) return;
     if (nthreads > MAX_THREADS_PER_BLOCK) fail("workgroup larger than 1024 threads");
     if (dyn > 160 * 1024) fail("more than 160 KB of dynamic LDS");
+    if (grid.y > 65535u || grid.z > 65535u) fail("gridDim.y / gridDim.z beyond 65535");
     Job job;
     job.grid = grid;
     job.block = block;

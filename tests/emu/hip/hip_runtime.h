@@ -132,6 +132,8 @@ void block_barrier();
 void os_yield();
 [[noreturn]] void fail(const char* what);
 void launch_impl(dim3 grid, dim3 block, size_t dyn, void (*thunk)(void*), void* ctx, const char* name);
+void set_max_dynamic_lds(const void* kernel, int bytes);      // hipFuncSetAttribute(MaxDynamicSharedMemorySize)
+void check_dynamic_lds(const void* kernel, size_t dyn, const char* name);
 unsigned long long ticks();
 
 static inline void* dyn_smem() { return g_cur->blk->dyn_lds; }
@@ -152,6 +154,7 @@ template <typename K, typename... A>
 static inline void launch_kernel(const char* name, K kern, dim3 grid, dim3 block, size_t dyn, hipStream_t, A&&... a) {
     auto args = std::make_tuple(std::forward<A>(a)...);
     auto body = [&]() { std::apply(kern, args); };
+    check_dynamic_lds(reinterpret_cast<const void*>(+kern), dyn, name);      // > 64 KB needs the function attribute, per kernel
     launch(grid, block, dyn, body, name);
 }
 
@@ -169,7 +172,10 @@ static inline void launch_kernel(const char* name, K kern, dim3 grid, dim3 block
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 template <typename T>
-static inline hipError_t hipFuncSetAttribute(T, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(T fn, hipFuncAttribute a, int v) {
+    if (a == hipFuncAttributeMaxDynamicSharedMemorySize) emu::set_max_dynamic_lds(reinterpret_cast<const void*>(fn), v);
+    return hipSuccess;
+}
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
     memset(p, v, n);
     return hipSuccess;
