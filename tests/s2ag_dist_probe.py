@@ -11,6 +11,10 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
+if os.environ.get('S2AG_EMU', '0') == '1':      # TEST INFRASTRUCTURE: on the CPU device model (tests/emu)
+    sys.path.insert(0, os.path.join(HERE, 'emu'))
+    import harness
+    harness.install()
 
 from oracle import s2ag_oracle as O  # noqa: E402
 from s2ag_testing import STEP_SEED, to_cuda  # noqa: E402
