@@ -56,7 +56,7 @@ int s2ag_get_option(const char* name);
  * flush: the fp32 atomicAdd sites behind loss.backward() at processor_v2.py:841,937) performs its atomics in the order of its
  * linear workgroup index, and in-workgroup LDS accumulation goes wavefront by wavefront -- two runs of a step on ONE stream
  * give bit-identical gradients and weights.  The caller serialises the passes of a step (Processor(deterministic=True) /
- * S2AG_DETERMINISTIC=1 does).  fp32 mode; the bf16-mode kernels of conv_bf16.hip are not covered. */
+ * S2AG_DETERMINISTIC=1 does).  Both precision modes. */
 int s2ag_set_deterministic(int* zero_device_word);
 
 /* 1-D convolution geometry, channels-last.  Input rows (n*Lin + pos), output rows (n*Lout + l),

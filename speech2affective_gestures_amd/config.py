@@ -45,7 +45,7 @@ _S = [
     Switch('PREFETCH', True, _flag, "0: yield_batch gathers / decodes on the host synchronously (the reference's data path) "
            "instead of data.BatchFeeder", 'tests/test_gpu_step.py::test_prefetching_batch_feeder_matches_the_host_path'),
     Switch('DETERMINISTIC', False, _flag, "debug: passes of a step on one stream, accumulating launches ordered by workgroup index "
-           "(s2ag_set_deterministic): two runs from the same state are bit-identical (fp32 mode)",
+           "(s2ag_set_deterministic): two runs from the same state are bit-identical",
            'tests/test_gpu_step.py::test_deterministic_mode_two_runs_are_bit_identical'),
     # ---- fused paths with a layer-by-layer fall-back that parity tests compare against ------------------------------------
     Switch('WAVE12', True, _flag, "0: the wave encoder's head (conv1 + BatchNorm + LeakyReLU + conv2) layer by layer instead "

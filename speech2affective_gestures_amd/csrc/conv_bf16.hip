@@ -424,6 +424,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int tile, const i
         mma();
     }
     // C layout: column (lane & 15) = x channel, rows (lane >> 4)*4 + {0..3} = output channel
+    s2ag::det_enter();                    // deterministic mode: the splits of a tile add in workgroup-index order
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -447,14 +448,17 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int tile, const i
         }
     if (do_bias) {
         __syncthreads();
+        s2ag::det_wave_ordered([&] {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(&bsum[ch * 8 + j], bacc[j]);
+            for (int j = 0; j < 8; ++j) atomicAdd(&bsum[ch * 8 + j], bacc[j]);
+        });
         __syncthreads();
         if (tid < 64 && co0 + tid < p.Cout) {
             if (p.part) p.part_b[((long long)split * nco + cot) * 64 + tid] = bsum[tid];
             else atomicAdd(p.db + co0 + tid, bsum[tid]);
         }
     }
+    s2ag::det_leave();
 }
 
 // second half of a split launch: dw (+ db) += the sum over the splits of the stored tiles -- one thread per element, no
@@ -510,7 +514,11 @@ struct WgJobs {
 };
 __global__ __launch_bounds__(256) void conv_bf16_wgrad_multi_k(const WgJobs js) {
     const int job = blockIdx.z;
-    if ((int)blockIdx.x >= js.tiles[job] || (int)blockIdx.y >= js.splits[job]) return;
+    if ((int)blockIdx.x >= js.tiles[job] || (int)blockIdx.y >= js.splits[job]) {
+        s2ag::det_enter();                // (an idle workgroup of the padded grid still takes and passes on its turn)
+        s2ag::det_leave();
+        return;
+    }
     wgrad_body(js.j[job], blockIdx.x, blockIdx.y);
 }
 
@@ -605,6 +613,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_bf16_k(const bf16_t* __restri
     const int lanes_c = cpr < 256 ? cpr : 256;                  // threads along the chunk axis
     const int rstep = 256 / lanes_c;
     const int cc = threadIdx.x % lanes_c, rr = threadIdx.x / lanes_c;
+    s2ag::det_wave_ordered([&] {          // (deterministic mode: the LDS sums take the waves' terms one wave after the other)
     if (rr < rstep) {
         for (int cb = cc; cb < cpr; cb += lanes_c) {
             const int c = cb * 8;
@@ -634,8 +643,11 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_bf16_k(const bf16_t* __restri
             }
         }
     }
+    });
     __syncthreads();
+    s2ag::det_enter();
     for (int i = threadIdx.x; i < 2 * cols; i += 256) atomicAdd(sums + i, sm[i]);
+    s2ag::det_leave();
 }
 
 // pass 2 (one block): dgamma += q, dbeta += p (atomically: several passes may share the parameters), c1 = p / rows,
@@ -812,6 +824,8 @@ __global__ __launch_bounds__(256) void embedding_bwd_bf16_k(const long long* __r
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.y * 128 + 2 * lane;                 // a lane owns a channel pair: 4-byte loads (ld and dim are even)
     float pad0 = 0.f, pad1 = 0.f;
+    s2ag::det_enter();                    // deterministic mode: workgroups in index order, waves one after the other
+    s2ag::det_wave_ordered([&] {
     if (c < dim) {
         const int i0 = wave * (rows_per_block / 4), i1 = min(nr, i0 + rows_per_block / 4);
         for (int ib = i0; ib < i1; ib += 16) {              // all 16 loads before the first atomic (see misc.hip)
@@ -838,6 +852,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_bf16_k(const long long* __r
             }
         }
     }
+    });
     pad_s[wave][lane] = pad0;
     pad_s[wave][64 + lane] = pad1;
     __syncthreads();
@@ -847,6 +862,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_bf16_k(const long long* __r
         if (t0 != 0.f) atomicAdd(dtable + c, t0);
         if (t1 != 0.f) atomicAdd(dtable + c + 1, t1);
     }
+    s2ag::det_leave();
 }
 
 inline int ew_blocks(long long n) {
@@ -1132,3 +1148,4 @@ extern "C" int s2ag_bf16_embedding_bwd(const long long* ids, const void* dy, int
     S2AG_LAUNCH_CHECK();
     return 0;
 }
+S2AG_DET_HOOK(conv_bf16)

@@ -286,6 +286,7 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
         }
     }
     __syncthreads();
+    s2ag::det_enter();
     for (int i = tid; i < CO * KS + CO; i += C1_NT) {
         const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
         if (p.part)             // 1 024 blocks x 256 atomics on the same 256 addresses were most of this kernel's time
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(C1_NT) void conv_c1_wgrad_k(const C1P p) {
         else if (p.db)
             atomicAdd(p.db + (i - CO * KS), v);
     }
+    s2ag::det_leave();
 }
 
 // dw[i] += sum_b part[b][i] (i < CO * KS), db[c] += sum_b part[b][CO * KS + c]: one block, 256 = CO * KS + CO threads,
@@ -463,3 +465,4 @@ extern "C" int s2ag_wave_conv1_fwd(const float* x, const float* w, const float* 
     S2AG_LAUNCH_CHECK();
     return 0;
 }
+S2AG_DET_HOOK(conv_c1)

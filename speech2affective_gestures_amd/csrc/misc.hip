@@ -1026,11 +1026,15 @@ extern "C" int s2ag_det_hook_conv_gemm(int*);
 extern "C" int s2ag_det_hook_gemm_lin(int*);
 extern "C" int s2ag_det_hook_norm_elementwise(int*);
 extern "C" int s2ag_det_hook_wgrad_tr(int*);
+extern "C" int s2ag_det_hook_conv_bf16(int*);
+extern "C" int s2ag_det_hook_conv_c1(int*);
 extern "C" int s2ag_set_deterministic(int* zero_device_word) {
     int rc = s2ag_det_hook_misc(zero_device_word);
     if (!rc) rc = s2ag_det_hook_conv_gemm(zero_device_word);
     if (!rc) rc = s2ag_det_hook_gemm_lin(zero_device_word);
     if (!rc) rc = s2ag_det_hook_norm_elementwise(zero_device_word);
     if (!rc) rc = s2ag_det_hook_wgrad_tr(zero_device_word);
+    if (!rc) rc = s2ag_det_hook_conv_bf16(zero_device_word);
+    if (!rc) rc = s2ag_det_hook_conv_c1(zero_device_word);
     return rc;
 }

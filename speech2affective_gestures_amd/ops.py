@@ -1928,7 +1928,7 @@ def set_deterministic(on: bool, device=None) -> None:
     workgroup index (s2ag_set_deterministic: csrc/s2ag_common.h det_enter / det_leave / det_wave_ordered) and weight-gradient
     kernels stay on the stream of their backward pass.  The trainer additionally runs the passes of a step on ONE stream
     (Processor(..., deterministic=True)): two runs from the same state then give bit-identical gradients and weights, at
-    the price of serialised accumulation phases.  fp32 mode."""
+    the price of serialised accumulation phases.  Both precision modes."""
     global ASYNC_WGRAD
     dev = torch.device('cuda' if device is None else device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()

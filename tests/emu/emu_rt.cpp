@@ -230,7 +230,20 @@ void run_block(Worker* w, long long lin) {
                 sched_yield();
                 spin_streak = 0;
             }
-            cur_wave = wrapped ? (wv + 1) % b.nwaves : wv;
+            if (wrapped) {
+                // every lane of this wavefront has polled once: hand over to the NEXT wavefront that can run, in the mode's own
+                // direction (mode 2 searches downwards: stepping up by one and searching down came straight back here and
+                // starved every other wavefront -- a cooperative-GRU gather under the reversed schedule never ended)
+                const int dir = g_sched_mode == 2 ? -1 : 1;
+                int nxt = wv;
+                for (int k = 1; k < b.nwaves; ++k) {
+                    const int c = ((wv + dir * k) % b.nwaves + b.nwaves) % b.nwaves;
+                    if (w->runnable[c] > 0) { nxt = c; break; }
+                }
+                cur_wave = nxt;
+            } else {
+                cur_wave = wv;
+            }
             continue;
         }
         spin_streak = 0;

@@ -367,15 +367,16 @@ def test_hip_graph_replay_equals_eager(monkeypatch, gan):
             assert ok, (k, info)
 
 
-@pytest.mark.parametrize('hidden,B', [(32, 6), (300, 33)])
-def test_deterministic_mode_two_runs_are_bit_identical(monkeypatch, hidden, B):
+@pytest.mark.parametrize('hidden,B,mode', [(32, 6, 'fp32'), (300, 33, 'fp32'), (300, 6, 'bf16')])
+def test_deterministic_mode_two_runs_are_bit_identical(monkeypatch, hidden, B, mode):
     """Deterministic mode (config switch DETERMINISTIC / Processor(deterministic=True); csrc/s2ag_common.h det_enter /
     det_leave / det_wave_ordered): two runs of the same two GAN steps from the same state leave EVERY weight, every
     gradient, every BatchNorm running statistic and every logged loss bit-identical -- where the default mode differs in
     the last bits of ~95 % of the tensors (fp32 atomics arrive in another order) and the replay test above has to allow for
     what Adam makes of that.  H = 300 goes through the cooperative GRU, the clip-resident TCN and the transpose-read weight
-    gradients; on the CPU device model (tests/emu) the second run additionally uses another wavefront schedule."""
-    from speech2affective_gestures_amd import noise, ops
+    gradients; 'bf16': the Conv1d path in bf16 mode (csrc/conv_bf16.hip, tcn_fused.hip, wgrad_tr.hip); on the CPU device model
+    (tests/emu) the second run additionally uses another wavefront schedule."""
+    from speech2affective_gestures_amd import bf16, noise, ops
     from speech2affective_gestures_amd import processor_v2 as P
     n_words, n_spk, s0 = 64, 12, 9300
     perm = torch.arange(B - 1, -1, -1).cuda()
@@ -394,9 +395,10 @@ def test_deterministic_mode_two_runs_are_bit_identical(monkeypatch, hidden, B):
         assert pr.deterministic and not pr.overlap_passes and ops.deterministic()
         noise.manual_seed(STEP_SEED)
         losses = []
-        for b in batches:
-            pr.forward_pass_s2ag(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'], True)
-            losses.append(dict(pr.last_losses))
+        with bf16.precision(mode):
+            for b in batches:
+                pr.forward_pass_s2ag(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'], True)
+                losses.append(dict(pr.last_losses))
         out = {}
         for tag, mod in (('G', pr.s2ag_generator), ('D', pr.s2ag_discriminator)):
             for k, p in mod.named_parameters():
