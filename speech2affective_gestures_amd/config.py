@@ -105,8 +105,8 @@ def push_to_library(lib) -> None:
 
 
 def set_value(name: str, value):
-    """Set a switch in process; returns the previous value.  (Module-level mirrors -- wave12.ENABLED, ops.BN_FUSED, ... --
-    are refreshed by the modules' own ``_refresh`` hooks registered with ``on_change``.)"""
+    """Set a switch in process; returns the previous value.  Module-level mirrors (wave12.ENABLED, ops.BN_FUSED, ...: see
+    ``mirror``) follow through ``on_change``; switches the C library consumes are pushed through ``s2ag_set_option``."""
     sw = REGISTRY[name]
     prev = get(name)
     _values[name] = value

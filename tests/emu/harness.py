@@ -130,10 +130,6 @@ class _DeviceRewrite(TorchFunctionMode):
         return func(*args, **kwargs)
 
 
-_CPU = torch.device('cpu')
-_real_device = torch.device
-
-
 def install():
     global _ACTIVE
     if _ACTIVE:
