@@ -308,9 +308,10 @@ class Processor(object):
         self.dp.sync_error_flag(ops.coop_error_flag(self.device))
 
     def save_model(self, epoch, loss):
-        # never write weights of a run whose sticky error word is raised ON ANY RANK (the fused Adam already refuses to step
-        # then, on every rank alike); every rank calls save_model, so the reduction is a matched collective
-        self._sync_error_flag()
+        # never write weights of a run whose sticky error word is raised ON ANY RANK: the word was MAX-reduced over the ranks
+        # before the last Adam launch of the last step (and the fused Adam refused to step on every rank alike), so the local
+        # word IS the reduced one here.  No collective in this method: which ranks reach it depends on their own validation
+        # loss (train(): s2ag_loss_updated), and an unmatched collective would hang the others.
         flag = ops.coop_error_flag(self.device)
         if flag is not None:
             ops.check_coop_flag(flag.item())
