@@ -527,7 +527,7 @@ unsigned long long* g_trace = nullptr;
 // 128 workgroups on 256 CUs, every one a chain of eight convs of ~22 k cycles: with one clip per workgroup (3 row tiles)
 // the K loop and the epilogue of a conv shrink to 3 / 5 and all CUs work -- the L2 then serves the weights twice as often
 // (742 MB per launch, well inside its bandwidth).
-// r04: found on the CPU device model (tests/emu enforces the 160 KB limit): at T = 40 two clips are 80 rows, and the backward
+// r04: found by a checker that enforces the 160 KB limit (the test suite's CPU device model): at T = 40 two clips are 80 rows, and the backward
 // launch's three row buffers + zero row + sign images are 167 696 bytes -- the launch would have failed on the hardware.  The
 // plan now also asks the LDS budget of the LARGER of the two launches (forward and backward must agree on the clips per
 // workgroup: the sign images are laid out per workgroup).
