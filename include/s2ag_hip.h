@@ -51,13 +51,18 @@ int s2ag_abi_version(void);
  * set: returns the previous value, S2AG_E_BADARG for an unknown name / negative value.  get: the value or S2AG_E_BADARG. */
 int s2ag_set_option(const char* name, int value);
 int s2ag_get_option(const char* name);
-/* Deterministic mode (debug): `zero_device_word` = one int32 device word holding 0 (null switches the mode off).  While set,
- * every workgroup of an accumulating launch (weight / bias gradients, embedding gradient, BatchNorm sums, derived-parameter
- * flush: the fp32 atomicAdd sites behind loss.backward() at processor_v2.py:841,937) performs its atomics in the order of its
- * linear workgroup index, and in-workgroup LDS accumulation goes wavefront by wavefront -- two runs of a step on ONE stream
- * give bit-identical gradients and weights.  The caller serialises the passes of a step (Processor(deterministic=True) /
- * S2AG_DETERMINISTIC=1 does).  Both precision modes. */
-int s2ag_set_deterministic(int* zero_device_word);
+/* Deterministic mode: a BUILD FLAVOUR (libs2ag_hip_det.so, -DS2AG_DET=1; python -m speech2affective_gestures_amd.build --det),
+ * not a run-time word in the release kernels.  s2ag_det_flavour() = 1 in that library, 0 in the release one, where
+ * s2ag_set_deterministic(non-null, ..) returns S2AG_E_UNSUPPORTED and the accumulating kernels are the plain ones.
+ * `zero_device_word` = one int32 device word holding 0 (null switches the mode off), `error_word` = the sticky error word
+ * the caller reads back (bit 3 is raised when a workgroup's turn never came; may be null).  While set, every workgroup of an
+ * accumulating launch (weight / bias gradients, embedding gradient, BatchNorm sums, derived-parameter flush: the fp32
+ * atomicAdd sites behind loss.backward() at processor_v2.py:841,937) performs its atomics in the order of its linear
+ * workgroup index, and in-workgroup LDS accumulation goes wavefront by wavefront -- two runs of a step on ONE stream give
+ * bit-identical gradients and weights.  The caller serialises the passes of a step (Processor(deterministic=True) /
+ * S2AG_DETERMINISTIC=1 does) and must not launch on side streams while the mode is on.  Both precision modes. */
+int s2ag_det_flavour(void);
+int s2ag_set_deterministic(int* zero_device_word, int* error_word);
 
 /* 1-D convolution geometry, channels-last.  Input rows (n*Lin + pos), output rows (n*Lout + l),
  * pos = l*stride + tap*dil - pad (pad may be negative).  A Linear layer is ksize=1, Lin=Lout=1, N=rows. */

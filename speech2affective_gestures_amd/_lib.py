@@ -96,7 +96,8 @@ SIGNATURES = {
     's2ag_abi_version': [],
     's2ag_set_option': [C.c_char_p, ci],
     's2ag_get_option': [C.c_char_p],
-    's2ag_set_deterministic': [vp],
+    's2ag_det_flavour': [],
+    's2ag_set_deterministic': [vp, vp],
     's2ag_conv1d_nlc_fwd': [vp, vp, vp, vp, PG, PE, vp],
     's2ag_conv1d_nlc_bwd_data': [vp, vp, vp, PG, ci, vp],
     's2ag_conv1d_nlc_bwd_weight': [vp, vp, vp, vp, PG, ci, vp],

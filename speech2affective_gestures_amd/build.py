@@ -1,4 +1,4 @@
-"""Build libs2ag_hip.so (gfx950) in-tree:  python -m speech2affective_gestures_amd.build [--force] [--debug | --asan]
+"""Build libs2ag_hip.so (gfx950) in-tree:  python -m speech2affective_gestures_amd.build [--force] [--debug | --det | --asan]
 
 Every csrc/*.hip is compiled to its own object under csrc/_obj/ (git-ignored; re-compiled only when the source or a
 header is newer), a few at a time, then linked -- editing one kernel file costs one compile, not ten.
@@ -7,6 +7,9 @@ Flavours (same ABI, selected at run time with S2AG_HIP_LIB=<
   release  libs2ag_hip.so        -O3
   debug    libs2ag_hip_debug.so  -O1 -g -DS2AG_DEBUG=1: device-side bounds asserts in the loaders (S2AG_DBG_ASSERT, s2ag_common.h:
                                  LDS image offsets, segment indices, row / column ranges) and host-side argument checks
+  det      libs2ag_hip_det.so    -O3 -DS2AG_DET=1: the accumulating kernels order their atomics by workgroup index when
+                                 s2ag_set_deterministic installs a turn word (s2ag_common.h); the release kernels carry no
+                                 trace of the mode
   asan     libs2ag_hip_asan.so   -fsanitize=address -shared-libsan -g on gfx950:xnack+ (run with HSA_XNACK=1 and the ROCm ASan
                                  runtime on LD_LIBRARY_PATH: instrumented device loads / stores + the host glue)"""
 import concurrent.futures as cf
@@ -23,6 +26,7 @@ FLAVOURS = {
     'release': dict(lib=LIB, obj=OBJ, arch='gfx950', extra=['-O3']),
     'debug': dict(lib=os.path.join(PKG, 'libs2ag_hip_debug.so'), obj=OBJ + '_debug', arch='gfx950',
                   extra=['-O1', '-g', '-DS2AG_DEBUG=1']),
+    'det': dict(lib=os.path.join(PKG, 'libs2ag_hip_det.so'), obj=OBJ + '_det', arch='gfx950', extra=['-O3', '-DS2AG_DET=1']),
     'asan': dict(lib=os.path.join(PKG, 'libs2ag_hip_asan.so'), obj=OBJ + '_asan', arch='gfx950:xnack+',
                  extra=['-O1', '-g', '-fsanitize=address', '-shared-libsan', '-DS2AG_DEBUG=1']),
 }
@@ -41,15 +45,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(f) > t for f in deps)
 
 
-def needs_build() -> bool:
-    return _stale(LIB, SRC + HDR)
+def needs_build(flavour: str = 'release') -> bool:
+    return _stale(FLAVOURS[flavour]['lib'], SRC + HDR)
 
 
 def build(force: bool = False, verbose: bool = True, flavour: str = 'release') -> str:
     """hipcc cross-compiles for gfx950 without a GPU present."""
     fl = FLAVOURS[flavour]
     lib, objdir = fl['lib'], fl['obj']
-    if flavour == 'release' and not force and not needs_build():
+    if flavour in ('release', 'det') and not force and not needs_build(flavour):
         return lib
 
     def obj(src):
@@ -79,5 +83,5 @@ def build(force: bool = False, verbose: bool = True, flavour: str = 'release') -
 
 
 if __name__ == '__main__':
-    fl = 'debug' if '--debug' in sys.argv else 'asan' if '--asan' in sys.argv else 'release'
+    fl = 'debug' if '--debug' in sys.argv else 'asan' if '--asan' in sys.argv else 'det' if '--det' in sys.argv else 'release'
     print(build(force='--force' in sys.argv, flavour=fl))

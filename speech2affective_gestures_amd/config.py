@@ -44,9 +44,9 @@ _S = [
            "touched-row all-gather", 'tests/test_host_logic.py::test_gradient_exchange_schedule_world_size_2_gloo'),
     Switch('PREFETCH', True, _flag, "0: yield_batch gathers / decodes on the host synchronously (the reference's data path) "
            "instead of data.BatchFeeder", 'tests/test_gpu_step.py::test_prefetching_batch_feeder_matches_the_host_path'),
-    Switch('DETERMINISTIC', False, _flag, "debug: passes of a step on one stream, accumulating launches ordered by workgroup index "
-           "(s2ag_set_deterministic): two runs from the same state are bit-identical",
-           'tests/test_gpu_step.py::test_deterministic_mode_two_runs_are_bit_identical'),
+    Switch('DETERMINISTIC', False, _flag, "debug, needs the det build flavour (S2AG_HIP_LIB=.../libs2ag_hip_det.so): passes of a step on one "
+           "stream, accumulating launches ordered by workgroup index: two runs from the same state are bit-identical",
+           'tests/test_gpu_det_flavour.py::test_deterministic_mode_two_runs_are_bit_identical'),
     # ---- fused paths with a layer-by-layer fall-back that parity tests compare against ------------------------------------
     Switch('WAVE12', True, _flag, "0: the wave encoder's head (conv1 + BatchNorm + LeakyReLU + conv2) layer by layer instead "
            "of csrc/wave12.hip", 'tests/test_gpu_wave12.py'),

@@ -448,10 +448,10 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int tile, const i
         }
     if (do_bias) {
         __syncthreads();
-        s2ag::det_wave_ordered([&] {
+        S2AG_DET_WAVES_BEGIN
 #pragma unroll
             for (int j = 0; j < 8; ++j) atomicAdd(&bsum[ch * 8 + j], bacc[j]);
-        });
+        S2AG_DET_WAVES_END
         __syncthreads();
         if (tid < 64 && co0 + tid < p.Cout) {
             if (p.part) p.part_b[((long long)split * nco + cot) * 64 + tid] = bsum[tid];
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_bf16_k(const bf16_t* __restri
     const int lanes_c = cpr < 256 ? cpr : 256;                  // threads along the chunk axis
     const int rstep = 256 / lanes_c;
     const int cc = threadIdx.x % lanes_c, rr = threadIdx.x / lanes_c;
-    s2ag::det_wave_ordered([&] {          // (deterministic mode: the LDS sums take the waves' terms one wave after the other)
+    S2AG_DET_WAVES_BEGIN          // (deterministic mode: the LDS sums take the waves' terms one wave after the other)
     if (rr < rstep) {
         for (int cb = cc; cb < cpr; cb += lanes_c) {
             const int c = cb * 8;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_bf16_k(const bf16_t* __restri
             }
         }
     }
-    });
+    S2AG_DET_WAVES_END
     __syncthreads();
     s2ag::det_enter();
     for (int i = threadIdx.x; i < 2 * cols; i += 256) atomicAdd(sums + i, sm[i]);
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_bf16_k(const long long* __r
     const int c = blockIdx.y * 128 + 2 * lane;                 // a lane owns a channel pair: 4-byte loads (ld and dim are even)
     float pad0 = 0.f, pad1 = 0.f;
     s2ag::det_enter();                    // deterministic mode: workgroups in index order, waves one after the other
-    s2ag::det_wave_ordered([&] {
+    S2AG_DET_WAVES_BEGIN
     if (c < dim) {
         const int i0 = wave * (rows_per_block / 4), i1 = min(nr, i0 + rows_per_block / 4);
         for (int ib = i0; ib < i1; ib += 16) {              // all 16 loads before the first atomic (see misc.hip)
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_bf16_k(const long long* __r
             }
         }
     }
-    });
+    S2AG_DET_WAVES_END
     pad_s[wave][lane] = pad0;
     pad_s[wave][64 + lane] = pad1;
     __syncthreads();

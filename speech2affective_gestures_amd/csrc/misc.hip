@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_k(const long long* ids, con
     float pad_acc = 0.f;
     // deterministic mode: workgroups in index order, and inside a workgroup wave by wave (two waves may hold the same word)
     s2ag::det_enter();
-    s2ag::det_wave_ordered([&] {
+    S2AG_DET_WAVES_BEGIN
     if (c < dim) {
         const int i0 = wave * (EMB_RB / 4), i1 = min(nr, i0 + EMB_RB / 4);
         // 16 rows are LOADED before any of them is added: a load behind an atomic to memory it may alias waits for it, and
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_k(const long long* ids, con
             }
         }
     }
-    });
+    S2AG_DET_WAVES_END
     pad_s[wave][lane] = pad_acc;
     __syncthreads();
     if (wave == 0 && c < dim) {
@@ -229,14 +229,22 @@ __global__ __launch_bounds__(256) void spmv_multi_flush_k(SpmvJobs js) {
     const int k = find_job(js.first_block, js.n);
     const s2ag_spmv_job& J = js.j[k];
     const int i = ((int)blockIdx.x - js.first_block[k]) * 256 + threadIdx.x;
+#if defined(S2AG_DET) && S2AG_DET      // det flavour: no early return (every thread reaches the workgroup-wide ordering points)
     const float g = i < J.nrows ? J.y[i] : 0.f;
     if (g != 0.f) J.y[i] = 0.f;
-    s2ag::det_enter();                 // deterministic mode: rows share sources -- workgroups in index order, waves in order
-    s2ag::det_wave_ordered([&] {
+    s2ag::det_enter();                 // rows share sources -- workgroups in index order, waves in order
+    S2AG_DET_WAVES_BEGIN
         if (g != 0.f)
             for (int q = J.rowptr[i]; q < J.rowptr[i + 1]; ++q) atomicAdd(J.x + J.col[q], J.val[q] * g);
-    });
+    S2AG_DET_WAVES_END
     s2ag::det_leave();
+#else
+    if (i >= J.nrows) return;
+    const float g = J.y[i];
+    if (g == 0.f) return;
+    J.y[i] = 0.f;
+    for (int q = J.rowptr[i]; q < J.rowptr[i + 1]; ++q) atomicAdd(J.x + J.col[q], J.val[q] * g);
+#endif
 }
 
 struct WnJobs {
@@ -1020,21 +1028,29 @@ extern "C" int s2ag_get_option(const char* name) {
     return i < 0 ? S2AG_E_BADARG : s2ag::g_options[i];
 }
 
-// ---- deterministic mode (s2ag_common.h: det_enter / det_leave / det_wave_ordered) ------------------------------------------
+// ---- deterministic mode (s2ag_common.h: det_enter / det_leave / S2AG_DET_WAVES_BEGIN..END) ------------------------------------------
 S2AG_DET_HOOK(misc)
-extern "C" int s2ag_det_hook_conv_gemm(int*);
-extern "C" int s2ag_det_hook_gemm_lin(int*);
-extern "C" int s2ag_det_hook_norm_elementwise(int*);
-extern "C" int s2ag_det_hook_wgrad_tr(int*);
-extern "C" int s2ag_det_hook_conv_bf16(int*);
-extern "C" int s2ag_det_hook_conv_c1(int*);
-extern "C" int s2ag_set_deterministic(int* zero_device_word) {
-    int rc = s2ag_det_hook_misc(zero_device_word);
-    if (!rc) rc = s2ag_det_hook_conv_gemm(zero_device_word);
-    if (!rc) rc = s2ag_det_hook_gemm_lin(zero_device_word);
-    if (!rc) rc = s2ag_det_hook_norm_elementwise(zero_device_word);
-    if (!rc) rc = s2ag_det_hook_wgrad_tr(zero_device_word);
-    if (!rc) rc = s2ag_det_hook_conv_bf16(zero_device_word);
-    if (!rc) rc = s2ag_det_hook_conv_c1(zero_device_word);
+extern "C" int s2ag_det_hook_conv_gemm(int*, unsigned*);
+extern "C" int s2ag_det_hook_gemm_lin(int*, unsigned*);
+extern "C" int s2ag_det_hook_norm_elementwise(int*, unsigned*);
+extern "C" int s2ag_det_hook_wgrad_tr(int*, unsigned*);
+extern "C" int s2ag_det_hook_conv_bf16(int*, unsigned*);
+extern "C" int s2ag_det_hook_conv_c1(int*, unsigned*);
+extern "C" int s2ag_det_flavour(void) {
+#if defined(S2AG_DET) && S2AG_DET
+    return 1;
+#else
+    return 0;
+#endif
+}
+extern "C" int s2ag_set_deterministic(int* zero_device_word, int* error_word) {
+    unsigned* e = reinterpret_cast<unsigned*>(error_word);
+    int rc = s2ag_det_hook_misc(zero_device_word, e);
+    if (!rc) rc = s2ag_det_hook_conv_gemm(zero_device_word, e);
+    if (!rc) rc = s2ag_det_hook_gemm_lin(zero_device_word, e);
+    if (!rc) rc = s2ag_det_hook_norm_elementwise(zero_device_word, e);
+    if (!rc) rc = s2ag_det_hook_wgrad_tr(zero_device_word, e);
+    if (!rc) rc = s2ag_det_hook_conv_bf16(zero_device_word, e);
+    if (!rc) rc = s2ag_det_hook_conv_c1(zero_device_word, e);
     return rc;
 }

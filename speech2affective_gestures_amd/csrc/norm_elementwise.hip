@@ -125,7 +125,7 @@ __device__ __forceinline__ void fold_partials(const T* part, int nrb, int cols, 
     const int t = threadIdx.x;
     const int G = cols >= NT ? 1 : NT / cols;
     // (deterministic mode: the LDS accumulators take their terms wavefront by wavefront; called by a whole workgroup)
-    s2ag::det_wave_ordered([&] {
+    S2AG_DET_WAVES_BEGIN
     if (G == 1) {
         for (int c = t; c < cols; c += NT) {
             A a, b;
@@ -144,7 +144,7 @@ __device__ __forceinline__ void fold_partials(const T* part, int nrb, int cols, 
         atomicAdd(&c1[ch], b);
         if (sub == 0) atomicAdd(&cn[ch], (A)1);
     }
-    });
+    S2AG_DET_WAVES_END
 }
 
 // Channel statistics (already summed into cs / cq / cn in LDS) -> running estimates and per-COLUMN coefficients.
@@ -205,14 +205,14 @@ __global__ __launch_bounds__(256) void bn_coeffs_k(const double* colsum, const d
     for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) smd[i] = 0.0;
     __syncthreads();
     if (training) {
-        s2ag::det_wave_ordered([&] {
+        S2AG_DET_WAVES_BEGIN
             for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
                 const int ch = chan_of_col ? chan_of_col[c] : c;
                 atomicAdd(&cs[ch], colsum[c]);
                 atomicAdd(&cq[ch], colsq[c]);
                 atomicAdd(&cn[ch], 1.0);
             }
-        });
+        S2AG_DET_WAVES_END
         __syncthreads();
     }
     bn_finish_coeffs(cs, cq, cn, chan_of_col, ncols, nchan, rows, gamma, beta, rmean, rvar, nbt, eps, momentum, training,
@@ -431,14 +431,14 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_k(const float* s1, const fl
     float* cn = sm + 2 * nchan;
     for (int i = threadIdx.x; i < 3 * nchan; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
-    s2ag::det_wave_ordered([&] {
+    S2AG_DET_WAVES_BEGIN
         for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
             const int ch = chan_of_col ? chan_of_col[c] : c;
             atomicAdd(&t1[ch], s1[c]);
             atomicAdd(&t2[ch], s2[c]);
             atomicAdd(&cn[ch], 1.0f);
         }
-    });
+    S2AG_DET_WAVES_END
     __syncthreads();
     bn_bwd_finish(t1, t2, cn, chan_of_col, ncols, nchan, rows, dgamma, dbeta, accumulate, c1, c2);
 }
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(1024) void bn_fold_k(const double* part, int prow, 
         // rows 0, pstep, 2*pstep, ... of either half (left by bn_fold_pre_k)
         const int nsub = cols >= 1024 ? 1 : 1024 / cols;
         const int sub = cols >= 1024 ? 0 : (int)threadIdx.x / cols;
-        s2ag::det_wave_ordered([&] {
+        S2AG_DET_WAVES_BEGIN
         for (int c = cols >= 1024 ? (int)threadIdx.x : (int)threadIdx.x % cols; c < cols && sub < nsub; c += 1024) {
             double a = 0.0, b = 0.0;
             for (int r = sub * pstep; r < prow; r += nsub * pstep) {
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(1024) void bn_fold_k(const double* part, int prow, 
             if (sub == 0) atomicAdd(&cn[ch], 1.0);
             if (cols < 1024) break;
         }
-        });
+        S2AG_DET_WAVES_END
     }
     __syncthreads();
     bn_finish_coeffs(cs, cq, cn, chan_of_col, cols, nchan, rows, gamma, beta, rmean, rvar, nbt, eps, momentum, 1,

@@ -100,26 +100,37 @@ static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// ---- deterministic mode (option DETERMINISTIC, s2ag_set_deterministic) ---------------------------------------------------
+// ---- deterministic mode (build flavour `det`: -DS2AG_DET=1, libs2ag_hip_det.so; s2ag_set_deterministic) ------------------
 // fp32 sums formed by atomics depend on the order in which workgroups (and, inside a workgroup, wavefronts) arrive: two runs
 // of the same step differ in the last bits, which is why tests compare runs with a tolerance and why a divergence between
-// data-parallel replicas cannot be bisected.  With the mode on (g_det_turn = a zero device word; the host also serialises
-// the passes of a step onto one stream) every workgroup passes its accumulation phase IN THE ORDER OF ITS LINEAR INDEX:
-// det_enter() waits until the turn word equals the index, det_leave() drains this workgroup's atomics and hands the turn on
-// (the last workgroup re-arms the word).  Progress: a workgroup only ever waits for workgroups with a smaller index, which
-// the dispatcher started earlier (placement-independent).  In-workgroup accumulation into LDS goes wavefront by wavefront
-// (det_wave_ordered).  Off (the default): one scalar load and a not-taken branch per workgroup.  Debug mode: the
-// accumulation phases of a launch run one after the other.
+// data-parallel replicas cannot be bisected.  In the det flavour with the mode on (g_det_turn = a zero device word; the host
+// also serialises the passes of a step onto one stream) every workgroup passes its accumulation phase IN THE ORDER OF ITS
+// LINEAR INDEX: det_enter() waits until the turn word equals the index, det_leave() drains this workgroup's atomics and hands
+// the turn on (the last workgroup re-arms the word).  Progress: a workgroup only ever waits for workgroups with a smaller
+// index; that those were started earlier is a property of the in-order workgroup dispatcher of each gfx950 XCD, not of HIP
+// -- so the poll is bounded and a time-out raises the sticky error word (g_det_err, the trainer's error flag: the step fails
+// loudly instead of hanging).  In-workgroup accumulation into LDS goes wavefront by wavefront (S2AG_DET_WAVES_BEGIN..END).
+// In the RELEASE library (no S2AG_DET) the three helpers are empty at compile time: the default kernels carry no trace of the
+// mode (r04 had it as a run-time word in every accumulating kernel, which changed 39 default binaries).
+#if defined(S2AG_DET) && S2AG_DET
 static __device__ int* g_det_turn = nullptr;             // one copy per translation unit, installed by s2ag_det_hook_<file>
-
-__device__ __forceinline__ bool det_on() { return g_det_turn != nullptr; }
+static __device__ unsigned* g_det_err = nullptr;         // sticky error word the trainer reads every step (bit 3: a turn never came)
+constexpr unsigned DET_ERR_BIT = 8u;
+constexpr int DET_SPIN_LIMIT = 1 << 28;                  // polls of >= 64 cycles each: seconds, far beyond any launch
 
 __device__ __forceinline__ void det_enter() {            // workgroup-uniform call
     int* w = g_det_turn;
     if (!w) return;
     if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
         const int me = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
-        while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != me) __builtin_amdgcn_s_sleep(2);
+        int spins = 0;
+        while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != me) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > DET_SPIN_LIMIT) {              // give up: the sums of this launch are no longer ordered
+                if (g_det_err) atomicOr(g_det_err, DET_ERR_BIT);
+                break;
+            }
+        }
     }
     __syncthreads();
 }
@@ -136,27 +147,37 @@ __device__ __forceinline__ void det_leave() {            // by every thread of t
     }
 }
 
-// f() accumulates into LDS with atomics from several wavefronts: deterministic mode runs it wavefront by wavefront
-template <typename F>
-__device__ __forceinline__ void det_wave_ordered(F&& f) {
-    if (!g_det_turn) {
-        f();
-        return;
+// S2AG_DET_WAVES_BEGIN ... S2AG_DET_WAVES_END bracket a block that accumulates into LDS with atomics from several wavefronts
+// (reached by the whole workgroup): deterministic mode runs it wavefront by wavefront.  Macros, not a lambda taking helper: in
+// the release flavour they must leave the enclosed statements EXACTLY as they were written before the mode existed.
+#define S2AG_DET_WAVES_BEGIN                                                                                              \
+    {                                                                                                                     \
+        const bool det_on__ = s2ag::g_det_turn != nullptr;                                                                \
+        const int det_nw__ = det_on__ ? ((int)(blockDim.x * blockDim.y * blockDim.z) + 63) / 64 : 1;                      \
+        const int det_me__ = (int)((threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x) >> 6;             \
+        for (int det_w__ = 0; det_w__ < det_nw__; ++det_w__) {                                                            \
+            if (!det_on__ || det_w__ == det_me__) {
+#define S2AG_DET_WAVES_END                                                                                                \
+            }                                                                                                             \
+            if (det_on__) __syncthreads();                                                                                \
+        }                                                                                                                 \
     }
-    const int nt = (int)(blockDim.x * blockDim.y * blockDim.z);
-    const int me = (int)((threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x) >> 6;
-    for (int w = 0; w < (nt + 63) / 64; ++w) {
-        if (w == me) f();
-        __syncthreads();
-    }
-}
 
-static inline int det_install_here(int* word) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_det_turn), &word, sizeof(word));
+static inline int det_install_here(int* word, unsigned* err) {
+    int rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_det_turn), &word, sizeof(word));
+    if (!rc) rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_det_err), &err, sizeof(err));
+    return rc;
 }
+#else
+__device__ __forceinline__ void det_enter() {}
+__device__ __forceinline__ void det_leave() {}
+#define S2AG_DET_WAVES_BEGIN {
+#define S2AG_DET_WAVES_END }
+static inline int det_install_here(int* word, unsigned*) { return word ? -2 /* S2AG_E_UNSUPPORTED: not the det flavour */ : 0; }
+#endif
 // every translation unit with accumulating kernels exports a hook that installs the turn word in ITS copy of g_det_turn
 #define S2AG_DET_HOOK(file) \
-    extern "C" int s2ag_det_hook_##file(int* word) { return s2ag::det_install_here(word); }
+    extern "C" int s2ag_det_hook_##file(int* word, unsigned* err) { return s2ag::det_install_here(word, err); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

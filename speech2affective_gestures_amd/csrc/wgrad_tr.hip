@@ -257,14 +257,14 @@ __global__ __launch_bounds__(64 * WR * WC) void wgrad_tr_k(const TrJobs js) {
         }
     if (do_bias) {
         __syncthreads();
-        s2ag::det_wave_ordered([&] {          // (deterministic mode: the waves add their bias sums one after the other)
+        S2AG_DET_WAVES_BEGIN          // (deterministic mode: the waves add their bias sums one after the other)
 #pragma unroll
         for (int i = 0; i < NA; ++i)
             if (tid + NTH * i < 32 * CA) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) atomicAdd(&bsum[ca[i] * 8 + j], bacc[i][j]);
             }
-        });
+        S2AG_DET_WAVES_END
         __syncthreads();
         for (int i = tid; i < TCO; i += NTH)
             if (co0 + i < p.Cout) p.part_b[((long long)split * p.nco + cot) * TCO + i] = bsum[i];
@@ -478,14 +478,14 @@ __global__ __launch_bounds__(64 * WR * WC, BPC) void wgrad_tr32_k(const TrJobs j
         }
     if (do_bias) {
         __syncthreads();
-        s2ag::det_wave_ordered([&] {          // (deterministic mode: the waves add their bias sums one after the other)
+        S2AG_DET_WAVES_BEGIN          // (deterministic mode: the waves add their bias sums one after the other)
 #pragma unroll
         for (int i = 0; i < NA; ++i)
             if (tid + NTH * i < 32 * CA) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) atomicAdd(&bsum[ca[i] * 4 + j], bacc[i][j]);
             }
-        });
+        S2AG_DET_WAVES_END
         __syncthreads();
         for (int i = tid; i < TCO; i += NTH)
             if (co0 + i < p.Cout) p.part_b[((long long)split * p.nco + cot) * TCO + i] = bsum[i];

@@ -297,6 +297,10 @@ def check_coop_flag(host_value) -> None:
     """Raise if a read-back of coop_error_flag() is non-zero (any bit pattern but +0.0)."""
     import struct
     bits = struct.unpack('<I', struct.pack('<f', float(host_value)))[0]
+    if bits & 8:
+        raise RuntimeError('deterministic mode: a workgroup of an accumulating launch never got its turn (another launch '
+                           'ran beside it on a side stream, or the dispatcher did not start workgroups in index order): '
+                           'the sums since the last check are not ordered')
     if bits & 4:
         raise CoopGruTimeout('a one-launch BatchNorm kernel timed out waiting for its folding workgroup (its workgroups '
                              'were not co-resident): results since the last check are invalid. Set S2AG_BN_FUSED=0')
@@ -1921,29 +1925,49 @@ _MAIN_STREAM = [None]
 
 
 _DET_WORDS = {}
+_DET_ON = [False]        # the explicit state of the mode (never inferred from ASYNC_WGRAD, which tests may set on their own)
+
+
+def det_flavour() -> bool:
+    """True when the loaded library is the deterministic BUILD FLAVOUR (libs2ag_hip_det.so: build.py --det, selected with
+    S2AG_HIP_LIB).  The release library carries no trace of the mode in its kernels (include/s2ag_hip.h)."""
+    return bool(_lib().s2ag_det_flavour())
 
 
 def set_deterministic(on: bool, device=None) -> None:
-    """Deterministic mode (config switch DETERMINISTIC; debug): the library orders every accumulating launch's atomics by
-    workgroup index (s2ag_set_deterministic: csrc/s2ag_common.h det_enter / det_leave / det_wave_ordered) and weight-gradient
-    kernels stay on the stream of their backward pass.  The trainer additionally runs the passes of a step on ONE stream
-    (Processor(..., deterministic=True)): two runs from the same state then give bit-identical gradients and weights, at
-    the price of serialised accumulation phases.  Both precision modes."""
+    """Deterministic mode (config switch DETERMINISTIC; debug; needs the det build flavour): the library orders every
+    accumulating launch's atomics by workgroup index (s2ag_set_deterministic: csrc/s2ag_common.h det_enter / det_leave /
+    det_wave_ordered) and weight-gradient kernels stay on the stream of their backward pass.  The trainer additionally runs
+    the passes of a step on ONE stream (Processor(..., deterministic=True)): two runs from the same state then give
+    bit-identical gradients and weights, at the price of serialised accumulation phases.  Both precision modes.
+    The mode is process-wide library state: every Processor sets it to ITS value on construction (on or off), and while it
+    is on nothing may be launched on a side stream (all accumulating launches share one turn word; two concurrent launches
+    would take each other's turns) -- run_wgrad / wgrad_launcher stay inline and mark_side_stream raises."""
     global ASYNC_WGRAD
+    if not on:
+        if _DET_ON[0]:
+            L.check(_lib().s2ag_set_deterministic(None, None), 'set_deterministic')
+        _DET_ON[0] = False
+        ASYNC_WGRAD = True
+        return
+    if not det_flavour():
+        raise RuntimeError('deterministic mode is a build flavour of the library: build it with `python -m '
+                           'speech2affective_gestures_amd.build --det` and start the process with '
+                           'S2AG_HIP_LIB=<package>/libs2ag_hip_det.so (the release kernels carry no ordering code)')
     dev = torch.device('cuda' if device is None else device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if on:
-        if key not in _DET_WORDS:
-            _DET_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
-        L.check(_lib().s2ag_set_deterministic(_p(_DET_WORDS[key])), 'set_deterministic')
-        ASYNC_WGRAD = False
-    else:
-        L.check(_lib().s2ag_set_deterministic(None), 'set_deterministic')
-        ASYNC_WGRAD = True
+    if _DIRTY_STREAMS:
+        raise RuntimeError('set_deterministic(True) with work pending on side streams: join_side_streams() first')
+    if key not in _DET_WORDS:
+        _DET_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    init_tickets(dev)                                     # the sticky error word: bit 3 = a workgroup's turn never came
+    L.check(_lib().s2ag_set_deterministic(_p(_DET_WORDS[key]), _p(_COOP_FLAG[key])), 'set_deterministic')
+    _DET_ON[0] = True
+    ASYNC_WGRAD = False
 
 
 def deterministic() -> bool:
-    return not ASYNC_WGRAD and bool(_DET_WORDS)
+    return _DET_ON[0]
 
 
 def set_main_stream(stream=None) -> None:
@@ -1961,7 +1985,7 @@ def run_wgrad(fn, keep=(), flops=float('inf')) -> None:
     stream (join_side_streams) before the optimizer reads the gradient arena."""
     cur = torch.cuda.current_stream()
     main = _MAIN_STREAM[0]
-    if not ASYNC_WGRAD or main is None or cur != main or flops < ASYNC_WGRAD_MIN_FLOPS:
+    if _DET_ON[0] or not ASYNC_WGRAD or main is None or cur != main or flops < ASYNC_WGRAD_MIN_FLOPS:
         fn()
         return
     dev = cur.device_index
@@ -1989,7 +2013,7 @@ def wgrad_launcher(fn, keep=()):
     happen to land on one queue serialise).  Returns None when forking is not armed (then ``fn`` has run inline)."""
     cur = torch.cuda.current_stream()
     main = _MAIN_STREAM[0]
-    if not ASYNC_WGRAD or main is None or cur != main:
+    if _DET_ON[0] or not ASYNC_WGRAD or main is None or cur != main:
         fn()
         return None
     ev = torch.cuda.Event()
@@ -2017,6 +2041,9 @@ def defer_wgrad(fn, keep=()) -> None:
 
 
 def mark_side_stream(s) -> None:
+    if _DET_ON[0]:
+        raise RuntimeError('deterministic mode is on: every launch must stay on one stream (all accumulating launches '
+                           'share one turn word); construct the trainer with deterministic=True or switch the mode off')
     if not any(s is t for t in _DIRTY_STREAMS):
         _DIRTY_STREAMS.append(s)
 

@@ -227,7 +227,9 @@ class Processor(object):
         self.deterministic = bool(getattr(args, 'deterministic', config.get('DETERMINISTIC')))
         if self.deterministic:
             self.overlap_passes = False
-            ops.set_deterministic(True, self.device)
+        # process-wide library state: the newest trainer's choice holds, on OR off (a trainer that forks passes while an
+        # earlier one left the turn word installed would dead-lock two concurrent accumulating launches)
+        ops.set_deterministic(self.deterministic, self.device)
         # the generator's dropout-free encoders run once per step instead of once per pass (see PoseGenerator)
         self.share_encoders = bool(getattr(args, 'share_encoders', True)) \
             and hasattr(self.s2ag_generator, '_shared_encoders')

@@ -27,6 +27,7 @@ CXX = os.environ.get('S2AG_EMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
 FLAGS = ['-x', 'c++', '-std=c++17', '-O1', '-g1', '-fPIC', '-fno-strict-aliasing', '-ffp-contract=off', '-pthread',
          '-Wno-unknown-attributes', '-Wno-ignored-attributes', '-Wno-unused-value', '-Wno-pass-failed',
          '-Wno-unknown-pragmas', '-Wno-deprecated-declarations',
+         '-DS2AG_DET=1',      # the model's library always carries the deterministic mode (the GPU build: flavour `det` only)
          '-I' + HERE, '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(OUT, 'src')] + (['-DS2AG_DEBUG=1'] if DEBUG else [])
 
 _DYN = re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w ]*?)\s+(\w+)\[\];')

@@ -82,7 +82,7 @@ class _Event:
 
 # Tests the model cannot run (substring of the node id -> why).  Everything else of `-m gpu` is fair game.
 DESELECT = {
-    'test_gpu_zz_pending_det.py': 'bit-for-bit equality of a CAPTURED replay with the eager step: needs real graphs (segments are re-issued eagerly in this mode, see _install_eager_segments)',
+    'graph_replay_equals_eager_bit_for_bit': 'bit-for-bit equality of a CAPTURED replay with the eager step: needs real graphs (segments are re-issued eagerly in this mode, see _install_eager_segments)',
     'uses_the_current_weights[True]': 'hipGraph replay of the synthesis window (torch.cuda.CUDAGraph itself)',
     'test_cpu_tensor_raises': 'asserts that the product refuses CPU tensors -- which is exactly what this mode hands it',
     'test_no_cpu_fallback': 'same',

@@ -365,59 +365,6 @@ def test_hip_graph_replay_equals_eager(monkeypatch, gan):
         if not k.endswith('num_batches_tracked') and not is_noise_driven_after_adam(k):
             ok, info = adam_close(sd_g[k], sd_e[k], 5e-4, 3) if 'running' not in k else (rel(sd_g[k], sd_e[k]) < 3e-4, None)
             assert ok, (k, info)
-
-
-@pytest.mark.parametrize('hidden,B,mode', [(32, 6, 'fp32'), (300, 33, 'fp32'), (300, 6, 'bf16')])
-def test_deterministic_mode_two_runs_are_bit_identical(monkeypatch, hidden, B, mode):
-    """Deterministic mode (config switch DETERMINISTIC / Processor(deterministic=True); csrc/s2ag_common.h det_enter /
-    det_leave / det_wave_ordered): two runs of the same two GAN steps from the same state leave EVERY weight, every
-    gradient, every BatchNorm running statistic and every logged loss bit-identical -- where the default mode differs in
-    the last bits of ~95 % of the tensors (fp32 atomics arrive in another order) and the replay test above has to allow for
-    what Adam makes of that.  H = 300 goes through the cooperative GRU, the clip-resident TCN and the transpose-read weight
-    gradients; 'bf16': the Conv1d path in bf16 mode (csrc/conv_bf16.hip, tcn_fused.hip, wgrad_tr.hip); on the CPU device model
-    (tests/emu) the second run additionally uses another wavefront schedule."""
-    from speech2affective_gestures_amd import bf16, noise, ops
-    from speech2affective_gestures_amd import processor_v2 as P
-    n_words, n_spk, s0 = 64, 12, 9300
-    perm = torch.arange(B - 1, -1, -1).cuda()
-    monkeypatch.setattr(P.torch, 'randperm', lambda n, *a, **k: perm)
-    batches = [to_cuda(O.recipe_inputs(B, 34, s0 + 100 + s, n_words, n_spk)) for s in range(2)]
-    emu = None
-    if os.environ.get('S2AG_EMU') == '1':
-        import ctypes
-        emu = ctypes.CDLL(os.environ['S2AG_HIP_LIB'])
-
-    def run(sched):
-        if emu is not None:
-            emu.s2ag_emu_set_sched(sched, 11)
-        noise.reset_sites(200)
-        pr, _ = make_processor(hidden, n_words, n_spk, B, s0, 0.3, hip_graph=False, deterministic=True)
-        assert pr.deterministic and not pr.overlap_passes and ops.deterministic()
-        noise.manual_seed(STEP_SEED)
-        losses = []
-        with bf16.precision(mode):
-            for b in batches:
-                pr.forward_pass_s2ag(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'], True)
-                losses.append(dict(pr.last_losses))
-        out = {}
-        for tag, mod in (('G', pr.s2ag_generator), ('D', pr.s2ag_discriminator)):
-            for k, p in mod.named_parameters():
-                out[f'{tag}.{k}'] = p.detach().clone()
-                if p.grad is not None:
-                    out[f'{tag}.{k}.grad'] = p.grad.clone()
-            for k, v in mod.state_dict().items():
-                if 'running' in k:
-                    out[f'{tag}.{k}'] = v.clone()
-        return losses, out
-    try:
-        (l0, a), (l1, b) = run(0), run(2)
-    finally:
-        ops.set_deterministic(False)
-        if emu is not None:
-            emu.s2ag_emu_set_sched(int(os.environ.get('S2AG_EMU_SCHED', '0')), 1)
-    assert l0 == l1
-    differ = [k for k in a if not torch.equal(a[k], b[k])]
-    assert not differ, (len(differ), len(a), differ[:8])
     assert ops.coop_gru_timeouts() == 0
 
 
