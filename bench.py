@@ -552,7 +552,7 @@ def alt_modes(pr, dp, batch, B, steps=20):
     from speech2affective_gestures_amd import _lib as L
     lib = L.load()
     out = {}
-    prev = int(lib.s2ag_gru_coop_split_pieces())
+    prev = int(lib.s2ag_gru_coop_split_override())
     try:
         for pieces, tag in ((3, 'fp32_equivalent_3_bf16_pieces'), (0, 'f32_mfma_everywhere')):
             lib.s2ag_gru_coop_set_split_pieces(pieces)
@@ -560,7 +560,7 @@ def alt_modes(pr, dp, batch, B, steps=20):
             el = timed_steps(pr, dp, batch, steps, 2, False)
             out[tag] = dict(clips_per_s=B * dp.world_size * steps / el, ms_per_step=el / steps * 1e3, steps=steps)
     finally:
-        lib.s2ag_gru_coop_set_split_pieces(prev if prev in (0, 1, 2, 3) else -1)
+        lib.s2ag_gru_coop_set_split_pieces(prev)
         pr._graphed = None
     # BASELINE configs[1] names bf16: the same step with the Conv1d path (wave encoder, text TCN) in bf16 mode -- bf16
     # activations in HBM, fp32 accumulation / statistics / master weights (bf16.py; its own, looser parity tests)

@@ -45,9 +45,6 @@ int s2ag_abi_version(void);
  * the library is loaded, and tests flip them in-process.  Nothing in the reference corresponds (it has no native code);
  * what the options select are alternative kernels for the reference call sites cited at the entry points they affect.
  *   "GRU_SPLIT"      0 f32 MFMA | 1 | 2 (default) | 3 bf16 pieces per fp32 operand (nn.GRU, net/multimodal_context_net_v2.py:480)
- *   "TCN_RING_DEEP"  1: twice the weight fragments in flight in the clip-resident TCN launches (net/tcn.py:16-46)
- *   "W12_FWD_PIPE"   1: software-pipelined K loop in the wave head's fp32 forward (net/multimodal_context_net_v2.py:18-21)
- *   "EMB_FWD_ROWS"   1: row-form embedding forward (net/multimodal_context_net_v2.py:70-78)
  * set: returns the previous value, S2AG_E_BADARG for an unknown name / negative value.  get: the value or S2AG_E_BADARG. */
 int s2ag_set_option(const char* name, int value);
 int s2ag_get_option(const char* name);
@@ -354,7 +351,10 @@ int s2ag_gru_coop_split_pieces(void);
 /* 16-clip slices one forward workgroup alternates between (2 when B > 16 with the 3-piece products: while one slice's
  * new state travels to the peers the other slice is computed; a launch then occupies 10 * ceil(B/32) * 2 CUs) */
 int s2ag_gru_coop_fwd_slices(int B);
-int s2ag_gru_coop_set_split_pieces(int pieces /*0, 1, 2, 3; anything else: back to option GRU_SPLIT*/);  /* returns the previous value */
+/* an override of option GRU_SPLIT for an extent (precision contexts, tests): returns the previous OVERRIDE (-1: none), which
+ * is what a caller hands back to restore -- the effective count would pin the option */
+int s2ag_gru_coop_set_split_pieces(int pieces /*0, 1, 2, 3; anything else (-1): back to option GRU_SPLIT*/);
+int s2ag_gru_coop_split_override(void);       /* -1: none */
 long long s2ag_gru_coop_workspace_bytes(int B, int T, int H, int backward);
 int s2ag_gru_coop_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* ydrop, float* gates,
                       int B, int T, int H, const s2ag_epilogue* e /*host, nullable*/, void* workspace, void* stream);
@@ -551,34 +551,6 @@ int s2ag_wave_conv1_wgrad_blocks(const s2ag_conv_geom* g);
 int s2ag_wave_conv1_wgrad(const void* dz, const void* y1, const float* ca, const float* cb, const float* cc, const float* x,
                           float* partials, float* dw, float* db, const s2ag_conv_geom* g, void* stream);
 
-/* ---- the same folding for the fp32 mode: conv3 / conv4 of the wave encoder on fp32 rows (csrc/wave_fused.hip) ------------
- * feat_extractor.{4..9} of WavEncoder (net/multimodal_context_net_v2.py:22-27: BatchNorm1d(32) LeakyReLU(0.3)
- * Conv1d(32,64,15,stride 6) BatchNorm1d(64) LeakyReLU(0.3) Conv1d(64,32,15,stride 6)) and their backward, every tensor fp32
- * in HBM.  Forward products on the f32 matrix pipe (an fmaf chain: the reference's arithmetic); the two gradients take dy,
- * the activation and the weights as two bf16 pieces each (hi = rn(v), lo = rn(v - hi): three products, 16 mantissa bits,
- * as s2ag_f32_wgrad_tr).  (Cin, Cout) in {(32, 64), (64, 32)}.
- *   s2ag_wave_tail32_pack   w3 (64, 32, 15), w4 (32, 64, 15) -> one buffer of s2ag_wave_tail32_pack_bytes() bytes (16-byte
- *                           aligned): per layer the k-major fp32 matrix (15 Cin, Cout) of the forward and the phase form
- *                           (2 pieces, 6, Cin, 3, Cout) bf16 of the data gradient, at s2ag_wave_tail32_pack_offset(layer, phases)
- *   s2ag_wave_conv_fwd32    y = conv(leaky(in_scale x + in_shift)) + bias; stats / fold as s2ag_wave_conv_fwd
- *                           (partial rows: s2ag_wave_fwd_rows)
- *   s2ag_wave_conv_dgrad32  s2ag_wave_conv_dgrad on fp32 rows (g_is_dy: `dz` is dy itself -- the last conv)
- *   s2ag_wave_conv_wgrad32  s2ag_wave_conv_wgrad on fp32 rows (partials: s2ag_wave_wgrad_blocks) */
-long long s2ag_wave_tail32_pack_bytes(void);
-long long s2ag_wave_tail32_pack_offset(int layer /*0: conv3, 1: conv4*/, int phases /*0: k-major fp32, 1: phase form*/);
-int s2ag_wave_tail32_pack(const float* w3, const float* w4, void* out, void* stream);
-int s2ag_wave_conv_fwd32(const float* x, const float* in_scale, const float* in_shift, float slope, const float* w_kmajor,
-                         const float* bias, float* y, double* stats, const s2ag_bn_fold_args* fold, int N, int Lin, int Lout,
-                         int Cin, int Cout, void* stream);
-int s2ag_wave_conv_dgrad32(const float* dz, const float* y, const float* ca, const float* cb, const float* cc, int g_is_dy,
-                           const void* w_phases2, const float* y_prev, const float* p_scale, const float* p_shift,
-                           const float* p_mean, const float* p_invstd, float slope, float* dz_prev, double* stats, int* ticket,
-                           const float* p_gamma, float* dgamma, float* dbeta, float* out_ca, float* out_cb, float* out_cc, int N,
-                           int Lin, int Lout, int Cin, int Cout, void* stream);
-int s2ag_wave_conv_wgrad32(const float* dz, const float* y, const float* ca, const float* cb, const float* cc, int g_is_dy,
-                           const float* y_prev, const float* p_scale, const float* p_shift, float slope, float* partials,
-                           float* partials_b, float* dw, float* db, int N, int Lin, int Lout, int Cin, int Cout, void* stream);
-
 /* ---- head of the wave encoder without its (N, L1, 16) tensor in HBM (csrc/wave12.hip) ---------------------------------
  * Replaces feat_extractor[0..3] of WavEncoder (net/multimodal_context_net_v2.py:18-21: Conv1d(1,16,15,stride 5,padding)
  * BatchNorm1d(16) LeakyReLU(0.3) Conv1d(16,32,15,stride 6)) in training mode, forward and backward: conv1's output is
@@ -595,8 +567,7 @@ int s2ag_wave_conv_wgrad32(const float* dz, const float* y, const float* ca, con
  *                      as two bf16 pieces, three products); partials (nullable): (2, rows (+ ceil(rows / 16)), 32) doubles,
  *                      rows = s2ag_wave12_fwd_rows: column sums of z2 / z2^2; fold (nullable): BatchNorm 2's fold in the
  *                      same launch.
- *   s2ag_wave12_bwd    from dy2 = the gradient w.r.t. z2 -- fp32 rows (dz_f32 = 1), or ca2 dz + cc2 z2 + cb2 from bf16 rows
- *                      (dz_f32 = 0, bf16 mode) or from fp32 rows (dz_f32 = 2: the fp32 tail above it, same blocks as 1)
+ *   s2ag_wave12_bwd    from dy2 = the gradient w.r.t. z2 -- fp32 rows (dz_f32 = 1) or, in bf16 mode, ca2 dz + cc2 z2 + cb2
  *                      formed from the bf16 rows dz / z2 (wave_fused.hip) --: dw2 (32, 16, 15) +=,
  *                      dw1 (16, 1, 15) += (each nullable), dgamma1 / dbeta1 += (nullable), and ca1 / cb1 / cc1 (16 each:
  *                      dz1 = ca1 du1 + cc1 z1 + cb1, kept for inspection).  0 <= slope <= 1.  The gradients of the two biases are identically
@@ -667,10 +638,8 @@ int s2ag_wave12_bwd(const s2ag_wave12_bwd_args* a, void* stream);
  * counter-based ones of s2ag_conv1d_nlc_fwd (index row*C + channel, site[2*b + j]).
  * s2ag_bf16_tcn_clips_per_block: clips one workgroup holds (0: shape unsupported -- use the layer-by-layer kernels). */
 #define S2AG_TCN_MAX_BLOCKS 4
-#define S2AG_TCN32_MAX_PASSES 4
 typedef struct {
-    const void* x;                              /* bf16 (clips*T, 320): input of the first block (written by the forward
-                                                   launch when emb_ids is set) */
+    const void* x;                              /* bf16 (clips*T, 320): input of the first block */
     void* h1[S2AG_TCN_MAX_BLOCKS];              /* bf16 (clips*T, 320) each: written forward; the weight gradients' operands */
     void* sign[S2AG_TCN_MAX_BLOCKS];            /* s2ag_bf16_tcn_sign_bytes each: "h1 > 0", "h2 > 0", "y > 0" bits, written
                                                    forward, read backward */
@@ -690,15 +659,6 @@ typedef struct {
     /* forward only, drop_p > 0: workspace of s2ag_bf16_tcn_keep_bytes bytes (the pass's dropout keep bits, generated by a
      * launch of their own in front of the forward kernel) */
     void* keep;
-    /* forward only, optional (emb_ids != NULL): the first block's input is nn.Embedding(ids) + dropout
-     * (net/multimodal_context_net_v2.py:83-84), formed in the forward launch's loader exactly as s2ag_bf16_embedding_fwd forms
-     * it (same mask: `rng`, emb_site, index row * emb_dim + channel) -- `x` is then an OUTPUT (the rows the backward pass's
-     * weight gradient reads); emb_dim % 4 == 0, <= 320 */
-    const long long* emb_ids;                   /* (clips*T) token ids */
-    const float* emb_table;                     /* (emb_entries, emb_dim) fp32 */
-    int emb_dim, emb_entries;
-    float emb_drop_p;
-    unsigned emb_site;
 } s2ag_bf16_tcn_args;
 int s2ag_bf16_tcn_clips_per_block(int T, int C, int ksize);
 long long s2ag_bf16_tcn_sign_bytes(int n_clips, int T);  /* bytes of one block's sign buffer */
@@ -737,16 +697,6 @@ typedef struct {
     float* gx;
     float* gp1[S2AG_TCN_MAX_BLOCKS];
     float* gp2[S2AG_TCN_MAX_BLOCKS];
-    /* forward only, optional (emb_ids != NULL): the first block's input is nn.Embedding(ids) + dropout
-     * (net/multimodal_context_net_v2.py:83-84) formed in the forward launch's loader exactly as s2ag_embedding_fwd forms it
-     * (the table has C columns; mask: the pass's rng, emb_site, index row * C + channel with the row counted inside the pass)
-     * -- `x` is then an OUTPUT, written for the clips < save_clips only.  With s2ag_tcn32_fwd_passes the passes share the
-     * ids ((n_clips / n_passes) * T of them); at most S2AG_TCN32_MAX_PASSES passes. */
-    const long long* emb_ids;
-    const float* emb_table;                     /* (emb_entries, C) fp32, 16-byte aligned */
-    int emb_entries;
-    float emb_drop_p;
-    unsigned emb_site;
 } s2ag_tcn32_args;
 int s2ag_tcn32_supported(int T, int C, int ksize);
 long long s2ag_tcn32_pack_elems(int n_convs);

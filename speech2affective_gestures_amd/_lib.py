@@ -74,15 +74,13 @@ class BF16PackJob(C.Structure):   # s2ag_bf16_pack_job
 class BF16Tcn(C.Structure):       # s2ag_bf16_tcn_args
     _fields_ = [('x', vp), ('h1', vp * 4), ('sign', vp * 4), ('y', vp * 4), ('wfrag', vp), ('bias', vp * 8), ('dil', ci * 4),
                 ('n_blocks', ci), ('n_clips', ci), ('T', ci), ('C', ci), ('drop_p', cf), ('rng', vp), ('site', cu * 8),
-                ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4), ('keep', vp), ('emb_ids', vp), ('emb_table', vp),
-                ('emb_dim', ci), ('emb_entries', ci), ('emb_drop_p', cf), ('emb_site', cu)]
+                ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4), ('keep', vp)]
 
 
 class Tcn32(C.Structure):         # s2ag_tcn32_args
     _fields_ = [('x', vp), ('h1', vp * 4), ('h2', vp * 4), ('y', vp * 4), ('wfrag', vp), ('bias', vp * 8), ('dil', ci * 4),
                 ('n_blocks', ci), ('n_clips', ci), ('T', ci), ('C', ci), ('drop_p', cf), ('rng', vp), ('site', cu * 8),
-                ('keep', vp), ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4), ('emb_ids', vp), ('emb_table', vp),
-                ('emb_entries', ci), ('emb_drop_p', cf), ('emb_site', cu)]
+                ('keep', vp), ('gy', vp), ('gx', vp), ('gp1', vp * 4), ('gp2', vp * 4)]
 
 
 MAX_JOBS = 8
@@ -90,7 +88,6 @@ MAX_WGRAD_JOBS = 4
 BF16_MAX_PACK = 32
 BF16_MAX_WGRAD_JOBS = 8
 TCN_MAX_BLOCKS = 4
-TCN32_MAX_PASSES = 4
 
 SIGNATURES = {
     's2ag_abi_version': [],
@@ -148,6 +145,7 @@ SIGNATURES = {
     's2ag_gru_coop_split_pieces': [],
     's2ag_gru_coop_fwd_slices': [ci],
     's2ag_gru_coop_set_split_pieces': [ci],
+    's2ag_gru_coop_split_override': [],
     's2ag_gru_coop_workspace_bytes': [ci, ci, ci, ci],
     's2ag_gru_coop_fwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, PE, vp, vp],
     's2ag_gru_coop_fwd_multi_supported': [ci, ci, ci],
@@ -183,12 +181,6 @@ SIGNATURES = {
     's2ag_wave_wgrad_blocks': [ci, ci, ci, ci],
     's2ag_wave_conv_wgrad': [vp, vp, vp, vp, vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     's2ag_wave_bn_bwd_fold': [vp, ci, ci, cll, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    's2ag_wave_tail32_pack_bytes': [],
-    's2ag_wave_tail32_pack_offset': [ci, ci],
-    's2ag_wave_tail32_pack': [vp, vp, vp, vp],
-    's2ag_wave_conv_fwd32': [vp, vp, vp, cf, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
-    's2ag_wave_conv_dgrad32': [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
-    's2ag_wave_conv_wgrad32': [vp, vp, vp, vp, vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     's2ag_wave12_pack_elems': [],
     's2ag_wave12_pack': [vp, vp, vp, vp],
     's2ag_wave12_stats_rows': [ci, ci],
@@ -272,8 +264,7 @@ def load():
         fn.argtypes = args
         fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_gru_coop_fwd_multi_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes', 's2ag_bf16_tcn_keep_bytes',
                               's2ag_bf16_conv_wgrad_scratch_floats', 's2ag_bf16_conv_wgrad_tr_scratch_floats',
-                              's2ag_f32_wgrad_tr_scratch_floats', 's2ag_f32_wgrad_tr_scratch_floats_n', 's2ag_tcn32_pack_elems', 's2ag_tcn32_keep_bytes', 's2ag_wave_tail32_pack_bytes',
-                              's2ag_wave_tail32_pack_offset') else ci
+                              's2ag_f32_wgrad_tr_scratch_floats', 's2ag_f32_wgrad_tr_scratch_floats_n', 's2ag_tcn32_pack_elems', 's2ag_tcn32_keep_bytes') else ci
     if lib.s2ag_abi_version() != 1:
         raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
     if config.get('CRASH_TRACE'):     # native back trace on SIGSEGV & co (csrc/debug.hip)

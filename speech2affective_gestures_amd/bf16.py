@@ -458,27 +458,15 @@ class TcnFragments:
         return self._frag
 
 
-# the embedding gather + dropout in front of the clip-resident TCN done by its forward launch's loader (csrc/tcn_fused.hip,
-# GATHER): one launch and one pass over the (B, T, 320) rows less.  Written without access to a GPU: opt-in until run there.
-TCN_GATHER = config.mirror('TCN_GATHER', globals(), 'TCN_GATHER')
-
-
 class _TcnFused16(torch.autograd.Function):
     """x (N, T, 320) bf16 -> y (N, T, 320) bf16 through all TemporalBlocks.  ``params`` = the 2*nb normalised weights
-    (fp32 (C, 2, C) gradient stages) followed by the 2*nb biases.  With ``meta[3]`` = (emb_drop_p, emb_site): ``x`` is the
-    (N, T) int64 token ids and one more parameter follows, the embedding table -- the launch forms the rows itself."""
+    (fp32 (C, 2, C) gradient stages) followed by the 2*nb biases."""
 
     @staticmethod
     def forward(ctx, x, frags, meta, noise, *params):
-        dils, sites, drop_p = meta[:3]
-        emb = meta[3] if len(meta) > 3 else None
+        dils, sites, drop_p = meta
         nb = len(dils)
-        ws, bs = params[:2 * nb], params[2 * nb:4 * nb]
-        ids = table = None
-        if emb is not None:
-            ids, table = x.contiguous(), params[4 * nb]
-            assert ids.dim() == 2 and ids.dtype == torch.int64 and table.dtype == torch.float32 and table.is_contiguous()
-            x = torch.empty(ids.shape[0], ids.shape[1], 320, dtype=torch.bfloat16, device=ids.device)
+        ws, bs = params[:2 * nb], params[2 * nb:]
         x, rows, ld = _rows16(x)
         N, T = ctx_shape = x.shape[0], x.shape[1]
         assert ld == 320 and x.dim() == 3
@@ -501,26 +489,18 @@ class _TcnFused16(torch.autograd.Function):
         if drop_p > 0:
             keep = torch.empty(int(_lib().s2ag_bf16_tcn_keep_bytes(N, T, nb)), dtype=torch.uint8, device=x.device)
             a.keep = keep.data_ptr()
-        if emb is not None:
-            a.emb_ids, a.emb_table = ids.data_ptr(), table.data_ptr()
-            a.emb_dim, a.emb_entries = int(table.shape[1]), int(table.shape[0])
-            a.emb_drop_p, a.emb_site = float(emb[0]), int(emb[1])
-            if emb[0] > 0:
-                a.rng = noise.data_ptr()
         L.check(_lib().s2ag_bf16_tcn_fwd(C.byref(a), _s()), 'bf16_tcn_fwd')
         ctx.meta, ctx.frags, ctx.noise, ctx.params, ctx.shape = meta, frags, noise, params, ctx_shape
-        ctx.ids = ids
         ctx.save_for_backward(x, saved, signs)
         return saved[2 * nb - 1].view(N, T, 320)
 
     @staticmethod
     def backward(ctx, gy):
         x, saved, signs = ctx.saved_tensors
-        dils, sites, drop_p = ctx.meta[:3]
-        emb = ctx.meta[3] if len(ctx.meta) > 3 else None
+        dils, sites, drop_p = ctx.meta
         nb = len(dils)
         params = ctx.params
-        ws, bs = params[:2 * nb], params[2 * nb:4 * nb]
+        ws, bs = params[:2 * nb], params[2 * nb:]
         N, T = ctx.shape
         rows = N * T
         C_ = ws[0].shape[0]
@@ -578,28 +558,10 @@ class _TcnFused16(torch.autograd.Function):
                 else:
                     L.check(lib.s2ag_bf16_conv_wgrad_multi(jobs, nj, _s()), 'bf16_conv_wgrad_multi')
             ops.run_wgrad(launch, keep=(gp, saved, x), flops=2.0 * rows * C_ * C_ * 2 * nj)
-        if emb is not None:
-            # the gradient w.r.t. the gathered rows goes straight to the table (what _Embedding16.backward does)
-            table, dt = params[4 * nb], None
-            if ctx.needs_input_grad[4 + 4 * nb]:
-                e = L.Epilogue(L.ACT_NONE, 1.0, float(emb[0]), _p(ctx.noise) if emb[0] > 0 else None, int(emb[1]))
-                slot = ops._grad_slot(table)
-                if slot is None:
-                    dt = torch.zeros(table.shape[0], table.shape[1], dtype=torch.float32, device=gy.device)
-                    slot = dt
-                L.check(lib.s2ag_bf16_embedding_bwd(_p(ctx.ids), _p(gx), 320, rows, int(table.shape[1]), int(table.shape[0]), _p(slot),
-                                                    C.byref(e), _s()), 'bf16_embedding_bwd')
-            return (None, None, None, None) + tuple(grads) + (dt,)
         return (gx.view(N, T, 320), None, None, None) + tuple(grads)
 
 
-def tcn_fused(x: Tensor, frags: TcnFragments, ws, biases, dils, sites, drop_p: float, noise, emb=None) -> Tensor:
-    """``emb`` = (ids (N, T) int64, table, drop_p, site): the input rows are dropout(table[ids]), formed by the launch
-    (``x`` is ignored)."""
-    if emb is not None:
-        ids, table, p_emb, site_emb = emb
-        return _TcnFused16.apply(ids, frags, (tuple(dils), tuple(sites), float(drop_p), (float(p_emb), int(site_emb))), noise,
-                                 *ws, *biases, table)
+def tcn_fused(x: Tensor, frags: TcnFragments, ws, biases, dils, sites, drop_p: float, noise) -> Tensor:
     return _TcnFused16.apply(x, frags, (tuple(dils), tuple(sites), float(drop_p)), noise, *ws, *biases)
 
 

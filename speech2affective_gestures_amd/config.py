@@ -58,17 +58,6 @@ _S = [
            'tests/test_gpu_ops.py::test_batch_norm_fused_statistics_shapes_and_ticket_rearm'),
     Switch('SYNTH_GRAPH', True, _flag, "0: sliding-window synthesis with eager launches instead of one hipGraph replay per "
            "window", 'tests/test_gpu_step.py::test_synthesis_after_training_steps_uses_the_current_weights'),
-    # ---- written in r03 while GPU access was closed: not yet run on hardware, off by default, validated on the CPU device model
-    Switch('WAVE_TAIL32', False, _flag, "fp32 wave encoder with BatchNorm 2 / 3 folded into conv3 / conv4 (wave32.py)",
-           'tests/test_gpu_zz_pending_wave32.py'),
-    Switch('TCN_GATHER', False, _flag, "embedding gather + dropout inside the clip-resident TCN forward launch (both modes)",
-           'tests/test_gpu_zz_pending_tcn.py'),
-    Switch('TCN_RING_DEEP', False, _flag, "twice the weight fragments in flight in the clip-resident TCN launches (bit "
-           "identical products)", 'tests/test_gpu_zz_pending_tcn.py::test_deep_weight_rings_are_bit_identical', clib=True),
-    Switch('W12_FWD_PIPE', False, _flag, "software-pipelined K loop in the wave head's fp32 forward (bit identical)",
-           'tests/test_gpu_zz_pending_wave32.py::test_pipelined_fp32_forward_is_bit_identical', clib=True),
-    Switch('EMB_FWD_ROWS', False, _flag, "row-form embedding forward (no 64-bit division per element)",
-           'tests/test_gpu_zz_pending_tcn.py::test_embedding_forward_row_form_equals_element_form', clib=True),
     # ---- process plumbing (no kernel is selected by these) --------------------------------------------------------------
     Switch('HIP_LIB', '', str, "path of another build of the same C ABI (debug / asan flavour)", None),
     Switch('CRASH_TRACE', False, _flag, "native back trace on a fatal signal (csrc/debug.hip)", None),

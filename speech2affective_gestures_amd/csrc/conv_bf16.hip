@@ -748,8 +748,8 @@ __global__ __launch_bounds__(256) void epilogue_bwd_bf16_k(const bf16_t* __restr
     }
 }
 
-// flat-index form (the default until the row form below has been through the GPU suite)
-__global__ __launch_bounds__(256) void embedding_fwd_bf16_flat_k(const long long* __restrict__ ids, const float* __restrict__ table,
+// embedding rows -> bf16 (rows, ld) with dropout; pad columns zero
+__global__ __launch_bounds__(256) void embedding_fwd_bf16_k(const long long* __restrict__ ids, const float* __restrict__ table,
                                                             long long rows, int dim, int n_entries, int ld, float drop_p,
                                                             float inv_keep, const unsigned long long* rng, unsigned site,
                                                             bf16_t* __restrict__ out) {
@@ -771,96 +771,39 @@ __global__ __launch_bounds__(256) void embedding_fwd_bf16_flat_k(const long long
     }
 }
 
-// embedding rows -> bf16 (rows, ld) with dropout; pad columns zero.  A workgroup owns 8 token rows (a wave two), lanes run
-// over channel pairs: no index division per element, 4-byte stores (ld is even: a multiple of 32)
-__global__ __launch_bounds__(256) void embedding_fwd_bf16_k(const long long* __restrict__ ids, const float* __restrict__ table,
-                                                            long long rows, int dim, int n_entries, int ld, float drop_p,
-                                                            float inv_keep, const unsigned long long* rng, unsigned site,
-                                                            bf16_t* __restrict__ out) {
-    SiteKey key{0, 0};
-    const bool drop = drop_p > 0.f;
-    if (drop) key = site_key(rng, site);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const long long r = (long long)blockIdx.x * 8 + wave * 2 + k;
-        if (r >= rows) break;
-        long long id = ids[r];
-        if (id < 0 || id >= n_entries) id = 0;
-        const float* src = table + id * dim;
-        unsigned* dst = reinterpret_cast<unsigned*>(out + r * ld);
-        for (int c = 2 * lane; c < ld; c += 128) {
-            float v0 = c < dim ? src[c] : 0.f, v1 = c + 1 < dim ? src[c + 1] : 0.f;
-            if (drop) {
-                v0 *= keep_scale(key, (unsigned long long)r * dim + c, drop_p, inv_keep);
-                v1 *= keep_scale(key, (unsigned long long)r * dim + c + 1, drop_p, inv_keep);
-            }
-            dst[c >> 1] = bf16_rn(v0) | (bf16_rn(v1) << 16);
-        }
-    }
-}
-
 // table gradient += dy (bf16) * mask.  A block owns 32 token rows, a thread one channel: the rows' loads are independent
 // (unrolled, many in flight); contributions to the PAD row (id 0: most frames of a clip) are summed in a register and leave
 // the block as ONE atomic per channel, the few word rows use direct atomics.
-__global__ __launch_bounds__(256) void embedding_bwd_bf16_k(const long long* __restrict__ ids, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(320) void embedding_bwd_bf16_k(const long long* __restrict__ ids, const bf16_t* __restrict__ dy,
                                                             int ld, int dim, int n_entries, float drop_p, float inv_keep,
                                                             const unsigned long long* rng, unsigned site,
                                                             float* __restrict__ dtable, long long rows, int rows_per_block) {
-    // a workgroup = 256 rows x 128 channels, 64 rows per wave (misc.hip embedding_bwd_k: the PAD row's cache lines take one
-    // atomic per workgroup -- 34 at 256 clips -- instead of 272)
-    __shared__ int sid[256];
-    __shared__ float pad_s[4][128];
+    __shared__ long long sid[32];
     SiteKey key{0, 0};
     const bool drop = drop_p > 0.f;
     if (drop) key = site_key(rng, site);
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const int nr = (int)min((long long)rows_per_block, rows - r0);
-    {
-        long long id = (int)threadIdx.x < nr ? ids[r0 + threadIdx.x] : 0;
-        sid[threadIdx.x] = (int)((id < 0 || id >= n_entries) ? 0 : id);
+    if (threadIdx.x < 32) {
+        long long id = threadIdx.x < nr ? ids[r0 + threadIdx.x] : -1;
+        if (threadIdx.x < nr && (id < 0 || id >= n_entries)) id = 0;
+        sid[threadIdx.x] = id;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.y * 128 + 2 * lane;                 // a lane owns a channel pair: 4-byte loads (ld and dim are even)
-    float pad0 = 0.f, pad1 = 0.f;
-    s2ag::det_enter();                    // deterministic mode: workgroups in index order, waves one after the other
-    S2AG_DET_WAVES_BEGIN
-    if (c < dim) {
-        const int i0 = wave * (rows_per_block / 4), i1 = min(nr, i0 + rows_per_block / 4);
-        for (int ib = i0; ib < i1; ib += 16) {              // all 16 loads before the first atomic (see misc.hip)
-            unsigned v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = ib + j < i1 ? *reinterpret_cast<const unsigned*>(dy + (r0 + ib + j) * ld + c) : 0u;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (ib + j >= i1) break;
-                const long long r = r0 + ib + j;
-                float d0 = __uint_as_float(v[j] << 16), d1 = __uint_as_float(v[j] & 0xffff0000u);
-                if (drop) {
-                    d0 *= keep_scale(key, (unsigned long long)r * dim + c, drop_p, inv_keep);
-                    d1 *= keep_scale(key, (unsigned long long)r * dim + c + 1, drop_p, inv_keep);
-                }
-                const int id = sid[ib + j];
-                if (id == 0) {
-                    pad0 += d0;
-                    pad1 += d1;
-                } else {
-                    atomicAdd(dtable + (long long)id * dim + c, d0);
-                    atomicAdd(dtable + (long long)id * dim + c + 1, d1);
-                }
-            }
+    s2ag::det_enter();                    // (det flavour: row blocks share table rows -- workgroups in index order; a thread owns its channel)
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        float pad_acc = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            if (i >= nr) break;
+            const long long r = r0 + i;
+            float d = bf16_f(dy[r * ld + c]);
+            if (drop) d *= keep_scale(key, (unsigned long long)r * dim + c, drop_p, inv_keep);
+            const long long id = sid[i];
+            if (id == 0) pad_acc += d;
+            else atomicAdd(dtable + id * dim + c, d);
         }
-    }
-    S2AG_DET_WAVES_END
-    pad_s[wave][lane] = pad0;
-    pad_s[wave][64 + lane] = pad1;
-    __syncthreads();
-    if (wave == 0 && c < dim) {
-        const float t0 = (pad_s[0][lane] + pad_s[1][lane]) + (pad_s[2][lane] + pad_s[3][lane]);
-        const float t1 = (pad_s[0][64 + lane] + pad_s[1][64 + lane]) + (pad_s[2][64 + lane] + pad_s[3][64 + lane]);
-        if (t0 != 0.f) atomicAdd(dtable + c, t0);
-        if (t1 != 0.f) atomicAdd(dtable + c + 1, t1);
+        if (pad_acc != 0.f) atomicAdd(dtable + c, pad_acc);
     }
     s2ag::det_leave();
 }
@@ -1122,15 +1065,9 @@ extern "C" int s2ag_bf16_embedding_fwd(const long long* ids, const float* table,
     if (!ids || !table || !out || rows <= 0 || dim <= 0 || ld < dim) return S2AG_E_BADARG;
     const float p = e ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
-    const int row_form = s2ag::option(s2ag::OPT_EMB_FWD_ROWS);
-    if (row_form && !(ld & 1) && !((uintptr_t)out & 3))
-        hipLaunchKernelGGL(embedding_fwd_bf16_k, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, ids, table,
-                           rows, dim, n_entries, ld, p, p > 0.f ? 1.f / (1.f - p) : 1.f, e ? e->rng : nullptr,
-                           e ? e->site : 0u, static_cast<bf16_t*>(out));
-    else
-        hipLaunchKernelGGL(embedding_fwd_bf16_flat_k, dim3(ew_blocks(rows * ld)), dim3(256), 0, (hipStream_t)stream, ids, table,
-                           rows, dim, n_entries, ld, p, p > 0.f ? 1.f / (1.f - p) : 1.f, e ? e->rng : nullptr,
-                           e ? e->site : 0u, static_cast<bf16_t*>(out));
+    hipLaunchKernelGGL(embedding_fwd_bf16_k, dim3(ew_blocks(rows * ld)), dim3(256), 0, (hipStream_t)stream, ids, table, rows,
+                       dim, n_entries, ld, p, p > 0.f ? 1.f / (1.f - p) : 1.f, e ? e->rng : nullptr, e ? e->site : 0u,
+                       static_cast<bf16_t*>(out));
     S2AG_LAUNCH_CHECK();
     return 0;
 }
@@ -1138,11 +1075,10 @@ extern "C" int s2ag_bf16_embedding_fwd(const long long* ids, const float* table,
 extern "C" int s2ag_bf16_embedding_bwd(const long long* ids, const void* dy, int ld, long long rows, int dim, int n_entries,
                                        float* dtable, const s2ag_epilogue* e, void* stream) {
     if (!ids || !dy || !dtable || rows <= 0 || dim <= 0 || ld < dim) return S2AG_E_BADARG;
-    if ((ld & 1) || (dim & 1) || ((uintptr_t)dy & 3)) return S2AG_E_UNSUPPORTED;      // channel pairs: 4-byte loads
     const float p = e ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
-    const int rpb = 256;
-    hipLaunchKernelGGL(embedding_bwd_bf16_k, dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)((dim + 127) / 128)), dim3(256), 0, (hipStream_t)stream, ids,
+    const int rpb = 32;
+    hipLaunchKernelGGL(embedding_bwd_bf16_k, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(320), 0, (hipStream_t)stream, ids,
                        static_cast<const bf16_t*>(dy), ld, dim, n_entries, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
                        e ? e->rng : nullptr, e ? e->site : 0u, dtable, rows, rpb);
     S2AG_LAUNCH_CHECK();

@@ -1048,8 +1048,9 @@ Ws carve(void* ws, int B, int H, int backward) {
 extern "C" int s2ag_gru_coop_supported(int H) { return H == 300 ? 1 : 0; }
 extern "C" int s2ag_gru_coop_split_pieces(void) { return coop_split_pieces(); }
 extern "C" int s2ag_gru_coop_fwd_slices(int B) { return (coop_split_pieces() != 0 && B > CBS && coop_two_slices()) ? 2 : 1; }
+extern "C" int s2ag_gru_coop_split_override(void) { return g_split_override; }
 extern "C" int s2ag_gru_coop_set_split_pieces(int pieces) {
-    const int prev = coop_split_pieces();
+    const int prev = g_split_override;          // the OVERRIDE (-1: none), so that restoring it un-pins option GRU_SPLIT again
     g_split_override = (pieces >= 1 && pieces <= 3) ? pieces : (pieces == 0 ? 0 : -1);
     return prev;
 }

@@ -16,8 +16,7 @@ inline int ew_grid(long long total) {
 }
 
 // ---- embedding -------------------------------------------------------------------------------------
-// flat-index form (one element per thread and trip; the default until the row form below has been through the GPU suite)
-__global__ __launch_bounds__(256) void embedding_fwd_flat_k(const long long* ids, const float* __restrict__ table, int rows,
+__global__ __launch_bounds__(256) void embedding_fwd_k(const long long* ids, const float* __restrict__ table, int rows,
                                                        int dim, int n_entries, float* __restrict__ out, int ldo,
                                                        float drop_p, float inv_keep, const unsigned long long* rng,
                                                        unsigned site) {
@@ -36,89 +35,34 @@ __global__ __launch_bounds__(256) void embedding_fwd_flat_k(const long long* ids
     }
 }
 
-// A workgroup owns 8 consecutive token rows (a wave two of them), its lanes run over the columns: no index division per
-// element (the flat-index form spent its time in a 64-bit i / dim: 12.5 us for 20 MB at 256 clips).
-constexpr int EMBF_RB = 8;
-__global__ __launch_bounds__(256) void embedding_fwd_k(const long long* ids, const float* __restrict__ table, int rows,
-                                                       int dim, int n_entries, float* __restrict__ out, int ldo,
-                                                       float drop_p, float inv_keep, const unsigned long long* rng,
-                                                       unsigned site) {
-    SiteKey key{0, 0};
-    const bool drop = drop_p > 0.f;
-    if (drop) key = site_key(rng, site);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < EMBF_RB / 4; ++k) {
-        const int r = blockIdx.x * EMBF_RB + wave * (EMBF_RB / 4) + k;
-        if (r >= rows) break;
-        long long id = ids[r];
-        S2AG_DBG_ASSERT(id >= 0 && id < n_entries);      // nn.Embedding raises here; the release build clamps
-        id = id < 0 ? 0 : (id >= n_entries ? n_entries - 1 : id);
-        const float* src = table + id * dim;
-        float* dst = out + (long long)r * ldo;
-        for (int c = lane; c < dim; c += 64) {
-            float v = src[c];
-            if (drop) v *= keep_scale(key, (unsigned long long)r * dim + c, drop_p, inv_keep);
-            dst[c] = v;
-        }
-    }
-}
-
-// Rows that repeat an id would hammer the same `dim` addresses with atomics, and one id does: PAD (id 0: vocab.py's PAD_token)
-// fills ~85 % of every transcript.  r01 merged runs of equal ids over 32 consecutive rows (one atomic per run and column:
-// 110 -> 35 us); what was left were 272 workgroups x ~4 PAD runs, i.e. ~1 000 dependent read-modify-writes on each of the PAD
-// row's 19 cache lines -- the L2 serialises atomics to one line at ~30 ns apiece, and that WAS the kernel's time (41 us at
-// 256 clips for 10 MB of traffic).  Now a workgroup owns 256 rows x 64 columns, its four waves take 64 rows each (16 loads in
-// flight per lane), sum the PAD rows in a register, meet in LDS and leave ONE atomic per column: 34 per PAD line.  Word rows
-// (a few per clip, rarely the same twice) go out as direct atomics.  Exact for any id pattern.
-constexpr int EMB_RB = 256, EMB_CB = 64;
+// Rows that repeat an id (the PAD token fills most of every transcript) would hammer the same `dim` addresses with
+// atomics -- 110 us per step.  A block walks RB consecutive rows with one thread per column and merges RUNS of equal
+// ids in a register: one atomic per (run, column) instead of one per (row, column).  Exact for any id pattern.
+constexpr int EMB_RB = 32;
 __global__ __launch_bounds__(256) void embedding_bwd_k(const long long* ids, const float* __restrict__ g, int ldg,
                                                        int rows, int dim, int n_entries, float* dtable, float drop_p,
                                                        float inv_keep, const unsigned long long* rng, unsigned site) {
-    __shared__ int sid[EMB_RB];
-    __shared__ float pad_s[4][EMB_CB];
     SiteKey key{0, 0};
-    const bool drop = drop_p > 0.f;
-    if (drop) key = site_key(rng, site);
+    if (drop_p > 0.f) key = site_key(rng, site);
     const int r0 = blockIdx.x * EMB_RB;
-    const int nr = min(EMB_RB, rows - r0);
-    {
-        long long id = (int)threadIdx.x < nr ? ids[r0 + threadIdx.x] : 0;
-        sid[threadIdx.x] = (int)(id < 0 ? 0 : (id >= n_entries ? n_entries - 1 : id));
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.y * EMB_CB + lane;
-    float pad_acc = 0.f;
-    // deterministic mode: workgroups in index order, and inside a workgroup wave by wave (two waves may hold the same word)
-    s2ag::det_enter();
-    S2AG_DET_WAVES_BEGIN
-    if (c < dim) {
-        const int i0 = wave * (EMB_RB / 4), i1 = min(nr, i0 + EMB_RB / 4);
-        // 16 rows are LOADED before any of them is added: a load behind an atomic to memory it may alias waits for it, and
-        // the loop was a chain of 64 memory round trips (33 us)
-        for (int ib = i0; ib < i1; ib += 16) {
-            float v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = ib + j < i1 ? g[(long long)(r0 + ib + j) * ldg + c] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (ib + j >= i1) break;
-                const long long r = r0 + ib + j;
-                float x = v[j];
-                if (drop) x *= keep_scale(key, (unsigned long long)r * dim + c, drop_p, inv_keep);
-                const int id = sid[ib + j];
-                if (id == 0) pad_acc += x;
-                else atomicAdd(dtable + (long long)id * dim + c, x);
+    const int r1 = min(rows, r0 + EMB_RB);
+    s2ag::det_enter();          // (det flavour: row blocks share table rows -- workgroups in index order; a thread owns its column)
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < dim; c += gridDim.y * 256) {
+        long long run_id = -1;
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            long long id = ids[r];
+            id = id < 0 ? 0 : (id >= n_entries ? n_entries - 1 : id);
+            float v = g[(long long)r * ldg + c];
+            if (drop_p > 0.f) v *= keep_scale(key, (unsigned long long)r * dim + c, drop_p, inv_keep);
+            if (id != run_id) {
+                if (run_id >= 0) atomicAdd(dtable + run_id * dim + c, acc);
+                run_id = id;
+                acc = 0.f;
             }
+            acc += v;
         }
-    }
-    S2AG_DET_WAVES_END
-    pad_s[wave][lane] = pad_acc;
-    __syncthreads();
-    if (wave == 0 && c < dim) {
-        const float t = (pad_s[0][lane] + pad_s[1][lane]) + (pad_s[2][lane] + pad_s[3][lane]);
-        if (t != 0.f) atomicAdd(dtable + c, t);
+        if (run_id >= 0) atomicAdd(dtable + run_id * dim + c, acc);
     }
     s2ag::det_leave();
 }
@@ -588,15 +532,9 @@ extern "C" int s2ag_embedding_fwd(const long long* ids, const float* table, int 
     if (!ids || !table || !out || rows <= 0 || dim <= 0 || n_entries <= 0 || ldo < dim) return S2AG_E_BADARG;
     const float p = e ? e->drop_p : 0.f;
     if (p > 0.f && !e->rng) return S2AG_E_BADARG;
-    const int row_form = s2ag::option(s2ag::OPT_EMB_FWD_ROWS);
-    if (row_form)
-        hipLaunchKernelGGL(embedding_fwd_k, dim3(cdiv(rows, EMBF_RB)), dim3(256), 0, (hipStream_t)stream, ids,
-                           table, rows, dim, n_entries, out, ldo, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
-                           e ? e->rng : nullptr, e ? e->site : 0u);
-    else
-        hipLaunchKernelGGL(embedding_fwd_flat_k, dim3(ew_grid((long long)rows * dim)), dim3(256), 0, (hipStream_t)stream, ids,
-                           table, rows, dim, n_entries, out, ldo, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
-                           e ? e->rng : nullptr, e ? e->site : 0u);
+    hipLaunchKernelGGL(embedding_fwd_k, dim3(ew_grid((long long)rows * dim)), dim3(256), 0, (hipStream_t)stream, ids,
+                       table, rows, dim, n_entries, out, ldo, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
+                       e ? e->rng : nullptr, e ? e->site : 0u);
     S2AG_LAUNCH_CHECK();
     return 0;
 }
@@ -610,7 +548,7 @@ extern "C" int s2ag_embedding_bwd(const long long* ids, const float* g, int ldg,
         hipError_t me = zero_async(dtable, sizeof(float) * (size_t)n_entries * dim, (hipStream_t)stream);
         if (me != hipSuccess) return (int)me;
     }
-    hipLaunchKernelGGL(embedding_bwd_k, dim3(cdiv(rows, EMB_RB), cdiv(dim, EMB_CB)), dim3(256), 0, (hipStream_t)stream, ids,
+    hipLaunchKernelGGL(embedding_bwd_k, dim3(cdiv(rows, EMB_RB), cdiv(dim, 256)), dim3(256), 0, (hipStream_t)stream, ids,
                        g, ldg, rows, dim, n_entries, dtable, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
                        e ? e->rng : nullptr, e ? e->site : 0u);
     S2AG_LAUNCH_CHECK();
@@ -1003,8 +941,8 @@ extern "C" int s2ag_normal_noise(const unsigned long long* rng, unsigned site, l
 // ---- run-time options (the registry is speech2affective_gestures_amd/config.py) ------------------------------------------
 namespace s2ag {
 namespace {
-int g_options[OPT_COUNT] = {2, 0, 0, 0};
-const char* const g_option_names[OPT_COUNT] = {"GRU_SPLIT", "TCN_RING_DEEP", "W12_FWD_PIPE", "EMB_FWD_ROWS"};
+int g_options[OPT_COUNT] = {2};
+const char* const g_option_names[OPT_COUNT] = {"GRU_SPLIT"};
 int option_index(const char* name) {
     if (!name) return -1;
     for (int i = 0; i < OPT_COUNT; ++i)

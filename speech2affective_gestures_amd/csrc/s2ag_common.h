@@ -27,7 +27,7 @@ constexpr int WAVE = 64;
 
 // Run-time options of the library: set through s2ag_set_option (misc.hip) by the ONE registry of switches,
 // speech2affective_gestures_amd/config.py.  The library itself never reads the environment.
-enum Option { OPT_GRU_SPLIT = 0, OPT_TCN_RING_DEEP, OPT_W12_FWD_PIPE, OPT_EMB_FWD_ROWS, OPT_COUNT };
+enum Option { OPT_GRU_SPLIT = 0, OPT_COUNT };
 int option(Option o);
 
 __host__ __device__ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -21,8 +21,6 @@
 // kept and pre > 0 -- and of h2 and of y's sign that ONE BIT per element is all the backward pass needs, so the forward
 // pass leaves sign bytes (3 bits per element) instead of a third activation tensor, and the backward launch reads 8 KB of
 // them per workgroup and block (prefetched a block ahead) instead of 130 KB of activations it would wait for.
-#include <stdlib.h>
-
 #include "s2ag_common.h"
 
 namespace {
@@ -75,14 +73,6 @@ struct TcnP {
     bf16_t* gp1[S2AG_TCN_MAX_BLOCKS];
     bf16_t* gp2[S2AG_TCN_MAX_BLOCKS];
     u32x4* keep;                        // dropout keep bits of the forward pass (tcn_keep_k), one u32x4 per thread and conv
-    // GATHER (forward): the first block's input rows are nn.Embedding rows + dropout, formed in the loader (and written to
-    // `xo` for the backward pass's weight gradient) instead of read from `x`
-    const long long* emb_ids;           // (clips * T) token ids
-    const float* emb_table;             // (entries, emb_dim) fp32
-    bf16_t* xo;
-    int emb_dim, emb_entries;
-    float emb_p, emb_ik;
-    unsigned emb_site;
     unsigned long long* trace;          // diagnostics (s2ag_bf16_tcn_set_trace): s_memtime stamps of workgroup 0, wave 0
 };
 
@@ -98,11 +88,7 @@ struct TcnP {
 // matrix-pipe cycles for the L2 round trip), the activation fragments of tile kt + 1 are read from LDS before the MFMAs
 // of tile kt.  sched_barrier pins that order -- left alone the compiler sinks every load next to its first use
 // (s_waitcnt vmcnt(1) in front of each group of 5 MFMAs: 21 us per conv instead of 4).
-// RING: register sets of weight fragments in flight (default 4 = 20 KB per wave).  The kernels are bound by the bytes they
-// keep in flight against a ~1.8 us loaded L2 round trip (80 KB per CU -> ~44 GB/s per CU, 19 % MFMA utilisation), and a wave
-// alone on its SIMD owns 512 registers of which ~380 are used: RING = 8 doubles the bytes in flight (opt-in, option TCN_RING_DEEP,
-// not yet run on a GPU; same products in the same order = bit-identical results).
-template <bool BWD, int MT, int RING = 4>
+template <bool BWD, int MT>
 __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_off, const u32x4* __restrict__ wa, int d, int T,
                                           int R, int lane, f32x4 (&acc)[CT_W][MT]) {
     int off0[MT], off1[MT];
@@ -115,10 +101,10 @@ __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_o
         off1[mt] = (ok ? src_off + m * PITCH : z_off) + (lane >> 4) * 8;
         off0[mt] = (ok0 ? src_off + (BWD ? m + d : m - d) * PITCH : z_off) + (lane >> 4) * 8;
     }
-    static_assert(NKT % 4 == 0 && RING >= 2 && RING <= NKT, "ring");
-    u32x4 a[RING][CT_W];
+    static_assert(NKT % 4 == 0, "ring of four");
+    u32x4 a[4][CT_W];
 #pragma unroll
-    for (int s = 0; s < RING; ++s)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < CT_W; ++i) a[s][i] = wa[(i * NKT + s) * 64];
     bf16x8 b[2][MT];
@@ -130,7 +116,6 @@ __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_o
             dst[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sm + (t0 ? off0[mt] : off1[mt]) + c0));
     };
     load_b(0, b[0]);
-    if constexpr (RING == 4) {
 #pragma unroll
     for (int kp = 0; kp < NKT / 4; ++kp) {       // fully unrolled: a rolled loop made the allocator rotate the accumulators
 #pragma unroll
@@ -152,59 +137,6 @@ __device__ __forceinline__ void conv_tile(const bf16_t* sm, int src_off, int z_o
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
-    } else {
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {       // fully unrolled: the set index kt % RING is a compile-time constant
-            const int s = kt % RING;
-            if (kt + 1 < NKT) load_b(kt + 1, b[(kt + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < CT_W; ++i) {
-                const bf16x8 av = __builtin_bit_cast(bf16x8, a[s][i]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[kt & 1][mt], acc[i][mt], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + RING < NKT) {
-#pragma unroll
-                for (int i = 0; i < CT_W; ++i) a[s][i] = wa[(i * NKT + kt + RING) * 64];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// the workgroup's rows as embedding rows: row m = table[ids[row0 + m]] * dropout (the counter-based mask of
-// s2ag_bf16_embedding_fwd: index row * dim + channel), rounded to bf16, pad channels zero -- to LDS and to HBM (`xo`)
-__device__ __forceinline__ void rows_gather(bf16_t* lds, const TcnP& p, long long row0, int R, int tid) {
-    SiteKey key{0, 0};
-    const bool drop = p.emb_p > 0.f;
-    if (drop) key = site_key(p.rng, p.emb_site);
-    const int dim = p.emb_dim;
-    for (int idx = tid; idx < R * (CP / 8); idx += 256) {
-        const int m = idx / (CP / 8), kc = idx - m * (CP / 8);
-        const long long row = row0 + m;
-        long long id = p.emb_ids[row];
-        if (id < 0 || id >= p.emb_entries) id = 0;
-        const float* src = p.emb_table + id * dim + kc * 8;
-        float v[8];
-        if (kc * 8 + 8 <= dim) {                       // dim % 4 == 0: both halves are 16-byte aligned
-            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = kc * 8 + j < dim ? src[j] : 0.f;
-        }
-        if (drop) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (kc * 8 + j < dim) v[j] *= keep_scale(key, (unsigned long long)row * dim + kc * 8 + j, p.emb_p, p.emb_ik);
-        }
-        const u32x4 o = u32x4{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
-        *reinterpret_cast<u32x4*>(lds + m * PITCH + kc * 8) = o;
-        *reinterpret_cast<u32x4*>(p.xo + row * CP + kc * 8) = o;
     }
 }
 
@@ -269,7 +201,7 @@ __global__ __launch_bounds__(256) void tcn_keep_k(const TcnP p) {
 __host__ __device__ inline int sign_s1(int rows) { return (rows * 40 + 15) / 16 * 16; }
 __host__ __device__ inline int sign_s2(int rows) { return (rows * 80 + 15) / 16 * 16; }
 
-template <int MT, bool GATHER = false, int RING = 4>
+template <int MT>
 __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sm = reinterpret_cast<bf16_t*>(smem_raw);
@@ -284,8 +216,7 @@ __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
     const int R = min(p.cpb, p.n_clips - clip0) * p.T;
     const long long row0 = (long long)clip0 * p.T;
 
-    if constexpr (GATHER) rows_gather(sm + X, p, row0, R, tid);
-    else rows_in(sm + X, p.x + row0 * CP, R, tid);
+    rows_in(sm + X, p.x + row0 * CP, R, tid);
     for (int i = tid; i < PITCH / 2; i += 256) reinterpret_cast<unsigned*>(sm + Z)[i] = 0u;
     const bool drop = p.drop_p > 0.f;
     __syncthreads();
@@ -312,7 +243,7 @@ __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
             u32x4 kv = u32x4{0u, 0u, 0u, 0u};                    // this thread's keep bits: requested now, used after the K loop
             if (drop) kv = p.keep[((size_t)cv * gridDim.x + blockIdx.x) * 256 + tid];
             zero_acc(acc);
-            conv_tile<false, MT, RING>(sm, j == 0 ? X : H1, Z, wa, d, p.T, R, lane, acc);
+            conv_tile<false, MT>(sm, j == 0 ? X : H1, Z, wa, d, p.T, R, lane, acc);
             TCN_STAMP();
             const unsigned kw[4] = {kv.x, kv.y, kv.z, kv.w};
             const float ik = p.inv_keep;
@@ -380,7 +311,7 @@ __global__ __launch_bounds__(256) void tcn_fwd_k(const TcnP p) {
     }
 }
 
-template <int MT, int RING = 4>
+template <int MT>
 __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sm = reinterpret_cast<bf16_t*>(smem_raw);
@@ -447,7 +378,7 @@ __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
             const int cv = 2 * blk + 1;
             const u32x4* wa = reinterpret_cast<const u32x4*>(p.wfrag + (long long)(2 * cv + 1) * FRAG) + (wave * CT_W * NKT) * 64 + lane;
             zero_acc(acc);
-            conv_tile<true, MT, RING>(sm, P2, Z, wa, d, p.T, R, lane, acc);
+            conv_tile<true, MT>(sm, P2, Z, wa, d, p.T, R, lane, acc);
             TCN_STAMP();
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
@@ -472,7 +403,7 @@ __global__ __launch_bounds__(256) void tcn_bwd_k(const TcnP p) {
             const int cv = 2 * blk;
             const u32x4* wa = reinterpret_cast<const u32x4*>(p.wfrag + (long long)(2 * cv + 1) * FRAG) + (wave * CT_W * NKT) * 64 + lane;
             zero_acc(acc);
-            conv_tile<true, MT, RING>(sm, P1, Z, wa, d, p.T, R, lane, acc);
+            conv_tile<true, MT>(sm, P1, Z, wa, d, p.T, R, lane, acc);
             TCN_STAMP();
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
@@ -527,14 +458,15 @@ unsigned long long* g_trace = nullptr;
 // 128 workgroups on 256 CUs, every one a chain of eight convs of ~22 k cycles: with one clip per workgroup (3 row tiles)
 // the K loop and the epilogue of a conv shrink to 3 / 5 and all CUs work -- the L2 then serves the weights twice as often
 // (742 MB per launch, well inside its bandwidth).
-// r04: found by a checker that enforces the 160 KB limit (the test suite's CPU device model): at T = 40 two clips are 80 rows, and the backward
-// launch's three row buffers + zero row + sign images are 167 696 bytes -- the launch would have failed on the hardware.  The
-// plan now also asks the LDS budget of the LARGER of the two launches (forward and backward must agree on the clips per
-// workgroup: the sign images are laid out per workgroup).
+// r04: found by a checker that enforces the 160 KB limit (the test suite's CPU device model): at T = 40 two clips are 80 rows,
+// and the backward launch's three row buffers + zero row + sign images are 167 696 bytes -- the launch would have failed on
+// the hardware.  The plan asks the LDS budget of the LARGER of the two launches (forward and backward must agree on the
+// clips per workgroup: the sign images are laid out per workgroup).  r05: ONE clip of 79 / 80 frames does not
+// fit either -- plan_cpb returns 0 and the caller takes the layer-by-layer path (s2ag_bf16_tcn_clips_per_block = 0).
 size_t lds_bytes(int cpb, int T, bool bwd);
 int plan_cpb(int n_clips, int T) {
     int max_cpb = (MT_MAX * 16) / T > 2 ? 2 : (MT_MAX * 16) / T;
-    while (max_cpb > 1 && lds_bytes(max_cpb, T, true) > (size_t)160 * 1024) --max_cpb;
+    while (max_cpb > 0 && lds_bytes(max_cpb, T, true) > (size_t)160 * 1024) --max_cpb;
     if (max_cpb >= 2 && T <= 48 && n_clips >= 192) return 1;
     return max_cpb;
 }
@@ -543,6 +475,7 @@ int fill(const s2ag_bf16_tcn_args* a, TcnP& p, bool bwd) {
     if (!a || !a->x || !a->wfrag || a->n_blocks < 1 || a->n_blocks > S2AG_TCN_MAX_BLOCKS || a->n_clips <= 0) return S2AG_E_BADARG;
     if (s2ag_bf16_tcn_clips_per_block(a->T, a->C, 2) <= 0) return S2AG_E_UNSUPPORTED;
     const int cpb = plan_cpb(a->n_clips, a->T);
+    if (cpb < 1) return S2AG_E_UNSUPPORTED;
     if (a->drop_p < 0.f || a->drop_p >= 1.f || (a->drop_p > 0.f && !a->rng)) return S2AG_E_BADARG;
     p.x = static_cast<const bf16_t*>(a->x);
     p.wfrag = static_cast<const bf16_t*>(a->wfrag);
@@ -573,16 +506,6 @@ int fill(const s2ag_bf16_tcn_args* a, TcnP& p, bool bwd) {
     p.rng = static_cast<const unsigned long long*>(a->rng);
     p.keep = static_cast<u32x4*>(a->keep);
     if (!bwd && a->drop_p > 0.f && !a->keep) return S2AG_E_BADARG;
-    if (!bwd && a->emb_ids) {
-        if (!a->emb_table || a->emb_dim <= 0 || a->emb_entries <= 0 || !(a->emb_drop_p >= 0.f && a->emb_drop_p < 1.f))
-            return S2AG_E_BADARG;
-        if (a->emb_dim > CP || (a->emb_dim & 3) || ((uintptr_t)a->emb_table & 15)) return S2AG_E_UNSUPPORTED;
-        if (a->emb_drop_p > 0.f && !a->rng) return S2AG_E_BADARG;
-        p.emb_ids = a->emb_ids; p.emb_table = a->emb_table; p.xo = const_cast<bf16_t*>(p.x);
-        p.emb_dim = a->emb_dim; p.emb_entries = a->emb_entries; p.emb_p = a->emb_drop_p;
-        p.emb_ik = a->emb_drop_p > 0.f ? 1.f / (1.f - a->emb_drop_p) : 1.f;
-        p.emb_site = a->emb_site;
-    }
     p.trace = g_trace;
     return 0;
 }
@@ -594,7 +517,7 @@ size_t lds_bytes(int cpb, int T, bool bwd) {
 
 extern "C" int s2ag_bf16_tcn_clips_per_block(int T, int C, int ksize) {      // the most a workgroup takes (see plan_cpb)
     if (ksize != 2 || C < 1 || C > CP || T < 1 || T > MT_MAX * 16) return 0;
-    return plan_cpb(1, T);                                          // (few clips: the most the row tiles AND the LDS allow)
+    return plan_cpb(1, T);                                          // (few clips: the most the row tiles AND the LDS allow; 0: none)
 }
 
 extern "C" int s2ag_bf16_tcn_set_trace(void* buf) {
@@ -646,28 +569,7 @@ extern "C" int s2ag_bf16_tcn_fwd(const s2ag_bf16_tcn_args* a, void* stream) {
         if (small) hipLaunchKernelGGL(tcn_keep_k<3>, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(tcn_keep_k<5>, dim3(cdiv(p.n_clips, p.cpb), 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, p);
     }
-    const int ring = s2ag::option(s2ag::OPT_TCN_RING_DEEP) ? 8 : 4;
-    if (ring == 8 && !p.emb_ids) {
-        static bool attr_r = false;
-        if (!attr_r) {
-            if (hipFuncSetAttribute((const void*)tcn_fwd_k<5, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)tcn_fwd_k<3, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return S2AG_E_UNSUPPORTED;
-            attr_r = true;
-        }
-        if (small) hipLaunchKernelGGL((tcn_fwd_k<3, false, 8>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((tcn_fwd_k<5, false, 8>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
-    } else if (p.emb_ids) {
-        static bool attr_g = false;
-        if (!attr_g) {
-            if (hipFuncSetAttribute((const void*)tcn_fwd_k<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)tcn_fwd_k<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return S2AG_E_UNSUPPORTED;
-            attr_g = true;
-        }
-        if (small) hipLaunchKernelGGL((tcn_fwd_k<3, true>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((tcn_fwd_k<5, true>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
-    } else if (small) hipLaunchKernelGGL(tcn_fwd_k<3>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    if (small) hipLaunchKernelGGL(tcn_fwd_k<3>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(tcn_fwd_k<5>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
@@ -685,18 +587,7 @@ extern "C" int s2ag_bf16_tcn_bwd(const s2ag_bf16_tcn_args* a, void* stream) {
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
-    const int ring = s2ag::option(s2ag::OPT_TCN_RING_DEEP) ? 8 : 4;
-    if (ring == 8) {
-        static bool attr_r = false;
-        if (!attr_r) {
-            if (hipFuncSetAttribute((const void*)tcn_bwd_k<5, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)tcn_bwd_k<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return S2AG_E_UNSUPPORTED;
-            attr_r = true;
-        }
-        if (p.cpb * p.T <= 48) hipLaunchKernelGGL((tcn_bwd_k<3, 8>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((tcn_bwd_k<5, 8>), dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
-    } else if (p.cpb * p.T <= 48) hipLaunchKernelGGL(tcn_bwd_k<3>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
+    if (p.cpb * p.T <= 48) hipLaunchKernelGGL(tcn_bwd_k<3>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(tcn_bwd_k<5>, dim3(cdiv(p.n_clips, p.cpb)), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;

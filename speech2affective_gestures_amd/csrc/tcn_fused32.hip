@@ -11,8 +11,6 @@
 // 3 x 2 activation fragments from LDS, 45 MFMAs.
 // What the (layer-by-layer) backward pass needs goes to HBM once: h1, h2 (post-dropout conv outputs) and the block output
 // y, as fp32 (clips*T, C) rows -- exactly the tensors the per-layer forward kernels would have left.
-#include <stdlib.h>
-
 #include "s2ag_common.h"
 
 namespace {
@@ -57,16 +55,6 @@ struct T32P {
     u32x4* keep;                                // one u32x4 per thread, workgroup and conv (tcn32_keep_k)
     int keep_total, keep_off;                   // clips of the keep layout [conv][clip][256]; first clip of this pass in it
     int save_clips;                             // clips < save_clips leave h1 / h2 / y of every block, the others only the last y
-    // GATHER: the first block's input rows are nn.Embedding rows + dropout formed in the loader; clips < save_clips also
-    // leave them in `xo` (the weight gradient's operand).  The passes of a lockstep batch share the ids; pass k draws its
-    // mask from prng[k] with the row index inside the pass, as s2ag_embedding_fwd run per pass does.
-    const long long* emb_ids;                   // (per_pass * T) token ids
-    const float* emb_table;                     // (entries, C) fp32
-    float* xo;
-    const unsigned long long* prng[S2AG_TCN32_MAX_PASSES];
-    int per_pass, emb_entries;
-    float emb_p, emb_ik;
-    unsigned emb_site;
 };
 
 // keep bits of one pass in the epilogue's register layout: bit (i*MT + mt)*4 + c of thread (wave, lane)
@@ -98,10 +86,7 @@ __global__ __launch_bounds__(256) void tcn32_keep_k(const T32P p) {
 // acc += conv over the fp32 LDS rows at `src`: K tile kt = tap kt / KT_TAP (rows q - d forward, q + d backward for tap 0;
 // q for tap 1), channels (kt % KT_TAP)*32 .. +32.  wh / wl: this wave's hi / lo weight fragments (+ lane); a ring of three
 // K tiles in flight.  The activation fragments are split here: hi = rn(v), lo = rn(v - hi).
-// RING: K tiles of weight fragments in flight (default 3 = 30 KB per wave; 6 with option TCN_RING_DEEP: the kernels wait for their
-// weight stream -- 34 % MFMA utilisation -- and a wave alone on its SIMD has ~170 registers to spare; not yet run on a GPU;
-// same products in the same order = bit-identical results).
-template <bool BWD, int RING = 3>
+template <bool BWD>
 __device__ __forceinline__ void conv32_tile(const float* sm, int src, int Z, const u32x4* __restrict__ wh,
                                             const u32x4* __restrict__ wl, int d, int T, int lane, f32x4 (&acc)[CT_W][MT]) {
     int off0[MT], off1[MT];
@@ -112,10 +97,9 @@ __device__ __forceinline__ void conv32_tile(const float* sm, int src, int Z, con
         off1[mt] = (m < T ? src + m * PITCH : Z) + (lane >> 4) * 8;
         off0[mt] = (ok0 ? src + (BWD ? m + d : m - d) * PITCH : Z) + (lane >> 4) * 8;
     }
-    static_assert(RING >= 2 && RING <= NKT, "ring");
-    u32x4 ah[RING][CT_W], al[RING][CT_W];
+    u32x4 ah[3][CT_W], al[3][CT_W];
 #pragma unroll
-    for (int s = 0; s < RING; ++s)
+    for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int i = 0; i < CT_W; ++i) {
             ah[s][i] = wh[(i * NKT + s) * 64];
@@ -123,7 +107,7 @@ __device__ __forceinline__ void conv32_tile(const float* sm, int src, int Z, con
         }
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        const int s = kt % RING;
+        const int s = kt % 3;
         const bool t0 = kt < KT_TAP;
         const int c0 = (t0 ? kt : kt - KT_TAP) * 32;
         bf16x8 bh[MT], bl[MT];
@@ -152,18 +136,17 @@ __device__ __forceinline__ void conv32_tile(const float* sm, int src, int Z, con
             for (int mt = 0; mt < MT; ++mt) acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avh, bh[mt], acc[i][mt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + RING < NKT) {
+        if (kt + 3 < NKT) {
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
-                ah[s][i] = wh[(i * NKT + kt + RING) * 64];
-                al[s][i] = wl[(i * NKT + kt + RING) * 64];
+                ah[s][i] = wh[(i * NKT + kt + 3) * 64];
+                al[s][i] = wl[(i * NKT + kt + 3) * 64];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <bool GATHER, int RING = 3>
 __global__ __launch_bounds__(256) void tcn32_fwd_k(const T32P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
@@ -175,28 +158,10 @@ __global__ __launch_bounds__(256) void tcn32_fwd_k(const T32P p) {
     const int cpr = C / 4;                                       // 16-byte chunks of an HBM row
 
     // rows in: (row0 + m, 0..C) -> X[m][0..C), pad channels zero
-    SiteKey ekey{0, 0};
-    const int pass = GATHER ? (int)blockIdx.x / p.per_pass : 0;
-    const long long lrow0 = GATHER ? (long long)((int)blockIdx.x - pass * p.per_pass) * T : 0;     // first row inside the pass
-    if (GATHER && p.emb_p > 0.f) ekey = site_key(p.prng[pass], p.emb_site);
     for (int idx = tid; idx < T * (CP / 4); idx += 256) {
         const int m = idx / (CP / 4), kc = idx - m * (CP / 4);
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (GATHER) {
-            if (kc < cpr) {
-                long long id = p.emb_ids[lrow0 + m];
-                id = id < 0 ? 0 : (id >= p.emb_entries ? p.emb_entries - 1 : id);       // as embedding_fwd_k clamps
-                v = *reinterpret_cast<const f32x4*>(p.emb_table + id * C + kc * 4);
-                if (p.emb_p > 0.f) {
-                    const unsigned long long i0 = (unsigned long long)(lrow0 + m) * C + kc * 4;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= keep_scale(ekey, i0 + j, p.emb_p, p.emb_ik);
-                }
-                if ((int)blockIdx.x < p.save_clips) *reinterpret_cast<f32x4*>(p.xo + (row0 + m) * C + kc * 4) = v;
-            }
-        } else {
-            if (kc < cpr) v = *reinterpret_cast<const f32x4*>(p.x + (row0 + m) * C + kc * 4);
-        }
+        if (kc < cpr) v = *reinterpret_cast<const f32x4*>(p.x + (row0 + m) * C + kc * 4);
         *reinterpret_cast<f32x4*>(sm + X + m * PITCH + kc * 4) = v;
         *reinterpret_cast<f32x4*>(sm + H1 + m * PITCH + kc * 4) = f32x4{0.f, 0.f, 0.f, 0.f};      // pad channels of H1 stay zero
     }
@@ -228,7 +193,7 @@ __global__ __launch_bounds__(256) void tcn32_fwd_k(const T32P p) {
             for (int i = 0; i < CT_W; ++i)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            conv32_tile<false, RING>(sm, src, Z, wh, wl, d, T, lane, acc);
+            conv32_tile<false>(sm, src, Z, wh, wl, d, T, lane, acc);
             // epilogue: bias, ReLU, dropout; conv2 also adds the residual and writes the block output over the block input
             const unsigned kw[4] = {kv.x, kv.y, kv.z, kv.w};
             const int dst = j == 0 ? H1 : H2;
@@ -307,7 +272,6 @@ __global__ __launch_bounds__(256) void tcn32_pack_k(const Pack32 p) {
 // The chain of data gradients of all blocks in one launch: G <- G * [y > 0]; P2 <- G * [h2 > 0] / keep (h2 = mask * relu(pre)
 // is positive exactly where the element was kept and pre > 0); P1 <- dgrad_conv2(P2) * [h1 > 0] / keep; G <- dgrad_conv1(P1) + G.
 // P2 / P1 go to HBM as gp2 / gp1: the `gy` operands of the eight weight gradients (s2ag_f32_wgrad_tr, one launch).
-template <int RING = 3>
 __global__ __launch_bounds__(256) void tcn32_bwd_k(const T32P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
@@ -361,7 +325,7 @@ __global__ __launch_bounds__(256) void tcn32_bwd_k(const T32P p) {
             for (int i = 0; i < CT_W; ++i)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            conv32_tile<true, RING>(sm, P2, Z, wh, wl, d, T, lane, acc);
+            conv32_tile<true>(sm, P2, Z, wh, wl, d, T, lane, acc);
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
                 const int co = (wave * CT_W + i) * 16 + (lane >> 4) * 4;
@@ -390,7 +354,7 @@ __global__ __launch_bounds__(256) void tcn32_bwd_k(const T32P p) {
             for (int i = 0; i < CT_W; ++i)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            conv32_tile<true, RING>(sm, P1, Z, wh, wl, d, T, lane, acc);
+            conv32_tile<true>(sm, P1, Z, wh, wl, d, T, lane, acc);
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
                 const int co = (wave * CT_W + i) * 16 + (lane >> 4) * 4;
@@ -439,19 +403,6 @@ static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* co
     if ((reinterpret_cast<uintptr_t>(a->x)) & 15) return S2AG_E_BADARG;
     T32P p{};
     p.x = a->x; p.wfrag = static_cast<const bf16_t*>(a->wfrag);
-    if (a->emb_ids) {
-        if (!a->emb_table || a->emb_entries <= 0 || !(a->emb_drop_p >= 0.f && a->emb_drop_p < 1.f)) return S2AG_E_BADARG;
-        if (n_passes > S2AG_TCN32_MAX_PASSES || ((uintptr_t)a->emb_table & 15)) return S2AG_E_UNSUPPORTED;
-        if (a->emb_drop_p > 0.f && !rngs) return S2AG_E_BADARG;
-        p.emb_ids = a->emb_ids; p.emb_table = a->emb_table; p.xo = const_cast<float*>(a->x);
-        p.per_pass = a->n_clips / n_passes; p.emb_entries = a->emb_entries; p.emb_p = a->emb_drop_p;
-        p.emb_ik = a->emb_drop_p > 0.f ? 1.f / (1.f - a->emb_drop_p) : 1.f;
-        p.emb_site = a->emb_site;
-        for (int k = 0; k < n_passes; ++k) {
-            if (a->emb_drop_p > 0.f && !rngs[k]) return S2AG_E_BADARG;
-            p.prng[k] = rngs ? static_cast<const unsigned long long*>(rngs[k]) : nullptr;
-        }
-    }
     for (int b = 0; b < a->n_blocks; ++b) {
         if (!a->h1[b] || !a->h2[b] || !a->y[b] || a->dil[b] < 1) return S2AG_E_BADARG;
         p.h1[b] = a->h1[b]; p.h2[b] = a->h2[b]; p.y[b] = a->y[b];
@@ -469,9 +420,7 @@ static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* co
     const size_t lds = (size_t)(3 * p.T + 1) * PITCH * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)tcn32_fwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)tcn32_fwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)tcn32_fwd_k<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)tcn32_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
@@ -485,10 +434,7 @@ static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* co
             hipLaunchKernelGGL(tcn32_keep_k, dim3(per, 2 * p.n_blocks), dim3(256), 0, (hipStream_t)stream, q);
         }
     }
-    const int ring = s2ag::option(s2ag::OPT_TCN_RING_DEEP) ? 6 : 3;
-    if (p.emb_ids) hipLaunchKernelGGL(tcn32_fwd_k<true>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
-    else if (ring == 6) hipLaunchKernelGGL((tcn32_fwd_k<false, 6>), dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(tcn32_fwd_k<false>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(tcn32_fwd_k, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }
@@ -523,14 +469,11 @@ extern "C" int s2ag_tcn32_bwd(const s2ag_tcn32_args* a, void* stream) {
     const size_t lds = (size_t)(3 * p.T + 1) * PITCH * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)tcn32_bwd_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)tcn32_bwd_k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)tcn32_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
-    const int ring = s2ag::option(s2ag::OPT_TCN_RING_DEEP) ? 6 : 3;
-    if (ring == 6) hipLaunchKernelGGL(tcn32_bwd_k<6>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(tcn32_bwd_k<3>, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(tcn32_bwd_k, dim3(p.n_clips), dim3(256), lds, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
 }

@@ -34,8 +34,6 @@
 // mantissa bits per product, the precision of the step's other large gradient products, bench.py `matrix_products`).
 #include <type_traits>
 
-#include <stdlib.h>
-
 #include "s2ag_common.h"
 #include "bn_fold_inl.h"
 
@@ -335,14 +333,9 @@ struct W12FwdP {
 //           the banks), 8 K tiles of v_mfma_f32_16x16x32_bf16, z2 stored as bf16;
 //   NP = 2  fp32 image at e + 2 (e / 96) (row pitch 98 floats: the 16 frames x 2 taps of a half-wave read hit 32 different
 //           banks), 60 K steps of v_mfma_f32_16x16x4_f32 -- the reference's fp32 arithmetic, no operand splitting --, z2 fp32.
-// PIPE (fp32 only; S2AG_W12_FWD_PIPE=1, not yet run on a GPU): the B values of the next two K steps are requested before the
-// current four products are issued.  Left alone the scheduler places each LDS read directly in front of its use and waits
-// for it with the matrix pipe idle (53 % MFMA utilisation, profiles/r03_mfma_util_cfg3_fp32.txt).  Same products in the same
-// order on the same accumulators: bit-identical results.
-template <int NP, bool PIPE = false>
+template <int NP>
 __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
     constexpr bool F32 = NP == 2;
-    static_assert(!PIPE || F32, "the pipelined K loop is the fp32 one");
     constexpr int RS = S2 * C1, NKT = K2P / 32, NKB = KS * C1 / 4;
     constexpr int RPAD = F32 ? 2 : 16, PITCH = RS + RPAD;         // elements between the windows of consecutive output frames
     constexpr int AFR = 112;                                      // a1 frames per sub-tile: 6 * 15 + 15 = 105 -> 7 tiles
@@ -443,28 +436,6 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
             // four accumulator chains (channel tile x K parity): a dependent f32 MFMA waits for its predecessor's result
             f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             const float* frow = img32 + n * PITCH + g;
-            if constexpr (PIPE) {
-                float bq[2][2];
-                bq[0][0] = frow[0];
-                bq[0][1] = frow[4 / RS * PITCH + (4 - 4 / RS * RS)];
-#pragma unroll
-                for (int kb = 0; kb < NKB; kb += 2) {
-                    const int cur = (kb >> 1) & 1;
-                    if (kb + 2 < NKB) {
-                        const int k0 = 4 * (kb + 2), j0 = k0 / RS, k1 = k0 + 4, j1 = k1 / RS;      // compile time
-                        S2AG_DBG_ASSERT(n * PITCH + g + j1 * PITCH + (k1 - j1 * RS) < IMG);
-                        bq[cur ^ 1][0] = frow[j0 * PITCH + (k0 - j0 * RS)];
-                        bq[cur ^ 1][1] = frow[j1 * PITCH + (k1 - j1 * RS)];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][kb], bq[cur][0], acc[ct], 0, 0, 0);
-                        acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][kb + 1], bq[cur][1], acc2[ct], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
 #pragma unroll
             for (int kb = 0; kb < NKB; kb += 2) {
                 const int k0 = 4 * kb, j0 = k0 / RS, k1 = k0 + 4, j1 = k1 / RS;      // compile time
@@ -475,7 +446,6 @@ __global__ __launch_bounds__(256) void wv12_fwd_k(const W12FwdP p) {
                     acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][kb], b0, acc[ct], 0, 0, 0);
                     acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][kb + 1], b1, acc2[ct], 0, 0, 0);
                 }
-            }
             }
             acc[0] += acc2[0];
             acc[1] += acc2[1];
@@ -559,10 +529,9 @@ struct W12BwdP {
     const float* mean1;
     const float* inv1;
     float slope;
-    // dy2: XF = 1: ca du2 + cc z2 + cb from the bf16 rows of du2 and z2 (wave_fused.hip); XF = 2: the same from fp32 rows;
-    // XF = 0: dy2 itself, fp32 rows in `dz`
+    // dy2: XF: ca du2 + cc z2 + cb from the bf16 rows of du2 and z2 (wave_fused.hip); else fp32 rows in `dz`
     const void* dz;
-    const void* z2;
+    const bf16_t* z2;
     const float* ca;
     const float* cb;
     const float* cc;
@@ -600,10 +569,8 @@ __device__ __forceinline__ float ld_agent_f(const float* p) { return __hip_atomi
 //   phase 3 wave = (co tile, phase half): dW2[co, r + 6 i, ci] += sum_q dy2[q - i, co] a1[6 q + r, ci] (transpose reads);
 //           wave = (du1 | z1, phase half): S[c, t] += sum_q M[6 q + r, c] x[5 (6 q + r) + t]; the du1 waves also
 //           S_x[t] += sum_q x[5 (6 q + r) + t] (a ones-matrix against the same windows)
-template <int NP, int XF>
+template <int NP, bool XF>
 __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP p) {
-    static_assert(XF != 2 || NP == 2, "fp32 operands of dy2 belong to the fp32 mode");
-    constexpr int XW = XF == 2 ? 2 : 1;                            // 16-byte loads per 8-channel chunk of an operand of dy2
     constexpr int QT = 32, DROWS = QT + NT - 1;
     constexpr int PG = C2 + 8, PA = C1 + 8;
     constexpr int SEGN = 1024;                                     // >= 30 * 31 + 5 * 5 + 15 + 1 = 971
@@ -626,7 +593,8 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
     // the kernel over the 256 registers two workgroups per CU can have; a fragment is re-read per use (9 reads per step)
     constexpr int W2PN = S2 * C1 * NT * C2;
     __shared__ __attribute__((aligned(16))) bf16_t wlds[NP][W2PN];
-    // dy2 = ca du2 + cc z2 + cb (XF): read per use, not 24 registers; written here so that the barrier below orders it too
+    // dy2 = ca du2 + cc z2 + cb (XF): read per use, not 24 registers; written HERE so that the barrier below orders it too
+    // (r03 wrote it after that barrier: the first stash() of waves 2 / 3 could read it before waves 0 / 1 had written it)
     __shared__ float coef2[3][C2];
     if (XF && tid < 3 * C2) coef2[tid / C2][tid % C2] = (tid < C2 ? p.ca : tid < 2 * C2 ? p.cb : p.cc)[tid % C2];
 #pragma unroll
@@ -660,30 +628,22 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
     int c_clip = f_clip, c_q0 = f_q0;
     const int q_wrap = p.QS * QT;
 
-    u32x4 rd[RING][XW], ry[RING][XW];
+    u32x4 rd[RING], ry[RING];
     float rx[RING][4];
     auto fetch = [&](int s, int set) {
         const bool live = s < s_end;
-#pragma unroll
-        for (int k = 0; k < XW; ++k) rd[set][k] = ry[set][k] = u32x4{0u, 0u, 0u, 0u};
+        rd[set] = ry[set] = u32x4{0u, 0u, 0u, 0u};
         const int l = f_q0 - (NT - 1) + d_row;
         if (live && d_own && (unsigned)l < (unsigned)p.L2) {
             S2AG_DBG_ASSERT(f_clip < p.N);
             const long long off = ((long long)f_clip * p.L2 + l) * C2 + d_col;
-            if constexpr (XF == 1) {
-                rd[set][0] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off);
-                ry[set][0] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.z2) + off);
-            } else if constexpr (XF == 2) {
-                const float* gp = static_cast<const float*>(p.dz) + off;
-                const float* zp = static_cast<const float*>(p.z2) + off;
-                rd[set][0] = *reinterpret_cast<const u32x4*>(gp);
-                rd[set][XW - 1] = *reinterpret_cast<const u32x4*>(gp + 4);
-                ry[set][0] = *reinterpret_cast<const u32x4*>(zp);
-                ry[set][XW - 1] = *reinterpret_cast<const u32x4*>(zp + 4);
+            if constexpr (XF) {
+                rd[set] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off);
+                ry[set] = *reinterpret_cast<const u32x4*>(p.z2 + off);
             } else {
                 const float* gp = static_cast<const float*>(p.dz) + off;
-                rd[set][0] = *reinterpret_cast<const u32x4*>(gp);
-                ry[set][0] = *reinterpret_cast<const u32x4*>(gp + 4);
+                rd[set] = *reinterpret_cast<const u32x4*>(gp);
+                ry[set] = *reinterpret_cast<const u32x4*>(gp + 4);
             }
         }
         const long long base = (long long)f_q0 * (S2 * S1) - p.pad;
@@ -706,25 +666,17 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void wv12_bwd_k(const W12BwdP
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = 0.f;
             if ((unsigned)l < (unsigned)p.L2) {
-                if constexpr (XF == 1) {
-                    const unsigned d[4] = {rd[set][0].x, rd[set][0].y, rd[set][0].z, rd[set][0].w};
-                    const unsigned w[4] = {ry[set][0].x, ry[set][0].y, ry[set][0].z, ry[set][0].w};
+                if constexpr (XF) {
+                    const unsigned d[4] = {rd[set].x, rd[set].y, rd[set].z, rd[set].w};
+                    const unsigned w[4] = {ry[set].x, ry[set].y, ry[set].z, ry[set].w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int c = d_col + 2 * j;
                         v[2 * j] = fmaf(coef2[0][c], bf_lo(d[j]), fmaf(coef2[2][c], bf_lo(w[j]), coef2[1][c]));
                         v[2 * j + 1] = fmaf(coef2[0][c + 1], bf_hi(d[j]), fmaf(coef2[2][c + 1], bf_hi(w[j]), coef2[1][c + 1]));
                     }
-                } else if constexpr (XF == 2) {
-                    const f32x4 d0 = __builtin_bit_cast(f32x4, rd[set][0]), d1 = __builtin_bit_cast(f32x4, rd[set][XW - 1]);
-                    const f32x4 w0 = __builtin_bit_cast(f32x4, ry[set][0]), w1 = __builtin_bit_cast(f32x4, ry[set][XW - 1]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = fmaf(coef2[0][d_col + j], d0[j], fmaf(coef2[2][d_col + j], w0[j], coef2[1][d_col + j]));
-                        v[4 + j] = fmaf(coef2[0][d_col + 4 + j], d1[j], fmaf(coef2[2][d_col + 4 + j], w1[j], coef2[1][d_col + 4 + j]));
-                    }
                 } else {
-                    const f32x4 a = __builtin_bit_cast(f32x4, rd[set][0]), b = __builtin_bit_cast(f32x4, ry[set][0]);
+                    const f32x4 a = __builtin_bit_cast(f32x4, rd[set]), b = __builtin_bit_cast(f32x4, ry[set]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         v[j] = a[j];
@@ -1144,9 +1096,7 @@ extern "C" int s2ag_wave12_fwd(const float* x, const void* packed, const float* 
     p.N = N; p.Lin = Lin; p.L1 = L1; p.L2 = L2; p.pad = pad;
     p.chunks = fwd_chunks(N, L2, &p.LC);
     const dim3 grid(N * p.chunks);
-    const int pipe = s2ag::option(s2ag::OPT_W12_FWD_PIPE);
-    if (out_f32 && pipe) hipLaunchKernelGGL((wv12_fwd_k<2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (out_f32) hipLaunchKernelGGL(wv12_fwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (out_f32) hipLaunchKernelGGL(wv12_fwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wv12_fwd_k<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
     S2AG_LAUNCH_CHECK();
     return 0;
@@ -1172,13 +1122,12 @@ extern "C" int s2ag_wave12_bwd(const s2ag_wave12_bwd_args* a, void* stream) {
         !a->part_w2 || !a->part_s || !a->stats || !a->ticket || !a->ca1 || !a->cb1 || !a->cc1 ||
         !geom_ok(a->N, a->Lin, a->L1, a->L2, a->pad))
         return S2AG_E_BADARG;
-    if (a->dz_f32 < 0 || a->dz_f32 > 2) return S2AG_E_BADARG;
-    if (a->dz_f32 != 1 && (!a->z2 || !a->ca2 || !a->cb2 || !a->cc2)) return S2AG_E_BADARG;
+    if (!a->dz_f32 && (!a->z2 || !a->ca2 || !a->cb2 || !a->cc2)) return S2AG_E_BADARG;
     if (!(a->slope >= 0.f && a->slope <= 1.f)) return S2AG_E_UNSUPPORTED;      // leaky(t) = max(t, slope t)
     if (((uintptr_t)a->dz & 15) || ((uintptr_t)a->z2 & 15) || ((uintptr_t)a->packed & 15)) return S2AG_E_BADARG;
     W12BwdP p{};
     p.x = a->x; p.wp = static_cast<const bf16_t*>(a->packed); p.b1 = a->b1; p.sc1 = a->scale1; p.sh1 = a->shift1;
-    p.mean1 = a->mean1; p.inv1 = a->invstd1; p.slope = a->slope; p.dz = a->dz; p.z2 = a->z2;
+    p.mean1 = a->mean1; p.inv1 = a->invstd1; p.slope = a->slope; p.dz = a->dz; p.z2 = static_cast<const bf16_t*>(a->z2);
     p.ca = a->ca2; p.cb = a->cb2; p.cc = a->cc2; p.part_w2 = a->part_w2; p.part_s = a->part_s;
     p.stats = a->stats; p.ticket = a->ticket; p.gamma1 = a->gamma1; p.dgamma1 = a->dgamma1;
     p.dbeta1 = a->dbeta1; p.oca = a->ca1; p.ocb = a->cb1; p.occ = a->cc1;
@@ -1189,9 +1138,8 @@ extern "C" int s2ag_wave12_bwd(const s2ag_wave12_bwd_args* a, void* stream) {
     p.total_steps = a->N * p.QS;
     const int blocks = bwd_blocks(a->N, a->L1, a->dz_f32);
     hipStream_t s = (hipStream_t)stream;
-    if (a->dz_f32 == 1) hipLaunchKernelGGL((wv12_bwd_k<2, 0>), dim3(blocks), dim3(256), 0, s, p);
-    else if (a->dz_f32 == 2) hipLaunchKernelGGL((wv12_bwd_k<2, 2>), dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((wv12_bwd_k<1, 1>), dim3(blocks), dim3(256), 0, s, p);
+    if (a->dz_f32) hipLaunchKernelGGL((wv12_bwd_k<2, false>), dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wv12_bwd_k<1, true>), dim3(blocks), dim3(256), 0, s, p);
     W12FinP f{};
     f.part_w2 = a->part_w2; f.group_s = a->part_s + (size_t)blocks * SROW;
     f.ca = a->ca1; f.cb = a->cb1; f.cc = a->cc1; f.dw2 = a->dw2; f.dw1 = a->dw1;

@@ -27,7 +27,6 @@
 //
 // Every global access is a coalesced 16-byte load / store of a contiguous span; every operand element is read from HBM
 // once per kernel; the weights (<= 120 KB) live in registers.  v_mfma_f32_16x16x32_bf16, fp32 accumulation.
-#include <type_traits>
 #include "s2ag_common.h"
 #include "bn_fold_inl.h"
 
@@ -56,23 +55,6 @@ using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 // two fp32 -> packed bf16 pair, round to nearest even: ONE v_cvt_pk_bf16_f32 (the integer form is 5 instructions per element)
 __device__ __forceinline__ unsigned bf_pack(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-
-// what the hi piece leaves of two fp32 values (exact in fp32): the second bf16 piece of an fp32 operand
-__device__ __forceinline__ unsigned bf_pack_rest(float a, float b, unsigned hi) { return bf_pack(a - bf_lo(hi), b - bf_hi(hi)); }
-// eight fp32 values -> the chunk of their hi pieces and the chunk of what those leave (two bf16 pieces = 16 mantissa bits)
-__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
-    const unsigned h0 = bf_pack(v[0], v[1]), h1 = bf_pack(v[2], v[3]), h2 = bf_pack(v[4], v[5]), h3 = bf_pack(v[6], v[7]);
-    hi = u32x4{h0, h1, h2, h3};
-    lo = u32x4{bf_pack_rest(v[0], v[1], h0), bf_pack_rest(v[2], v[3], h1), bf_pack_rest(v[4], v[5], h2), bf_pack_rest(v[6], v[7], h3)};
-}
-__device__ __forceinline__ void unpack8(u32x4 a, u32x4 b, float (&v)[8]) {
-    const f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        v[j] = x[j];
-        v[4 + j] = y[j];
-    }
 }
 
 // a = leaky(scale * y + shift) on a 16-byte chunk of 8 consecutive channels (the chunk's channels are the lane's own:
@@ -329,268 +311,24 @@ int launch_fwd(WvFwdP p, hipStream_t stream) {
     return p.N * p.chunks;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// forward of conv3 / conv4 in fp32 mode: fp32 rows in HBM, products on v_mfma_f32_16x16x4_f32 (bit-for-bit an fmaf chain:
-// the forward pass keeps the reference's fp32 arithmetic -- a forward formed from bf16 pieces moves LeakyReLU branch
-// decisions at the 1e-5 level, which the gradient tests see).  Same shape as wv_fwd_k with TEAM = 4: a sub-tile of 16 output
-// frames per step on a shared, double-buffered fp32 image of the 15 RS + K input elements under it (pitch RS + 2: the 32
-// lanes of a half-wave -- 16 frames x 2 k -- read 32 different banks); wave = (channel tile, K part); weights k-major
-// (15 CIN, COUT) fp32, a wave's 120 K steps in registers.  BatchNorm + LeakyReLU of the previous layer on the way into LDS.
-struct WvF32P {
-    const float* x;           // (N, Lin, CIN) raw output of the previous conv
-    const float* sc;          // CIN: scale / shift of the previous BatchNorm
-    const float* sh;
-    float slope;
-    const float* wk;          // (15 CIN, COUT): wk[t CIN + ci][co] = W[co][ci][t]
-    const float* bias;        // COUT, nullable
-    float* y;                 // (N, Lout, COUT)
-    double* stats;            // (2, gridDim.x (+ groups), COUT) or null
-    int N, Lin, Lout;
-    int chunks, LC;
-    FwdFold fold;
-};
-
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void wv_fwd32_k(const WvF32P p) {
-    constexpr int K = WKS * CIN;
-    constexpr int RS = WS * CIN;
-    constexpr int PITCH = RS + 2;
-    constexpr int SPAN = 15 * RS + K;                     // floats under a sub-tile of 16 frames
-    constexpr int IROWS = (SPAN + RS - 1) / RS;
-    constexpr int NCT = COUT / 16;
-    constexpr int KSPLIT = 4 / NCT;
-    constexpr int NKB = K / 4 / KSPLIT;                   // K steps (of 4) per wave
-    constexpr int NLD = (SPAN / 4 + 255) / 256;
-    constexpr int RING = CIN >= 64 ? 2 : 3;
-    static_assert(NCT * KSPLIT == 4 && (K / 4) % KSPLIT == 0 && RS % 4 == 0 && SPAN % 4 == 0, "shape");
-    static_assert(1024 % CIN == 0, "a thread's chunks must all start at the same channel");
-    static_assert(NKB % 4 == 0, "four accumulator chains");
-    __shared__ __attribute__((aligned(16))) float img_s[2][IROWS * PITCH];
-    __shared__ double red[4][2][COUT];
-    __shared__ __attribute__((aligned(16))) float kred[KSPLIT > 1 ? (KSPLIT - 1) * NCT : 1][16 * 16 + 4];
-
-    const int tid = threadIdx.x, lane = tid & 63, fn = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ct0 = wave % NCT, kpart = KSPLIT == 1 ? 0 : wave / NCT;
-
-    // weights: wf[kb] = wk[k = 4 (kpart NKB + kb) + g][co = 16 ct0 + fn]
-    float wf[NKB];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) wf[kb] = p.wk[(size_t)(4 * (kpart * NKB + kb) + g) * COUT + 16 * ct0 + fn];
-    float bias[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) bias[v] = p.bias ? p.bias[16 * ct0 + 4 * g + v] : 0.f;
-    float sc[4], sh[4];
-    {
-        const int c0 = (tid * 4) % CIN;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sc[j] = p.sc[c0 + j];
-            sh[j] = p.sh[c0 + j];
-        }
-    }
-
-    const int n = blockIdx.x / p.chunks;
-    const int l_lo = (blockIdx.x - n * p.chunks) * p.LC;
-    int l_hi = l_lo + p.LC;
-    if (l_hi > p.Lout) l_hi = p.Lout;
-    const float* xc = p.x + (long long)n * p.Lin * CIN;
-    const long long xlen = (long long)p.Lin * CIN;
-
-    f32x4 st[RING][NLD];
-    auto fetch = [&](int l0, int set) {
-        const long long base = (long long)l0 * RS;
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int e = (u * 256 + tid) * 4;
-            st[set][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (e < SPAN && base + e + 3 < xlen) st[set][u] = *reinterpret_cast<const f32x4*>(xc + base + e);
-        }
-    };
-    auto stash = [&](float* img, int l0, int set) {
-        const long long base = (long long)l0 * RS;
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int e = (u * 256 + tid) * 4;
-            if (e < SPAN) {
-                S2AG_DBG_ASSERT(e + 2 * (e / RS) + 4 <= IROWS * PITCH);
-                f32x2 a = f32x2{0.f, 0.f}, b = f32x2{0.f, 0.f};
-                if (base + e + 3 < xlen) {
-                    const f32x4 v = st[set][u];
-                    a = f32x2{leaky(fmaf(sc[0], v[0], sh[0]), p.slope), leaky(fmaf(sc[1], v[1], sh[1]), p.slope)};
-                    b = f32x2{leaky(fmaf(sc[2], v[2], sh[2]), p.slope), leaky(fmaf(sc[3], v[3], sh[3]), p.slope)};
-                }
-                float* d = img + e + 2 * (e / RS);        // 8-byte aligned
-                *reinterpret_cast<f32x2*>(d) = a;
-                *reinterpret_cast<f32x2*>(d + 2) = b;
-            }
-        }
-    };
-
-    double s1[4], s2[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) s1[v] = s2[v] = 0.0;
-
-    int buf = 0;
-#pragma unroll
-    for (int r = 0; r < RING; ++r)
-        if (l_lo + r * 16 < l_hi) fetch(l_lo + r * 16, r);
-    for (int lb = l_lo; lb < l_hi; lb += RING * 16)
-#pragma unroll
-    for (int rs = 0; rs < RING; ++rs) {
-        const int l0 = lb + rs * 16;
-        if (l0 >= l_hi) break;                            // uniform over the workgroup
-        float* img = img_s[buf];
-        stash(img, l0, rs);
-        __syncthreads();
-        if (l0 + RING * 16 < l_hi) fetch(l0 + RING * 16, rs);
-        // frame fn's window starts at flat element fn RS; element k of it sits at fn PITCH + k + 2 (k / RS)
-        const float* frow = img + fn * PITCH + g;
-        f32x4 acc[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // K part as a compile-time constant (every LDS offset an immediate); the B values of the next GB steps are requested
-        // before the current GB products are issued (a product takes 32 cycles, an LDS read arrives after ~64+); four
-        // accumulator chains: a dependent f32 MFMA waits for its predecessor's result
-        auto products = [&](auto kp_c) {
-            constexpr int KP = decltype(kp_c)::value;
-            constexpr int GB = 8, NG = NKB / GB;
-            static_assert(NKB % GB == 0, "groups");
-            float bv[2][GB];
-#pragma unroll
-            for (int j = 0; j < GB; ++j) {
-                constexpr int kz = 4 * (KP * NKB);
-                const int k0 = kz + 4 * j;
-                bv[0][j] = frow[k0 + 2 * (k0 / RS)];
-            }
-#pragma unroll
-            for (int gi = 0; gi < NG; ++gi) {
-                if (gi + 1 < NG) {
-#pragma unroll
-                    for (int j = 0; j < GB; ++j) {
-                        const int k0 = 4 * (KP * NKB + (gi + 1) * GB + j);
-                        bv[(gi + 1) & 1][j] = frow[k0 + 2 * (k0 / RS)];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);         // (left alone the scheduler sinks each read to just before its use)
-#pragma unroll
-                for (int j = 0; j < GB; ++j)
-                    acc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gi * GB + j], bv[gi & 1][j], acc[j & 3], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if constexpr (KSPLIT == 1) {
-            products(std::integral_constant<int, 0>{});
-        } else {
-            static_assert(KSPLIT == 2, "K parts");
-            if (kpart == 0) products(std::integral_constant<int, 0>{});
-            else products(std::integral_constant<int, 1>{});
-        }
-        f32x4 out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-        if (KSPLIT > 1) {                                 // the K parts of a channel tile meet in LDS; part 0 finishes
-            if (kpart > 0) *reinterpret_cast<f32x4*>(&kred[(kpart - 1) * NCT + ct0][lane * 4]) = out;
-            __syncthreads();
-            if (kpart == 0) {
-#pragma unroll
-                for (int kp = 1; kp < KSPLIT; ++kp) out += *reinterpret_cast<const f32x4*>(&kred[(kp - 1) * NCT + ct0][lane * 4]);
-            }
-        }
-        // D[co][frame]: this lane holds channels 16 ct0 + 4 g + v of frame l0 + fn
-        const int l = l0 + fn;
-        if (kpart == 0 && l < l_hi) {
-            float r[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) r[v] = out[v] + bias[v];
-            *reinterpret_cast<f32x4*>(p.y + ((long long)n * p.Lout + l) * COUT + 16 * ct0 + 4 * g) = f32x4{r[0], r[1], r[2], r[3]};
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                s1[v] += (double)r[v];
-                s2[v] += (double)r[v] * (double)r[v];
-            }
-        }
-        buf ^= 1;          // (the barrier of the next step's stash separates this step's kred reads from its next writes)
-    }
-    if (p.stats) {          // (2, gridDim.x, COUT): one partial row per workgroup
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            double a1 = s1[v], a2 = s2[v];
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
-                a1 += __shfl_xor(a1, m, 64);
-                a2 += __shfl_xor(a2, m, 64);
-            }
-            if (fn == 0) {
-                red[wave][0][16 * ct0 + 4 * g + v] = a1;
-                red[wave][1][16 * ct0 + 4 * g + v] = a2;
-            }
-        }
-        __syncthreads();
-        if (tid < 2 * COUT) {
-            const int which = tid / COUT, c = tid - which * COUT;
-            st_agent(p.stats + ((size_t)which * gridDim.x + blockIdx.x) * COUT + c, red[(c / 16) % NCT][which][c]);   // the K-part-0 wave
-        }
-        if (p.fold.ticket && two_level_done(p.stats, gridDim.x, COUT, p.fold.ticket)) {
-            __shared__ double fred[2][256];
-            bn_fwd_fold_body(p.stats + (size_t)2 * gridDim.x * COUT, fold_groups(gridDim.x), COUT, p.fold, fred);
-        }
-    }
-}
-
-template <int CIN, int COUT>
-int launch_fwd32(WvF32P p, hipStream_t stream) {
-    int per_clip = cdiv(512, p.N);
-    if (per_clip < 1) per_clip = 1;
-    p.LC = cdiv(cdiv(p.Lout, per_clip), 16) * 16;
-    p.chunks = cdiv(p.Lout, p.LC);
-    hipLaunchKernelGGL((wv_fwd32_k<CIN, COUT>), dim3(p.N * p.chunks), dim3(256), 0, stream, p);
-    return p.N * p.chunks;
-}
-
-// operand layouts of conv3 / conv4 for the fp32 tail, one launch for both layers (blockIdx.y): the forward's k-major fp32
-// matrix (15 CIN, COUT) and the data gradient's phase form (6, CIN, 3, COUT) as two bf16 pieces
-__global__ __launch_bounds__(256) void wv_tail32_pack_k(const float* __restrict__ w3, const float* __restrict__ w4,
-                                                        float* __restrict__ k3, float* __restrict__ k4,
-                                                        bf16_t* __restrict__ p3, bf16_t* __restrict__ p4) {
-    const int layer = blockIdx.y;
-    const int CIN = layer ? 64 : 32, COUT = layer ? 32 : 64;
-    const float* w = layer ? w4 : w3;                     // (COUT, CIN, 15)
-    float* wk = layer ? k4 : k3;
-    bf16_t* wp = layer ? p4 : p3;
-    const int nk = WKS * CIN * COUT, np = WS * CIN * WNT * COUT;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nk + np; i += gridDim.x * 256) {
-        if (i < nk) {
-            const int co = i % COUT, k = i / COUT, ci = k % CIN, t = k / CIN;
-            wk[i] = w[((size_t)co * CIN + ci) * WKS + t];
-        } else {
-            const int j = i - nk;
-            const int co = j % COUT, ti = (j / COUT) % WNT, ci = (j / (COUT * WNT)) % CIN, r = j / (COUT * WNT * CIN);
-            const int t = r + WS * ti;
-            const float v = t < WKS ? w[((size_t)co * CIN + ci) * WKS + t] : 0.f;
-            const unsigned hi = bf_rn(v);
-            wp[j] = (bf16_t)hi;
-            wp[np + j] = (bf16_t)bf_rn(v - __uint_as_float(hi << 16));
-        }
-    }
-}
-
 // =====================================================================================================================
 // data gradient (poly-phase) with the BatchNorm backward on both sides
 // =====================================================================================================================
 struct WvDgP {
-    const void* dz;           // (N, Lout, COUT): dz_i (bf16; fp32 with F32), or the fp32 output gradient of the last conv (G_F32)
-    const void* y;            // (N, Lout, COUT) raw output of conv i (unused with G_F32)
+    const void* dz;           // (N, Lout, COUT): dz_i (bf16), or the fp32 output gradient of the last conv (G_F32)
+    const bf16_t* y;          // (N, Lout, COUT) raw output of conv i (unused with G_F32)
     const float* ca;          // COUT: dy = ca dz + cc y + cb (unused with G_F32)
     const float* cb;
     const float* cc;
-    const bf16_t* w;          // (pieces, 6, CIN, 3, CPO) bf16: w[r][ci][i][co] = W[co][ci][r + 6 i], zero beyond the taps / COUT
+    const bf16_t* w;          // (6, CIN, 3, CPO) bf16: w[r][ci][i][co] = W[co][ci][r + 6 i], zero beyond the taps / COUT
     int CPO;
-    const void* yp;           // (N, Lin, CIN) raw output of conv i-1
+    const bf16_t* yp;         // (N, Lin, CIN) raw output of conv i-1
     const float* psc;         // CIN: scale / shift / mean / invstd of BatchNorm i-1
     const float* psh;
     const float* pmean;
     const float* pinv;
     float slope;
-    void* dzp;                // (N, Lin, CIN) out: dz_{i-1} = da_{i-1} * leaky'(psc yp + psh)
+    bf16_t* dzp;              // (N, Lin, CIN) out: dz_{i-1} = da_{i-1} * leaky'(psc yp + psh)
     double* stats;            // (2, gridDim.x, CIN): column sums of dz_{i-1} and of dz_{i-1} * xhat_{i-1}
     int N, Lin, Lout, Q, chunks, QC;
     // fold of those sums by the workgroup that finishes last (ticket != null): gradients of gamma / beta of BatchNorm i-1
@@ -605,10 +343,7 @@ struct WvDgP {
     double inv_rows;
 };
 
-// F32 (the fp32 mode's tail of the encoder): every tensor is fp32 in HBM; dy and the weights enter the bf16 matrix pipe as
-// two pieces each (hi = rn(v), lo = rn(v - hi): three products, 16 mantissa bits -- the same treatment the other large
-// gradients of the fp32 mode get, wgrad_tr.hip / gru_coop.hip); everything around the products is fp32.
-template <int COUT, int CIN, int TEAM, bool G_F32, bool F32 = false>
+template <int COUT, int CIN, int TEAM, bool G_F32>
 __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
     constexpr int NCT = CIN / 16;                         // 16-channel tiles of the output
     constexpr int KC = COUT / 32;                         // MFMA K steps per tap
@@ -620,13 +355,10 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
     constexpr int NTH = TEAM == 1 ? 64 : 256;
     constexpr int NLD = (DROWS * COUT / 8 + NTH - 1) / NTH;
     constexpr int NOC = (16 * WS * CIN / 8 + NTH - 1) / NTH;  // output chunks per thread
-    constexpr int NPL = F32 ? 2 : 1;                      // bf16 planes of an operand
-    constexpr int WD = (F32 && !G_F32) ? 2 : 1;           // 16-byte loads per 8-channel chunk of dz / y ...
-    constexpr int WY = F32 ? 2 : 1;                       // ... and of y_{i-1}
     static_assert(TEAM == 1 ? NCT == 1 : (NCT == 2 || NCT == 4), "teams");
     static_assert((NTH * 8) % COUT == 0 && (NTH * 8) % CIN == 0, "a thread's chunks must all start at the same channel");
     constexpr int NIMG = TEAM == 1 ? 4 : 1;
-    __shared__ __attribute__((aligned(16))) bf16_t dimg_s[NIMG][NPL][DROWS * PD];
+    __shared__ __attribute__((aligned(16))) bf16_t dimg_s[NIMG][DROWS * PD];
     __shared__ __attribute__((aligned(16))) float oimg_s[NIMG][16 * WS * OP];
     __shared__ double red[4][2][CIN];
 
@@ -636,21 +368,18 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
     const int ct = TEAM == 1 ? 0 : (NCT == 2 ? (wave & 1) : wave);
     const int pstart = (TEAM == 4 && NCT == 2) ? (wave >> 1) : 0;
 
-    // weights of this wave: wa[piece][j][i][kc] = w[r_j][ci = 16 ct + (lane & 15)][i][co = 32 kc + 8 (lane >> 4) .. + 8]
-    bf16x8 wa[NPL][NPH][WNT][KC];
+    // weights of this wave: wa[j][i][kc] = w[r_j][ci = 16 ct + (lane & 15)][i][co = 32 kc + 8 (lane >> 4) .. + 8]
+    bf16x8 wa[NPH][WNT][KC];
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl)
+    for (int j = 0; j < NPH; ++j)
 #pragma unroll
-        for (int j = 0; j < NPH; ++j)
+        for (int i = 0; i < WNT; ++i)
 #pragma unroll
-            for (int i = 0; i < WNT; ++i)
-#pragma unroll
-                for (int kc = 0; kc < KC; ++kc)
-                    wa[pl][j][i][kc] = __builtin_bit_cast(
-                        bf16x8, *reinterpret_cast<const u32x4*>(
-                                    p.w + (long long)pl * WS * CIN * WNT * p.CPO +
-                                    ((long long)((pstart + j * PSTEP) * CIN + 16 * ct + (lane & 15)) * WNT + i) * p.CPO +
-                                    32 * kc + 8 * (lane >> 4)));
+            for (int kc = 0; kc < KC; ++kc)
+                wa[j][i][kc] = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const u32x4*>(
+                                p.w + ((long long)((pstart + j * PSTEP) * CIN + 16 * ct + (lane & 15)) * WNT + i) * p.CPO +
+                                32 * kc + 8 * (lane >> 4)));
     // coefficient sets of a thread's 8 source channels (loader) and 8 output channels (epilogue): in LDS, read per use -- as
     // 56 registers per lane they left no room for a ring of prefetched sub-tiles at two workgroups per CU
     __shared__ float cf_src[3][COUT], cf_out[4][CIN];
@@ -677,36 +406,29 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
     int q_hi = q_lo + p.QC;
     if (q_hi > p.Q) q_hi = p.Q;
     const long long src_clip = (long long)n * p.Lout * COUT;
-    const long long prev_clip = (long long)n * p.Lin * CIN;
+    const bf16_t* ypc = p.yp + (long long)n * p.Lin * CIN;
+    bf16_t* dzc = p.dzp + (long long)n * p.Lin * CIN;
 
     // RING sub-tiles' raw rows (the operands of dy and the rows of y_{i-1} the epilogue needs) in flight in registers: with
     // one set a workgroup's sub-tiles were a chain of memory round trips.  The dy transform runs when a set goes to LDS.
     constexpr int RING = TEAM == 1 ? 2 : 3;
-    u32x4 sd[RING][NLD][WD], sy[RING][NLD][WD], yvr[RING][NOC][WY];
+    u32x4 sd[RING][NLD], sy[RING][NLD], yvr[RING][NOC];
     auto fetch = [&](int q0, int set) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int e = (u * NTH + st_id) * 8;
             const int row = e / COUT, col = e - row * COUT;
             const int l = q0 - (WNT - 1) + row;
-#pragma unroll
-            for (int k = 0; k < WD; ++k) sd[set][u][k] = sy[set][u][k] = u32x4{0u, 0u, 0u, 0u};
+            sd[set][u] = sy[set][u] = u32x4{0u, 0u, 0u, 0u};
             if (row < DROWS && (unsigned)l < (unsigned)p.Lout) {
                 const long long off = src_clip + (long long)l * COUT + col;
                 if constexpr (G_F32) {
                     const float* g = static_cast<const float*>(p.dz) + off;
-                    sd[set][u][0] = *reinterpret_cast<const u32x4*>(g);
-                    sy[set][u][0] = *reinterpret_cast<const u32x4*>(g + 4);
-                } else if constexpr (F32) {
-                    const float* a = static_cast<const float*>(p.dz) + off;
-                    const float* b = static_cast<const float*>(p.y) + off;
-                    sd[set][u][0] = *reinterpret_cast<const u32x4*>(a);
-                    sd[set][u][1] = *reinterpret_cast<const u32x4*>(a + 4);
-                    sy[set][u][0] = *reinterpret_cast<const u32x4*>(b);
-                    sy[set][u][1] = *reinterpret_cast<const u32x4*>(b + 4);
+                    sd[set][u] = *reinterpret_cast<const u32x4*>(g);
+                    sy[set][u] = *reinterpret_cast<const u32x4*>(g + 4);
                 } else {
-                    sd[set][u][0] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off);
-                    sy[set][u][0] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.y) + off);
+                    sd[set][u] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off);
+                    sy[set][u] = *reinterpret_cast<const u32x4*>(p.y + off);
                 }
             }
         }
@@ -716,21 +438,11 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
         for (int u = 0; u < NOC; ++u) {
             const int e = (u * NTH + st_id) * 8;
             const int row = e / CIN;
-#pragma unroll
-            for (int k = 0; k < WY; ++k) yvr[set][u][k] = u32x4{0u, 0u, 0u, 0u};
-            if (row < 16 * WS && pos0 + row < p.Lin) {
-                const long long off = prev_clip + (long long)pos0 * CIN + e;
-                if constexpr (F32) {
-                    const float* a = static_cast<const float*>(p.yp) + off;
-                    yvr[set][u][0] = *reinterpret_cast<const u32x4*>(a);
-                    yvr[set][u][1] = *reinterpret_cast<const u32x4*>(a + 4);
-                } else {
-                    yvr[set][u][0] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.yp) + off);
-                }
-            }
+            yvr[set][u] = u32x4{0u, 0u, 0u, 0u};
+            if (row < 16 * WS && pos0 + row < p.Lin) yvr[set][u] = *reinterpret_cast<const u32x4*>(ypc + (long long)pos0 * CIN + e);
         }
     };
-    auto stash = [&](bf16_t (*img)[DROWS * PD], int q0, int set) {
+    auto stash = [&](bf16_t* img, int q0, int set) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int e = (u * NTH + st_id) * 8;
@@ -738,30 +450,16 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
             const int l = q0 - (WNT - 1) + row;
             if (row < DROWS) {
                 S2AG_DBG_ASSERT(row * PD + col + 8 <= DROWS * PD);
-                u32x4 v = u32x4{0u, 0u, 0u, 0u}, vl = u32x4{0u, 0u, 0u, 0u};
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
                 if ((unsigned)l < (unsigned)p.Lout) {
-                    if constexpr (F32) {
-                        float dy[8];
-                        if constexpr (G_F32) {
-                            unpack8(sd[set][u][0], sy[set][u][0], dy);
-                        } else {
-                            float d[8], yy[8];
-                            unpack8(sd[set][u][0], sd[set][u][1], d);
-                            unpack8(sy[set][u][0], sy[set][u][1], yy);
-#pragma unroll
-                            for (int k = 0; k < 8; ++k)
-                                dy[k] = fmaf(cf_src[0][c_src + k], d[k], fmaf(cf_src[2][c_src + k], yy[k], cf_src[1][c_src + k]));
-                        }
-                        split8(dy, v, vl);
-                    } else if constexpr (G_F32) {
-                        const f32x4 a = __builtin_bit_cast(f32x4, sd[set][u][0]), b = __builtin_bit_cast(f32x4, sy[set][u][0]);
+                    if constexpr (G_F32) {
+                        const f32x4 a = __builtin_bit_cast(f32x4, sd[set][u]), b = __builtin_bit_cast(f32x4, sy[set][u]);
                         v = u32x4{bf_pack(a[0], a[1]), bf_pack(a[2], a[3]), bf_pack(b[0], b[1]), bf_pack(b[2], b[3])};
                     } else {
-                        v = bn_bwd8(sd[set][u][0], sy[set][u][0], cf_src[0] + c_src, cf_src[1] + c_src, cf_src[2] + c_src);
+                        v = bn_bwd8(sd[set][u], sy[set][u], cf_src[0] + c_src, cf_src[1] + c_src, cf_src[2] + c_src);
                     }
                 }
-                *reinterpret_cast<u32x4*>(img[0] + row * PD + col) = v;
-                if constexpr (F32) *reinterpret_cast<u32x4*>(img[NPL - 1] + row * PD + col) = vl;
+                *reinterpret_cast<u32x4*>(img + row * PD + col) = v;
             }
         }
     };
@@ -776,29 +474,25 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
     for (int rs = 0; rs < RING; ++rs) {
         const int q0 = qb + rs * STEP;
         if (q0 >= q_hi) break;                            // uniform over the workgroup (TEAM = 4) / the wave (TEAM = 1)
-        bf16_t (*dimg)[DROWS * PD] = TEAM == 1 ? dimg_s[wave] : dimg_s[0];
+        bf16_t* dimg = TEAM == 1 ? dimg_s[wave] : dimg_s[0];
         float* oimg = TEAM == 1 ? oimg_s[wave] : oimg_s[0];
         if (TEAM == 1) __builtin_amdgcn_wave_barrier();
         stash(dimg, q0, rs);
         if (TEAM == 1) __builtin_amdgcn_wave_barrier();
         else __syncthreads();
-        u32x4 yv[NOC][WY];
+        u32x4 yv[NOC];
 #pragma unroll
-        for (int u = 0; u < NOC; ++u)
-#pragma unroll
-            for (int k = 0; k < WY; ++k) yv[u][k] = yvr[rs][u][k];
+        for (int u = 0; u < NOC; ++u) yv[u] = yvr[rs][u];
         const int pos0 = WS * q0;
         if (q0 + RING * STEP < q_hi) fetch(q0 + RING * STEP, rs);
-        // B fragments: b[piece][i][kc] = dy[q0 + (lane & 15) - i][32 kc + 8 (lane >> 4) .. + 8]
-        bf16x8 b[NPL][WNT][KC];
+        // B fragments: b[i][kc] = dy[q0 + (lane & 15) - i][32 kc + 8 (lane >> 4) .. + 8]
+        bf16x8 b[WNT][KC];
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
+        for (int i = 0; i < WNT; ++i)
 #pragma unroll
-            for (int i = 0; i < WNT; ++i)
-#pragma unroll
-                for (int kc = 0; kc < KC; ++kc)
-                    b[pl][i][kc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
-                                                                  dimg[pl] + ((lane & 15) + WNT - 1 - i) * PD + 32 * kc + 8 * (lane >> 4)));
+            for (int kc = 0; kc < KC; ++kc)
+                b[i][kc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                                                          dimg + ((lane & 15) + WNT - 1 - i) * PD + 32 * kc + 8 * (lane >> 4)));
         f32x4 acc[NPH];
 #pragma unroll
         for (int j = 0; j < NPH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -808,13 +502,8 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
             for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
                 for (int j = 0; j < NPH; ++j)
-                    if (pstart + j * PSTEP + WS * i < WKS) {     // wave-uniform: the last phases have one tap less
-                        if constexpr (F32) {                     // the two cross products first, the large one last
-                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[NPL - 1][j][i][kc], b[0][i][kc], acc[j], 0, 0, 0);
-                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][j][i][kc], b[NPL - 1][i][kc], acc[j], 0, 0, 0);
-                        }
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][j][i][kc], b[0][i][kc], acc[j], 0, 0, 0);
-                    }
+                    if (pstart + j * PSTEP + WS * i < WKS)       // wave-uniform: the last phases have one tap less
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][i][kc], b[i][kc], acc[j], 0, 0, 0);
         // D[ci][q] -> fp32 image of the 96 output frames: row 6 (lane & 15) + r, channels 16 ct + 4 (lane >> 4) .. + 4
 #pragma unroll
         for (int j = 0; j < NPH; ++j)
@@ -834,31 +523,18 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
                 const f32x4 d0 = *reinterpret_cast<const f32x4*>(oimg + row * OP + col);
                 const f32x4 d1 = *reinterpret_cast<const f32x4*>(oimg + row * OP + col + 4);
                 const float da[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-                float yk[8];
-                if constexpr (F32) {
-                    unpack8(yv[u][0], yv[u][WY - 1], yk);
-                } else {
-                    const unsigned w[4] = {yv[u][0].x, yv[u][0].y, yv[u][0].z, yv[u][0].w};
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) yk[k] = (k & 1) ? bf_hi(w[k >> 1]) : bf_lo(w[k >> 1]);
-                }
+                const unsigned w[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
                 float dzv[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float z = fmaf(cf_out[0][c_out + k], yk[k], cf_out[1][c_out + k]);
+                    const float yk = (k & 1) ? bf_hi(w[k >> 1]) : bf_lo(w[k >> 1]);
+                    const float z = fmaf(cf_out[0][c_out + k], yk, cf_out[1][c_out + k]);
                     dzv[k] = z > 0.f ? da[k] : da[k] * p.slope;
                     s1[k] += dzv[k];
-                    s2[k] = fmaf(dzv[k], fmaf(yk[k], cf_out[2][c_out + k], cf_out[3][c_out + k]), s2[k]);
+                    s2[k] = fmaf(dzv[k], fmaf(yk, cf_out[2][c_out + k], cf_out[3][c_out + k]), s2[k]);
                 }
-                const long long off = prev_clip + (long long)pos0 * CIN + e;
-                if constexpr (F32) {
-                    float* o = static_cast<float*>(p.dzp) + off;
-                    *reinterpret_cast<f32x4*>(o) = f32x4{dzv[0], dzv[1], dzv[2], dzv[3]};
-                    *reinterpret_cast<f32x4*>(o + 4) = f32x4{dzv[4], dzv[5], dzv[6], dzv[7]};
-                } else {
-                    *reinterpret_cast<u32x4*>(static_cast<bf16_t*>(p.dzp) + off) =
-                        u32x4{bf_pack(dzv[0], dzv[1]), bf_pack(dzv[2], dzv[3]), bf_pack(dzv[4], dzv[5]), bf_pack(dzv[6], dzv[7])};
-                }
+                *reinterpret_cast<u32x4*>(dzc + (long long)pos0 * CIN + e) =
+                    u32x4{bf_pack(dzv[0], dzv[1]), bf_pack(dzv[2], dzv[3]), bf_pack(dzv[4], dzv[5]), bf_pack(dzv[6], dzv[7])};
             }
         }
     }
@@ -890,7 +566,7 @@ __global__ __launch_bounds__(256) void wv_dgrad_k(const WvDgP p) {
     }
 }
 
-template <int COUT, int CIN, int TEAM, bool G_F32, bool F32 = false>
+template <int COUT, int CIN, int TEAM, bool G_F32>
 int launch_dgrad(WvDgP p, hipStream_t stream) {
     const int step = TEAM == 1 ? 64 : 16;
     p.Q = cdiv(p.Lin, WS);
@@ -898,7 +574,7 @@ int launch_dgrad(WvDgP p, hipStream_t stream) {
     if (per_clip < 1) per_clip = 1;
     p.QC = cdiv(cdiv(p.Q, per_clip), step) * step;
     p.chunks = cdiv(p.Q, p.QC);
-    hipLaunchKernelGGL((wv_dgrad_k<COUT, CIN, TEAM, G_F32, F32>), dim3(p.N * p.chunks), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((wv_dgrad_k<COUT, CIN, TEAM, G_F32>), dim3(p.N * p.chunks), dim3(256), 0, stream, p);
     return p.N * p.chunks;
 }
 
@@ -907,11 +583,11 @@ int launch_dgrad(WvDgP p, hipStream_t stream) {
 // =====================================================================================================================
 struct WvWgP {
     const void* dz;           // as in WvDgP: the operands of dy_i
-    const void* y;
+    const bf16_t* y;
     const float* ca;
     const float* cb;
     const float* cc;
-    const void* yp;           // (N, Lin, CIN) raw output of conv i-1; a = leaky(psc yp + psh)
+    const bf16_t* yp;         // (N, Lin, CIN) raw output of conv i-1; a = leaky(psc yp + psh)
     const float* psc;
     const float* psh;
     float slope;
@@ -933,8 +609,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int off, int pitch)
 // index i) are split over the waves -- (32, 16): wave = (co tile, phase half);  (64, 32): wave = co tile;  (32, 64): wave =
 // ci tile -- and, for the two small layers, the phases over blockIdx.y (PSPLIT = 3: a workgroup stages the frames of ITS two
 // phases only, so the input is still read once; the 123 KB partial tile of a workgroup is shared by the three).
-// F32: fp32 tensors in HBM, dy and a as two bf16 pieces each in LDS (three products), see wv_dgrad_k.
-template <int COUT, int CIN, bool G_F32, int PSPLIT, bool F32 = false>
+template <int COUT, int CIN, bool G_F32, int PSPLIT>
 __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
     constexpr int NCOT = COUT / 16, NCIT = CIN / 16;
     constexpr int WCOT = (NCOT == 2 && NCIT == 4) ? 2 : 1;    // co tiles per wave
@@ -948,13 +623,10 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
     constexpr int NDC = DROWS * COUT / 8, NAC = QT * NPW * CIN / 8;
     constexpr int NLD = (NDC + 255) / 256, NLA = (NAC + 255) / 256;
     constexpr int RING = 3;
-    constexpr int NPL = F32 ? 2 : 1;                           // bf16 planes of an operand
-    constexpr int WD = (F32 && !G_F32) ? 2 : 1;                // 16-byte loads per 8-channel chunk of dz / y ...
-    constexpr int WY = F32 ? 2 : 1;                            // ... and of y_{i-1}
     static_assert(2048 % COUT == 0 && 2048 % CIN == 0, "a thread's chunks must all start at the same channel");
     static_assert(WS % PSPLIT == 0 && NPW % RSPLIT == 0, "phase split");
-    __shared__ __attribute__((aligned(16))) bf16_t dimg[2][NPL][DROWS * PG];
-    __shared__ __attribute__((aligned(16))) bf16_t aimg[2][NPL][NPW * QT * PA];
+    __shared__ __attribute__((aligned(16))) bf16_t dimg[2][DROWS * PG];
+    __shared__ __attribute__((aligned(16))) bf16_t aimg[2][NPW * QT * PA];
     __shared__ float bred[4][COUT];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -997,7 +669,7 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
     const int s_end = s_beg + per + ((int)blockIdx.x < extra ? 1 : 0);
 
     // raw loads of a step: rd = dz chunks (or the first four floats of g), ry = y chunks (or the second four), ra = y_prev
-    u32x4 rd[RING][NLD][WD], ry[RING][NLD][WD], ra[RING][NLA][WY];
+    u32x4 rd[RING][NLD], ry[RING][NLD], ra[RING][NLA];
     auto fetch = [&](int s, int set) {
         const bool live = s < s_end;
         const int n = live ? s / p.QS : 0, q0 = live ? (s - n * p.QS) * QT : 0;
@@ -1007,28 +679,20 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
             const int e = (u * 256 + tid) * 8;
             const int row = e / COUT, col = e - row * COUT;
             const int l = q0 - (WNT - 1) + row;
-#pragma unroll
-            for (int k = 0; k < WD; ++k) rd[set][u][k] = ry[set][u][k] = u32x4{0u, 0u, 0u, 0u};
+            rd[set][u] = ry[set][u] = u32x4{0u, 0u, 0u, 0u};
             if (live && row < DROWS && (unsigned)l < (unsigned)p.Lout) {
                 const long long off = gclip + (long long)l * COUT + col;
                 if constexpr (G_F32) {
                     const float* g = static_cast<const float*>(p.dz) + off;
-                    rd[set][u][0] = *reinterpret_cast<const u32x4*>(g);
-                    ry[set][u][0] = *reinterpret_cast<const u32x4*>(g + 4);
-                } else if constexpr (F32) {
-                    const float* a = static_cast<const float*>(p.dz) + off;
-                    const float* b = static_cast<const float*>(p.y) + off;
-                    rd[set][u][0] = *reinterpret_cast<const u32x4*>(a);
-                    rd[set][u][1] = *reinterpret_cast<const u32x4*>(a + 4);
-                    ry[set][u][0] = *reinterpret_cast<const u32x4*>(b);
-                    ry[set][u][1] = *reinterpret_cast<const u32x4*>(b + 4);
+                    rd[set][u] = *reinterpret_cast<const u32x4*>(g);
+                    ry[set][u] = *reinterpret_cast<const u32x4*>(g + 4);
                 } else {
-                    rd[set][u][0] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off);
-                    ry[set][u][0] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.y) + off);
+                    rd[set][u] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.dz) + off);
+                    ry[set][u] = *reinterpret_cast<const u32x4*>(p.y + off);
                 }
             }
         }
-        const long long pbase = ((long long)n * p.Lin + (long long)WS * q0) * CIN;
+        const bf16_t* ypc = p.yp + ((long long)n * p.Lin + (long long)WS * q0) * CIN;
         const int frames = live ? p.Lin - WS * q0 : 0;         // valid frames from the block start
 #pragma unroll
         for (int u = 0; u < NLA; ++u) {
@@ -1036,18 +700,8 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
             const int fp = e / CIN, col = e - fp * CIN;        // frame index among the staged ones: fp = ql * NPW + rl
             const int ql = fp / NPW, rl = fp - ql * NPW;
             const int fl = ql * WS + ph0 + rl;                 // frame inside the block of 192
-#pragma unroll
-            for (int k = 0; k < WY; ++k) ra[set][u][k] = u32x4{0u, 0u, 0u, 0u};
-            if (fp < QT * NPW && fl < frames) {
-                const long long off = pbase + (long long)fl * CIN + col;
-                if constexpr (F32) {
-                    const float* a = static_cast<const float*>(p.yp) + off;
-                    ra[set][u][0] = *reinterpret_cast<const u32x4*>(a);
-                    ra[set][u][1] = *reinterpret_cast<const u32x4*>(a + 4);
-                } else {
-                    ra[set][u][0] = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(p.yp) + off);
-                }
-            }
+            ra[set][u] = u32x4{0u, 0u, 0u, 0u};
+            if (fp < QT * NPW && fl < frames) ra[set][u] = *reinterpret_cast<const u32x4*>(ypc + (long long)fl * CIN + col);
         }
     };
     // transform + LDS stores of a fetched step; a live flag travels with the data (zeros stay zeros: B != 0 otherwise)
@@ -1060,42 +714,22 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
             const int row = e / COUT, col = e - row * COUT;
             const int l = q0 - (WNT - 1) + row;
             if (row < DROWS) {
-                u32x4 v = u32x4{0u, 0u, 0u, 0u}, vl = u32x4{0u, 0u, 0u, 0u};
-                float dy[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) dy[k] = 0.f;
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
                 if (live && (unsigned)l < (unsigned)p.Lout) {
-                    if constexpr (F32) {
-                        if constexpr (G_F32) {
-                            unpack8(rd[set][u][0], ry[set][u][0], dy);
-                        } else {
-                            float d[8], yy[8];
-                            unpack8(rd[set][u][0], rd[set][u][WD - 1], d);
-                            unpack8(ry[set][u][0], ry[set][u][WD - 1], yy);
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) dy[k] = fmaf(ca[k], d[k], fmaf(cc[k], yy[k], cb[k]));
-                        }
-                        split8(dy, v, vl);
-                    } else if constexpr (G_F32) {
-                        const f32x4 a = __builtin_bit_cast(f32x4, rd[set][u][0]), b = __builtin_bit_cast(f32x4, ry[set][u][0]);
+                    if constexpr (G_F32) {
+                        const f32x4 a = __builtin_bit_cast(f32x4, rd[set][u]), b = __builtin_bit_cast(f32x4, ry[set][u]);
                         v = u32x4{bf_pack(a[0], a[1]), bf_pack(a[2], a[3]), bf_pack(b[0], b[1]), bf_pack(b[2], b[3])};
                     } else {
-                        v = bn_bwd8(rd[set][u][0], ry[set][u][0], ca, cb, cc);
+                        v = bn_bwd8(rd[set][u], ry[set][u], ca, cb, cc);
                     }
                 }
-                *reinterpret_cast<u32x4*>(&dimg[buf][0][row * PG + col]) = v;
-                if constexpr (F32) *reinterpret_cast<u32x4*>(&dimg[buf][NPL - 1][row * PG + col]) = vl;
+                *reinterpret_cast<u32x4*>(&dimg[buf][row * PG + col]) = v;
                 if (row >= WNT - 1 && blockIdx.y == 0) {       // the halo rows are the previous step's core rows
-                    if constexpr (F32) {
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) bacc[j] += dy[j];
-                    } else {
-                        const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            bacc[2 * j] += bf_lo(w[j]);
-                            bacc[2 * j + 1] += bf_hi(w[j]);
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        bacc[2 * j] += bf_lo(w[j]);
+                        bacc[2 * j + 1] += bf_hi(w[j]);
                     }
                 }
             }
@@ -1107,20 +741,9 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
             const int fp = e / CIN, col = e - fp * CIN;
             const int ql = fp / NPW, rl = fp - ql * NPW;
             if (fp < QT * NPW) {
-                u32x4 v = u32x4{0u, 0u, 0u, 0u}, vl = u32x4{0u, 0u, 0u, 0u};
-                if (ql * WS + ph0 + rl < frames) {
-                    if constexpr (F32) {
-                        float yy[8], a[8];
-                        unpack8(ra[set][u][0], ra[set][u][WY - 1], yy);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) a[k] = leaky(fmaf(psc[k], yy[k], psh[k]), p.slope);
-                        split8(a, v, vl);
-                    } else {
-                        v = bn_act8(ra[set][u][0], psc, psh, p.slope);
-                    }
-                }
-                *reinterpret_cast<u32x4*>(&aimg[buf][0][(rl * QT + ql) * PA + col]) = v;
-                if constexpr (F32) *reinterpret_cast<u32x4*>(&aimg[buf][NPL - 1][(rl * QT + ql) * PA + col]) = vl;
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (ql * WS + ph0 + rl < frames) v = bn_act8(ra[set][u], psc, psh, p.slope);
+                *reinterpret_cast<u32x4*>(&aimg[buf][(rl * QT + ql) * PA + col]) = v;
             }
         }
     };
@@ -1128,36 +751,27 @@ __global__ __launch_bounds__(256) void wv_wgrad_k(const WvWgP p) {
     const int g = lane >> 4, t = lane & 15;
     const int tr_row = 8 * g + (t >> 2), tr_col = 4 * (t & 3);
     auto mma = [&](int buf) {
-        // A = dy^T shifted by the tap index: af[piece][i][a] holds dy[q0 + 8 g .. + 8 - i][co tile a]
-        bf16x8 af[NPL][WNT][WCOT];
+        // A = dy^T shifted by the tap index: af[i][a] holds dy[q0 + 8 g .. + 8 - i][co tile a]
+        bf16x8 af[WNT][WCOT];
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
+        for (int i = 0; i < WNT; ++i)
 #pragma unroll
-            for (int i = 0; i < WNT; ++i)
-#pragma unroll
-                for (int a = 0; a < WCOT; ++a)
-                    af[pl][i][a] = tr_frag(dimg[buf][pl], (tr_row + WNT - 1 - i) * PG + 16 * (cot0 + a) + tr_col, PG);
+            for (int a = 0; a < WCOT; ++a)
+                af[i][a] = tr_frag(dimg[buf], (tr_row + WNT - 1 - i) * PG + 16 * (cot0 + a) + tr_col, PG);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            bf16x8 bfr[NPL][WCIT];
+            bf16x8 bfr[WCIT];
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-                for (int b = 0; b < WCIT; ++b)
-                    bfr[pl][b] = tr_frag(aimg[buf][pl], ((r0 + r) * QT + tr_row) * PA + 16 * (cit0 + b) + tr_col, PA);
+            for (int b = 0; b < WCIT; ++b)
+                bfr[b] = tr_frag(aimg[buf], ((r0 + r) * QT + tr_row) * PA + 16 * (cit0 + b) + tr_col, PA);
 #pragma unroll
             for (int i = 0; i < WNT; ++i)
                 if (ph0 + r0 + r + WS * i < WKS) {             // wave-uniform
 #pragma unroll
                     for (int a = 0; a < WCOT; ++a)
 #pragma unroll
-                        for (int b = 0; b < WCIT; ++b) {
-                            if constexpr (F32) {               // the two cross products first, the large one last
-                                acc[a][b][r][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NPL - 1][i][a], bfr[0][b], acc[a][b][r][i], 0, 0, 0);
-                                acc[a][b][r][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i][a], bfr[NPL - 1][b], acc[a][b][r][i], 0, 0, 0);
-                            }
-                            acc[a][b][r][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i][a], bfr[0][b], acc[a][b][r][i], 0, 0, 0);
-                        }
+                        for (int b = 0; b < WCIT; ++b)
+                            acc[a][b][r][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][a], bfr[b], acc[a][b][r][i], 0, 0, 0);
                 }
         }
     };
@@ -1293,49 +907,6 @@ extern "C" int s2ag_wave_conv_fwd(const void* x, const float* in_scale, const fl
     return 0;
 }
 
-extern "C" int s2ag_wave_conv_fwd32(const float* x, const float* in_scale, const float* in_shift, float slope, const float* w_kmajor,
-                                    const float* bias, float* y, double* stats, const s2ag_bn_fold_args* fold, int N, int Lin,
-                                    int Lout, int Cin, int Cout, void* stream) {
-    if (!x || !in_scale || !in_shift || !w_kmajor || !y || N <= 0 || Lin <= 0 || Lout <= 0) return S2AG_E_BADARG;
-    if (fold && (!stats || !fold->ticket || !fold->gamma || !fold->beta || !fold->running_mean || !fold->running_var ||
-                 !fold->scale || !fold->shift || !fold->mean || !fold->invstd || fold->repeat < 1))
-        return S2AG_E_BADARG;
-    if ((long long)(Lout - 1) * WS + WKS > Lin) return S2AG_E_BADARG;
-    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return S2AG_E_BADARG;
-    WvF32P p{};
-    p.x = x; p.sc = in_scale; p.sh = in_shift; p.slope = slope; p.wk = w_kmajor; p.bias = bias; p.y = y; p.stats = stats;
-    p.N = N; p.Lin = Lin; p.Lout = Lout;
-    if (fold)
-        p.fold = FwdFold{fold->ticket, fold->gamma, fold->beta, fold->running_mean, fold->running_var, fold->num_batches_tracked,
-                         fold->eps, fold->momentum, fold->repeat, (long long)N * Lout, fold->scale, fold->shift, fold->mean,
-                         fold->invstd};
-    hipStream_t s = (hipStream_t)stream;
-    if (Cin == 32 && Cout == 64) launch_fwd32<32, 64>(p, s);
-    else if (Cin == 64 && Cout == 32) launch_fwd32<64, 32>(p, s);
-    else return S2AG_E_UNSUPPORTED;
-    S2AG_LAUNCH_CHECK();
-    return 0;
-}
-
-// byte offsets of the four blocks in the pack: k-major fp32 of conv3 / conv4, then their phase forms (two bf16 pieces each)
-static constexpr size_t T32_K3 = 0, T32_K4 = T32_K3 + (size_t)WKS * 32 * 64 * 4, T32_P3 = T32_K4 + (size_t)WKS * 64 * 32 * 4,
-                        T32_P4 = T32_P3 + (size_t)2 * WS * 32 * WNT * 64 * 2, T32_END = T32_P4 + (size_t)2 * WS * 64 * WNT * 32 * 2;
-
-extern "C" long long s2ag_wave_tail32_pack_bytes(void) { return (long long)T32_END; }
-extern "C" long long s2ag_wave_tail32_pack_offset(int layer /*0: conv3, 1: conv4*/, int phases) {
-    if ((layer != 0 && layer != 1) || (phases != 0 && phases != 1)) return S2AG_E_BADARG;
-    return (long long)(phases ? (layer ? T32_P4 : T32_P3) : (layer ? T32_K4 : T32_K3));
-}
-
-extern "C" int s2ag_wave_tail32_pack(const float* w3, const float* w4, void* out, void* stream) {
-    if (!w3 || !w4 || !out || ((uintptr_t)out & 15)) return S2AG_E_BADARG;
-    char* o = static_cast<char*>(out);
-    hipLaunchKernelGGL(wv_tail32_pack_k, dim3(64, 2), dim3(256), 0, (hipStream_t)stream, w3, w4, reinterpret_cast<float*>(o + T32_K3),
-                       reinterpret_cast<float*>(o + T32_K4), reinterpret_cast<bf16_t*>(o + T32_P3), reinterpret_cast<bf16_t*>(o + T32_P4));
-    S2AG_LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int s2ag_wave_dgrad_rows(int N, int Lin, int Cin) {
     if (N <= 0 || Lin <= 0) return S2AG_E_BADARG;
     const int step = Cin == 16 ? 64 : 16;
@@ -1346,11 +917,11 @@ extern "C" int s2ag_wave_dgrad_rows(int N, int Lin, int Cin) {
     return N * cdiv(Q, QC);
 }
 
-static int dgrad_impl(bool f32, const void* dz, const void* y, const float* ca, const float* cb, const float* cc, int g_f32,
-                      const void* w_phases, int CPO, const void* y_prev, const float* p_scale,
-                      const float* p_shift, const float* p_mean, const float* p_invstd, float slope, void* dz_prev,
-                      double* stats, int* ticket, const float* p_gamma, float* dgamma, float* dbeta, float* out_ca,
-                      float* out_cb, float* out_cc, int N, int Lin, int Lout, int Cin, int Cout, void* stream) {
+extern "C" int s2ag_wave_conv_dgrad(const void* dz, const void* y, const float* ca, const float* cb, const float* cc, int g_f32,
+                                    const void* w_phases, int CPO, const void* y_prev, const float* p_scale,
+                                    const float* p_shift, const float* p_mean, const float* p_invstd, float slope, void* dz_prev,
+                                    double* stats, int* ticket, const float* p_gamma, float* dgamma, float* dbeta, float* out_ca,
+                                    float* out_cb, float* out_cc, int N, int Lin, int Lout, int Cin, int Cout, void* stream) {
     if (!dz || !w_phases || !y_prev || !p_scale || !p_shift || !p_mean || !p_invstd || !dz_prev || !stats || N <= 0 ||
         Lin <= 0 || Lout <= 0)
         return S2AG_E_BADARG;
@@ -1361,41 +932,19 @@ static int dgrad_impl(bool f32, const void* dz, const void* y, const float* ca, 
         ((uintptr_t)dz_prev & 15))
         return S2AG_E_BADARG;
     WvDgP p{};
-    p.dz = dz; p.y = y; p.ca = ca; p.cb = cb; p.cc = cc;
-    p.w = static_cast<const bf16_t*>(w_phases); p.CPO = CPO; p.yp = y_prev;
+    p.dz = dz; p.y = static_cast<const bf16_t*>(y); p.ca = ca; p.cb = cb; p.cc = cc;
+    p.w = static_cast<const bf16_t*>(w_phases); p.CPO = CPO; p.yp = static_cast<const bf16_t*>(y_prev);
     p.psc = p_scale; p.psh = p_shift; p.pmean = p_mean; p.pinv = p_invstd; p.slope = slope;
-    p.dzp = dz_prev; p.stats = stats; p.N = N; p.Lin = Lin; p.Lout = Lout;
+    p.dzp = static_cast<bf16_t*>(dz_prev); p.stats = stats; p.N = N; p.Lin = Lin; p.Lout = Lout;
     p.ticket = ticket; p.pgamma = p_gamma; p.dgamma = dgamma; p.dbeta = dbeta; p.oca = out_ca; p.ocb = out_cb; p.occ = out_cc;
     p.inv_rows = 1.0 / ((double)N * Lin);
     hipStream_t s = (hipStream_t)stream;
-    if (f32) {
-        if (Cout == 64 && Cin == 32 && !g_f32 && CPO == 64) launch_dgrad<64, 32, 4, false, true>(p, s);
-        else if (Cout == 32 && Cin == 64 && g_f32 && CPO == 32) launch_dgrad<32, 64, 4, true, true>(p, s);
-        else return S2AG_E_UNSUPPORTED;
-    } else if (Cout == 32 && Cin == 16 && !g_f32 && CPO >= 32) launch_dgrad<32, 16, 1, false>(p, s);
+    if (Cout == 32 && Cin == 16 && !g_f32 && CPO >= 32) launch_dgrad<32, 16, 1, false>(p, s);
     else if (Cout == 64 && Cin == 32 && !g_f32 && CPO >= 64) launch_dgrad<64, 32, 4, false>(p, s);
     else if (Cout == 32 && Cin == 64 && g_f32 && CPO >= 32) launch_dgrad<32, 64, 4, true>(p, s);
     else return S2AG_E_UNSUPPORTED;
     S2AG_LAUNCH_CHECK();
     return 0;
-}
-
-extern "C" int s2ag_wave_conv_dgrad(const void* dz, const void* y, const float* ca, const float* cb, const float* cc, int g_f32,
-                                    const void* w_phases, int CPO, const void* y_prev, const float* p_scale,
-                                    const float* p_shift, const float* p_mean, const float* p_invstd, float slope, void* dz_prev,
-                                    double* stats, int* ticket, const float* p_gamma, float* dgamma, float* dbeta, float* out_ca,
-                                    float* out_cb, float* out_cc, int N, int Lin, int Lout, int Cin, int Cout, void* stream) {
-    return dgrad_impl(false, dz, y, ca, cb, cc, g_f32, w_phases, CPO, y_prev, p_scale, p_shift, p_mean, p_invstd, slope, dz_prev,
-                      stats, ticket, p_gamma, dgamma, dbeta, out_ca, out_cb, out_cc, N, Lin, Lout, Cin, Cout, stream);
-}
-
-extern "C" int s2ag_wave_conv_dgrad32(const float* dz, const float* y, const float* ca, const float* cb, const float* cc, int g_is_dy,
-                                      const void* w_phases2, const float* y_prev, const float* p_scale, const float* p_shift,
-                                      const float* p_mean, const float* p_invstd, float slope, float* dz_prev, double* stats,
-                                      int* ticket, const float* p_gamma, float* dgamma, float* dbeta, float* out_ca, float* out_cb,
-                                      float* out_cc, int N, int Lin, int Lout, int Cin, int Cout, void* stream) {
-    return dgrad_impl(true, dz, y, ca, cb, cc, g_is_dy, w_phases2, Cout, y_prev, p_scale, p_shift, p_mean, p_invstd, slope, dz_prev,
-                      stats, ticket, p_gamma, dgamma, dbeta, out_ca, out_cb, out_cc, N, Lin, Lout, Cin, Cout, stream);
 }
 
 static int wgrad_blocks(int total_steps, int Cin, int Cout) {
@@ -1412,27 +961,24 @@ extern "C" int s2ag_wave_wgrad_blocks(int N, int Lout, int Cin, int Cout) {
     return wgrad_blocks(N * cdiv(Lout + WNT - 1, 32), Cin, Cout);
 }
 
-static int wgrad_impl(bool f32, const void* dz, const void* y, const float* ca, const float* cb, const float* cc, int g_f32,
-                      const void* y_prev, const float* p_scale, const float* p_shift, float slope, float* partials,
-                      float* partials_b, float* dw, float* db, int N, int Lin, int Lout, int Cin, int Cout, void* stream) {
+extern "C" int s2ag_wave_conv_wgrad(const void* dz, const void* y, const float* ca, const float* cb, const float* cc, int g_f32,
+                                    const void* y_prev, const float* p_scale, const float* p_shift, float slope, float* partials,
+                                    float* partials_b, float* dw, float* db, int N, int Lin, int Lout, int Cin, int Cout,
+                                    void* stream) {
     if (!dz || !y_prev || !p_scale || !p_shift || !partials || !partials_b || !dw || N <= 0 || Lin <= 0 || Lout <= 0)
         return S2AG_E_BADARG;
     if (!g_f32 && (!y || !ca || !cb || !cc)) return S2AG_E_BADARG;
     if ((long long)(Lout - 1) * WS + WKS > Lin) return S2AG_E_BADARG;
     if (((uintptr_t)dz & 15) || ((uintptr_t)y & 15) || ((uintptr_t)y_prev & 15)) return S2AG_E_BADARG;
     WvWgP p{};
-    p.dz = dz; p.y = y; p.ca = ca; p.cb = cb; p.cc = cc;
-    p.yp = y_prev; p.psc = p_scale; p.psh = p_shift; p.slope = slope;
+    p.dz = dz; p.y = static_cast<const bf16_t*>(y); p.ca = ca; p.cb = cb; p.cc = cc;
+    p.yp = static_cast<const bf16_t*>(y_prev); p.psc = p_scale; p.psh = p_shift; p.slope = slope;
     p.part = partials; p.part_b = partials_b; p.N = N; p.Lin = Lin; p.Lout = Lout;
     p.QS = cdiv(Lout + WNT - 1, 32);
     p.total_steps = N * p.QS;
     const int blocks = wgrad_blocks(p.total_steps, Cin, Cout);
     hipStream_t s = (hipStream_t)stream;
-    if (f32) {
-        if (Cout == 64 && Cin == 32 && !g_f32) hipLaunchKernelGGL((wv_wgrad_k<64, 32, false, 3, true>), dim3(blocks, 3), dim3(256), 0, s, p);
-        else if (Cout == 32 && Cin == 64 && g_f32) hipLaunchKernelGGL((wv_wgrad_k<32, 64, true, 3, true>), dim3(blocks, 3), dim3(256), 0, s, p);
-        else return S2AG_E_UNSUPPORTED;
-    } else if (Cout == 32 && Cin == 16 && !g_f32) hipLaunchKernelGGL((wv_wgrad_k<32, 16, false, 1>), dim3(blocks), dim3(256), 0, s, p);
+    if (Cout == 32 && Cin == 16 && !g_f32) hipLaunchKernelGGL((wv_wgrad_k<32, 16, false, 1>), dim3(blocks), dim3(256), 0, s, p);
     else if (Cout == 64 && Cin == 32 && !g_f32) hipLaunchKernelGGL((wv_wgrad_k<64, 32, false, 3>), dim3(blocks, 3), dim3(256), 0, s, p);
     else if (Cout == 32 && Cin == 64 && g_f32) hipLaunchKernelGGL((wv_wgrad_k<32, 64, true, 3>), dim3(blocks, 3), dim3(256), 0, s, p);
     else return S2AG_E_UNSUPPORTED;
@@ -1440,22 +986,6 @@ static int wgrad_impl(bool f32, const void* dz, const void* y, const float* ca, 
     hipLaunchKernelGGL(wv_wgrad_reduce_k, dim3(cdiv(total, 32)), dim3(256), 0, s, partials, partials_b, blocks, Cout, Cin, dw, db);
     S2AG_LAUNCH_CHECK();
     return 0;
-}
-
-extern "C" int s2ag_wave_conv_wgrad(const void* dz, const void* y, const float* ca, const float* cb, const float* cc, int g_f32,
-                                    const void* y_prev, const float* p_scale, const float* p_shift, float slope, float* partials,
-                                    float* partials_b, float* dw, float* db, int N, int Lin, int Lout, int Cin, int Cout,
-                                    void* stream) {
-    return wgrad_impl(false, dz, y, ca, cb, cc, g_f32, y_prev, p_scale, p_shift, slope, partials, partials_b, dw, db, N, Lin, Lout,
-                      Cin, Cout, stream);
-}
-
-extern "C" int s2ag_wave_conv_wgrad32(const float* dz, const float* y, const float* ca, const float* cb, const float* cc, int g_is_dy,
-                                      const float* y_prev, const float* p_scale, const float* p_shift, float slope, float* partials,
-                                      float* partials_b, float* dw, float* db, int N, int Lin, int Lout, int Cin, int Cout,
-                                      void* stream) {
-    return wgrad_impl(true, dz, y, ca, cb, cc, g_is_dy, y_prev, p_scale, p_shift, slope, partials, partials_b, dw, db, N, Lin, Lout,
-                      Cin, Cout, stream);
 }
 
 extern "C" int s2ag_wave_bn_bwd_fold(const double* partials, int partial_rows, int C, long long rows, const float* gamma,

@@ -136,11 +136,8 @@ class WavEncoder(nn.Module):
         from .. import bf16
         if bf16.enabled() and self.training:
             return self._forward_bf16(wav_data)
-        from .. import wave12, wave32
+        from .. import wave12
         fe = self.feat_extractor
-        if (wave32.ENABLED and all(fe[i].training for i in (1, 4, 7)) and wav_data.is_cuda and wav_data.dtype == torch.float32
-                and wav_data.dim() == 2 and wave32.supported(fe)):
-            return wave32.encoder_f32(wav_data, fe)                   # all three BatchNorms folded into the convs (opt-in)
         if (fe[1].training and fe[4].training and wav_data.is_cuda and wav_data.dtype == torch.float32 and wav_data.dim() == 2
                 and wave12.supported(fe)):
             # conv1 -> BatchNorm -> LeakyReLU -> conv2 without conv1's (B, 7891, 16) output in HBM (csrc/wave12.hip)
@@ -214,21 +211,11 @@ class TextEncoderTCN(nn.Module):
             p = self.drop.p if self.training else 0.0
             if bf16.enabled() and self.training and self.tcn.bf16_capable():
                 # bf16 mode: (B, T, 320) bf16 rows with zero pad channels from the embedding gather to the decoder
-                if bf16.TCN_GATHER and in_data.dim() == 2:
-                    # the gather + dropout happen in the TCN forward launch's loader (opt-in, csrc/tcn_fused.hip GATHER)
-                    y = self.tcn.forward_nlc_bf16(None, nz, decoder=self.decoder,
-                                                  emb=(in_data, self.embedding.weight, p, self.site))
-                    return y.contiguous(), 0
                 emb = bf16.embedding(in_data, self.embedding.weight, p, nz, self.site)
                 y = self.tcn.forward_nlc_bf16(emb, nz, decoder=self.decoder)
                 return y.contiguous(), 0
-            if (self.training and in_data.dim() == 2 and not bf16.enabled()
-                    and self.tcn.gather_capable(in_data.shape[1], self.embedding.weight.shape[1])):
-                # gather + dropout inside the TCN forward launch (opt-in, csrc/tcn_fused32.hip GATHER)
-                y = self.tcn.forward_nlc(None, nz, emb=(in_data, self.embedding.weight, p, self.site))
-            else:
-                emb = ops.embedding(in_data, self.embedding.weight, p, nz, self.site)      # (B, T, E) channels-last
-                y = self.tcn.forward_nlc(emb, nz)
+            emb = ops.embedding(in_data, self.embedding.weight, p, nz, self.site)      # (B, T, E) channels-last
+            y = self.tcn.forward_nlc(emb, nz)
             y = ops.linear(y, self.decoder.weight, self.decoder.bias)
         return y.contiguous(), 0
 
@@ -247,20 +234,8 @@ class TextEncoderTCN(nn.Module):
         nP, (B, T) = len(noises), in_data.shape
         E = self.embedding.weight.shape[1]
         p = self.drop.p if self.training else 0.0
-        outer = torch.is_grad_enabled()
-        if nP <= ops.L.TCN32_MAX_PASSES and self.tcn.gather_capable(T, E):
-            # every pass gathers its rows inside the one TCN launch (opt-in): no embedding launches, no (nP * B, T, E) batch
-            with torch.set_grad_enabled(bool(grad) and outer):
-                y0, ym = self.tcn.forward_nlc(None, noises[0], noises=noises,
-                                              emb=(in_data, self.embedding.weight, p, self.site)) if nP > 1 else \
-                    (self.tcn.forward_nlc(None, noises[0], emb=(in_data, self.embedding.weight, p, self.site)), None)
-                out0 = ops.linear(y0, self.decoder.weight, self.decoder.bias)
-            if nP == 1:
-                return [out0.contiguous()]
-            with torch.no_grad():
-                outm = ops.linear(ym, self.decoder.weight, self.decoder.bias)
-            return [out0.contiguous()] + [outm[(k - 1) * B:k * B] for k in range(1, nP)]
         big = torch.empty(nP * B, T, E, dtype=torch.float32, device=in_data.device)
+        outer = torch.is_grad_enabled()
         with torch.set_grad_enabled(bool(grad) and outer):
             emb0 = ops.embedding(in_data, self.embedding.weight, p, noises[0], self.site, out=big[:B])
         with torch.no_grad():

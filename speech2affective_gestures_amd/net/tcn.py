@@ -107,19 +107,10 @@ class TemporalConvNet(nn.Module):
                 and ops.tcn_fused32_supported(x.shape[1], blks[0].conv1.out_channels, 2, len(blks))
                 and x.shape[2] == blks[0].conv1.in_channels == blks[0].conv1.out_channels)
 
-    def forward_nlc(self, x, noise, batch=None, noises=None, emb=None):
-        """``batch`` / ``noises``: x is the first pass of a lockstep batch (ops.tcn_fused32); then (out, mate outputs).
-        ``emb`` = (ids, table, drop_p, site) with x = None: the input rows are dropout(table[ids]), gathered by the
-        clip-resident forward launch itself (ops.TCN32_GATHER; callers check gather_capable first)."""
+    def forward_nlc(self, x, noise, batch=None, noises=None):
+        """``batch`` / ``noises``: x is the first pass of a lockstep batch (ops.tcn_fused32); then (out, mate outputs)."""
         ws = [w for g in self._weight_groups() for w in g.tensors()]
         blks = list(self.network)
-        if emb is not None:
-            assert x is None and batch is None and self.gather_capable(emb[0].shape[1], emb[1].shape[1])
-            if self.__dict__.get('_frag32') is None:
-                self.__dict__['_frag32'] = ops.TcnFragments32()
-            p = blks[0].p if self.training else 0.0
-            return ops.tcn_fused32(None, self.__dict__['_frag32'], ws, [c.bias for b in blks for c in (b.conv1, b.conv2)],
-                                   [b.dilation for b in blks], [s for b in blks for s in b.sites], p, noise, noises=noises, emb=emb)
         if self._fused32_ok(x, blks):
             # clip-resident forward (csrc/tcn_fused32.hip): every block in ONE launch; backward layer by layer
             if self.__dict__.get('_frag32') is None:
@@ -137,27 +128,19 @@ class TemporalConvNet(nn.Module):
         blks = list(self.network)
         return self._fused32_ok(torch.empty(0, T, C), blks)
 
-    def gather_capable(self, T, C):
-        """the clip-resident forward launch can form its input rows from an embedding table with C columns"""
-        return bool(ops.TCN32_GATHER and self.lockstep_capable(T, C))
-
     def bf16_capable(self):
         """The bf16 path covers the shape the S2AG text encoder uses: no down-sampling residual (in == out channels)."""
         return all(blk.downsample is None for blk in self.network)
 
-    def forward_nlc_bf16(self, x, noise, decoder=None, emb=None):
-        """bf16 mode (bf16.py): x (B, T, Cp) bf16 -- or, with ``emb`` = (ids, table, drop_p, site), None: the input rows are
-        dropout(table[ids]), gathered by the clip-resident forward launch itself (bf16.TCN_GATHER).  The weight-normed fp32 weights stay the gradient stages; their bf16
+    def forward_nlc_bf16(self, x, noise, decoder=None):
+        """bf16 mode (bf16.py): x (B, T, Cp) bf16.  The weight-normed fp32 weights stay the gradient stages; their bf16
         forward / data-gradient layouts (and the decoder Linear's) are refreshed with one launch per optimizer step.
         Returns bf16 (B, T, Cp), or the decoder's fp32 (B, T, out) when ``decoder`` is given."""
         from .. import bf16
         ws = [w for g in self._weight_groups() for w in g.tensors()]
         blks = list(self.network)
-        width, T_ = (x.shape[-1], x.shape[1]) if x is not None else (bf16.pad32(emb[1].shape[1]), emb[0].shape[1])
-        fused = (width == 320 and all(b.kernel_size == 2 and b.p == blks[0].p for b in blks)
-                 and bf16.tcn_fused_supported(T_, blks[0].conv1.out_channels, 2, len(blks)))
-        if emb is not None and not (fused and emb[1].shape[1] % 4 == 0):
-            x, emb = bf16.embedding(emb[0], emb[1], emb[2], noise, emb[3]), None    # the gather as a launch of its own
+        fused = (x.shape[-1] == 320 and all(b.kernel_size == 2 and b.p == blks[0].p for b in blks)
+                 and bf16.tcn_fused_supported(x.shape[1], blks[0].conv1.out_channels, 2, len(blks)))
         if (self.__dict__.get('_pack16') is None or self.__dict__.get('_pack16_dec') is not decoder
                 or self.__dict__.get('_pack16_fused') != fused):
             pk = bf16.WeightPack()
@@ -178,7 +161,7 @@ class TemporalConvNet(nn.Module):
             if self.__dict__.get('_frag16') is None:
                 self.__dict__['_frag16'] = bf16.TcnFragments()
             x = bf16.tcn_fused(x, self.__dict__['_frag16'], ws, [c.bias for b in blks for c in (b.conv1, b.conv2)],
-                               [b.dilation for b in blks], [s for b in blks for s in b.sites], p, noise, emb=emb)
+                               [b.dilation for b in blks], [s for b in blks for s in b.sites], p, noise)
         else:
             for i, blk in enumerate(blks):
                 x = blk.forward_nlc_bf16(x, noise, ws[2 * i:2 * i + 2], self.__dict__['_pack16'], i)

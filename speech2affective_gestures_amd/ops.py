@@ -805,41 +805,23 @@ class _FakeCtx:
     pass
 
 
-# the embedding gather + dropout in front of the clip-resident TCN done by its forward launch's loader (csrc/tcn_fused32.hip,
-# GATHER): per text-encoder pass one launch and one pass over the (B, T, 300) rows less; the no-grad passes of a lockstep batch
-# never write their rows at all.  Written without access to a GPU: opt-in until run there.
-TCN32_GATHER = config.mirror('TCN_GATHER', globals(), 'TCN32_GATHER')
-
-
 class _TcnFused32(torch.autograd.Function):
     """x (B, T, C) fp32 -> the last TemporalBlock's output; ``params`` = the 2*nb normalised (C, 2, C) tap-major weights
     followed by the 2*nb biases.  Forward: one launch (+ the keep bits).  Backward: the layer-by-layer kernels on the
-    tensors the forward left behind (h1, h2, y per block) -- exactly what the per-layer path would have saved.
-    With ``meta[5]`` = (emb_drop_p, emb_site): ``x`` is the (B, T) int64 token ids and one more parameter follows, the
-    embedding table (entries, C) -- the launch forms the rows itself (every pass of a lockstep batch from the same ids)."""
+    tensors the forward left behind (h1, h2, y per block) -- exactly what the per-layer path would have saved."""
 
     @staticmethod
     def forward(ctx, x, frags, meta, noise, *params):
         dils, sites, drop_p = meta[:3]
         big, noises = (meta[3], meta[4]) if len(meta) > 3 else (None, None)
-        emb = meta[5] if len(meta) > 5 else None
         nb = len(dils)
-        ws, bs = params[:2 * nb], params[2 * nb:4 * nb]
+        ws, bs = params[:2 * nb], params[2 * nb:]
         lib = _lib()
-        ids = table = None
-        if emb is not None:
-            ids, table = x.contiguous(), params[4 * nb]
-            _need_cuda(ids, table)
-            assert ids.dim() == 2 and ids.dtype == torch.int64 and table.dtype == torch.float32 and table.is_contiguous() and big is None
-            x = torch.empty(ids.shape[0], ids.shape[1], table.shape[1], dtype=torch.float32, device=table.device)
         B, T, Cch = x.shape
         x2, rows, cols, ldx = as_rows(x)
         if ldx != cols:
             x2 = x2.contiguous()
         nP = 1
-        if emb is not None and noises is not None:
-            nP = len(noises)
-            assert noises[0] is noise and nP <= L.TCN32_MAX_PASSES
         if big is not None:
             # lockstep batch: x is the first B clips of ``big`` (nP * B clips, one pass after the other; pass k draws its keep
             # bits from noises[k]); only x's pass keeps what the backward pass needs
@@ -862,18 +844,12 @@ class _TcnFused32(torch.autograd.Function):
         if drop_p > 0:
             keep = torch.empty(int(lib.s2ag_tcn32_keep_bytes(nP * B, nb)), dtype=torch.uint8, device=x.device)
             a.rng, a.keep = noise.data_ptr(), keep.data_ptr()
-        if emb is not None:
-            a.emb_ids, a.emb_table, a.emb_entries = ids.data_ptr(), table.data_ptr(), int(table.shape[0])
-            a.emb_drop_p, a.emb_site = float(emb[0]), int(emb[1])
-            if emb[0] > 0:
-                a.rng = noise.data_ptr()
         if nP == 1:
             L.check(lib.s2ag_tcn32_fwd(C.byref(a), _stream()), 'tcn32_fwd')
         else:
             rngs = (C.c_void_p * nP)(*[nz.data_ptr() for nz in noises])
             L.check(lib.s2ag_tcn32_fwd_passes(C.byref(a), nP, rngs, B, _stream()), 'tcn32_fwd_passes')
         ctx.meta, ctx.noise, ctx.params, ctx.shape, ctx.frags = (dils, sites, drop_p), noise, params, (B, T, Cch), frags
-        ctx.emb, ctx.ids = emb, ids
         ctx.save_for_backward(x2, saved, y_last)
         out = y_last[:rows].view(B, T, Cch)
         if nP == 1:
@@ -890,33 +866,11 @@ class _TcnFused32(torch.autograd.Function):
         # h1, h2, y per block as before; the last block's y lives at the head of the passes' output buffer
         saved = [saved_t[i] for i in range(3 * nb - 1)] + [y_last[:x2.numel() // x2.shape[-1]]]
         params = ctx.params
-        ws, bs = params[:2 * nb], params[2 * nb:4 * nb]
+        ws, bs = params[:2 * nb], params[2 * nb:]
         B, T, Cch = ctx.shape
         rows = B * T
         grads = [None] * (4 * nb)
         g = gy.reshape(rows, Cch)
-        emb = ctx.emb
-        need_table = emb is not None and ctx.needs_input_grad[4 + 4 * nb]
-        need_gx = need_table if emb is not None else ctx.needs_input_grad[0]
-
-        def finish(gx_rows):
-            """what leaves for input 0 (and, with the gather inside the launch, for the table: _Embedding.backward's work)"""
-            if emb is None:
-                return (gx_rows.view(B, T, Cch) if (gx_rows is not None and need_gx) else None, None, None, None) + tuple(grads)
-            dt = None
-            if need_table and gx_rows is not None:
-                table = params[4 * nb]
-                e = _epi(L.ACT_NONE, 1.0, float(emb[0]), ctx.noise, int(emb[1]))
-                dy, r_, _, ldg = as_rows(gx_rows.view(rows, Cch))
-                slot = _grad_slot(table)
-                if slot is not None:
-                    L.check(_lib().s2ag_embedding_bwd(_p(ctx.ids), _p(dy), ldg, r_, Cch, int(table.shape[0]), _p(slot), 1, C.byref(e),
-                                                      _stream()), 'embedding_bwd')
-                else:
-                    dt = torch.empty(table.shape[0], Cch, dtype=torch.float32, device=dy.device)
-                    L.check(_lib().s2ag_embedding_bwd(_p(ctx.ids), _p(dy), ldg, r_, Cch, int(table.shape[0]), _p(dt), 0, C.byref(e),
-                                                      _stream()), 'embedding_bwd')
-            return (None, None, None, None) + tuple(grads) + (dt,)
         need_w = [ctx.needs_input_grad[4 + k] for k in range(2 * nb)]
         need_b = [bs[k] is not None and ctx.needs_input_grad[4 + 2 * nb + k] for k in range(2 * nb)]
         wsl = [_grad_slot(ws[k]) if need_w[k] else None for k in range(2 * nb)]
@@ -963,7 +917,7 @@ class _TcnFused32(torch.autograd.Function):
                 _note_staged(ws[k])
                 if bs[k] is not None:
                     _note_staged(bs[k])
-            return finish(gx)
+            return (gx.view(B, T, Cch) if ctx.needs_input_grad[0] else None, None, None, None) + tuple(grads)
         for b in range(nb - 1, -1, -1):
             d = int(dils[b])
             h1, h2, yb = saved[3 * b], saved[3 * b + 1], saved[3 * b + 2]
@@ -979,7 +933,7 @@ class _TcnFused32(torch.autograd.Function):
                 fc.epi = (L.ACT_LEAKY, 0.0, float(drop_p), int(sites[k]))
                 fc.noise, fc.w_leaf, fc.b_leaf, fc.has_bias = ctx.noise, ws[k], bs[k], bs[k] is not None
                 fc.wtm_k, fc.w_shape = 1, ws[k].shape
-                need_x = True if (j == 1 or b > 0) else need_gx
+                need_x = True if (j == 1 or b > 0) else ctx.needs_input_grad[0]
                 fc.needs_input_grad = (need_x, ctx.needs_input_grad[4 + k],
                                        bs[k] is not None and ctx.needs_input_grad[4 + 2 * nb + k])
                 out = _ConvNLC.backward(fc, cur.view(B, T, Cch))
@@ -991,20 +945,13 @@ class _TcnFused32(torch.autograd.Function):
             gn = torch.empty(rows, Cch, dtype=torch.float32, device=cur.device)
             add_act_raw(cur, gs, gn, 1.0)                                                # + the residual branch
             g = gn
-        return finish(g)
+        gx = g.view(B, T, Cch) if (g is not None and ctx.needs_input_grad[0]) else None
+        return (gx, None, None, None) + tuple(grads)
 
 
-def tcn_fused32(x: Tensor, frags: TcnFragments32, ws, biases, dils, sites, drop_p: float, noise, batch=None, noises=None,
-                emb=None):
+def tcn_fused32(x: Tensor, frags: TcnFragments32, ws, biases, dils, sites, drop_p: float, noise, batch=None, noises=None):
     """``batch`` (nP * B, T, C) + ``noises``: x is the first B clips of a lockstep batch of nP passes (see _TcnFused32);
-    returns (out of x's pass, outputs of the other passes ((nP - 1) * B, T, C), no autograd).
-    ``emb`` = (ids (B, T) int64, table, drop_p, site): the input rows are dropout(table[ids]), formed by the launch (``x`` and
-    ``batch`` are ignored; with ``noises`` every pass gathers from the same ids with its own mask)."""
-    if emb is not None:
-        ids, table, p_emb, site_emb = emb
-        return _TcnFused32.apply(ids, frags, (tuple(dils), tuple(sites), float(drop_p), None,
-                                              tuple(noises) if noises is not None else None, (float(p_emb), int(site_emb))),
-                                 noise, *ws, *biases, table)
+    returns (out of x's pass, outputs of the other passes ((nP - 1) * B, T, C), no autograd)."""
     if batch is None:
         return _TcnFused32.apply(x, frags, (tuple(dils), tuple(sites), float(drop_p)), noise, *ws, *biases)
     return _TcnFused32.apply(x, frags, (tuple(dils), tuple(sites), float(drop_p), batch, tuple(noises)), noise, *ws, *biases)

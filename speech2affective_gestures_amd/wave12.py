@@ -130,24 +130,21 @@ def forward(wav: Tensor, pk: Tensor, b1: Tensor, coef1: Tensor, slope: float, b2
 def backward(wav: Tensor, pk: Tensor, b1: Tensor, coef1: Tensor, gamma1: Tensor, slope: float, dz: Tensor, z2: Optional[Tensor],
              cabc2: Optional[Tensor], slots: dict, pad: int = PAD1) -> Tensor:
     """One launch (+ the fold of its partial tiles) for everything behind z2.  ``dz``: fp32 gradient w.r.t. z2, or -- with
-    ``z2`` / ``cabc2`` (3, 32) -- the operands of dy2 = ca dz + cc z2 + cb (both bf16 rows: bf16 mode; both fp32 rows: wave32.py).  ``slots``: accumulation targets
+    ``z2`` / ``cabc2`` (3, 32) -- the bf16 operands of dy2 = ca dz + cc z2 + cb.  ``slots``: accumulation targets
     {'w1', 'g1', 'e1', 'w2'} -> fp32 tensor or None (the two biases feed BatchNorms: zero gradient).  Returns ca / cb / cc of BatchNorm 1's backward (3, 16)."""
     lib = _lib()
     N, Lin = wav.shape
     L1, L2 = lengths(Lin, pad)
     dev = wav.device
     f32 = z2 is None
-    mode = 1 if f32 else (2 if z2.dtype == torch.float32 else 0)   # s2ag_wave12_bwd_args.dz_f32
-    if mode == 2 and dz.dtype != torch.float32 or mode == 0 and (dz.dtype != torch.bfloat16 or z2.dtype != torch.bfloat16):
-        raise RuntimeError('wave12.backward: dz and z2 must both be bf16 rows or both fp32 rows')
-    nb = lib.s2ag_wave12_bwd_blocks(N, L1, mode)
+    nb = lib.s2ag_wave12_bwd_blocks(N, L1, int(f32))
     ng = (nb + 15) // 16
     scratch = torch.empty(nb * 7680 + (nb + ng) * 528, dtype=torch.float32, device=dev)
     st = torch.empty(2 * (nb + ng) * 16, dtype=torch.float64, device=dev)
     cabc1 = torch.empty(3, 16, dtype=torch.float32, device=dev)
     o1 = nb * 7680
     a = L.Wave12Bwd(_p(wav), _p(pk), _p(b1), _p(coef1[0]), _p(coef1[1]), _p(coef1[2]), _p(coef1[3]), _p(gamma1), float(slope),
-                    _p(dz), mode, _p(z2), *((None, None, None) if f32 else (_p(cabc2[0]), _p(cabc2[1]), _p(cabc2[2]))),
+                    _p(dz), int(f32), _p(z2), *((None, None, None) if f32 else (_p(cabc2[0]), _p(cabc2[1]), _p(cabc2[2]))),
                     _p(scratch), _p(scratch[o1:]), _p(st), ops._tickets(dev, 1 + ng),
                     _p(slots.get('g1')), _p(slots.get('e1')), _p(cabc1[0]), _p(cabc1[1]), _p(cabc1[2]), _p(slots.get('w2')),
                     _p(slots.get('w1')), N, Lin, L1, L2, pad)

@@ -1,6 +1,5 @@
-"""CPU dry run of TextEncoderTCN (argv[2]: bf16 mode, fp32 mode, or fp32 lockstep passes; argv[1] = 1: with the embedding gather
-inside the clip-resident TCN forward launch, bf16.TCN_GATHER / ops.TCN32_GATHER): real ctypes signatures and the library's argument validation, every launch failing for want of a
-device (codes recorded, not raised).  The guards that make the product refuse CPU tensors are patched out HERE only.
+"""CPU dry run of TextEncoderTCN (argv[1]: bf16 mode, fp32 mode, or fp32 lockstep passes): real ctypes signatures and the
+library's argument validation, every launch failing for want of a device (codes recorded, not raised).  The guards that make the product refuse CPU tensors are patched out HERE only.
 Prints one JSON line; run by tests/test_host_logic.py."""
 import json
 import os
@@ -25,9 +24,7 @@ ops._need_cuda = lambda *a: None
 ops.join_side_streams = lambda *a, **k: None
 torch.cuda.is_current_stream_capturing = lambda: False
 noise.begin_pass = lambda device: torch.zeros(2, dtype=torch.int64)
-gather = len(sys.argv) > 1 and sys.argv[1] == '1'
-mode = sys.argv[2] if len(sys.argv) > 2 else 'bf16'          # bf16 | fp32 | fp32_passes
-bf16.TCN_GATHER = ops.TCN32_GATHER = gather
+mode = sys.argv[1] if len(sys.argv) > 1 else 'bf16'          # bf16 | fp32 | fp32_passes
 
 args = types.SimpleNamespace(hidden_size=300, n_layers=4, freeze_wordembed=False)
 enc = TextEncoderTCN(args, 1000).train()

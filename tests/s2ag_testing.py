@@ -86,8 +86,8 @@ class StepSignTap:
     OWNER = ('G', 'D', 'D', 'T3', 'G', 'D', 'G')
 
     def __init__(self, pr, counter0):
-        from speech2affective_gestures_amd import noise, ops, wave12, wave32
-        self.ops, self.noise, self.w12, self.w32, self.c0 = ops, noise, wave12, wave32, int(counter0)
+        from speech2affective_gestures_amd import noise, ops, wave12
+        self.ops, self.noise, self.w12, self.c0 = ops, noise, wave12, int(counter0)
         self.mods = {'G': pr.s2ag_generator, 'D': pr.s2ag_discriminator, 'T3': pr.trimodal_generator}
         self.owner = {}
         for tag, m in self.mods.items():
@@ -108,14 +108,14 @@ class StepSignTap:
         key = (tag, k)
         if key not in self.children:
             c = SignTap(self.mods[tag])
-            c._w12, c._w32, c.pre = self.w12, self.w32, {}
+            c._w12, c.pre = self.w12, {}
             self.children[key] = c
         return self.children[key]
 
     def __enter__(self):
         ops = self.ops
-        self._orig = (ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32, self.w12.head_f32, self.w32.encoder_f32)
-        o_bn, o_add, o_lin, o_tcn, o_head, o_enc = self._orig
+        self._orig = (ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32, self.w12.head_f32)
+        o_bn, o_add, o_lin, o_tcn, o_head = self._orig
 
         def by_pass(k):                      # modules without an object to identify them by: the pass says whose they are
             return self.OWNER[k] if k is not None else 'G'
@@ -162,18 +162,13 @@ class StepSignTap:
                 c.heads.clear()
             return z2
 
-        def enc(wav, fe):
-            out = o_enc(wav, fe)
-            if id(fe[1]) in self.owner:
-                self._child(self.owner[id(fe[1])], self._pass()).encs.append((out, fe))
-            return out
         ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32 = bn_act, add_act, linear, tcn
-        self.w12.head_f32, self.w32.encoder_f32 = head, enc
+        self.w12.head_f32 = head
         return self
 
     def __exit__(self, *a):
         ops = self.ops
-        ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32, self.w12.head_f32, self.w32.encoder_f32 = self._orig
+        ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32, self.w12.head_f32 = self._orig
 
     def signs_per_pass(self):
         """{pass name: {site: bool tensor}} for oracle.gan_step(signs=...)."""
@@ -252,7 +247,7 @@ class SignTap:
         self.ops, self.module, self.tcn_prefix = ops, module, tcn_prefix
         self.names = {id(m): n for n, m in module.named_modules()}
         self.params = {id(p): n for n, p in module.named_parameters()}
-        self.bn, self.adds, self.lin, self.tcn, self.heads, self.encs = [], [], [], [], [], []
+        self.bn, self.adds, self.lin, self.tcn, self.heads = [], [], [], [], []
 
     def __enter__(self):
         ops = self.ops
@@ -293,23 +288,12 @@ class SignTap:
                 self.heads.append((self.names[id(fe[1])], z2, fe[0].bias))
             return z2
         wave12.head_f32 = head
-        # the fully folded fp32 encoder (wave32.py, opt-in): all three BatchNorm + LeakyReLU pairs happen inside its launches
-        from speech2affective_gestures_amd import wave32
-        self._w32, self._o_enc = wave32, wave32.encoder_f32
-
-        def enc(wav, fe):
-            out = self._o_enc(wav, fe)
-            if id(fe[1]) in self.names:
-                self.encs.append((out, fe))
-            return out
-        wave32.encoder_f32 = enc
         return self
 
     def __exit__(self, *a):
         ops = self.ops
         ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32 = self._orig
         self._w12.head_f32 = self._o_head
-        self._w32.encoder_f32 = self._o_enc
 
     def signs(self):
         import numpy as np
@@ -332,9 +316,6 @@ class SignTap:
         for name, z2, b1 in self.heads:
             wav, pk, coef1 = z2.grad_fn.saved_tensors
             out[name + '.'] = self._w12.act_signs(wav, pk, b1, coef1, False, z2.grad_fn.pad).permute(0, 2, 1).cpu()
-        for enc_out, fe in self.encs:
-            for bn, sg in zip((fe[1], fe[4], fe[7]), self._w32.act_signs(enc_out, fe)):
-                out[self.names[id(bn)] + '.'] = sg.permute(0, 2, 1).cpu()
         for key, y in zip(sorted(cols), self.adds):                      # st_gcn1 runs before st_gcn2
             out[key + 'out'] = (vertex_layout(y, cols[key]) > 0).cpu()
         for pname, y in self.lin:

@@ -53,16 +53,12 @@ GROUPS = {
         (['tests/test_gpu_wave12.py'], 'test_backward and 1000', 8, 2),
     'bf16 wave tail with folded BatchNorms (csrc/wave_fused.hip)':
         (['tests/test_gpu_wave_fused.py'], 'not 40', 10, 0),
-    'PENDING HARDWARE: fp32 wave tail with folded BatchNorms + pipelined head forward (wave32.py)':
-        (['tests/test_gpu_zz_pending_wave32.py'], 'not 40-1313 and not [40] and not 36267', 8, 0),
-    'PENDING HARDWARE: embedding gather in the TCN launch, deep weight rings, row-form embedding':
-        (['tests/test_gpu_zz_pending_tcn.py'], '[5] or [3- or row_form or lockstep[16]', 7, 0),
     'embedding / rows / losses / Adam / BatchNorm one-launch grid wait (csrc/misc.hip, rows.hip, norm_elementwise.hip)':
         (['tests/test_gpu_ops.py'], 'embedding or rows or loss or adam or batch_norm or rng', 20, 0),
     'cooperative GRU: tagged-cell exchange between workgroups, three product modes (csrc/gru_coop.hip)':
         (['tests/test_gpu_ops.py'], 'test_gru_forward_backward and (9-6 or 17-1 or 33-2 or 16-3 or 5-7 or 3-5)', 6, 0),
     'deterministic mode: two GAN steps, two wavefront schedules, every weight / gradient / statistic bit-identical':
-        (['tests/test_gpu_step.py'], 'deterministic_mode and 32-6', 1, 0),
+        (['tests/test_gpu_det_flavour.py'], 'deterministic_mode and 32-6', 1, 0),
     'one whole GAN step strictly: branch decisions of all seven module passes replayed in the oracle (H = 300)':
         (['tests/test_gpu_step.py'], 'one_step_strictly and 300-6', 1, 0),
     'strict parity of both discriminators with the product\'s branch decisions (small batch)':

@@ -260,7 +260,7 @@ def test_bf16_embedding_against_torch_with_pad_runs_and_duplicates(B, dim, n_ent
     assert torch.equal(tg.grad.cpu() == 0, want == 0)
 
 
-@pytest.mark.parametrize('B,T', [(5, 34), (64, 34), (200, 34), (2, 40), (3, 39), (1, 17)])
+@pytest.mark.parametrize('B,T', [(5, 34), (64, 34), (200, 34), (2, 40), (3, 39), (1, 17), (1, 79)])
 def test_clip_resident_tcn_equals_the_layer_by_layer_bf16_path(B, T):
     """csrc/tcn_fused.hip (all TemporalBlocks in one launch, activations resident in LDS; two clips per workgroup, or -- from
     192 clips on, B = 200 here -- one clip and three row tiles) against the layer-by-layer bf16
@@ -268,7 +268,9 @@ def test_clip_resident_tcn_equals_the_layer_by_layer_bf16_path(B, T):
     of the accumulation is the same -> identical up to a few bf16 ulps; backward: the data gradient sums its taps in the
     other order and adds the residual branch before rounding (once instead of twice) -> 2^-8 per element.
     T = 40 / 39: the row limit of the kernels -- at 40 frames two clips per workgroup would need 167 696 bytes of LDS in the
-    backward launch (found on the CPU device model in r04, which enforces the 160 KB limit; plan_cpb now asks the budget)."""
+    backward launch (found on the CPU device model in r04, which enforces the 160 KB limit; plan_cpb now asks the budget).
+    T = 79: ONE clip does not fit either (165 616 bytes): the library reports the shape as unsupported and the text encoder
+    takes the layer-by-layer kernels instead of failing mid-backward."""
     import types
     from speech2affective_gestures_amd import bf16, noise, ops
     from speech2affective_gestures_amd.net.multimodal_context_net_v2 import TextEncoderTCN
@@ -290,7 +292,7 @@ def test_clip_resident_tcn_equals_the_layer_by_layer_bf16_path(B, T):
             ops.begin_step()
             noise.manual_seed(5)
             with bf16.precision('bf16'):
-                assert bf16.tcn_fused_supported(T, 300, 2, 4) == fused
+                assert bf16.tcn_fused_supported(T, 300, 2, 4) == (fused and T <= 78)
                 t = txt(ids.cuda())[0]
                 (t * dt).sum().backward()
             torch.cuda.synchronize()

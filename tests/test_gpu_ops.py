@@ -580,7 +580,8 @@ def test_coop_gru_products_on_the_bf16_pipe(S, pieces, tol):
     yr, _ = ref(xr)
     dy = torch.randn(yr.shape, generator=g)
     yr.backward(dy.double())
-    prev = lib.s2ag_gru_coop_set_split_pieces(pieces)
+    prev = lib.s2ag_gru_coop_split_pieces()
+    lib.s2ag_gru_coop_set_split_pieces(pieces)
     try:
         assert lib.s2ag_gru_coop_split_pieces() == pieces
         wg = [w.cuda().requires_grad_(True) for w in _flat(sd, L_)]

@@ -448,6 +448,14 @@ def test_precision_modes_select_the_product_setting_and_restore_it():
             assert bf16.enabled() and not bf16.step_mode() and lib.s2ag_gru_coop_split_pieces() == before
         assert lib.s2ag_gru_coop_split_pieces() == 1
     assert not bf16.enabled() and lib.s2ag_gru_coop_split_pieces() == before
+    # leaving a precision context must not leave the override pinned at the effective count -- the registry's
+    # GRU_SPLIT has to reach the library afterwards
+    from speech2affective_gestures_amd import config
+    assert lib.s2ag_gru_coop_split_override() == -1
+    other = 3 if before != 3 else 2
+    with config.override('GRU_SPLIT', other):
+        assert lib.s2ag_gru_coop_split_pieces() == other
+    assert lib.s2ag_gru_coop_split_pieces() == before
 
 
 def test_fused_wave_head_geometry_and_build_flavours():
@@ -461,7 +469,9 @@ def test_fused_wave_head_geometry_and_build_flavours():
     assert wave12.supported(fe)
     fe2 = nn.Sequential(nn.Conv1d(1, 16, 15, stride=4, padding=1600), *list(fe)[1:])
     assert not wave12.supported(fe2)
-    assert set(build.FLAVOURS) == {'release', 'debug', 'asan'}
+    assert set(build.FLAVOURS) == {'release', 'debug', 'det', 'asan'}
+    assert '-DS2AG_DET=1' in build.FLAVOURS['det']['extra'] and '-O3' in build.FLAVOURS['det']['extra']
+    assert not any('S2AG_DET' in f for f in build.FLAVOURS['release']['extra'])     # the release kernels carry no ordering code
     assert build.FLAVOURS['debug']['lib'].endswith('libs2ag_hip_debug.so') and '-DS2AG_DEBUG=1' in build.FLAVOURS['debug']['extra']
     assert 'xnack+' in build.FLAVOURS['asan']['arch']
 
@@ -515,29 +525,6 @@ def test_conv1_weight_gradient_from_three_sums_identity():
     assert float(b1.grad.abs().max()) < 1e-12 * float(dy2.abs().sum()) and float(dz1.sum(dim=(0, 2)).abs().max()) < 1e-9
 
 
-def test_fp32_tail_of_the_wave_encoder_is_opt_in_and_its_pack_layout_is_consistent():
-    """wave32.py: off unless S2AG_WAVE_TAIL32=1 (not yet run on a GPU); the pack's four blocks are 16-byte aligned, disjoint
-    and fill s2ag_wave_tail32_pack_bytes; lengths follow the reference's conv arithmetic."""
-    import os
-    from speech2affective_gestures_amd import _lib as L
-    from speech2affective_gestures_amd import wave32
-    from speech2affective_gestures_amd.net.multimodal_context_net_v2 import WavEncoder
-    assert wave32.ENABLED == (os.environ.get('S2AG_WAVE_TAIL32', '0') == '1')
-    fe = WavEncoder().feat_extractor
-    assert wave32.supported(fe) == wave32.ENABLED
-    assert wave32.tail_lengths(1313) == (217, 34)             # the TED clip: 36267 samples -> 7891 -> 1313 -> 217 -> 34
-    lib = L.load()
-    total = lib.s2ag_wave_tail32_pack_bytes()
-    offs = sorted((lib.s2ag_wave_tail32_pack_offset(layer, ph), size) for layer, ph, size in
-                  ((0, 0, 15 * 32 * 64 * 4), (1, 0, 15 * 64 * 32 * 4), (0, 1, 2 * 6 * 32 * 3 * 64 * 2), (1, 1, 2 * 6 * 64 * 3 * 32 * 2)))
-    end = 0
-    for off, size in offs:
-        assert off == end and off % 16 == 0
-        end = off + size
-    assert end == total
-    assert lib.s2ag_wave_tail32_pack_offset(2, 0) < 0
-
-
 def test_flat_window_forward_and_polyphase_data_gradient_identities():
     """The two index identities csrc/wave_fused.hip is built on, in float64 on the CPU for Conv1d(32, 64, 15, stride 6)
     (net/multimodal_context_net_v2.py:24) on channels-last rows:
@@ -575,10 +562,10 @@ def test_flat_window_forward_and_polyphase_data_gradient_identities():
     assert float(((hi + lo) - v).abs().max() / v.abs().max()) < 2.0 ** -16
 
 
-@pytest.mark.parametrize('mode', ['fp32_folded', 'bf16', 'fp32'])
+@pytest.mark.parametrize('mode', ['bf16', 'fp32'])
 def test_wave_encoder_dry_run_passes_every_entry_points_argument_checks(mode):
-    """tests/s2ag_dry_wave32.py: WavEncoder forward + backward through the fused encoders (bf16 mode's default, and the opt-in
-    fp32 one of wave32.py) on the CPU with the launches failing for want of a device.  Every call must get as far as the launch
+    """tests/s2ag_dry_wave.py: WavEncoder forward + backward in both precision modes on the CPU with the launches failing for
+    want of a device.  Every call must get as far as the launch
     (a positive hipError_t), none may be refused by the library's argument validation (negative S2AG_E_*), and the launch
     sequence is the documented one: 6 launches forward, 5 backward."""
     import json
@@ -586,7 +573,7 @@ def test_wave_encoder_dry_run_passes_every_entry_points_argument_checks(mode):
     import sys
     if torch.cuda.is_available():
         pytest.skip('the dry run is for boxes without a GPU')
-    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 's2ag_dry_wave32.py')
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 's2ag_dry_wave.py')
     r = subprocess.run([sys.executable, script, mode], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -594,37 +581,30 @@ def test_wave_encoder_dry_run_passes_every_entry_points_argument_checks(mode):
     if mode == 'bf16':
         assert d['forward'] == ['wave12_pack', 'wave12_stats', 'wave12_fwd', 'bf16_pack_weights', 'wave_conv_fwd', 'wave_conv_fwd']
         assert d['backward'] == ['wave_conv_wgrad', 'wave_conv_dgrad', 'wave_conv_wgrad', 'wave_conv_dgrad', 'wave12_bwd']
-    elif mode == 'fp32':                   # the default fp32 mode: fused head, then BatchNorm / conv layer by layer
+    else:                                  # the default fp32 mode: fused head, then BatchNorm / conv layer by layer
         assert d['forward'][:3] == ['wave12_pack', 'wave12_stats', 'wave12_fwd'] and d['forward'][-1] == 'conv_fwd'
         assert d['backward'][-1] == 'wave12_bwd' and d['backward'].count('conv_bwd_weight') == 2
-    else:
-        assert d['forward'] == ['wave12_pack', 'wave12_stats', 'wave12_fwd', 'wave_tail32_pack', 'wave_conv_fwd32', 'wave_conv_fwd32']
-        assert d['backward'] == ['wave_conv_wgrad32', 'wave_conv_dgrad32', 'wave_conv_wgrad32', 'wave_conv_dgrad32', 'wave12_bwd']
-        assert d['signs'] == [[2, 7891, 16], [2, 1313, 32], [2, 217, 64]]
     assert all(c > 0 for c in d['codes']), d['codes']          # hipError_t (no device), never S2AG_E_BADARG / _UNSUPPORTED
     assert all(v is not None for v in d['grads'].values())
 
 
 @pytest.mark.parametrize('mode', ['bf16', 'fp32', 'fp32_passes'])
-@pytest.mark.parametrize('gather', [0, 1])
-def test_text_encoder_dry_run(gather, mode):
+def test_text_encoder_dry_run(mode):
     """tests/s2ag_dry_text.py: TextEncoderTCN forward + backward on the CPU (bf16 mode; fp32 mode; three fp32 passes in
-    lockstep), launches failing for want of a device; with the opt-in gather (bf16.TCN_GATHER / ops.TCN32_GATHER) the
-    embedding forward launches are gone and the table still receives its gradient.  No entry point may refuse its arguments
-    (S2AG_E_BADARG)."""
+    lockstep), launches failing for want of a device.  No entry point may refuse its arguments (S2AG_E_BADARG)."""
     import json
     import subprocess
     import sys
     if torch.cuda.is_available():
         pytest.skip('the dry run is for boxes without a GPU')
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 's2ag_dry_text.py')
-    r = subprocess.run([sys.executable, script, str(gather), mode], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, script, mode], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d['out'] == [4, 34, 32] and d['refused'] == []
     pre = 'bf16_' if mode == 'bf16' else ''
     n_emb = sum(w == pre + 'embedding_fwd' for w in d['forward'])
-    assert n_emb == (0 if gather else (3 if mode == 'fp32_passes' else 1))
+    assert n_emb == (3 if mode == 'fp32_passes' else 1)
     fwd = {'bf16': 'bf16_tcn_fwd', 'fp32': 'tcn32_fwd', 'fp32_passes': 'tcn32_fwd_passes'}[mode]
     assert fwd in d['forward'] and pre + 'embedding_bwd' in d['backward']
     assert all(v is not None for v in d['grads'].values())
@@ -632,11 +612,11 @@ def test_text_encoder_dry_run(gather, mode):
 
 def test_every_switch_is_registered_and_the_library_reads_no_environment():
     """one registry (speech2affective_gestures_amd/config.py: name, default, what it selects, the test
-    that arms it), at most 20 switches, no getenv in the C library, and no S2AG_* environment name anywhere in the package --
+    that arms it), at most 15 switches, no getenv in the C library, and no S2AG_* environment name anywhere in the package --
     read OR merely advertised as `S2AG_X=...` in a comment / message -- that the registry does not know."""
     from speech2affective_gestures_amd import config
     pkg = os.path.join(ROOT, 'speech2affective_gestures_amd')
-    assert len(config.REGISTRY) <= 20, sorted(config.REGISTRY)
+    assert len(config.REGISTRY) <= 15, sorted(config.REGISTRY)
     files = []
     for base, _, names in os.walk(pkg):
         if '_obj' in base or '__pycache__' in base:
@@ -667,7 +647,25 @@ def test_every_switch_is_registered_and_the_library_reads_no_environment():
         if sw.clib:
             assert lib.s2ag_get_option(sw.name.encode()) == int(config.get(sw.name)), sw.name
     assert lib.s2ag_get_option(b'NO_SUCH_OPTION') < 0 and lib.s2ag_set_option(b'NO_SUCH_OPTION', 1) < 0
-    before = lib.s2ag_get_option(b'TCN_RING_DEEP')
-    with config.override('TCN_RING_DEEP', not before):
-        assert lib.s2ag_get_option(b'TCN_RING_DEEP') == int(not before)
-    assert lib.s2ag_get_option(b'TCN_RING_DEEP') == before
+    before = lib.s2ag_get_option(b'GRU_SPLIT')
+    with config.override('GRU_SPLIT', 3 if before != 3 else 2):
+        assert lib.s2ag_get_option(b'GRU_SPLIT') == (3 if before != 3 else 2)
+    assert lib.s2ag_get_option(b'GRU_SPLIT') == before
+
+
+def test_bf16_clip_resident_tcn_reports_shapes_beyond_its_lds_budget_as_unsupported():
+    """ADVICE r04: lds_bytes(1 clip, T, backward) = (3 T + 1) * 656 + sign images exceeds 160 KB from T = 79 on;
+    s2ag_bf16_tcn_clips_per_block must then return 0 (callers take the layer-by-layer kernels) instead of 1 (the backward
+    launch would fail with a HIP error mid-backward).  Host arithmetic only: no GPU needed."""
+    from speech2affective_gestures_amd import _lib as L
+    lib = L.load()
+
+    def lds(cpb, T):
+        rows = cpb * T
+        return (3 * rows + 1) * 656 + (rows * 40 + 15) // 16 * 16 + (rows * 80 + 15) // 16 * 16
+    for T in range(1, 81):
+        want = 2 if (80 // T >= 2 and lds(2, T) <= 160 * 1024) else (1 if lds(1, T) <= 160 * 1024 else 0)
+        assert lib.s2ag_bf16_tcn_clips_per_block(T, 300, 2) == want, (T, want)
+    assert lib.s2ag_bf16_tcn_clips_per_block(78, 300, 2) == 1 and lib.s2ag_bf16_tcn_clips_per_block(79, 300, 2) == 0
+    assert lib.s2ag_bf16_tcn_clips_per_block(34, 300, 2) == 2 and lib.s2ag_bf16_tcn_clips_per_block(40, 300, 2) == 1
+    assert lib.s2ag_bf16_tcn_clips_per_block(81, 300, 2) == 0

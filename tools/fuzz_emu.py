@@ -27,15 +27,11 @@ def main():
     rnd = random.Random(seed)
     import test_gpu_wave12 as w12
     import test_gpu_wave_fused as wf
-    import test_gpu_zz_pending_wave32 as w32
-    import test_gpu_zz_pending_tcn as tcn
     import test_gpu_bf16 as b16
 
     def lin():                # samples -> at least 15 frames behind conv1 (stride 5, pad 1600) and 1 behind conv2
         return rnd.choice([rnd.randint(120, 900), rnd.randint(900, 6000), rnd.randint(6000, 40000)])
 
-    def l2():                 # frames into the tail: conv3 (k 15, s 6) then conv4 need >= 99
-        return rnd.choice([99, 105, rnd.randint(99, 400), rnd.randint(400, 1400)])
     menu = [
         ('wave12 stats+forward', w12.test_statistics_and_forward, lambda: (rnd.randint(1, 6), lin(), rnd.random() < 0.5)),
         ('wave12 backward', w12.test_backward, lambda: (rnd.randint(1, 5), lin(), rnd.choice([0, 0, 2, 3, 5]), rnd.random() < 0.5,
@@ -43,11 +39,6 @@ def main():
         ('wave_fused forward', wf.test_fused_forward_conv, lambda: (*rnd.choice(wf.SHAPES), rnd.randint(1, 6), rnd.randint(1, 200))),
         ('wave_fused dgrad', wf.test_fused_data_gradient, lambda: (*rnd.choice(wf.SHAPES), rnd.randint(1, 6), rnd.randint(1, 200))),
         ('wave_fused wgrad', wf.test_fused_weight_gradient, lambda: (*rnd.choice(wf.SHAPES), rnd.randint(1, 8), rnd.randint(1, 200))),
-        ('wave32 tail forward', w32.test_forward_of_conv3_and_conv4, lambda: (rnd.randint(1, 6), l2())),
-        ('wave32 tail backward', w32.test_backward_of_conv4_and_conv3, lambda: (rnd.randint(1, 5), l2(), rnd.choice([1.0, 0.3]))),
-        ('wave12 pipelined forward', w32.test_pipelined_fp32_forward_is_bit_identical, lambda: (rnd.randint(1, 5), lin())),
-        ('tcn opt-in paths', tcn.test_gather_and_deep_rings_at_other_clip_lengths,
-         lambda: (rnd.choice(['fp32', 'bf16']), rnd.randint(1, 9), rnd.randint(2, 40))),
         ('bf16 tcn vs layer by layer', b16.test_clip_resident_tcn_equals_the_layer_by_layer_bf16_path,
          lambda: (rnd.randint(1, 9), rnd.randint(9, 40))),
     ]
