@@ -365,6 +365,7 @@ class ModelCfg:
 
 
 def _speaker_z(sd: SD, vid: Tensor, noise: Noise):
+    assert vid is not None                 # net/multimodal_context_net_v2.py:511 (what z_type 'random' runs into, processor_v2.py:906)
     z = F.embedding(vid, sd['speaker_embedding.0.weight'])
     z = F.linear(z, sd['speaker_embedding.1.weight'], sd['speaker_embedding.1.bias'])
     mu = F.linear(z, sd['speaker_mu.weight'], sd['speaker_mu.bias'])
@@ -757,15 +758,29 @@ def dis_loss(dis_real: Tensor, dis_fake: Tensor) -> Tensor:
     return torch.sum(-torch.mean(torch.log(dis_real + 1e-8) + torch.log(1 - dis_fake + 1e-8)))
 
 
+def uses_divergence_term(scfg: StepCfg) -> bool:
+    """processor_v2.py:899-900: the branch with the second generator pass (other speakers), the divergence regulariser and --
+    for z_type 'speaker' only (:924-929) -- the KLD term.  Otherwise (:933-934) the loss is the regression term alone."""
+    return scfg.z_type in ('speaker', 'random') and scfg.loss_reg_weight > 0.0
+
+
 def gen_losses(scfg: StepCfg, out, target, dis_out, out_rand, z, z_rand, mu, log_var, use_gan: bool):
-    """processor_v2.py:893-937.  Returns (total, dict of unweighted components)."""
+    """processor_v2.py:893-937.  Returns (total, dict of unweighted components; kld / div_reg are None where the reference
+    leaves them None: out_rand is None <=> the branch of :933-934)."""
     huber = F.smooth_l1_loss(out / 0.1, target / 0.1) * 0.1
     gen_error = -torch.mean(torch.log(dis_out + 1e-8))
-    pose_l1 = (F.smooth_l1_loss(out / 0.05, out_rand.detach() / 0.05, reduction='none') * 0.05).sum(dim=(1, 2))
-    z_l1 = (z.detach() - z_rand.detach()).abs().mean(1)
-    div_reg = torch.clamp(-(pose_l1 / (z_l1 + 1.0e-5)), min=-1000).mean()
-    kld = -0.5 * torch.mean(1 + log_var - mu.pow(2) - log_var.exp())
-    loss = scfg.loss_regression_weight * huber + scfg.loss_kld_weight * kld + scfg.loss_reg_weight * div_reg
+    kld = div_reg = None
+    if uses_divergence_term(scfg):
+        pose_l1 = (F.smooth_l1_loss(out / 0.05, out_rand.detach() / 0.05, reduction='none') * 0.05).sum(dim=(1, 2))
+        z_l1 = (z.detach() - z_rand.detach()).abs().mean(1)
+        div_reg = torch.clamp(-(pose_l1 / (z_l1 + 1.0e-5)), min=-1000).mean()
+        if scfg.z_type == 'speaker':
+            kld = -0.5 * torch.mean(1 + log_var - mu.pow(2) - log_var.exp())
+            loss = scfg.loss_regression_weight * huber + scfg.loss_kld_weight * kld + scfg.loss_reg_weight * div_reg
+        else:
+            loss = scfg.loss_regression_weight * huber + scfg.loss_reg_weight * div_reg
+    else:
+        loss = scfg.loss_regression_weight * huber
     if use_gan:
         loss = loss + scfg.loss_gan_weight * gen_error
     return loss, dict(huber=huber, gen=gen_error, div_reg=div_reg, kld=kld)
@@ -867,15 +882,24 @@ def gan_step(G: SD, D: SD, PGT: SD, g_opt: AdamState, d_opt: AdamState, mcfg: Mo
         out, z, mu, log_var = pose_generator(Gl, mcfg, pre_seq, in_text, in_mfcc, vid, train, noise.g_main, fast)
     with _P('d_gen'):
         d_out = aff_discriminator(Dl, out, train, noise.d_gen, fast)
-    perm = noise.perm if noise.perm is not None else torch.randperm(vid.shape[0])
-    with torch.no_grad(), _P('g_rand'):
-        out_rand, z_rand, _, _ = pose_generator(Gl, mcfg, pre_seq, in_text, in_mfcc, vid[perm], train,
-                                                noise.g_rand, fast)
+    out_rand = z_rand = None
+    if uses_divergence_term(scfg):         # processor_v2.py:899-910 (z_type 'random': rand_vids = None -- the speaker-embedding
+        # generator then asserts, net/multimodal_context_net_v2.py:511, exactly as the reference's own step does)
+        if scfg.z_type == 'speaker':
+            perm = noise.perm if noise.perm is not None else torch.randperm(vid.shape[0])
+            rand_vids = vid[perm]
+        else:
+            rand_vids = None
+        with torch.no_grad(), _P('g_rand'):
+            out_rand, z_rand, _, _ = pose_generator(Gl, mcfg, pre_seq, in_text, in_mfcc, rand_vids, train,
+                                                    noise.g_rand, fast)
     loss, comp = gen_losses(scfg, out, target, d_out, out_rand, z, z_rand, mu, log_var,
                             epoch > scfg.loss_warmup)
-    losses.update(loss=scfg.loss_regression_weight * float(comp['huber'].detach()),
-                  KLD=scfg.loss_kld_weight * float(comp['kld'].detach()),
-                  DIV_REG=scfg.loss_reg_weight * float(comp['div_reg'].detach()))
+    losses.update(loss=scfg.loss_regression_weight * float(comp['huber'].detach()))
+    if comp['kld'] is not None:
+        losses['KLD'] = scfg.loss_kld_weight * float(comp['kld'].detach())
+    if comp['div_reg'] is not None:
+        losses['DIV_REG'] = scfg.loss_reg_weight * float(comp['div_reg'].detach())
     if use_gan:
         losses['gen'] = scfg.loss_gan_weight * float(comp['gen'].detach())
     losses['total'] = float(loss.detach())

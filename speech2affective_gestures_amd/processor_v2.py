@@ -132,6 +132,27 @@ class _GraphSegments:
 class Processor(object):
     """Processor for emotive gesture generation (hot-path subset)."""
 
+    @staticmethod
+    def regulariser_branch(cfg) -> bool:
+        """The generator-loss branch of the step (processor_v2.py:899-934), fixed at construction like every other static shape
+        of the step.  True: z_type 'speaker' and loss_reg_weight > 0 -- the generator runs a third time with shuffled speakers
+        and the loss carries the divergence regulariser and the KLD term (:901-929).  False: z_type 'none' or loss_reg_weight
+        == 0 -- the loss is the regression term (+ the GAN term) alone and that pass does not exist (:933-934).
+        z_type 'random' with the regulariser on hands vid_indices = None to a generator whose z_obj is the speaker Vocab (the
+        only kind this class and the reference's build, :140): the reference's own step dies on `assert vid_indices is not
+        None` (net/multimodal_context_net_v2.py:511) at its first batch -- here the same configuration fails at construction."""
+        z_type = getattr(cfg, 'z_type', 'speaker')
+        if z_type not in ('speaker', 'random', 'none'):
+            raise ValueError(f"z_type must be 'speaker', 'random' or 'none' (config/multimodal_context_v2.yml:25), got {z_type!r}")
+        on = z_type in ('speaker', 'random') and float(cfg.loss_reg_weight) > 0.0
+        if on and z_type == 'random':
+            raise ValueError("z_type 'random' with loss_reg_weight > 0 calls the generator with vid_indices=None "
+                             "(processor_v2.py:906-910), which a generator built with the speaker model as z_obj -- the only "
+                             "kind Processor builds -- refuses (assert vid_indices is not None, "
+                             "net/multimodal_context_net_v2.py:511): the reference fails on its first batch with this "
+                             "configuration; use z_type 'speaker', or 'none' / loss_reg_weight 0 for no regulariser")
+        return on
+
     def __init__(self, base_path, args, s2ag_config_args, data_loader, pose_dim, coords, audio_sr,
                  min_train_epochs=20, zfill=6):
         if not torch.cuda.is_available():
@@ -219,6 +240,7 @@ class Processor(object):
         self.s2ag_gen_optimizer = FusedAdam(self.gen_arena, lr=self.lr_s2ag_gen, betas=(0.5, 0.999))
         self.s2ag_dis_optimizer = FusedAdam(self.dis_arena, lr=self.lr_s2ag_dis, betas=(0.5, 0.999))
 
+        self.use_div_reg = self.regulariser_branch(cfg)
         self.use_hip_graph = bool(getattr(args, 'hip_graph', True))
         # independent forward passes of a step run on forked streams (every kernel here fills only part of the chip)
         self.overlap_passes = bool(getattr(args, 'overlap_passes', True))
@@ -239,7 +261,7 @@ class Processor(object):
         self.encoders_apart = self.encoders_aside and \
             bool(getattr(args, 'encoders_apart', True))
         self.early_real_backward = bool(getattr(args, 'early_real_backward', True))
-        self.early_rand = bool(getattr(args, 'early_rand', True))
+        self.early_rand = bool(getattr(args, 'early_rand', True)) and self.use_div_reg     # no third pass without the regulariser
         # the loss pass of the generator (with autograd) and the frozen tri-modal baseline read nothing the D step
         # writes: they run beside the D step instead of at the head of the generator phase (see _dis_phase)
         self.early_main = int(getattr(args, 'early_main', 3))
@@ -522,6 +544,11 @@ class Processor(object):
         return self.meta_info['epoch'] > self.s2ag_config_args.loss_warmup and \
             self.s2ag_config_args.loss_gan_weight > 0.0
 
+    def _gen_passes(self):
+        """Forward passes of the trainable generator per step (processor_v2.py:798, :823, :909): for D (GAN phase only), for
+        the loss, with shuffled speakers (regulariser branch only) -- what the shared encoders' BatchNorm statistics advance by."""
+        return 1 + int(self._use_gan()) + int(self.use_div_reg)
+
     def _make_pre_seq(self, target_poses):
         n_pre = self.s2ag_config_args.n_pre_poses
         return ops.make_pre_seq(target_poses, n_pre)
@@ -724,7 +751,8 @@ class Processor(object):
         nz_tri, nz_main, nz_dgen, nz_rand = noise.begin_passes(dev, 4)
         early = getattr(self, '_early_rand', None)        # G(rand) already ran beside the D step (see _dis_phase)
         self._early_rand = None
-        if early is None:
+        with_rand = self.use_div_reg                       # processor_v2.py:899-900; False: the branch of :933-934
+        if early is None and with_rand:
             rand_idx = torch.randperm(vid_indices.shape[0], device=vid_indices.device)
             rand_vids = vid_indices[rand_idx]
         cur = torch.cuda.current_stream()
@@ -748,6 +776,8 @@ class Processor(object):
             ops.stamp('G:G(main) fwd end [main]')
         if early is not None:
             out_rand, z_rand = early
+        elif not with_rand:
+            out_rand = z_rand = None
         elif self.overlap_passes:    # G(rand) follows G(main) (BatchNorm running stats order) but runs beside D(gen)
             side1 = self._fork(1)
             with torch.cuda.stream(side1), torch.no_grad(), noise.use_pass(nz_rand), ops.sequential_branches():
@@ -768,15 +798,20 @@ class Processor(object):
         if self.overlap_passes:
             if early_tri is None:
                 cur.wait_stream(side0)
-            if early is None:
+            if early is None and with_rand:
                 cur.wait_stream(side1)
-        elif early is None:
+        elif early is None and with_rand:
             with torch.no_grad(), noise.use_pass(nz_rand):
                 out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, rand_vids)
         self._last_outs = (out_tri.detach(), out.detach())      # forward_pass_s2ag(calculate_metrics=True) reads them
         w_gan = cfg.loss_gan_weight if self.meta_info['epoch'] > cfg.loss_warmup else 0.0
-        total, comps = ops.gen_loss(out, dis_output, z_mu, z_log_var, target_poses, out_tri, out_rand, z, z_rand,
-                                    (cfg.loss_regression_weight, w_gan, cfg.loss_reg_weight, cfg.loss_kld_weight))
+        if with_rand:
+            weights = (cfg.loss_regression_weight, w_gan, cfg.loss_reg_weight, cfg.loss_kld_weight)
+        else:
+            # regression (+ GAN) term alone: the fused loss is handed the main pass in place of the missing one (its
+            # divergence term is then exactly 0) with zero weights on the two terms the reference leaves out
+            out_rand, z_rand, weights = out, z, (cfg.loss_regression_weight, w_gan, 0.0, 0.0)
+        total, comps = ops.gen_loss(out, dis_output, z_mu, z_log_var, target_poses, out_tri, out_rand, z, z_rand, weights)
         ops.stamp('G:losses done, backward begins')
         if self.overlap_passes and self.encoders_aside and self.s2ag_generator.share_passes and self._use_gan():
             ops.mark_side_stream(self._side[1])      # the shared encoders' backward runs on the stream of their forward
@@ -812,8 +847,10 @@ class Processor(object):
         host = torch.cat((comps, dis_error.reshape(1) if dis_error is not None else comps.new_zeros(1), flag)).tolist()
         total, huber, gen_error, div_reg, kld, l1, l1_tri, _, dis, timed_out = host
         ops.check_coop_flag(timed_out)       # a cooperative recurrence that lost a peer continued with wrong values
-        d = {'loss': cfg.loss_regression_weight * huber, 'KLD': cfg.loss_kld_weight * kld,
-             'DIV_REG': cfg.loss_reg_weight * div_reg, 'total': total}
+        d = {'loss': cfg.loss_regression_weight * huber, 'total': total}
+        if self.use_div_reg:                  # (the reference's loss_dict has these entries in that branch only, :943-947)
+            d['KLD'] = cfg.loss_kld_weight * kld
+            d['DIV_REG'] = cfg.loss_reg_weight * div_reg
         if self._use_gan():
             d['gen'] = cfg.loss_gan_weight * gen_error
             d['dis'] = dis
@@ -857,7 +894,7 @@ class Processor(object):
                 assert v is not None, '{} cannot be None when calculate_metrics is True'.format(name)
         ops.begin_step()
         # encoder sharing is scoped to THIS step (the cache is keyed on buffer addresses): off again when the step ends
-        self.s2ag_generator.share_passes = (3 if self._use_gan() else 2) if self.share_encoders else None
+        self.s2ag_generator.share_passes = self._gen_passes() if self.share_encoders else None
         try:
             ret = self._step(in_text, in_audio, in_mfcc, target_poses, vid_indices, train)
             if calculate_metrics:
@@ -909,7 +946,7 @@ class Processor(object):
 
         def seg_dis():
             ops.begin_step()
-            self.s2ag_generator.share_passes = (3 if use_gan else 2) if self.share_encoders else None
+            self.s2ag_generator.share_passes = self._gen_passes() if self.share_encoders else None
             out['pre'] = self._make_pre_seq(st['target'])
             out['dis'] = self._dis_phase(st['text'], st['mfcc'] if self.use_mfcc else st['audio'], st['target'],
                                          st['vid'], out['pre'], True, in_audio=st['audio'],

@@ -233,10 +233,26 @@ def tcn_dropout_golden(seed0):
     print('wrote tcn_dropout.npz', len(order), 'masks')
 
 
-def step_golden(seed0, n_steps=3):
+# the branches of the step the reference's configuration selects (processor_v2.py:793, :899-934, :936): what each variant
+# changes in the config, the file it writes, and the noise passes (counter offset inside the step, site) whose eps the
+# reference's re_parametrize calls consume, in call order -- the product numbers its passes 0 G(dis) 1 D(real) 2 D(fake) 3 PGT
+# 4 G(main) 5 D(gen) 6 G(rand) with the GAN phase on, and 0 PGT 1 G(main) 2 D(gen) 3 G(rand) during warm-up (no D phase)
+STEP_VARIANTS = {
+    'speaker': (dict(), 'step_small.npz', 7, ((0, G_Z_SITE), (3, PGT_Z_SITE), (4, G_Z_SITE), (6, G_Z_SITE))),
+    'znone': (dict(z_type='none'), 'step_small_znone.npz', 7, ((0, G_Z_SITE), (3, PGT_Z_SITE), (4, G_Z_SITE))),
+    'noreg': (dict(loss_reg_weight=0.0), 'step_small_noreg.npz', 7, ((0, G_Z_SITE), (3, PGT_Z_SITE), (4, G_Z_SITE))),
+    'warmup': (dict(loss_warmup=5), 'step_small_warmup.npz', 4, ((0, PGT_Z_SITE), (1, G_Z_SITE), (3, G_Z_SITE))),
+}
+
+
+def step_golden(seed0, n_steps=3, variant='speaker'):
     """Three reference GAN steps (Processor.forward_pass_s2ag) at reduced width, dropout off, noise pinned."""
     hidden, n_words, n_spk, B = 32, 64, 12, 4
+    overrides, fname, passes_per_step, eps_passes = STEP_VARIANTS[variant]
     cfg, mods = build(hidden, n_words, n_spk, 0.0, seed0)
+    for k, v in overrides.items():
+        assert hasattr(cfg, k), k
+        setattr(cfg, k, v)
     G, D, T3 = mods['G'], mods['D'], mods['T3']
     for m in (G, D, T3):
         m.train()
@@ -267,19 +283,25 @@ def step_golden(seed0, n_steps=3):
         for s in range(n_steps):
             inp = O.recipe_inputs(B, 34, seed0 + 100 + s, n_words, n_spk)
             # eps exactly as libs2ag_hip.so will draw them: (seed, pass counter, site) -> normal deviates
-            eps = [torch.from_numpy(s2ag_rng.normal(STEP_SEED, PASSES_PER_STEP * s + k, site, B * 16).reshape(B, 16))
-                   for k, site in ((0, G_Z_SITE), (3, PGT_Z_SITE), (4, G_Z_SITE), (6, G_Z_SITE))]
+            eps = [torch.from_numpy(s2ag_rng.normal(STEP_SEED, passes_per_step * s + k, site, B * 16).reshape(B, 16))
+                   for k, site in eps_passes]
             perm = torch.from_numpy(rs.permutation(B))
-            out[f's{s}.eps'] = np.stack([npy(e) for e in eps])     # order: G(dis), PGT, G(main), G(rand)
+            out[f's{s}.eps'] = np.stack([npy(e) for e in eps])     # order: G(dis), PGT, G(main), G(rand) -- those that run
             out[f's{s}.perm'] = npy(perm)
-            pin_eps(eps)
+            queue = pin_eps(eps)
             torch.randperm = lambda n, *a, **k: perm
             recorded.clear()
             ret = pr.forward_pass_s2ag(inp['in_text'], inp['in_audio'], inp['in_mfcc'], inp['target'],
                                        inp['vid'], train=True)
+            assert not queue, (variant, 'eps left over', len(queue))   # every pinned deviate was consumed: the pass list is right
             out[f's{s}.metric'] = np.float64(ret[0])
-            out[f's{s}.dis_error'] = np.float64(recorded[0])
-            out[f's{s}.loss'] = np.float64(recorded[1])
+            if variant == 'warmup':                                   # no D phase: one backward() per step
+                assert len(recorded) == 1
+                out[f's{s}.loss'] = np.float64(recorded[0])
+            else:
+                assert len(recorded) == 2
+                out[f's{s}.dis_error'] = np.float64(recorded[0])
+                out[f's{s}.loss'] = np.float64(recorded[1])
             if s == 0:
                 for k, p in G.named_parameters():
                     if k in ('out.2.weight', 'gru.weight_hh_l3_reverse', 'aff_encoder.st_gcn1.gcn.conv.weight',
@@ -305,8 +327,8 @@ def step_golden(seed0, n_steps=3):
         out['final.G.' + k] = npy(sdG[k])
     for k in ('out2.weight', 'gru.weight_ih_l0', 'aff_encoder.st_gcn2.tcn.2.weight'):
         out['final.D.' + k] = npy(sdD[k])
-    np.savez_compressed(os.path.join(HERE, 'step_small.npz'), **out)
-    print('wrote step_small.npz', [(k, float(out[k])) for k in out if k.endswith('.loss') or k.endswith('.dis_error')])
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print('wrote', fname, [(k, float(out[k])) for k in out if k.endswith('.loss') or k.endswith('.dis_error')])
 
 
 def misc_goldens():
@@ -342,4 +364,5 @@ if __name__ == '__main__':
     module_goldens('small', hidden=32, n_words=64, n_spk=12, B=2, seed0=1000)
     module_goldens('full', hidden=300, n_words=2000, n_spk=1371, B=4, seed0=2000)
     tcn_dropout_golden(3000)
-    step_golden(4000)
+    for v in STEP_VARIANTS:
+        step_golden(4000, variant=v)

@@ -125,6 +125,7 @@ def test_deterministic_mode_two_runs_are_bit_identical(monkeypatch, hidden, B, m
     assert l0 == l1
     differ = [k for k in a if not torch.equal(a[k], b[k])]
     assert not differ, (len(differ), len(a), differ[:8])
+    assert ops.coop_gru_timeouts() == 0
 
 
 def test_deterministic_graph_replay_equals_eager_bit_for_bit(monkeypatch):

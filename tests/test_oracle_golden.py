@@ -118,24 +118,50 @@ def test_gru_fast_equals_cellwise():
     assert (a - b).abs().max() < 1e-5
 
 
-def test_three_step_trace_matches_reference(golden_dir):
-    g = _load(golden_dir, 'step_small.npz')
+# the branches of the step (tests/golden/gen_golden.py STEP_VARIANTS: traces recorded from the reference's own
+# forward_pass_s2ag with the config changed as named): file, StepCfg overrides, eps rows -> passes
+_STEP_VARIANTS = {
+    'speaker': ('step_small.npz', {}, ('g_dis', 'pgt', 'g_main', 'g_rand')),
+    'znone': ('step_small_znone.npz', {'z_type': 'none'}, ('g_dis', 'pgt', 'g_main')),
+    'noreg': ('step_small_noreg.npz', {'loss_reg_weight': 0.0}, ('g_dis', 'pgt', 'g_main')),
+    'warmup': ('step_small_warmup.npz', {'loss_warmup': 5}, ('pgt', 'g_main', 'g_rand')),
+}
+
+
+class _NoPass:
+    """A pass the branch must not run: any noise request fails the test."""
+    def __getattr__(self, k):
+        raise AssertionError('this pass does not exist in this branch of the step (processor_v2.py:793, :899-934)')
+
+
+@pytest.mark.parametrize('variant', list(_STEP_VARIANTS))
+def test_three_step_trace_matches_reference(golden_dir, variant):
+    fname, overrides, eps_passes = _STEP_VARIANTS[variant]
+    g = _load(golden_dir, fname)
     hidden, n_words, n_spk, B, s0 = 32, 64, 12, 4, 4000
     oc = O.ModelCfg(hidden_size=hidden, hidden_size_s2eg=hidden, dropout_prob=0.0)
     G = O.recipe_state_dict(O.generator_shapes(oc, n_words, n_spk), s0 + 1)
     D = O.recipe_state_dict(O.aff_discriminator_shapes(), s0 + 2)
     T3 = O.recipe_state_dict(O.trimodal_shapes(oc, n_words, n_spk), s0 + 4)
     gopt, dopt = O.AdamState(), O.AdamState()
-    scfg = O.StepCfg()
+    scfg = O.StepCfg(**overrides)
     for s in range(3):
         inp = O.recipe_inputs(B, 34, s0 + 100 + s, n_words, n_spk)
         eps = torch.from_numpy(g[f's{s}.eps'])
-        nz = O.StepNoise(g_dis=_TrainNoise(eps[0]), d_real=O.Noise('off'), d_fake=O.Noise('off'),
-                         pgt=_TrainNoise(eps[1]), g_main=_TrainNoise(eps[2]), d_gen=O.Noise('off'),
-                         g_rand=_TrainNoise(eps[3]), perm=torch.from_numpy(g[f's{s}.perm']))
+        assert eps.shape[0] == len(eps_passes)
+        by_pass = {name: _TrainNoise(eps[i]) for i, name in enumerate(eps_passes)}
+        gen_pass = lambda name: by_pass.get(name, _NoPass())                       # noqa: E731
+        dis_pass = O.Noise('off') if variant != 'warmup' else _NoPass()
+        nz = O.StepNoise(g_dis=gen_pass('g_dis'), d_real=dis_pass, d_fake=dis_pass, pgt=gen_pass('pgt'),
+                         g_main=gen_pass('g_main'), d_gen=O.Noise('off'), g_rand=gen_pass('g_rand'),
+                         perm=torch.from_numpy(g[f's{s}.perm']))
         metric, losses, grads = O.gan_step(G, D, T3, gopt, dopt, oc, scfg, inp['in_text'], inp['in_audio'],
                                            inp['in_mfcc'], inp['target'], inp['vid'], epoch=1, noise=nz)
-        assert losses['dis'] == pytest.approx(float(g[f's{s}.dis_error']), rel=2e-5)
+        if variant == 'warmup':
+            assert 'dis' not in losses and 'gen' not in losses and 'D' not in grads
+        else:
+            assert losses['dis'] == pytest.approx(float(g[f's{s}.dis_error']), rel=2e-5)
+        assert ('KLD' in losses) == ('DIV_REG' in losses) == (variant in ('speaker', 'warmup'))
         assert losses['total'] == pytest.approx(float(g[f's{s}.loss']), rel=2e-5)
         assert metric == pytest.approx(float(g[f's{s}.metric']), rel=1e-3, abs=1e-6)
         if s == 0:
@@ -156,6 +182,20 @@ def test_three_step_trace_matches_reference(golden_dir):
             _close(g[k], G[k[8:]], tol=1e-4)
         if k.startswith('final.D.'):
             _close(g[k], D[k[8:]], tol=1e-4)
+
+
+def test_z_type_random_with_the_regulariser_fails_like_the_reference():
+    """processor_v2.py:906-910: z_type 'random' hands vid_indices = None to a generator built with the speaker model as z_obj
+    (the only kind Processor builds, :140) -> `assert vid_indices is not None` (net/multimodal_context_net_v2.py:511)."""
+    hidden, n_words, n_spk, B, s0 = 32, 64, 12, 2, 4000
+    oc = O.ModelCfg(hidden_size=hidden, hidden_size_s2eg=hidden, dropout_prob=0.0)
+    G = O.recipe_state_dict(O.generator_shapes(oc, n_words, n_spk), s0 + 1)
+    D = O.recipe_state_dict(O.aff_discriminator_shapes(), s0 + 2)
+    T3 = O.recipe_state_dict(O.trimodal_shapes(oc, n_words, n_spk), s0 + 4)
+    inp = O.recipe_inputs(B, 34, s0 + 100, n_words, n_spk)
+    with pytest.raises(AssertionError):
+        O.gan_step(G, D, T3, O.AdamState(), O.AdamState(), oc, O.StepCfg(z_type='random'), inp['in_text'], inp['in_audio'],
+                   inp['in_mfcc'], inp['target'], inp['vid'], epoch=1, noise=O.StepNoise.fresh())
 
 
 def test_checkpoint_name_protocol(golden_dir):
