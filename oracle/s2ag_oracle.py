@@ -134,6 +134,13 @@ class Noise:
         self.drawn[name] = m
         return x * m
 
+    def keep(self, name: str, p: float) -> Optional[Tensor]:
+        """The elements the dropout at ``name`` will keep (bool), when that is known before it is applied (pinned masks);
+        None = all of them / not known (fresh randomness is never combined with a sign replay)."""
+        if p <= 0.0 or not isinstance(self.pinned, dict):
+            return None
+        return self.pinned[name] != 0
+
     def normal(self, name: str, like: Tensor) -> Tensor:
         if self.pinned == 'off':
             return torch.zeros_like(like)
@@ -165,13 +172,19 @@ def _bn(sd: SD, p: str, x: Tensor, training: bool) -> Tensor:
 # outputs, so both sides differentiate the SAME piecewise-linear function and gradients can be compared strictly.
 # Site names: '<BatchNorm prefix>' for BN + activation pairs (e.g. 'audio_encoder.batch_norm1.'), '<prefix>linear1.',
 # '<prefix>tcn.<i>.relu1|relu2|relu3', '<prefix>st_gcn<k>.tcn.0.' / '<prefix>st_gcn<k>.out', 'out.1.'.
-_SIGNS: List[Optional[Dict[str, Tensor]]] = [None]
+# The replay is AUDITED, so that it cannot hide a wrong branch: at every replayed site the oracle also takes its own decision
+# (x > 0) and files, in ``use_signs(...).audit[site]``, how many LIVE elements (not zeroed by the dropout that follows the
+# site) were replayed against it and how far from the kink the oracle's own pre-activation is at the worst of them, relative
+# to the site's largest |x|.  A test asserts that these are a handful of elements within rounding distance of zero
+# (``assert_benign``) -- a product that takes the wrong side of a LARGE pre-activation fails there, replayed or not.
+_SIGNS: List[Optional['use_signs']] = [None]
 
 
 class use_signs:
     def __init__(self, signs: Optional[Dict[str, Tensor]]):
         self.signs = signs
         self.used: List[str] = []
+        self.audit: Dict[str, Dict[str, float]] = {}
 
     def __enter__(self):
         self.prev = _SIGNS[0]
@@ -181,13 +194,39 @@ class use_signs:
     def __exit__(self, *a):
         _SIGNS[0] = self.prev
 
+    def assert_benign(self, base: int, density: float, max_rel: float, what: str = '') -> Dict[str, float]:
+        """Every replayed site: at most ``base + density * live elements`` live elements decided differently from the oracle's
+        own x > 0, each with |x| <= max_rel * max|x| of its site.  Returns the totals (for a test's log line)."""
+        return audit_benign(self.audit, base, density, max_rel, what)
 
-def _act(x: Tensor, slope: float, name: str) -> Tensor:
+
+def audit_benign(audit: Dict[str, Dict[str, float]], base: int, density: float, max_rel: float,
+                 what: str = '') -> Dict[str, float]:
+    bad = {k: v for k, v in audit.items() if v['flipped'] > base + density * v['live'] or v['worst_rel'] > max_rel}
+    assert not bad, (what, 'replayed branch decisions that are NOT a few elements within rounding distance of the kink', bad)
+    return dict(sites=len(audit), elements=sum(v['live'] for v in audit.values()),
+                flipped=sum(v['flipped'] for v in audit.values()),
+                worst_rel=max([v['worst_rel'] for v in audit.values()] + [0.0]))
+
+
+def _act(x: Tensor, slope: float, name: str, live: Optional[Tensor] = None) -> Tensor:
+    """ReLU (slope 0) / LeakyReLU at the named site.  ``live`` (bool, like x; None = all): elements the dropout behind the
+    site keeps -- where it drops, the branch is immaterial (and the product's recorded decision, read off its post-dropout
+    output, is meaningless), so the audit of a replay skips them."""
     ctx = _SIGNS[0]
     if ctx is not None and ctx.signs is not None and name in ctx.signs:
         m = ctx.signs[name]
         assert m.shape == x.shape and m.dtype == torch.bool, (name, m.shape, x.shape)
         ctx.used.append(name)
+        with torch.no_grad():
+            own = x > 0
+            diff = own != m
+            if live is not None:
+                diff = diff & live
+            n = int(diff.sum())
+            top = float(x.abs().max())
+            ctx.audit[name] = dict(live=int(x.numel() if live is None else live.sum()), flipped=n,
+                                   worst_rel=(float(x[diff].abs().max()) / max(top, 1e-30)) if n else 0.0)
         return torch.where(m, x, x * slope)
     return F.leaky_relu(x, slope) if slope != 0.0 else F.relu(x)
 
@@ -231,7 +270,8 @@ def temporal_block(sd: SD, p: str, x: Tensor, dilation: int, training: bool, dro
         k = w.shape[2]
         pad = (k - 1) * dilation
         out = F.conv1d(out, w, sd[f'{p}{tag}.bias'], padding=pad, dilation=dilation)
-        out = _act(out[:, :, :-pad], 0.0, f'{name}.relu{j}')
+        out = _act(out[:, :, :-pad], 0.0, f'{name}.relu{j}',
+                   live=noise.keep(f'{name}.drop{j}', drop_p) if training else None)
         if training:
             out = noise.dropout(f'{name}.drop{j}', out, drop_p)
     if (p + 'downsample.weight') in sd:
@@ -842,6 +882,7 @@ def gan_step(G: SD, D: SD, PGT: SD, g_opt: AdamState, d_opt: AdamState, mcfg: Mo
     # tests record them from the product's own step, tests/s2ag_testing.py StepSignTap); ``signs_used`` lists what was consumed
     sg = signs or {}
     used: Dict[str, List[str]] = {}
+    audit: Dict[str, Dict[str, float]] = {}          # '<pass>/<site>' -> use_signs.audit entry (audit_benign checks it)
 
     class _P:                              # use_signs scope of one pass that also remembers which sites were consumed
         def __init__(self, name):
@@ -852,8 +893,10 @@ def gan_step(G: SD, D: SD, PGT: SD, g_opt: AdamState, d_opt: AdamState, mcfg: Mo
 
         def __exit__(self, *a):
             used[self.name] = list(self.ctx.used)
+            audit.update({f'{self.name}/{k}': v for k, v in self.ctx.audit.items()})
             return self.ctx.__exit__(*a)
     gan_step.signs_used = used
+    gan_step.signs_audit = audit
     pre_seq = make_pre_seq(target, scfg.n_pre_poses)
     use_gan = epoch > scfg.loss_warmup and scfg.loss_gan_weight > 0.0
     losses: Dict[str, float] = {}

@@ -219,6 +219,13 @@ def grad_err(a, b, key=''):
     return float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
 
 
+# What a sign replay (oracle.use_signs) may override, per site: at most 8 + 5e-6 x (live elements of the site) elements decided
+# against the oracle's own x > 0, each with |x| <= 1e-5 of the site's largest |x| (oracle/s2ag_oracle.py `audit_benign`).
+# Measured on the device model at H = 300, B = 88 .. 128 (1.1e7 .. 2.6e7 live elements in 22 .. 24 sites): 20 .. 23 flips in
+# all (density 1e-6 .. 2e-6), |x| <= 3.2e-6 of the largest.  A wrong branch at a pre-activation of ordinary size fails this.
+REPLAY_LIMITS = (8, 5e-6, 1e-5)
+
+
 def adam_close(v, ref, lr, steps):
     """Weights after a few Adam steps.  Adam turns a gradient element g into a step lr*m/sqrt(v), i.e. ~lr*sign(g)
     early on, so elements whose true gradient is at rounding-noise level may legitimately differ by a fraction of

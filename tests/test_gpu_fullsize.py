@@ -235,6 +235,18 @@ def test_full_size_step_matches_the_oracle(monkeypatch, config):
     for k in ('dis', 'total', 'loss', 'KLD', 'DIV_REG', 'gen'):
         assert pr.last_losses[k] == pytest.approx(losses[k], rel=3e-4, abs=1e-6), k
     assert ret[0] == pytest.approx(metric, rel=5e-3, abs=2e-6)
+    # the replay must not hide a wrong branch: what it overrode are a few live elements within rounding
+    # distance of the kink, in every pass -- and the oracle WITHOUT any replay gives the same losses
+    from s2ag_testing import REPLAY_LIMITS
+    info = O.audit_benign(O.gan_step.signs_audit, *REPLAY_LIMITS, what=f'full-size step {config}')
+    print(f'[replay audit full-size step {config}] {info}')
+    G0, D0, T0 = ({k: v.clone() for k, v in sds[n].items()} for n in ('G', 'D', 'T3'))
+    nz0 = _materialise_step_noise(pr, 0, B, T, hidden)
+    nz0.perm = perm
+    _, own, _ = O.gan_step(G0, D0, T0, O.AdamState(), O.AdamState(), oracle_cfg(hidden, 0.3, T), O.StepCfg(), inp['in_text'],
+                           inp['in_audio'], inp['in_mfcc'], inp['target'], inp['vid'], epoch=1, noise=nz0)
+    for k in ('dis', 'total', 'loss', 'KLD', 'DIV_REG', 'gen'):
+        assert pr.last_losses[k] == pytest.approx(own[k], rel=3e-4, abs=1e-6), ('without replay', k)
     # STRICT since r04: the oracle differentiates the same piecewise-linear function as the product (branch decisions of all
     # seven passes replayed), so no kink-tolerant criterion is needed -- every gradient tensor of G and of D within 1e-3 of
     # its largest element (r03: 5 % per tensor, 0.2 max-norm).  The small-batch twin of this test
@@ -298,6 +310,14 @@ def test_conv1d_roofline_run_gradients_match_the_oracle_strictly(B):
         rt = O.text_encoder_tcn(leaf, 'txt.', inp['in_text'], True, oc.dropout_prob, O.Noise(pin))
     assert set(used.used) == set(signs) and len(signs) == 3 + 12, (sorted(signs), sorted(used.used))
     assert rel(yw.cpu(), rw) < 3e-4 and rel(yt.cpu(), rt) < 3e-4
+    # (the replay must not hide a wrong branch: see test_full_size_step_matches_the_oracle)
+    from s2ag_testing import REPLAY_LIMITS
+    info = used.assert_benign(*REPLAY_LIMITS, what=f'configs[3] B={B}')
+    print(f'[replay audit configs[3] B={B}] {info}')
+    with torch.no_grad():
+        own = {k: v.detach().clone() for k, v in sd.items()}
+        assert rel(yw.cpu(), O.wav_encoder(own, 'wav.', inp['in_audio'], True)) < 3e-4
+        assert rel(yt.cpu(), O.text_encoder_tcn(own, 'txt.', inp['in_text'], True, oc.dropout_prob, O.Noise(pin))) < 3e-4
     g = torch.Generator().manual_seed(2)
     dw, dt = torch.randn(rw.shape, generator=g), torch.randn(rt.shape, generator=g)
     ((rw * dw).sum() + (rt * dt).sum()).backward()

@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import s2ag_oracle as O  # noqa: E402
-from s2ag_testing import (G_Z_SITE, STEP_SEED, build_product, grad_err, oracle_cfg, set_dropout,  # noqa: E402
+from s2ag_testing import (G_Z_SITE, REPLAY_LIMITS, STEP_SEED, build_product, grad_err, oracle_cfg, set_dropout,  # noqa: E402
                           to_cuda)
 
 TOL = 2e-4
@@ -182,6 +182,15 @@ def test_full_width_gradients_strictly_with_the_products_branch_decisions(which,
     assert set(used.used) == set(signs), set(signs) ^ set(used.used)           # every recorded site was consumed
     assert len(signs) == (5 if which == 'G' else 3) + 12 + 6 + 1
     assert rel(out, o_r) < TOL and rel(z, z_r) < TOL and rel(mu, mu_r) < TOL and rel(lv, lv_r) < TOL
+    # the replay is not allowed to hide a wrong branch: what it overrode are a few live elements within
+    # rounding distance of the kink, and WITHOUT any replay the forward still agrees
+    info = used.assert_benign(*REPLAY_LIMITS, what=f'{which} H={hidden} B={B}')
+    with torch.no_grad():
+        o_own, z_own, *_ = fn({k: v.detach().clone() for k, v in sds[which].items()}, oracle_cfg(hidden, 0.3), pre_seq,
+                              inp['in_text'], inp['in_mfcc'] if which == 'G' else inp['in_audio'], inp['vid'], True,
+                              O.Noise(pin))
+    assert rel(out, o_own) < TOL and rel(z, z_own) < TOL
+    print(f'[replay audit {which} H={hidden} B={B}] {info}')
     gen = torch.Generator().manual_seed(1)
     d_out, d_mu = torch.randn(o_r.shape, generator=gen), torch.randn(mu_r.shape, generator=gen)
     (o_r * d_out).sum().add((mu_r * d_mu).sum()).add((lv_r * d_mu).sum()).backward()
@@ -318,6 +327,11 @@ def test_discriminators_strictly_with_the_products_branch_decisions(B):
         assert set(used.used) == set(signs), set(signs) ^ set(used.used)
         assert len(signs) == (6 if key == 'D' else 0), sorted(signs)
         assert rel(y, yr) < TOL
+        info = used.assert_benign(*REPLAY_LIMITS, what=f'{key} B={B}')       # (see the generators' test above)
+        with torch.no_grad():
+            y_own = fn({k: v.detach().clone() for k, v in sds[key].items()}, inp['target'].clone(), True, O.Noise(pin))
+        assert rel(y, y_own) < TOL
+        print(f'[replay audit {key} B={B}] {info}')
         dy = torch.randn(yr.shape, generator=gen)
         (yr * dy).sum().backward()
         (y * dy.cuda()).sum().backward()

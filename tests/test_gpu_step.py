@@ -14,7 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import s2ag_oracle as O  # noqa: E402
-from s2ag_testing import (adam_close, G_Z_SITE, PASSES_PER_STEP, PGT_Z_SITE, STEP_SEED, Vocab, grad_err, make_cfg,  # noqa: E402
+from s2ag_testing import (adam_close, G_Z_SITE, PASSES_PER_STEP, REPLAY_LIMITS, PGT_Z_SITE, STEP_SEED, Vocab, grad_err, make_cfg,  # noqa: E402
                           is_noise_driven_after_adam, oracle_cfg, recipe_sds, set_dropout, to_cuda)
 
 TOL = 3e-4
@@ -240,6 +240,17 @@ def test_one_step_strictly_with_the_products_branch_decisions(monkeypatch, hidde
     for k in ('dis', 'total', 'loss', 'KLD', 'DIV_REG', 'gen'):
         assert pr.last_losses[k] == pytest.approx(losses[k], rel=3e-4, abs=1e-6), k
     assert ret[0] == pytest.approx(metric, rel=5e-3, abs=2e-6)
+    # the replay must not hide a wrong branch: what it overrode, in every pass, are a few live elements
+    # within rounding distance of the kink -- and the oracle WITHOUT any replay gives the same losses
+    info = O.audit_benign(O.gan_step.signs_audit, *REPLAY_LIMITS, what=f'step H={hidden} B={B}')
+    G0, D0, T0 = ({k: v.clone() for k, v in sds[n].items()} for n in ('G', 'D', 'T3'))
+    nz0 = _materialise_step_noise(pr, 0, B, 34, hidden)
+    nz0.perm = perm
+    _, own, _ = O.gan_step(G0, D0, T0, O.AdamState(), O.AdamState(), oracle_cfg(hidden, 0.3), O.StepCfg(), inp['in_text'],
+                           inp['in_audio'], inp['in_mfcc'], inp['target'], inp['vid'], epoch=1, noise=nz0)
+    for k in ('dis', 'total', 'loss', 'KLD', 'DIV_REG', 'gen'):
+        assert pr.last_losses[k] == pytest.approx(own[k], rel=3e-4, abs=1e-6), ('without replay', k)
+    print(f'[replay audit step H={hidden} B={B}] {info}')
     for tag, mod in (('G', pr.s2ag_generator), ('D', pr.s2ag_discriminator)):
         errs = {k: grad_err(p.grad, grads[tag][k], k) for k, p in mod.named_parameters() if '.net.' not in k}
         top = sorted(errs.items(), key=lambda kv: -kv[1])[:3]

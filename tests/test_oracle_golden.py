@@ -319,3 +319,46 @@ def test_push_samples_metrics_match_reference(golden_dir):
         count += BATCH_SIZES[b]
     np.testing.assert_allclose(sums / count, g['avgs'], rtol=1e-6)
     assert count == int(g['counts'][0])
+
+
+def test_sign_replay_is_audited_and_a_wrong_branch_fails_the_audit():
+    """replaying the product's branch decisions in the oracle (use_signs) must not be able to hide a
+    product that took the WRONG branch.  The replay files, per site, how many live elements it overrode and how far from
+    the kink the oracle's own pre-activation is there; audit_benign accepts a few elements within rounding distance of
+    zero and nothing else.  Dropped-out elements of the TCN's ReLU sites (whose recorded decision, read off a post-dropout
+    output, is meaningless) are not counted."""
+    torch.manual_seed(0)
+    x = torch.randn(4, 6, 50)
+    x[0, 0, 0] = 1e-7                                   # within rounding distance of the kink
+    own = x > 0
+    near = own.clone()
+    near[0, 0, 0] = False                               # the 'product' landed on the other side there: benign
+    with O.use_signs({'s': near}) as u:
+        y = O._act(x, 0.3, 's')
+    assert torch.equal(y, torch.where(near, x, 0.3 * x)) and u.used == ['s']
+    assert u.audit['s']['flipped'] == 1 and u.audit['s']['worst_rel'] < 1e-6
+    u.assert_benign(8, 5e-6, 1e-5)
+    wrong = own.clone()
+    i = int(x.abs().flatten().argmax())
+    wrong.view(-1)[i] = not bool(wrong.view(-1)[i])     # the wrong side of the LARGEST pre-activation
+    with O.use_signs({'s': wrong}) as u:
+        O._act(x, 0.3, 's')
+    assert u.audit['s']['flipped'] == 1 and u.audit['s']['worst_rel'] == pytest.approx(1.0)
+    with pytest.raises(AssertionError, match='NOT a few elements within rounding distance'):
+        u.assert_benign(8, 5e-6, 1e-5)
+    many = own.clone()
+    many.view(-1)[:100] = ~many.view(-1)[:100]          # many flips: refused whatever their size
+    with O.use_signs({'s': many}) as u:
+        O._act(x, 0.3, 's')
+    with pytest.raises(AssertionError):
+        u.assert_benign(8, 5e-6, 1.0)
+    # dropped-out elements are not live: a ReLU site whose recorded sign is False wherever the dropout dropped
+    keep = torch.rand(4, 6, 50) > 0.3
+    rec = own & keep
+    with O.use_signs({'s': rec}) as u:
+        O._act(x, 0.0, 's', live=keep)
+    assert u.audit['s']['flipped'] == 0 and u.audit['s']['live'] == int(keep.sum())
+    with O.use_signs({'s': rec}) as u:
+        O._act(x, 0.0, 's')
+    assert u.audit['s']['flipped'] == int((own & ~keep).sum())
+    assert O.Noise({'d': keep.float() / 0.7}).keep('d', 0.3).equal(keep) and O.Noise('off').keep('d', 0.3) is None
