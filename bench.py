@@ -67,9 +67,12 @@ def synthetic_batch(B, seed, device, frames=T, audio_len=AUDIO_LEN):
     return [t.to(device) for t in (text, audio, mfcc, target, vid)]
 
 
+HIDDEN = 300                      # (--dry-width: a launch-path dry run at reduced width, never the benchmark)
+
+
 def make_cfg(frames=T):
-    return types.SimpleNamespace(n_pre_poses=4, n_poses=frames, input_context='both', hidden_size=300,
-                                 hidden_size_s2eg=300, n_layers=4, dropout_prob=0.3, freeze_wordembed=False,
+    return types.SimpleNamespace(n_pre_poses=4, n_poses=frames, input_context='both', hidden_size=HIDDEN,
+                                 hidden_size_s2eg=HIDDEN, n_layers=4, dropout_prob=0.3, freeze_wordembed=False,
                                  loss_warmup=0, loss_gan_weight=5.0, z_type='speaker', loss_reg_weight=0.05,
                                  loss_regression_weight=500, loss_kld_weight=0.1, wordembed_dim=300,
                                  learning_rate=5e-4, discriminator_lr_weight=0.2)
@@ -443,7 +446,7 @@ def conv1d_roofline_run(device, B=256, iters=30, cpu=True, mode='fp32'):
     return out
 
 
-def cpu_baseline(B, steps=2, frames=T, audio_len=AUDIO_LEN):
+def cpu_baseline(B, steps=5, frames=T, audio_len=AUDIO_LEN):      # 2 warm-up + 5 timed steps
     """The oracle's gan_step (ATen fused GRU, drawn dropout) on the host cores -- bounded sample."""
     from oracle import s2ag_oracle as O
     phys, cand = _cpu_threads()
@@ -598,7 +601,14 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip gen-forward latency, the Conv1d roofline run, alternative product modes, the long config')
+    ap.add_argument('--dry-width', default=None, metavar='HIDDEN,N_WORDS,N_SPEAKERS',
+                    help='DRY RUN of the launch path (rank env, process group, timing protocol, the one JSON line) at a reduced '
+                         'model width -- what the CPU test of the N > 1 launch uses (tests/test_emu_suite.py).  The line it '
+                         'prints is labelled as such and is not a measurement of the benchmark configuration')
     a = ap.parse_args()
+    if a.dry_width:
+        global HIDDEN, N_WORDS, N_SPK
+        HIDDEN, N_WORDS, N_SPK = (int(v) for v in a.dry_width.split(','))
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; the product has no CPU path')
@@ -622,23 +632,31 @@ def main():
     if dp.rank == 0:
         ex = pr._exchange()
         line = {
-            'metric': 'gan_train_step_clips_per_sec', 'value': value, 'unit': 'clips/s', 'n_gpus': dp.world_size,
+            'metric': 'gan_train_step_clips_per_sec' if not a.dry_width else
+                      'DRY_RUN_reduced_width_not_the_benchmark__gan_train_step_clips_per_sec', 'value': value, 'unit': 'clips/s', 'n_gpus': dp.world_size,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': dtype_label(), 'data': 'synthetic',
             'config': {'workload': wl['name'], 'batch_per_gpu': B, 'global_batch': B * dp.world_size, 'frames': frames,
-                       'audio_samples': audio_len, 'n_words': N_WORDS, 'n_speakers': N_SPK,
+                       'audio_samples': audio_len, 'n_words': N_WORDS, 'n_speakers': N_SPK, 'hidden_size': HIDDEN,
                        'parallelism': f'dp{dp.world_size}', 'hip_graph': not a.no_graph,
                        'matrix_products': matrix_products_mode(),
                        'gradient_exchange_bytes_per_rank': ex.bytes_per_step() if ex is not None else None,
                        'last_step_losses': pr.last_losses if metric is not None else None},
             'value_with_per_step_loss_readback': sync_value,
         }
-        line['roofline'] = gru_roofline(B, T=frames)
+        # the headline's large products carry 16 mantissa bits per operand (two bf16 pieces): the rate of the SAME step with
+        # fp32-equivalent products (three pieces) -- the figure to hold against an fp32 reference -- at the top level too
+        line['value_fp32_equivalent'] = None
+        line['roofline'] = gru_roofline(B, T=frames) if not a.dry_width else None
         if dp.world_size == 1 and not a.no_extras and not dp.active:
             line['value_epoch_loop'] = epoch_loop_rate(pr, B) if a.config == 'step' else None
             line['value_dp_structure'] = dp_structure_run(a.steps)
         if dp.world_size == 1 and not a.no_extras:
             line['alt_modes'] = alt_modes(pr, dp, batch, B)
+            if matrix_products_mode().startswith('fp32 operands as 2'):
+                line['value_fp32_equivalent'] = line['alt_modes']['fp32_equivalent_3_bf16_pieces']['clips_per_s']
+            elif int(__import__('speech2affective_gestures_amd._lib', fromlist=['load']).load().s2ag_gru_coop_split_pieces()) in (0, 3):
+                line['value_fp32_equivalent'] = value
             line['gen_fwd_ms'] = gen_forward_ms(pr, pr.device, cpu=not a.no_cpu_baseline)
             line['conv1d_roofline_run'] = conv1d_roofline_run(pr.device, cpu=not a.no_cpu_baseline)
             line['conv1d_roofline_run_bf16'] = conv1d_roofline_run(pr.device, cpu=False, mode='bf16')

@@ -34,6 +34,26 @@ def main():
     for b in batches + batches:
         m = pr.train_step(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'])
         steps.append(dict(metric=m, **pr.last_losses))
+    # S2AG_PROBE_RUNAHEAD=n: n more replayed steps WITHOUT the per-step read-back (train_step(sync=False): what bench.py times).
+    # Nothing then makes the host wait for the device except GradExchange.exchange_rest's wait for the id count it sent ahead
+    # at the start of the step (parallel.py): when train_step(k) returns, every earlier step must be complete on the device.
+    runahead = None
+    n_ahead = int(os.environ.get('S2AG_PROBE_RUNAHEAD', '0'))
+    if n_ahead:
+        events, worst = [], 0
+        for k in range(n_ahead):
+            b = batches[k % len(batches)]
+            pr.train_step(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'], sync=False)
+            worst = max(worst, sum(0 if e.query() else 1 for e in events))       # earlier steps still running on the device
+            e = torch.cuda.Event()
+            e.record()
+            events.append(e)
+        torch.cuda.synchronize()
+        b = batches[0]
+        m = pr.train_step(b['in_text'], b['in_audio'], b['in_mfcc'], b['target'], b['vid'])          # one read-back at the end
+        ex = pr._exchange()
+        runahead = dict(steps=n_ahead, max_unfinished_earlier_steps=worst, last=dict(metric=m, **pr.last_losses),
+                        dense_fallbacks=None if ex is None else ex.dense_fallbacks)
     sums = {}
     for tag, mod in (('G', pr.s2ag_generator), ('D', pr.s2ag_discriminator)):
         for k, v in mod.state_dict().items():
@@ -43,7 +63,7 @@ def main():
     import torch.distributed as dist
     print('PROBE ' + json.dumps(dict(steps=steps, sums=sums, dist=dist.is_initialized(), active=pr.dp.active,
                                      segments=len(pr._graphed['segs'].graphs), timeouts=ops.coop_gru_timeouts(),
-                                     collectives=getattr(pr.dp, 'n_collectives', None))), flush=True)
+                                     collectives=getattr(pr.dp, 'n_collectives', None), runahead=runahead)), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -1,0 +1,19 @@
+"""TEST INFRASTRUCTURE: bench.py on the CPU device model (tests/emu) -- run under torch.distributed.run exactly as the driver
+launches the N > 1 bench (one process per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), with gloo
+standing in for RCCL and `--dry-width` shrinking the model so that a step takes seconds on the model.  What this executes is
+the LAUNCH PATH of the multi-GPU bench -- rank environment, process-group set-up, the four-segment data-parallel step with
+its collectives between the segments, barrier + max-over-ranks timing, exactly one JSON line from rank 0 -- not a
+measurement.  Used by tests/test_emu_suite.py::test_bench_launch_path_with_two_ranks."""
+import os
+import runpy
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(HERE, 'emu'))
+import harness  # noqa: E402
+
+harness.install()
+sys.argv = [os.path.join(ROOT, 'bench.py')] + sys.argv[1:]
+runpy.run_path(sys.argv[0], run_name='__main__')

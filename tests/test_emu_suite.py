@@ -77,3 +77,36 @@ def test_gpu_parity_tests_on_the_cpu_device_model(emu_lib, group):
     m = re.search(r'(\d+) passed', p.stdout)
     assert p.returncode == 0, tail
     assert m and int(m.group(1)) >= at_least, tail
+
+
+def test_bench_launch_path_with_two_ranks(emu_lib):
+    """`bench.py --gpus 2` launched exactly as the driver launches it -- python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps K --warmup W -- has never
+    run anywhere (no multi-GPU node so far).  Here it runs with two gloo ranks on the CPU device model at a reduced width
+    (tests/s2ag_emu_bench.py; bench.py --dry-width): rank environment, process group, the data-parallel step (four segments
+    with the collectives between them), barrier + max-over-ranks timing, exactly ONE JSON line, from rank 0, with the
+    contract's keys and the whole-job aggregate.  A launch-path test, not a measurement."""
+    import json
+    port = 29800 + os.getpid() % 150
+    env = dict(os.environ)
+    env.pop('S2AG_HIP_LIB', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 's2ag_emu_bench.py'), '--gpus', '2', '--steps', '2',
+           '--warmup', '1', '--batch', '4', '--dry-width', '32,64,12', '--no-extras', '--no-cpu-baseline']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, lines                         # rank 0 prints; rank 1 prints nothing of the kind
+    d = json.loads(lines[0])
+    assert d['metric'].startswith('DRY_RUN_reduced_width_not_the_benchmark')        # cannot be mistaken for a measurement
+    for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config'):
+        assert k in d, k
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['unit'] == 'clips/s'
+    c = d['config']
+    assert c['parallelism'] == 'dp2' and c['batch_per_gpu'] == 4 and c['global_batch'] == 8 and c['hidden_size'] == 32
+    # whole-job aggregate: clips of BOTH ranks over the max-over-ranks time
+    assert d['value'] == pytest.approx(8 * 2 / (d['ms_per_step'] * 2e-3), rel=1e-6)
+    ex = c['gradient_exchange_bytes_per_rank']
+    assert ex['A'] > 0 and ex['B'] > 0 and ex['rows'] > 0 and ex['A'] + ex['B'] + ex['rows'] < ex['dense_arena']
+    assert all(v == v and abs(v) < 1e6 for v in c['last_step_losses'].values()), c['last_step_losses']

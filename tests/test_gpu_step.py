@@ -580,6 +580,30 @@ def test_world_size_1_rccl_between_graph_segments():
 
 
 @pytest.mark.gpu
+def test_host_runs_at_most_one_step_ahead_of_the_device_in_the_data_parallel_loop():
+    """the REAL data-parallel step (world-size-1 RCCL group, four replayed graph segments with the eager
+    collectives between them) in the loop bench.py times -- train_step(sync=False), 64 steps, no read-back.  The only thing
+    that holds the host back there is GradExchange.exchange_rest waiting for the id count it sent ahead at the start of the
+    SAME step (parallel.py): when train_step(k) returns, step k - 1 must have finished on the device -- the host is never
+    more than one step ahead, so the overflow branch is always taken with this step's count, on every rank.  Ends with one
+    synchronous step: finite losses, no dense fall-back, no lost GRU peer."""
+    import json
+    import math
+    import subprocess
+    import sys
+    env = dict(os.environ, S2AG_FORCE_DIST='1', S2AG_PROBE_RUNAHEAD='64', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(29450 + os.getpid() % 200), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 's2ag_dist_probe.py')],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    p = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('PROBE ')][-1][6:])
+    ra = p['runahead']
+    assert p['dist'] and p['active'] and p['timeouts'] == 0 and ra['steps'] == 64
+    assert ra['max_unfinished_earlier_steps'] <= 1, ra
+    assert ra['dense_fallbacks'] == 0 and all(math.isfinite(v) for v in ra['last'].values()), ra
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('hip_graph', [False, True])
 def test_synthesis_after_training_steps_uses_the_current_weights(golden_dir, hip_graph):
     """synthesize_clip in a process that has trained: (1) the generator's per-step encoder sharing (keyed on buffer
