@@ -686,3 +686,27 @@ def test_generator_loss_branch_is_chosen_from_the_config_or_refused():
         Processor.regulariser_branch(cfg('random', 0.05))
     with pytest.raises(ValueError, match='z_type must be'):
         Processor.regulariser_branch(cfg('speakers', 0.05))
+
+
+def test_isa_identity_evidence_is_for_the_current_kernel_sources():
+    """the default kernels at HEAD are the binaries of the last GPU-run build, and the tracked evidence of
+    that (profiles/r05_isa_diff_since_298c878.txt: every kernel of every csrc/*.hip, old tree vs this tree -- opcode mix,
+    registers, LDS, scratch AND the instruction stream) must have been made from THESE sources: its first line carries the
+    digest of csrc/*.hip, csrc/*.h and include/s2ag_hip.h (tools/csrc_digest.py).  Editing a kernel file without regenerating
+    the file (tools/isa_diff_since.sh 298c878, ~2 min, no GPU) fails here.  The one allowed difference is the wave head's
+    backward for the bf16 path (a missing barrier between a shared-memory write and its first read, fixed in r03 after the
+    last GPU run); instantiations that did not exist then (the one-piece bf16 step mode) are listed as `new`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('csrc_digest', os.path.join(ROOT, 'tools', 'csrc_digest.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = open(os.path.join(ROOT, 'profiles', 'r05_isa_diff_since_298c878.txt')).read()
+    first = text.splitlines()[0]
+    assert first.startswith('# csrc digest ') and first.split()[3] == mod.digest(), \
+        ('profiles/r05_isa_diff_since_298c878.txt is stale: run tools/isa_diff_since.sh 298c878 > that file', first, mod.digest())
+    differs = [ln for ln in text.splitlines() if ln.startswith(('DIFFERS', 'MISSING'))]
+    assert len(differs) <= 1 and all('wv12_bwd_kILi1E' in ln for ln in differs), differs
+    assert sum(ln.startswith('same') for ln in text.splitlines()) >= 200
+    files = {ln[3:].strip() for ln in text.splitlines() if ln.startswith('== ')}
+    have = {os.path.basename(f)[:-4] for f in __import__('glob').glob(os.path.join(ROOT, 'speech2affective_gestures_amd', 'csrc', '*.hip'))}
+    assert files == have, files ^ have

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Compare two device assembly files (hipcc -S --cuda-device-only) kernel by kernel: opcode histogram, registers, LDS, scratch.
+"""Compare two device assembly files (hipcc -S --cuda-device-only) kernel by kernel: opcode histogram, registers, LDS, scratch
+and (r05) the instruction stream itself, operands included (`same` = all of them equal).
 
 Used when a kernel template gains a parameter: the existing instantiations must come out of the compiler unchanged (same
 opcode mix and resources) -- a check that needs no GPU.   tools/isa_diff.py base.s new.s [--ignore-suffix Lb0E]"""
 import collections
+import hashlib
 import re
 import sys
 
@@ -14,16 +16,19 @@ def kernels(path):
     for m in re.finditer(r'^(_Z\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel', txt, re.S | re.M):
         name, body = m.group(1), m.group(2)
         ops = collections.Counter()
+        seq = hashlib.sha256()          # the instruction STREAM (operands included; labels / symbol names normalised)
         for line in body.split('\n'):
             line = line.split(';')[0].strip()
             if not line or line.startswith('.') or line.endswith(':'):
                 continue
             ops[line.split()[0]] += 1
+            seq.update(re.sub(r'_Z\w+', 'SYM', re.sub(r'\.L\w+', 'LBL', line)).encode() + b'\n')
         res = {}
         for key in ('next_free_vgpr', 'next_free_sgpr', 'group_segment_fixed_size', 'private_segment_fixed_size', 'accum_offset'):
             mm = re.search(r'\.amdhsa_' + key + r'\s+(\d+)', body)
             if mm:
                 res[key] = int(mm.group(1))
+        res['stream'] = seq.hexdigest()[:16]
         out[name] = (ops, res)
     return out
 
