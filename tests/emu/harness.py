@@ -95,6 +95,8 @@ DESELECT = {
 def deselected(nodeid: str):
     if nodeid.endswith('strictly[4]') or nodeid.endswith('branch_decisions[5]'):     # the small-size twins of full-size tests
         return None
+    if 'test_gpu_fullsize.py' in nodeid and os.environ.get('S2AG_EMU_FULLSIZE', '0') == '1':
+        return None                      # tools/run_emu_fullsize.sh: one pass at the bench's own sizes, hours, in the background
     for key, why in DESELECT.items():
         if key in nodeid:
             return why
