@@ -10,6 +10,8 @@ export S2AG_EMU=1 S2AG_EMU_FULLSIZE=1
 for t in "tests/test_gpu_fullsize.py::test_conv1d_roofline_run_gradients_match_the_oracle_strictly[256]" \
          "tests/test_gpu_fullsize.py::test_full_size_step_matches_the_oracle[step]"; do
   echo "=== $t  (started $(date -u +%H:%M:%S))"
-  /usr/bin/time -f "wall %e s, peak RSS %M KB" timeout ${BUDGET:-14000} python -m pytest "$t" -m gpu -q -s -p no:cacheprovider 2>&1 | grep -v "Warning\|WeightNorm\|^$" | tail -25
+  t0=$SECONDS
+  timeout ${BUDGET:-14000} python -m pytest "$t" -m gpu -q -s -p no:cacheprovider 2>&1 | grep -v "Warning\|WeightNorm\|^$" | tail -25
+  echo "    wall $((SECONDS - t0)) s"
 done
 echo "=== done $(date -u +%H:%M:%S)"
