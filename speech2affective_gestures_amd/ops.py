@@ -1884,7 +1884,7 @@ def det_flavour() -> bool:
 def set_deterministic(on: bool, device=None) -> None:
     """Deterministic mode (config switch DETERMINISTIC; debug; needs the det build flavour): the library orders every
     accumulating launch's atomics by workgroup index (s2ag_set_deterministic: csrc/s2ag_common.h det_enter / det_leave /
-    det_wave_ordered) and weight-gradient kernels stay on the stream of their backward pass.  The trainer additionally runs
+    S2AG_DET_WAVES_BEGIN..END) and weight-gradient kernels stay on the stream of their backward pass.  The trainer additionally runs
     the passes of a step on ONE stream (Processor(..., deterministic=True)): two runs from the same state then give
     bit-identical gradients and weights, at the price of serialised accumulation phases.  Both precision modes.
     The mode is process-wide library state: every Processor sets it to ITS value on construction (on or off), and while it
@@ -1892,10 +1892,10 @@ def set_deterministic(on: bool, device=None) -> None:
     would take each other's turns) -- run_wgrad / wgrad_launcher stay inline and mark_side_stream raises."""
     global ASYNC_WGRAD
     if not on:
-        if _DET_ON[0]:
+        if _DET_ON[0]:                     # (only what switching it ON changed is changed back)
             L.check(_lib().s2ag_set_deterministic(None, None), 'set_deterministic')
+            ASYNC_WGRAD = True
         _DET_ON[0] = False
-        ASYNC_WGRAD = True
         return
     if not det_flavour():
         raise RuntimeError('deterministic mode is a build flavour of the library: build it with `python -m '
