@@ -116,7 +116,13 @@ static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t stream) {
 static __device__ int* g_det_turn = nullptr;             // one copy per translation unit, installed by s2ag_det_hook_<file>
 static __device__ unsigned* g_det_err = nullptr;         // sticky error word the trainer reads every step (bit 3: a turn never came)
 constexpr unsigned DET_ERR_BIT = 8u;
-constexpr int DET_SPIN_LIMIT = 1 << 28;                  // polls of >= 64 cycles each: seconds, far beyond any launch
+// polls of >= 64 cycles each.  The longest legitimate wait is the LAST workgroup's: the serialised accumulation phases of a
+// whole launch, milliseconds at most; 2^22 polls (~0.2 s) is far beyond that and keeps a broken ordering assumption from
+// costing more than a fraction of a second per launch -- and once the error bit is up nobody waits at all any more.
+#ifndef S2AG_DET_SPIN_LIMIT
+#define S2AG_DET_SPIN_LIMIT (1 << 22)
+#endif
+constexpr int DET_SPIN_LIMIT = S2AG_DET_SPIN_LIMIT;
 
 __device__ __forceinline__ void det_enter() {            // workgroup-uniform call
     int* w = g_det_turn;
@@ -124,7 +130,8 @@ __device__ __forceinline__ void det_enter() {            // workgroup-uniform ca
     if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
         const int me = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
         int spins = 0;
-        while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != me) {
+        const bool failed = g_det_err && (__hip_atomic_load(g_det_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & DET_ERR_BIT);
+        while (!failed && __hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != me) {
             __builtin_amdgcn_s_sleep(2);
             if (++spins > DET_SPIN_LIMIT) {              // give up: the sums of this launch are no longer ordered
                 if (g_det_err) atomicOr(g_det_err, DET_ERR_BIT);

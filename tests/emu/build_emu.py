@@ -28,6 +28,7 @@ FLAGS = ['-x', 'c++', '-std=c++17', '-O1', '-g1', '-fPIC', '-fno-strict-aliasing
          '-Wno-unknown-attributes', '-Wno-ignored-attributes', '-Wno-unused-value', '-Wno-pass-failed',
          '-Wno-unknown-pragmas', '-Wno-deprecated-declarations',
          '-DS2AG_DET=1',      # the model's library always carries the deterministic mode (the GPU build: flavour `det` only)
+         '-DS2AG_DET_SPIN_LIMIT=(1<<30)',    # a poll of the model is a host-thread yield, not ~100 device cycles
          '-I' + HERE, '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(OUT, 'src')] + (['-DS2AG_DEBUG=1'] if DEBUG else [])
 
 _DYN = re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w ]*?)\s+(\w+)\[\];')
