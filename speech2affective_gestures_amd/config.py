@@ -46,7 +46,7 @@ _S = [
            "instead of data.BatchFeeder", 'tests/test_gpu_step.py::test_prefetching_batch_feeder_matches_the_host_path'),
     Switch('DETERMINISTIC', False, _flag, "debug, needs the det build flavour (S2AG_HIP_LIB=.../libs2ag_hip_det.so): passes of a step on one "
            "stream, accumulating launches ordered by workgroup index: two runs from the same state are bit-identical",
-           'tests/test_gpu_det_flavour.py::test_deterministic_mode_two_runs_are_bit_identical'),
+           'tests/test_gpu_zz_det_flavour.py::test_deterministic_mode_two_runs_are_bit_identical'),
     # ---- fused paths with a layer-by-layer fall-back that parity tests compare against ------------------------------------
     Switch('WAVE12', True, _flag, "0: the wave encoder's head (conv1 + BatchNorm + LeakyReLU + conv2) layer by layer instead "
            "of csrc/wave12.hip", 'tests/test_gpu_wave12.py'),

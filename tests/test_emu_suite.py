@@ -58,7 +58,7 @@ GROUPS = {
     'cooperative GRU: tagged-cell exchange between workgroups, three product modes (csrc/gru_coop.hip)':
         (['tests/test_gpu_ops.py'], 'test_gru_forward_backward and (9-6 or 17-1 or 33-2 or 16-3 or 5-7 or 3-5)', 6, 0),
     'deterministic mode: two GAN steps, two wavefront schedules, every weight / gradient / statistic bit-identical':
-        (['tests/test_gpu_det_flavour.py'], 'deterministic_mode and 32-6', 1, 0),
+        (['tests/test_gpu_zz_det_flavour.py'], 'deterministic_mode and 32-6', 1, 0),
     'one whole GAN step strictly: branch decisions of all seven module passes replayed in the oracle (H = 300)':
         (['tests/test_gpu_step.py'], 'one_step_strictly and 300-6', 1, 0),
     'strict parity of both discriminators with the product\'s branch decisions (small batch)':

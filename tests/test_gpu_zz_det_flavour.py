@@ -3,7 +3,10 @@ det_enter / det_leave / S2AG_DET_WAVES_BEGIN..END), not a run-time word in the r
 word it had changed 39 default binaries).  The tests below need that flavour: in a process that loaded the release library they
 skip, and `test_det_flavour_tests_in_a_process_of_their_own` runs this file again in a child process with S2AG_HIP_LIB pointing
 at the det library.  On the CPU device model (tests/emu, always compiled with the mode available) they run in place.
-The REPLAYED form (captured graphs) needs a real device and has not run on one yet."""
+The REPLAYED form (captured graphs) needs a real device and has not run on one yet.
+The file name sorts LAST among the GPU tests on purpose: this is a debug flavour outside the hot path whose tests have never
+seen hardware (GPU access closed since they were written) -- under `pytest -x` a surprise here must not cost the parity
+suite's run."""
 import copy
 import os
 import subprocess
@@ -34,7 +37,7 @@ def test_det_flavour_tests_in_a_process_of_their_own():
     assert os.path.exists(lib), f'{lib} missing: __graft_entry__.build() / build.py --det make it'
     env = dict(os.environ, S2AG_HIP_LIB=lib)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k',
-                        'not process_of_their_own', '-p', 'no:cacheprovider'], cwd=ROOT, env=env, capture_output=True,
+                        'not process_of_their_own and not release_library', '-p', 'no:cacheprovider'], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=1500)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
