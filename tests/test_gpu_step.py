@@ -107,9 +107,13 @@ def test_three_steps_match_the_reference_trace(golden_dir, monkeypatch, variant)
             for k in g:
                 if k.startswith('s0.grad.G.'):
                     assert grad_err(named[k[10:]].grad, g[k], k) < 5 * TOL, k
+        # per-module sums of |w|: 2e-5 (the default trace has met that on hardware since r01; the branches added in r05 have only
+        # seen the device model: 2e-5 after the first step, 1e-4 later -- a handful of Adam sign flips of rounding-level gradient
+        # elements, 2 lr each, is what separates the two, see _final_close)
+        tol_abs = 2e-5 if (variant == 'speaker' or s == 0) else 1e-4
         for tag, mod in (('G', pr.s2ag_generator), ('D', pr.s2ag_discriminator)):
             for top, val in _abs_groups(mod.state_dict()).items():
-                assert val == pytest.approx(float(g[f's{s}.abs.{tag}.{top}']), rel=2e-5), (s, tag, top)
+                assert val == pytest.approx(float(g[f's{s}.abs.{tag}.{top}']), rel=tol_abs), (s, tag, top)
     sdG, sdD = pr.s2ag_generator.state_dict(), pr.s2ag_discriminator.state_dict()
     # weights after three Adam steps (see _final_close)
     for k in g:

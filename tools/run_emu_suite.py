@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE driver: the whole `-m gpu` suite on the CPU device model (tests/emu), file by file.
 
-    python tools/run_emu_suite.py [--budget SECONDS_PER_TEST] [--sched N] [files...]  ->  profiles/r04_emu_suite.txt
+    python tools/run_emu_suite.py [--budget SECONDS_PER_TEST] [--sched N] [files...]  >  profiles/r05_emu_suite.txt
 
 A test that exceeds the budget kills its pytest process (a C call cannot be interrupted); it is recorded as `too slow for
 the model` and the file is re-run without it.  Tests listed in tests/emu/harness.py DESELECT never start (hipGraph capture,
