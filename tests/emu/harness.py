@@ -88,7 +88,7 @@ DESELECT = {
     'test_no_cpu_fallback': 'same',
     'batch_feeder': 'data.BatchFeeder: pinned host memory + a copy stream of the real runtime (no kernels of ours)',
     'epoch_loops_over_a_host_dataset': 'runs through data.BatchFeeder',
-    'test_gpu_fullsize.py': 'full-size batches (B = 128 / 256, H = 300): hours on the model; their kernels run here at small sizes',
+    'test_gpu_fullsize.py': 'full-size batches (B = 128 / 256, H = 300): 2.5 .. 10 min per single-step test, more than an hour for the multi-step / replayed ones; S2AG_EMU_FULLSIZE=1 (tools/run_emu_fullsize.sh) runs one step of each size',
 }
 
 
