@@ -129,7 +129,11 @@ class StepSignTap:
 
         def add_act(a, b, slope):
             y = o_add(a, b, slope)
-            if slope != 1.0:
+            if slope == 0.0:                 # a TemporalBlock's ReLU(out + x), layer by layer (autograd passes only)
+                if y.requires_grad:
+                    k = self._pass()
+                    self._child(by_pass(k), k).tcn_adds.append(y.detach())
+            elif slope != 1.0:
                 k = self._pass()
                 self._child(by_pass(k), k).adds.append(y.detach())
             return y
@@ -162,6 +166,22 @@ class StepSignTap:
                 c.heads.clear()
             return z2
 
+        # the layer-by-layer TemporalConvNet (T beyond the clip-resident kernels, e.g. configs[4]'s 136 frames): conv epilogues
+        # by their dropout site id, ReLU(out + x) through add_act (slope 0) -- like the fused form, autograd passes only
+        site_owner = {}
+        for tag, m in self.mods.items():
+            for sid in tcn_site_names(m, 'text_encoder.'):
+                site_owner[sid] = tag
+        self._o_conv = o_conv = ops.conv1d_nlc
+
+        def conv1d_nlc(*a, **kw):
+            y = o_conv(*a, **kw)
+            sid = kw.get('site')
+            if sid in site_owner and kw.get('slope', 1.0) == 0.0 and y.requires_grad:
+                c = self._child(site_owner[sid], self._pass())
+                c.tcn_conv.append((c.tcn_sites[sid], y.detach()))
+            return y
+        ops.conv1d_nlc = conv1d_nlc
         ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32 = bn_act, add_act, linear, tcn
         self.w12.head_f32 = head
         return self
@@ -169,6 +189,7 @@ class StepSignTap:
     def __exit__(self, *a):
         ops = self.ops
         ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32, self.w12.head_f32 = self._orig
+        ops.conv1d_nlc = self._o_conv
 
     def signs_per_pass(self):
         """{pass name: {site: bool tensor}} for oracle.gan_step(signs=...)."""
@@ -259,11 +280,23 @@ class SignTap:
         self.names = {id(m): n for n, m in module.named_modules()}
         self.params = {id(p): n for n, p in module.named_parameters()}
         self.bn, self.adds, self.lin, self.tcn, self.heads = [], [], [], [], []
+        # the layer-by-layer TemporalConvNet (clips longer than the clip-resident kernels take, e.g. T = 136): its ReLU sites
+        # are conv epilogues (identified by their dropout site id) and the residual add + ReLU of every block
+        self.tcn_sites = tcn_site_names(module, tcn_prefix)
+        self.tcn_conv, self.tcn_adds = [], []
 
     def __enter__(self):
         ops = self.ops
         self._orig = (ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32)
         o_bn, o_add, o_lin, o_tcn = self._orig
+        self._o_conv = o_conv = ops.conv1d_nlc
+
+        def conv1d_nlc(*a, **k):
+            y = o_conv(*a, **k)
+            if k.get('site') in self.tcn_sites and k.get('slope', 1.0) == 0.0:
+                self.tcn_conv.append((self.tcn_sites[k['site']], y.detach()))
+            return y
+        ops.conv1d_nlc = conv1d_nlc
 
         def bn_act(x, bn, slope=1.0, chan_map=None, training=None):
             y = o_bn(x, bn, slope=slope, chan_map=chan_map, training=training)
@@ -273,7 +306,9 @@ class SignTap:
 
         def add_act(a, b, slope):
             y = o_add(a, b, slope)
-            if slope != 1.0:
+            if slope == 0.0:                 # ReLU(out + x) of a TemporalBlock run layer by layer, in block order
+                self.tcn_adds.append(y.detach())
+            elif slope != 1.0:
                 self.adds.append(y.detach())
             return y
 
@@ -304,6 +339,7 @@ class SignTap:
     def __exit__(self, *a):
         ops = self.ops
         ops.batch_norm_act, ops.add_act, ops.linear, ops.tcn_fused32 = self._orig
+        ops.conv1d_nlc = self._o_conv
         self._w12.head_f32 = self._o_head
 
     def signs(self):
@@ -341,4 +377,18 @@ class SignTap:
                 tens = [saved[3 * b], saved[3 * b + 1], saved[3 * b + 2] if b < nb - 1 else y_last[:B * T]]
                 for j, t in enumerate(tens):
                     out[f'{prefix}tcn.{b}.relu{j + 1}'] = (t.view(B, T, Cch) > 0).permute(0, 2, 1).cpu()
+        for name, y in self.tcn_conv:                                     # layer-by-layer TemporalConvNet
+            out[name] = (y > 0).permute(0, 2, 1).cpu()
+        for b, y in enumerate(self.tcn_adds):
+            out[f'{self.tcn_prefix}tcn.{b}.relu3'] = (y > 0).permute(0, 2, 1).cpu()
         return out
+
+
+def tcn_site_names(module, prefix):
+    """{dropout site id of a TemporalBlock's conv: the oracle's name of the ReLU behind it} for every block under ``module``."""
+    out = {}
+    for name, m in module.named_modules():
+        if hasattr(m, 'sites') and hasattr(m, 'dilation') and '.network.' in '.' + name:
+            b = int(name.rsplit('.', 1)[1])
+            out[int(m.sites[0])], out[int(m.sites[1])] = f'{prefix}tcn.{b}.relu1', f'{prefix}tcn.{b}.relu2'
+    return out

@@ -208,7 +208,7 @@ def test_two_steps_with_dropout_match_the_oracle(monkeypatch):
     assert int(pr.s2ag_generator.state_dict()['aff_encoder.batch_norm1.num_batches_tracked']) == 6
 
 
-@pytest.mark.parametrize('hidden,B', [(300, 6), (300, 33)])       # (H = 300: the clip-resident TCN SignTap reads)
+@pytest.mark.parametrize('hidden,B', [(300, 6), (300, 33), (32, 6)])       # (H = 300: the clip-resident TCN; H = 32: the TCN layer by layer, as at T = 136)
 def test_one_step_strictly_with_the_products_branch_decisions(monkeypatch, hidden, B):
     """ONE GAN step against the oracle with the branch decisions of ALL SEVEN module passes replayed (StepSignTap files every
     ReLU / LeakyReLU output of the product under (module, pass) through the pass counter of its noise scope;
