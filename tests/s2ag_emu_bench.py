@@ -15,5 +15,21 @@ sys.path.insert(0, os.path.join(HERE, 'emu'))
 import harness  # noqa: E402
 
 harness.install()
-sys.argv = [os.path.join(ROOT, 'bench.py')] + sys.argv[1:]
-runpy.run_path(sys.argv[0], run_name='__main__')
+if '--stub-heavy-extras' in sys.argv:
+    # the single-process line WITH its extras (alt_modes, value_fp32_equivalent, cpu_baseline, long_context_run ...): the parts
+    # that run full-width kernels for minutes on the model are replaced by stubs, everything that assembles the line is real
+    sys.argv.remove('--stub-heavy-extras')
+    import bench
+    bench.conv1d_roofline_run = lambda *a, **k: {'stub': True}
+    bench.gen_forward_ms = lambda *a, **k: {'stub': True}
+    bench.epoch_loop_rate = lambda *a, **k: 1.0
+    bench.dp_structure_run = lambda *a, **k: {'stub': True}
+    _alt, _ts = bench.alt_modes, bench.timed_steps
+    bench.alt_modes = lambda pr, dp, batch, B, steps=1: _alt(pr, dp, batch, B, steps=1)
+    bench.timed_steps = lambda pr, dp, batch, steps, warmup, sync: _ts(pr, dp, batch, min(steps, 1), min(warmup, 1), sync)
+    bench.CONFIGS['long']['batch'] = 2
+    sys.argv = [os.path.join(ROOT, 'bench.py')] + sys.argv[1:]
+    bench.main()
+else:
+    sys.argv = [os.path.join(ROOT, 'bench.py')] + sys.argv[1:]
+    runpy.run_path(sys.argv[0], run_name='__main__')

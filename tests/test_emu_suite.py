@@ -110,3 +110,25 @@ def test_bench_launch_path_with_two_ranks(emu_lib):
     ex = c['gradient_exchange_bytes_per_rank']
     assert ex['A'] > 0 and ex['B'] > 0 and ex['rows'] > 0 and ex['A'] + ex['B'] + ex['rows'] < ex['dense_arena']
     assert all(v == v and abs(v) < 1e6 for v in c['last_step_losses'].values()), c['last_step_losses']
+
+
+def test_bench_line_with_its_extras_assembles(emu_lib):
+    """bench.py's default single-GPU line carries more than the two-rank dry run exercises: `alt_modes` and the top-level
+    `value_fp32_equivalent` taken from it (r05), `cpu_baseline` + `gpu_over_cpu`, `long_context_run` on a second processor.
+    None of that code can run without a device; here it runs on the model at a reduced width with the full-width sub-benches
+    stubbed (tests/s2ag_emu_bench.py --stub-heavy-extras) -- a typo in the assembly would otherwise first show in the
+    driver's BENCH run."""
+    import json
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    env.pop('S2AG_HIP_LIB', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'tests', 's2ag_emu_bench.py'), '--stub-heavy-extras', '--steps', '1', '--warmup', '1',
+           '--batch', '4', '--dry-width', '32,64,12']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert set(d['alt_modes']) >= {'fp32_equivalent_3_bf16_pieces', 'f32_mfma_everywhere', 'bf16_conv_path', 'bf16_step'}
+    assert d['value_fp32_equivalent'] == d['alt_modes']['fp32_equivalent_3_bf16_pieces']['clips_per_s']
+    assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['cores'] >= 1
+    assert '5 timed GAN steps' in d['cpu_baseline']['sample']
+    assert d['gpu_over_cpu'] == pytest.approx(d['value'] / d['cpu_baseline']['value'])
+    assert d['long_context_run']['frames'] == 136 and d['long_context_run']['clips_per_s'] > 0
