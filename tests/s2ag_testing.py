@@ -251,13 +251,13 @@ def grad_err(a, b, key=''):
 REPLAY_LIMITS = (8, 5e-6, 5e-5)
 
 
-def adam_close(v, ref, lr, steps):
+def adam_close(v, ref, lr, steps, frac=5e-3):
     """Weights after a few Adam steps.  Adam turns a gradient element g into a step lr*m/sqrt(v), i.e. ~lr*sign(g)
     early on, so elements whose true gradient is at rounding-noise level may legitimately differ by a fraction of
     lr per step.  Require: almost every element within 0.1*lr, and none beyond what sign flips can produce."""
     d = (torch.as_tensor(v).detach().cpu().double() - torch.as_tensor(ref).detach().cpu().double()).abs()
     frac_off = float((d > 0.1 * lr).double().mean())
-    return frac_off < 5e-3 and float(d.max()) <= 2.05 * lr * steps, (frac_off, float(d.max()))
+    return frac_off < frac and float(d.max()) <= 2.05 * lr * steps, (frac_off, float(d.max()))
 
 
 class SignTap:
