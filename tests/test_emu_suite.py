@@ -122,7 +122,7 @@ def test_bench_line_with_its_extras_assembles(emu_lib):
     env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     env.pop('S2AG_HIP_LIB', None)
     cmd = [sys.executable, os.path.join(ROOT, 'tests', 's2ag_emu_bench.py'), '--stub-heavy-extras', '--steps', '1', '--warmup', '1',
-           '--batch', '4', '--dry-width', '32,64,12']
+           '--batch', '4', '--dry-width', '32,64,12', '--no-graph']       # (eager steps: no capture warm-ups on the model)
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1])
@@ -131,4 +131,4 @@ def test_bench_line_with_its_extras_assembles(emu_lib):
     assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['cores'] >= 1
     assert '5 timed GAN steps' in d['cpu_baseline']['sample']
     assert d['gpu_over_cpu'] == pytest.approx(d['value'] / d['cpu_baseline']['value'])
-    assert d['long_context_run']['frames'] == 136 and d['long_context_run']['clips_per_s'] > 0
+    assert d['long_context_run']['clips_per_s'] > 0 and d['long_context_run']['steps'] == 10
