@@ -66,7 +66,7 @@ def _abs_groups(sd):
 # the branches of the step the configuration selects (processor_v2.py:793, :899-934, :936), each with a trace recorded from
 # the reference's own forward_pass_s2ag (tests/golden/gen_golden.py STEP_VARIANTS)
 STEP_VARIANTS = {'speaker': ({}, 'step_small.npz'), 'znone': ({'z_type': 'none'}, 'step_small_znone.npz'),
-                 'noreg': ({'loss_reg_weight': 0.0}, 'step_small_noreg.npz'),
+                 'noreg': ({'loss_reg_weight': 0.0}, 'step_small_znone.npz'),
                  'warmup': ({'loss_warmup': 5}, 'step_small_warmup.npz')}
 
 

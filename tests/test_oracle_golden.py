@@ -123,7 +123,7 @@ def test_gru_fast_equals_cellwise():
 _STEP_VARIANTS = {
     'speaker': ('step_small.npz', {}, ('g_dis', 'pgt', 'g_main', 'g_rand')),
     'znone': ('step_small_znone.npz', {'z_type': 'none'}, ('g_dis', 'pgt', 'g_main')),
-    'noreg': ('step_small_noreg.npz', {'loss_reg_weight': 0.0}, ('g_dis', 'pgt', 'g_main')),
+    'noreg': ('step_small_znone.npz', {'loss_reg_weight': 0.0}, ('g_dis', 'pgt', 'g_main')),
     'warmup': ('step_small_warmup.npz', {'loss_warmup': 5}, ('pgt', 'g_main', 'g_rand')),
 }
 
