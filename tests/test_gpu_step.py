@@ -116,11 +116,14 @@ def test_three_steps_match_the_reference_trace(golden_dir, monkeypatch, variant)
                 assert val == pytest.approx(float(g[f's{s}.abs.{tag}.{top}']), rel=tol_abs), (s, tag, top)
     sdG, sdD = pr.s2ag_generator.state_dict(), pr.s2ag_discriminator.state_dict()
     # weights after three Adam steps (see _final_close)
+    # the default trace keeps the bar it has met on hardware since r01 (rel < TOL); only the r05 branches get _final_close
+    def close(v, ref, lr):
+        return rel(v, ref) < TOL if variant == 'speaker' else _final_close(v, ref, lr, 3)
     for k in g:
         if k.startswith('final.G.'):
-            assert _final_close(sdG[k[8:]], g[k], 5e-4, 3), (k, rel(sdG[k[8:]], g[k]))
+            assert close(sdG[k[8:]], g[k], 5e-4), (k, rel(sdG[k[8:]], g[k]))
         if k.startswith('final.D.'):
-            assert _final_close(sdD[k[8:]], g[k], 1e-4, 3), (k, rel(sdD[k[8:]], g[k]))
+            assert close(sdD[k[8:]], g[k], 1e-4), (k, rel(sdD[k[8:]], g[k]))
 
 
 def _final_close(v, ref, lr, steps):
