@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define S2AG_ABI_VERSION 1
+/* Bumped whenever a signature, a struct layout or the meaning of an argument changes (2, r06: s2ag_set_deterministic takes
+ * two arguments, BF16Tcn / Tcn32 lost their emb_* fields, s2ag_wave12_bwd's dz_f32 == 2 mode is gone, s2ag_set_split_pieces
+ * returns the override, s2ag_gen_loss takes out_rand == NULL).  _lib.py refuses a library of another version. */
+#define S2AG_ABI_VERSION 2
 
 #define S2AG_E_BADARG (-1)
 #define S2AG_E_UNSUPPORTED (-2)
@@ -771,9 +774,12 @@ int s2ag_dis_loss(const float* d_real, const float* d_fake, int B, float* loss /
 /* Generator losses of processor_v2.py:893-937 (+ the L1 metric of :956) fused in two launches.
  *  comps[8] = {total, huber, gen_error, div_reg, kld, l1(out,target), l1(out_tri,target), 0}
  *  weights  = {loss_regression_weight, loss_gan_weight (0 during warm-up), loss_reg_weight, loss_kld_weight}
- *  gradients of `total`: g_out (B,TP), g_dis (B), g_mu (B,16), g_logvar (B,16).  scratch: B*8 floats. */
+ *  gradients of `total`: g_out (B,TP), g_dis (B), g_mu (B,16), g_logvar (B,16).  scratch: B*8 floats.
+ *  out_rand == NULL selects the branch without the regulariser (processor_v2.py:933-934: z_type 'none' or loss_reg_weight
+ *  0): the divergence and KLD terms are not evaluated (comps[3] = comps[4] = 0, exp(log_var) is never formed, as upstream),
+ *  z / z_rand / mu / log_var / g_mu / g_logvar are not touched and may be NULL, weights[2:4] are ignored. */
 int s2ag_gen_loss(const float* out, const float* target, const float* out_tri /*nullable*/, const float* dis_out,
-                  const float* out_rand, const float* z, const float* z_rand, const float* mu, const float* log_var,
+                  const float* out_rand /*nullable*/, const float* z, const float* z_rand, const float* mu, const float* log_var,
                   int B, int TP, int ZD, const float* weights /*host[4]*/, float* scratch, float* comps,
                   float* g_out, float* g_dis, float* g_mu, float* g_logvar, void* stream);
 

@@ -265,8 +265,9 @@ def load():
         fn.restype = cll if name in ('s2ag_gru_coop_workspace_bytes', 's2ag_gru_coop_fwd_multi_workspace_bytes', 's2ag_bf16_tcn_pack_elems', 's2ag_bf16_tcn_sign_bytes', 's2ag_bf16_tcn_keep_bytes',
                               's2ag_bf16_conv_wgrad_scratch_floats', 's2ag_bf16_conv_wgrad_tr_scratch_floats',
                               's2ag_f32_wgrad_tr_scratch_floats', 's2ag_f32_wgrad_tr_scratch_floats_n', 's2ag_tcn32_pack_elems', 's2ag_tcn32_keep_bytes') else ci
-    if lib.s2ag_abi_version() != 1:
-        raise S2AGLibraryError('ABI version mismatch between _lib.py and libs2ag_hip.so')
+    if lib.s2ag_abi_version() != ABI_VERSION:
+        raise S2AGLibraryError(f'ABI version mismatch: _lib.py binds version {ABI_VERSION} of include/s2ag_hip.h, {path} is '
+                               f'version {lib.s2ag_abi_version()}; rebuild it')
     if config.get('CRASH_TRACE'):     # native back trace on SIGSEGV & co (csrc/debug.hip)
         lib.s2ag_install_crash_handler(2)
     config.push_to_library(lib)        # the library never reads the environment: options come from the registry
@@ -274,6 +275,7 @@ def load():
     return lib
 
 
+ABI_VERSION = 2             # S2AG_ABI_VERSION (include/s2ag_hip.h); bump both with every signature / struct change
 E_UNSUPPORTED = -2          # S2AG_E_UNSUPPORTED (include/s2ag_hip.h)
 
 

@@ -304,22 +304,25 @@ __global__ __launch_bounds__(256) void gen_loss_partial_k(const float* out, cons
     const int b = blockIdx.x;
     const float* o = out + (long long)b * TP;
     const float* t = target + (long long)b * TP;
-    const float* rr = out_rand + (long long)b * TP;
+    // out_rand == nullptr: the branch without the regulariser (processor_v2.py:933-934) -- the divergence and KLD terms are
+    // not evaluated at all (the reference never forms exp(z_log_var) there), z / z_rand / mu / lv are not read
+    const float* rr = out_rand ? out_rand + (long long)b * TP : nullptr;
     const float* tri = out_tri ? out_tri + (long long)b * TP : nullptr;
     float hub = 0.f, pl1 = 0.f, l1 = 0.f, l1t = 0.f;
     for (int i = threadIdx.x; i < TP; i += blockDim.x) {
         const float ov = o[i], tv = t[i];
         hub += smooth_l1((ov - tv) * 10.f);
-        pl1 += smooth_l1((ov - rr[i]) * 20.f) * 0.05f;
+        if (rr) pl1 += smooth_l1((ov - rr[i]) * 20.f) * 0.05f;
         l1 += fabsf(ov - tv);
         if (tri) l1t += fabsf(tri[i] - tv);
     }
     float zl = 0.f, kl = 0.f;
-    for (int i = threadIdx.x; i < ZD; i += blockDim.x) {
-        zl += fabsf(z[b * ZD + i] - z_rand[b * ZD + i]);
-        const float m = mu[b * ZD + i], l = lv[b * ZD + i];
-        kl += 1.f + l - m * m - expf(l);
-    }
+    if (rr)
+        for (int i = threadIdx.x; i < ZD; i += blockDim.x) {
+            zl += fabsf(z[b * ZD + i] - z_rand[b * ZD + i]);
+            const float m = mu[b * ZD + i], l = lv[b * ZD + i];
+            kl += 1.f + l - m * m - expf(l);
+        }
     hub = block_sum(hub, sm);
     pl1 = block_sum(pl1, sm);
     l1 = block_sum(l1, sm);
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(256) void gen_loss_partial_k(const float* out, cons
     if (threadIdx.x == 0) {
         float* s = scratch + (long long)b * 8;
         const float zmean = zl / (float)ZD;
-        float div = -(pl1 / (zmean + 1.0e-5f));
+        float div = rr ? -(pl1 / (zmean + 1.0e-5f)) : 0.f;
         s[0] = hub;
         s[1] = pl1;
         s[2] = zmean;
@@ -386,20 +389,21 @@ __global__ __launch_bounds__(256) void gen_loss_grad_k(const float* out, const f
     const float* s = scratch + (long long)b * 8;
     const float n = (float)B * (float)TP;
     // d div_b / d out = -(1/(zmean+1e-5)) * clamp((out-rand)/0.05, -1, 1), unless clamped at -1000
-    const float dcoef = (s[3] >= -1000.f) ? -(w_div / (float)B) / (s[2] + 1.0e-5f) : 0.f;
+    const float dcoef = (out_rand && s[3] >= -1000.f) ? -(w_div / (float)B) / (s[2] + 1.0e-5f) : 0.f;
     for (int i = threadIdx.x; i < TP; i += blockDim.x) {
         const long long k = (long long)b * TP + i;
         const float ov = out[k];
         const float h = fminf(fmaxf((ov - target[k]) * 10.f, -1.f), 1.f);
-        const float d = fminf(fmaxf((ov - out_rand[k]) * 20.f, -1.f), 1.f);
+        const float d = out_rand ? fminf(fmaxf((ov - out_rand[k]) * 20.f, -1.f), 1.f) : 0.f;
         g_out[k] = w_reg * h / n + dcoef * d;
     }
-    for (int i = threadIdx.x; i < ZD; i += blockDim.x) {
-        const float m = mu[b * ZD + i], l = lv[b * ZD + i];
-        const float c = w_kld * (-0.5f) / ((float)B * (float)ZD);
-        g_mu[b * ZD + i] = c * (-2.f * m);
-        g_lv[b * ZD + i] = c * (1.f - expf(l));
-    }
+    if (out_rand)      // no regulariser: no KLD term, mu / log_var receive no gradient from the loss (g_mu / g_lv may be NULL)
+        for (int i = threadIdx.x; i < ZD; i += blockDim.x) {
+            const float m = mu[b * ZD + i], l = lv[b * ZD + i];
+            const float c = w_kld * (-0.5f) / ((float)B * (float)ZD);
+            g_mu[b * ZD + i] = c * (-2.f * m);
+            g_lv[b * ZD + i] = c * (1.f - expf(l));
+        }
     if (threadIdx.x == 0) g_dis[b] = -w_gan / ((float)B * (dis_out[b] + 1e-8f));
 }
 
@@ -765,10 +769,11 @@ extern "C" int s2ag_gen_loss(const float* out, const float* target, const float*
                              const float* out_rand, const float* z, const float* z_rand, const float* mu,
                              const float* log_var, int B, int TP, int ZD, const float* weights, float* scratch,
                              float* comps, float* g_out, float* g_dis, float* g_mu, float* g_logvar, void* stream) {
-    if (!out || !target || !dis_out || !out_rand || !z || !z_rand || !mu || !log_var || !weights || !scratch ||
-        !comps || !g_out || !g_dis || !g_mu || !g_logvar || B <= 0 || TP <= 0 || ZD <= 0)
+    if (!out || !target || !dis_out || !weights || !scratch || !comps || !g_out || !g_dis || B <= 0 || TP <= 0 || ZD <= 0)
         return S2AG_E_BADARG;
-    const float w_reg = weights[0], w_gan = weights[1], w_div = weights[2], w_kld = weights[3];
+    if (out_rand && (!z || !z_rand || !mu || !log_var || !g_mu || !g_logvar)) return S2AG_E_BADARG;
+    // without the regulariser the two weights the reference never reads are not read here either
+    const float w_reg = weights[0], w_gan = weights[1], w_div = out_rand ? weights[2] : 0.f, w_kld = out_rand ? weights[3] : 0.f;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gen_loss_partial_k, dim3(B), dim3(256), 0, s, out, target, out_tri, dis_out, out_rand, z, z_rand,
                        mu, log_var, TP, ZD, scratch);

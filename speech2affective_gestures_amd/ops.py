@@ -1802,37 +1802,49 @@ def dis_loss_half(d: Tensor, real: bool) -> Tensor:
 class _GenLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, out, dis_out, mu, log_var, target, out_tri, out_rand, z, z_rand, weights):
-        _need_cuda(out, dis_out, mu, log_var)
-        c = [t.contiguous() for t in (out, dis_out, mu, log_var, target, out_rand, z, z_rand)]
-        out, dis_out, mu, log_var, target, out_rand, z, z_rand = c
+        reg = out_rand is not None          # False: the branch without the regulariser (processor_v2.py:933-934)
+        if reg:
+            _need_cuda(out, dis_out, mu, log_var)
+            mu, log_var, out_rand, z, z_rand = [t.contiguous() for t in (mu, log_var, out_rand, z, z_rand)]
+        else:
+            _need_cuda(out, dis_out)
+            mu = log_var = z = z_rand = None
+        out, dis_out, target = out.contiguous(), dis_out.contiguous(), target.contiguous()
         out_tri = out_tri.contiguous() if out_tri is not None else None
         B = out.shape[0]
         TP = out.numel() // B
-        ZD = mu.numel() // B
+        ZD = mu.numel() // B if reg else 1
         dev = out.device
         scratch = torch.empty(B, 8, dtype=torch.float32, device=dev)
         comps = torch.empty(8, dtype=torch.float32, device=dev)
         g_out, g_dis = torch.empty_like(out), torch.empty_like(dis_out)
-        g_mu, g_lv = torch.empty_like(mu), torch.empty_like(log_var)
+        g_mu, g_lv = (torch.empty_like(mu), torch.empty_like(log_var)) if reg else (None, None)
         w = (C.c_float * 4)(*[float(v) for v in weights])
         L.check(_lib().s2ag_gen_loss(_p(out), _p(target), _p(out_tri), _p(dis_out), _p(out_rand), _p(z), _p(z_rand),
                                      _p(mu), _p(log_var), B, TP, ZD, w, _p(scratch), _p(comps), _p(g_out), _p(g_dis),
                                      _p(g_mu), _p(g_lv), _stream()), 'gen_loss')
-        ctx.save_for_backward(g_out, g_dis, g_mu, g_lv)
+        ctx.reg = reg
+        ctx.save_for_backward(*((g_out, g_dis, g_mu, g_lv) if reg else (g_out, g_dis)))
         ctx.mark_non_differentiable(comps)
         return comps[0].clone().view(()), comps
 
     @staticmethod
     def backward(ctx, dl, _dc):
-        g_out, g_dis, g_mu, g_lv = ctx.saved_tensors
-        if _UNIT_ROOT[0]:
-            return g_out, g_dis, g_mu, g_lv, None, None, None, None, None, None
-        return g_out * dl, g_dis * dl, g_mu * dl, g_lv * dl, None, None, None, None, None, None
+        g = list(ctx.saved_tensors) + ([] if ctx.reg else [None, None])
+        if not _UNIT_ROOT[0]:
+            g = [None if t is None else t * dl for t in g]
+        return (*g, None, None, None, None, None, None)
 
 
 def gen_loss(out, dis_out, mu, log_var, target, out_tri, out_rand, z, z_rand, weights):
     """Returns (total, comps[8]); comps = {total, huber, gen_error, div_reg, kld, l1, l1_tri, 0}.
-    weights = (regression, gan, div_reg, kld)."""
+    weights = (regression, gan, div_reg, kld).  ``out_rand=None``: the branch without the regulariser
+    (processor_v2.py:933-934) -- total = regression + GAN term; the divergence and KLD terms are not evaluated (upstream
+    never forms exp(z_log_var) there, so an overflowing log-variance cannot poison the loss), mu / log_var receive no
+    gradient from the loss, ``z`` / ``z_rand`` / ``mu`` / ``log_var`` and weights[2:] are ignored."""
+    if out_rand is None:
+        return _GenLoss.apply(out, dis_out, None, None, target.detach(), None if out_tri is None else out_tri.detach(),
+                              None, None, None, tuple(weights))
     return _GenLoss.apply(out, dis_out, mu, log_var, target.detach(), None if out_tri is None else out_tri.detach(),
                           out_rand.detach(), z.detach(), z_rand.detach(), tuple(weights))
 
@@ -1908,6 +1920,12 @@ def set_deterministic(on: bool, device=None) -> None:
     if key not in _DET_WORDS:
         _DET_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
     init_tickets(dev)                                     # the sticky error word: bit 3 = a workgroup's turn never came
+    # re-arming after a time-out: once bit 3 is up det_enter stops waiting while det_leave keeps storing, so the turn word can
+    # be left anywhere; switching the mode on again starts from a zero turn word and a clear bit 3 (the other bits of the
+    # error word -- cooperative GRU / BatchNorm time-outs -- are the trainer's to read and are left alone)
+    torch.cuda.synchronize(dev)
+    _DET_WORDS[key].zero_()
+    _COOP_FLAG[key].bitwise_and_(~8)
     L.check(_lib().s2ag_set_deterministic(_p(_DET_WORDS[key]), _p(_COOP_FLAG[key])), 'set_deterministic')
     _DET_ON[0] = True
     ASYNC_WGRAD = False

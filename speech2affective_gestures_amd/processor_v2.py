@@ -142,8 +142,7 @@ class Processor(object):
         only kind this class and the reference's build, :140): the reference's own step dies on `assert vid_indices is not
         None` (net/multimodal_context_net_v2.py:511) at its first batch -- here the same configuration fails at construction."""
         z_type = getattr(cfg, 'z_type', 'speaker')
-        if z_type not in ('speaker', 'random', 'none'):
-            raise ValueError(f"z_type must be 'speaker', 'random' or 'none' (config/multimodal_context_v2.yml:25), got {z_type!r}")
+        # any other string is the no-regulariser branch, as upstream (:899 tests for the two names and nothing else)
         on = z_type in ('speaker', 'random') and float(cfg.loss_reg_weight) > 0.0
         if on and z_type == 'random':
             raise ValueError("z_type 'random' with loss_reg_weight > 0 calls the generator with vid_indices=None "
@@ -241,6 +240,9 @@ class Processor(object):
         self.s2ag_dis_optimizer = FusedAdam(self.dis_arena, lr=self.lr_s2ag_dis, betas=(0.5, 0.999))
 
         self.use_div_reg = self.regulariser_branch(cfg)
+        # the weights of the generator loss are read ONCE, with the branch: a captured step holds them as launch arguments,
+        # so a later edit of cfg must not change the eager step either (it would silently mix branches); _graph_key carries both
+        self._loss_weights = (float(cfg.loss_regression_weight), float(cfg.loss_reg_weight), float(cfg.loss_kld_weight))
         self.use_hip_graph = bool(getattr(args, 'hip_graph', True))
         # independent forward passes of a step run on forked streams (every kernel here fills only part of the chip)
         self.overlap_passes = bool(getattr(args, 'overlap_passes', True))
@@ -805,13 +807,13 @@ class Processor(object):
                 out_rand, z_rand, _, _ = self.s2ag_generator(pre_seq, in_text, in_mfcc, rand_vids)
         self._last_outs = (out_tri.detach(), out.detach())      # forward_pass_s2ag(calculate_metrics=True) reads them
         w_gan = cfg.loss_gan_weight if self.meta_info['epoch'] > cfg.loss_warmup else 0.0
-        if with_rand:
-            weights = (cfg.loss_regression_weight, w_gan, cfg.loss_reg_weight, cfg.loss_kld_weight)
-        else:
-            # regression (+ GAN) term alone: the fused loss is handed the main pass in place of the missing one (its
-            # divergence term is then exactly 0) with zero weights on the two terms the reference leaves out
-            out_rand, z_rand, weights = out, z, (cfg.loss_regression_weight, w_gan, 0.0, 0.0)
-        total, comps = ops.gen_loss(out, dis_output, z_mu, z_log_var, target_poses, out_tri, out_rand, z, z_rand, weights)
+        # the loss weights were snapshotted at construction together with the branch (self._loss_weights): the captured
+        # replay and the eager step cannot drift apart when cfg is edited afterwards.  Without the regulariser the fused
+        # loss gets out_rand = None: regression (+ GAN) term alone, divergence / KLD not evaluated (processor_v2.py:933-934)
+        w_regr, w_div, w_kld = self._loss_weights
+        weights = (w_regr, w_gan, w_div, w_kld) if with_rand else (w_regr, w_gan, 0.0, 0.0)
+        total, comps = ops.gen_loss(out, dis_output, z_mu, z_log_var, target_poses, out_tri, out_rand if with_rand else None,
+                                    z, z_rand if with_rand else None, weights)
         ops.stamp('G:losses done, backward begins')
         if self.overlap_passes and self.encoders_aside and self.s2ag_generator.share_passes and self._use_gan():
             ops.mark_side_stream(self._side[1])      # the shared encoders' backward runs on the stream of their forward
@@ -847,10 +849,11 @@ class Processor(object):
         host = torch.cat((comps, dis_error.reshape(1) if dis_error is not None else comps.new_zeros(1), flag)).tolist()
         total, huber, gen_error, div_reg, kld, l1, l1_tri, _, dis, timed_out = host
         ops.check_coop_flag(timed_out)       # a cooperative recurrence that lost a peer continued with wrong values
-        d = {'loss': cfg.loss_regression_weight * huber, 'total': total}
+        w_regr, w_div, w_kld = self._loss_weights
+        d = {'loss': w_regr * huber, 'total': total}
         if self.use_div_reg:                  # (the reference's loss_dict has these entries in that branch only, :943-947)
-            d['KLD'] = cfg.loss_kld_weight * kld
-            d['DIV_REG'] = cfg.loss_reg_weight * div_reg
+            d['KLD'] = w_kld * kld
+            d['DIV_REG'] = w_div * div_reg
         if self._use_gan():
             d['gen'] = cfg.loss_gan_weight * gen_error
             d['dis'] = dis
@@ -991,6 +994,7 @@ class Processor(object):
         # a captured graph holds the kernels of ONE precision mode / split-piece count: switching either re-captures
         return (tuple(in_text.shape), tuple(in_audio.shape), tuple(in_mfcc.shape), tuple(target_poses.shape),
                 self._use_gan(), self.meta_info['epoch'] > self.s2ag_config_args.loss_warmup,
+                self.use_div_reg, self._loss_weights, float(self.s2ag_config_args.loss_gan_weight),
                 bf16.enabled(), bf16.step_mode(), ops._lib().s2ag_gru_coop_split_pieces())
 
     def train_step(self, in_text, in_audio, in_mfcc, target_poses, vid_indices, sync=True):

@@ -29,7 +29,7 @@ def test_device_model_library_exports_the_c_abi(emu_lib):
     lib = ctypes.CDLL(emu_lib)
     for name in _lib.SIGNATURES:
         assert hasattr(lib, name), name
-    assert lib.s2ag_abi_version() == 1
+    assert lib.s2ag_abi_version() == 2
     assert hasattr(lib, 's2ag_emu_set_sched') and hasattr(lib, 's2ag_emu_counters')
 
 

@@ -863,6 +863,36 @@ def test_losses_and_gradients(S):
         assert rel(a.grad, b.grad) < TOL
 
 
+def test_generator_loss_without_the_regulariser(S):
+    """processor_v2.py:933-934 (z_type 'none' / loss_reg_weight 0): regression + GAN term alone.  The fused loss takes
+    out_rand = None there and does not evaluate the divergence / KLD terms at all -- a log-variance whose exp() overflows
+    leaves the loss finite, as upstream (with zero weights it was 0 * inf = NaN), and mu / log_var get no
+    gradient from the loss."""
+    ops = S['ops']
+    g = torch.Generator().manual_seed(161)
+    B, T, P = 5, 34, 27
+    out, tgt = torch.randn(B, T, P, generator=g) * 0.3, torch.randn(B, T, P, generator=g) * 0.2
+    out_tri = torch.randn(B, T, P, generator=g) * 0.2
+    dis_out = torch.rand(B, 1, generator=g) * 0.9 + 0.05
+    mu, lv = torch.randn(B, 16, generator=g), torch.full((B, 16), 200.0)        # exp(200) = inf in fp32
+    scfg = O.StepCfg(loss_reg_weight=0.0)
+    assert not O.uses_divergence_term(scfg)
+    req = [t.clone().requires_grad_(True) for t in (out, dis_out)]
+    loss_r, comp = O.gen_losses(scfg, req[0], tgt, req[1], None, None, None, mu, lv, True)
+    loss_r.backward()
+    gq = [t.cuda().requires_grad_(True) for t in (out, dis_out, mu, lv)]
+    total, comps = ops.gen_loss(gq[0], gq[1], gq[2], gq[3], tgt.cuda(), out_tri.cuda(), None, None, None,
+                                (scfg.loss_regression_weight, scfg.loss_gan_weight, 123.0, 456.0))   # [2:] ignored
+    total.backward()
+    c = comps.cpu()
+    assert torch.isfinite(c).all() and rel(total, loss_r) < TOL
+    assert abs(float(c[1]) - float(comp['huber'])) < TOL and abs(float(c[2]) - float(comp['gen'])) < TOL
+    assert float(c[3]) == 0.0 and float(c[4]) == 0.0 and comp['div_reg'] is None and comp['kld'] is None
+    assert abs(float(c[5]) - float(F.l1_loss(out, tgt))) < 1e-6 and abs(float(c[6]) - float(F.l1_loss(out_tri, tgt))) < 1e-6
+    assert rel(gq[0].grad, req[0].grad) < TOL and rel(gq[1].grad, req[1].grad) < TOL
+    assert gq[2].grad is None and gq[3].grad is None
+
+
 def test_fused_adam_matches_torch_adam(S):
     optim = S['optim']
     g = torch.Generator().manual_seed(17)

@@ -72,6 +72,14 @@ def test_mode_is_set_by_every_trainer_and_side_streams_refuse_while_it_is_on():
         ops.join_side_streams()
         pr2, _ = make_processor(32, 64, 12, 4, 9100, 0.0, hip_graph=False)
         assert not pr2.deterministic and not ops.deterministic() and ops.ASYNC_WGRAD
+        # after a turn time-out (sticky bit 3, turn word left anywhere) the mode can be armed again in-process:
+        # switching it on starts from a zero turn word and a clear bit 3, the other error bits are left to the trainer
+        key = torch.cuda.current_device()
+        ops._DET_WORDS[key].fill_(7)
+        ops._COOP_FLAG[key].fill_(8 | 16)
+        ops.set_deterministic(True)
+        assert int(ops._DET_WORDS[key]) == 0 and int(ops._COOP_FLAG[key]) == 16
+        ops._COOP_FLAG[key].zero_()
     finally:
         ops.set_deterministic(False)
 

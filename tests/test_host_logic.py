@@ -22,7 +22,7 @@ def test_shared_library_exports_every_declared_symbol():
     assert declared and declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.s2ag_abi_version() == 1
+    assert lib.s2ag_abi_version() == 2
 
 
 def test_header_cites_the_reference_for_every_entry_point():
@@ -684,29 +684,45 @@ def test_generator_loss_branch_is_chosen_from_the_config_or_refused():
     assert Processor.regulariser_branch(cfg('random', 0.0)) is False
     with pytest.raises(ValueError, match='vid_indices=None'):
         Processor.regulariser_branch(cfg('random', 0.05))
-    with pytest.raises(ValueError, match='z_type must be'):
-        Processor.regulariser_branch(cfg('speakers', 0.05))
+    # any other string: the branch without the regulariser, as upstream (:899 compares with the two names only)
+    assert Processor.regulariser_branch(cfg('speakers', 0.05)) is False
+
+
+# kernels of the DEFAULT path whose device code differs, on purpose, from the last tree that ran on an MI355X (298c878): name
+# fragment -> why.  Anything else that differs fails the test below.
+ISA_ALLOWED_DIFFS = {
+    'wv12_bwd_kILi1E': 'r03: missing barrier between an LDS write and its first read (bf16 path of the wave head backward)',
+    'gen_loss_partial_k': 'r06 (ADVICE r05): out_rand == NULL selects the no-regulariser branch, KLD / divergence not evaluated',
+    'gen_loss_grad_k': 'r06 (ADVICE r05): same',
+}
+# kernel files that did not exist at 298c878: opt-in VARIANTS, one file each so that no default kernel moves (config switches,
+# default off; tools/ab_variants.sh times each against the default on the first GPU call)
+ISA_NEW_FILES = set()
 
 
 def test_isa_identity_evidence_is_for_the_current_kernel_sources():
-    """the default kernels at HEAD are the binaries of the last GPU-run build, and the tracked evidence of
-    that (profiles/r05_isa_diff_since_298c878.txt: every kernel of every csrc/*.hip, old tree vs this tree -- opcode mix,
+    """The default kernels at HEAD are the binaries of the last GPU-run build, and the tracked evidence of that
+    (profiles/r06_isa_diff_since_298c878.txt: every kernel of every csrc/*.hip, old tree vs this tree -- opcode mix,
     registers, LDS, scratch AND the instruction stream) must have been made from THESE sources: its first line carries the
     digest of csrc/*.hip, csrc/*.h and include/s2ag_hip.h (tools/csrc_digest.py).  Editing a kernel file without regenerating
-    the file (tools/isa_diff_since.sh 298c878, ~2 min, no GPU) fails here.  The one allowed difference is the wave head's
-    backward for the bf16 path (a missing barrier between a shared-memory write and its first read, fixed in r03 after the
-    last GPU run); instantiations that did not exist then (the one-piece bf16 step mode) are listed as `new`."""
+    the file (tools/isa_diff_since.sh 298c878, ~2 min, no GPU) fails here.  Allowed differences: ISA_ALLOWED_DIFFS above;
+    instantiations that did not exist then (the one-piece bf16 step mode) are listed as `new`, whole new files must be in
+    ISA_NEW_FILES."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('csrc_digest', os.path.join(ROOT, 'tools', 'csrc_digest.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    text = open(os.path.join(ROOT, 'profiles', 'r05_isa_diff_since_298c878.txt')).read()
+    text = open(os.path.join(ROOT, 'profiles', 'r06_isa_diff_since_298c878.txt')).read()
     first = text.splitlines()[0]
     assert first.startswith('# csrc digest ') and first.split()[3] == mod.digest(), \
-        ('profiles/r05_isa_diff_since_298c878.txt is stale: run tools/isa_diff_since.sh 298c878 > that file', first, mod.digest())
+        ('profiles/r06_isa_diff_since_298c878.txt is stale: run tools/isa_diff_since.sh 298c878 > that file', first, mod.digest())
     differs = [ln for ln in text.splitlines() if ln.startswith(('DIFFERS', 'MISSING'))]
-    assert len(differs) <= 1 and all('wv12_bwd_kILi1E' in ln for ln in differs), differs
+    stray = [ln for ln in differs if not any(k in ln for k in ISA_ALLOWED_DIFFS)]
+    assert not stray and len(differs) <= len(ISA_ALLOWED_DIFFS), stray or differs
     assert sum(ln.startswith('same') for ln in text.splitlines()) >= 200
-    files = {ln[3:].strip() for ln in text.splitlines() if ln.startswith('== ')}
+    heads = [ln[3:].strip() for ln in text.splitlines() if ln.startswith('== ')]
+    new_files = {h.split(':')[0] for h in heads if h.endswith(': new file')}
+    assert new_files == ISA_NEW_FILES, new_files ^ ISA_NEW_FILES
+    files = {h.split(':')[0] for h in heads}
     have = {os.path.basename(f)[:-4] for f in __import__('glob').glob(os.path.join(ROOT, 'speech2affective_gestures_amd', 'csrc', '*.hip'))}
     assert files == have, files ^ have
