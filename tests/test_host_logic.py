@@ -259,13 +259,29 @@ def _exchange_worker(rank, world, port, q):
                       MASTER_PORT=str(port))
     from speech2affective_gestures_amd.parallel import DataParallelContext, GradExchange
     dp = DataParallelContext.from_env(backend='gloo')
+    into_tensor_calls = []
+    if os.environ.get('S2AG_TEST_FORCE_INTO_TENSOR') == '1':
+        # the branch RCCL takes (parallel.py all_gather: dist.all_gather_into_tensor(out, inp)) has never run with more than
+        # one rank (the GPU tests are single-GPU, gloo takes the list form): here the backend NAME is faked and the call is
+        # carried by gloo's list form after checking what RCCL would be handed -- one flat contiguous output of exactly
+        # world * n elements of the input's dtype, filled rank-major
+        import torch.distributed as dist
+
+        def into_tensor(out_t, inp_t):
+            assert out_t.dim() == 1 and out_t.is_contiguous() and inp_t.is_contiguous() and out_t.dtype == inp_t.dtype
+            assert out_t.numel() == world * inp_t.numel(), (out_t.numel(), world, inp_t.numel())
+            into_tensor_calls.append(inp_t.numel())
+            dist.all_gather(list(out_t.view(world, -1).unbind(0)), inp_t)
+        dist.get_backend = lambda *a, **k: 'nccl'
+        dist.all_gather_into_tensor = into_tensor
     n_entries, dim, nb, na, cap = 50, 6, 37, 64, 16
+    over_rank = world - 3 if world > 2 else 1
     out = []
     for step in range(3):
         g = torch.Generator().manual_seed(100 * step + rank)
         ids = torch.randint(0, n_entries, (3, 5), generator=g)
         ids[:, 0] = 0                                           # the PAD row is touched by every rank
-        if step == 2 and rank == 1:                             # ONE rank's batch overflows the row capacity: every rank
+        if step == 2 and rank == over_rank:                     # ONE rank's batch overflows the row capacity: every rank
             ids = torch.arange(30).reshape(3, 10)               # must take the dense all-reduce for this step
         grad = torch.zeros(n_entries * dim + nb + na)
         emb = grad[:n_entries * dim].view(n_entries, dim)
@@ -285,7 +301,10 @@ def _exchange_worker(rank, world, port, q):
         ex.exchange_rest()
         ex.merge_rows()
         out.append((mine.tolist(), grad.tolist()))
+        assert tuple(ex.gathered.shape) == (world, cap, dim + 1)
     dp.barrier()
+    if os.environ.get('S2AG_TEST_FORCE_INTO_TENSOR') == '1':
+        assert into_tensor_calls == [cap * (dim + 1)] * 2, into_tensor_calls     # the two steps that did not go dense
     q.put((rank, out, dp.n_collectives, ex.dense_fallbacks))
 
 
@@ -312,6 +331,66 @@ def test_gradient_exchange_schedule_world_size_2_gloo():
         want = (torch.tensor(m0) + torch.tensor(m1))
         assert torch.allclose(torch.tensor(g0), want, rtol=0, atol=1e-6)
         assert torch.equal(torch.tensor(g0), want)      # two addends: the rank-ordered sum IS the plain sum
+
+
+def test_gradient_exchange_schedule_world_size_8_gloo(monkeypatch):
+    """the schedule at the node's real width.  Eight replicas, the row capacity overflowed on
+    ONE of them (rank 5) in the last step: every rank must take the dense all-reduce there; the touched-row merge must be the
+    sum IN RANK ORDER (bit-identical on all eight ranks, and equal to adding the eight dense row blocks rank by rank);
+    `gathered` is sized (8, cap, dim + 1); and the all-gather goes through the branch RCCL takes
+    (dist.all_gather_into_tensor), forced here by name with gloo underneath."""
+    import torch.multiprocessing as mp
+    world = 8
+    monkeypatch.setenv('S2AG_TEST_FORCE_INTO_TENSOR', '1')
+    monkeypatch.setenv('OMP_NUM_THREADS', '1')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29321 + os.getpid() % 150
+    procs = [ctx.Process(target=_guarded, args=(_exchange_worker, r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert not any(isinstance(r, str) for r in res), [r for r in res if isinstance(r, str)][:1]
+    res = sorted(res)
+    assert [r[0] for r in res] == list(range(world))
+    assert all(r[2] == 3 * 4 and r[3] == 1 for r in res), [(r[2], r[3]) for r in res]
+    n_rows = 50 * 6
+    for step in range(3):
+        mine = [torch.tensor(r[1][step][0]) for r in res]
+        got = [torch.tensor(r[1][step][1]) for r in res]
+        for g in got[1:]:
+            assert torch.equal(g, got[0])                               # identical bits on all eight ranks
+        assert torch.allclose(got[0], torch.stack(mine).double().sum(0).float(), rtol=0, atol=2e-5)
+        if step < 2:                                                    # sparse steps: rows summed rank by rank, exactly
+            acc = torch.zeros(n_rows)
+            touched = torch.zeros(n_rows, dtype=torch.bool)
+            for m in mine:                                              # rank order, first toucher assigns (as merge does)
+                t = (m[:n_rows].view(50, 6) != 0).any(1).repeat_interleave(6)
+                acc = torch.where(t & ~touched, m[:n_rows], torch.where(t, acc + m[:n_rows], acc))
+                touched |= t
+            assert torch.equal(got[0][:n_rows], acc)
+
+
+def test_data_parallel_context_world_size_8_gloo(monkeypatch):
+    """The flat-arena SUM, rank 0's broadcast, the MAX of the sticky error word and the max-over-ranks timing on eight ranks."""
+    import torch.multiprocessing as mp
+    world = 8
+    monkeypatch.setenv('OMP_NUM_THREADS', '1')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29471 + os.getpid() % 150
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[0] for r in res] == list(range(world))
+    assert all(r[1] == res[0][1] for r in res)                          # rank 0's parameters everywhere
+    assert all(r[2] == [36.0] * 15 for r in res)                        # 1 + 2 + ... + 8
+    assert all(r[3] == 0.125 and r[4] == 7.0 and r[5] == 4 for r in res)
 
 
 def _dp_worker(rank, world, port, q):
