@@ -239,6 +239,12 @@ def gru_roofline(B, iters=20, T=T):
     issued = {0: None, 1: 1, 2: 3, 3: 6}[np_]
     return dict(bound='mfma', kernel=name + f' (H=300, T={T}, 2 directions' + ('; average launch of the step: 4 three-pass lockstep launches + 4 one-pass launches)' if multi else ')'),
                 achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3,
+                # both denominators: `frac` prices the algorithmic fp32 FLOPs against the dense f32-MFMA
+                # peak; the products EXECUTE as `issued` bf16 MFMAs each on the 2.5 PFLOP/s bf16 pipe, and that is the pipe
+                # whose occupancy says how busy the matrix cores are
+                frac_of_executing_pipe=(achieved * issued / 2500.0) if issued else achieved / 157.3,
+                executing_pipe=(f'bf16 MFMA 16x16x32, dense peak 2500 TFLOP/s, {issued} issued per fp32 product' if issued
+                                else 'f32 MFMA 16x16x4, dense peak 157.3 TFLOP/s'),
                 frac_of_bf16_pipe=(achieved * issued / 2500.0) if issued else None,
                 bf16_pipe_tflops_issued=(achieved * issued) if issued else None, traffic=traffic,
                 traffic_source=source, algorithmic_bytes_per_launch=algo_bytes, ms_per_launch=ms,
@@ -409,6 +415,9 @@ def conv1d_roofline_run(device, B=256, iters=30, cpu=True, mode='fp32'):
     bytes_per_clip, flops_per_clip = (5.75e6 if mode == 'fp32' else 2.95e6), 413.8e6
     traffic, tsrc = pmc_traffic_per_iteration(mode) if B == 256 else (None, None)
     out = dict(workload=f'BASELINE configs[3]: WavEncoder + TextEncoderTCN fwd+bwd, B=256, T=34, {mode}, dropout on',
+               config=dict(workload="BASELINE configs[3] (ablation-audio 'Conv1d roofline run'): the north-star's HBM figure "
+                                    '(target >= 40 % of 8 TB/s) is roofline.frac of THIS sub-line', batch=B, frames=T,
+                           mode=mode, streams=2 if two_streams else 1),
                ms_per_iter=ms, clips_per_s=clips,
                dtype='f32 storage, bf16x2 products (TCN, weight gradients) / f32 MFMA' if mode == 'fp32'
                else 'bf16 storage, fp32 accumulation / statistics / master weights',
