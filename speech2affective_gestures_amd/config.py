@@ -58,6 +58,13 @@ _S = [
            'tests/test_gpu_ops.py::test_batch_norm_fused_statistics_shapes_and_ticket_rearm'),
     Switch('SYNTH_GRAPH', True, _flag, "0: sliding-window synthesis with eager launches instead of one hipGraph replay per "
            "window", 'tests/test_gpu_step.py::test_synthesis_after_training_steps_uses_the_current_weights'),
+    # ---- opt-in kernel VARIANTS (r06, written with the GPU closed: never timed).  One .hip file each, default OFF, so that no
+    # default binary moves; same results as the default kernel (tests/test_gpu_variants.py); tools/ab_variants.sh times each
+    # against its default in one process the day a GPU answers --------------------------------------------------------------
+    Switch('WGRAD32_PIPE', 0, int, "1 | 2: fp32-operand weight gradients (GRUs, text TCN) by csrc/wgrad_tr32p.hip -- the split + "
+           "LDS stores of step s + 1 run beside the MFMAs of step s, buffer loads with hardware bounds checks (1: three register "
+           "sets of loads in flight as the default kernel, 2: two, everything in architectural VGPRs); bit-identical dw",
+           'tests/test_gpu_variants.py::test_pipelined_weight_gradient_is_bit_identical', clib=True),
     # ---- process plumbing (no kernel is selected by these) --------------------------------------------------------------
     Switch('HIP_LIB', '', str, "path of another build of the same C ABI (debug / asan flavour)", None),
     Switch('CRASH_TRACE', False, _flag, "native back trace on a fatal signal (csrc/debug.hip)", None),

@@ -288,6 +288,7 @@ enum Op { OP_SHFL = 1, OP_BALLOT, OP_RFL, OP_MFMA_BF16_32, OP_MFMA_BF16_16, OP_M
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 struct ShflRec { uint64_t v; int src; int width; uint64_t out; };
 void shfl_fn(Wave*);
@@ -403,6 +404,32 @@ static inline unsigned emu_perm(unsigned a, unsigned b, unsigned sel) {
     return out;
 }
 #define __builtin_amdgcn_perm(a, b, sel) emu_perm(a, b, sel)
+
+// Raw buffer resource (stride 0) and buffer_load_dwordx4 ... offen: base + 32-bit byte offset (voffset + soffset), hardware
+// range check against num_records -- a dword at or beyond num_records reads as 0 (that is what the kernels use it for: rows
+// past the end of a matrix, pad channels).  A 16-byte load that STRADDLES num_records aborts here: whether the hardware checks
+// per dword or per instruction is not something a kernel of this repository may depend on.  Offsets are unsigned 32-bit.
+struct emu_buffer_rsrc {
+    const char* base;
+    unsigned num_records;
+};
+#define __amdgpu_buffer_rsrc_t emu_buffer_rsrc
+static inline emu_buffer_rsrc emu_make_buffer_rsrc(void* p, short stride, int num_records, int flags) {
+    if (stride != 0 || num_records < 0) { fprintf(stderr, "[s2ag emu] make_buffer_rsrc: stride %d num_records %d\n", (int)stride, num_records); abort(); }
+    (void)flags;
+    return emu_buffer_rsrc{(const char*)p, (unsigned)num_records};
+}
+static inline emu::u32x4_t emu_raw_buffer_load_b128(emu_buffer_rsrc r, unsigned voffset, unsigned soffset, int aux) {
+    (void)aux;
+    const unsigned long long off = (unsigned long long)voffset + soffset;
+    emu::u32x4_t out = {0u, 0u, 0u, 0u};
+    if (off >= r.num_records) return out;
+    if (off + 16 > r.num_records || (off & 3)) { fprintf(stderr, "[s2ag emu] buffer_load_dwordx4 straddles num_records / unaligned: offset %llu of %u\n", off, r.num_records); abort(); }
+    memcpy(&out, r.base + off, 16);
+    return out;
+}
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) emu_make_buffer_rsrc(p, stride, n, flags)
+#define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) emu_raw_buffer_load_b128(r, voff, soff, aux)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

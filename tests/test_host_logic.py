@@ -692,10 +692,19 @@ def test_text_encoder_dry_run(mode):
 def test_every_switch_is_registered_and_the_library_reads_no_environment():
     """one registry (speech2affective_gestures_amd/config.py: name, default, what it selects, the test
     that arms it), at most 15 switches, no getenv in the C library, and no S2AG_* environment name anywhere in the package --
-    read OR merely advertised as `S2AG_X=...` in a comment / message -- that the registry does not know."""
+    read OR merely advertised as `S2AG_X=...` in a comment / message -- that the registry does not know.
+    r06: the opt-in kernel VARIANTS ('put every variant in its own .hip file', A/B by one script) are a
+    group of their own with its own rules -- default off, a kernel file of its own that did not exist in the last GPU-run tree,
+    a parity test against the default kernel in tests/test_gpu_variants.py, and an entry in tools/ab_variants.py -- at most 6."""
     from speech2affective_gestures_amd import config
     pkg = os.path.join(ROOT, 'speech2affective_gestures_amd')
-    assert len(config.REGISTRY) <= 15, sorted(config.REGISTRY)
+    variants = {n: sw for n, sw in config.REGISTRY.items() if (sw.test or '').startswith('tests/test_gpu_variants.py')}
+    assert len(config.REGISTRY) - len(variants) <= 15, sorted(set(config.REGISTRY) - set(variants))
+    assert len(variants) <= 6, sorted(variants)
+    ab = open(os.path.join(ROOT, 'tools', 'ab_variants.py')).read()
+    for n, sw in variants.items():
+        assert not sw.default and sw.clib, sw
+        assert f"'{n}'" in ab, f'{n}: no A/B entry in tools/ab_variants.py'
     files = []
     for base, _, names in os.walk(pkg):
         if '_obj' in base or '__pycache__' in base:
@@ -776,7 +785,7 @@ ISA_ALLOWED_DIFFS = {
 }
 # kernel files that did not exist at 298c878: opt-in VARIANTS, one file each so that no default kernel moves (config switches,
 # default off; tools/ab_variants.sh times each against the default on the first GPU call)
-ISA_NEW_FILES = set()
+ISA_NEW_FILES = {'wgrad_tr32p'}
 
 
 def test_isa_identity_evidence_is_for_the_current_kernel_sources():

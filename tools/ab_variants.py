@@ -1,0 +1,165 @@
+"""A/B timing of the opt-in kernel variants (config.py group 'opt-in kernel variants', tests/test_gpu_variants.py) against the
+default kernels -- ONE process, variants interleaved round by round (cdna_hip_programming.md rule 24: a perf delta is a
+within-process interleaved measurement, N variants x M rounds, medians), HIP events on the launch stream.
+
+    python tools/ab_variants.py [--rounds 15] [--only wgrad,cfg3,step]      (needs an MI355X; ~2 min)
+
+Three levels per switch value:
+  micro   the kernel alone at the shapes the step / BASELINE configs[3] launch it with
+  cfg3    BASELINE configs[3] (WavEncoder + TextEncoderTCN forward + backward, B = 256), one captured iteration, fp32
+  step    the GAN step at B = 128 (captured), clips/s
+Prints a table and one JSON line (`AB {...}`); tools/gpu_first_call.sh keeps it under gpurun_out/first/ab_variants.txt.
+A variant whose `micro` AND `cfg3`/`step` medians beat the default by more than the round-to-round spread is a candidate for the
+default; until a GPU has said so every variant stays off."""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+if os.environ.get('S2AG_EMU', '0') == '1':      # DRY RUN of this script's logic on the CPU device model (tests/emu): times are meaningless
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
+    import harness
+    harness.install()
+SMALL = os.environ.get('AB_SMALL', '0') == '1'      # dry-run sizes
+
+# switch -> values to compare (first = default)
+VARIANTS = {
+    'WGRAD32_PIPE': [0, 1, 2],
+}
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def event_us(fn, stream):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    fn()
+    b.record(stream)
+    b.synchronize()
+    return a.elapsed_time(b) * 1e3
+
+
+def interleaved(cases, rounds, stream, warm=3):
+    """cases: {label: fn}.  Returns {label: (median_us, min_us, max_us)} from `rounds` rounds in which every case runs once, in
+    rotating order."""
+    labels = list(cases)
+    for _ in range(warm):
+        for k in labels:
+            cases[k]()
+    torch.cuda.synchronize()
+    ts = {k: [] for k in labels}
+    for r in range(rounds):
+        for k in labels[r % len(labels):] + labels[:r % len(labels)]:
+            ts[k].append(event_us(cases[k], stream))
+    return {k: (statistics.median(v), min(v), max(v)) for k, v in ts.items()}
+
+
+def wgrad_micro(rounds):
+    """WGRAD32_PIPE: (a) the text TCN's eight weight gradients at B = 256 (BASELINE configs[3]); (b) one H = 300 GRU layer's three
+    weight gradients at B = 128 (the step; 96 workgroups, as beside a cooperative recurrence)."""
+    from speech2affective_gestures_amd import _lib as L
+    from speech2affective_gestures_amd import config
+    from test_gpu_variants import _gru_jobs, _tcn_jobs
+    lib = L.load()
+    S = dict(L=L, lib=lib, config=config)
+    st = torch.cuda.current_stream()
+    sp = C.c_void_p(st.cuda_stream)
+    out = {}
+    for name, (fresh, jobs, _, keep), nj, blocks in (
+            ('tcn_wgrad_B256', _tcn_jobs(S, 256 if not SMALL else 3, 34, 300, 4 if not SMALL else 1, 1), 8 if not SMALL else 2, 256),
+            ('gru_wgrad_B128_in600', _gru_jobs(S, 128 if not SMALL else 2, 34, 300, 600, 2), 3, 0)):
+        o = fresh()
+        j = jobs(o)
+        need = int(lib.s2ag_f32_wgrad_tr_scratch_floats_n(j, nj, blocks))
+        sc = torch.empty(need, device='cuda')
+
+        def launch(v):
+            def fn():
+                lib.s2ag_set_option(b'WGRAD32_PIPE', v)
+                L.check(lib.s2ag_f32_wgrad_tr_n(j, nj, _p(sc), need, blocks, sp), 'f32_wgrad_tr')
+            return fn
+        res = interleaved({f'WGRAD32_PIPE={v}': launch(v) for v in VARIANTS['WGRAD32_PIPE']}, rounds, st)
+        lib.s2ag_set_option(b'WGRAD32_PIPE', 0)
+        out[name] = {k: dict(median_us=m, min_us=lo, max_us=hi) for k, (m, lo, hi) in res.items()}
+    return out
+
+
+def cfg3_level(rounds):
+    """One captured iteration of BASELINE configs[3] per switch value (bench.conv1d_roofline_run builds and times the graph;
+    values are visited `rounds // 5 + 1` times in rotating order, the best median per value is kept)."""
+    import bench
+    from speech2affective_gestures_amd import config
+    dev = torch.device('cuda')
+    out = {}
+    for sw, vals in VARIANTS.items():
+        ms = {v: [] for v in vals}
+        for r in range(rounds // 5 + 1):
+            for v in vals[r % len(vals):] + vals[:r % len(vals)]:
+                with config.override(sw, v):
+                    ms[v].append(bench.conv1d_roofline_run(dev, cpu=False, mode='fp32')['ms_per_iter'])
+        out[sw] = {f'{sw}={v}': dict(ms_per_iter=min(t), all=t, frac_hbm=256 * 5.75e6 / (min(t) * 1e-3) / 8e12) for v, t in ms.items()}
+    return out
+
+
+def step_level(rounds):
+    """The captured GAN step at B = 128 per switch value (a processor per value: the graph is captured under the switch)."""
+    import bench
+    from speech2affective_gestures_amd import config
+    out = {}
+    for sw, vals in VARIANTS.items():
+        res = {}
+        for v in vals:
+            with config.override(sw, v):
+                pr = bench.build_processor(128, True, 34, bench.CONFIGS['step']['audio_len'])
+                batch = bench.synthetic_batch(128, 0, pr.device, 34, bench.CONFIGS['step']['audio_len'])
+                rates = []
+                for _ in range(max(2, rounds // 5)):
+                    el = bench.timed_steps(pr, pr.dp, batch, 30, 5, sync=False)
+                    rates.append(128 * 30 / el)
+                res[f'{sw}={v}'] = dict(clips_per_s=statistics.median(rates), all=rates)
+                del pr
+                torch.cuda.empty_cache()
+        out[sw] = res
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rounds', type=int, default=15)
+    ap.add_argument('--only', default='micro,cfg3,step')
+    a = ap.parse_args()
+    if not torch.cuda.is_available() and os.environ.get('S2AG_EMU', '0') != '1':
+        raise SystemExit('tools/ab_variants.py needs an MI355X')
+    only = set(a.only.split(','))
+    res = {}
+    if 'micro' in only:
+        res['micro'] = dict(wgrad=wgrad_micro(a.rounds))
+        for name, r in res['micro']['wgrad'].items():
+            base = r['WGRAD32_PIPE=0']['median_us']
+            for k, v in r.items():
+                print(f'micro {name:24s} {k:16s} {v["median_us"]:8.1f} us  [{v["min_us"]:.1f} .. {v["max_us"]:.1f}]  x{base / v["median_us"]:.2f}')
+    if 'cfg3' in only:
+        res['cfg3'] = cfg3_level(a.rounds)
+        for sw, r in res['cfg3'].items():
+            for k, v in r.items():
+                print(f'cfg3  {k:24s} {v["ms_per_iter"]:.4f} ms/iter  {100 * v["frac_hbm"]:.1f} % of HBM')
+    if 'step' in only:
+        res['step'] = step_level(a.rounds)
+        for sw, r in res['step'].items():
+            for k, v in r.items():
+                print(f'step  {k:24s} {v["clips_per_s"]:.0f} clips/s')
+    print('AB ' + json.dumps(res), flush=True)
+
+
+if __name__ == '__main__':
+    main()
