@@ -65,6 +65,10 @@ _S = [
            "LDS stores of step s + 1 run beside the MFMAs of step s, buffer loads with hardware bounds checks (1: three register "
            "sets of loads in flight as the default kernel, 2: two, everything in architectural VGPRs); bit-identical dw",
            'tests/test_gpu_variants.py::test_pipelined_weight_gradient_is_bit_identical', clib=True),
+    Switch('TCN32_PAIR', 0, int, "1: the clip-resident text TCN of the fp32 step (forward and data-gradient chain) with TWO clips per "
+           "workgroup (csrc/tcn32p.hip): every weight fragment streamed once per two clips, 68 of 80 MFMA rows real instead of 34 "
+           "of 48, one LDS buffer + residual / running gradient in registers; bit-identical h1 / h2 / y / gp1 / gp2 / gx",
+           'tests/test_gpu_variants.py::test_pair_tcn_is_bit_identical', clib=True),
     # ---- process plumbing (no kernel is selected by these) --------------------------------------------------------------
     Switch('HIP_LIB', '', str, "path of another build of the same C ABI (debug / asan flavour)", None),
     Switch('CRASH_TRACE', False, _flag, "native back trace on a fatal signal (csrc/debug.hip)", None),

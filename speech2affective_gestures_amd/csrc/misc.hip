@@ -946,8 +946,8 @@ extern "C" int s2ag_normal_noise(const unsigned long long* rng, unsigned site, l
 // ---- run-time options (the registry is speech2affective_gestures_amd/config.py) ------------------------------------------
 namespace s2ag {
 namespace {
-int g_options[OPT_COUNT] = {2, 0};
-const char* const g_option_names[OPT_COUNT] = {"GRU_SPLIT", "WGRAD32_PIPE"};
+int g_options[OPT_COUNT] = {2, 0, 0};
+const char* const g_option_names[OPT_COUNT] = {"GRU_SPLIT", "WGRAD32_PIPE", "TCN32_PAIR"};
 int option_index(const char* name) {
     if (!name) return -1;
     for (int i = 0; i < OPT_COUNT; ++i)

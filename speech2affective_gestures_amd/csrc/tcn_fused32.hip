@@ -13,6 +13,12 @@
 // y, as fp32 (clips*T, C) rows -- exactly the tensors the per-layer forward kernels would have left.
 #include "s2ag_common.h"
 
+namespace s2ag {                                        // csrc/tcn32p.hip: the opt-in two-clips-per-workgroup form (option TCN32_PAIR)
+bool tcn32p_supported(int n_clips, int n_passes, int save_clips, int T);
+int tcn32p_fwd_launch(const void* params, int n_passes, const void* const* rngs, hipStream_t st);
+int tcn32p_bwd_launch(const void* params, hipStream_t st);
+}
+
 namespace {
 using namespace s2ag;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -22,40 +28,7 @@ using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 typedef unsigned short bf16_t;
 
-constexpr int CP = 320;                 // padded channels of an LDS row
-constexpr int NCT = CP / 16;
-constexpr int KT_TAP = CP / 32;
-constexpr int NKT = 2 * KT_TAP;
-constexpr int PITCH = 324;              // LDS row pitch in floats (1 296 B)
-constexpr int MT = 3;                   // 16-row tiles: up to 48 frames
-constexpr int CT_W = NCT / 4;
-constexpr long long FRAG = (long long)NCT * NKT * 64 * 8;      // bf16 elements of one plane of one conv
-
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-
-struct T32P {
-    const float* x;                             // (clips*T, C) fp32
-    float* h1[S2AG_TCN_MAX_BLOCKS];
-    float* h2[S2AG_TCN_MAX_BLOCKS];
-    float* y[S2AG_TCN_MAX_BLOCKS];
-    const bf16_t* wfrag;                        // [conv][forward / data gradient][plane hi / lo][ct][kt][64][8]
-    // backward (tcn32_bwd_k)
-    const float* gy;                            // (clips*T, C) gradient w.r.t. the last block's output
-    float* gx;
-    float* gp1[S2AG_TCN_MAX_BLOCKS];            // gradients w.r.t. the convs' pre-activations (weight-gradient operands)
-    float* gp2[S2AG_TCN_MAX_BLOCKS];
-    const float* bias[2 * S2AG_TCN_MAX_BLOCKS];
-    int dil[S2AG_TCN_MAX_BLOCKS];
-    int n_blocks, n_clips, T, C;
-    float drop_p, inv_keep;
-    const unsigned long long* rng;
-    unsigned site[2 * S2AG_TCN_MAX_BLOCKS];
-    u32x4* keep;                                // one u32x4 per thread, workgroup and conv (tcn32_keep_k)
-    int keep_total, keep_off;                   // clips of the keep layout [conv][clip][256]; first clip of this pass in it
-    int save_clips;                             // clips < save_clips leave h1 / h2 / y of every block, the others only the last y
-};
+#include "tcn_fused32_shared.h"
 
 // keep bits of one pass in the epilogue's register layout: bit (i*MT + mt)*4 + c of thread (wave, lane)
 __global__ __launch_bounds__(256) void tcn32_keep_k(const T32P p) {
@@ -417,6 +390,8 @@ static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* co
     p.inv_keep = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
     p.keep = static_cast<u32x4*>(a->keep);
     p.keep_total = a->n_clips; p.keep_off = 0; p.save_clips = save_clips;
+    if (s2ag::option(s2ag::OPT_TCN32_PAIR) && s2ag::tcn32p_supported(a->n_clips, n_passes, save_clips, a->T))
+        return s2ag::tcn32p_fwd_launch(&p, n_passes, rngs, (hipStream_t)stream);       // opt-in variant: bit-identical h1 / h2 / y
     const size_t lds = (size_t)(3 * p.T + 1) * PITCH * sizeof(float);
     static bool attr = false;
     if (!attr) {
@@ -466,6 +441,8 @@ extern "C" int s2ag_tcn32_bwd(const s2ag_tcn32_args* a, void* stream) {
     p.n_blocks = a->n_blocks; p.n_clips = a->n_clips; p.T = a->T; p.C = a->C;
     p.drop_p = a->drop_p;
     p.inv_keep = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
+    if (s2ag::option(s2ag::OPT_TCN32_PAIR) && s2ag::tcn32p_supported(a->n_clips, 1, a->n_clips, a->T))
+        return s2ag::tcn32p_bwd_launch(&p, (hipStream_t)stream);                        // opt-in variant: bit-identical gp1 / gp2 / gx
     const size_t lds = (size_t)(3 * p.T + 1) * PITCH * sizeof(float);
     static bool attr = false;
     if (!attr) {

@@ -189,3 +189,102 @@ def test_pipelined_weight_gradient_refuses_what_32_bit_offsets_cannot_address(S)
     x3 = torch.stack([x[b * T + 4:b * T + 4 + T] for b in range(B)]).double()
     ref = torch.einsum('bto,bti->oi', gy.double().view(B, T, Cch), x3)
     assert _rel(outs[1][:, :, 0], ref) < 2e-5
+
+
+# ---- TCN32_PAIR: two clips per workgroup in the clip-resident text TCN of the fp32 step (csrc/tcn32p.hip) -----------------------
+def _tcn32_run(S, x, ws, bs, dils, drop_p, n_passes, save_clips, gy, seed=5):
+    """One forward (s2ag_tcn32_fwd / _fwd_passes) + one data-gradient chain (s2ag_tcn32_bwd) through the C ABI, as
+    ops._TcnFused32 drives them.  Returns every tensor the launches write."""
+    L, lib = S['L'], S['lib']
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nb = len(dils)
+    n_clips, T, Cch = x.shape
+    B = n_clips // n_passes
+    frag = torch.empty(int(lib.s2ag_tcn32_pack_elems(2 * nb)), dtype=torch.bfloat16, device='cuda')
+    ptrs = (C.c_void_p * (2 * nb))(*[w.data_ptr() for w in ws])
+    L.check(lib.s2ag_tcn32_pack(ptrs, 2 * nb, Cch, _p(frag), st), 'tcn32_pack')
+    rows = save_clips * T
+    nan = float('nan')
+    saved = torch.full((3 * nb - 1, rows, Cch), nan, device='cuda')
+    y_last = torch.full((n_clips * T, Cch), nan, device='cuda')
+    a = L.Tcn32()
+    a.x, a.wfrag = x.data_ptr(), frag.data_ptr()
+    for b in range(nb):
+        a.h1[b], a.h2[b] = saved[3 * b].data_ptr(), saved[3 * b + 1].data_ptr()
+        a.y[b] = saved[3 * b + 2].data_ptr() if b < nb - 1 else y_last.data_ptr()
+        a.dil[b] = int(dils[b])
+        for j in range(2):
+            a.bias[2 * b + j] = bs[2 * b + j].data_ptr()
+            a.site[2 * b + j] = 40 + 2 * b + j
+    a.n_blocks, a.n_clips, a.T, a.C = nb, n_clips, T, Cch
+    a.drop_p = float(drop_p)
+    noises = [torch.tensor([seed, 10 + k], dtype=torch.int64, device='cuda') for k in range(n_passes)]
+    keep = torch.zeros(max(16, int(lib.s2ag_tcn32_keep_bytes(n_clips, nb))), dtype=torch.uint8, device='cuda')
+    a.rng, a.keep = noises[0].data_ptr(), keep.data_ptr()
+    if n_passes == 1:
+        L.check(lib.s2ag_tcn32_fwd(C.byref(a), st), 'tcn32_fwd')
+    else:
+        rngs = (C.c_void_p * n_passes)(*[nz.data_ptr() for nz in noises])
+        L.check(lib.s2ag_tcn32_fwd_passes(C.byref(a), n_passes, rngs, save_clips, st), 'tcn32_fwd_passes')
+    torch.cuda.synchronize()
+    out = dict(saved=saved.clone(), y_last=y_last.clone())
+    # backward over the clips that kept their activations
+    gx = torch.full((rows, Cch), nan, device='cuda')
+    gp = torch.full((2 * nb, rows, Cch), nan, device='cuda')
+    b_ = L.Tcn32()
+    b_.wfrag = frag.data_ptr()
+    for b in range(nb):
+        b_.h1[b], b_.h2[b] = saved[3 * b].data_ptr(), saved[3 * b + 1].data_ptr()
+        b_.y[b] = saved[3 * b + 2].data_ptr() if b < nb - 1 else y_last.data_ptr()
+        b_.gp1[b], b_.gp2[b] = gp[2 * b].data_ptr(), gp[2 * b + 1].data_ptr()
+        b_.dil[b] = int(dils[b])
+    b_.n_blocks, b_.n_clips, b_.T, b_.C = nb, save_clips, T, Cch
+    b_.drop_p = float(drop_p)
+    b_.gy, b_.gx = gy.data_ptr(), gx.data_ptr()
+    L.check(lib.s2ag_tcn32_bwd(C.byref(b_), st), 'tcn32_bwd')
+    torch.cuda.synchronize()
+    out.update(gx=gx, gp=gp)
+    return out
+
+
+@pytest.mark.parametrize('case', ['B4_T34', 'B5_T34_odd', 'B2_T40_nodrop', 'B3_T34_two_blocks', 'lockstep_3x4'])
+def test_pair_tcn_is_bit_identical(S, case):
+    """TCN32_PAIR (csrc/tcn32p.hip: two clips per workgroup, activations in LDS as bf16 hi / lo planes split once by their
+    producer, residual and running gradient in registers) against the default clip-resident kernels (csrc/tcn_fused32.hip)
+    through the same C entry points: everything the forward leaves (h1, h2, y of every block, the last y of every lockstep
+    pass) and everything the data-gradient chain leaves (gp1 / gp2 of every conv = the weight gradients' operands, gx) must be
+    EQUAL bit for bit -- same pieces, same K order, same fp32 epilogue, same keep bits.  Covers an odd batch (a workgroup
+    with a single clip), T = 40 (the kernels' limit), no dropout, two blocks, and the trainer's lockstep batch of three passes
+    with only the first pass saving."""
+    config, lib = S['config'], S['lib']
+    B, T, nb, drop, nP = {'B4_T34': (4, 34, 4, 0.3, 1), 'B5_T34_odd': (5, 34, 4, 0.3, 1), 'B2_T40_nodrop': (2, 40, 4, 0.0, 1),
+                          'B3_T34_two_blocks': (3, 34, 2, 0.3, 1), 'lockstep_3x4': (4, 34, 4, 0.3, 3)}[case]
+    Cch = 300
+    assert lib.s2ag_tcn32_supported(T, Cch, 2)
+    g = torch.Generator().manual_seed(8100 + B + T)
+    x = torch.randn(nP * B, T, Cch, generator=g).cuda()
+    ws = [(torch.randn(Cch, 2, Cch, generator=g) * (0.6 / (2 * Cch) ** 0.5)).cuda() for _ in range(2 * nb)]
+    bs = [(torch.randn(Cch, generator=g) * 0.1).cuda() for _ in range(2 * nb)]
+    gy = (torch.randn(B * T, Cch, generator=g) * 0.1).cuda()
+    dils = [2 ** b for b in range(nb)]
+    base = _tcn32_run(S, x, ws, bs, dils, drop, nP, B, gy)
+    with config.override('TCN32_PAIR', 1):
+        assert lib.s2ag_get_option(b'TCN32_PAIR') == 1
+        var = _tcn32_run(S, x, ws, bs, dils, drop, nP, B, gy)
+    assert lib.s2ag_get_option(b'TCN32_PAIR') == 0
+    for k in base:
+        assert torch.isfinite(base[k]).all(), k           # (every element written by the default ...)
+        assert torch.equal(base[k], var[k]), (k, _rel(var[k], base[k]))      # ... and the same bits by the variant
+    # and the forward is the TemporalConvNet it claims to be: fp64 reference with the kernels' own keep bits (drop 0: exact path)
+    if drop == 0.0:
+        xr = x.double()
+        for b in range(nb):
+            d = dils[b]
+            def conv(inp, w, bias):
+                prev = torch.zeros_like(inp)
+                prev[:, d:] = inp[:, :T - d]
+                return torch.einsum('bti,oi->bto', prev, w[:, 0].double()) + torch.einsum('bti,oi->bto', inp, w[:, 1].double()) + bias.double()
+            h1 = torch.relu(conv(xr, ws[2 * b], bs[2 * b]))
+            h2 = torch.relu(conv(h1, ws[2 * b + 1], bs[2 * b + 1]))
+            xr = torch.relu(h2 + xr)
+        assert _rel(var['y_last'].view(nP * B, T, Cch), xr) < 1e-4

@@ -33,6 +33,7 @@ SMALL = os.environ.get('AB_SMALL', '0') == '1'      # dry-run sizes
 # switch -> values to compare (first = default)
 VARIANTS = {
     'WGRAD32_PIPE': [0, 1, 2],
+    'TCN32_PAIR': [0, 1],
 }
 
 
@@ -94,6 +95,64 @@ def wgrad_micro(rounds):
     return out
 
 
+def tcn_micro(rounds):
+    """TCN32_PAIR: the clip-resident text TCN (4 blocks, C = 300, T = 34, dropout 0.3) forward and data-gradient chain at
+    B = 256 (BASELINE configs[3]) and as the step's lockstep batch (3 passes x 128 clips, only the first saving)."""
+    from speech2affective_gestures_amd import _lib as L
+    from speech2affective_gestures_amd import config
+    lib = L.load()
+    st = torch.cuda.current_stream()
+    sp = C.c_void_p(st.cuda_stream)
+    out = {}
+    Cch, T, nb = 300, 34, 4
+    g = torch.Generator().manual_seed(3)
+    ws = [(torch.randn(Cch, 2, Cch, generator=g) * 0.04).cuda() for _ in range(2 * nb)]
+    bs = [(torch.randn(Cch, generator=g) * 0.1).cuda() for _ in range(2 * nb)]
+    frag = torch.empty(int(lib.s2ag_tcn32_pack_elems(2 * nb)), dtype=torch.bfloat16, device='cuda')
+    L.check(lib.s2ag_tcn32_pack((C.c_void_p * (2 * nb))(*[w.data_ptr() for w in ws]), 2 * nb, Cch, _p(frag), sp), 'pack')
+    for name, B, nP in (('cfg3_B256', 256 if not SMALL else 4, 1), ('step_lockstep_3x128', 128 if not SMALL else 2, 3)):
+        n_clips, rows = nP * B, B * T
+        x = torch.randn(n_clips, T, Cch, generator=g).cuda()
+        gy = (torch.randn(rows, Cch, generator=g) * 0.1).cuda()
+        saved = torch.empty(3 * nb - 1, rows, Cch, device='cuda')
+        y_last = torch.empty(n_clips * T, Cch, device='cuda')
+        gx, gp = torch.empty(rows, Cch, device='cuda'), torch.empty(2 * nb, rows, Cch, device='cuda')
+        keep = torch.zeros(int(lib.s2ag_tcn32_keep_bytes(n_clips, nb)), dtype=torch.uint8, device='cuda')
+        noises = [torch.tensor([5, 10 + k], dtype=torch.int64, device='cuda') for k in range(nP)]
+        a, b_ = L.Tcn32(), L.Tcn32()
+        a.x, a.wfrag, b_.wfrag = x.data_ptr(), frag.data_ptr(), frag.data_ptr()
+        for b in range(nb):
+            for t_ in (a, b_):
+                t_.h1[b], t_.h2[b] = saved[3 * b].data_ptr(), saved[3 * b + 1].data_ptr()
+                t_.y[b] = saved[3 * b + 2].data_ptr() if b < nb - 1 else y_last.data_ptr()
+                t_.dil[b] = 2 ** b
+            b_.gp1[b], b_.gp2[b] = gp[2 * b].data_ptr(), gp[2 * b + 1].data_ptr()
+            for j in range(2):
+                a.bias[2 * b + j], a.site[2 * b + j] = bs[2 * b + j].data_ptr(), 40 + 2 * b + j
+        a.n_blocks, a.n_clips, a.T, a.C, a.drop_p = nb, n_clips, T, Cch, 0.3
+        a.rng, a.keep = noises[0].data_ptr(), keep.data_ptr()
+        b_.n_blocks, b_.n_clips, b_.T, b_.C, b_.drop_p = nb, B, T, Cch, 0.3
+        b_.gy, b_.gx = gy.data_ptr(), gx.data_ptr()
+        rngs = (C.c_void_p * nP)(*[nz.data_ptr() for nz in noises])
+
+        def fwd(v):
+            def fn():
+                lib.s2ag_set_option(b'TCN32_PAIR', v)
+                L.check(lib.s2ag_tcn32_fwd_passes(C.byref(a), nP, rngs, B, sp), 'tcn32_fwd')
+            return fn
+
+        def bwd(v):
+            def fn():
+                lib.s2ag_set_option(b'TCN32_PAIR', v)
+                L.check(lib.s2ag_tcn32_bwd(C.byref(b_), sp), 'tcn32_bwd')
+            return fn
+        for tag, mk in (('fwd', fwd), ('bwd', bwd)):
+            res = interleaved({f'TCN32_PAIR={v}': mk(v) for v in VARIANTS['TCN32_PAIR']}, rounds, st)
+            out[f'tcn_{tag}_{name}'] = {k: dict(median_us=m, min_us=lo, max_us=hi) for k, (m, lo, hi) in res.items()}
+        lib.s2ag_set_option(b'TCN32_PAIR', 0)
+    return out
+
+
 def cfg3_level(rounds):
     """One captured iteration of BASELINE configs[3] per switch value (bench.conv1d_roofline_run builds and times the graph;
     values are visited `rounds // 5 + 1` times in rotating order, the best median per value is kept)."""
@@ -143,11 +202,12 @@ def main():
     only = set(a.only.split(','))
     res = {}
     if 'micro' in only:
-        res['micro'] = dict(wgrad=wgrad_micro(a.rounds))
-        for name, r in res['micro']['wgrad'].items():
-            base = r['WGRAD32_PIPE=0']['median_us']
-            for k, v in r.items():
-                print(f'micro {name:24s} {k:16s} {v["median_us"]:8.1f} us  [{v["min_us"]:.1f} .. {v["max_us"]:.1f}]  x{base / v["median_us"]:.2f}')
+        res['micro'] = dict(wgrad=wgrad_micro(a.rounds), tcn=tcn_micro(a.rounds))
+        for grp in res['micro'].values():
+            for name, r in grp.items():
+                base = next(iter(r.values()))['median_us']          # (the first value of a switch is its default)
+                for k, v in r.items():
+                    print(f'micro {name:28s} {k:16s} {v["median_us"]:8.1f} us  [{v["min_us"]:.1f} .. {v["max_us"]:.1f}]  x{base / v["median_us"]:.2f}')
     if 'cfg3' in only:
         res['cfg3'] = cfg3_level(a.rounds)
         for sw, r in res['cfg3'].items():
