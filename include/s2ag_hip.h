@@ -202,6 +202,17 @@ int s2ag_bn_fold(double* partials /*consumed: large sets are pre-folded in place
                  int nchan, const float* gamma, const float* beta, float* running_mean, float* running_var,
                  long long* num_batches_tracked /*nullable*/, float eps, float momentum, int repeat, float* scale_col,
                  float* shift_col, float* mean_col, float* invstd_col, void* stream);
+/* OPT-IN VARIANT of s2ag_bn_fold + s2ag_bn_apply in one launch (csrc/bn_foldapply.hip; config switch BN_FOLD_APPLY): every
+ * workgroup folds the (2, partial_rows, cols) sums itself, in a fixed order, workgroup 0 writes the running estimates, the
+ * batch counter and the four coefficient vectors; y = leaky(x * scale + shift, slope).  Same reference call sites as
+ * s2ag_bn_fold (native_batch_norm + leaky_relu_ behind a conv: net/multimodal_context_net_v2.py:18-27,39-48,397-403).
+ * `partials` is only read.  supported: partial_rows * cols <= 16 384, cols <= 1 024, nchan <= 256. */
+int s2ag_bn_fold_apply_supported(int partial_rows, int cols, int nchan);
+int s2ag_bn_fold_apply(const double* partials, int partial_rows, int rows, int cols, const int* chan_of_col /*nullable*/,
+                       int nchan, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       long long* num_batches_tracked /*nullable*/, float eps, float momentum, int repeat, float* scale_col,
+                       float* shift_col, float* mean_col, float* invstd_col, const float* x, int ldx, float slope, float* y,
+                       int ldy, void* stream);
 /* ONE-launch BatchNorm (training): statistics, fold, coefficients AND the apply (forward: y = leaky(x*scale + shift);
  * backward: dx) in the same kernel -- the workgroups wait for the one that folds and then process the rows they have
  * just read.  replaces the same nn.BatchNorm1d/2d (+ LeakyReLU) call sites as s2ag_bn_fwd_stats + s2ag_bn_apply /

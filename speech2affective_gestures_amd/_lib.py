@@ -109,6 +109,8 @@ SIGNATURES = {
     's2ag_conv_stats_rows': [PG],
     's2ag_conv1d_nlc_fwd_stats': [vp, vp, vp, vp, PG, PE, vp, vp, vp],
     's2ag_bn_fold': [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp],
+    's2ag_bn_fold_apply_supported': [ci, ci, ci],
+    's2ag_bn_fold_apply': [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp, ci, cf, vp, ci, vp],
     's2ag_bn_apply': [vp, ci, ci, ci, vp, vp, cf, vp, ci, vp],
     's2ag_bn_fused_supported': [ci, ci],
     's2ag_bn_fused_partial_rows': [ci, ci, ci],

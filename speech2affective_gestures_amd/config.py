@@ -69,6 +69,9 @@ _S = [
            "workgroup (csrc/tcn32p.hip): every weight fragment streamed once per two clips, 68 of 80 MFMA rows real instead of 34 "
            "of 48, one LDS buffer + residual / running gradient in registers; bit-identical h1 / h2 / y / gp1 / gp2 / gx",
            'tests/test_gpu_variants.py::test_pair_tcn_is_bit_identical', clib=True),
+    Switch('BN_FOLD_APPLY', False, _flag, "1: a training-mode BatchNorm + LeakyReLU behind a conv that left its column sums (21 per "
+           "step) folds them and applies in ONE launch (csrc/bn_foldapply.hip: every workgroup folds the small sums itself, fixed "
+           "order, no grid-wide wait) instead of bn_fold_k + bn_apply_k", 'tests/test_gpu_variants.py::test_bn_fold_apply_in_one_launch'),
     # ---- process plumbing (no kernel is selected by these) --------------------------------------------------------------
     Switch('HIP_LIB', '', str, "path of another build of the same C ABI (debug / asan flavour)", None),
     Switch('CRASH_TRACE', False, _flag, "native back trace on a fatal signal (csrc/debug.hip)", None),

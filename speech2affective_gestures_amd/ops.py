@@ -631,6 +631,8 @@ def generation() -> int:
 # default.  <= 64 workgroups per launch, bounded poll, sticky error bit read with the step's losses (check_coop_flag);
 # S2AG_BN_FUSED=0 keeps the two launches, whose workgroups never wait for each other.
 BN_FUSED = config.mirror('BN_FUSED', globals(), 'BN_FUSED')
+# opt-in variant (csrc/bn_foldapply.hip): where the producing conv left its column sums, fold + apply in one launch (21 pairs a step)
+BN_FOLD_APPLY = config.mirror('BN_FOLD_APPLY', globals(), 'BN_FOLD_APPLY')
 
 
 class _BNAct(torch.autograd.Function):
@@ -645,7 +647,18 @@ class _BNAct(torch.autograd.Function):
         coef = torch.empty(4, cols, dtype=torch.float32, device=dev)
         pre = _BN_PRE[0]
         _BN_PRE[0] = None
-        if training and pre is not None:
+        if training and pre is not None and BN_FOLD_APPLY and lib.s2ag_bn_fold_apply_supported(int(pre[1]), cols, nchan):
+            part, prow = pre        # column sums left behind by the producing layer: fold + apply, one launch
+            y = torch.empty(rows, cols, dtype=torch.float32, device=dev)
+            L.check(lib.s2ag_bn_fold_apply(_p(part), int(prow), rows, cols, _p(chan_map), nchan, _p(gamma), _p(beta), _p(rmean),
+                                           _p(rvar), _p(nbt), float(eps), float(momentum), int(_BN_REPEAT[0]), _p(coef[0]),
+                                           _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(x), ldx, float(slope), _p(y), cols,
+                                           _stream()), 'bn_fold_apply')
+            ctx.save_for_backward(x, coef, chan_map)
+            ctx.meta = (rows, cols, ldx, nchan, float(slope), bool(training))
+            ctx.leaves = (gamma, beta)
+            return y
+        elif training and pre is not None:
             part, prow = pre        # column sums left behind by the producing layer: only the fold remains
             L.check(lib.s2ag_bn_fold(_p(part), int(prow), rows, cols, _p(chan_map), nchan, _p(gamma), _p(beta), _p(rmean),
                                      _p(rvar), _p(nbt), float(eps), float(momentum), int(_BN_REPEAT[0]), _p(coef[0]),

@@ -288,3 +288,63 @@ def test_pair_tcn_is_bit_identical(S, case):
             h2 = torch.relu(conv(h1, ws[2 * b + 1], bs[2 * b + 1]))
             xr = torch.relu(h2 + xr)
         assert _rel(var['y_last'].view(nP * B, T, Cch), xr) < 1e-4
+
+
+# ---- BN_FOLD_APPLY: statistics fold + normalise + LeakyReLU in one launch (csrc/bn_foldapply.hip) ----------------------------
+@pytest.mark.parametrize('case', ['mfcc_64ch', 'mfcc_48ch_k3', 'time_steps_34ch', 'repeat3'])
+def test_bn_fold_apply_in_one_launch(S, case):
+    """BN_FOLD_APPLY against the default pair bn_fold_k + bn_apply_k on the real call chain -- ops.conv1d_nlc(bn_stats=True)
+    leaves its column sums, ops.batch_norm_act consumes them -- at MFCCEncoder's shapes (net/multimodal_context_net_v2.py:39-48):
+    output, running estimates, batch counter, and every gradient of a loss through the layer (the backward pass reads the
+    coefficient vectors the forward stored) against the default path (1e-6: the default sums the partial rows through LDS
+    atomics in arrival order, the variant in a fixed order) and against torch's own batch_norm (1e-5).  `repeat3`: the
+    shared-encoder case, three passes of a step advance the running estimates in one launch (ops.bn_repeat)."""
+    ops, config = S['ops'], S['config']
+    import torch.nn.functional as F
+    B, Lpos, Cin, Cout, ks, rep = {'mfcc_64ch': (6, 37, 64, 64, 5, 1), 'mfcc_48ch_k3': (5, 37, 64, 48, 3, 1),
+                                   'time_steps_34ch': (7, 37, 48, 34, 3, 1), 'repeat3': (4, 37, 64, 64, 5, 3)}[case]
+    g = torch.Generator().manual_seed(9100 + Cout + B)
+    x = torch.randn(B, Lpos, Cin, generator=g)
+    w = torch.randn(Cout, Cin, ks, generator=g) * (1.0 / (Cin * ks) ** 0.5)
+    b = torch.randn(Cout, generator=g) * 0.1
+    gw, gb = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2
+    dy = torch.randn(B, Lpos, Cout, generator=g)
+
+    def run(on):
+        bn = torch.nn.BatchNorm1d(Cout).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(gw)
+            bn.bias.copy_(gb)
+        xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        with config.override('BN_FOLD_APPLY', on), ops.bn_repeat(rep):
+            assert ops.BN_FOLD_APPLY == bool(on)
+            z = ops.conv1d_nlc(xg, wg, bg, pad=ks // 2, bn_stats=True, tm_copy=True)      # as MFCCEncoder.forward calls it
+            assert getattr(z, '_s2ag_stats', None) is not None       # the path under test: sums left by the conv
+            y = ops.batch_norm_act(z, bn, slope=0.3)
+        y.backward(dy.cuda())
+        torch.cuda.synchronize()
+        return dict(y=y.detach(), rm=bn.running_mean.clone(), rv=bn.running_var.clone(), nbt=int(bn.num_batches_tracked),
+                    dx=xg.grad, dw=wg.grad, db=bg.grad, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
+    base, var = run(False), run(True)
+    assert base['nbt'] == var['nbt'] == rep
+    for k in base:
+        if k == 'db':        # a bias in front of a BatchNorm has NO gradient (the mean is subtracted): rounding residue of ~1e-6 x |dy| sums
+            assert float(var[k].abs().max()) < 1e-4 and float(base[k].abs().max()) < 1e-4
+        elif k != 'nbt':
+            assert torch.isfinite(var[k]).all() and _rel(var[k], base[k]) < 1e-6, (k, _rel(var[k], base[k]))
+    # torch reference (channels-first), one pass
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    bnr = torch.nn.BatchNorm1d(Cout).double().train()
+    with torch.no_grad():
+        bnr.weight.copy_(gw)
+        bnr.bias.copy_(gb)
+    zr = F.conv1d(xr.transpose(1, 2), wr, br, padding=ks // 2)
+    yr = F.leaky_relu(bnr(zr), 0.3).transpose(1, 2)
+    for _ in range(rep - 1):
+        bnr(zr.detach())
+    yr.backward(dy.double())
+    # (the large products of the step carry 16 mantissa bits: the same tolerance as the default path's own test)
+    tol = 3e-4
+    assert _rel(var['y'], yr.detach()) < tol and _rel(var['rm'], bnr.running_mean) < tol and _rel(var['rv'], bnr.running_var) < tol
+    for k, r in (('dx', xr.grad), ('dw', wr.grad), ('dgamma', bnr.weight.grad), ('dbeta', bnr.bias.grad)):
+        assert _rel(var[k], r) < 5 * tol, (k, _rel(var[k], r))

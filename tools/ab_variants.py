@@ -34,6 +34,7 @@ SMALL = os.environ.get('AB_SMALL', '0') == '1'      # dry-run sizes
 VARIANTS = {
     'WGRAD32_PIPE': [0, 1, 2],
     'TCN32_PAIR': [0, 1],
+    'BN_FOLD_APPLY': [0, 1],
 }
 
 
