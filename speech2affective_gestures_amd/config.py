@@ -59,19 +59,19 @@ _S = [
     Switch('SYNTH_GRAPH', True, _flag, "0: sliding-window synthesis with eager launches instead of one hipGraph replay per "
            "window", 'tests/test_gpu_step.py::test_synthesis_after_training_steps_uses_the_current_weights'),
     # ---- opt-in kernel VARIANTS (r06, written with the GPU closed: never timed).  One .hip file each, default OFF, so that no
-    # default binary moves; same results as the default kernel (tests/test_gpu_variants.py); tools/ab_variants.sh times each
+    # default binary moves; same results as the default kernel (tests/test_gpu_zy_variants.py); tools/ab_variants.sh times each
     # against its default in one process the day a GPU answers --------------------------------------------------------------
     Switch('WGRAD32_PIPE', 0, int, "1 | 2: fp32-operand weight gradients (GRUs, text TCN) by csrc/wgrad_tr32p.hip -- the split + "
            "LDS stores of step s + 1 run beside the MFMAs of step s, buffer loads with hardware bounds checks (1: three register "
            "sets of loads in flight as the default kernel, 2: two, everything in architectural VGPRs); bit-identical dw",
-           'tests/test_gpu_variants.py::test_pipelined_weight_gradient_is_bit_identical', clib=True),
+           'tests/test_gpu_zy_variants.py::test_pipelined_weight_gradient_is_bit_identical', clib=True),
     Switch('TCN32_PAIR', 0, int, "1: the clip-resident text TCN of the fp32 step (forward and data-gradient chain) with TWO clips per "
            "workgroup (csrc/tcn32p.hip): every weight fragment streamed once per two clips, 68 of 80 MFMA rows real instead of 34 "
            "of 48, one LDS buffer + residual / running gradient in registers; bit-identical h1 / h2 / y / gp1 / gp2 / gx",
-           'tests/test_gpu_variants.py::test_pair_tcn_is_bit_identical', clib=True),
+           'tests/test_gpu_zy_variants.py::test_pair_tcn_is_bit_identical', clib=True),
     Switch('BN_FOLD_APPLY', False, _flag, "1: a training-mode BatchNorm + LeakyReLU behind a conv that left its column sums (21 per "
            "step) folds them and applies in ONE launch (csrc/bn_foldapply.hip: every workgroup folds the small sums itself, fixed "
-           "order, no grid-wide wait) instead of bn_fold_k + bn_apply_k", 'tests/test_gpu_variants.py::test_bn_fold_apply_in_one_launch'),
+           "order, no grid-wide wait) instead of bn_fold_k + bn_apply_k", 'tests/test_gpu_zy_variants.py::test_bn_fold_apply_in_one_launch'),
     # ---- process plumbing (no kernel is selected by these) --------------------------------------------------------------
     Switch('HIP_LIB', '', str, "path of another build of the same C ABI (debug / asan flavour)", None),
     Switch('CRASH_TRACE', False, _flag, "native back trace on a fatal signal (csrc/debug.hip)", None),

@@ -16,7 +16,7 @@
 // Arithmetic = bn_finish_coeffs (fp64 statistics, biased variance for the normalisation, unbiased for the running estimate,
 // `repeat` running-estimate updates rounded to fp32 each, fp32 scale / shift); the default's bn_fold_k adds the partial rows
 // through LDS atomics in arrival order, so the two agree to fp64 rounding of the sums, not to the bit
-// (tests/test_gpu_variants.py: 1e-6 on y and on every coefficient, exact on the batch counter).
+// (tests/test_gpu_zy_variants.py: 1e-6 on y and on every coefficient, exact on the batch counter).
 #include "s2ag_common.h"
 
 namespace {

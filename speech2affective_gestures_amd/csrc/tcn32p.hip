@@ -27,7 +27,7 @@
 //
 // SAME MATH, SAME ORDER: every output element accumulates the same 20 K tiles x 3 piece products in the same order as in the
 // default kernel, bias / ReLU / dropout / residual are the same fp32 operations, the keep bits are the same function of
-// (seed, pass counter, site, element index) -- h1 / h2 / y, gp1 / gp2 and gx are bit-identical (tests/test_gpu_variants.py).
+// (seed, pass counter, site, element index) -- h1 / h2 / y, gp1 / gp2 and gx are bit-identical (tests/test_gpu_zy_variants.py).
 #include "s2ag_common.h"
 
 namespace {

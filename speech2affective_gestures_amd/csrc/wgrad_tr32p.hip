@@ -3,7 +3,7 @@
 // Config switch WGRAD32_PIPE (default OFF: the default kernel's binary does not move; tools/ab_variants.sh times one against
 // the other).  A file of its own on purpose: a variant that is to be A/B-timed must not perturb the default translation unit.
 //
-// SAME MATH, SAME ORDER -- the results are bit-identical to the default kernel's (tests/test_gpu_variants.py holds dw to
+// SAME MATH, SAME ORDER -- the results are bit-identical to the default kernel's (tests/test_gpu_zy_variants.py holds dw to
 // torch.equal): the same 160 x 160 tile on four waves, the same hi / lo bf16 split of every operand value, the same three
 // piece products per tile in the same order, the same 32-row steps, the same split of the contraction over workgroups, the
 // same second launch that sums the splits.  What differs is the SCHEDULE of a step, because the default kernel's step is its

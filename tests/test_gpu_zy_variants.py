@@ -3,7 +3,9 @@ that no default binary moves).  Written in r06 with GPU access closed: never tim
 process the day a GPU answers.  What is proven here (on the CPU device model now, on the MI355X with `-m gpu`): a variant
 returns what the default kernel returns on the same inputs -- bit for bit where the arithmetic and its order are the same,
 else to the tolerance the default kernel's own parity test uses -- and both agree with an fp64 / torch reference, so a
-variant that wins its A/B can become the default without touching a single parity test."""
+variant that wins its A/B can become the default without touching a single parity test.
+The file name sorts behind the parity suite of the default path on purpose (and before the debug flavour's tests): under
+`pytest -x` a surprise in a kernel that has never seen hardware must not cost the run of the tests that have."""
 import ctypes as C
 
 import pytest

@@ -695,10 +695,10 @@ def test_every_switch_is_registered_and_the_library_reads_no_environment():
     read OR merely advertised as `S2AG_X=...` in a comment / message -- that the registry does not know.
     r06: the opt-in kernel VARIANTS ('put every variant in its own .hip file', A/B by one script) are a
     group of their own with its own rules -- default off, a kernel file of its own that did not exist in the last GPU-run tree,
-    a parity test against the default kernel in tests/test_gpu_variants.py, and an entry in tools/ab_variants.py -- at most 6."""
+    a parity test against the default kernel in tests/test_gpu_zy_variants.py, and an entry in tools/ab_variants.py -- at most 6."""
     from speech2affective_gestures_amd import config
     pkg = os.path.join(ROOT, 'speech2affective_gestures_amd')
-    variants = {n: sw for n, sw in config.REGISTRY.items() if (sw.test or '').startswith('tests/test_gpu_variants.py')}
+    variants = {n: sw for n, sw in config.REGISTRY.items() if (sw.test or '').startswith('tests/test_gpu_zy_variants.py')}
     assert len(config.REGISTRY) - len(variants) <= 15, sorted(set(config.REGISTRY) - set(variants))
     assert len(variants) <= 6, sorted(variants)
     ab = open(os.path.join(ROOT, 'tools', 'ab_variants.py')).read()

@@ -1,4 +1,4 @@
-"""A/B timing of the opt-in kernel variants (config.py group 'opt-in kernel variants', tests/test_gpu_variants.py) against the
+"""A/B timing of the opt-in kernel variants (config.py group 'opt-in kernel variants', tests/test_gpu_zy_variants.py) against the
 default kernels -- ONE process, variants interleaved round by round (cdna_hip_programming.md rule 24: a perf delta is a
 within-process interleaved measurement, N variants x M rounds, medians), HIP events on the launch stream.
 
@@ -71,7 +71,7 @@ def wgrad_micro(rounds):
     weight gradients at B = 128 (the step; 96 workgroups, as beside a cooperative recurrence)."""
     from speech2affective_gestures_amd import _lib as L
     from speech2affective_gestures_amd import config
-    from test_gpu_variants import _gru_jobs, _tcn_jobs
+    from test_gpu_zy_variants import _gru_jobs, _tcn_jobs
     lib = L.load()
     S = dict(L=L, lib=lib, config=config)
     st = torch.cuda.current_stream()
