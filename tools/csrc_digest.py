@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """sha256 over the kernel sources the release library is built from (csrc/*.hip, csrc/*.h, include/s2ag_hip.h), names and
-contents: the identity profiles/r05_isa_diff_since_298c878.txt was made for (tools/isa_diff_since.sh stamps it, a CPU test
+contents: the identity profiles/r06_isa_diff_since_298c878.txt was made for (tools/isa_diff_since.sh stamps it, a CPU test
 compares)."""
 import glob
 import hashlib
