@@ -333,7 +333,11 @@ def test_bn_fold_apply_in_one_launch(S, case):
         if k == 'db':        # a bias in front of a BatchNorm has NO gradient (the mean is subtracted): rounding residue of ~1e-6 x |dy| sums
             assert float(var[k].abs().max()) < 1e-4 and float(base[k].abs().max()) < 1e-4
         elif k != 'nbt':
-            assert torch.isfinite(var[k]).all() and _rel(var[k], base[k]) < 1e-6, (k, _rel(var[k], base[k]))
+            # forward quantities: 1e-6 (fp64 sums in a different order, rounded to fp32).  Gradients: both runs accumulate
+            # weight / gamma / beta gradients through fp32 atomics whose order is not fixed on hardware (run-to-run ~3e-7 of the
+            # largest element): 5e-6
+            tol_k = 1e-6 if k in ('y', 'rm', 'rv') else 5e-6
+            assert torch.isfinite(var[k]).all() and _rel(var[k], base[k]) < tol_k, (k, _rel(var[k], base[k]))
     # torch reference (channels-first), one pass
     xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
     bnr = torch.nn.BatchNorm1d(Cout).double().train()

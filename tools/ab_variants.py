@@ -161,13 +161,17 @@ def cfg3_level(rounds):
     from speech2affective_gestures_amd import config
     dev = torch.device('cuda')
     out = {}
+    kw = dict(B=256, iters=30)
+    if SMALL:                                   # dry run on the device model: no graph objects there, four clips, one iteration
+        os.environ['S2AG_CFG3_EAGER'] = '1'
+        kw = dict(B=4, iters=1)
     for sw, vals in VARIANTS.items():
         ms = {v: [] for v in vals}
         for r in range(rounds // 5 + 1):
             for v in vals[r % len(vals):] + vals[:r % len(vals)]:
                 with config.override(sw, v):
-                    ms[v].append(bench.conv1d_roofline_run(dev, cpu=False, mode='fp32')['ms_per_iter'])
-        out[sw] = {f'{sw}={v}': dict(ms_per_iter=min(t), all=t, frac_hbm=256 * 5.75e6 / (min(t) * 1e-3) / 8e12) for v, t in ms.items()}
+                    ms[v].append(bench.conv1d_roofline_run(dev, cpu=False, mode='fp32', **kw)['ms_per_iter'])
+        out[sw] = {f'{sw}={v}': dict(ms_per_iter=min(t), all=t, frac_hbm=kw['B'] * 5.75e6 / (min(t) * 1e-3) / 8e12) for v, t in ms.items()}
     return out
 
 
@@ -176,16 +180,17 @@ def step_level(rounds):
     import bench
     from speech2affective_gestures_amd import config
     out = {}
+    B, steps, warm, graph = (128, 30, 5, True) if not SMALL else (2, 1, 1, False)
     for sw, vals in VARIANTS.items():
         res = {}
         for v in vals:
             with config.override(sw, v):
-                pr = bench.build_processor(128, True, 34, bench.CONFIGS['step']['audio_len'])
-                batch = bench.synthetic_batch(128, 0, pr.device, 34, bench.CONFIGS['step']['audio_len'])
+                pr = bench.build_processor(B, graph, 34, bench.CONFIGS['step']['audio_len'])
+                batch = bench.synthetic_batch(B, 0, pr.device, 34, bench.CONFIGS['step']['audio_len'])
                 rates = []
-                for _ in range(max(2, rounds // 5)):
-                    el = bench.timed_steps(pr, pr.dp, batch, 30, 5, sync=False)
-                    rates.append(128 * 30 / el)
+                for _ in range(max(2, rounds // 5) if not SMALL else 1):
+                    el = bench.timed_steps(pr, pr.dp, batch, steps, warm, sync=False)
+                    rates.append(B * steps / el)
                 res[f'{sw}={v}'] = dict(clips_per_s=statistics.median(rates), all=rates)
                 del pr
                 torch.cuda.empty_cache()
