@@ -72,6 +72,10 @@ _S = [
     Switch('BN_FOLD_APPLY', False, _flag, "1: a training-mode BatchNorm + LeakyReLU behind a conv that left its column sums (21 per "
            "step) folds them and applies in ONE launch (csrc/bn_foldapply.hip: every workgroup folds the small sums itself, fixed "
            "order, no grid-wide wait) instead of bn_fold_k + bn_apply_k", 'tests/test_gpu_zy_variants.py::test_bn_fold_apply_in_one_launch'),
+    Switch('EMB_BWD_ROWS', 0, int, "1: the word-embedding gradient by csrc/emb_rows.hip -- 256 rows x 64 columns per workgroup, the PAD row "
+           "(85 % of every transcript) summed in registers: one atomic per column and workgroup instead of ~4 runs (r03 micro-timing on "
+           "an MI355X: 42 -> 17 us at B = 256; never through the suite on hardware)",
+           'tests/test_gpu_zy_variants.py::test_row_block_embedding_backward', clib=True),
     # ---- process plumbing (no kernel is selected by these) --------------------------------------------------------------
     Switch('HIP_LIB', '', str, "path of another build of the same C ABI (debug / asan flavour)", None),
     Switch('CRASH_TRACE', False, _flag, "native back trace on a fatal signal (csrc/debug.hip)", None),

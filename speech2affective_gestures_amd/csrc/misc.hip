@@ -5,6 +5,11 @@
 #include "s2ag_common.h"
 #include <string.h>
 
+namespace s2ag {                                        // csrc/emb_rows.hip: the opt-in 256-row embedding backward (option EMB_BWD_ROWS)
+int embedding_bwd_rows_launch(const long long* ids, const float* g, int ldg, int rows, int dim, int n_entries, float* dtable,
+                              float drop_p, const unsigned long long* rng, unsigned site, hipStream_t st);
+}
+
 namespace {
 using namespace s2ag;
 
@@ -552,6 +557,9 @@ extern "C" int s2ag_embedding_bwd(const long long* ids, const float* g, int ldg,
         hipError_t me = zero_async(dtable, sizeof(float) * (size_t)n_entries * dim, (hipStream_t)stream);
         if (me != hipSuccess) return (int)me;
     }
+    if (s2ag::option(s2ag::OPT_EMB_BWD_ROWS))       // opt-in variant (csrc/emb_rows.hip): 256-row blocks, the PAD row summed in registers
+        return s2ag::embedding_bwd_rows_launch(ids, g, ldg, rows, dim, n_entries, dtable, p, e ? e->rng : nullptr,
+                                               e ? e->site : 0u, (hipStream_t)stream);
     hipLaunchKernelGGL(embedding_bwd_k, dim3(cdiv(rows, EMB_RB), cdiv(dim, 256)), dim3(256), 0, (hipStream_t)stream, ids,
                        g, ldg, rows, dim, n_entries, dtable, p, p > 0.f ? 1.f / (1.f - p) : 1.f,
                        e ? e->rng : nullptr, e ? e->site : 0u);
@@ -946,8 +954,8 @@ extern "C" int s2ag_normal_noise(const unsigned long long* rng, unsigned site, l
 // ---- run-time options (the registry is speech2affective_gestures_amd/config.py) ------------------------------------------
 namespace s2ag {
 namespace {
-int g_options[OPT_COUNT] = {2, 0, 0};
-const char* const g_option_names[OPT_COUNT] = {"GRU_SPLIT", "WGRAD32_PIPE", "TCN32_PAIR"};
+int g_options[OPT_COUNT] = {2, 0, 0, 0};
+const char* const g_option_names[OPT_COUNT] = {"GRU_SPLIT", "WGRAD32_PIPE", "TCN32_PAIR", "EMB_BWD_ROWS"};
 int option_index(const char* name) {
     if (!name) return -1;
     for (int i = 0; i < OPT_COUNT; ++i)
@@ -980,6 +988,7 @@ extern "C" int s2ag_det_hook_wgrad_tr(int*, unsigned*);
 extern "C" int s2ag_det_hook_conv_bf16(int*, unsigned*);
 extern "C" int s2ag_det_hook_conv_c1(int*, unsigned*);
 extern "C" int s2ag_det_hook_wgrad_tr32p(int*, unsigned*);
+extern "C" int s2ag_det_hook_emb_rows(int*, unsigned*);
 extern "C" int s2ag_det_flavour(void) {
 #if defined(S2AG_DET) && S2AG_DET
     return 1;
@@ -997,5 +1006,6 @@ extern "C" int s2ag_set_deterministic(int* zero_device_word, int* error_word) {
     if (!rc) rc = s2ag_det_hook_conv_bf16(zero_device_word, e);
     if (!rc) rc = s2ag_det_hook_conv_c1(zero_device_word, e);
     if (!rc) rc = s2ag_det_hook_wgrad_tr32p(zero_device_word, e);
+    if (!rc) rc = s2ag_det_hook_emb_rows(zero_device_word, e);
     return rc;
 }

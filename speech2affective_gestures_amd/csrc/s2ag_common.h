@@ -29,7 +29,7 @@ constexpr int WAVE = 64;
 // speech2affective_gestures_amd/config.py.  The library itself never reads the environment.
 // (OPT_GRU_SPLIT: a product mode.  The others: opt-in kernel VARIANTS that live in files of their own, default 0 -- each is
 //  A/B-timed against the default by tools/ab_variants.sh and held bit-identical / to the same tolerance by tests/test_gpu_zy_variants.py)
-enum Option { OPT_GRU_SPLIT = 0, OPT_WGRAD32_PIPE, OPT_TCN32_PAIR, OPT_COUNT };
+enum Option { OPT_GRU_SPLIT = 0, OPT_WGRAD32_PIPE, OPT_TCN32_PAIR, OPT_EMB_BWD_ROWS, OPT_COUNT };
 int option(Option o);
 
 __host__ __device__ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -354,3 +354,52 @@ def test_bn_fold_apply_in_one_launch(S, case):
     assert _rel(var['y'], yr.detach()) < tol and _rel(var['rm'], bnr.running_mean) < tol and _rel(var['rv'], bnr.running_var) < tol
     for k, r in (('dx', xr.grad), ('dw', wr.grad), ('dgamma', bnr.weight.grad), ('dbeta', bnr.bias.grad)):
         assert _rel(var[k], r) < 5 * tol, (k, _rel(var[k], r))
+
+
+# ---- EMB_BWD_ROWS: 256-row blocks, the PAD row summed in registers (csrc/emb_rows.hip) -----------------------------------------
+@pytest.mark.parametrize('case', ['transcripts_B9', 'all_pad', 'all_distinct', 'dropout_B5', 'strided_rows'])
+def test_row_block_embedding_backward(S, case):
+    """EMB_BWD_ROWS against the default embedding_bwd_k through ops.embedding's own backward (gradient scattered into a dense
+    (n_words, 300) table; net/multimodal_context_net_v2.py:84) and against index_add_ in fp64: TED-shaped transcripts (85 % PAD =
+    id 0, a few words per clip, some repeated), the all-PAD and all-distinct extremes, the dropout-scaled form (same keep bits
+    as the forward), a row count that is not a multiple of the 256-row block, and a gradient with a row pitch (a column slice
+    of a wider matrix).  Both kernels accumulate through fp32 atomics in different groupings: 2e-6 of the largest element."""
+    ops, config, lib = S['ops'], S['config'], S['lib']
+    B, T, n_words, dim, p = {'transcripts_B9': (9, 34, 500, 300, 0.0), 'all_pad': (4, 34, 50, 300, 0.0),
+                             'all_distinct': (3, 34, 400, 300, 0.0), 'dropout_B5': (5, 34, 300, 300, 0.1),
+                             'strided_rows': (8, 33, 200, 300, 0.0)}[case]
+    g = torch.Generator().manual_seed(9500 + B)
+    if case == 'all_pad':
+        ids = torch.zeros(B, T, dtype=torch.int64)
+    elif case == 'all_distinct':
+        ids = torch.randperm(n_words, generator=g)[:B * T].view(B, T)
+    else:
+        ids = torch.randint(1, n_words, (B, T), generator=g)
+        ids[torch.rand(B, T, generator=g) < 0.85] = 0
+        ids[:, 3] = 7                                            # one word in every clip: the same row from many workgroups
+    table = torch.randn(n_words, dim, generator=g)
+    wide = torch.randn(B * T, dim + 20, generator=g)
+    dy = wide[:, 4:4 + dim] if case == 'strided_rows' else wide[:, :dim].contiguous()
+    noise = torch.tensor([77, 5], dtype=torch.int64, device='cuda')
+
+    def run(on):
+        tg = table.cuda().requires_grad_(True)
+        with config.override('EMB_BWD_ROWS', on):
+            assert lib.s2ag_get_option(b'EMB_BWD_ROWS') == on
+            y = ops.embedding(ids.cuda(), tg, p, noise, 31)
+            wc = wide.cuda()                                    # (sliced ON the device: a host-side slice would arrive contiguous)
+            dyc = wc[:, 4:4 + dim] if case == 'strided_rows' else wc[:, :dim].contiguous()
+            assert dyc.is_contiguous() == (case != 'strided_rows')
+            y.backward(dyc.view(B, T, dim))
+        torch.cuda.synchronize()
+        return y.detach(), tg.grad
+    (y0, g0), (y1, g1) = run(0), run(1)
+    assert torch.equal(y0, y1)
+    mask = torch.ones(B * T, dim, dtype=torch.float64)
+    if p > 0:
+        mask = ops.dropout_mask(noise, 31, p, (B * T, dim)).cpu().double()       # the keep / scale factors the kernels draw
+    ref = torch.zeros(n_words, dim, dtype=torch.float64).index_add_(0, ids.view(-1), dy.double() * mask)
+    assert _rel(g1, g0) < 2e-6 and _rel(g1, ref) < 2e-6 and _rel(g0, ref) < 2e-6, (_rel(g1, g0), _rel(g1, ref))
+    touched = torch.zeros(n_words, dtype=torch.bool)
+    touched[ids.view(-1)] = True
+    assert float(g1[~touched.cuda()].abs().max() if (~touched).any() else 0.0) == 0.0      # untouched rows stay exactly zero

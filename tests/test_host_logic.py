@@ -785,7 +785,7 @@ ISA_ALLOWED_DIFFS = {
 }
 # kernel files that did not exist at 298c878: opt-in VARIANTS, one file each so that no default kernel moves (config switches,
 # default off; tools/ab_variants.sh times each against the default on the first GPU call)
-ISA_NEW_FILES = {'wgrad_tr32p', 'tcn32p', 'bn_foldapply'}
+ISA_NEW_FILES = {'wgrad_tr32p', 'tcn32p', 'bn_foldapply', 'emb_rows'}
 
 
 def test_isa_identity_evidence_is_for_the_current_kernel_sources():

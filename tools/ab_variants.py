@@ -35,6 +35,7 @@ VARIANTS = {
     'WGRAD32_PIPE': [0, 1, 2],
     'TCN32_PAIR': [0, 1],
     'BN_FOLD_APPLY': [0, 1],
+    'EMB_BWD_ROWS': [0, 1],
 }
 
 
@@ -154,6 +155,31 @@ def tcn_micro(rounds):
     return out
 
 
+def emb_micro(rounds):
+    """EMB_BWD_ROWS: the word-embedding gradient at configs[3]'s shape (B = 256 x 34 ids, 85 % PAD, 300 columns, dropout 0.1)."""
+    from speech2affective_gestures_amd import _lib as L
+    lib = L.load()
+    st = torch.cuda.current_stream()
+    sp = C.c_void_p(st.cuda_stream)
+    B, T, n_words, dim = (256 if not SMALL else 4), 34, 20000, 300
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(1, n_words, (B * T,), generator=g)
+    ids[torch.rand(B * T, generator=g) < 0.85] = 0
+    ids, dy = ids.cuda(), torch.randn(B * T, dim, generator=g).cuda()
+    dt = torch.zeros(n_words, dim, device='cuda')
+    rng = torch.tensor([1, 2], dtype=torch.int64, device='cuda')
+    e = L.Epilogue(0, 1.0, 0.1, C.c_void_p(rng.data_ptr()), 31)
+
+    def mk(v):
+        def fn():
+            lib.s2ag_set_option(b'EMB_BWD_ROWS', v)
+            L.check(lib.s2ag_embedding_bwd(_p(ids), _p(dy), dim, B * T, dim, n_words, _p(dt), 1, C.byref(e), sp), 'embedding_bwd')
+        return fn
+    res = interleaved({f'EMB_BWD_ROWS={v}': mk(v) for v in VARIANTS['EMB_BWD_ROWS']}, rounds, st)
+    lib.s2ag_set_option(b'EMB_BWD_ROWS', 0)
+    return {'embedding_bwd_B256': {k: dict(median_us=m, min_us=lo, max_us=hi) for k, (m, lo, hi) in res.items()}}
+
+
 def cfg3_level(rounds):
     """One captured iteration of BASELINE configs[3] per switch value (bench.conv1d_roofline_run builds and times the graph;
     values are visited `rounds // 5 + 1` times in rotating order, the best median per value is kept)."""
@@ -208,7 +234,7 @@ def main():
     only = set(a.only.split(','))
     res = {}
     if 'micro' in only:
-        res['micro'] = dict(wgrad=wgrad_micro(a.rounds), tcn=tcn_micro(a.rounds))
+        res['micro'] = dict(wgrad=wgrad_micro(a.rounds), tcn=tcn_micro(a.rounds), emb=emb_micro(a.rounds))
         for grp in res['micro'].values():
             for name, r in grp.items():
                 base = next(iter(r.values()))['median_us']          # (the first value of a switch is its default)
