@@ -94,6 +94,12 @@ def build_processor(B, hip_graph, frames=T, audio_len=AUDIO_LEN):
     return pr
 
 
+def non_default_switches():
+    from speech2affective_gestures_amd import config
+    return {n: config.get(n) for n, sw in config.REGISTRY.items()
+            if n not in ('HIP_LIB', 'CRASH_TRACE', 'BUILD_JOBS') and config.get(n) != sw.default}
+
+
 def matrix_products_mode():
     """How the large matrix products are formed in this run (see the module docstring)."""
     from speech2affective_gestures_amd import _lib as L
@@ -649,6 +655,9 @@ def main():
                        'audio_samples': audio_len, 'n_words': N_WORDS, 'n_speakers': N_SPK, 'hidden_size': HIDDEN,
                        'parallelism': f'dp{dp.world_size}', 'hip_graph': not a.no_graph,
                        'matrix_products': matrix_products_mode(),
+                       # every registry switch that is not at its default in this run (opt-in kernel variants included): a line
+                       # measured with S2AG_TCN32_PAIR=1 etc. says so itself
+                       'non_default_switches': non_default_switches(),
                        'gradient_exchange_bytes_per_rank': ex.bytes_per_step() if ex is not None else None,
                        'last_step_losses': pr.last_losses if metric is not None else None},
             'value_with_per_step_loss_readback': sync_value,

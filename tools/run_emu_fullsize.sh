@@ -9,9 +9,9 @@ cd "$(dirname "$0")/.."
 export S2AG_EMU=1 S2AG_EMU_FULLSIZE=1
 # (measured in r05 on 8 cores: configs[3] at B = 256 2.5 min, the step at B = 128 9.5 min; test_full_size_training_steps --
 # capture + many steps -- ran for more than an hour and was stopped: one step of each size is what this script is for)
-for t in "tests/test_gpu_fullsize.py::test_conv1d_roofline_run_gradients_match_the_oracle_strictly[256]" \
-         "tests/test_gpu_fullsize.py::test_full_size_step_matches_the_oracle[step]" \
-         "tests/test_gpu_fullsize.py::test_full_size_step_matches_the_oracle[long]"; do
+# TESTS="node-id node-id ..." selects; switches of the registry (S2AG_TCN32_PAIR=1 ...) may be exported around the call
+TESTS=${TESTS:-"tests/test_gpu_fullsize.py::test_conv1d_roofline_run_gradients_match_the_oracle_strictly[256] tests/test_gpu_fullsize.py::test_full_size_step_matches_the_oracle[step] tests/test_gpu_fullsize.py::test_full_size_step_matches_the_oracle[long]"}
+for t in $TESTS; do
   echo "=== $t  (started $(date -u +%H:%M:%S))"
   t0=$SECONDS
   timeout ${BUDGET:-14000} python -u -m pytest "$t" -m gpu -q -s -p no:cacheprovider 2>&1 | grep -v "Warning\|WeightNorm\|^$" | tail -25
