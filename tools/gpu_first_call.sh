@@ -1,11 +1,11 @@
 #!/bin/bash
 # The FIRST gpurun call of the round in which GPU access comes back (closed since the middle of r03):
-#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'TAG=r06 bash tools/gpu_first_call.sh'
+#   /usr/local/graft/bin/gpurun --timeout 4500 -- 'TAG=r07 bash tools/gpu_first_call.sh'
 #   1. the full -m gpu suite at HEAD (no -x), with durations  -> gpurun_out/first/t_all.log
 #   2. one full un-profiled bench line of HEAD               -> gpurun_out/first/bench_line.json
 #   3. tools/ab_variants.py: every opt-in variant against its default, interleaved in one process -> gpurun_out/first/ab_variants.txt
 #   4. TAG=<round> tools/profile_round.sh -- kernel stats, FETCH/WRITE_SIZE traffic, MFMA-busy for the step and configs[3]
-# ~35 GPU-minutes.  Copy the summaries (gpurun_out/<TAG>p/<TAG>_*) into profiles/ afterwards.
+# ~50 GPU-minutes (each part has its own timeout: 40 + 15 + 15 min + the profiles).  Copy the summaries (gpurun_out/<TAG>p/<TAG>_*) into profiles/ afterwards.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/first; mkdir -p $O
 cd $R
