@@ -63,6 +63,8 @@ GROUPS = {
         (['tests/test_gpu_step.py'], 'one_step_strictly and 300-6', 1, 0),
     'strict parity of both discriminators with the product\'s branch decisions (small batch)':
         (['tests/test_gpu_modules.py'], 'branch_decisions[5]', 1, 0),
+    'r06 opt-in kernel variants against their default kernels (csrc/wgrad_tr32p.hip, tcn32p.hip, bn_foldapply.hip, emb_rows.hip), reversed wavefront order':
+        (['tests/test_gpu_zy_variants.py'], '', 30, 2),
 }
 
 
@@ -71,7 +73,7 @@ def test_gpu_parity_tests_on_the_cpu_device_model(emu_lib, group):
     files, expr, at_least, sched = GROUPS[group]
     env = dict(os.environ, S2AG_EMU='1', S2AG_EMU_SCHED=str(sched))
     env.pop('S2AG_HIP_LIB', None)
-    cmd = [sys.executable, '-m', 'pytest', *files, '-m', 'gpu', '-q', '-p', 'no:cacheprovider', '-k', expr]
+    cmd = [sys.executable, '-m', 'pytest', *files, '-m', 'gpu', '-q', '-p', 'no:cacheprovider'] + (['-k', expr] if expr else [])
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     tail = p.stdout[-3000:]
     m = re.search(r'(\d+) passed', p.stdout)

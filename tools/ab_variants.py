@@ -39,6 +39,18 @@ VARIANTS = {
 }
 
 
+# all variants together (the value each is expected to win with), timed at the cfg3 and step levels beside the single switches
+ALL_ON = {'WGRAD32_PIPE': 2, 'TCN32_PAIR': 1, 'BN_FOLD_APPLY': 1, 'EMB_BWD_ROWS': 1}
+
+
+def _all_on(config):
+    import contextlib
+    st = contextlib.ExitStack()
+    for k, v in ALL_ON.items():
+        st.enter_context(config.override(k, v))
+    return st
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr())
 
@@ -198,6 +210,11 @@ def cfg3_level(rounds):
                 with config.override(sw, v):
                     ms[v].append(bench.conv1d_roofline_run(dev, cpu=False, mode='fp32', **kw)['ms_per_iter'])
         out[sw] = {f'{sw}={v}': dict(ms_per_iter=min(t), all=t, frac_hbm=kw['B'] * 5.75e6 / (min(t) * 1e-3) / 8e12) for v, t in ms.items()}
+    ts = []
+    for _ in range(rounds // 5 + 1):
+        with _all_on(config):
+            ts.append(bench.conv1d_roofline_run(dev, cpu=False, mode='fp32', **kw)['ms_per_iter'])
+    out['ALL'] = {'ALL_ON ' + ','.join(f'{k}={v}' for k, v in ALL_ON.items()): dict(ms_per_iter=min(ts), all=ts, frac_hbm=kw['B'] * 5.75e6 / (min(ts) * 1e-3) / 8e12)}
     return out
 
 
@@ -221,6 +238,12 @@ def step_level(rounds):
                 del pr
                 torch.cuda.empty_cache()
         out[sw] = res
+    with _all_on(config):
+        pr = bench.build_processor(B, graph, 34, bench.CONFIGS['step']['audio_len'])
+        batch = bench.synthetic_batch(B, 0, pr.device, 34, bench.CONFIGS['step']['audio_len'])
+        rates = [B * steps / bench.timed_steps(pr, pr.dp, batch, steps, warm, sync=False) for _ in range(max(2, rounds // 5) if not SMALL else 1)]
+        out['ALL'] = {'ALL_ON': dict(clips_per_s=statistics.median(rates), all=rates)}
+        del pr
     return out
 
 
