@@ -340,3 +340,41 @@ def test_full_size_steps_with_the_conv_path_in_bf16_mode():
         assert abs(first['bf16'][k] - v) <= 0.03 * max(abs(v), 0.05), (k, v, first['bf16'][k])
         # ... and with single-piece bf16 products in the GRU, its projections and the weight gradients as well
         assert abs(first['bf16_step'][k] - v) <= 0.03 * max(abs(v), 0.05), (k, v, first['bf16_step'][k])
+
+
+@pytest.mark.parametrize('tag', ['small', 'full'])
+def test_bf16_conv_path_against_the_reference_goldens(golden_dir, tag):
+    """the bf16 mode was held to torch on bf16-rounded operands and to the product's own fp32 mode, never to
+    the REFERENCE.  Here the train-mode goldens the reference itself produced (tests/golden/modules_*.npz, the vectors the fp32
+    path meets at 2e-4) are the yardstick for the two encoders that change precision in this mode and for the generator
+    built on them (`_abl_audio.PoseGenerator`: WavEncoder + TextEncoderTCN + GRU decoder, BASELINE configs[3]'s model).
+    Tolerances are the MEASURED distance of 8-mantissa-bit storage from the fp32 reference (device model; the arithmetic is
+    the hardware's) with a factor of ~2-3: encoder features 7.1e-3 / 6.5e-3 (wave) and 4.2e-3 (text, full width; at hidden 32
+    the TCN is not bf16-capable and stays fp32: 4e-7) of the largest element -> 1.5e-2; the GENERATOR OUTPUT 2.9e-4 / 8.1e-4 ->
+    3e-3: behind the GRU decoder the encoders' rounding mostly averages out, so even this mode sits at the north star's 1e-3
+    on the poses at full width -- but not with margin, which is why fp32 stays the default and the mode the bar is proven in."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import numpy as np
+    from oracle import s2ag_oracle as O
+    from s2ag_testing import STEP_SEED, build_product, set_dropout, to_cuda
+    from speech2affective_gestures_amd import bf16, noise
+    c = {'small': dict(hidden=32, n_words=64, n_spk=12, B=2, seed0=1000),
+         'full': dict(hidden=300, n_words=2000, n_spk=1371, B=4, seed0=2000)}[tag]
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, f'modules_{tag}.npz')).items() if v.dtype.kind == 'f'}
+    inp = to_cuda(O.recipe_inputs(c['B'], 34, c['seed0'] + 10, c['n_words'], c['n_spk']))
+    pre_seq = O.make_pre_seq(inp['target'], 4)
+    _, m, _ = build_product(c['hidden'], c['n_words'], c['n_spk'], 0.0, c['seed0'])
+    for mod in m.values():
+        mod.train(True)
+        set_dropout(mod, 0.0, 0.0, 0.0)
+    errs = {}
+    with torch.no_grad(), bf16.precision('bf16'):
+        assert bf16.enabled()
+        errs['wav_encoder'] = rel(m['T3'].audio_encoder(inp['in_audio']), g['train.wav_encoder'])
+        errs['text_encoder'] = rel(m['G'].text_encoder(inp['in_text'])[0], g['train.text_encoder'])
+        noise.manual_seed(STEP_SEED)
+        errs['GA.out'] = rel(m['GA'](pre_seq, inp['in_text'], inp['in_audio'], inp['vid'])[0], g['train.GA.out'])
+    print(f'[bf16 Conv1d path vs REFERENCE goldens, {tag}] ' + ', '.join(f'{k} {v:.2e}' for k, v in errs.items()))
+    for k, v in errs.items():
+        assert v < (3e-3 if k == 'GA.out' else 1.5e-2), (k, v)
+    assert errs['wav_encoder'] > 2e-4          # (the mode really ran: the fp32 path meets 2e-4 on the same vectors)
