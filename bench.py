@@ -129,8 +129,10 @@ def pmc_traffic(kernel_prefix):
     separate rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, written by tools/pmc_traffic.py from
     FETCH_SIZE / WRITE_SIZE with the gfx950 corrections of the micro-architecture guide).  None when the file or the
     kernel is absent: the line then says traffic = null instead of quoting a stale constant."""
-    for fname in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
-        path = os.path.join(ROOT, 'profiles', fname)
+    import glob
+    # newest round first (profiles/r<NN>_pmc_traffic.json, copied there from tools/profile_round.sh's output)
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic.json')), reverse=True):
+        fname = os.path.basename(path)
         try:
             with open(path) as f:
                 table = json.load(f)
@@ -146,7 +148,9 @@ def pmc_traffic_per_iteration(mode):
     """HBM bytes of ONE iteration of the Conv1d roofline run (all its kernels), from the tracked summary of the two separate
     rocprofv3 --pmc passes over tools/run_cfg4.py (profiles/r03_pmc_traffic_cfg3_<mode>.json, tools/pmc_traffic.py).  None
     when the file is absent."""
-    path = os.path.join(ROOT, 'profiles', f'r03_pmc_traffic_cfg3_{mode}.json')
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_pmc_traffic_cfg3_{mode}.json')), reverse=True)
+    path = cands[0] if cands else os.path.join(ROOT, 'profiles', f'r03_pmc_traffic_cfg3_{mode}.json')
     try:
         with open(path) as f:
             table = json.load(f)

@@ -13,4 +13,4 @@ timeout 2400 python -m pytest tests -q -m gpu --durations=25 > $O/t_all.log 2>&1
 timeout 900 python bench.py > $O/bench.log 2>&1; echo "bench rc=$?"; grep '^{"metric"' $O/bench.log | tail -1 > $O/bench_line.json; cut -c1-400 $O/bench_line.json
 # 4. the opt-in variants written while the GPU was closed: parity already ran with the suite (tests/test_gpu_zy_variants.py); A/B timing
 timeout 900 python tools/ab_variants.py --rounds 15 > $O/ab_variants.txt 2>&1; echo "ab rc=$?"; grep -v '^AB ' $O/ab_variants.txt | tail -30
-TAG=${TAG:-r06} bash $R/tools/profile_round.sh > $O/profile.log 2>&1; tail -5 $O/profile.log
+TAG=${TAG:-r07} bash $R/tools/profile_round.sh > $O/profile.log 2>&1; tail -5 $O/profile.log

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Profiles of a round on the GPU box (TAG=r05 bash tools/profile_round.sh): the r03 script with the round as a parameter (writes under gpurun_out/${TAG}p; the summaries are copied to profiles/ afterwards):
+# Profiles of a round on the GPU box (TAG=r07 bash tools/profile_round.sh): the r03 script with the round as a parameter (writes under gpurun_out/${TAG}p; the summaries are copied to profiles/ afterwards):
 #   step kernel stats, configs[3] kernel stats (fp32 / bf16, one stream), FETCH_SIZE / WRITE_SIZE passes of the step and of
 #   configs[3] in both modes (-> traffic JSONs bench.py reads), the calibration passes, and an MFMA-busy pass of both.
 #   PARTS="step cfg3 pmc mfma" selects (default: all).
-TAG=${TAG:-r05}
+TAG=${TAG:-r07}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG}p; mkdir -p $O
 cd $R
