@@ -380,7 +380,7 @@ def test_data_parallel_context_world_size_8_gloo(monkeypatch):
     monkeypatch.setenv('OMP_NUM_THREADS', '1')
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29471 + os.getpid() % 150
+    port = 29160 + os.getpid() % 150
     procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
