@@ -15,16 +15,18 @@
 //      into bf16 pieces, LDS stores) and the matrix pipe never work at the same time, because the barrier sits between them
 //      and there is no second wave on the SIMD to fill the gap.  Here step s + 1 is split and stored into the OTHER LDS image
 //      while the MFMAs of step s run:   { mma(s) || stash(s + 1) } | fetch | barrier.   One barrier per step as before; the
-//      stash code is placed between the MFMA groups of the five row tiles, so the 75 MFMAs (1 200 cycles at 16 per
-//      v_mfma_f32_16x16x32_bf16) cover the ~190 vector-ALU instructions that are left (760 cycles).
+//      stash code is placed between the MFMA groups of the five row tiles and `sched_group_barrier` puts two of its
+//      instructions behind every MFMA, so the 75 MFMAs (1 200 cycles at 16 per v_mfma_f32_16x16x32_bf16) cover most of the
+//      ~210 vector-ALU instructions that are left (profiles/r06_variants_isa.txt: 150 of 212 are issued between MFMAs).
 //   2. BUFFER LOADS WITH HARDWARE BOUNDS CHECKS instead of 64-bit flat pointers with per-chunk select + zero-fill: a chunk that
 //      must read as zeros (rows past the end of the matrix, pad channels, the causal pad rows of a dilated tap) gets a byte
 //      offset beyond num_records and the load returns zeros -- no pointer select, no 4 x v_cndmask per chunk, 32-bit offsets
 //      (half the address registers and half the adds).  The gy offsets advance by a constant: one v_add_u32 per chunk and step.
 //   3. No diagnostic stamps in the loop (the default carries 3 conditional s_memtime stores per step).
 //
-// Static evidence (no GPU in r06): profiles/r06_variants_isa.txt -- registers, spills, instruction mix of the main loop and
-// the longest run of MFMAs without a vector-ALU instruction between them, default vs variant.
+// Static evidence (no GPU in r06): profiles/r06_variants_isa.txt -- registers, spills, instruction mix of the main loop, the
+// spread of the MFMAs and an in-order issue model (2 953 -> 1 689 cycles per step with two register sets), default vs variant.
+// 80 random job mixes bit-identical on the device model: profiles/r06_variants_fuzz.txt.
 #include <stdlib.h>
 
 #include "s2ag_common.h"
