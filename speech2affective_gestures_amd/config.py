@@ -67,7 +67,9 @@ _S = [
            'tests/test_gpu_zy_variants.py::test_pipelined_weight_gradient_is_bit_identical', clib=True),
     Switch('TCN32_PAIR', 0, int, "1: the clip-resident text TCN of the fp32 step (forward and data-gradient chain) with TWO clips per "
            "workgroup (csrc/tcn32p.hip): every weight fragment streamed once per two clips, 68 of 80 MFMA rows real instead of 34 "
-           "of 48, one LDS buffer + residual / running gradient in registers; bit-identical h1 / h2 / y / gp1 / gp2 / gx",
+           "of 48, activations in LDS as bf16 hi / lo planes split ONCE by their producer, one image + residual / running gradient in "
+           "registers; 2: the same kernel with ONE clip per workgroup (what the planes buy without the pairing); bit-identical "
+           "h1 / h2 / y / gp1 / gp2 / gx",
            'tests/test_gpu_zy_variants.py::test_pair_tcn_is_bit_identical', clib=True),
     Switch('BN_FOLD_APPLY', False, _flag, "1: a training-mode BatchNorm + LeakyReLU behind a conv that left its column sums (21 per "
            "step) folds them and applies in ONE launch (csrc/bn_foldapply.hip: every workgroup folds the small sums itself, fixed "

@@ -41,19 +41,24 @@ typedef unsigned short bf16_t;
 
 #include "tcn_fused32_shared.h"
 
-constexpr int MTP = 5;                  // 16-row tiles of a pair: two clips of up to 40 frames
-static_assert(CT_W * MTP * 4 <= 128, "keep bits of a thread fit one u32x4");
+// NCL clips per workgroup: 2 (TCN32_PAIR=1: five 16-row tiles for two clips of up to 40 frames) or 1 (TCN32_PAIR=2: the same
+// kernel -- split-once planes, one LDS image, residual in registers -- on the default's one clip per workgroup and three row
+// tiles, so that the A/B separates what the planes buy from what the pairing buys).
+template <int NCL> struct Tiles { static constexpr int MT = NCL == 2 ? 5 : 3; };
+static_assert(CT_W * 5 * 4 <= 128, "keep bits of a thread fit one u32x4");
 
-// row m of the pair: clip m / T, frame m % T; global row = first row of the pair + m (the two clips are adjacent in memory)
+// row m of the workgroup's rows: clip m / T, frame m % T; global row = first row + m (the clips are adjacent in memory)
 __device__ __forceinline__ int frame_of(int m, int T) { return m >= T ? m - T : m; }
 
 // keep bits of one pass in the pair epilogue's register layout: bit (i*MTP + mt)*4 + c of thread (wave, lane); blockIdx.x = pair
 // index inside the pass (the element index a keep bit is drawn for is relative to the pass, as in tcn32_keep_k)
+template <int NCL>
 __global__ __launch_bounds__(256) void tcn32p_keep_k(const T32P p, int clips_in_pass) {
+    constexpr int MTP = Tiles<NCL>::MT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x, cv = blockIdx.y;
-    const int rows = min(2, clips_in_pass - 2 * wg) * p.T;
-    const long long row0 = (long long)2 * wg * p.T;
+    const int rows = min(NCL, clips_in_pass - NCL * wg) * p.T;
+    const long long row0 = (long long)NCL * wg * p.T;
     const SiteKey key = site_key(p.rng, p.site[cv]);
     unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -96,13 +101,13 @@ __device__ __forceinline__ void split_store4(bf16_t* hi, bf16_t* lo, int off, f3
 
 // acc += conv over the planes: K tile kt = tap kt / KT_TAP (rows q - d forward, q + d backward for tap 0, inside the SAME
 // clip, else the zero row; q for tap 1), channels (kt % KT_TAP)*32 .. +32.  wh / wl: this wave's hi / lo weight fragments
-// (+ lane), a ring of RW K tiles in flight (2: at 75 MFMAs per K tile that is the ~2 400 cycles of cover the default's ring
-// of three has at 45).  Same K order and same order of the three piece products as conv32_tile: bit-identical sums.
-constexpr int RW = 2;
-template <bool BWD>
+// (+ lane), a ring of RW K tiles in flight (two clips: 2 -- at 75 MFMAs per K tile that is the ~2 400 cycles of cover the
+// default's ring of three has at 45; one clip: 3).  Same K order and same order of the three piece products as conv32_tile: bit-identical sums.
+template <bool BWD, int MTP>
 __device__ __forceinline__ void conv32p_tile(const bf16_t* hi, const bf16_t* lo, int Zrow, const u32x4* __restrict__ wh,
                                              const u32x4* __restrict__ wl, int d, int T, int rows, int lane,
                                              f32x4 (&acc)[CT_W][MTP]) {
+    constexpr int RW = MTP == 3 ? 3 : 2;                        // K tiles of weight fragments in flight (~2 200-2 400 cycles of MFMAs either way)
     int off0[MTP], off1[MTP];
 #pragma unroll
     for (int mt = 0; mt < MTP; ++mt) {
@@ -153,16 +158,18 @@ __device__ __forceinline__ void conv32p_tile(const bf16_t* hi, const bf16_t* lo,
     }
 }
 
+template <int NCL>
 __global__ __launch_bounds__(256) void tcn32p_fwd_k(const T32P p) {
+    constexpr int MTP = Tiles<NCL>::MT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* hi = reinterpret_cast<bf16_t*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, C = p.C;
-    bf16_t* lo = hi + (2 * T + 1) * PH;                          // each plane: 2T rows + the zero row (row index 2T)
-    const int Zrow = 2 * T;
-    const int clip0 = 2 * (int)blockIdx.x;
-    const int rows = min(2, p.n_clips - clip0) * T;
+    bf16_t* lo = hi + (NCL * T + 1) * PH;                        // each plane: NCL * T rows + the zero row (row index NCL * T)
+    const int Zrow = NCL * T;
+    const int clip0 = NCL * (int)blockIdx.x;
+    const int rows = min(NCL, p.n_clips - clip0) * T;
     const long long row0 = (long long)clip0 * T;
     const int cpr = C / 4;                                       // 16-byte chunks of an HBM row
     const bool save = clip0 < p.save_clips;                      // a no-grad pass of a lockstep batch keeps nothing
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256) void tcn32p_fwd_k(const T32P p) {
             for (int i = 0; i < CT_W; ++i)
 #pragma unroll
                 for (int mt = 0; mt < MTP; ++mt) acc[i][mt] = zero4;
-            conv32p_tile<false>(hi, lo, Zrow, wh, wl, d, T, rows, lane, acc);
+            conv32p_tile<false, MTP>(hi, lo, Zrow, wh, wl, d, T, rows, lane, acc);
             __syncthreads();                                     // every wave has read its input rows: the planes may be overwritten
             // epilogue: bias, ReLU, dropout (conv1: h1; conv2: h2, + residual, ReLU = the block output).  What the backward
             // pass needs goes to HBM from the registers (64 contiguous bytes per row and channel tile); the next conv's
@@ -255,16 +262,18 @@ __global__ __launch_bounds__(256) void tcn32p_fwd_k(const T32P p) {
 
 // The chain of data gradients (tcn32_bwd_k), two clips per workgroup: the running gradient G in registers (accumulator
 // layout), the planes hold the operand of the next conv (P2, then P1).
+template <int NCL>
 __global__ __launch_bounds__(256) void tcn32p_bwd_k(const T32P p) {
+    constexpr int MTP = Tiles<NCL>::MT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* hi = reinterpret_cast<bf16_t*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, C = p.C;
-    bf16_t* lo = hi + (2 * T + 1) * PH;
-    const int Zrow = 2 * T;
-    const int clip0 = 2 * (int)blockIdx.x;
-    const int rows = min(2, p.n_clips - clip0) * T;
+    bf16_t* lo = hi + (NCL * T + 1) * PH;
+    const int Zrow = NCL * T;
+    const int clip0 = NCL * (int)blockIdx.x;
+    const int rows = min(NCL, p.n_clips - clip0) * T;
     const long long row0 = (long long)clip0 * T;
     const float ik = p.inv_keep;
     for (int i = tid; i < PH / 2; i += 256) {
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(256) void tcn32p_bwd_k(const T32P p) {
             for (int i = 0; i < CT_W; ++i)
 #pragma unroll
                 for (int mt = 0; mt < MTP; ++mt) acc[i][mt] = zero4;
-            conv32p_tile<true>(hi, lo, Zrow, wh, wl, d, T, rows, lane, acc);
+            conv32p_tile<true, MTP>(hi, lo, Zrow, wh, wl, d, T, rows, lane, acc);
             __syncthreads();                                     // every wave has read P2: the planes may take P1
 #pragma unroll
             for (int i = 0; i < CT_W; ++i) {
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(256) void tcn32p_bwd_k(const T32P p) {
             for (int i = 0; i < CT_W; ++i)
 #pragma unroll
                 for (int mt = 0; mt < MTP; ++mt) acc[i][mt] = zero4;
-            conv32p_tile<true>(hi, lo, Zrow, wh, wl, d, T, rows, lane, acc);
+            conv32p_tile<true, MTP>(hi, lo, Zrow, wh, wl, d, T, rows, lane, acc);
 #pragma unroll
             for (int i = 0; i < CT_W; ++i)
 #pragma unroll
@@ -374,52 +383,67 @@ __global__ __launch_bounds__(256) void tcn32p_bwd_k(const T32P p) {
 }  // namespace
 
 namespace s2ag {
-// pairs must not straddle passes (the keep bits of a pass are drawn relative to it) nor the saved / unsaved boundary
-bool tcn32p_supported(int n_clips, int n_passes, int save_clips, int T) {
+// ncl = clips per workgroup (2: TCN32_PAIR=1, 1: TCN32_PAIR=2).  Pairs must not straddle passes (the keep bits of a pass are
+// drawn relative to it) nor the saved / unsaved boundary; single clips have no such condition.
+bool tcn32p_supported(int n_clips, int n_passes, int save_clips, int T, int ncl) {
     if (n_passes < 1 || n_clips % n_passes) return false;
-    const int per = n_clips / n_passes;
-    if (n_passes > 1 && (per & 1)) return false;
-    if (save_clips != n_clips && (save_clips & 1)) return false;
-    return T >= 1 && T <= 40 && (size_t)2 * (2 * T + 1) * PH * sizeof(bf16_t) <= 160 * 1024;
+    if (ncl == 2) {
+        const int per = n_clips / n_passes;
+        if (n_passes > 1 && (per & 1)) return false;
+        if (save_clips != n_clips && (save_clips & 1)) return false;
+    } else if (ncl != 1) {
+        return false;
+    }
+    return T >= 1 && T <= 40 && (size_t)2 * (ncl * T + 1) * PH * sizeof(bf16_t) <= 160 * 1024;
 }
 
-// `params`: the T32P tcn32_fwd_impl filled (same layout: both files include tcn_fused32_shared.h); keep_total / keep_off are
-// set here, in pairs.  rngs: one noise snapshot per pass (drop_p > 0).
-int tcn32p_fwd_launch(const void* params, int n_passes, const void* const* rngs, hipStream_t st) {
-    T32P p = *static_cast<const T32P*>(params);
-    const int per = p.n_clips / n_passes, pairs_per = (per + 1) / 2, pairs = (p.n_clips + 1) / 2;
-    const size_t lds = (size_t)2 * (2 * p.T + 1) * PH * sizeof(bf16_t);
+template <int NCL>
+static int fwd_launch(T32P p, int n_passes, const void* const* rngs, hipStream_t st) {
+    const int per = p.n_clips / n_passes, wg_per = (per + NCL - 1) / NCL, wgs = (p.n_clips + NCL - 1) / NCL;
+    const size_t lds = (size_t)2 * (NCL * p.T + 1) * PH * sizeof(bf16_t);
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)tcn32p_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)tcn32p_fwd_k<NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
-    p.keep_total = n_passes * pairs_per;
+    p.keep_total = n_passes * wg_per;             // keep_total / keep_off count WORKGROUPS of this layout
     p.keep_off = 0;
     if (p.drop_p > 0.f) {
         for (int k = 0; k < n_passes; ++k) {
             if (!rngs || !rngs[k]) return S2AG_E_BADARG;
             T32P q = p;
             q.rng = static_cast<const unsigned long long*>(rngs[k]);
-            q.keep_off = k * pairs_per;
-            hipLaunchKernelGGL(tcn32p_keep_k, dim3(pairs_per, 2 * p.n_blocks), dim3(256), 0, st, q, per);
+            q.keep_off = k * wg_per;
+            hipLaunchKernelGGL(tcn32p_keep_k<NCL>, dim3(wg_per, 2 * p.n_blocks), dim3(256), 0, st, q, per);
         }
     }
-    hipLaunchKernelGGL(tcn32p_fwd_k, dim3(pairs), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(tcn32p_fwd_k<NCL>, dim3(wgs), dim3(256), lds, st, p);
     return (int)hipGetLastError();
 }
 
-int tcn32p_bwd_launch(const void* params, hipStream_t st) {
+// `params`: the T32P tcn32_fwd_impl filled (same layout: both files include tcn_fused32_shared.h); keep_total / keep_off are
+// set here.  rngs: one noise snapshot per pass (drop_p > 0).
+int tcn32p_fwd_launch(const void* params, int n_passes, const void* const* rngs, int ncl, hipStream_t st) {
     const T32P& p = *static_cast<const T32P*>(params);
-    const size_t lds = (size_t)2 * (2 * p.T + 1) * PH * sizeof(bf16_t);
+    return ncl == 2 ? fwd_launch<2>(p, n_passes, rngs, st) : fwd_launch<1>(p, n_passes, rngs, st);
+}
+
+template <int NCL>
+static int bwd_launch(const T32P& p, hipStream_t st) {
+    const size_t lds = (size_t)2 * (NCL * p.T + 1) * PH * sizeof(bf16_t);
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)tcn32p_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)tcn32p_bwd_k<NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return S2AG_E_UNSUPPORTED;
         attr = true;
     }
-    hipLaunchKernelGGL(tcn32p_bwd_k, dim3((p.n_clips + 1) / 2), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(tcn32p_bwd_k<NCL>, dim3((p.n_clips + NCL - 1) / NCL), dim3(256), lds, st, p);
     return (int)hipGetLastError();
+}
+
+int tcn32p_bwd_launch(const void* params, int ncl, hipStream_t st) {
+    const T32P& p = *static_cast<const T32P*>(params);
+    return ncl == 2 ? bwd_launch<2>(p, st) : bwd_launch<1>(p, st);
 }
 }  // namespace s2ag

@@ -14,9 +14,9 @@
 #include "s2ag_common.h"
 
 namespace s2ag {                                        // csrc/tcn32p.hip: the opt-in two-clips-per-workgroup form (option TCN32_PAIR)
-bool tcn32p_supported(int n_clips, int n_passes, int save_clips, int T);
-int tcn32p_fwd_launch(const void* params, int n_passes, const void* const* rngs, hipStream_t st);
-int tcn32p_bwd_launch(const void* params, hipStream_t st);
+bool tcn32p_supported(int n_clips, int n_passes, int save_clips, int T, int ncl);
+int tcn32p_fwd_launch(const void* params, int n_passes, const void* const* rngs, int ncl, hipStream_t st);
+int tcn32p_bwd_launch(const void* params, int ncl, hipStream_t st);
 }
 
 namespace {
@@ -390,8 +390,9 @@ static int tcn32_fwd_impl(const s2ag_tcn32_args* a, int n_passes, const void* co
     p.inv_keep = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
     p.keep = static_cast<u32x4*>(a->keep);
     p.keep_total = a->n_clips; p.keep_off = 0; p.save_clips = save_clips;
-    if (s2ag::option(s2ag::OPT_TCN32_PAIR) && s2ag::tcn32p_supported(a->n_clips, n_passes, save_clips, a->T))
-        return s2ag::tcn32p_fwd_launch(&p, n_passes, rngs, (hipStream_t)stream);       // opt-in variant: bit-identical h1 / h2 / y
+    // opt-in variant (1: two clips per workgroup, 2: one): bit-identical h1 / h2 / y
+    if (const int v = s2ag::option(s2ag::OPT_TCN32_PAIR); v && s2ag::tcn32p_supported(a->n_clips, n_passes, save_clips, a->T, v == 2 ? 1 : 2))
+        return s2ag::tcn32p_fwd_launch(&p, n_passes, rngs, v == 2 ? 1 : 2, (hipStream_t)stream);
     const size_t lds = (size_t)(3 * p.T + 1) * PITCH * sizeof(float);
     static bool attr = false;
     if (!attr) {
@@ -441,8 +442,9 @@ extern "C" int s2ag_tcn32_bwd(const s2ag_tcn32_args* a, void* stream) {
     p.n_blocks = a->n_blocks; p.n_clips = a->n_clips; p.T = a->T; p.C = a->C;
     p.drop_p = a->drop_p;
     p.inv_keep = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
-    if (s2ag::option(s2ag::OPT_TCN32_PAIR) && s2ag::tcn32p_supported(a->n_clips, 1, a->n_clips, a->T))
-        return s2ag::tcn32p_bwd_launch(&p, (hipStream_t)stream);                        // opt-in variant: bit-identical gp1 / gp2 / gx
+    // opt-in variant: bit-identical gp1 / gp2 / gx
+    if (const int v = s2ag::option(s2ag::OPT_TCN32_PAIR); v && s2ag::tcn32p_supported(a->n_clips, 1, a->n_clips, a->T, v == 2 ? 1 : 2))
+        return s2ag::tcn32p_bwd_launch(&p, v == 2 ? 1 : 2, (hipStream_t)stream);
     const size_t lds = (size_t)(3 * p.T + 1) * PITCH * sizeof(float);
     static bool attr = false;
     if (!attr) {

@@ -249,18 +249,21 @@ def _tcn32_run(S, x, ws, bs, dils, drop_p, n_passes, save_clips, gy, seed=5):
     return out
 
 
-@pytest.mark.parametrize('case', ['B4_T34', 'B5_T34_odd', 'B2_T40_nodrop', 'B3_T34_two_blocks', 'lockstep_3x4'])
-def test_pair_tcn_is_bit_identical(S, case):
+@pytest.mark.parametrize('ncl_switch', [1, 2])
+@pytest.mark.parametrize('case', ['B4_T34', 'B5_T34_odd', 'B2_T40_nodrop', 'B3_T34_two_blocks', 'lockstep_3x4', 'lockstep_3x3'])
+def test_pair_tcn_is_bit_identical(S, case, ncl_switch):
     """TCN32_PAIR (csrc/tcn32p.hip: two clips per workgroup, activations in LDS as bf16 hi / lo planes split once by their
     producer, residual and running gradient in registers) against the default clip-resident kernels (csrc/tcn_fused32.hip)
     through the same C entry points: everything the forward leaves (h1, h2, y of every block, the last y of every lockstep
     pass) and everything the data-gradient chain leaves (gp1 / gp2 of every conv = the weight gradients' operands, gx) must be
     EQUAL bit for bit -- same pieces, same K order, same fp32 epilogue, same keep bits.  Covers an odd batch (a workgroup
     with a single clip), T = 40 (the kernels' limit), no dropout, two blocks, and the trainer's lockstep batch of three passes
-    with only the first pass saving."""
+    with only the first pass saving.  `ncl_switch` 2 = the same kernel with ONE clip per workgroup (TCN32_PAIR=2); `lockstep_3x3`
+    (an odd number of clips per pass) is taken by the one-clip form and falls back to the default kernel in the pair form."""
     config, lib = S['config'], S['lib']
     B, T, nb, drop, nP = {'B4_T34': (4, 34, 4, 0.3, 1), 'B5_T34_odd': (5, 34, 4, 0.3, 1), 'B2_T40_nodrop': (2, 40, 4, 0.0, 1),
-                          'B3_T34_two_blocks': (3, 34, 2, 0.3, 1), 'lockstep_3x4': (4, 34, 4, 0.3, 3)}[case]
+                          'B3_T34_two_blocks': (3, 34, 2, 0.3, 1), 'lockstep_3x4': (4, 34, 4, 0.3, 3),
+                          'lockstep_3x3': (3, 34, 4, 0.3, 3)}[case]
     Cch = 300
     assert lib.s2ag_tcn32_supported(T, Cch, 2)
     g = torch.Generator().manual_seed(8100 + B + T)
@@ -270,8 +273,8 @@ def test_pair_tcn_is_bit_identical(S, case):
     gy = (torch.randn(B * T, Cch, generator=g) * 0.1).cuda()
     dils = [2 ** b for b in range(nb)]
     base = _tcn32_run(S, x, ws, bs, dils, drop, nP, B, gy)
-    with config.override('TCN32_PAIR', 1):
-        assert lib.s2ag_get_option(b'TCN32_PAIR') == 1
+    with config.override('TCN32_PAIR', ncl_switch):
+        assert lib.s2ag_get_option(b'TCN32_PAIR') == ncl_switch
         var = _tcn32_run(S, x, ws, bs, dils, drop, nP, B, gy)
     assert lib.s2ag_get_option(b'TCN32_PAIR') == 0
     for k in base:

@@ -33,7 +33,7 @@ SMALL = os.environ.get('AB_SMALL', '0') == '1'      # dry-run sizes
 # switch -> values to compare (first = default)
 VARIANTS = {
     'WGRAD32_PIPE': [0, 1, 2],
-    'TCN32_PAIR': [0, 1],
+    'TCN32_PAIR': [0, 1, 2],
     'BN_FOLD_APPLY': [0, 1],
     'EMB_BWD_ROWS': [0, 1],
 }

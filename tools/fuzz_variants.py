@@ -41,11 +41,12 @@ def main():
         gy = (torch.randn(B * T, Cch, generator=g) * 0.1).cuda()
         dils = [2 ** b for b in range(nb)]
         base = V._tcn32_run(S, x, ws, bs, dils, drop, nP, B, gy)
-        with config.override('TCN32_PAIR', 1):
+        form = rnd.choice([1, 2])                                     # TCN32_PAIR=1: two clips per workgroup, =2: one
+        with config.override('TCN32_PAIR', form):
             var = V._tcn32_run(S, x, ws, bs, dils, drop, nP, B, gy)
         ok = all(torch.equal(base[k], var[k]) for k in base)
         bad += not ok
-        print(f'tcn32 pair   B={B} passes={nP} T={T} C={Cch} blocks={nb} drop={drop}: {"bit-identical" if ok else "DIFFERS"}', flush=True)
+        print(f'tcn32 planes TCN32_PAIR={form} B={B} passes={nP} T={T} C={Cch} blocks={nb} drop={drop}: {"bit-identical" if ok else "DIFFERS"}', flush=True)
         # ---- WGRAD32_PIPE
         pieces, ring = rnd.choice([1, 2]), rnd.choice([1, 2])
         if rnd.random() < 0.5:

@@ -25,10 +25,14 @@ python3 $R/tools/isa_loop.py $W/wgrad_tr32p.s wgrad_tr32p_kILi1ELi2E 6
 echo; echo "== TCN32_PAIR: clip-resident text TCN of the fp32 step; hottest loop = ONE conv (forward: 20 K tiles) / the two data-gradient convs of a block (backward: 2 x 20 K tiles)"
 echo "-- default  csrc/tcn_fused32.hip tcn32_fwd_k  (ONE clip per workgroup: divide per-loop numbers by 1 clip)"
 python3 $R/tools/isa_loop.py $W/tcn_fused32.s tcn32_fwd_k 1
-echo "-- variant  csrc/tcn32p.hip tcn32p_fwd_k      (TWO clips per workgroup: divide by 2 clips)"
-python3 $R/tools/isa_loop.py $W/tcn32p.s tcn32p_fwd_k 1
+echo "-- variant  csrc/tcn32p.hip tcn32p_fwd_k<2>   (TCN32_PAIR=1, TWO clips per workgroup: divide by 2 clips)"
+python3 $R/tools/isa_loop.py $W/tcn32p.s tcn32p_fwd_kILi2E 1
+echo "-- variant  csrc/tcn32p.hip tcn32p_fwd_k<1>   (TCN32_PAIR=2, the planes kernel with ONE clip per workgroup)"
+python3 $R/tools/isa_loop.py $W/tcn32p.s tcn32p_fwd_kILi1E 1
 echo "-- default  tcn32_bwd_k"
 python3 $R/tools/isa_loop.py $W/tcn_fused32.s tcn32_bwd_k 1
-echo "-- variant  tcn32p_bwd_k"
-python3 $R/tools/isa_loop.py $W/tcn32p.s tcn32p_bwd_k 1
+echo "-- variant  tcn32p_bwd_k<2>  (two clips)"
+python3 $R/tools/isa_loop.py $W/tcn32p.s tcn32p_bwd_kILi2E 1
+echo "-- variant  tcn32p_bwd_k<1>  (one clip)"
+python3 $R/tools/isa_loop.py $W/tcn32p.s tcn32p_bwd_kILi1E 1
 rm -rf $W
