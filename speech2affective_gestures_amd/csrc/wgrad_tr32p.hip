@@ -26,7 +26,7 @@
 //
 // Static evidence (no GPU in r06): profiles/r06_variants_isa.txt -- registers, spills, instruction mix of the main loop, the
 // spread of the MFMAs and an in-order issue model (2 953 -> 1 689 cycles per step with two register sets), default vs variant.
-// 80 random job mixes bit-identical on the device model: profiles/r06_variants_fuzz.txt.
+// Random job mixes bit-identical on the device model: profiles/r06_variants_fuzz.txt.
 #include <stdlib.h>
 
 #include "s2ag_common.h"
