@@ -273,6 +273,36 @@ def main():
         for sw, r in res['step'].items():
             for k, v in r.items():
                 print(f'step  {k:24s} {v["clips_per_s"]:.0f} clips/s')
+    # the decision the script is for, spelled out: a variant WINS a level when its gain over the default exceeds twice the
+    # default's own spread at that level; a variant becomes the default only if it wins micro AND (configs[3] OR step)
+    def gain_time(entries, key):          # {label: {key: t, ...}} -> {label: default_t / t}
+        items = list(entries.items())
+        base = items[0][1][key]
+        return {k: base / v[key] for k, v in items[1:]}
+    verdicts = {}
+    for sw in VARIANTS:
+        v = {}
+        for grp in res.get('micro', {}).values():
+            for name, r in grp.items():
+                if next(iter(r)).startswith(sw + '='):
+                    spread = (next(iter(r.values()))['max_us'] - next(iter(r.values()))['min_us']) / next(iter(r.values()))['median_us']
+                    v.setdefault('micro', {})[name] = dict(gain=gain_time(r, 'median_us'), default_spread=spread)
+        if sw in res.get('cfg3', {}):
+            r = res['cfg3'][sw]
+            d = next(iter(r.values()))['all']
+            v['cfg3'] = dict(gain=gain_time(r, 'ms_per_iter'), default_spread=(max(d) - min(d)) / min(d))
+        if sw in res.get('step', {}):
+            r = res['step'][sw]
+            base = next(iter(r.values()))
+            v['step'] = dict(gain={k: x['clips_per_s'] / max(1e-30, base['clips_per_s']) for k, x in list(r.items())[1:]},
+                             default_spread=(max(base['all']) - min(base['all'])) / max(1e-30, base['clips_per_s']))
+        verdicts[sw] = v
+        for lvl, e in v.items():
+            for name, ee in (e.items() if lvl == 'micro' else [(lvl, e)]):
+                for k, gval in ee['gain'].items():
+                    mark = 'WINS' if gval > 1.0 + 2.0 * ee['default_spread'] else ('loses' if gval < 1.0 - 2.0 * ee['default_spread'] else 'within spread')
+                    print(f'verdict {lvl:5s} {name:28s} {k:18s} x{gval:.3f} (default spread {100 * ee["default_spread"]:.1f} %): {mark}')
+    res['verdicts'] = verdicts
     print('AB ' + json.dumps(res), flush=True)
 
 
