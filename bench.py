@@ -100,6 +100,54 @@ def non_default_switches():
             if n not in ('HIP_LIB', 'CRASH_TRACE', 'BUILD_JOBS') and config.get(n) != sw.default}
 
 
+# the value each opt-in variant is expected to win with (tools/ab_variants.py times every value separately)
+VARIANTS_ALL_ON = {'WGRAD32_PIPE': 2, 'TCN32_PAIR': 1, 'BN_FOLD_APPLY': 1, 'EMB_BWD_ROWS': 1}
+
+
+def variants_probe_child(a):
+    """`bench.py --variants-probe` (started by variants_probe with S2AG_<switch> in the environment): 20 timed steps of the
+    headline configuration and one captured configs[3] fp32 iteration; prints ONE line `VARIANTS_PROBE {json}`."""
+    wl = CONFIGS['step']
+    B = a.batch or wl['batch']
+    pr = build_processor(B, not a.no_graph, wl['frames'], wl['audio_len'])
+    from speech2affective_gestures_amd import noise
+    noise.manual_seed(1234)
+    batch = synthetic_batch(B, 0, pr.device, wl['frames'], wl['audio_len'])
+    steps, warm = min(20, a.steps), min(5, a.warmup)
+    el = timed_steps(pr, pr.dp, batch, steps, warm, sync=False)
+    out = dict(switches=non_default_switches(), step_clips_per_s=B * steps / el, step_ms=el / steps * 1e3, steps=steps)
+    del pr
+    torch.cuda.empty_cache()
+    out['conv1d_ms_per_iter'] = conv1d_roofline_run(torch.device('cuda'), cpu=False, mode='fp32').get('ms_per_iter')
+    print('VARIANTS_PROBE ' + json.dumps(out), flush=True)
+
+
+def variants_probe(a, default_value, default_conv1d_ms, timeout_s=300):
+    """Child process of the default run: the same measurements with every opt-in kernel variant on.  Isolated on purpose -- the
+    variants have never run on hardware; a fault or a time-out there costs this sub-object, not the line."""
+    import shlex
+    import subprocess
+    env = dict(os.environ, **{'S2AG_' + k: str(v) for k, v in VARIANTS_ALL_ON.items()})
+    # BENCH_PROBE_CMD: test hook -- the CPU suite starts the child through the device-model wrapper (tests/s2ag_emu_bench.py)
+    self_cmd = shlex.split(os.environ['BENCH_PROBE_CMD']) if os.environ.get('BENCH_PROBE_CMD') else [sys.executable, os.path.abspath(__file__)]
+    cmd = self_cmd + ['--variants-probe', '--steps', str(a.steps), '--warmup', str(a.warmup)] + \
+          (['--batch', str(a.batch)] if a.batch else []) + (['--no-graph'] if a.no_graph else []) + \
+          (['--dry-width', a.dry_width] if a.dry_width else [])
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return dict(ok=False, error=f'no answer within {timeout_s} s', switches=VARIANTS_ALL_ON)
+    ln = [x for x in p.stdout.splitlines() if x.startswith('VARIANTS_PROBE ')]
+    if p.returncode != 0 or not ln:
+        return dict(ok=False, error=f'rc {p.returncode}: ' + (p.stderr or p.stdout)[-400:], switches=VARIANTS_ALL_ON)
+    d = json.loads(ln[-1][len('VARIANTS_PROBE '):])
+    d.update(ok=True, step_vs_default=d['step_clips_per_s'] / default_value,
+             conv1d_vs_default=(default_conv1d_ms / d['conv1d_ms_per_iter']) if d.get('conv1d_ms_per_iter') and default_conv1d_ms else None,
+             note='20 timed steps / one captured configs[3] fp32 iteration in a child process with S2AG_<switch> set; parity of every '
+                  'variant against its default kernel: tests/test_gpu_zy_variants.py; per-switch A/B: tools/ab_variants.py')
+    return d
+
+
 def matrix_products_mode():
     """How the large matrix products are formed in this run (see the module docstring)."""
     from speech2affective_gestures_amd import _lib as L
@@ -620,6 +668,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip gen-forward latency, the Conv1d roofline run, alternative product modes, the long config')
+    ap.add_argument('--variants-probe', action='store_true',
+                    help='(child process of the default run) the step rate and the configs[3] fp32 iteration with whatever '
+                         'S2AG_* switches the environment sets, as one small JSON line')
     ap.add_argument('--dry-width', default=None, metavar='HIDDEN,N_WORDS,N_SPEAKERS',
                     help='DRY RUN of the launch path (rank env, process group, timing protocol, the one JSON line) at a reduced '
                          'model width -- what the CPU test of the N > 1 launch uses (tests/test_emu_suite.py).  The line it '
@@ -631,6 +682,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; the product has no CPU path')
+    if a.variants_probe:
+        return variants_probe_child(a)
     wl = CONFIGS[a.config]
     B, frames, audio_len = a.batch or wl['batch'], wl['frames'], wl['audio_len']
     pr = build_processor(B, not a.no_graph, frames, audio_len)
@@ -682,6 +735,10 @@ def main():
             line['gen_fwd_ms'] = gen_forward_ms(pr, pr.device, cpu=not a.no_cpu_baseline)
             line['conv1d_roofline_run'] = conv1d_roofline_run(pr.device, cpu=not a.no_cpu_baseline)
             line['conv1d_roofline_run_bf16'] = conv1d_roofline_run(pr.device, cpu=False, mode='bf16')
+            if (not a.dry_width or os.environ.get('BENCH_PROBE_CMD')) and not (set(non_default_switches()) & set(VARIANTS_ALL_ON)):
+                # the opt-in kernel variants (written with the GPU closed, never timed): the same step and the same configs[3]
+                # iteration with all of them ON, in a child process with a time limit -- whatever happens there, this line stands
+                line['opt_in_variants_all_on'] = variants_probe(a, value, line['conv1d_roofline_run'].get('ms_per_iter'))
         if dp.world_size == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(B, frames=frames, audio_len=audio_len)
             line['gpu_over_cpu'] = value / line['cpu_baseline']['value']

@@ -123,6 +123,9 @@ def test_bench_line_with_its_extras_assembles(emu_lib):
     import json
     env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     env.pop('S2AG_HIP_LIB', None)
+    # r06: the line also carries `opt_in_variants_all_on`, measured by a CHILD process with the variant switches in its
+    # environment (isolated: the variants have never run on hardware).  Here the child is the same wrapper on the model.
+    env['BENCH_PROBE_CMD'] = f"{sys.executable} {os.path.join(ROOT, 'tests', 's2ag_emu_bench.py')} --stub-heavy-extras"
     cmd = [sys.executable, os.path.join(ROOT, 'tests', 's2ag_emu_bench.py'), '--stub-heavy-extras', '--steps', '1', '--warmup', '1',
            '--batch', '4', '--dry-width', '32,64,12', '--no-graph']       # (eager steps: no capture warm-ups on the model)
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
@@ -134,3 +137,9 @@ def test_bench_line_with_its_extras_assembles(emu_lib):
     assert '5 timed GAN steps' in d['cpu_baseline']['sample']
     assert d['gpu_over_cpu'] == pytest.approx(d['value'] / d['cpu_baseline']['value'])
     assert d['long_context_run']['clips_per_s'] > 0 and d['long_context_run']['steps'] == 10
+    v = d['opt_in_variants_all_on']
+    assert v['ok'], v
+    assert {k: int(x) for k, x in v['switches'].items() if k in ('WGRAD32_PIPE', 'TCN32_PAIR', 'BN_FOLD_APPLY', 'EMB_BWD_ROWS')} == \
+        {'WGRAD32_PIPE': 2, 'TCN32_PAIR': 1, 'BN_FOLD_APPLY': 1, 'EMB_BWD_ROWS': 1} and v['step_clips_per_s'] > 0
+    assert v['step_vs_default'] == pytest.approx(v['step_clips_per_s'] / d['value'])
+    assert not set(d['config']['non_default_switches']) & {'WGRAD32_PIPE', 'TCN32_PAIR', 'BN_FOLD_APPLY', 'EMB_BWD_ROWS'}      # the line itself: the default path
