@@ -122,7 +122,7 @@ def variants_probe_child(a):
     print('VARIANTS_PROBE ' + json.dumps(out), flush=True)
 
 
-def variants_probe(a, default_value, default_conv1d_ms, timeout_s=300):
+def variants_probe(a, default_value, default_conv1d_ms, timeout_s=180):
     """Child process of the default run: the same measurements with every opt-in kernel variant on.  Isolated on purpose -- the
     variants have never run on hardware; a fault or a time-out there costs this sub-object, not the line."""
     import shlex
