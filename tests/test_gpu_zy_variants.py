@@ -406,3 +406,55 @@ def test_row_block_embedding_backward(S, case):
     touched = torch.zeros(n_words, dtype=torch.bool)
     touched[ids.view(-1)] = True
     assert float(g1[~touched.cuda()].abs().max() if (~touched).any() else 0.0) == 0.0      # untouched rows stay exactly zero
+
+
+@pytest.mark.parametrize('cols,nchan,prow', [(48, 16, 7), (480, 48, 5), (300, 300, 9)])
+def test_bn_fold_apply_with_a_column_to_channel_map(S, cols, nchan, prow):
+    """The ST-GCN blocks' BatchNorm2d sees (N * T, V * C) rows: several COLUMNS belong to one channel (ops.batch_norm_act's
+    chan_map).  The folded convs in front of them leave column sums like any other conv; the one-launch fold + apply must sum
+    them per channel (columns of a channel in ascending order) exactly like bn_fold_k.  Partials are built here from the input
+    itself (row blocks of uneven length), both paths consume the same ones; reference: torch batch_norm over the channel axis."""
+    ops, config = S['ops'], S['config']
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(9700 + cols)
+    rows = 204
+    x = torch.randn(rows, cols, generator=g) * 1.5 + 0.3
+    per = cols // nchan
+    cmap = (torch.arange(cols) % nchan).to(torch.int32) if per > 1 else None        # column c -> channel c mod nchan (interleaved)
+    cuts = sorted(torch.randperm(rows - 1, generator=g)[:prow - 1].add(1).tolist())
+    blocks = [x[a:b].double() for a, b in zip([0] + cuts, cuts + [rows])]
+    part = torch.stack([torch.stack([b.sum(0) for b in blocks]), torch.stack([(b * b).sum(0) for b in blocks])]).contiguous()
+    gw, gb = torch.rand(nchan, generator=g) + 0.5, torch.randn(nchan, generator=g) * 0.2
+    dy = torch.randn(rows, cols, generator=g)
+
+    def run(on):
+        bn = torch.nn.BatchNorm1d(nchan).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(gw)
+            bn.bias.copy_(gb)
+        xg = x.cuda().requires_grad_(True)
+        xin = xg * 1.0                                            # a non-leaf tensor carries the attribute, as a conv output does
+        xin._s2ag_stats = (part.cuda().view(-1).clone(), prow)
+        with config.override('BN_FOLD_APPLY', on):
+            y = ops.batch_norm_act(xin, bn, slope=0.3, chan_map=None if cmap is None else cmap.cuda())
+        y.backward(dy.cuda())
+        torch.cuda.synchronize()
+        return dict(y=y.detach(), rm=bn.running_mean.clone(), rv=bn.running_var.clone(), dx=xg.grad, dgamma=bn.weight.grad,
+                    dbeta=bn.bias.grad, nbt=int(bn.num_batches_tracked))
+    base, var = run(False), run(True)
+    assert base['nbt'] == var['nbt'] == 1
+    for k in base:
+        if k != 'nbt':
+            assert _rel(var[k], base[k]) < (1e-6 if k in ('y', 'rm', 'rv') else 5e-6), (k, _rel(var[k], base[k]))
+    # torch: the columns of a channel are extra 'spatial' positions of that channel
+    xr = x.double().requires_grad_(True)
+    xc = xr.view(rows, per, nchan).permute(0, 2, 1) if per > 1 else xr.view(rows, nchan, 1)
+    bnr = torch.nn.BatchNorm1d(nchan).double().train()
+    with torch.no_grad():
+        bnr.weight.copy_(gw)
+        bnr.bias.copy_(gb)
+    yr = F.leaky_relu(bnr(xc), 0.3)
+    yr = yr.permute(0, 2, 1).reshape(rows, cols) if per > 1 else yr.view(rows, cols)
+    yr.backward(dy.double())
+    assert _rel(var['y'], yr.detach()) < 1e-5 and _rel(var['rm'], bnr.running_mean) < 1e-5 and _rel(var['rv'], bnr.running_var) < 1e-5
+    assert _rel(var['dx'], xr.grad) < 1e-4 and _rel(var['dgamma'], bnr.weight.grad) < 1e-4 and _rel(var['dbeta'], bnr.bias.grad) < 1e-4
