@@ -88,7 +88,6 @@ __global__ __launch_bounds__(256) void tcn32p_keep_k(const T32P p, int clips_in_
 // lane and plane).  Same bytes as the fp32 image.  Row pitch 656 B = 164 dwords: 16 consecutive rows tile the 64 banks for
 // 16-byte reads.
 constexpr int PH = 328;                 // plane row pitch in bf16 elements
-__device__ __forceinline__ int plane_elems(int T) { return 2 * T * PH; }
 
 // 4 fp32 -> 4 hi + 4 lo bf16 at element offset `off` of the two planes (8-byte stores)
 __device__ __forceinline__ void split_store4(bf16_t* hi, bf16_t* lo, int off, f32x4 v) {
