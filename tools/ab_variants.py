@@ -192,6 +192,44 @@ def emb_micro(rounds):
     return {'embedding_bwd_B256': {k: dict(median_us=m, min_us=lo, max_us=hi) for k, (m, lo, hi) in res.items()}}
 
 
+def bn_micro(rounds):
+    """BN_FOLD_APPLY: fold + apply of a BatchNorm behind a stats-epilogue conv as two launches (default) or one, at MFCCEncoder's
+    shape in the step (B = 128: 4 736 rows x 64 channels, 74 partial rows) and at the wave encoder's BatchNorm 3 in configs[3]
+    (B = 256: 9 216 rows x 64 channels)."""
+    from speech2affective_gestures_amd import _lib as L
+    lib = L.load()
+    st = torch.cuda.current_stream()
+    sp = C.c_void_p(st.cuda_stream)
+    out = {}
+    for name, rows, cols, prow in (('mfcc_B128_64ch', 4736 if not SMALL else 150, 64, 74 if not SMALL else 3),
+                                   ('wave_bn3_B256_64ch', 9216 if not SMALL else 144, 64, 144 if not SMALL else 3)):
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(rows, cols, generator=g).cuda()
+        xb = x.double().view(prow, rows // prow, cols)
+        part = torch.stack([xb.sum(1), (xb * xb).sum(1)]).contiguous()
+        gamma, beta = torch.ones(cols, device='cuda'), torch.zeros(cols, device='cuda')
+        rm, rv = torch.zeros(cols, device='cuda'), torch.ones(cols, device='cuda')
+        nbt = torch.zeros(1, dtype=torch.int64, device='cuda')
+        coef = torch.empty(4, cols, device='cuda')
+        y = torch.empty(rows, cols, device='cuda')
+        assert lib.s2ag_bn_fold_apply_supported(prow, cols, cols)
+
+        def two():
+            pp = part.clone()                                  # (s2ag_bn_fold may pre-fold its partials in place)
+            L.check(lib.s2ag_bn_fold(_p(pp), prow, rows, cols, None, cols, _p(gamma), _p(beta), _p(rm), _p(rv), _p(nbt), 1e-5, 0.1, 1,
+                                     _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), sp), 'bn_fold')
+            L.check(lib.s2ag_bn_apply(_p(x), rows, cols, cols, _p(coef[0]), _p(coef[1]), 0.3, _p(y), cols, sp), 'bn_apply')
+
+        def one():
+            pp = part.clone()                                  # (the same extra copy, so that the two sides differ in the launches only)
+            L.check(lib.s2ag_bn_fold_apply(_p(pp), prow, rows, cols, None, cols, _p(gamma), _p(beta), _p(rm), _p(rv), _p(nbt), 1e-5,
+                                           0.1, 1, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(x), cols, 0.3, _p(y), cols,
+                                           sp), 'bn_fold_apply')
+        res = interleaved({'BN_FOLD_APPLY=0': two, 'BN_FOLD_APPLY=1': one}, rounds, st)
+        out['bn_' + name] = {k: dict(median_us=m, min_us=lo, max_us=hi) for k, (m, lo, hi) in res.items()}
+    return out
+
+
 def cfg3_level(rounds):
     """One captured iteration of BASELINE configs[3] per switch value (bench.conv1d_roofline_run builds and times the graph;
     values are visited `rounds // 5 + 1` times in rotating order, the best median per value is kept)."""
@@ -257,7 +295,7 @@ def main():
     only = set(a.only.split(','))
     res = {}
     if 'micro' in only:
-        res['micro'] = dict(wgrad=wgrad_micro(a.rounds), tcn=tcn_micro(a.rounds), emb=emb_micro(a.rounds))
+        res['micro'] = dict(wgrad=wgrad_micro(a.rounds), tcn=tcn_micro(a.rounds), emb=emb_micro(a.rounds), bn=bn_micro(a.rounds))
         for grp in res['micro'].values():
             for name, r in grp.items():
                 base = next(iter(r.values()))['median_us']          # (the first value of a switch is its default)
